@@ -1,0 +1,190 @@
+/*
+ * spaghetti_rank.h — C ABI of the MI355X-native ranking hot path.
+ *
+ * This is the drop-in boundary for SpaghettiSearch's ranking path.  The
+ * reference has no FFI/plugin layer: its boundary is three exported Go
+ * functions.  A cgo shim that keeps those three signatures
+ * (go/ranking, go/retrieval) binds exactly the entry points
+ * declared here; each entry point cites the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns int32 status, 0 = SS_OK; ss_last_error() gives text.
+ *     The Go shim turns any non-zero status into panic(err), matching the
+ *     reference's error policy (pagerank.go:20,29,49,57,76,81).
+ *   - input pointers may be host OR device memory (copied with
+ *     hipMemcpyDefault before the call returns: cgo forbids retaining Go
+ *     pointers).  Output pointers likewise, caller-allocated.
+ *   - opaque handles are freed by the matching *_destroy.
+ *   - one ss_ctx per GPU per process (one process per GPU for multi-GPU).
+ *   - compute entry points are thread-safe on a shared handle
+ *     (retrieval.Retrieve is called from one goroutine per HTTP request,
+ *     cmd/server/server.go:47); calls on one ctx are serialised internally.
+ *   - there is NO CPU fallback: without a gfx950 device ss_init fails.
+ */
+#ifndef SPAGHETTI_RANK_H
+#define SPAGHETTI_RANK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+
+enum {
+    SS_OK = 0,
+    SS_ERR_INVALID = 1,      /* bad argument (null handle, k<=0, ids out of range, ...) */
+    SS_ERR_NO_DEVICE = 2,    /* no usable gfx950 device / HIP runtime error at init */
+    SS_ERR_HIP = 3,          /* HIP runtime error (text in ss_last_error) */
+    SS_ERR_OOM = 4,          /* device or host allocation failed */
+    SS_ERR_UNSORTED = 5,     /* a posting list is not strictly ascending by doc id */
+    SS_ERR_STATE = 6,        /* call sequence error (e.g. scoring before tfidf build) */
+    SS_ERR_UNSUPPORTED = 7   /* e.g. k > SS_MAX_TOPK, k_topics > SS_MAX_TOPICS */
+};
+
+#define SS_MAX_TOPK 1024     /* largest k accepted by ss_score_topk */
+#define SS_MAX_TOPICS 64     /* largest k_topics accepted */
+#define SS_MAX_QUERY_TERMS 64
+#define SS_UNKNOWN_TERM 0xFFFFFFFFu /* term id for "key not found" (main_retrieve.go:193,218) */
+
+typedef struct ss_ctx ss_ctx;
+typedef struct ss_graph ss_graph;
+typedef struct ss_pr ss_pr;
+typedef struct ss_index ss_index;
+typedef struct ss_scorer ss_scorer;
+
+/* Result row.  The Go shim maps it into retrieval.Rank_combined
+ * (retrieval/util.go:25-36: PageRank, FinalRank) and decorates only the k
+ * winners with DocInfo/summary (get_metadata.go:79-235 stays host-side Go). */
+typedef struct ss_hit {
+    uint32_t doc;      /* dense doc id assigned by the shim (md5-hex docHash <-> id) */
+    uint32_t _pad;
+    double title;      /* TitleRank after cosine normalisation, get_metadata.go:58,64-66 */
+    double body;       /* BodyRank  after cosine normalisation, get_metadata.go:57,61-63 */
+    double pagerank;   /* sqd, get_metadata.go:39-42,68 */
+    double final;      /* FinalRank, get_metadata.go:69 */
+} ss_hit;
+
+typedef struct ss_graph_info {
+    uint64_t n_nodes, n_edges;
+    uint64_t n_nondangling;      /* nodes with out-degree > 0 */
+    uint64_t n_rows_local;       /* destination rows owned by this rank */
+    uint64_t n_edges_local;      /* in-edges of those rows */
+    uint32_t max_indeg;
+    int32_t rank, world;
+} ss_graph_info;
+
+/* ---- context ---------------------------------------------------------- */
+int32_t ss_abi_version(void);
+int32_t ss_init(int32_t device_id, ss_ctx** out);
+int32_t ss_shutdown(ss_ctx* ctx);
+/* Use the caller's HIP stream (e.g. torch's current stream) for all work of this ctx.
+ * NULL = the library's own stream (default). */
+int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream);
+int32_t ss_synchronize(ss_ctx* ctx);
+const char* ss_last_error(ss_ctx* ctx); /* ctx may be NULL: last global error */
+
+/* ---- link graph: ranking/pagerank.go:17-44 ---------------------------- */
+/* Graph as the reference holds it: forw[2] rows parent -> children, flattened
+ * to an out-edge CSR over dense ids (node set = parents U children, Q1;
+ * frontier pages are nodes with out-degree 0).  The library builds its own
+ * HBM layout (in-edge lists, degree-binned row order, non-dangling-first
+ * numbering) on the device.  rank/world: this process owns the destination
+ * rows of shard `rank` of `world` (doc-range sharding);
+ * single GPU = (0, 1). */
+int32_t ss_graph_create(ss_ctx* ctx, uint64_t n_nodes, uint64_t n_edges,
+                        const uint64_t* out_ptr /*[n_nodes+1]*/, const uint32_t* out_dst /*[n_edges]*/,
+                        int32_t rank, int32_t world, ss_graph** out);
+int32_t ss_graph_get_info(const ss_graph* g, ss_graph_info* info);
+int32_t ss_graph_destroy(ss_graph* g);
+
+/* ---- PageRank: ranking/pagerank.go:14-145 ------------------------------ */
+/* One call = the whole of UpdateTopicSensitivePagerank's compute: all k_topics
+ * power iterations (pagerank.go:54-63 runs them sequentially; here they run as
+ * one K-wide sweep per iteration), device-resident loop incl. the stop rule
+ * (pagerank.go:93,115-119).  n_topic[k] = int(numPages) of category k.
+ * eps < 0 never converges (fixed-iteration benchmarking); max_iter = 0 means
+ * unbounded.  rank_out [k_topics][n_nodes] topic-major, original ids;
+ * iters_out [k_topics].  Requires a (0,1) graph. */
+int32_t ss_pagerank_run(ss_graph* g, double damping, double eps, int32_t max_iter,
+                        int32_t k_topics, const int32_t* n_topic,
+                        double* rank_out, int32_t* iters_out);
+
+/* Step-wise form of the same loop, for multi-GPU hosts (one process per GPU;
+ * the host owns the collective, e.g. torch.distributed/RCCL) and for timing.
+ *   ss_pr_create   : allocate state for k_topics vectors on this rank's rows
+ *   ss_pr_begin    : x0 = 1/n_topic (pagerank.go:103-106) + first contributions
+ *   ss_pr_step     : one K-wide sweep over the local rows (computeRankInherited
+ *                    :126-145 as a pull SpMV + fused normalise/delta :115-119)
+ *   ss_pr_finalize : combine per-rank partial sums, apply the stop rule.
+ *                    world==1: folded into begin/step, must not be called.
+ *   exchange       : world>1: after begin/step the host all-gathers `send`
+ *                    (send_bytes from every rank, rank order) into `recv`,
+ *                    then calls ss_pr_finalize.
+ * All calls enqueue on the ctx stream and return without waiting, except
+ * ss_pr_status / ss_pr_read_*.
+ */
+int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter,
+                     int32_t k_topics, const int32_t* n_topic, ss_pr** out);
+int32_t ss_pr_destroy(ss_pr* pr);
+int32_t ss_pr_begin(ss_pr* pr);
+int32_t ss_pr_step(ss_pr* pr, int32_t n_steps);
+int32_t ss_pr_finalize(ss_pr* pr);
+int32_t ss_pr_exchange_buffers(ss_pr* pr, void** send_dev, uint64_t* send_bytes,
+                               void** recv_dev, uint64_t* recv_bytes);
+/* Waits for the stream; iters_out[k_topics] = iterations executed per topic,
+ * *n_active = topics still iterating, *sweeps = K-wide sweeps executed. */
+int32_t ss_pr_status(ss_pr* pr, int32_t* iters_out, int32_t* n_active, int32_t* sweeps,
+                     double* last_delta_out /*[k_topics] nullable*/, double* last_total_out /*[k_topics] nullable*/);
+/* Local rows of this rank: ids_out[n_rows_local] original node ids,
+ * rank_out[k_topics][n_rows_local]. */
+int32_t ss_pr_read_local(ss_pr* pr, uint32_t* ids_out, double* rank_out);
+/* world==1 only: rank_out[k_topics][n_nodes] in original id order. */
+int32_t ss_pr_read(ss_pr* pr, double* rank_out);
+
+/* ---- inverted index + TF-IDF: ranking/term_weighting.go:10-123 --------- */
+/* One inverted table (inv[0] title or inv[1] body), term-major CSR over dense
+ * term/doc ids; post_tf = listPos[0] (normalised tf, indexer.go:362).  Each
+ * term's postings must be strictly ascending by doc id (SS_ERR_UNSORTED). */
+int32_t ss_index_create(ss_ctx* ctx, uint64_t n_docs, uint64_t n_terms,
+                        const uint64_t* term_ptr /*[n_terms+1]*/, const uint32_t* post_doc,
+                        const float* post_tf, ss_index** out);
+int32_t ss_index_destroy(ss_index* idx);
+/* UpdateTermWeights: idf = float32(log2(total_docs/df)) (:37), w = tf*idf in
+ * place (:42), mag[doc] = sqrt(sum float64(float32(w*w))) (:44,:72).
+ * total_docs = len(forw[3]) = number of PageRank nodes (:13-17, Q7).
+ * w_out [P] / mag_out [n_docs] / idf_out [n_terms] nullable (the shim writes
+ * them back to inv[*] / forw[4]).  Not idempotent, like the reference. */
+int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs,
+                       float* w_out, double* mag_out, float* idf_out);
+/* Load precomputed weights/magnitudes instead (tables already weighted). */
+int32_t ss_index_set_weighted(ss_index* idx, const double* mag /*[n_docs]*/);
+
+/* ---- scoring: retrieval/main_retrieve.go:50-103, get_metadata.go:31-69 -- */
+int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer** out);
+int32_t ss_scorer_destroy(ss_scorer* s);
+/* forw[3] ranks for the PageRank blend (get_metadata.go:31-42):
+ * rank [k_topics][n_docs] topic-major (ss_pagerank_run's layout). k_topics=0 clears. */
+int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank);
+/* Batch of OR queries.  q_ptr[n_q+1] into q_terms (term ids in query order,
+ * duplicates kept, SS_UNKNOWN_TERM for unknown words); query_len[n_q]
+ * (len(queryTokenised)+len(phraseTokenised), main_retrieve.go:90; NULL = term
+ * count); topic_probs [n_q][k_topics] or NULL (nil map => sqd = 0,
+ * main_retrieve.go:88).  hits_out [n_q][k], n_hits_out [n_q] (host or device).
+ * Order: FinalRank descending (util.go:48-54), ties ascending doc id, NaN last;
+ * reference k = 50 (main_retrieve.go:99-100). */
+int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
+                      const int32_t* query_len, const double* topic_probs, int32_t k,
+                      ss_hit* hits_out, int32_t* n_hits_out);
+
+/* Timing hook for bench.py: milliseconds between the start and end HIP events
+ * recorded on the ctx stream around the LAST compute call of the given kind
+ * (0 = ss_pr_step batch, 1 = ss_score_topk, 2 = ss_tfidf_build). */
+int32_t ss_last_kernel_ms(ss_ctx* ctx, int32_t kind, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,539 @@
+/*
+ * oracle.c — CPU restatement of SpaghettiSearch's ranking hot path (plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY — see oracle.h.  PARITY UNPINNED (no reference
+ * fixtures exist, reference not buildable here); pinned by hand-derived KATs
+ * and an independent numpy restatement instead.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: the reference runs on
+ * amd64, where the Go compiler never fuses a*b+c, so neither may we).
+ */
+#include "oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* Go's math.Log / math.Log2 (go1.12 src/math/log.go, log10.go), restated.    */
+/* term_weighting.go:37 calls math.Log2.                                      */
+/* ------------------------------------------------------------------------- */
+double orc_go_log(double x)
+{
+    static const double Ln2Hi = 6.93147180369123816490e-01; /* 3fe62e42 fee00000 */
+    static const double Ln2Lo = 1.90821492927058770002e-10; /* 3dea39ef 35793c76 */
+    static const double L1 = 6.666666666666735130e-01;
+    static const double L2 = 3.999999999940941908e-01;
+    static const double L3 = 2.857142874366239149e-01;
+    static const double L4 = 2.222219843214978396e-01;
+    static const double L5 = 1.818357216161805012e-01;
+    static const double L6 = 1.531383769920937332e-01;
+    static const double L7 = 1.479819860511658591e-01;
+    static const double Sqrt2Half = 0.70710678118654752440084436210484903928483593768847 ;
+
+    if (isnan(x) || (isinf(x) && x > 0)) return x;
+    if (x < 0) return NAN;
+    if (x == 0) return -INFINITY;
+
+    int ki;
+    double f1 = frexp(x, &ki);
+    if (f1 < Sqrt2Half) {
+        f1 *= 2;
+        ki--;
+    }
+    double f = f1 - 1;
+    double k = (double)ki;
+
+    double s = f / (2 + f);
+    double s2 = s * s;
+    double s4 = s2 * s2;
+    double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    double R = t1 + t2;
+    double hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+
+double orc_go_log2(double x)
+{
+    /* 1/Ln2, constant-folded exactly by the Go compiler then rounded once. */
+    static const double InvLn2 = 1.44269504088896340735992468100189214;
+    int e;
+    double frac = frexp(x, &e);
+    /* exact powers of two give an exact answer (log10.go: log2) */
+    if (frac == 0.5) return (double)(e - 1);
+    return orc_go_log(frac) * InvLn2 + (double)e;
+}
+
+/* ------------------------------------------------------------------------- */
+/* PageRank — ranking/pagerank.go:85-145                                      */
+/* ------------------------------------------------------------------------- */
+int orc_pagerank_topic(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
+                       double d, double eps, int32_t max_iter, int32_t n_init,
+                       double* rank, int32_t* iters, double* last_change_out, double* last_total_out)
+{
+    const uint64_t N = n_nodes;
+    double* a = (double*)malloc(sizeof(double) * (N ? N : 1));
+    double* b = (double*)malloc(sizeof(double) * (N ? N : 1));
+    if (!a || !b) { free(a); free(b); return -1; }
+    double* cur = a;  /* currentRank */
+    double* last = b; /* lastRank */
+
+    const double teleport = 1.0 - d; /* pagerank.go:90 */
+    double last_change = DBL_MAX;    /* pagerank.go:93: math.MaxFloat64 */
+    double total = 0.0;
+    int32_t iteration = 1;
+    for (; last_change > eps; iteration++) {
+        /* pagerank.go:94 */
+        double* t = cur; cur = last; last = t;
+
+        if (iteration > 1) {
+            for (uint64_t v = 0; v < N; v++) cur[v] = 0.0;          /* :98-100 */
+        } else {
+            const double u = 1.0 / (double)n_init;                   /* :104-105 */
+            for (uint64_t v = 0; v < N; v++) { cur[v] = u; last[v] = u; }
+        }
+
+        /* computeRankInherited, pagerank.go:126-145 */
+        total = 0.0;
+        for (uint64_t p = 0; p < N; p++) {
+            const uint64_t beg = out_ptr[p], end = out_ptr[p + 1];
+            if (end == beg) continue;                                /* :132-134 dangling dropped */
+            const double w = d * last[p] / (double)(end - beg);      /* :136 */
+            total += w;                                              /* :137 */
+            for (uint64_t e = beg; e < end; e++) cur[out_dst[e]] += w; /* :140-142 */
+        }
+        total += teleport * (double)N;                               /* :112 */
+
+        last_change = 0.0;
+        for (uint64_t v = 0; v < N; v++) {                           /* :116-119 */
+            cur[v] = (cur[v] + teleport) / total;
+            last_change += fabs(cur[v] - last[v]);
+        }
+        if (max_iter > 0 && iteration >= max_iter) { iteration++; break; }
+    }
+    memcpy(rank, cur, sizeof(double) * N);
+    if (iters) *iters = iteration - 1;
+    if (last_change_out) *last_change_out = last_change;
+    if (last_total_out) *last_total_out = total;
+    free(a); free(b);
+    return 0;
+}
+
+int orc_pagerank(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
+                 double d, double eps, int32_t max_iter, int32_t k_topics,
+                 const int32_t* n_topic, double* rank_out, int32_t* iters_out)
+{
+    /* pagerank.go:54-63: sequential loop over categories */
+    for (int32_t k = 0; k < k_topics; k++) {
+        int rc = orc_pagerank_topic(n_nodes, out_ptr, out_dst, d, eps, max_iter, n_topic[k],
+                                    rank_out + (uint64_t)k * n_nodes,
+                                    iters_out ? iters_out + k : NULL, NULL, NULL);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* --- reference-shaped variant: string-keyed hash maps (CPU baseline only) --- */
+
+typedef struct { char key[32]; double val; uint8_t used; } hm_slot;
+typedef struct { hm_slot* s; uint64_t mask; } hmap;
+
+static uint64_t hm_hash(const char* k)
+{
+    /* FNV-1a over the 32 key bytes, like hashing a Go string key */
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < 32; i++) { h ^= (uint8_t)k[i]; h *= 1099511628211ull; }
+    return h ^ (h >> 29);
+}
+static int hm_init(hmap* m, uint64_t n)
+{
+    uint64_t cap = 16;
+    while (cap < n * 2) cap <<= 1;
+    m->s = (hm_slot*)calloc(cap, sizeof(hm_slot));
+    m->mask = cap - 1;
+    return m->s ? 0 : -1;
+}
+static double* hm_at(hmap* m, const char* k)
+{
+    uint64_t i = hm_hash(k) & m->mask;
+    for (;;) {
+        hm_slot* s = &m->s[i];
+        if (!s->used) { memcpy(s->key, k, 32); s->used = 1; s->val = 0.0; return &s->val; }
+        if (memcmp(s->key, k, 32) == 0) return &s->val;
+        i = (i + 1) & m->mask;
+    }
+}
+static void id_to_key(uint32_t id, char* out)
+{
+    /* stand-in for md5-hex(url): 128 mixed bits printed as 32 hex chars */
+    static const char hex[] = "0123456789abcdef";
+    uint64_t x = (uint64_t)id * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    uint64_t y = x;
+    for (int w = 0; w < 2; w++) {
+        y ^= y >> 30; y *= 0xBF58476D1CE4E5B9ull; y ^= y >> 27; y *= 0x94D049BB133111EBull; y ^= y >> 31;
+        for (int i = 0; i < 16; i++) out[w * 16 + i] = hex[(y >> (4 * i)) & 15];
+        y += x;
+    }
+}
+
+int orc_pagerank_topic_hashed(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
+                              double d, double eps, int32_t max_iter, int32_t n_init,
+                              double* rank, int32_t* iters)
+{
+    const uint64_t N = n_nodes;
+    char* keys = (char*)malloc(32 * (N ? N : 1));
+    hmap A, B;
+    if (!keys || hm_init(&A, N) || hm_init(&B, N)) return -1;
+    for (uint64_t v = 0; v < N; v++) id_to_key((uint32_t)v, keys + 32 * v);
+    hmap* cur = &A; hmap* last = &B;
+    const double teleport = 1.0 - d;
+    double last_change = DBL_MAX;
+    int32_t iteration = 1;
+    for (; last_change > eps; iteration++) {
+        hmap* t = cur; cur = last; last = t;
+        if (iteration > 1) {
+            for (uint64_t v = 0; v < N; v++) *hm_at(cur, keys + 32 * v) = 0.0;
+        } else {
+            const double u = 1.0 / (double)n_init;
+            for (uint64_t v = 0; v < N; v++) { *hm_at(cur, keys + 32 * v) = u; *hm_at(last, keys + 32 * v) = u; }
+        }
+        double total = 0.0;
+        for (uint64_t p = 0; p < N; p++) {
+            const uint64_t beg = out_ptr[p], end = out_ptr[p + 1];
+            if (end == beg) continue;
+            const double w = d * *hm_at(last, keys + 32 * p) / (double)(end - beg);
+            total += w;
+            for (uint64_t e = beg; e < end; e++) *hm_at(cur, keys + 32 * (uint64_t)out_dst[e]) += w;
+        }
+        total += teleport * (double)N;
+        last_change = 0.0;
+        for (uint64_t v = 0; v < N; v++) {
+            double* c = hm_at(cur, keys + 32 * v);
+            *c = (*c + teleport) / total;
+            last_change += fabs(*c - *hm_at(last, keys + 32 * v));
+        }
+        if (max_iter > 0 && iteration >= max_iter) { iteration++; break; }
+    }
+    for (uint64_t v = 0; v < N; v++) rank[v] = *hm_at(cur, keys + 32 * v);
+    if (iters) *iters = iteration - 1;
+    free(A.s); free(B.s); free(keys);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* TF-IDF build — ranking/term_weighting.go:10-57                             */
+/* ------------------------------------------------------------------------- */
+int orc_tfidf(uint64_t n_terms, const uint64_t* term_ptr, const uint32_t* post_doc,
+              float* post_w, double total_docs, uint64_t n_docs, double* mag2, float* idf_out)
+{
+    for (uint64_t t = 0; t < n_terms; t++) {                        /* :29 */
+        const uint64_t beg = term_ptr[t], end = term_ptr[t + 1];
+        const double df = (double)(end - beg);                       /* len(val) */
+        const float idf = (float)orc_go_log2(total_docs / df);       /* :37 */
+        if (idf_out) idf_out[t] = idf;
+        for (uint64_t i = beg; i < end; i++) {                       /* :40 */
+            const float w = post_w[i] * idf;                         /* :42 float32 multiply */
+            post_w[i] = w;
+            const float sq = w * w;                                  /* :44 float32 product ... */
+            if (post_doc[i] >= n_docs) return -2;
+            mag2[post_doc[i]] += (double)sq;                         /* ... widened, float64 sum */
+        }
+    }
+    return 0;
+}
+
+void orc_sqrt_inplace(uint64_t n, double* v)
+{
+    for (uint64_t i = 0; i < n; i++) v[i] = sqrt(v[i]);              /* term_weighting.go:72,97,105 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* Scoring — retrieval/main_retrieve.go:50-103, get_metadata.go:31-69,         */
+/*           util.go:48-54                                                     */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t n_docs;
+    double* acc_t;      /* TitleRank accumulators (genAggrDocsPipeline :176-178) */
+    double* acc_b;      /* BodyRank  accumulators (:180-182) */
+    uint8_t* touched;
+    uint32_t* cand;     /* touched doc list */
+    uint64_t n_cand, cap_cand;
+    orc_hit* rows;
+    uint64_t cap_rows;
+} score_ws;
+
+static int ws_init(score_ws* w, uint64_t n_docs)
+{
+    memset(w, 0, sizeof(*w));
+    w->n_docs = n_docs;
+    w->acc_t = (double*)calloc(n_docs ? n_docs : 1, sizeof(double));
+    w->acc_b = (double*)calloc(n_docs ? n_docs : 1, sizeof(double));
+    w->touched = (uint8_t*)calloc(n_docs ? n_docs : 1, 1);
+    w->cap_cand = 1024;
+    w->cand = (uint32_t*)malloc(sizeof(uint32_t) * w->cap_cand);
+    w->cap_rows = 1024;
+    w->rows = (orc_hit*)malloc(sizeof(orc_hit) * w->cap_rows);
+    return (w->acc_t && w->acc_b && w->touched && w->cand && w->rows) ? 0 : -1;
+}
+static void ws_free(score_ws* w)
+{
+    free(w->acc_t); free(w->acc_b); free(w->touched); free(w->cand); free(w->rows);
+}
+static int ws_touch(score_ws* w, uint32_t doc)
+{
+    if (!w->touched[doc]) {
+        w->touched[doc] = 1;
+        if (w->n_cand == w->cap_cand) {
+            w->cap_cand *= 2;
+            uint32_t* nc = (uint32_t*)realloc(w->cand, sizeof(uint32_t) * w->cap_cand);
+            if (!nc) return -1;
+            w->cand = nc;
+        }
+        w->cand[w->n_cand++] = doc;
+    }
+    return 0;
+}
+
+/* util.go:49: descending FinalRank; equal elements keep insertion order in the
+ * reference (arrival order, unspecified) — fixed here as ascending doc id.
+ * NaN finals sort last. */
+static int hit_cmp(const void* pa, const void* pb)
+{
+    const orc_hit* a = (const orc_hit*)pa;
+    const orc_hit* b = (const orc_hit*)pb;
+    const int an = isnan(a->final), bn = isnan(b->final);
+    if (an != bn) return an ? 1 : -1;
+    if (!an) {
+        if (a->final > b->final) return -1;
+        if (a->final < b->final) return 1;
+    }
+    return (a->doc > b->doc) - (a->doc < b->doc);
+}
+
+static int score_one(score_ws* w, uint64_t n_terms,
+                     const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+                     const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+                     const double* mag_title, const double* mag_body,
+                     int32_t k_topics, const double* prior, const double* topic_probs,
+                     const uint32_t* q_terms, int32_t n_q_terms, int32_t query_len,
+                     int32_t n_extra, const uint32_t* extra_docs, const float* extra_title,
+                     const float* extra_body, const uint8_t* extra_flags,
+                     int32_t k, orc_hit* hits, int32_t* n_hits, uint64_t* n_cand_out)
+{
+    w->n_cand = 0;
+    /* main_retrieve.go:55-69 — one getFromInverted result per query token
+     * (duplicates fetched and appended twice), weights appended then summed in
+     * float64 (:176-182).  Summing as we go is the same float64 sequence. */
+    for (int32_t i = 0; i < n_q_terms; i++) {
+        const uint32_t t = q_terms[i];
+        if ((uint64_t)t >= n_terms) continue;                       /* ErrKeyNotFound => empty */
+        if (b_ptr) for (uint64_t p = b_ptr[t]; p < b_ptr[t + 1]; p++) {  /* :226-232 */
+            if (b_doc[p] >= w->n_docs || ws_touch(w, b_doc[p])) return -2;
+            w->acc_b[b_doc[p]] += (double)b_w[p];
+        }
+        if (t_ptr) for (uint64_t p = t_ptr[t]; p < t_ptr[t + 1]; p++) {  /* :234-239 */
+            if (t_doc[p] >= w->n_docs || ws_touch(w, t_doc[p])) return -2;
+            w->acc_t[t_doc[p]] += (double)t_w[p];
+        }
+    }
+    /* main_retrieve.go:73-78 — phrase contributions appended after the terms */
+    for (int32_t i = 0; i < n_extra; i++) {
+        const uint32_t doc = extra_docs[i];
+        if (doc >= w->n_docs || ws_touch(w, doc)) return -2;
+        if (extra_flags[i] & 1) w->acc_t[doc] += (double)extra_title[i];
+        if (extra_flags[i] & 2) w->acc_b[doc] += (double)extra_body[i];
+    }
+
+    if (w->n_cand > w->cap_rows) {
+        w->cap_rows = w->n_cand * 2;
+        orc_hit* nr = (orc_hit*)realloc(w->rows, sizeof(orc_hit) * w->cap_rows);
+        if (!nr) return -1;
+        w->rows = nr;
+    }
+    const double qmag = sqrt((double)query_len);                    /* get_metadata.go:53 */
+    for (uint64_t c = 0; c < w->n_cand; c++) {
+        const uint32_t doc = w->cand[c];
+        double sqd = 0.0;                                            /* :39-42 */
+        if (topic_probs && prior)
+            for (int32_t t = 0; t < k_topics; t++) sqd += topic_probs[t] * prior[(uint64_t)doc * k_topics + t];
+        double body = w->acc_b[doc];
+        double title = w->acc_t[doc];
+        body /= (mag_body[doc] * qmag);                              /* :57 */
+        title /= (mag_title[doc] * qmag);                            /* :58 */
+        if (isnan(body)) body = 0;                                   /* :61-63 */
+        if (isnan(title)) title = 0;                                 /* :64-66 */
+        orc_hit* r = &w->rows[c];
+        r->doc = doc; r->_pad = 0;
+        r->title = title; r->body = body; r->pagerank = sqd;         /* :68 */
+        r->final = (0.33 * sqd + 0.38 * title + 0.29 * body) * 100.0; /* :69 */
+        w->acc_b[doc] = 0.0; w->acc_t[doc] = 0.0; w->touched[doc] = 0;
+    }
+    qsort(w->rows, w->n_cand, sizeof(orc_hit), hit_cmp);            /* util.go:48-54 */
+    const uint64_t nh = w->n_cand < (uint64_t)k ? w->n_cand : (uint64_t)k; /* main_retrieve.go:99-103 */
+    memcpy(hits, w->rows, sizeof(orc_hit) * nh);
+    *n_hits = (int32_t)nh;
+    if (n_cand_out) *n_cand_out = w->n_cand;
+    return 0;
+}
+
+int orc_score_topk(uint64_t n_docs, uint64_t n_terms,
+                   const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+                   const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+                   const double* mag_title, const double* mag_body,
+                   int32_t k_topics, const double* prior, const double* topic_probs,
+                   const uint32_t* q_terms, int32_t n_q_terms, int32_t query_len,
+                   int32_t n_extra, const uint32_t* extra_docs, const float* extra_title,
+                   const float* extra_body, const uint8_t* extra_flags,
+                   int32_t k, orc_hit* hits, int32_t* n_hits, uint64_t* n_cand)
+{
+    score_ws w;
+    if (ws_init(&w, n_docs)) { ws_free(&w); return -1; }
+    int rc = score_one(&w, n_terms, t_ptr, t_doc, t_w, b_ptr, b_doc, b_w, mag_title, mag_body,
+                       k_topics, prior, topic_probs, q_terms, n_q_terms, query_len,
+                       n_extra, extra_docs, extra_title, extra_body, extra_flags,
+                       k, hits, n_hits, n_cand);
+    ws_free(&w);
+    return rc;
+}
+
+int orc_score_topk_batch(uint64_t n_docs, uint64_t n_terms,
+                         const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+                         const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+                         const double* mag_title, const double* mag_body,
+                         int32_t k_topics, const double* prior, const double* topic_probs,
+                         int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
+                         const int32_t* query_len, int32_t k, orc_hit* hits, int32_t* n_hits)
+{
+    score_ws w;
+    if (ws_init(&w, n_docs)) { ws_free(&w); return -1; }
+    int rc = 0;
+    for (int32_t q = 0; q < n_q && !rc; q++) {
+        const int32_t nt = (int32_t)(q_ptr[q + 1] - q_ptr[q]);
+        const int32_t ql = query_len ? query_len[q] : nt;
+        rc = score_one(&w, n_terms, t_ptr, t_doc, t_w, b_ptr, b_doc, b_w, mag_title, mag_body,
+                       k_topics, prior, topic_probs ? topic_probs + (uint64_t)q * k_topics : NULL,
+                       q_terms + q_ptr[q], nt, ql, 0, NULL, NULL, NULL, NULL,
+                       k, hits + (uint64_t)q * k, n_hits + q, NULL);
+    }
+    ws_free(&w);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Phrase search — retrieval/phrase.go:11-170, util.go:162-203                 */
+/* ------------------------------------------------------------------------- */
+static int f32_cmp(const void* a, const void* b)
+{
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* util.go:179-203 intersect: sort both (util.go:162-177), two-pointer match.
+ * a is overwritten with the intersection; returns its length.  A NULL slice in
+ * Go is represented by len < 0. */
+static int64_t go_intersect(float* a, int64_t na, float* b, int64_t nb)
+{
+    if (na < 0 || nb < 0) return -1;                                 /* :180-182 */
+    qsort(a, (size_t)na, sizeof(float), f32_cmp);
+    qsort(b, (size_t)nb, sizeof(float), f32_cmp);
+    int64_t i = 0, j = 0, n = 0;
+    while (i != na && j != nb) {                                     /* :191 */
+        if (a[i] == b[j]) { a[n++] = a[i]; i++; j++; }
+        else if (a[i] > b[j]) j++;
+        else i++;
+    }
+    return n ? n : -1;                                               /* ret stays nil when nothing appended */
+}
+
+static int64_t find_doc(const uint32_t* docs, uint64_t beg, uint64_t end, uint32_t doc)
+{
+    /* posting docs are not required to be sorted for the oracle: linear scan */
+    for (uint64_t i = beg; i < end; i++) if (docs[i] == doc) return (int64_t)i;
+    return -1;
+}
+
+int orc_phrase(uint64_t n_terms,
+               const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+               const uint64_t* t_pos_ptr, const float* t_pos,
+               const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+               const uint64_t* b_pos_ptr, const float* b_pos,
+               const uint32_t* phrase_terms, int32_t n_phrase,
+               int32_t cap, uint32_t* out_docs, float* out_title, float* out_body,
+               uint8_t* out_flags, int32_t* n_out)
+{
+    *n_out = 0;
+    if (n_phrase <= 0) return 0;
+    /* Candidate docs: any doc appearing for phrase term 0 in body or title; a
+     * doc must have an entry for EVERY term position (phrase.go:63), so term 0's
+     * docs are a superset of the result. */
+    const uint32_t t0 = phrase_terms[0];
+    if ((uint64_t)t0 >= n_terms) return 0;
+    uint64_t ncand = (b_ptr[t0 + 1] - b_ptr[t0]) + (t_ptr[t0 + 1] - t_ptr[t0]);
+    uint32_t* cands = (uint32_t*)malloc(sizeof(uint32_t) * (ncand ? ncand : 1));
+    if (!cands) return -1;
+    uint64_t nc = 0;
+    for (uint64_t p = b_ptr[t0]; p < b_ptr[t0 + 1]; p++) cands[nc++] = b_doc[p];
+    for (uint64_t p = t_ptr[t0]; p < t_ptr[t0 + 1]; p++) {
+        if (find_doc(b_doc, b_ptr[t0], b_ptr[t0 + 1], t_doc[p]) < 0) cands[nc++] = t_doc[p];
+    }
+    /* deterministic output order: ascending doc id */
+    for (uint64_t i = 1; i < nc; i++) { /* insertion sort: oracle sizes are small */
+        uint32_t v = cands[i]; uint64_t j = i;
+        while (j > 0 && cands[j - 1] > v) { cands[j] = cands[j - 1]; j--; }
+        cands[j] = v;
+    }
+
+    int rc = 0;
+    for (uint64_t c = 0; c < nc && !rc; c++) {
+        const uint32_t doc = cands[c];
+        float sum_body = 0.0f, sum_title = 0.0f;                     /* phrase.go:59 */
+        float* bi = NULL; int64_t nbi = -1;                          /* bodyIntersect (nil) */
+        float* ti = NULL; int64_t nti = -1;                          /* titleIntersect (nil) */
+        int all_present = 1;
+        for (int32_t idx = 0; idx < n_phrase; idx++) {
+            const uint32_t t = phrase_terms[idx];
+            int64_t pb = -1, pt = -1;
+            if ((uint64_t)t < n_terms) {
+                pb = find_doc(b_doc, b_ptr[t], b_ptr[t + 1], doc);
+                pt = find_doc(t_doc, t_ptr[t], t_ptr[t + 1], doc);
+            }
+            if (pb < 0 && pt < 0) { all_present = 0; break; }        /* :63 len(termWeights) != lengthPhrase */
+            /* getPosTerm :142-163: positions shifted by the term's index in the phrase */
+            if (pb >= 0) {
+                const uint64_t np = b_pos_ptr[pb + 1] - b_pos_ptr[pb];
+                float* sh = (float*)malloc(sizeof(float) * (np ? np : 1));
+                for (uint64_t i = 0; i < np; i++) sh[i] = b_pos[b_pos_ptr[pb] + i] - (float)idx; /* :145 */
+                sum_body += b_w[pb];                                 /* :69 / :83 */
+                if (idx == 0) { bi = sh; nbi = (int64_t)np; }        /* :70 */
+                else { nbi = go_intersect(bi, nbi, sh, (int64_t)np); free(sh); } /* :84 */
+            } else if (idx > 0) {
+                nbi = -1;                                            /* :80-81 */
+            }
+            if (pt >= 0) {
+                const uint64_t np = t_pos_ptr[pt + 1] - t_pos_ptr[pt];
+                float* sh = (float*)malloc(sizeof(float) * (np ? np : 1));
+                for (uint64_t i = 0; i < np; i++) sh[i] = t_pos[t_pos_ptr[pt] + i] - (float)idx; /* :157 */
+                sum_title += t_w[pt];                                /* :73 / :90 */
+                if (idx == 0) { ti = sh; nti = (int64_t)np; }        /* :74 */
+                else { nti = go_intersect(ti, nti, sh, (int64_t)np); free(sh); } /* :91 */
+            } else if (idx > 0) {
+                nti = -1;                                            /* :87-88 */
+            }
+        }
+        if (all_present && (nbi > 0 || nti > 0)) {                   /* :97 */
+            if (*n_out >= cap) { rc = -3; }
+            else {
+                const int32_t o = (*n_out)++;
+                out_docs[o] = doc;
+                out_flags[o] = (uint8_t)((nti > 0 ? 1 : 0) | (nbi > 0 ? 2 : 0));
+                out_title[o] = nti > 0 ? sum_title : 0.0f;           /* :102-104 */
+                out_body[o] = nbi > 0 ? sum_body : 0.0f;             /* :99-101 */
+            }
+        }
+        free(bi); free(ti);
+    }
+    free(cands);
+    return rc;
+}

@@ -1,0 +1,229 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module.  The product package (spaghettisearch_amd/) never does.  PARITY UNPINNED:
+see oracle/oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+
+class OrcHit(C.Structure):
+    _fields_ = [("doc", C.c_uint32), ("_pad", C.c_uint32), ("title", C.c_double),
+                ("body", C.c_double), ("pagerank", C.c_double), ("final", C.c_double)]
+
+
+HIT_DTYPE = np.dtype([("doc", "<u4"), ("_pad", "<u4"), ("title", "<f8"), ("body", "<f8"),
+                      ("pagerank", "<f8"), ("final", "<f8")])
+
+
+def build() -> str:
+    src = os.path.join(_HERE, "oracle.c")
+    if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "oracle.h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_go_log.restype = C.c_double
+        _lib.orc_go_log.argtypes = [C.c_double]
+        _lib.orc_go_log2.restype = C.c_double
+        _lib.orc_go_log2.argtypes = [C.c_double]
+    return _lib
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def go_log2(x: float) -> float:
+    return lib().orc_go_log2(float(x))
+
+
+def go_log(x: float) -> float:
+    return lib().orc_go_log(float(x))
+
+
+def pagerank(n_nodes, out_ptr, out_dst, d, eps, n_topic, max_iter=0, hashed=False):
+    """-> (rank [K][N] float64, iters [K] int32)"""
+    out_ptr = _c(out_ptr, np.uint64)
+    out_dst = _c(out_dst, np.uint32)
+    n_topic = _c(np.atleast_1d(n_topic), np.int32)
+    K = len(n_topic)
+    rank = np.zeros((K, n_nodes), dtype=np.float64)
+    iters = np.zeros(K, dtype=np.int32)
+    L = lib()
+    if hashed:
+        for k in range(K):
+            rc = L.orc_pagerank_topic_hashed(
+                C.c_uint64(n_nodes), _p(out_ptr, C.c_uint64), _p(out_dst, C.c_uint32),
+                C.c_double(d), C.c_double(eps), C.c_int32(max_iter), C.c_int32(int(n_topic[k])),
+                _p(rank[k], C.c_double), _p(iters[k:k + 1], C.c_int32))
+            if rc:
+                raise RuntimeError(f"orc_pagerank_topic_hashed rc={rc}")
+        return rank, iters
+    rc = L.orc_pagerank(C.c_uint64(n_nodes), _p(out_ptr, C.c_uint64), _p(out_dst, C.c_uint32),
+                        C.c_double(d), C.c_double(eps), C.c_int32(max_iter), C.c_int32(K),
+                        _p(n_topic, C.c_int32), _p(rank, C.c_double), _p(iters, C.c_int32))
+    if rc:
+        raise RuntimeError(f"orc_pagerank rc={rc}")
+    return rank, iters
+
+
+def pagerank_topic_detail(n_nodes, out_ptr, out_dst, d, eps, n_init, max_iter=0):
+    """-> (rank[N], iters, last_change, last_total)"""
+    out_ptr = _c(out_ptr, np.uint64)
+    out_dst = _c(out_dst, np.uint32)
+    rank = np.zeros(n_nodes, dtype=np.float64)
+    it = C.c_int32(0)
+    lc = C.c_double(0)
+    lt = C.c_double(0)
+    rc = lib().orc_pagerank_topic(C.c_uint64(n_nodes), _p(out_ptr, C.c_uint64), _p(out_dst, C.c_uint32),
+                                  C.c_double(d), C.c_double(eps), C.c_int32(max_iter), C.c_int32(n_init),
+                                  _p(rank, C.c_double), C.byref(it), C.byref(lc), C.byref(lt))
+    if rc:
+        raise RuntimeError(f"orc_pagerank_topic rc={rc}")
+    return rank, it.value, lc.value, lt.value
+
+
+def tfidf(term_ptr, post_doc, post_tf, total_docs, n_docs):
+    """-> (w float32[P], mag float64[n_docs] (sqrt applied), idf float32[T])"""
+    term_ptr = _c(term_ptr, np.uint64)
+    post_doc = _c(post_doc, np.uint32)
+    w = np.array(post_tf, dtype=np.float32, copy=True)
+    T = len(term_ptr) - 1
+    mag2 = np.zeros(n_docs, dtype=np.float64)
+    idf = np.zeros(T, dtype=np.float32)
+    rc = lib().orc_tfidf(C.c_uint64(T), _p(term_ptr, C.c_uint64), _p(post_doc, C.c_uint32),
+                         _p(w, C.c_float), C.c_double(float(total_docs)), C.c_uint64(n_docs),
+                         _p(mag2, C.c_double), _p(idf, C.c_float))
+    if rc:
+        raise RuntimeError(f"orc_tfidf rc={rc}")
+    lib().orc_sqrt_inplace(C.c_uint64(n_docs), _p(mag2, C.c_double))
+    return w, mag2, idf
+
+
+def score_topk_batch(n_docs, title, body, mag_title, mag_body, q_ptr, q_terms, k,
+                     prior=None, topic_probs=None, query_len=None):
+    """title/body = (term_ptr u64, post_doc u32, post_w f32).  -> (hits [n_q][k] HIT_DTYPE, n_hits [n_q])"""
+    t_ptr, t_doc, t_w = _c(title[0], np.uint64), _c(title[1], np.uint32), _c(title[2], np.float32)
+    b_ptr, b_doc, b_w = _c(body[0], np.uint64), _c(body[1], np.uint32), _c(body[2], np.float32)
+    n_terms = len(b_ptr) - 1
+    assert len(t_ptr) - 1 == n_terms
+    mag_title = _c(mag_title, np.float64)
+    mag_body = _c(mag_body, np.float64)
+    q_ptr = _c(q_ptr, np.uint32)
+    q_terms = _c(q_terms, np.uint32)
+    n_q = len(q_ptr) - 1
+    K = 0
+    if prior is not None:
+        prior = _c(prior, np.float64)
+        K = prior.shape[1]
+    if topic_probs is not None:
+        topic_probs = _c(topic_probs, np.float64)
+        assert topic_probs.shape == (n_q, K)
+    query_len = _c(query_len, np.int32)
+    hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
+    n_hits = np.zeros(n_q, dtype=np.int32)
+    rc = lib().orc_score_topk_batch(
+        C.c_uint64(n_docs), C.c_uint64(n_terms),
+        _p(t_ptr, C.c_uint64), _p(t_doc, C.c_uint32), _p(t_w, C.c_float),
+        _p(b_ptr, C.c_uint64), _p(b_doc, C.c_uint32), _p(b_w, C.c_float),
+        _p(mag_title, C.c_double), _p(mag_body, C.c_double),
+        C.c_int32(K), _p(prior, C.c_double), _p(topic_probs, C.c_double),
+        C.c_int32(n_q), _p(q_ptr, C.c_uint32), _p(q_terms, C.c_uint32), _p(query_len, C.c_int32),
+        C.c_int32(k), hits.ctypes.data_as(C.POINTER(OrcHit)), _p(n_hits, C.c_int32))
+    if rc:
+        raise RuntimeError(f"orc_score_topk_batch rc={rc}")
+    return hits, n_hits
+
+
+def score_topk(n_docs, title, body, mag_title, mag_body, q_terms, k, query_len=None,
+               prior=None, topic_probs=None, extra=None):
+    """Single query with optional phrase contributions extra=(docs u32, title f32, body f32, flags u8)."""
+    t_ptr, t_doc, t_w = _c(title[0], np.uint64), _c(title[1], np.uint32), _c(title[2], np.float32)
+    b_ptr, b_doc, b_w = _c(body[0], np.uint64), _c(body[1], np.uint32), _c(body[2], np.float32)
+    n_terms = len(b_ptr) - 1
+    mag_title = _c(mag_title, np.float64)
+    mag_body = _c(mag_body, np.float64)
+    q_terms = _c(q_terms, np.uint32)
+    K = 0
+    if prior is not None:
+        prior = _c(prior, np.float64)
+        K = prior.shape[1]
+    topic_probs = _c(topic_probs, np.float64)
+    if query_len is None:
+        query_len = len(q_terms)
+    n_extra = 0
+    e_docs = e_t = e_b = e_f = None
+    if extra is not None:
+        e_docs, e_t, e_b, e_f = (_c(extra[0], np.uint32), _c(extra[1], np.float32),
+                                 _c(extra[2], np.float32), _c(extra[3], np.uint8))
+        n_extra = len(e_docs)
+    hits = np.zeros(k, dtype=HIT_DTYPE)
+    n_hits = C.c_int32(0)
+    n_cand = C.c_uint64(0)
+    rc = lib().orc_score_topk(
+        C.c_uint64(n_docs), C.c_uint64(n_terms),
+        _p(t_ptr, C.c_uint64), _p(t_doc, C.c_uint32), _p(t_w, C.c_float),
+        _p(b_ptr, C.c_uint64), _p(b_doc, C.c_uint32), _p(b_w, C.c_float),
+        _p(mag_title, C.c_double), _p(mag_body, C.c_double),
+        C.c_int32(K), _p(prior, C.c_double), _p(topic_probs, C.c_double),
+        _p(q_terms, C.c_uint32), C.c_int32(len(q_terms)), C.c_int32(query_len),
+        C.c_int32(n_extra), _p(e_docs, C.c_uint32), _p(e_t, C.c_float), _p(e_b, C.c_float),
+        _p(e_f, C.c_uint8),
+        C.c_int32(k), hits.ctypes.data_as(C.POINTER(OrcHit)), C.byref(n_hits), C.byref(n_cand))
+    if rc:
+        raise RuntimeError(f"orc_score_topk rc={rc}")
+    return hits[:n_hits.value], n_cand.value
+
+
+def phrase(title, body, title_pos, body_pos, phrase_terms, cap=None):
+    """title/body = (term_ptr, post_doc, post_w); *_pos = (pos_ptr u64[P+1], pos f32).
+    -> (docs u32, title f32, body f32, flags u8)"""
+    t_ptr, t_doc, t_w = _c(title[0], np.uint64), _c(title[1], np.uint32), _c(title[2], np.float32)
+    b_ptr, b_doc, b_w = _c(body[0], np.uint64), _c(body[1], np.uint32), _c(body[2], np.float32)
+    tpp, tp = _c(title_pos[0], np.uint64), _c(title_pos[1], np.float32)
+    bpp, bp = _c(body_pos[0], np.uint64), _c(body_pos[1], np.float32)
+    n_terms = len(b_ptr) - 1
+    ph = _c(phrase_terms, np.uint32)
+    if cap is None:
+        cap = max(1, len(t_doc) + len(b_doc))
+    docs = np.zeros(cap, np.uint32)
+    ot = np.zeros(cap, np.float32)
+    ob = np.zeros(cap, np.float32)
+    fl = np.zeros(cap, np.uint8)
+    n = C.c_int32(0)
+    rc = lib().orc_phrase(C.c_uint64(n_terms),
+                          _p(t_ptr, C.c_uint64), _p(t_doc, C.c_uint32), _p(t_w, C.c_float),
+                          _p(tpp, C.c_uint64), _p(tp, C.c_float),
+                          _p(b_ptr, C.c_uint64), _p(b_doc, C.c_uint32), _p(b_w, C.c_float),
+                          _p(bpp, C.c_uint64), _p(bp, C.c_float),
+                          _p(ph, C.c_uint32), C.c_int32(len(ph)), C.c_int32(cap),
+                          _p(docs, C.c_uint32), _p(ot, C.c_float), _p(ob, C.c_float),
+                          _p(fl, C.c_uint8), C.byref(n))
+    if rc:
+        raise RuntimeError(f"orc_phrase rc={rc}")
+    m = n.value
+    return docs[:m], ot[:m], ob[:m], fl[:m]

@@ -1,0 +1,95 @@
+// common.hpp — shared host-side infrastructure of libspaghetti_rank (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/spaghetti_rank.h"
+
+namespace ss {
+
+void set_global_error(const std::string& msg);
+
+}  // namespace ss
+
+struct ss_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream all work is enqueued on
+    hipStream_t own_stream = nullptr;  // created by ss_init
+    std::recursive_mutex mu;           // serialises calls on this ctx
+    std::string last_error;
+    // timing hook (ss_last_kernel_ms): [kind][0]=start, [1]=stop
+    hipEvent_t ev[3][2] = {};
+    bool ev_valid[3] = {false, false, false};
+    int cu_count = 256;
+    size_t total_mem = 0;
+
+    int32_t fail(int32_t code, const char* fmt, ...) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        last_error = buf;
+        ss::set_global_error(last_error);
+        return code;
+    }
+};
+
+#define SS_HIP(ctx, expr)                                                                  \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            return (ctx)->fail(_e == hipErrorOutOfMemory ? SS_ERR_OOM : SS_ERR_HIP,        \
+                               "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,               \
+                               hipGetErrorString(_e));                                     \
+        }                                                                                  \
+    } while (0)
+
+#define SS_TRY(expr)                   \
+    do {                               \
+        int32_t _rc = (expr);          \
+        if (_rc != SS_OK) return _rc;  \
+    } while (0)
+
+namespace ss {
+
+// Device allocation that frees itself; raw pointers are handed to kernels.
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace ss

@@ -1,0 +1,122 @@
+// ctx.hip — context, stream and error plumbing of the C ABI (include/spaghetti_rank.h).
+#include "common.hpp"
+
+namespace ss {
+static std::mutex g_err_mu;
+static std::string g_err;
+void set_global_error(const std::string& msg) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = msg;
+}
+}  // namespace ss
+
+extern "C" {
+
+int32_t ss_abi_version(void) { return SS_ABI_VERSION; }
+
+int32_t ss_init(int32_t device_id, ss_ctx** out) {
+    if (!out) {
+        ss::set_global_error("ss_init: out is NULL");
+        return SS_ERR_INVALID;
+    }
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        // No CPU fallback: the product path requires a HIP device.
+        ss::set_global_error(std::string("ss_init: no HIP device (") + hipGetErrorString(e) + ")");
+        return SS_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) {
+        ss::set_global_error("ss_init: device_id out of range");
+        return SS_ERR_INVALID;
+    }
+    ss_ctx* ctx = new (std::nothrow) ss_ctx();
+    if (!ctx) return SS_ERR_OOM;
+    ctx->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        ss::set_global_error(std::string("ss_init: hipSetDevice: ") + hipGetErrorString(e));
+        delete ctx;
+        return SS_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+        ss::set_global_error(std::string("ss_init: hipGetDeviceProperties: ") + hipGetErrorString(e));
+        delete ctx;
+        return SS_ERR_NO_DEVICE;
+    }
+    // Kernels are built for gfx950 only (wave64, 160 KiB LDS, ds_add_f64).
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        ss::set_global_error(std::string("ss_init: device is ") + prop.gcnArchName +
+                             ", this library is built for gfx950 (MI355X) only");
+        delete ctx;
+        return SS_ERR_NO_DEVICE;
+    }
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->total_mem = prop.totalGlobalMem;
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        ss::set_global_error(std::string("ss_init: hipStreamCreate: ") + hipGetErrorString(e));
+        delete ctx;
+        return SS_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    for (int k = 0; k < 3; k++)
+        for (int j = 0; j < 2; j++)
+            if ((e = hipEventCreate(&ctx->ev[k][j])) != hipSuccess) {
+                ss::set_global_error(std::string("ss_init: hipEventCreate: ") + hipGetErrorString(e));
+                delete ctx;
+                return SS_ERR_HIP;
+            }
+    *out = ctx;
+    return SS_OK;
+}
+
+int32_t ss_shutdown(ss_ctx* ctx) {
+    if (!ctx) return SS_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 3; k++)
+        for (int j = 0; j < 2; j++)
+            if (ctx->ev[k][j]) (void)hipEventDestroy(ctx->ev[k][j]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SS_OK;
+}
+
+int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SS_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return SS_OK;
+}
+
+int32_t ss_synchronize(ss_ctx* ctx) {
+    if (!ctx) return SS_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+const char* ss_last_error(ss_ctx* ctx) {
+    if (ctx) return ctx->last_error.c_str();
+    // global: copy into a thread-local buffer so the pointer stays valid
+    static thread_local std::string tl;
+    {
+        std::lock_guard<std::mutex> lk(ss::g_err_mu);
+        tl = ss::g_err;
+    }
+    return tl.c_str();
+}
+
+int32_t ss_last_kernel_ms(ss_ctx* ctx, int32_t kind, float* ms_out) {
+    if (!ctx || !ms_out || kind < 0 || kind > 2) return SS_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!ctx->ev_valid[kind]) return ctx->fail(SS_ERR_STATE, "ss_last_kernel_ms: no timed call of kind %d yet", kind);
+    SS_HIP(ctx, hipEventSynchronize(ctx->ev[kind][1]));
+    SS_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev[kind][0], ctx->ev[kind][1]));
+    return SS_OK;
+}
+
+}  // extern "C"

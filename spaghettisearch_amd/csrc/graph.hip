@@ -1,0 +1,327 @@
+// graph.hip — build the PageRank graph layout on the device (see graph.hpp).
+// Setup code: runs once per UpdateTopicSensitivePagerank call.  Sorting and
+// scanning use rocPRIM device primitives; the hot loop lives in pagerank.hip.
+#include "graph.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+
+namespace {
+
+constexpr int TPB = 256;
+
+// out-degree per node, count of non-dangling nodes
+__global__ void k_outdeg(const uint64_t* __restrict__ out_ptr, uint64_t n, uint32_t* __restrict__ outdeg,
+                         unsigned long long* __restrict__ n_nd, uint32_t* __restrict__ err) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned nd = 0;
+    if (v < n) {
+        uint64_t a = out_ptr[v], b = out_ptr[v + 1];
+        if (b < a || b - a > 0xFFFFFFFFull) { atomicOr(err, 1u); b = a; }
+        outdeg[v] = (uint32_t)(b - a);
+        nd = b > a;
+    }
+    unsigned long long m = __ballot(nd);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_nd, (unsigned long long)__popcll(m));
+}
+
+// in-degree histogram + range check of out_dst
+__global__ void k_indeg(const uint32_t* __restrict__ out_dst, uint64_t e, uint64_t n,
+                        uint32_t* __restrict__ indeg, uint32_t* __restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < e; i += stride) {
+        uint32_t c = out_dst[i];
+        if (c >= n) { atomicOr(err, 2u); continue; }
+        atomicAdd(&indeg[c], 1u);
+    }
+}
+
+// sort key per node: class (dangling last), in-degree descending, original id ascending
+__global__ void k_row_keys(const uint32_t* __restrict__ outdeg, const uint32_t* __restrict__ indeg, uint64_t n,
+                           uint64_t* __restrict__ keys) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint64_t cls = outdeg[v] == 0 ? 1ull : 0ull;
+    keys[v] = (cls << 63) | ((uint64_t)(0x7FFFFFFFu - min(indeg[v], 0x7FFFFFFFu)) << 32) | v;
+}
+
+// sorted position -> internal id (round-robin deal over ranks inside each class)
+__global__ void k_assign_ids(const uint64_t* __restrict__ sorted_keys, uint64_t n, uint64_t n_nd, uint32_t world,
+                             uint32_t sl_nd, uint32_t sl_d, const uint32_t* __restrict__ indeg,
+                             uint32_t* __restrict__ new_id, uint32_t* __restrict__ old_id,
+                             uint32_t* __restrict__ indeg_int) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = (uint32_t)(sorted_keys[i] & 0xFFFFFFFFull);
+    uint64_t id;
+    if (i < n_nd) {
+        uint64_t g = i % world, pos = i / world;
+        id = g * sl_nd + pos;
+    } else {
+        uint64_t j = i - n_nd;
+        uint64_t g = j % world, pos = j / world;
+        id = (uint64_t)world * sl_nd + g * sl_d + pos;
+    }
+    new_id[v] = (uint32_t)id;
+    old_id[id] = v;
+    indeg_int[id] = indeg[v];
+}
+
+// one thread per edge: find its source row (upper_bound on out_ptr), emit (dst_int<<32 | src_int)
+__global__ void k_edge_keys(const uint64_t* __restrict__ out_ptr, const uint32_t* __restrict__ out_dst,
+                            uint64_t n, uint64_t e, const uint32_t* __restrict__ new_id,
+                            uint64_t* __restrict__ keys) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < e; i += stride) {
+        // largest p with out_ptr[p] <= i
+        uint64_t lo = 0, hi = n;  // invariant: out_ptr[lo] <= i < out_ptr[hi]
+        while (hi - lo > 1) {
+            uint64_t mid = (lo + hi) >> 1;
+            if (out_ptr[mid] <= i) lo = mid; else hi = mid;
+        }
+        keys[i] = ((uint64_t)new_id[out_dst[i]] << 32) | new_id[lo];
+    }
+}
+
+__global__ void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// local in_ptr from the internal-id in_ptr (two contiguous id ranges -> one local row space)
+__global__ void k_local_ptr(const uint64_t* __restrict__ in_ptr_int, uint32_t sl_nd, uint32_t sl_d,
+                            uint64_t id0_nd, uint64_t id0_d, uint64_t off_nd, uint64_t off_d, uint64_t e_nd,
+                            uint32_t* __restrict__ in_ptr_local) {
+    uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t n_local = (uint64_t)sl_nd + sl_d;
+    if (l > n_local) return;
+    uint64_t v;
+    if (l < sl_nd) v = in_ptr_int[id0_nd + l] - off_nd;
+    else v = e_nd + in_ptr_int[id0_d + (l - sl_nd)] - off_d;   // l == n_local: id0_d + sl_d is valid (n_int+1 entries)
+    in_ptr_local[l] = (uint32_t)v;
+}
+
+__global__ void k_extract_src(const uint64_t* __restrict__ keys, uint64_t off_nd, uint64_t e_nd, uint64_t off_d,
+                              uint64_t e_loc, uint32_t* __restrict__ in_src) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < e_loc; i += stride) {
+        uint64_t k = i < e_nd ? keys[off_nd + i] : keys[off_d + (i - e_nd)];
+        in_src[i] = (uint32_t)(k & 0xFFFFFFFFull);
+    }
+}
+
+__global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n,
+                             uint32_t* __restrict__ dst) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t j = idx[i];
+    dst[i] = j == 0xFFFFFFFFu ? 0u : src[j];
+}
+
+inline unsigned grid_for(uint64_t n, unsigned cap = 65535u * 16u) {
+    uint64_t b = (n + TPB - 1) / TPB;
+    if (b < 1) b = 1;
+    return (unsigned)std::min<uint64_t>(b, cap);
+}
+
+int32_t sort_u64(ss_ctx* ctx, uint64_t* in, uint64_t* out, uint64_t n, unsigned end_bit) {
+    if (n == 0) return SS_OK;
+    size_t tmp_bytes = 0;
+    SS_HIP(ctx, rocprim::radix_sort_keys(nullptr, tmp_bytes, in, out, (size_t)n, 0u, end_bit, ctx->stream));
+    ss::DevBuf<char> tmp;
+    SS_HIP(ctx, tmp.alloc(tmp_bytes));
+    SS_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tmp_bytes, in, out, (size_t)n, 0u, end_bit, ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_in) {
+    ss_ctx* ctx = g->ctx;
+    hipStream_t st = ctx->stream;
+    const uint64_t n = g->n, e = g->e;
+    const uint32_t W = (uint32_t)g->world;
+
+    ss::DevBuf<uint64_t> d_out_ptr;
+    ss::DevBuf<uint32_t> d_out_dst, d_outdeg, d_indeg;
+    ss::DevBuf<unsigned long long> d_cnt;
+    ss::DevBuf<uint32_t> d_err;
+    SS_HIP(ctx, d_out_ptr.alloc(n + 1));
+    SS_HIP(ctx, d_out_dst.alloc(e));
+    SS_HIP(ctx, d_outdeg.alloc(n));
+    SS_HIP(ctx, d_indeg.alloc(n));
+    SS_HIP(ctx, d_cnt.alloc(1));
+    SS_HIP(ctx, d_err.alloc(1));
+    SS_HIP(ctx, hipMemcpyAsync(d_out_ptr.p, out_ptr_in, (n + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
+    if (e) SS_HIP(ctx, hipMemcpyAsync(d_out_dst.p, out_dst_in, e * sizeof(uint32_t), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipMemsetAsync(d_indeg.p, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), st));
+    SS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned long long), st));
+    SS_HIP(ctx, hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), st));
+
+    // the first/last offsets must frame out_dst exactly
+    uint64_t h_first = 0, h_last = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&h_first, d_out_ptr.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&h_last, d_out_ptr.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+
+    if (n) hipLaunchKernelGGL(k_outdeg, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_out_ptr.p, n, d_outdeg.p, d_cnt.p, d_err.p);
+    if (e) hipLaunchKernelGGL(k_indeg, dim3(grid_for(e, 8192)), dim3(TPB), 0, st, d_out_dst.p, e, n, d_indeg.p, d_err.p);
+    unsigned long long h_nd = 0;
+    uint32_t h_err = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&h_nd, d_cnt.p, sizeof(h_nd), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (h_first != 0 || h_last != e) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: out_ptr[0]=%llu, out_ptr[n]=%llu, expected 0 and n_edges=%llu",
+                                                      (unsigned long long)h_first, (unsigned long long)h_last, (unsigned long long)e);
+    if (h_err & 1) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: out_ptr is not non-decreasing");
+    if (h_err & 2) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: out_dst holds a node id >= n_nodes");
+
+    g->n_nd = h_nd;
+    const uint64_t n_d = n - h_nd;
+    // world>1: every rank's all-gather piece ends in two extra (edge-less) rows that carry
+    // its partial sums (contribution sum, L1 delta) — see pagerank.hip block_reduce_and_publish
+    g->sl_nd = (uint32_t)((h_nd + W - 1) / W) + (W > 1 ? 2u : 0u);
+    g->sl_d = (uint32_t)((n_d + W - 1) / W);
+    g->nd_int = (uint64_t)W * g->sl_nd;
+    g->n_int = (uint64_t)W * ((uint64_t)g->sl_nd + g->sl_d);
+    if (g->n_int >= 0xFFFFFFFFull) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_graph_create: too many nodes for 32-bit ids");
+    // rows of class c dealt round-robin: rank r gets positions r, r+W, ...
+    g->cnt_nd = (uint32_t)((h_nd + W - 1 - g->rank) / W);
+    g->cnt_d = (uint32_t)((n_d + W - 1 - g->rank) / W);
+
+    // ---- node order ---------------------------------------------------------
+    ss::DevBuf<uint64_t> keys_a, keys_b;
+    SS_HIP(ctx, keys_a.alloc(std::max<uint64_t>(n, e)));
+    SS_HIP(ctx, keys_b.alloc(std::max<uint64_t>(n, e)));
+    if (n) hipLaunchKernelGGL(k_row_keys, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_outdeg.p, d_indeg.p, n, keys_a.p);
+    SS_TRY(sort_u64(ctx, keys_a.p, keys_b.p, n, 64));
+
+    ss::DevBuf<uint32_t> indeg_int;
+    SS_HIP(ctx, g->new_id.alloc(n));
+    SS_HIP(ctx, g->old_id.alloc(g->n_int));
+    SS_HIP(ctx, indeg_int.alloc(g->n_int + 1));
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(g->n_int + 1, 4096)), dim3(TPB), 0, st, g->old_id.p, g->n_int, 0xFFFFFFFFu);
+    SS_HIP(ctx, hipMemsetAsync(indeg_int.p, 0, (g->n_int + 1) * sizeof(uint32_t), st));
+    if (n) hipLaunchKernelGGL(k_assign_ids, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, keys_b.p, n, (uint64_t)h_nd, W,
+                              g->sl_nd, g->sl_d, d_indeg.p, g->new_id.p, g->old_id.p, indeg_int.p);
+
+    // in_ptr over internal ids (exclusive scan of in-degrees, n_int+1 entries)
+    ss::DevBuf<uint64_t> in_ptr_int;
+    SS_HIP(ctx, in_ptr_int.alloc(g->n_int + 1));
+    {
+        size_t tmp_bytes = 0;
+        auto in_it = rocprim::make_transform_iterator(indeg_int.p, [] __device__(uint32_t x) { return (uint64_t)x; });
+        SS_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, in_it, in_ptr_int.p, (uint64_t)0, (size_t)(g->n_int + 1),
+                                            rocprim::plus<uint64_t>(), st));
+        ss::DevBuf<char> tmp;
+        SS_HIP(ctx, tmp.alloc(tmp_bytes));
+        SS_HIP(ctx, rocprim::exclusive_scan(tmp.p, tmp_bytes, in_it, in_ptr_int.p, (uint64_t)0, (size_t)(g->n_int + 1),
+                                            rocprim::plus<uint64_t>(), st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+    }
+
+    // ---- edges: (dst_int, src_int) sorted ------------------------------------
+    if (e) {
+        hipLaunchKernelGGL(k_edge_keys, dim3(grid_for(e, 16384)), dim3(TPB), 0, st, d_out_ptr.p, d_out_dst.p, n, e,
+                           g->new_id.p, keys_a.p);
+        SS_TRY(sort_u64(ctx, keys_a.p, keys_b.p, e, 64));
+    }
+
+    // ---- this rank's rows -----------------------------------------------------
+    const uint64_t id0_nd = (uint64_t)g->rank * g->sl_nd;
+    const uint64_t id0_d = g->nd_int + (uint64_t)g->rank * g->sl_d;
+    uint64_t h_ptr[4] = {0, 0, 0, 0};
+    SS_HIP(ctx, hipMemcpyAsync(&h_ptr[0], in_ptr_int.p + id0_nd, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&h_ptr[1], in_ptr_int.p + id0_nd + g->sl_nd, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&h_ptr[2], in_ptr_int.p + id0_d, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&h_ptr[3], in_ptr_int.p + id0_d + g->sl_d, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t e_nd = h_ptr[1] - h_ptr[0], e_d = h_ptr[3] - h_ptr[2];
+    g->e_local_nd = e_nd;
+    g->e_local = e_nd + e_d;
+    if (g->e_local >= 0xFFFFFFFFull) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_graph_create: > 2^32-1 local edges");
+
+    const uint32_t n_local = g->n_local();
+    SS_HIP(ctx, g->in_ptr.alloc((size_t)n_local + 1));
+    SS_HIP(ctx, g->in_src.alloc(g->e_local));
+    SS_HIP(ctx, g->outdeg.alloc(g->sl_nd));
+    hipLaunchKernelGGL(k_local_ptr, dim3(ss::div_up((uint64_t)n_local + 1, TPB)), dim3(TPB), 0, st, in_ptr_int.p, g->sl_nd,
+                       g->sl_d, id0_nd, id0_d, h_ptr[0], h_ptr[2], e_nd, g->in_ptr.p);
+    if (g->e_local)
+        hipLaunchKernelGGL(k_extract_src, dim3(grid_for(g->e_local, 16384)), dim3(TPB), 0, st, keys_b.p, h_ptr[0], e_nd,
+                           h_ptr[2], g->e_local, g->in_src.p);
+    if (g->sl_nd)
+        hipLaunchKernelGGL(k_gather_u32, dim3(ss::div_up(g->sl_nd, TPB)), dim3(TPB), 0, st, d_outdeg.p, g->old_id.p + id0_nd,
+                           (uint64_t)g->sl_nd, g->outdeg.p);
+
+    // host copies of local in-degrees (already sorted descending inside each class slice)
+    g->h_indeg_nd.assign(g->cnt_nd, 0);
+    g->h_indeg_d.assign(g->cnt_d, 0);
+    if (g->cnt_nd) SS_HIP(ctx, hipMemcpyAsync(g->h_indeg_nd.data(), indeg_int.p + id0_nd, g->cnt_nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (g->cnt_d) SS_HIP(ctx, hipMemcpyAsync(g->h_indeg_d.data(), indeg_int.p + id0_d, g->cnt_d * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    g->max_indeg = 0;
+    if (g->cnt_nd) g->max_indeg = std::max(g->max_indeg, g->h_indeg_nd[0]);
+    if (g->cnt_d) g->max_indeg = std::max(g->max_indeg, g->h_indeg_d[0]);
+    SS_HIP(ctx, hipGetLastError());
+    return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ss_graph_create(ss_ctx* ctx, uint64_t n_nodes, uint64_t n_edges, const uint64_t* out_ptr,
+                        const uint32_t* out_dst, int32_t rank, int32_t world, ss_graph** out) {
+    if (!ctx) return SS_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!out) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: out is NULL");
+    *out = nullptr;
+    if (!out_ptr || (n_edges && !out_dst)) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: NULL adjacency");
+    if (world < 1 || rank < 0 || rank >= world) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: bad rank/world %d/%d", rank, world);
+    if (n_nodes == 0) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: empty node set");
+    if (n_nodes >= 0xFFFFFFF0ull) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_graph_create: n_nodes exceeds 32-bit ids");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    ss_graph* g = new (std::nothrow) ss_graph();
+    if (!g) return ctx->fail(SS_ERR_OOM, "ss_graph_create: host OOM");
+    g->ctx = ctx;
+    g->n = n_nodes;
+    g->e = n_edges;
+    g->rank = rank;
+    g->world = world;
+    int32_t rc = build(g, out_ptr, out_dst);
+    if (rc != SS_OK) {
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return SS_OK;
+}
+
+int32_t ss_graph_get_info(const ss_graph* g, ss_graph_info* info) {
+    if (!g || !info) return SS_ERR_INVALID;
+    info->n_nodes = g->n;
+    info->n_edges = g->e;
+    info->n_nondangling = g->n_nd;
+    info->n_rows_local = (uint64_t)g->cnt_nd + g->cnt_d;
+    info->n_edges_local = g->e_local;
+    info->max_indeg = g->max_indeg;
+    info->rank = g->rank;
+    info->world = g->world;
+    return SS_OK;
+}
+
+int32_t ss_graph_destroy(ss_graph* g) {
+    if (!g) return SS_ERR_INVALID;
+    ss_ctx* ctx = g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete g;
+    return SS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// graph.hpp — device-resident link graph in the layout the PageRank kernels want.
+//
+// Reference: ranking/pagerank.go:17-44 builds map[parent][]child and the node
+// set (parents U children).  Here the Go shim hands over the same adjacency as
+// an out-edge CSR over dense ids and this module rebuilds it, on the device, as
+//
+//   * an internal node numbering:  [ non-dangling nodes | dangling nodes ]
+//       - only non-dangling nodes ever contribute rank (pagerank.go:131-134),
+//         so the gathered "contribution table" is compact (n_nd rows) and, with
+//         several GPUs, only that part is exchanged;
+//       - inside each class rows are sorted by in-degree (descending) and dealt
+//         round-robin to the `world` ranks, so every rank's slice is contiguous
+//         (one all-gather piece), edge-balanced, and degree-binned
+//         (block-per-row / wave-per-row / lane-group-per-row / no-edge rows);
+//   * in-edge lists (pull form) of this rank's rows, sources in internal ids,
+//     sorted by (row, source): the SpMV needs no atomics and is deterministic.
+#pragma once
+#include "common.hpp"
+
+struct ss_graph {
+    ss_ctx* ctx = nullptr;
+    uint64_t n = 0, e = 0;
+    int rank = 0, world = 1;
+    uint64_t n_nd = 0;            // nodes with out-degree > 0
+    uint32_t sl_nd = 0, sl_d = 0; // rows per rank slice (padded), per class
+    uint32_t cnt_nd = 0, cnt_d = 0; // real rows of this rank, per class
+    uint64_t nd_int = 0;          // world * sl_nd: rows of the contribution table
+    uint64_t n_int = 0;           // world * (sl_nd + sl_d)
+    uint64_t e_local = 0, e_local_nd = 0;
+    uint32_t max_indeg = 0;
+
+    ss::DevBuf<uint32_t> new_id;  // [n]     original id -> internal id
+    ss::DevBuf<uint32_t> old_id;  // [n_int] internal id -> original id (0xFFFFFFFF = padding row)
+    // local rows: lrow in [0, sl_nd) = non-dangling slice, [sl_nd, sl_nd+sl_d) = dangling slice
+    ss::DevBuf<uint32_t> in_ptr;  // [sl_nd + sl_d + 1]
+    ss::DevBuf<uint32_t> in_src;  // [e_local] internal ids, all < nd_int
+    ss::DevBuf<uint32_t> outdeg;  // [sl_nd] out-degree of the local non-dangling rows
+    // host copies of the local in-degrees (sorted descending per class) for work-table building
+    std::vector<uint32_t> h_indeg_nd, h_indeg_d;
+
+    uint32_t n_local() const { return sl_nd + sl_d; }
+    // internal id of local row
+    uint64_t int_id(uint32_t lrow) const {
+        return lrow < sl_nd ? (uint64_t)rank * sl_nd + lrow
+                            : nd_int + (uint64_t)rank * sl_d + (lrow - sl_nd);
+    }
+};

@@ -1,0 +1,735 @@
+// pagerank.hip — Topic-Sensitive PageRank power iteration for gfx950 (MI355X).
+//
+// Replaces ranking/pagerank.go:85-145 (updatePagerank + computeRankInherited),
+// all categories of pagerank.go:54-63 at once: one K-wide sweep per iteration.
+//
+// Reference arithmetic per topic (Q3-Q6 of SURVEY.md §7):
+//   w_p      = d * last[p] / outdeg(p)            for every p with outdeg>0   (:136)
+//   total    = sum_p w_p + (1-d) * N                                          (:137,:112)
+//   cur[v]   = (1/n if iteration==1 else 0) + sum_{p->v} w_p                  (:97-107,:140-142)
+//   cur[v]   = (cur[v] + (1-d)) / total                                       (:117)
+//   change   = sum_v |cur[v]-last[v]| ; loop while change > eps               (:93,:118)
+//
+// HBM layout (node-major, the K topic values of a node are contiguous so that ONE
+// index read serves K gathers and a K=16 gather is one 128-byte line):
+//   x     [n_local][GW]   rank of this rank's rows, updated in place
+//   table [nd_int ][GW]   contributions w_p of ALL non-dangling nodes, read by
+//                         random gather; written for the next sweep
+//                         (world==1: ping-pong pair; world>1: own slice -> `send`,
+//                          host all-gathers it into `table`)
+// One kernel per sweep.  The pull SpMV, the normalise, the L1 delta, the next
+// sweep's contributions and their sum (next `total`) are fused; block partial
+// sums are combined deterministically by the last block to arrive
+// (agent-scope release/acquire, cdna_hip_programming.md Guideline 16), which also
+// applies the stop rule — the loop needs no host round trip per iteration.
+//
+// Algorithmic bytes per sweep: 4E + 8N + 16*K*N.
+#include "graph.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int WAVES = TPB / 64;
+constexpr int MAXK = 16;
+
+struct PrCtl {
+    double S[MAXK];       // normaliser (`totalValue`) for the next sweep
+    double delta[MAXK];   // last L1 change
+    double csum[MAXK];    // last contribution sum (diagnostics)
+    int32_t active[MAXK];
+    int32_t iters[MAXK];
+    int32_t sweep;        // sweeps completed
+    int32_t n_active;
+    uint32_t ticket;      // last-block arrival counter
+    uint32_t pad;
+};
+
+enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3 };
+
+struct WorkItem {
+    uint32_t kind;
+    uint32_t row;     // first local row
+    uint32_t count;   // rows (WAVE/GROUP/ZERO) or segment index (SEG)
+    uint32_t nseg;    // SEG: segments of this row
+    uint32_t sbase;   // SEG: index of the row's first segment partial
+    uint32_t tix;     // SEG: per-row ticket index
+};
+
+struct PrParams {
+    const uint32_t* in_ptr;
+    const uint32_t* in_src;
+    const uint32_t* outdeg;
+    double* x;
+    const double* tab_rd[2];
+    double* tab_wr[2];
+    const WorkItem* work;
+    double* partials;     // [nblocks][2][GW]
+    double* segpart;      // [nsegs][GW]
+    uint32_t* rowticket;  // [n multi-segment rows]
+    PrCtl* ctl;
+    const double* x0;     // [GW] 1/n_topic
+    double d, teleport, eps, tele_n;
+    int32_t max_iter, k_topics, world;
+    uint32_t sl_nd, cnt_nd, sl_d, cnt_d, seg_edges;
+};
+
+// ---- reductions --------------------------------------------------------------
+
+// sum over the lanes of a wave that hold the same topic (lane % GW), fixed butterfly order
+template <int GW>
+__device__ __forceinline__ double wave_sum_topic(double v) {
+#pragma unroll
+    for (int off = GW; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl, const double* cs, bool is_begin) {
+    PrCtl* ctl = p.ctl;
+    if (is_begin) {
+        for (int k = 0; k < MAXK; k++) {
+            const bool real = k < p.k_topics;
+            ctl->S[k] = real ? cs[k] + p.tele_n : 1.0;
+            ctl->csum[k] = real ? cs[k] : 0.0;
+            ctl->delta[k] = 0.0;
+            ctl->active[k] = real ? 1 : 0;
+            ctl->iters[k] = 0;
+        }
+        ctl->sweep = 0;
+        ctl->n_active = p.k_topics;
+        return;
+    }
+    const int it = ctl->sweep + 1;
+    int na = 0;
+    for (int k = 0; k < p.k_topics; k++) {
+        if (ctl->active[k]) {
+            ctl->iters[k] = it;
+            ctl->delta[k] = dl[k];
+            bool cont = dl[k] > p.eps;                      // pagerank.go:93
+            if (p.max_iter > 0 && it >= p.max_iter) cont = false;
+            ctl->active[k] = cont ? 1 : 0;
+            na += cont ? 1 : 0;
+            ctl->S[k] = cs[k] + p.tele_n;                   // pagerank.go:111-112
+            ctl->csum[k] = cs[k];
+        }
+    }
+    ctl->sweep = it;
+    ctl->n_active = na;
+}
+
+// Block partial -> global partials; the last block to arrive sums all partials in a
+// fixed order and either finalises the control block (world==1) or leaves this
+// rank's totals in the tail rows of the send buffer (world>1).
+template <int GW>
+__device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, double dsum, double csum, double* tail,
+                                                         bool is_begin) {
+    __shared__ double red[WAVES][2][MAXK];
+    __shared__ double tot[2][MAXK];
+    __shared__ double colsum[TPB];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane % GW;
+    dsum = wave_sum_topic<GW>(dsum);
+    csum = wave_sum_topic<GW>(csum);
+    if (lane < GW) {
+        red[wave][0][t] = dsum;
+        red[wave][1][t] = csum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * GW) {
+        const int which = threadIdx.x / GW, tt = threadIdx.x % GW;
+        double v = red[0][which][tt];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++) v += red[w][which][tt];
+        p.partials[(size_t)blockIdx.x * 2 * GW + threadIdx.x] = v;
+    }
+    // publish: drain stores, barrier, one lane releases and takes a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    // deterministic column sums over all blocks: column = (which, topic)
+    constexpr int NCOL = 2 * GW;
+    constexpr int NPART = TPB / NCOL;
+    const int col = threadIdx.x % NCOL, part = threadIdx.x / NCOL;
+    double acc = 0.0;
+    for (unsigned b = part; b < gridDim.x; b += NPART) acc += p.partials[(size_t)b * NCOL + col];
+    colsum[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < NCOL) {
+        double v = 0.0;
+        for (int q = 0; q < NPART; q++) v += colsum[q * NCOL + threadIdx.x];
+        tot[threadIdx.x / GW][threadIdx.x % GW] = v;
+    }
+    __syncthreads();
+    if (p.world == 1) {
+        if (threadIdx.x == 0) {
+            double dl[MAXK], cs[MAXK];
+            for (int k = 0; k < MAXK; k++) {
+                dl[k] = k < GW ? tot[0][k] : 0.0;
+                cs[k] = k < GW ? tot[1][k] : 0.0;
+            }
+            finalize_ctl(p, dl, cs, is_begin);
+            p.ctl->ticket = 0;
+        }
+    } else {
+        // tail rows of this rank's all-gather piece: row sl_nd-2 = contribution sums, row sl_nd-1 = deltas
+        if (threadIdx.x < GW) {
+            tail[(size_t)(p.sl_nd - 2) * GW + threadIdx.x] = tot[1][threadIdx.x];
+            tail[(size_t)(p.sl_nd - 1) * GW + threadIdx.x] = tot[0][threadIdx.x];
+        }
+        if (threadIdx.x == 0) p.ctl->ticket = 0;
+    }
+}
+
+// ---- gather ------------------------------------------------------------------
+
+// sum of T[src][t] over edges beg+first, beg+first+stride, ... < end; 4 gathers in flight
+template <int GW>
+__device__ __forceinline__ double gather_sum(const double* __restrict__ T, const uint32_t* __restrict__ in_src,
+                                             size_t beg, size_t end, unsigned first, unsigned stride, int t) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    size_t e = beg + first;
+    for (; e + 3 * (size_t)stride < end; e += 4 * (size_t)stride) {
+        const uint32_t s0 = in_src[e], s1 = in_src[e + stride], s2 = in_src[e + 2 * (size_t)stride],
+                       s3 = in_src[e + 3 * (size_t)stride];
+        a0 += T[(size_t)s0 * GW + t];
+        a1 += T[(size_t)s1 * GW + t];
+        a2 += T[(size_t)s2 * GW + t];
+        a3 += T[(size_t)s3 * GW + t];
+    }
+    for (; e < end; e += stride) a0 += T[(size_t)in_src[e] * GW + t];
+    return (a0 + a1) + (a2 + a3);
+}
+
+// ---- the sweep ---------------------------------------------------------------
+template <int GW>
+__global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
+    constexpr int NSLOT = 64 / GW;
+    __shared__ double rowred[WAVES][MAXK];
+    __shared__ int s_rowlast;
+
+    PrCtl* ctl = p.ctl;
+    if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
+    const int sweep = ctl->sweep;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane % GW, slot = lane / GW;
+    const double S = ctl->S[t];
+    const bool act = ctl->active[t] != 0;
+    const double x0 = sweep == 0 ? p.x0[t] : 0.0;      // Q4: iteration 1 accumulates onto 1/n
+    const double* __restrict__ T = p.tab_rd[sweep & 1];
+    double* __restrict__ Tw = p.tab_wr[sweep & 1];
+    const WorkItem w = p.work[blockIdx.x];
+
+    double dsum = 0.0, csum = 0.0;
+
+    auto finish = [&](uint32_t lrow, double y) {
+        y += x0;
+        const size_t xi = (size_t)lrow * GW + t;
+        const double xo = p.x[xi];
+        double xn = (y + p.teleport) / S;               // pagerank.go:117
+        if (act) {
+            p.x[xi] = xn;
+            dsum += fabs(xn - xo);                      // pagerank.go:118
+        } else {
+            xn = xo;                                    // converged topic: frozen
+        }
+        if (lrow < p.sl_nd) {                           // non-dangling row: next sweep's contribution
+            const double c = p.d * xn / (double)p.outdeg[lrow];   // pagerank.go:136
+            Tw[xi] = c;
+            csum += c;                                  // pagerank.go:137
+        }
+    };
+
+    if (w.kind == W_SEG) {
+        // one block per segment of a long row; all 4 waves stride the segment
+        const uint32_t lrow = w.row;
+        const size_t rbeg = p.in_ptr[lrow], rend = p.in_ptr[lrow + 1];
+        const size_t beg = rbeg + (size_t)w.count * p.seg_edges;
+        const size_t end = min(rend, beg + (size_t)p.seg_edges);
+        double acc = gather_sum<GW>(T, p.in_src, beg, end, wave * NSLOT + slot, WAVES * NSLOT, t);
+        acc = wave_sum_topic<GW>(acc);
+        if (lane < GW) rowred[wave][t] = acc;
+        __syncthreads();
+        double y = 0.0;
+        if (threadIdx.x < GW) {
+            y = rowred[0][t];
+#pragma unroll
+            for (int q = 1; q < WAVES; q++) y += rowred[q][t];
+        }
+        if (w.nseg == 1) {
+            if (threadIdx.x < GW) finish(lrow, y);
+        } else {
+            // several blocks share this row: publish the segment partial; the last
+            // arriver adds the partials in segment order and finishes the row
+            if (threadIdx.x < GW) p.segpart[(size_t)(w.sbase + w.count) * GW + t] = y;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned prev = __hip_atomic_fetch_add(&p.rowticket[w.tix], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = prev == w.nseg - 1;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    p.rowticket[w.tix] = 0;
+                }
+                s_rowlast = last;
+            }
+            __syncthreads();
+            if (s_rowlast && threadIdx.x < GW) {
+                double ys = 0.0;
+                for (uint32_t q = 0; q < w.nseg; q++) ys += p.segpart[(size_t)(w.sbase + q) * GW + t];
+                finish(lrow, ys);
+            }
+        }
+    } else if (w.kind == W_WAVE) {
+        // one wave per row, the wave's lane groups stride the row's in-edges
+        if ((uint32_t)wave < w.count) {
+            const uint32_t lrow = w.row + wave;
+            const size_t beg = p.in_ptr[lrow], end = p.in_ptr[lrow + 1];
+            double acc = gather_sum<GW>(T, p.in_src, beg, end, slot, NSLOT, t);
+            acc = wave_sum_topic<GW>(acc);
+            if (slot == 0) finish(lrow, acc);
+        }
+    } else if (w.kind == W_GROUP) {
+        // one lane group (GW lanes) per row; rows are degree-sorted so trip counts match inside a wave
+        for (uint32_t r = wave * NSLOT + slot; r < w.count; r += WAVES * NSLOT) {
+            const uint32_t lrow = w.row + r;
+            const size_t beg = p.in_ptr[lrow], end = p.in_ptr[lrow + 1];
+            double acc = 0.0;
+            for (size_t e = beg; e < end; e++) acc += T[(size_t)p.in_src[e] * GW + t];
+            finish(lrow, acc);
+        }
+    } else {
+        // rows without in-edges: pure streaming update
+        const uint32_t nel = w.count * GW;
+        for (uint32_t i = threadIdx.x; i < nel; i += TPB) finish(w.row + i / GW, 0.0);
+    }
+
+    block_reduce_and_publish<GW>(p, dsum, csum, Tw, false);
+}
+
+// x0 = 1/n, first contributions and their sum (pagerank.go:103-106 + first :136-137)
+template <int GW>
+__global__ __launch_bounds__(TPB) void k_pr_begin(PrParams p) {
+    const int lane = threadIdx.x & 63;
+    const int t = lane % GW;
+    const double x0 = p.x0[t];
+    double* __restrict__ Tw = p.tab_wr[1];   // the table sweep 0 reads (tab_rd[0]) — see pr_make_params
+    double csum = 0.0;
+    const size_t n_el = ((size_t)p.sl_nd + p.sl_d) * GW;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n_el; i += (size_t)gridDim.x * TPB) {
+        const uint32_t lrow = (uint32_t)(i / GW);
+        const bool real = lrow < p.sl_nd ? lrow < p.cnt_nd : (lrow - p.sl_nd) < p.cnt_d;
+        p.x[i] = real ? x0 : 0.0;
+        if (lrow < p.sl_nd) {
+            double c = 0.0;
+            if (real) c = p.d * x0 / (double)p.outdeg[lrow];
+            if (p.world == 1 || lrow + 2 < p.sl_nd) Tw[i] = c;   // world>1: last two rows are the tail
+            csum += c;
+        }
+    }
+    block_reduce_and_publish<GW>(p, 0.0, csum, Tw, true);
+}
+
+// world>1: after the all-gather, combine the per-rank tails (rank order) and apply the stop rule
+template <int GW>
+__global__ void k_pr_finalize(PrParams p, const double* __restrict__ table, int is_begin) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!is_begin && p.ctl->n_active == 0) return;
+    double dl[MAXK], cs[MAXK];
+    for (int k = 0; k < MAXK; k++) { dl[k] = 0.0; cs[k] = 0.0; }
+    for (int r = 0; r < p.world; r++) {
+        const size_t base = ((size_t)r * p.sl_nd + (p.sl_nd - 2)) * GW;
+        for (int k = 0; k < GW; k++) {
+            cs[k] += table[base + k];
+            dl[k] += table[base + GW + k];
+        }
+    }
+    finalize_ctl(p, dl, cs, is_begin != 0);
+}
+
+template <int GW>
+__global__ void k_pr_read(const double* __restrict__ x, const uint32_t* __restrict__ old_id, uint32_t sl_nd, uint32_t cnt_nd,
+                          uint32_t sl_d, uint32_t cnt_d, uint64_t id0_nd, uint64_t id0_d, int k_topics, uint64_t out_stride,
+                          int by_original_id, uint32_t* __restrict__ ids_out, double* __restrict__ out) {
+    const size_t n_rows = (size_t)cnt_nd + cnt_d;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t lrow = i < cnt_nd ? (uint32_t)i : sl_nd + (uint32_t)(i - cnt_nd);
+    const uint64_t iid = lrow < sl_nd ? id0_nd + lrow : id0_d + (lrow - sl_nd);
+    const uint32_t orig = old_id[iid];
+    const size_t o = by_original_id ? (size_t)orig : i;
+    if (ids_out) ids_out[i] = orig;
+    for (int k = 0; k < k_topics; k++) out[(size_t)k * out_stride + o] = x[(size_t)lrow * GW + k];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------
+
+struct ss_pr {
+    ss_graph* g = nullptr;
+    int gw = 1;            // lane-group width = padded topic count
+    int k = 1;
+    PrParams prm{};
+    unsigned nblocks = 0;
+    ss::DevBuf<double> x, tab0, tab1, send, partials, segpart, x0;
+    ss::DevBuf<uint32_t> rowticket;
+    ss::DevBuf<WorkItem> work;
+    ss::DevBuf<PrCtl> ctl;
+    bool begun = false;
+    bool need_finalize = false;   // world>1: a begin/step is waiting for its exchange + finalize
+    bool finalize_is_begin = false;
+};
+
+namespace {
+
+int pick_gw(int k) {
+    int gw = 1;
+    while (gw < k) gw <<= 1;
+    return gw;
+}
+
+void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
+                uint32_t& seg_edges) {
+    const uint32_t NSLOT = 64 / gw;
+    const uint32_t T_SEG = 32 * NSLOT;      // longer rows: block(s) per row
+    const uint32_t T_WAVE = 2 * NSLOT;      // longer rows: wave per row
+    seg_edges = 128 * NSLOT;
+    nsegs = 0;
+    nmulti = 0;
+    std::vector<WorkItem> seg, wav, grp, zer;
+    auto emit = [&](const std::vector<uint32_t>& deg, uint32_t row0) {
+        const uint32_t cnt = (uint32_t)deg.size();
+        // deg is sorted descending: find class boundaries
+        uint32_t a = 0;
+        while (a < cnt && deg[a] > T_SEG) a++;
+        uint32_t b = a;
+        while (b < cnt && deg[b] > T_WAVE) b++;
+        uint32_t c = b;
+        while (c < cnt && deg[c] > 0) c++;
+        for (uint32_t r = 0; r < a; r++) {
+            const uint32_t ns = (deg[r] + seg_edges - 1) / seg_edges;
+            const uint32_t tix = ns > 1 ? nmulti++ : 0;
+            for (uint32_t s = 0; s < ns; s++) seg.push_back({W_SEG, row0 + r, s, ns, nsegs, tix});
+            nsegs += ns;
+        }
+        for (uint32_t r = a; r < b; r += WAVES) wav.push_back({W_WAVE, row0 + r, std::min<uint32_t>(WAVES, b - r), 0, 0, 0});
+        const uint32_t GROUP_ROWS = WAVES * NSLOT * 4;   // 4 rows per lane group per block
+        for (uint32_t r = b; r < c; r += GROUP_ROWS) grp.push_back({W_GROUP, row0 + r, std::min<uint32_t>(GROUP_ROWS, c - r), 0, 0, 0});
+        const uint32_t ZERO_ROWS = (TPB * 8) / gw;       // 8 elements per thread
+        for (uint32_t r = c; r < cnt; r += ZERO_ROWS) zer.push_back({W_ZERO, row0 + r, std::min<uint32_t>(ZERO_ROWS, cnt - r), 0, 0, 0});
+    };
+    emit(g->h_indeg_nd, 0);
+    emit(g->h_indeg_d, g->sl_nd);
+    items.clear();
+    items.reserve(seg.size() + wav.size() + grp.size() + zer.size());
+    // heavy work first
+    items.insert(items.end(), seg.begin(), seg.end());
+    items.insert(items.end(), wav.begin(), wav.end());
+    items.insert(items.end(), grp.begin(), grp.end());
+    items.insert(items.end(), zer.begin(), zer.end());
+}
+
+template <int GW>
+void launch_step(ss_pr* pr, hipStream_t st) {
+    hipLaunchKernelGGL(k_pr_step<GW>, dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+}
+template <int GW>
+void launch_begin(ss_pr* pr, hipStream_t st, unsigned nb) {
+    hipLaunchKernelGGL(k_pr_begin<GW>, dim3(nb), dim3(TPB), 0, st, pr->prm);
+}
+template <int GW>
+void launch_finalize(ss_pr* pr, hipStream_t st, int is_begin) {
+    hipLaunchKernelGGL(k_pr_finalize<GW>, dim3(1), dim3(64), 0, st, pr->prm, (const double*)pr->tab0.p, is_begin);
+}
+template <int GW>
+void launch_read(ss_pr* pr, hipStream_t st, int by_orig, uint64_t stride, uint32_t* ids, double* out) {
+    const ss_graph* g = pr->g;
+    const size_t n_rows = (size_t)g->cnt_nd + g->cnt_d;
+    if (!n_rows) return;
+    hipLaunchKernelGGL(k_pr_read<GW>, dim3(ss::div_up(n_rows, TPB)), dim3(TPB), 0, st, (const double*)pr->x.p,
+                       (const uint32_t*)g->old_id.p, g->sl_nd, g->cnt_nd, g->sl_d, g->cnt_d,
+                       (uint64_t)g->rank * g->sl_nd, g->nd_int + (uint64_t)g->rank * g->sl_d, pr->k, stride, by_orig, ids, out);
+}
+
+#define SS_GW_DISPATCH(gw, fn, ...)          \
+    switch (gw) {                            \
+        case 1: fn<1>(__VA_ARGS__); break;   \
+        case 2: fn<2>(__VA_ARGS__); break;   \
+        case 4: fn<4>(__VA_ARGS__); break;   \
+        case 8: fn<8>(__VA_ARGS__); break;   \
+        default: fn<16>(__VA_ARGS__); break; \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, int32_t k_topics,
+                     const int32_t* n_topic, ss_pr** out) {
+    if (!g) return SS_ERR_INVALID;
+    ss_ctx* ctx = g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!out) return ctx->fail(SS_ERR_INVALID, "ss_pr_create: out is NULL");
+    *out = nullptr;
+    if (k_topics < 1 || !n_topic) return ctx->fail(SS_ERR_INVALID, "ss_pr_create: k_topics < 1 or n_topic NULL");
+    if (k_topics > MAXK) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_create: k_topics %d > %d per state (ss_pagerank_run splits larger K)", k_topics, MAXK);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    ss_pr* pr = new (std::nothrow) ss_pr();
+    if (!pr) return ctx->fail(SS_ERR_OOM, "ss_pr_create: host OOM");
+    std::unique_ptr<ss_pr> guard(pr);
+    pr->g = g;
+    pr->k = k_topics;
+    pr->gw = pick_gw(k_topics);
+    const int GW = pr->gw;
+    const size_t n_local = g->n_local();
+
+    std::vector<WorkItem> items;
+    uint32_t nsegs = 0, nmulti = 0, seg_edges = 0;
+    build_work(g, GW, items, nsegs, nmulti, seg_edges);
+    if (items.empty()) items.push_back({W_ZERO, 0, 0, 0, 0, 0});
+    pr->nblocks = (unsigned)items.size();
+
+    SS_HIP(ctx, pr->x.alloc(n_local * GW));
+    SS_HIP(ctx, pr->tab0.alloc((size_t)g->nd_int * GW));
+    SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, std::max<size_t>(pr->tab0.bytes(), 8), st));
+    if (g->world == 1) {
+        SS_HIP(ctx, pr->tab1.alloc((size_t)g->nd_int * GW));
+        SS_HIP(ctx, hipMemsetAsync(pr->tab1.p, 0, std::max<size_t>(pr->tab1.bytes(), 8), st));
+    } else {
+        SS_HIP(ctx, pr->send.alloc((size_t)g->sl_nd * GW));
+        SS_HIP(ctx, hipMemsetAsync(pr->send.p, 0, std::max<size_t>(pr->send.bytes(), 8), st));
+    }
+    const unsigned begin_blocks = std::max(1u, std::min(2048u, ss::div_up(n_local * GW, TPB)));
+    SS_HIP(ctx, pr->partials.alloc((size_t)std::max(pr->nblocks, begin_blocks) * 2 * GW));
+    SS_HIP(ctx, pr->segpart.alloc((size_t)std::max(nsegs, 1u) * GW));
+    SS_HIP(ctx, pr->rowticket.alloc(std::max(nmulti, 1u)));
+    SS_HIP(ctx, hipMemsetAsync(pr->rowticket.p, 0, pr->rowticket.bytes(), st));
+    SS_HIP(ctx, pr->work.alloc(items.size()));
+    SS_HIP(ctx, hipMemcpyAsync(pr->work.p, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
+    SS_HIP(ctx, pr->ctl.alloc(1));
+    SS_HIP(ctx, hipMemsetAsync(pr->ctl.p, 0, sizeof(PrCtl), st));
+    double h_x0[MAXK];
+    for (int k = 0; k < MAXK; k++) h_x0[k] = k < k_topics ? 1.0 / (double)n_topic[k] : 0.0;   // pagerank.go:104
+    SS_HIP(ctx, pr->x0.alloc(MAXK));
+    SS_HIP(ctx, hipMemcpyAsync(pr->x0.p, h_x0, sizeof(h_x0), hipMemcpyHostToDevice, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));   // items / h_x0 are stack/host temporaries
+
+    PrParams& p = pr->prm;
+    p.in_ptr = g->in_ptr.p;
+    p.in_src = g->in_src.p;
+    p.outdeg = g->outdeg.p;
+    p.x = pr->x.p;
+    if (g->world == 1) {
+        // sweep s reads tab[s&1], writes tab[(s&1)^1]; begin writes tab_wr[1] = tab0
+        p.tab_rd[0] = pr->tab0.p; p.tab_wr[0] = pr->tab1.p;
+        p.tab_rd[1] = pr->tab1.p; p.tab_wr[1] = pr->tab0.p;
+    } else {
+        p.tab_rd[0] = p.tab_rd[1] = pr->tab0.p;
+        p.tab_wr[0] = p.tab_wr[1] = pr->send.p;
+    }
+    p.work = pr->work.p;
+    p.partials = pr->partials.p;
+    p.segpart = pr->segpart.p;
+    p.rowticket = pr->rowticket.p;
+    p.ctl = pr->ctl.p;
+    p.x0 = pr->x0.p;
+    p.d = damping;
+    p.teleport = 1.0 - damping;                       // pagerank.go:90
+    p.eps = eps;
+    p.tele_n = p.teleport * (double)g->n;             // pagerank.go:112
+    p.max_iter = max_iter;
+    p.k_topics = k_topics;
+    p.world = g->world;
+    p.sl_nd = g->sl_nd;
+    p.cnt_nd = g->cnt_nd;
+    p.sl_d = g->sl_d;
+    p.cnt_d = g->cnt_d;
+    p.seg_edges = seg_edges;
+    *out = guard.release();
+    return SS_OK;
+}
+
+int32_t ss_pr_destroy(ss_pr* pr) {
+    if (!pr) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete pr;
+    return SS_OK;
+}
+
+int32_t ss_pr_begin(ss_pr* pr) {
+    if (!pr) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    if (pr->need_finalize) return ctx->fail(SS_ERR_STATE, "ss_pr_begin: pending exchange/finalize");
+    const size_t n_el = (size_t)pr->g->n_local() * pr->gw;
+    const unsigned nb = std::max(1u, std::min(2048u, ss::div_up(n_el, TPB)));
+    SS_HIP(ctx, hipMemsetAsync(&pr->ctl.p->ticket, 0, sizeof(uint32_t), ctx->stream));
+    SS_GW_DISPATCH(pr->gw, launch_begin, pr, ctx->stream, nb);
+    SS_HIP(ctx, hipGetLastError());
+    pr->begun = true;
+    if (pr->g->world > 1) {
+        pr->need_finalize = true;
+        pr->finalize_is_begin = true;
+    }
+    return SS_OK;
+}
+
+int32_t ss_pr_step(ss_pr* pr, int32_t n_steps) {
+    if (!pr) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!pr->begun) return ctx->fail(SS_ERR_STATE, "ss_pr_step: ss_pr_begin not called");
+    if (pr->need_finalize) return ctx->fail(SS_ERR_STATE, "ss_pr_step: pending exchange/finalize");
+    if (n_steps < 1) return ctx->fail(SS_ERR_INVALID, "ss_pr_step: n_steps < 1");
+    if (pr->g->world > 1 && n_steps != 1) return ctx->fail(SS_ERR_INVALID, "ss_pr_step: world>1 needs an exchange after every step");
+    SS_HIP(ctx, hipEventRecord(ctx->ev[0][0], ctx->stream));
+    for (int i = 0; i < n_steps; i++) SS_GW_DISPATCH(pr->gw, launch_step, pr, ctx->stream);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[0][1], ctx->stream));
+    ctx->ev_valid[0] = true;
+    SS_HIP(ctx, hipGetLastError());
+    if (pr->g->world > 1) {
+        pr->need_finalize = true;
+        pr->finalize_is_begin = false;
+    }
+    return SS_OK;
+}
+
+int32_t ss_pr_finalize(ss_pr* pr) {
+    if (!pr) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    if (pr->g->world == 1) return ctx->fail(SS_ERR_STATE, "ss_pr_finalize: world==1 folds the finalize into the sweep");
+    if (!pr->need_finalize) return ctx->fail(SS_ERR_STATE, "ss_pr_finalize: nothing to finalize");
+    SS_GW_DISPATCH(pr->gw, launch_finalize, pr, ctx->stream, pr->finalize_is_begin ? 1 : 0);
+    SS_HIP(ctx, hipGetLastError());
+    pr->need_finalize = false;
+    return SS_OK;
+}
+
+int32_t ss_pr_exchange_buffers(ss_pr* pr, void** send_dev, uint64_t* send_bytes, void** recv_dev, uint64_t* recv_bytes) {
+    if (!pr) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    if (pr->g->world == 1) return ctx->fail(SS_ERR_STATE, "ss_pr_exchange_buffers: world==1 has no exchange");
+    if (send_dev) *send_dev = pr->send.p;
+    if (send_bytes) *send_bytes = pr->send.bytes();
+    if (recv_dev) *recv_dev = pr->tab0.p;
+    if (recv_bytes) *recv_bytes = pr->tab0.bytes();
+    return SS_OK;
+}
+
+int32_t ss_pr_status(ss_pr* pr, int32_t* iters_out, int32_t* n_active, int32_t* sweeps, double* last_delta_out,
+                     double* last_total_out) {
+    if (!pr) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    PrCtl h;
+    SS_HIP(ctx, hipMemcpyAsync(&h, pr->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < pr->k; k++) {
+        if (iters_out) iters_out[k] = h.iters[k];
+        if (last_delta_out) last_delta_out[k] = h.delta[k];
+        if (last_total_out) last_total_out[k] = h.S[k];
+    }
+    if (n_active) *n_active = h.n_active;
+    if (sweeps) *sweeps = h.sweep;
+    return SS_OK;
+}
+
+int32_t ss_pr_read_local(ss_pr* pr, uint32_t* ids_out, double* rank_out) {
+    if (!pr || !rank_out) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    const ss_graph* g = pr->g;
+    const size_t n_rows = (size_t)g->cnt_nd + g->cnt_d;
+    ss::DevBuf<uint32_t> d_ids;
+    ss::DevBuf<double> d_out;
+    SS_HIP(ctx, d_ids.alloc(n_rows));
+    SS_HIP(ctx, d_out.alloc(n_rows * pr->k));
+    SS_GW_DISPATCH(pr->gw, launch_read, pr, ctx->stream, 0, (uint64_t)n_rows, d_ids.p, d_out.p);
+    SS_HIP(ctx, hipGetLastError());
+    if (ids_out && n_rows) SS_HIP(ctx, hipMemcpyAsync(ids_out, d_ids.p, n_rows * sizeof(uint32_t), hipMemcpyDefault, ctx->stream));
+    if (n_rows) SS_HIP(ctx, hipMemcpyAsync(rank_out, d_out.p, n_rows * pr->k * sizeof(double), hipMemcpyDefault, ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+int32_t ss_pr_read(ss_pr* pr, double* rank_out) {
+    if (!pr || !rank_out) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    const ss_graph* g = pr->g;
+    if (g->world != 1) return ctx->fail(SS_ERR_STATE, "ss_pr_read: world>1, use ss_pr_read_local");
+    ss::DevBuf<double> d_out;
+    SS_HIP(ctx, d_out.alloc((size_t)g->n * pr->k));
+    SS_GW_DISPATCH(pr->gw, launch_read, pr, ctx->stream, 1, (uint64_t)g->n, (uint32_t*)nullptr, d_out.p);
+    SS_HIP(ctx, hipGetLastError());
+    SS_HIP(ctx, hipMemcpyAsync(rank_out, d_out.p, (size_t)g->n * pr->k * sizeof(double), hipMemcpyDefault, ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+int32_t ss_pagerank_run(ss_graph* g, double damping, double eps, int32_t max_iter, int32_t k_topics,
+                        const int32_t* n_topic, double* rank_out, int32_t* iters_out) {
+    if (!g) return SS_ERR_INVALID;
+    ss_ctx* ctx = g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (g->world != 1) return ctx->fail(SS_ERR_STATE, "ss_pagerank_run: needs a (rank 0, world 1) graph");
+    if (k_topics < 1 || k_topics > SS_MAX_TOPICS || !n_topic || !rank_out)
+        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run: bad k_topics / NULL argument");
+    if (!(eps >= 0.0) && max_iter <= 0 && !(eps != eps))
+        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run: eps < 0 (never converges) needs max_iter > 0");
+    // topics are independent power iterations (pagerank.go:54-63): run them MAXK at a time
+    for (int k0 = 0; k0 < k_topics; k0 += MAXK) {
+        const int kk = std::min(MAXK, k_topics - k0);
+        ss_pr* pr = nullptr;
+        SS_TRY(ss_pr_create(g, damping, eps, max_iter, kk, n_topic + k0, &pr));
+        int32_t rc = ss_pr_begin(pr);
+        int32_t n_active = kk, sweeps = 0;
+        // the stop rule lives on the device; the host only looks every BATCH sweeps
+        // (launches after convergence are no-ops)
+        const int BATCH = 8;
+        while (rc == SS_OK && n_active > 0) {
+            int todo = BATCH;
+            if (max_iter > 0) todo = std::min(BATCH, std::max(1, max_iter - sweeps));
+            rc = ss_pr_step(pr, todo);
+            if (rc == SS_OK) rc = ss_pr_status(pr, iters_out ? iters_out + k0 : nullptr, &n_active, &sweeps, nullptr, nullptr);
+        }
+        if (rc == SS_OK) rc = ss_pr_read(pr, rank_out + (size_t)k0 * g->n);
+        ss_pr_destroy(pr);
+        if (rc != SS_OK) return rc;
+    }
+    return SS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// tfidf.hip — inverted-index upload + TF-IDF weight/magnitude build for gfx950.
+//
+// Replaces ranking/term_weighting.go:10-57 (UpdateTermWeights) and the sqrt of
+// saveMagnitude (:72,:97,:105):
+//   idf   = float32(math.Log2(totalDocs / float64(len(val))))        (:37)
+//   w     = tf * idf                      float32 multiply, in place  (:42)
+//   mag2[doc] += float64(w * w)           float32 product, f64 sum    (:44)
+//   mag   = sqrt(mag2)                                                (:72)
+// HBM-bound: 12 B/posting (doc id, read w, write w) + 8 B per doc and term.
+#include "index.hpp"
+
+#include <algorithm>
+#include <memory>
+
+namespace {
+
+constexpr int TPB = 256;
+
+// Go's math.Log / math.Log2 (go1.12 src/math/log.go, log10.go; FreeBSD e_log.c algorithm),
+// restated for the device.  Same IEEE operation sequence as oracle/oracle.c:orc_go_log2
+// (this file is compiled with -ffp-contract=off), so idf is bit-identical to the oracle's.
+__device__ __forceinline__ double go_log(double x) {
+    const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10;
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                 L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                 L7 = 1.479819860511658591e-01;
+    const double Sqrt2Half = 0.70710678118654752440084436210484903928483593768847;
+    if (x != x || (isinf(x) && x > 0)) return x;
+    if (x < 0) return __builtin_nan("");
+    if (x == 0) return -__builtin_inf();
+    int ki;
+    double f1 = frexp(x, &ki);
+    if (f1 < Sqrt2Half) { f1 *= 2; ki--; }
+    const double f = f1 - 1;
+    const double k = (double)ki;
+    const double s = f / (2 + f);
+    const double s2 = s * s;
+    const double s4 = s2 * s2;
+    const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+__device__ __forceinline__ double go_log2(double x) {
+    const double InvLn2 = 1.44269504088896340735992468100189214;
+    int e;
+    const double frac = frexp(x, &e);
+    if (frac == 0.5) return (double)(e - 1);
+    return go_log(frac) * InvLn2 + (double)e;
+}
+
+__global__ void k_idf(const uint64_t* __restrict__ term_ptr, uint64_t n_terms, double total_docs, float* __restrict__ idf) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_terms) return;
+    const double df = (double)(term_ptr[t + 1] - term_ptr[t]);
+    idf[t] = (float)go_log2(total_docs / df);                       // term_weighting.go:37
+}
+
+// validate: term_ptr non-decreasing, doc ids in range, count adjacent non-ascending pairs
+__global__ void k_check_ptr(const uint64_t* __restrict__ term_ptr, uint64_t n_terms, const uint32_t* __restrict__ post_doc,
+                            unsigned long long* __restrict__ n_boundary_desc, uint32_t* __restrict__ err) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_terms) return;
+    const uint64_t a = term_ptr[t], b = term_ptr[t + 1];
+    if (b < a) { atomicOr(err, 1u); return; }
+    // a legitimate descent can only sit at the start of a non-empty list
+    if (b > a && a > 0 && post_doc[a] <= post_doc[a - 1]) atomicAdd(n_boundary_desc, 1ull);
+}
+__global__ void k_check_docs(const uint32_t* __restrict__ post_doc, uint64_t n_post, uint64_t n_docs,
+                             unsigned long long* __restrict__ n_desc, uint32_t* __restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long local = 0;
+    bool bad = false;
+    for (; i < n_post; i += stride) {
+        const uint32_t d = post_doc[i];
+        if (d >= n_docs) bad = true;
+        if (i > 0 && d <= post_doc[i - 1]) local++;
+    }
+    if (bad) atomicOr(err, 2u);
+    // wave-reduce then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_desc, local);
+}
+
+// One block per chunk of CH consecutive postings.  The block finds the terms its chunk spans
+// with two binary searches, then every posting finds its own term inside that (short) range.
+constexpr int CH = TPB * 16;
+__global__ __launch_bounds__(TPB) void k_weight(const uint64_t* __restrict__ term_ptr, uint64_t n_terms,
+                                                const uint32_t* __restrict__ post_doc, float* __restrict__ post_w,
+                                                const float* __restrict__ idf, uint64_t n_post, double* __restrict__ mag2) {
+    __shared__ uint64_t s_t[2];
+    const uint64_t base = (uint64_t)blockIdx.x * CH;
+    const uint64_t last = min(base + CH, n_post) - 1;
+    if (threadIdx.x < 2) {
+        // largest t with term_ptr[t] <= target
+        const uint64_t target = threadIdx.x == 0 ? base : last;
+        uint64_t lo = 0, hi = n_terms;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (term_ptr[mid] <= target) lo = mid; else hi = mid;
+        }
+        s_t[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const uint64_t t_lo = s_t[0], t_hi = s_t[1];
+#pragma unroll 4
+    for (int j = 0; j < CH / TPB; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        if (i >= n_post) break;
+        uint64_t lo = t_lo, hi = t_hi + 1;   // term_ptr[lo] <= i < term_ptr[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (term_ptr[mid] <= i) lo = mid; else hi = mid;
+        }
+        const float w = post_w[i] * idf[lo];                          // term_weighting.go:42
+        post_w[i] = w;
+        const float sq = w * w;                                       // :44 (float32 product)
+        unsafeAtomicAdd(&mag2[post_doc[i]], (double)sq);              // :44 (float64 accumulate)
+    }
+}
+
+__global__ void k_sqrt(double* __restrict__ v, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = sqrt(v[i]);                                     // term_weighting.go:72
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ss_index_create(ss_ctx* ctx, uint64_t n_docs, uint64_t n_terms, const uint64_t* term_ptr,
+                        const uint32_t* post_doc, const float* post_tf, ss_index** out) {
+    if (!ctx) return SS_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!out) return ctx->fail(SS_ERR_INVALID, "ss_index_create: out is NULL");
+    *out = nullptr;
+    if (!term_ptr) return ctx->fail(SS_ERR_INVALID, "ss_index_create: term_ptr is NULL");
+    if (n_docs == 0 || n_docs >= 0xFFFFFFF0ull || n_terms >= 0xFFFFFFF0ull)
+        return ctx->fail(SS_ERR_INVALID, "ss_index_create: n_docs/n_terms out of range");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    std::unique_ptr<ss_index> idx(new (std::nothrow) ss_index());
+    if (!idx) return ctx->fail(SS_ERR_OOM, "ss_index_create: host OOM");
+    idx->ctx = ctx;
+    idx->n_docs = n_docs;
+    idx->n_terms = n_terms;
+    idx->h_term_ptr.resize(n_terms + 1);
+    SS_HIP(ctx, idx->term_ptr.alloc(n_terms + 1));
+    SS_HIP(ctx, hipMemcpyAsync(idx->term_ptr.p, term_ptr, (n_terms + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipMemcpyAsync(idx->h_term_ptr.data(), idx->term_ptr.p, (n_terms + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (idx->h_term_ptr[0] != 0) return ctx->fail(SS_ERR_INVALID, "ss_index_create: term_ptr[0] != 0");
+    const uint64_t P = idx->h_term_ptr[n_terms];
+    idx->n_post = P;
+    if (P && (!post_doc || !post_tf)) return ctx->fail(SS_ERR_INVALID, "ss_index_create: NULL postings");
+    SS_HIP(ctx, idx->post_doc.alloc(P));
+    SS_HIP(ctx, idx->post_w.alloc(P));
+    SS_HIP(ctx, idx->mag.alloc(n_docs));
+    if (P) {
+        SS_HIP(ctx, hipMemcpyAsync(idx->post_doc.p, post_doc, P * sizeof(uint32_t), hipMemcpyDefault, st));
+        SS_HIP(ctx, hipMemcpyAsync(idx->post_w.p, post_tf, P * sizeof(float), hipMemcpyDefault, st));
+    }
+    SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, n_docs * sizeof(double), st));
+
+    // validation (the scorer relies on strictly ascending doc ids inside a term)
+    ss::DevBuf<unsigned long long> d_cnt;
+    ss::DevBuf<uint32_t> d_err;
+    SS_HIP(ctx, d_cnt.alloc(2));
+    SS_HIP(ctx, d_err.alloc(1));
+    SS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(unsigned long long), st));
+    SS_HIP(ctx, hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), st));
+    if (n_terms) hipLaunchKernelGGL(k_check_ptr, dim3(ss::div_up(n_terms, TPB)), dim3(TPB), 0, st, idx->term_ptr.p, n_terms,
+                                    idx->post_doc.p, d_cnt.p, d_err.p);
+    if (P) hipLaunchKernelGGL(k_check_docs, dim3(std::min<unsigned>(ss::div_up(P, TPB), 16384u)), dim3(TPB), 0, st,
+                              idx->post_doc.p, P, n_docs, d_cnt.p + 1, d_err.p);
+    unsigned long long h_cnt[2] = {0, 0};
+    uint32_t h_err = 0;
+    SS_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    SS_HIP(ctx, hipGetLastError());
+    if (h_err & 1) return ctx->fail(SS_ERR_INVALID, "ss_index_create: term_ptr is not non-decreasing");
+    if (h_err & 2) return ctx->fail(SS_ERR_INVALID, "ss_index_create: posting holds a doc id >= n_docs");
+    if (h_cnt[1] != h_cnt[0])
+        return ctx->fail(SS_ERR_UNSORTED, "ss_index_create: %llu posting(s) not strictly ascending by doc id inside a term",
+                         h_cnt[1] - h_cnt[0]);
+    *out = idx.release();
+    return SS_OK;
+}
+
+int32_t ss_index_destroy(ss_index* idx) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (idx->users > 0) return ctx->fail(SS_ERR_STATE, "ss_index_destroy: index still used by %d scorer(s)", idx->users);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete idx;
+    return SS_OK;
+}
+
+int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double* mag_out, float* idf_out) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t P = idx->n_post, T = idx->n_terms, N = idx->n_docs;
+    ss::DevBuf<float> idf;
+    SS_HIP(ctx, idf.alloc(T));
+    SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[2][0], st));
+    if (T) hipLaunchKernelGGL(k_idf, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p, T, (double)total_docs, idf.p);
+    if (P) hipLaunchKernelGGL(k_weight, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p,
+                              idx->post_w.p, idf.p, P, idx->mag.p);
+    hipLaunchKernelGGL(k_sqrt, dim3(ss::div_up(N, TPB)), dim3(TPB), 0, st, idx->mag.p, N);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[2][1], st));
+    ctx->ev_valid[2] = true;
+    SS_HIP(ctx, hipGetLastError());
+    idx->weighted = true;
+    if (w_out && P) SS_HIP(ctx, hipMemcpyAsync(w_out, idx->post_w.p, P * sizeof(float), hipMemcpyDefault, st));
+    if (mag_out) SS_HIP(ctx, hipMemcpyAsync(mag_out, idx->mag.p, N * sizeof(double), hipMemcpyDefault, st));
+    if (idf_out && T) SS_HIP(ctx, hipMemcpyAsync(idf_out, idf.p, T * sizeof(float), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    return SS_OK;
+}
+
+int32_t ss_index_set_weighted(ss_index* idx, const double* mag) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!mag) return ctx->fail(SS_ERR_INVALID, "ss_index_set_weighted: mag is NULL");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    SS_HIP(ctx, hipMemcpyAsync(idx->mag.p, mag, idx->n_docs * sizeof(double), hipMemcpyDefault, ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    idx->weighted = true;
+    return SS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+"""Thin object wrappers over the C ABI (include/spaghetti_rank.h).
+
+Arrays may be numpy arrays (host) or torch tensors (host or device): the library
+copies with hipMemcpyDefault, so both kinds of pointer are accepted.  Every call
+goes through libspaghetti_rank.so — there is no Python/CPU implementation here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import SsGraphInfo, SsHit, check
+
+HIT_DTYPE = np.dtype([("doc", "<u4"), ("_pad", "<u4"), ("title", "<f8"), ("body", "<f8"),
+                      ("pagerank", "<f8"), ("final", "<f8")])
+
+_NP2T = {"uint64": "int64", "uint32": "int32"}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _as(x, dtype: str):
+    """Contiguous array of the wanted dtype (numpy or torch), no copy when already right.
+    torch has no uint32/uint64 storage: int32/int64 tensors of the same bits are accepted."""
+    if x is None:
+        return None
+    if _is_torch(x):
+        import torch
+        want = getattr(torch, _NP2T.get(dtype, dtype))
+        if x.dtype != want:
+            raise TypeError(f"torch tensor has dtype {x.dtype}, expected {want}")
+        return x.contiguous()
+    return np.ascontiguousarray(x, dtype=np.dtype(dtype))
+
+
+def _ptr(x) -> Optional[int]:
+    if x is None:
+        return None
+    if _is_torch(x):
+        return x.data_ptr()
+    return x.ctypes.data
+
+
+class Context:
+    """One per GPU per process (ss_init)."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.ss_init(device_id, C.byref(h)))
+        self.h = h
+        self.device_id = device_id
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        check(self.lib.ss_set_stream(self.h, C.c_void_p(hip_stream)), self.h)
+
+    def synchronize(self) -> None:
+        check(self.lib.ss_synchronize(self.h), self.h)
+
+    def last_kernel_ms(self, kind: int) -> float:
+        ms = C.c_float(0)
+        check(self.lib.ss_last_kernel_ms(self.h, kind, C.byref(ms)), self.h)
+        return float(ms.value)
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.ss_shutdown(self.h)
+            self.h = None
+
+
+class Graph:
+    """Link graph (ranking/pagerank.go:17-44) in the library's HBM layout."""
+
+    def __init__(self, ctx: Context, n_nodes: int, out_ptr, out_dst, rank: int = 0, world: int = 1):
+        self.ctx = ctx
+        self.n = int(n_nodes)
+        out_ptr = _as(out_ptr, "uint64")
+        out_dst = _as(out_dst, "uint32")
+        self.e = int(out_dst.shape[0]) if out_dst is not None else 0
+        if out_ptr.shape[0] != self.n + 1:
+            raise ValueError("out_ptr must have n_nodes+1 entries")
+        h = C.c_void_p()
+        check(ctx.lib.ss_graph_create(ctx.h, self.n, self.e, _ptr(out_ptr), _ptr(out_dst), rank, world, C.byref(h)), ctx.h)
+        self.h = h
+        self.rank, self.world = rank, world
+
+    def info(self) -> SsGraphInfo:
+        gi = SsGraphInfo()
+        check(self.ctx.lib.ss_graph_get_info(self.h, C.byref(gi)), self.ctx.h)
+        return gi
+
+    def pagerank(self, damping: float, eps: float, n_topic: Sequence[int], max_iter: int = 0):
+        """ss_pagerank_run: -> (rank [K][N] float64, iters [K] int32)."""
+        n_topic = np.ascontiguousarray(np.atleast_1d(n_topic), dtype=np.int32)
+        K = len(n_topic)
+        rank = np.zeros((K, self.n), dtype=np.float64)
+        iters = np.zeros(K, dtype=np.int32)
+        check(self.ctx.lib.ss_pagerank_run(self.h, damping, eps, max_iter, K, _ptr(n_topic), _ptr(rank), _ptr(iters)),
+              self.ctx.h)
+        return rank, iters
+
+    def close(self) -> None:
+        if self.h:
+            self.ctx.lib.ss_graph_destroy(self.h)
+            self.h = None
+
+
+class PageRankState:
+    """Step-wise power iteration (ss_pr_*), used for timing and by the multi-GPU host."""
+
+    def __init__(self, graph: Graph, damping: float, eps: float, n_topic: Sequence[int], max_iter: int = 0):
+        self.g = graph
+        self.ctx = graph.ctx
+        n_topic = np.ascontiguousarray(np.atleast_1d(n_topic), dtype=np.int32)
+        self.k = len(n_topic)
+        h = C.c_void_p()
+        check(self.ctx.lib.ss_pr_create(graph.h, damping, eps, max_iter, self.k, _ptr(n_topic), C.byref(h)), self.ctx.h)
+        self.h = h
+
+    def begin(self) -> None:
+        check(self.ctx.lib.ss_pr_begin(self.h), self.ctx.h)
+
+    def step(self, n_steps: int = 1) -> None:
+        check(self.ctx.lib.ss_pr_step(self.h, n_steps), self.ctx.h)
+
+    def finalize(self) -> None:
+        check(self.ctx.lib.ss_pr_finalize(self.h), self.ctx.h)
+
+    def exchange_buffers(self):
+        """-> (send_ptr, send_bytes, recv_ptr, recv_bytes) device pointers."""
+        sp, rp = C.c_void_p(), C.c_void_p()
+        sb, rb = C.c_uint64(), C.c_uint64()
+        check(self.ctx.lib.ss_pr_exchange_buffers(self.h, C.byref(sp), C.byref(sb), C.byref(rp), C.byref(rb)), self.ctx.h)
+        return sp.value, sb.value, rp.value, rb.value
+
+    def status(self):
+        """-> dict(iters, n_active, sweeps, delta, total); waits for the stream."""
+        iters = np.zeros(self.k, dtype=np.int32)
+        delta = np.zeros(self.k, dtype=np.float64)
+        total = np.zeros(self.k, dtype=np.float64)
+        na, sw = C.c_int32(), C.c_int32()
+        check(self.ctx.lib.ss_pr_status(self.h, _ptr(iters), C.byref(na), C.byref(sw), _ptr(delta), _ptr(total)), self.ctx.h)
+        return {"iters": iters, "n_active": na.value, "sweeps": sw.value, "delta": delta, "total": total}
+
+    def read(self) -> np.ndarray:
+        out = np.zeros((self.k, self.g.n), dtype=np.float64)
+        check(self.ctx.lib.ss_pr_read(self.h, _ptr(out)), self.ctx.h)
+        return out
+
+    def read_local(self):
+        n_rows = int(self.g.info().n_rows_local)
+        ids = np.zeros(n_rows, dtype=np.uint32)
+        out = np.zeros((self.k, n_rows), dtype=np.float64)
+        check(self.ctx.lib.ss_pr_read_local(self.h, _ptr(ids), _ptr(out)), self.ctx.h)
+        return ids, out
+
+    def close(self) -> None:
+        if self.h:
+            self.ctx.lib.ss_pr_destroy(self.h)
+            self.h = None
+
+
+class InvertedIndex:
+    """One inverted table (inv[0] title / inv[1] body) — ss_index_*."""
+
+    def __init__(self, ctx: Context, n_docs: int, term_ptr, post_doc, post_tf):
+        self.ctx = ctx
+        self.n_docs = int(n_docs)
+        term_ptr = _as(term_ptr, "uint64")
+        post_doc = _as(post_doc, "uint32")
+        post_tf = _as(post_tf, "float32")
+        self.n_terms = int(term_ptr.shape[0]) - 1
+        self.n_post = int(post_doc.shape[0])
+        h = C.c_void_p()
+        check(ctx.lib.ss_index_create(ctx.h, self.n_docs, self.n_terms, _ptr(term_ptr), _ptr(post_doc), _ptr(post_tf),
+                                      C.byref(h)), ctx.h)
+        self.h = h
+
+    def tfidf_build(self, total_docs: int, want_w: bool = True, want_mag: bool = True, want_idf: bool = True):
+        """ss_tfidf_build (ranking.UpdateTermWeights): -> (w f32[P] | None, mag f64[N] | None, idf f32[T] | None)."""
+        w = np.zeros(self.n_post, dtype=np.float32) if want_w else None
+        mag = np.zeros(self.n_docs, dtype=np.float64) if want_mag else None
+        idf = np.zeros(self.n_terms, dtype=np.float32) if want_idf else None
+        check(self.ctx.lib.ss_tfidf_build(self.h, int(total_docs), _ptr(w), _ptr(mag), _ptr(idf)), self.ctx.h)
+        return w, mag, idf
+
+    def set_weighted(self, mag) -> None:
+        mag = _as(mag, "float64")
+        check(self.ctx.lib.ss_index_set_weighted(self.h, _ptr(mag)), self.ctx.h)
+
+    def close(self) -> None:
+        if self.h:
+            check(self.ctx.lib.ss_index_destroy(self.h), self.ctx.h)
+            self.h = None
+
+
+class Scorer:
+    """Batched OR-query cosine scorer + PageRank blend + top-k (ss_score_topk)."""
+
+    def __init__(self, ctx: Context, title: InvertedIndex, body: InvertedIndex):
+        self.ctx = ctx
+        self.title, self.body = title, body
+        h = C.c_void_p()
+        check(ctx.lib.ss_scorer_create(ctx.h, title.h, body.h, C.byref(h)), ctx.h)
+        self.h = h
+        self.k_topics = 0
+
+    def set_prior(self, rank) -> None:
+        """rank [K][n_docs] topic-major (ss_pagerank_run layout) or None to clear."""
+        if rank is None:
+            check(self.ctx.lib.ss_scorer_set_prior(self.h, 0, None), self.ctx.h)
+            self.k_topics = 0
+            return
+        rank = _as(rank, "float64")
+        self.k_topics = int(rank.shape[0])
+        check(self.ctx.lib.ss_scorer_set_prior(self.h, self.k_topics, _ptr(rank)), self.ctx.h)
+
+    def score_topk(self, q_ptr, q_terms, k: int, query_len=None, topic_probs=None):
+        """-> (hits [n_q][k] HIT_DTYPE, n_hits [n_q] int32)."""
+        q_ptr = _as(q_ptr, "uint32")
+        q_terms = _as(q_terms, "uint32")
+        query_len = _as(query_len, "int32")
+        topic_probs = _as(topic_probs, "float64")
+        n_q = int(q_ptr.shape[0]) - 1
+        hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
+        n_hits = np.zeros(n_q, dtype=np.int32)
+        check(self.ctx.lib.ss_score_topk(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(query_len), _ptr(topic_probs), k,
+                                         hits.ctypes.data, _ptr(n_hits)), self.ctx.h)
+        return hits, n_hits
+
+    def close(self) -> None:
+        if self.h:
+            self.ctx.lib.ss_scorer_destroy(self.h)
+            self.h = None
+
+
+__all__ = ["Context", "Graph", "PageRankState", "InvertedIndex", "Scorer", "HIT_DTYPE", "SsHit"]

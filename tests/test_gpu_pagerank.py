@@ -1,0 +1,175 @@
+"""GPU parity: HIP PageRank (through the C ABI) vs the CPU oracle.
+
+Reference: ranking/pagerank.go:14-145.  Gates: ranks within 1e-6
+relative on x AND on the inherited part y = x*S-(1-d); iteration counts equal.
+In practice fp64 agrees to ~1e-13; the tests assert much tighter than the gate.
+"""
+import numpy as np
+import pytest
+
+from spaghettisearch_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+D = 0.75
+
+
+def inherited(x, total, d=D):
+    return x * total - (1.0 - d)
+
+
+def run_both(ss_ctx, oracle, n, out_ptr, out_dst, n_topic, eps, max_iter=0, d=D):
+    from spaghettisearch_amd import engine
+    g = engine.Graph(ss_ctx, n, out_ptr, out_dst)
+    try:
+        rank, iters = g.pagerank(d, eps, n_topic, max_iter=max_iter)
+    finally:
+        g.close()
+    ref, ref_iters = oracle.pagerank(n, out_ptr, out_dst, d, eps, n_topic, max_iter=max_iter)
+    return rank, iters, ref, ref_iters
+
+
+def csr(n, edges):
+    edges = sorted(edges)
+    ptr = np.zeros(n + 1, dtype=np.uint64)
+    for s, _ in edges:
+        ptr[s + 1] += 1
+    return np.cumsum(ptr).astype(np.uint64), np.array([d for _, d in edges], dtype=np.uint32)
+
+
+def test_kat_graph(ss_ctx, oracle):
+    # the hand-worked 5-node graph of tests/test_oracle_kat.py (self-loop, frontier child, n_init != N)
+    ptr, dst = csr(5, [(0, 1), (0, 2), (1, 2), (2, 0), (2, 3), (4, 4)])
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 5, ptr, dst, [4], 0.0, max_iter=1)
+    np.testing.assert_allclose(rank[0], [19 / 58, 19 / 58, 25 / 58, 19 / 58, 22 / 58], rtol=1e-15)
+    assert iters.tolist() == [1]
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 5, ptr, dst, [4, 5, 1000], 1e-12)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-13)
+
+
+@pytest.mark.parametrize("k_topics", [1, 2, 3, 4, 8, 16])
+def test_rmat_small_all_group_widths(ss_ctx, oracle, k_topics):
+    n, e = 20000, 100000
+    ptr, dst = synth.rmat_graph(n, e, seed=100 + k_topics)
+    n_topic = synth.topic_sizes(n, k_topics)
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-9)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-12)
+
+
+def test_more_topics_than_one_state(ss_ctx, oracle):
+    # K > 16 is run as successive groups of 16 (topics are independent, pagerank.go:54-63)
+    n, e = 3000, 12000
+    ptr, dst = synth.rmat_graph(n, e, seed=5)
+    n_topic = synth.topic_sizes(n, 19)
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-12)
+
+
+def test_inherited_part_and_fixed_iterations(ss_ctx, oracle):
+    # ranks are nearly uniform at scale: compare the inherited part too
+    n, e = 200000, 1000000
+    ptr, dst = synth.rmat_graph(n, e, seed=42)
+    from spaghettisearch_amd import engine
+    g = engine.Graph(ss_ctx, n, ptr, dst)
+    st = engine.PageRankState(g, D, -1.0, [n], max_iter=0)
+    st.begin()
+    st.step(6)
+    s = st.status()
+    x = st.read()[0]
+    st.close()
+    g.close()
+    assert s["sweeps"] == 6 and s["n_active"] == 1 and s["iters"].tolist() == [6]
+    ref, it, change, total = oracle.pagerank_topic_detail(n, ptr, dst, D, -1.0, n, max_iter=6)
+    assert it == 6
+    np.testing.assert_allclose(x, ref, rtol=1e-12)
+    assert s["delta"][0] == pytest.approx(change, rel=1e-9)
+    # y = x*S - (1-d) with the normaliser of the last sweep
+    y, y_ref = inherited(x, total), inherited(ref, total)
+    nz = y_ref > 1e-12
+    np.testing.assert_allclose(y[nz], y_ref[nz], rtol=1e-6)
+    np.testing.assert_allclose(y, y_ref, atol=1e-9 * y_ref.max())
+
+
+def test_skewed_rows_block_per_segment(ss_ctx, oracle):
+    # one hub with ~60k in-edges (multi-block row), a few medium rows, many empty rows
+    rng = np.random.default_rng(3)
+    n = 70000
+    edges = {(int(s), 0) for s in range(1, 60001)}
+    edges |= {(int(s), 1) for s in rng.choice(n, 3000, replace=False)}
+    edges |= {(int(s), 2) for s in rng.choice(n, 300, replace=False)}
+    edges |= {(int(a), int(b)) for a, b in rng.integers(0, n, size=(50000, 2))}
+    ptr, dst = csr(n, list(edges))
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, [n, 7], 1e-10)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-12)
+    rank16, iters16, ref16, ref_iters16 = run_both(ss_ctx, oracle, n, ptr, dst, synth.topic_sizes(n, 16), 1e-10)
+    assert iters16.tolist() == ref_iters16.tolist()
+    np.testing.assert_allclose(rank16, ref16, rtol=1e-12)
+
+
+def test_edge_cases(ss_ctx, oracle):
+    # no edges at all: every node dangling (pagerank.go:131-134)
+    ptr = np.zeros(11, dtype=np.uint64)
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 10, ptr, np.zeros(0, np.uint32), [10, 3], 1e-12)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-14)
+    # single node with a self loop
+    ptr, dst = csr(1, [(0, 0)])
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 1, ptr, dst, [1], 1e-12)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-14)
+    # complete graph on 40 nodes
+    ptr, dst = csr(40, [(a, b) for a in range(40) for b in range(40)])
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 40, ptr, dst, [40], 1e-13)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-13)
+    # max_iter cut
+    ptr, dst = synth.rmat_graph(1000, 5000, seed=1)
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 1000, ptr, dst, [1000, 10], 1e-30, max_iter=3)
+    assert iters.tolist() == [3, 3] == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-13)
+
+
+def test_bad_input_is_rejected(ss_ctx):
+    from spaghettisearch_amd import SpaghettiError, engine
+    ptr = np.array([0, 1, 2], dtype=np.uint64)
+    with pytest.raises(SpaghettiError):
+        engine.Graph(ss_ctx, 2, ptr, np.array([0, 5], dtype=np.uint32))      # child id out of range
+    with pytest.raises(SpaghettiError):
+        engine.Graph(ss_ctx, 2, np.array([0, 2, 1], dtype=np.uint64), np.array([0, 1], dtype=np.uint32))
+
+
+def test_sharded_layout_single_process(ss_ctx, oracle):
+    """world=2/4 shards driven from ONE process: the host plays the all-gather.
+    Checks the doc-range sharding + exchange protocol of SURVEY.md §8e on the real kernels."""
+    import torch
+    from spaghettisearch_amd import engine
+    from spaghettisearch_amd.sharding import LocalExchange, run_sharded
+    n, e = 30000, 160000
+    ptr, dst = synth.rmat_graph(n, e, seed=77)
+    n_topic = synth.topic_sizes(n, 5)
+    ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-9, n_topic)
+    stream = torch.cuda.Stream()          # library kernels and the torch copies share one stream
+    ss_ctx.set_stream(stream.cuda_stream)
+    try:
+        with torch.cuda.stream(stream):
+            for world in (2, 4):
+                graphs = [engine.Graph(ss_ctx, n, ptr, dst, rank=r, world=world) for r in range(world)]
+                infos = [g.info() for g in graphs]
+                assert sum(i.n_rows_local for i in infos) == n
+                assert sum(i.n_edges_local for i in infos) == e
+                assert max(i.n_edges_local for i in infos) < 1.2 * e / world   # edge-balanced shards
+                states = [engine.PageRankState(g, D, 1e-9, n_topic) for g in graphs]
+                rank, iters = run_sharded(states, LocalExchange(states, torch.device("cuda:0")))
+                for s in states:
+                    s.close()
+                for g in graphs:
+                    g.close()
+                assert iters.tolist() == ref_iters.tolist()
+                np.testing.assert_allclose(rank, ref, rtol=1e-12)
+    finally:
+        torch.cuda.synchronize()
+        ss_ctx.set_stream(None)

@@ -1,0 +1,74 @@
+"""GPU parity: HIP TF-IDF weight / magnitude build vs the CPU oracle.
+
+Reference: ranking/term_weighting.go:10-57 (+ sqrt at :72).  idf and the float32
+weights must be BIT-EXACT (same IEEE operation sequence as the oracle, built with
+-ffp-contract=off); magnitudes are float64 sums in a different order: 1e-12.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from spaghettisearch_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def build_both(ss_ctx, oracle, n_docs, term_ptr, post_doc, tf, total_docs):
+    from spaghettisearch_amd import engine
+    idx = engine.InvertedIndex(ss_ctx, n_docs, term_ptr, post_doc, tf)
+    try:
+        w, mag, idf = idx.tfidf_build(total_docs)
+    finally:
+        idx.close()
+    w_ref, mag_ref, idf_ref = oracle.tfidf(term_ptr, post_doc, tf, total_docs, n_docs)
+    return (w, mag, idf), (w_ref, mag_ref, idf_ref)
+
+
+def test_kat(ss_ctx, oracle):
+    # the hand-worked table of tests/test_oracle_kat.py::test_tfidf_by_hand (N=8 != 4 indexed docs, Q7)
+    term_ptr = np.array([0, 2, 6, 9, 9], dtype=np.uint64)
+    post_doc = np.array([0, 1, 0, 1, 2, 3, 1, 2, 3], dtype=np.uint32)
+    tf = np.array([.5, 1, .25, .25, .25, .25, 1, .5, .125], dtype=np.float32)
+    (w, mag, idf), (w_ref, mag_ref, idf_ref) = build_both(ss_ctx, oracle, 4, term_ptr, post_doc, tf, 8)
+    assert idf[0] == 2.0 and idf[1] == 1.0 and idf[2] == np.float32(math.log2(8 / 3)) and np.isinf(idf[3])
+    assert np.array_equal(w, w_ref)
+    np.testing.assert_allclose(mag, mag_ref, rtol=1e-15)
+
+
+@pytest.mark.parametrize("n_docs,n_terms,n_post,total", [(500, 200, 5000, 700), (20000, 5000, 300000, 20000),
+                                                          (100000, 30000, 2000000, 131072)])
+def test_zipf_index(ss_ctx, oracle, n_docs, n_terms, n_post, total):
+    tp, pd, tf = synth.zipf_index(n_docs, n_terms, n_post, seed=n_terms)
+    (w, mag, idf), (w_ref, mag_ref, idf_ref) = build_both(ss_ctx, oracle, n_docs, tp, pd, tf, total)
+    live = np.diff(tp.astype(np.int64)) > 0
+    assert np.array_equal(idf[live], idf_ref[live])          # bit-exact float32 idf
+    assert np.array_equal(w, w_ref)                          # bit-exact float32 weights
+    np.testing.assert_allclose(mag, mag_ref, rtol=1e-12)
+
+
+def test_not_idempotent_like_the_reference(ss_ctx, oracle):
+    # UpdateTermWeights multiplies the stored weight in place (term_weighting.go:42)
+    from spaghettisearch_amd import engine
+    tp, pd, tf = synth.zipf_index(300, 50, 1500, seed=2)
+    idx = engine.InvertedIndex(ss_ctx, 300, tp, pd, tf)
+    w1, _, idf = idx.tfidf_build(300)
+    w2, mag2, _ = idx.tfidf_build(300)
+    idx.close()
+    per_post_idf = np.repeat(idf, np.diff(tp.astype(np.int64)))
+    assert np.array_equal(w2, (w1 * per_post_idf).astype(np.float32))
+
+
+def test_rejects_unsorted_and_out_of_range(ss_ctx):
+    from spaghettisearch_amd import SpaghettiError, engine
+    tp = np.array([0, 3, 5], dtype=np.uint64)
+    ok_docs = np.array([0, 2, 4, 1, 3], dtype=np.uint32)    # descent only at the term boundary: fine
+    engine.InvertedIndex(ss_ctx, 5, tp, ok_docs, np.ones(5, np.float32)).close()
+    with pytest.raises(SpaghettiError) as ei:
+        engine.InvertedIndex(ss_ctx, 5, tp, np.array([0, 4, 2, 1, 3], dtype=np.uint32), np.ones(5, np.float32))
+    assert ei.value.code == 5
+    with pytest.raises(SpaghettiError) as ei:
+        engine.InvertedIndex(ss_ctx, 5, tp, np.array([0, 2, 2, 1, 3], dtype=np.uint32), np.ones(5, np.float32))
+    assert ei.value.code == 5                                 # duplicate doc inside a term
+    with pytest.raises(SpaghettiError):
+        engine.InvertedIndex(ss_ctx, 5, tp, np.array([0, 2, 9, 1, 3], dtype=np.uint32), np.ones(5, np.float32))

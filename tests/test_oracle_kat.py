@@ -1,0 +1,302 @@
+"""Known-answer tests that pin the CPU oracle (oracle/oracle.c) to the reference Go source.
+
+The reference ships no tests or golden vectors for this path
+and cannot be built here, so PARITY IS UNPINNED by the reference itself.  These
+KATs are hand-derived from the Go code (file:line cited per test) and cover the
+quirk list Q1-Q11 of SURVEY.md §7; the second, independently written numpy
+restatement (oracle/oracle_np.py) and an exact-rational recomputation must agree.
+"""
+import math
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+
+
+def csr(n, edges):
+    edges = sorted(edges)
+    ptr = np.zeros(n + 1, dtype=np.uint64)
+    for s, _ in edges:
+        ptr[s + 1] += 1
+    ptr = np.cumsum(ptr).astype(np.uint64)
+    dst = np.array([d for _, d in edges], dtype=np.uint32)
+    return ptr, dst
+
+
+# 0->{1,2}, 1->{2}, 2->{0,3}, 4->{4} (self-loop, Q5); node 3 is an uncrawled frontier child (Q1)
+KAT_EDGES = [(0, 1), (0, 2), (1, 2), (2, 0), (2, 3), (4, 4)]
+
+
+def exact_pagerank(n, edges, d, n_init, iters):
+    """pagerank.go:93-119 in exact rational arithmetic."""
+    d = Fraction(d)
+    tele = 1 - d
+    children = {p: [c for (s, c) in edges if s == p] for p in range(n)}
+    last = [Fraction(1, n_init)] * n
+    total = None
+    for it in range(1, iters + 1):
+        cur = [Fraction(1, n_init)] * n if it == 1 else [Fraction(0)] * n
+        total = Fraction(0)
+        for p in range(n):
+            if not children[p]:
+                continue
+            w = d * last[p] / len(children[p])
+            total += w
+            for c in children[p]:
+                cur[c] += w
+        total += tele * n
+        cur = [(v + tele) / total for v in cur]
+        change = sum(abs(a - b) for a, b in zip(cur, last))
+        last = cur
+    return last, total, change
+
+
+def test_pagerank_first_iteration_by_hand(oracle):
+    # d=0.75, n_init=4 != N=5 (pagerank.go:61,104): worked on paper —
+    # w0=w2=0.09375, w1=w4=0.1875, total=0.5625+0.25*5=1.8125,
+    # cur = 0.25 + inherited, then (cur+0.25)/total
+    ptr, dst = csr(5, KAT_EDGES)
+    rank, iters, change, total = oracle.pagerank_topic_detail(5, ptr, dst, 0.75, 0.0, 4, max_iter=1)
+    assert iters == 1
+    assert total == 1.8125
+    expect = [19 / 58, 19 / 58, 25 / 58, 19 / 58, 22 / 58]
+    np.testing.assert_allclose(rank, expect, rtol=1e-15)
+    assert change == pytest.approx(3 * (19 / 58 - 0.25) + (25 / 58 - 0.25) + (22 / 58 - 0.25), rel=1e-14)
+    # Q3: ranks are NOT a probability vector
+    assert abs(rank.sum() - 1.0) > 0.5
+
+
+@pytest.mark.parametrize("n_init", [5, 4, 1, 1000])
+def test_pagerank_matches_exact_rationals(oracle, n_init):
+    ptr, dst = csr(5, KAT_EDGES)
+    for iters in (1, 2, 3, 7):
+        ex, ex_total, ex_change = exact_pagerank(5, KAT_EDGES, Fraction(3, 4), n_init, iters)
+        rank, it, change, total = oracle.pagerank_topic_detail(5, ptr, dst, 0.75, 0.0, n_init, max_iter=iters)
+        assert it == iters
+        np.testing.assert_allclose(rank, [float(v) for v in ex], rtol=1e-14)
+        assert total == pytest.approx(float(ex_total), rel=1e-14)
+        assert change == pytest.approx(float(ex_change), rel=1e-12, abs=1e-16)
+
+
+def test_pagerank_random_graph_exact(oracle):
+    rng = np.random.default_rng(7)
+    n = 12
+    edges = sorted({(int(a), int(b)) for a, b in rng.integers(0, n, size=(30, 2)) if a not in (3, 9)})
+    ptr, dst = csr(n, edges)
+    ex, _, _ = exact_pagerank(n, edges, Fraction(17, 20), 12, 5)
+    rank, _, _, _ = oracle.pagerank_topic_detail(n, ptr, dst, 0.85, 0.0, 12, max_iter=5)
+    np.testing.assert_allclose(rank, [float(v) for v in ex], rtol=1e-13)
+
+
+def test_pagerank_stop_rule(oracle):
+    # Q6: first iteration always runs; loop continues while change > eps (pagerank.go:93)
+    ptr, dst = csr(5, KAT_EDGES)
+    _, iters, change, _ = oracle.pagerank_topic_detail(5, ptr, dst, 0.75, 1e9, 4)
+    assert iters == 1 and change < 1e9
+    r, iters, change, _ = oracle.pagerank_topic_detail(5, ptr, dst, 0.75, 1e-12, 4)
+    assert iters > 5 and change <= 1e-12
+    # one iteration less must not have met the criterion
+    _, _, change_prev, _ = oracle.pagerank_topic_detail(5, ptr, dst, 0.75, 0.0, 4, max_iter=iters - 1)
+    assert change_prev > 1e-12
+
+
+def test_pagerank_topics_share_fixed_point(oracle):
+    # Q2: topics differ only by the initial value 1/n (pagerank.go:61,104-105)
+    ptr, dst = csr(5, KAT_EDGES)
+    rank, iters = oracle.pagerank(5, ptr, dst, 0.75, 1e-14, [5, 2, 1000])
+    np.testing.assert_allclose(rank[1], rank[0], rtol=1e-11)
+    np.testing.assert_allclose(rank[2], rank[0], rtol=1e-11)
+    assert len(set(iters.tolist())) >= 1
+    # after ONE iteration they differ
+    r1, _ = oracle.pagerank(5, ptr, dst, 0.75, 0.0, [5, 2], max_iter=1)
+    assert np.abs(r1[0] - r1[1]).max() > 1e-3
+
+
+def test_pagerank_dangling_mass_dropped(oracle):
+    # Q5: a node without children passes nothing on and is not in `total` (pagerank.go:131-137)
+    ptr, dst = csr(3, [(0, 1)])           # 1 and 2 dangling
+    rank, _, _, total = oracle.pagerank_topic_detail(3, ptr, dst, 0.5, 0.0, 3, max_iter=1)
+    w0 = 0.5 * (1 / 3) / 1
+    assert total == pytest.approx(w0 + 0.5 * 3, rel=1e-15)
+    np.testing.assert_allclose(rank, [(1 / 3 + 0.5) / total, (1 / 3 + w0 + 0.5) / total, (1 / 3 + 0.5) / total], rtol=1e-15)
+
+
+def test_pagerank_two_restatements_agree(oracle):
+    from spaghettisearch_amd import synth
+    ptr, dst = synth.rmat_graph(3000, 14000, seed=3)
+    a, ia = oracle.pagerank(3000, ptr, dst, 0.75, 1e-10, [3000, 1500, 17])
+    b, ib = onp.pagerank(3000, ptr, dst, 0.75, 1e-10, [3000, 1500, 17])
+    assert ia.tolist() == ib.tolist()
+    np.testing.assert_allclose(a, b, rtol=1e-12)
+    # inherited part y = x*S-(1-d) is where the information is (SURVEY.md §7 hard parts)
+    c, ic = oracle.pagerank(3000, ptr, dst, 0.75, 1e-10, [3000], hashed=True)
+    assert ic[0] == ia[0]
+    np.testing.assert_allclose(c[0], a[0], rtol=1e-13)
+
+
+def test_go_log2(oracle):
+    # log10.go log2(): exact powers of two are exact
+    for e in range(-20, 40):
+        assert oracle.go_log2(2.0 ** e) == float(e)
+    rng = np.random.default_rng(0)
+    for x in rng.uniform(1.0, 1e7, size=2000):
+        assert abs(oracle.go_log2(x) - math.log2(x)) <= 4e-15 * max(1.0, abs(math.log2(x)))
+    assert oracle.go_log2(float("inf")) == float("inf")
+    assert math.isnan(oracle.go_log(-1.0))
+    assert oracle.go_log(0.0) == float("-inf")
+
+
+def test_tfidf_by_hand(oracle):
+    # term_weighting.go:37-44, N = 8 PageRank nodes (Q7: N is NOT the number of indexed docs = 4)
+    #   term0: df=2 -> idf=log2(4)=2      docs 0 (tf .5), 1 (tf 1)
+    #   term1: df=8?? cannot exceed docs; use df=4 -> idf=log2(2)=1   docs 0,1,2,3 (tf .25 each)
+    #   term2: df=3 -> idf=float32(log2(8/3))                          docs 1,2,3 (tf 1, .5, .125)
+    #   term3: df=0 (empty row)
+    term_ptr = np.array([0, 2, 6, 9, 9], dtype=np.uint64)
+    post_doc = np.array([0, 1, 0, 1, 2, 3, 1, 2, 3], dtype=np.uint32)
+    tf = np.array([.5, 1, .25, .25, .25, .25, 1, .5, .125], dtype=np.float32)
+    w, mag, idf = oracle.tfidf(term_ptr, post_doc, tf, 8, 4)
+    idf2 = np.float32(math.log2(8 / 3))
+    assert idf[0] == 2.0 and idf[1] == 1.0 and idf[2] == idf2 and np.isinf(idf[3])
+    exp_w = np.array([1.0, 2.0, .25, .25, .25, .25, idf2, np.float32(.5) * idf2, np.float32(.125) * idf2], dtype=np.float32)
+    assert np.array_equal(w, exp_w)
+
+    def sq(v):
+        return float(np.float32(v) * np.float32(v))   # float32 product, then widened (:44)
+    exp_mag = [math.sqrt(sq(1.0) + sq(.25)),
+               math.sqrt(sq(2.0) + sq(.25) + sq(exp_w[6])),
+               math.sqrt(sq(.25) + sq(exp_w[7])),
+               math.sqrt(sq(.25) + sq(exp_w[8]))]
+    np.testing.assert_allclose(mag, exp_mag, rtol=1e-15)
+    # second restatement
+    w2, mag2, idf2v = onp.tfidf(term_ptr, post_doc, tf, 8, 4)
+    assert np.array_equal(w, w2)
+    np.testing.assert_allclose(mag, mag2, rtol=1e-15)
+
+
+def _tiny_index():
+    # 5 docs, 3 terms. body and title tables (already weighted).
+    b_ptr = np.array([0, 3, 5, 6], dtype=np.uint64)
+    b_doc = np.array([0, 1, 2, 1, 3, 4], dtype=np.uint32)
+    b_w = np.array([1.0, 2.0, 0.5, 4.0, 1.0, 3.0], dtype=np.float32)
+    t_ptr = np.array([0, 1, 2, 2], dtype=np.uint64)
+    t_doc = np.array([1, 3], dtype=np.uint32)
+    t_w = np.array([8.0, 2.0], dtype=np.float32)
+    mag_b = np.array([2.0, 4.0, 0.0, 1.0, 0.0], dtype=np.float64)   # doc 2,4: missing key -> 0 (Q8)
+    mag_t = np.array([0.0, 2.0, 0.0, 4.0, 0.0], dtype=np.float64)
+    return (t_ptr, t_doc, t_w), (b_ptr, b_doc, b_w), mag_t, mag_b
+
+
+def test_scoring_by_hand(oracle):
+    title, body, mag_t, mag_b = _tiny_index()
+    # query [0, 1]: qmag = sqrt(2)
+    hits, n_cand = oracle.score_topk(5, title, body, mag_t, mag_b, [0, 1], k=10)
+    q = math.sqrt(2.0)
+    exp = {
+        0: (0.0, 1.0 / (2.0 * q)),                       # title 0/0 -> NaN -> 0 (get_metadata.go:64-66)
+        1: (8.0 / (2.0 * q), (2.0 + 4.0) / (4.0 * q)),   # OR: body weights of both terms summed (:176-182)
+        2: (0.0, math.inf),                              # 0.5/0 = +Inf stays (Q8)
+        3: (2.0 / (4.0 * q), 1.0 / (1.0 * q)),
+    }
+    assert n_cand == 4
+    got = {int(h["doc"]): h for h in hits}
+    assert set(got) == set(exp)
+    for doc, (t, b) in exp.items():
+        assert got[doc]["title"] == pytest.approx(t, rel=1e-15)
+        assert got[doc]["body"] == pytest.approx(b, rel=1e-15) or (math.isinf(b) and math.isinf(got[doc]["body"]))
+        f = (0.33 * 0.0 + 0.38 * t + 0.29 * b) * 100.0
+        assert got[doc]["final"] == f or (math.isinf(f) and math.isinf(got[doc]["final"]))
+        assert got[doc]["pagerank"] == 0.0               # Q9: nil topicProbs
+    # descending FinalRank (util.go:48-54)
+    assert [int(h["doc"]) for h in hits] == [2, 1, 3, 0]
+
+
+def test_scoring_duplicates_unknown_and_cut(oracle):
+    title, body, mag_t, mag_b = _tiny_index()
+    # duplicate token counts twice (main_retrieve.go:29-36, Q8); qmag uses the token count
+    h2, _ = oracle.score_topk(5, title, body, mag_t, mag_b, [0, 0], k=10)
+    h1, _ = oracle.score_topk(5, title, body, mag_t, mag_b, [0], k=10)
+    g1 = {int(h["doc"]): h for h in h1}
+    g2 = {int(h["doc"]): h for h in h2}
+    for doc in (0, 1):
+        assert g2[doc]["body"] == pytest.approx(2 * g1[doc]["body"] / math.sqrt(2.0), rel=1e-15)
+    # unknown term (ErrKeyNotFound, main_retrieve.go:193,218) contributes nothing but still counts in qmag
+    h3, _ = oracle.score_topk(5, title, body, mag_t, mag_b, [0, 0xFFFFFFFF], k=10)
+    g3 = {int(h["doc"]): h for h in h3}
+    assert g3[0]["body"] == pytest.approx(g1[0]["body"] / math.sqrt(2.0), rel=1e-15)
+    # cut to k (main_retrieve.go:99-103)
+    hk, n_cand = oracle.score_topk(5, title, body, mag_t, mag_b, [0, 1], k=2)
+    assert len(hk) == 2 and n_cand == 4 and [int(h["doc"]) for h in hk] == [2, 1]
+    # query_len = len(query tokens)+len(phrase tokens) (main_retrieve.go:90)
+    h4, _ = oracle.score_topk(5, title, body, mag_t, mag_b, [0], k=10, query_len=4)
+    g4 = {int(h["doc"]): h for h in h4}
+    assert g4[0]["body"] == pytest.approx(g1[0]["body"] / 2.0, rel=1e-15)
+
+
+def test_scoring_ties_and_prior(oracle):
+    # Q10: equal FinalRank -> ascending doc id (fixed linearisation)
+    b_ptr = np.array([0, 4], dtype=np.uint64)
+    b_doc = np.array([0, 1, 2, 3], dtype=np.uint32)
+    b_w = np.array([1, 1, 2, 1], dtype=np.float32)
+    t_ptr = np.array([0, 0], dtype=np.uint64)
+    empty_title = (t_ptr, np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    mag = np.ones(4)
+    hits, _ = oracle.score_topk(4, empty_title, (b_ptr, b_doc, b_w), mag, mag, [0], k=4)
+    assert [int(h["doc"]) for h in hits] == [2, 0, 1, 3]
+    # Q9: non-nil topicProbs: sqd = sum_t p_t*PR[doc][t], weight 0.33 (get_metadata.go:39-42,69)
+    prior = np.array([[0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [10.0, 20.0]])
+    probs = np.array([0.25, 0.5])
+    hits, _ = oracle.score_topk(4, empty_title, (b_ptr, b_doc, b_w), mag, mag, [0], k=4, prior=prior, topic_probs=probs)
+    assert int(hits[0]["doc"]) == 3
+    assert hits[0]["pagerank"] == 0.25 * 10 + 0.5 * 20
+    assert hits[0]["final"] == (0.33 * 12.5 + 0.38 * 0.0 + 0.29 * 1.0) * 100.0
+    # second restatement agrees
+    d, T, B, S, F = onp.score_topk(4, empty_title, (b_ptr, b_doc, b_w), mag, mag, [0], 4, prior=prior, topic_probs=probs)
+    assert d.tolist() == [int(h["doc"]) for h in hits]
+    np.testing.assert_array_equal(F, hits["final"])
+
+
+def test_scoring_restatements_agree_random(oracle):
+    from spaghettisearch_amd import synth
+    n_docs = 400
+    tp, pd, tf = synth.zipf_index(n_docs, 120, 4000, seed=5)
+    tp2, pd2, tf2 = synth.zipf_index(n_docs, 120, 600, seed=6)
+    wb, mb, _ = oracle.tfidf(tp, pd, tf, 500, n_docs)
+    wt, mt, _ = oracle.tfidf(tp2, pd2, tf2, 500, n_docs)
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        q = rng.integers(0, 120, size=rng.integers(1, 5))
+        hits, _ = oracle.score_topk(n_docs, (tp2, pd2, wt), (tp, pd, wb), mt, mb, q, k=15)
+        d, T, B, S, F = onp.score_topk(n_docs, (tp2, pd2, wt), (tp, pd, wb), mt, mb, q, 15)
+        assert d.tolist() == [int(h["doc"]) for h in hits]
+        np.testing.assert_array_equal(F, hits["final"])
+        np.testing.assert_array_equal(T, hits["title"])
+
+
+def test_phrase_by_hand(oracle):
+    # phrase.go:53-109: doc must hold every phrase term; positions shifted by the term's index
+    # (phrase.go:145) and intersected (util.go:179-203); weights summed in float32 (phrase.go:59).
+    # body: term0 in docs 0 (pos 3,7), 1 (pos 1); term1 in docs 0 (pos 8), 1 (pos 5), 2 (pos 0)
+    b_ptr = np.array([0, 2, 5], dtype=np.uint64)
+    b_doc = np.array([0, 1, 0, 1, 2], dtype=np.uint32)
+    b_w = np.array([.5, .25, 1.5, .75, 2.0], dtype=np.float32)
+    bpp = np.array([0, 2, 3, 4, 5, 6], dtype=np.uint64)
+    bp = np.array([3, 7, 1, 8, 5, 0], dtype=np.float32)
+    # title: term0 in doc 1 (pos -100 anchor), term1 in doc 1 (pos -99 -> shifted -100: matches!)
+    t_ptr = np.array([0, 1, 2], dtype=np.uint64)
+    t_doc = np.array([1, 1], dtype=np.uint32)
+    t_w = np.array([4.0, 8.0], dtype=np.float32)
+    tpp = np.array([0, 1, 2], dtype=np.uint64)
+    tp = np.array([-100, -99], dtype=np.float32)
+    docs, ot, ob, fl = oracle.phrase((t_ptr, t_doc, t_w), (b_ptr, b_doc, b_w), (tpp, tp), (bpp, bp), [0, 1])
+    # doc0: body positions {3,7} vs {8-1=7} -> match, sum .5+1.5; no title
+    # doc1: body {1} vs {4} -> none; title {-100} vs {-100} -> match, sum 12
+    # doc2: lacks term0 -> dropped (phrase.go:63)
+    assert docs.tolist() == [0, 1]
+    assert fl.tolist() == [2, 1]
+    assert ob[0] == np.float32(2.0) and ot[1] == np.float32(12.0)
+    # single-term phrase: any position list non-empty matches
+    docs, ot, ob, fl = oracle.phrase((t_ptr, t_doc, t_w), (b_ptr, b_doc, b_w), (tpp, tp), (bpp, bp), [1])
+    assert docs.tolist() == [0, 1, 2] and fl.tolist() == [2, 3, 2]
