@@ -86,6 +86,15 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C spaghettisearch_amd/csrc). There is no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.
+    # If this library pulled in /opt/rocm's copy first, a later `import torch` would bring up a
+    # second runtime in the same process ("no ROCm-capable device"), and torch streams / device
+    # pointers could not be shared with the library.  Importing torch first makes the dynamic
+    # loader resolve our libamdhip64.so.7 dependency to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol

@@ -1,0 +1,210 @@
+"""GPU parity: HIP cosine scorer + PageRank blend + top-k (through the C ABI) vs the CPU oracle.
+
+Reference: retrieval/main_retrieve.go:50-103, get_metadata.go:31-69, util.go:48-54.
+Gate: top-k doc ids identical (ties by ascending doc id, Q10); scores within 1e-6
+relative.  float32 weights summed in float64 are exact and the
+library is built without FMA contraction, so the tests assert BIT-EXACT scores.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from spaghettisearch_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make_scorer(ss_ctx, n_docs, title, body, mag_t, mag_b):
+    from spaghettisearch_amd import engine
+    ti = engine.InvertedIndex(ss_ctx, n_docs, *title)
+    bi = engine.InvertedIndex(ss_ctx, n_docs, *body)
+    ti.set_weighted(mag_t)
+    bi.set_weighted(mag_b)
+    return engine.Scorer(ss_ctx, ti, bi), ti, bi
+
+
+def close_all(sc, ti, bi):
+    sc.close()
+    ti.close()
+    bi.close()
+
+
+def assert_same_hits(hits, n_hits, ref, ref_n, exact=True):
+    assert n_hits.tolist() == ref_n.tolist()
+    for q in range(len(n_hits)):
+        n = int(n_hits[q])
+        assert hits["doc"][q, :n].tolist() == ref["doc"][q, :n].tolist(), f"query {q}"
+        for f in ("title", "body", "pagerank", "final"):
+            a, b = hits[f][q, :n], ref[f][q, :n]
+            if exact:
+                assert np.array_equal(a, b), (q, f, a[:5], b[:5])
+            else:
+                np.testing.assert_allclose(a, b, rtol=1e-6)
+
+
+def tiny_index():
+    b_ptr = np.array([0, 3, 5, 6], dtype=np.uint64)
+    b_doc = np.array([0, 1, 2, 1, 3, 4], dtype=np.uint32)
+    b_w = np.array([1.0, 2.0, 0.5, 4.0, 1.0, 3.0], dtype=np.float32)
+    t_ptr = np.array([0, 1, 2, 2], dtype=np.uint64)
+    t_doc = np.array([1, 3], dtype=np.uint32)
+    t_w = np.array([8.0, 2.0], dtype=np.float32)
+    mag_b = np.array([2.0, 4.0, 0.0, 1.0, 0.0], dtype=np.float64)
+    mag_t = np.array([0.0, 2.0, 0.0, 4.0, 0.0], dtype=np.float64)
+    return (t_ptr, t_doc, t_w), (b_ptr, b_doc, b_w), mag_t, mag_b
+
+
+def test_kat(ss_ctx, oracle):
+    # hand-worked cases of tests/test_oracle_kat.py: NaN->0, x/0=+Inf, OR sums, duplicates, unknown term, cut
+    title, body, mag_t, mag_b = tiny_index()
+    sc, ti, bi = make_scorer(ss_ctx, 5, title, body, mag_t, mag_b)
+    try:
+        q_terms = np.array([0, 1, 0, 0, 0, 0xFFFFFFFF, 2, 0xFFFFFFFF], dtype=np.uint32)
+        q_ptr = np.array([0, 2, 4, 6, 7, 8, 8], dtype=np.uint32)
+        for k in (10, 2, 1):
+            hits, n_hits = sc.score_topk(q_ptr, q_terms, k)
+            ref, ref_n = oracle.score_topk_batch(5, title, body, mag_t, mag_b, q_ptr, q_terms, k)
+            assert_same_hits(hits, n_hits, ref, ref_n)
+        hits, n_hits = sc.score_topk(q_ptr, q_terms, 10)
+        assert hits["doc"][0, :4].tolist() == [2, 1, 3, 0]
+        assert math.isinf(hits["final"][0, 0]) and hits["title"][0, 3] == 0.0
+        assert n_hits.tolist() == [4, 3, 3, 1, 0, 0]
+        # query_len = len(queryTokenised)+len(phraseTokenised) (main_retrieve.go:90)
+        qlen = np.array([4, 2, 2, 9, 1, 0], dtype=np.int32)
+        hits, n_hits = sc.score_topk(q_ptr, q_terms, 10, query_len=qlen)
+        ref, ref_n = oracle.score_topk_batch(5, title, body, mag_t, mag_b, q_ptr, q_terms, 10, query_len=qlen)
+        assert_same_hits(hits, n_hits, ref, ref_n)
+    finally:
+        close_all(sc, ti, bi)
+
+
+def build_weighted(oracle, n_docs, n_terms, p_body, p_title, seed):
+    tp, pd, tf = synth.zipf_index(n_docs, n_terms, p_body, seed=seed)
+    tp2, pd2, tf2 = synth.zipf_index(n_docs, n_terms, p_title, seed=seed + 1)
+    wb, mb, _ = oracle.tfidf(tp, pd, tf, n_docs, n_docs)
+    wt, mt, _ = oracle.tfidf(tp2, pd2, tf2, n_docs, n_docs)
+    return (tp2, pd2, wt), (tp, pd, wb), mt, mb
+
+
+@pytest.mark.parametrize("n_docs,n_terms,p_body,p_title,n_q,k", [
+    (400, 120, 4000, 600, 64, 15),
+    (50000, 3000, 600000, 40000, 128, 100),      # multi-slice queries, compaction
+    (200000, 2000, 1500000, 100000, 48, 1000),   # large k
+])
+def test_random_index(ss_ctx, oracle, n_docs, n_terms, p_body, p_title, n_q, k):
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, p_body, p_title, seed=n_docs)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        rng = np.random.default_rng(n_q)
+        lens = rng.integers(1, 6, size=n_q)
+        q_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        # head-heavy term choice incl. duplicates and a few unknown ids
+        q_terms = np.minimum(rng.geometric(0.02, size=int(lens.sum())) - 1, n_terms + 5).astype(np.uint32)
+        hits, n_hits = sc.score_topk(q_ptr, q_terms, k)
+        ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, k)
+        assert_same_hits(hits, n_hits, ref, ref_n)
+        assert ref_n.max() == min(k, ref_n.max())
+    finally:
+        close_all(sc, ti, bi)
+
+
+def test_three_term_or_batch_like_config3(ss_ctx, oracle):
+    # BASELINE config 3 shape, scaled down: 3 distinct head/torso terms per query, top-100
+    n_docs, n_terms = 300000, 20000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 6000000, 400000, seed=44)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        q_ptr, q_terms = synth.make_queries(256, 3, 2000, seed=45)
+        hits, n_hits = sc.score_topk(q_ptr, q_terms, 100)
+        ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, 100)
+        assert_same_hits(hits, n_hits, ref, ref_n)
+    finally:
+        close_all(sc, ti, bi)
+
+
+def test_pagerank_blend(ss_ctx, oracle):
+    # Q9: sqd = sum_t topicProbs[t]*PR[doc][t], weight 0.33 (get_metadata.go:39-42,69); nil probs => 0
+    n_docs, n_terms, K = 20000, 1000, 16
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 200000, 20000, seed=7)
+    rng = np.random.default_rng(46)
+    prior = rng.random((K, n_docs)) * 50.0          # large enough to reorder results
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        sc.set_prior(prior)
+        q_ptr, q_terms = synth.make_queries(64, 3, 300, seed=3)
+        probs = rng.dirichlet(np.ones(K), size=64)
+        hits, n_hits = sc.score_topk(q_ptr, q_terms, 50, topic_probs=probs)
+        ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, 50,
+                                             prior=np.ascontiguousarray(prior.T), topic_probs=probs)
+        assert_same_hits(hits, n_hits, ref, ref_n)
+        assert (hits["pagerank"][:, 0] > 0).all()
+        # without topic_probs the prior is ignored (reference default, main_retrieve.go:88)
+        hits0, n0 = sc.score_topk(q_ptr, q_terms, 50)
+        ref0, refn0 = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, 50)
+        assert_same_hits(hits0, n0, ref0, refn0)
+        assert (hits0["pagerank"] == 0).all()
+    finally:
+        close_all(sc, ti, bi)
+
+
+def test_end_to_end_offline_then_online(ss_ctx, oracle):
+    """start_crawl.go:175-177 order: PageRank -> UpdateTermWeights(title) -> (body), then Retrieve."""
+    from spaghettisearch_amd import engine
+    n = 30000
+    ptr, dst = synth.rmat_graph(n, 150000, seed=9)
+    n_topic = synth.topic_sizes(n, 4)
+    g = engine.Graph(ss_ctx, n, ptr, dst)
+    rank, iters = g.pagerank(0.75, 1e-9, n_topic)
+    g.close()
+    tp, pd, tf = synth.zipf_index(n, 2000, 300000, seed=1)
+    tp2, pd2, tf2 = synth.zipf_index(n, 2000, 30000, seed=2)
+    bi = engine.InvertedIndex(ss_ctx, n, tp, pd, tf)
+    ti = engine.InvertedIndex(ss_ctx, n, tp2, pd2, tf2)
+    wt, mt, _ = ti.tfidf_build(n)        # N = len(forw[3]) = PageRank nodes (Q7)
+    wb, mb, _ = bi.tfidf_build(n)
+    sc = engine.Scorer(ss_ctx, ti, bi)
+    sc.set_prior(rank)
+    q_ptr, q_terms = synth.make_queries(32, 3, 500, seed=8)
+    probs = np.random.default_rng(1).dirichlet(np.ones(4), size=32)
+    hits, n_hits = sc.score_topk(q_ptr, q_terms, 50, topic_probs=probs)
+    close_all(sc, ti, bi)
+    # oracle pipeline
+    r_rank, r_iters = oracle.pagerank(n, ptr, dst, 0.75, 1e-9, n_topic)
+    r_wb, r_mb, _ = oracle.tfidf(tp, pd, tf, n, n)
+    r_wt, r_mt, _ = oracle.tfidf(tp2, pd2, tf2, n, n)
+    assert iters.tolist() == r_iters.tolist()
+    assert np.array_equal(wb, r_wb) and np.array_equal(wt, r_wt)
+    ref, ref_n = oracle.score_topk_batch(n, (tp2, pd2, r_wt), (tp, pd, r_wb), r_mt, r_mb, q_ptr, q_terms, 50,
+                                         prior=np.ascontiguousarray(r_rank.T), topic_probs=probs)
+    # magnitudes / ranks differ in the last bits (summation order): ids must match, scores to 1e-9
+    assert n_hits.tolist() == ref_n.tolist()
+    same = sum(hits["doc"][q, :n_hits[q]].tolist() == ref["doc"][q, :ref_n[q]].tolist() for q in range(32))
+    assert same >= 31, same      # a near-tie may legitimately swap (SURVEY.md §8d parity gates)
+    for q in range(32):
+        nn = int(n_hits[q])
+        np.testing.assert_allclose(np.sort(hits["final"][q, :nn]), np.sort(ref["final"][q, :nn]), rtol=1e-9)
+
+
+def test_errors(ss_ctx, oracle):
+    from spaghettisearch_amd import SpaghettiError, engine
+    title, body, mag_t, mag_b = tiny_index()
+    ti = engine.InvertedIndex(ss_ctx, 5, *title)
+    bi = engine.InvertedIndex(ss_ctx, 5, *body)
+    with pytest.raises(SpaghettiError) as ei:
+        engine.Scorer(ss_ctx, ti, bi)                 # weights not built yet
+    assert ei.value.code == 6
+    ti.set_weighted(mag_t)
+    bi.set_weighted(mag_b)
+    sc = engine.Scorer(ss_ctx, ti, bi)
+    q_ptr = np.array([0, 1], dtype=np.uint32)
+    q_terms = np.array([0], dtype=np.uint32)
+    with pytest.raises(SpaghettiError):
+        sc.score_topk(q_ptr, q_terms, 0)
+    with pytest.raises(SpaghettiError):
+        sc.score_topk(q_ptr, q_terms, 5000)
+    with pytest.raises(SpaghettiError):
+        sc.score_topk(q_ptr, q_terms, 5, topic_probs=np.ones((1, 3)))   # no prior set
+    with pytest.raises(SpaghettiError):
+        ti.close()                                    # still in use by the scorer
+    close_all(sc, ti, bi)
