@@ -115,6 +115,14 @@ __global__ void k_extract_src(const uint64_t* __restrict__ keys, uint64_t off_nd
     }
 }
 
+// bit 31 of the last in-edge entry of every row marks the row end (pagerank.hip walks rows by it)
+__global__ void k_flag_row_ends(const uint32_t* __restrict__ in_ptr, uint64_t n_rows, uint32_t* __restrict__ in_src) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t a = in_ptr[r], b = in_ptr[r + 1];
+    if (b > a) in_src[b - 1] |= 0x80000000u;
+}
+
 __global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n,
                              uint32_t* __restrict__ dst) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,7 +195,8 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     g->sl_d = (uint32_t)((n_d + W - 1) / W);
     g->nd_int = (uint64_t)W * g->sl_nd;
     g->n_int = (uint64_t)W * ((uint64_t)g->sl_nd + g->sl_d);
-    if (g->n_int >= 0xFFFFFFFFull) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_graph_create: too many nodes for 32-bit ids");
+    // bit 31 of an in-edge source id is the row-end flag
+    if (g->n_int >= 0x7FFFFFFFull) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_graph_create: too many nodes for 31-bit ids");
     // rows of class c dealt round-robin: rank r gets positions r, r+W, ...
     g->cnt_nd = (uint32_t)((h_nd + W - 1 - g->rank) / W);
     g->cnt_d = (uint32_t)((n_d + W - 1 - g->rank) / W);
@@ -253,6 +262,9 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     if (g->e_local)
         hipLaunchKernelGGL(k_extract_src, dim3(grid_for(g->e_local, 16384)), dim3(TPB), 0, st, keys_b.p, h_ptr[0], e_nd,
                            h_ptr[2], g->e_local, g->in_src.p);
+    if (g->e_local)
+        hipLaunchKernelGGL(k_flag_row_ends, dim3(ss::div_up((uint64_t)n_local, TPB)), dim3(TPB), 0, st, (const uint32_t*)g->in_ptr.p,
+                           (uint64_t)n_local, g->in_src.p);
     if (g->sl_nd)
         hipLaunchKernelGGL(k_gather_u32, dim3(ss::div_up(g->sl_nd, TPB)), dim3(TPB), 0, st, d_outdeg.p, g->old_id.p + id0_nd,
                            (uint64_t)g->sl_nd, g->outdeg.p);

@@ -48,7 +48,7 @@ struct PrCtl {
     uint32_t pad;
 };
 
-enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3 };
+enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3, W_ROWS = 4 };
 
 struct WorkItem {
     uint32_t kind;
@@ -74,7 +74,7 @@ struct PrParams {
     const double* x0;     // [GW] 1/n_topic
     double d, teleport, eps, tele_n;
     int32_t max_iter, k_topics, world;
-    uint32_t sl_nd, cnt_nd, sl_d, cnt_d, seg_edges;
+    uint32_t sl_nd, cnt_nd, sl_d, cnt_d, seg_edges, n_items;
 };
 
 // ---- reductions --------------------------------------------------------------
@@ -198,6 +198,8 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
 }
 
 // ---- gather ------------------------------------------------------------------
+constexpr uint32_t SRC_MASK = 0x7FFFFFFFu;   // in_src bit 31 = "last in-edge of its row" (graph.hip)
+constexpr int CH = 16;                       // edges per chunk of the GW=16 path
 
 // sum of T[src][t] over edges beg+first, beg+first+stride, ... < end; 4 gathers in flight
 template <int GW>
@@ -206,23 +208,43 @@ __device__ __forceinline__ double gather_sum(const double* __restrict__ T, const
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     size_t e = beg + first;
     for (; e + 3 * (size_t)stride < end; e += 4 * (size_t)stride) {
-        const uint32_t s0 = in_src[e], s1 = in_src[e + stride], s2 = in_src[e + 2 * (size_t)stride],
-                       s3 = in_src[e + 3 * (size_t)stride];
+        const uint32_t s0 = in_src[e] & SRC_MASK, s1 = in_src[e + stride] & SRC_MASK,
+                       s2 = in_src[e + 2 * (size_t)stride] & SRC_MASK, s3 = in_src[e + 3 * (size_t)stride] & SRC_MASK;
         a0 += T[(size_t)s0 * GW + t];
         a1 += T[(size_t)s1 * GW + t];
         a2 += T[(size_t)s2 * GW + t];
         a3 += T[(size_t)s3 * GW + t];
     }
-    for (; e < end; e += stride) a0 += T[(size_t)in_src[e] * GW + t];
+    for (; e < end; e += stride) a0 += T[(size_t)(in_src[e] & SRC_MASK) * GW + t];
     return (a0 + a1) + (a2 + a3);
 }
 
+// GW=16: one lane group (16 lanes = 16 topics) takes CH=16 consecutive in-edges: ONE coalesced
+// 64-byte index load, then 16 independent 128-byte gathers in flight (one table row each).
+// v[j] = T[src_j][t] for j < n, 0 otherwise; returns the group's 16 "last edge of row" flags.
+__device__ __forceinline__ uint32_t gather_chunk16(const double* __restrict__ T, const uint32_t* __restrict__ in_src,
+                                                   size_t pos, uint32_t n, int lane, double (&v)[CH]) {
+    const int t = lane & 15, gbase = lane & 48;
+    const uint32_t raw = (uint32_t)t < n ? in_src[pos + t] : 0u;
+    const unsigned long long flags = __ballot(raw >> 31);
+    const uint32_t src = raw & SRC_MASK;
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const uint32_t sj = (uint32_t)__shfl((int)src, gbase + j, 64);
+        v[j] = (uint32_t)j < n ? T[(size_t)sj * 16 + t] : 0.0;
+    }
+    return (uint32_t)(flags >> gbase) & 0xFFFFu;
+}
+
 // ---- the sweep ---------------------------------------------------------------
+// Persistent grid: a fixed number of blocks walks the work table round-robin, so the
+// per-launch costs (partials, release fence, ticket) are paid ~2k times, not per work item.
 template <int GW>
 __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     constexpr int NSLOT = 64 / GW;
     __shared__ double rowred[WAVES][MAXK];
     __shared__ int s_rowlast;
+    __shared__ double rowsum[GW == 16 ? WAVES * CH * 64 : 1];   // GW=16: finished row sums of a chunk
 
     PrCtl* ctl = p.ctl;
     if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
@@ -234,7 +256,6 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     const double x0 = sweep == 0 ? p.x0[t] : 0.0;      // Q4: iteration 1 accumulates onto 1/n
     const double* __restrict__ T = p.tab_rd[sweep & 1];
     double* __restrict__ Tw = p.tab_wr[sweep & 1];
-    const WorkItem w = p.work[blockIdx.x];
 
     double dsum = 0.0, csum = 0.0;
 
@@ -256,71 +277,119 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
         }
     };
 
-    if (w.kind == W_SEG) {
-        // one block per segment of a long row; all 4 waves stride the segment
-        const uint32_t lrow = w.row;
-        const size_t rbeg = p.in_ptr[lrow], rend = p.in_ptr[lrow + 1];
-        const size_t beg = rbeg + (size_t)w.count * p.seg_edges;
-        const size_t end = min(rend, beg + (size_t)p.seg_edges);
-        double acc = gather_sum<GW>(T, p.in_src, beg, end, wave * NSLOT + slot, WAVES * NSLOT, t);
-        acc = wave_sum_topic<GW>(acc);
-        if (lane < GW) rowred[wave][t] = acc;
-        __syncthreads();
-        double y = 0.0;
-        if (threadIdx.x < GW) {
-            y = rowred[0][t];
-#pragma unroll
-            for (int q = 1; q < WAVES; q++) y += rowred[q][t];
-        }
-        if (w.nseg == 1) {
-            if (threadIdx.x < GW) finish(lrow, y);
-        } else {
-            // several blocks share this row: publish the segment partial; the last
-            // arriver adds the partials in segment order and finishes the row
-            if (threadIdx.x < GW) p.segpart[(size_t)(w.sbase + w.count) * GW + t] = y;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned prev = __hip_atomic_fetch_add(&p.rowticket[w.tix], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = prev == w.nseg - 1;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    p.rowticket[w.tix] = 0;
-                }
-                s_rowlast = last;
-            }
-            __syncthreads();
-            if (s_rowlast && threadIdx.x < GW) {
-                double ys = 0.0;
-                for (uint32_t q = 0; q < w.nseg; q++) ys += p.segpart[(size_t)(w.sbase + q) * GW + t];
-                finish(lrow, ys);
-            }
-        }
-    } else if (w.kind == W_WAVE) {
-        // one wave per row, the wave's lane groups stride the row's in-edges
-        if ((uint32_t)wave < w.count) {
-            const uint32_t lrow = w.row + wave;
-            const size_t beg = p.in_ptr[lrow], end = p.in_ptr[lrow + 1];
-            double acc = gather_sum<GW>(T, p.in_src, beg, end, slot, NSLOT, t);
-            acc = wave_sum_topic<GW>(acc);
-            if (slot == 0) finish(lrow, acc);
-        }
-    } else if (w.kind == W_GROUP) {
-        // one lane group (GW lanes) per row; rows are degree-sorted so trip counts match inside a wave
-        for (uint32_t r = wave * NSLOT + slot; r < w.count; r += WAVES * NSLOT) {
-            const uint32_t lrow = w.row + r;
-            const size_t beg = p.in_ptr[lrow], end = p.in_ptr[lrow + 1];
+    for (uint32_t item = blockIdx.x; item < p.n_items; item += gridDim.x) {
+        const WorkItem w = p.work[item];
+        if (w.kind == W_SEG) {
+            // one block per segment of a long row
+            const uint32_t lrow = w.row;
+            const size_t rbeg = p.in_ptr[lrow], rend = p.in_ptr[lrow + 1];
+            const size_t beg = rbeg + (size_t)w.count * p.seg_edges;
+            const size_t end = min(rend, beg + (size_t)p.seg_edges);
             double acc = 0.0;
-            for (size_t e = beg; e < end; e++) acc += T[(size_t)p.in_src[e] * GW + t];
-            finish(lrow, acc);
+            if constexpr (GW == 16) {
+                // the block's 16 lane groups take 16-edge chunks round-robin
+                for (size_t pos = beg + (size_t)(wave * NSLOT + slot) * CH; pos < end; pos += (size_t)WAVES * NSLOT * CH) {
+                    double v[CH];
+                    gather_chunk16(T, p.in_src, pos, (uint32_t)min((size_t)CH, end - pos), lane, v);
+                    double a = 0.0;
+#pragma unroll
+                    for (int j = 0; j < CH; j++) a += v[j];
+                    acc += a;
+                }
+            } else {
+                acc = gather_sum<GW>(T, p.in_src, beg, end, wave * NSLOT + slot, WAVES * NSLOT, t);
+            }
+            acc = wave_sum_topic<GW>(acc);
+            __syncthreads();                            // rowred / s_rowlast reuse across items
+            if (lane < GW) rowred[wave][t] = acc;
+            __syncthreads();
+            double y = 0.0;
+            if (threadIdx.x < GW) {
+                y = rowred[0][t];
+#pragma unroll
+                for (int q = 1; q < WAVES; q++) y += rowred[q][t];
+            }
+            if (w.nseg == 1) {
+                if (threadIdx.x < GW) finish(lrow, y);
+            } else {
+                // several blocks share this row: publish the segment partial; the last
+                // arriver adds the partials in segment order and finishes the row
+                if (threadIdx.x < GW) p.segpart[(size_t)(w.sbase + w.count) * GW + t] = y;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned prev = __hip_atomic_fetch_add(&p.rowticket[w.tix], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = prev == w.nseg - 1;
+                    if (last) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        p.rowticket[w.tix] = 0;
+                    }
+                    s_rowlast = last;
+                }
+                __syncthreads();
+                if (s_rowlast && threadIdx.x < GW) {
+                    double ys = 0.0;
+                    for (uint32_t q = 0; q < w.nseg; q++) ys += p.segpart[(size_t)(w.sbase + q) * GW + t];
+                    finish(lrow, ys);
+                }
+            }
+        } else if (w.kind == W_ROWS) {
+            if constexpr (GW == 16) {
+                // every lane group owns a contiguous run of rows (and so of in-edges) and walks it
+                // in 16-edge chunks; row ends come from the flag bit, finished sums go through LDS
+                const uint32_t gi = wave * NSLOT + slot;
+                const uint32_t rpg = (w.count + WAVES * NSLOT - 1) / (WAVES * NSLOT);
+                uint32_t row = w.row + min(gi * rpg, w.count);
+                const uint32_t row_hi = w.row + min((gi + 1) * rpg, w.count);
+                size_t pos = p.in_ptr[row];
+                const size_t end = p.in_ptr[row_hi];
+                double* my = rowsum + (size_t)wave * CH * 64 + lane;
+                double acc = 0.0;
+                while (pos < end) {
+                    const uint32_t n = (uint32_t)min((size_t)CH, end - pos);
+                    double v[CH];
+                    const uint32_t last = gather_chunk16(T, p.in_src, pos, n, lane, v);
+                    uint32_t nfin = 0;
+#pragma unroll
+                    for (int j = 0; j < CH; j++) {
+                        acc += v[j];
+                        if ((last >> j) & 1u) {
+                            my[nfin * 64] = acc;
+                            nfin++;
+                            acc = 0.0;
+                        }
+                    }
+                    for (uint32_t r = 0; r < nfin; r++) finish(row + r, my[r * 64]);
+                    row += nfin;
+                    pos += n;
+                }
+            }
+        } else if (w.kind == W_WAVE) {
+            // one wave per row, the wave's lane groups stride the row's in-edges
+            if ((uint32_t)wave < w.count) {
+                const uint32_t lrow = w.row + wave;
+                const size_t beg = p.in_ptr[lrow], end = p.in_ptr[lrow + 1];
+                double acc = gather_sum<GW>(T, p.in_src, beg, end, slot, NSLOT, t);
+                acc = wave_sum_topic<GW>(acc);
+                if (slot == 0) finish(lrow, acc);
+            }
+        } else if (w.kind == W_GROUP) {
+            // one lane group (GW lanes) per row; rows are degree-sorted so trip counts match inside a wave
+            for (uint32_t r = wave * NSLOT + slot; r < w.count; r += WAVES * NSLOT) {
+                const uint32_t lrow = w.row + r;
+                const size_t beg = p.in_ptr[lrow], end = p.in_ptr[lrow + 1];
+                double acc = 0.0;
+                for (size_t e = beg; e < end; e++) acc += T[(size_t)(p.in_src[e] & SRC_MASK) * GW + t];
+                finish(lrow, acc);
+            }
+        } else {
+            // rows without in-edges: pure streaming update
+            const uint32_t nel = w.count * GW;
+            for (uint32_t i = threadIdx.x; i < nel; i += TPB) finish(w.row + i / GW, 0.0);
         }
-    } else {
-        // rows without in-edges: pure streaming update
-        const uint32_t nel = w.count * GW;
-        for (uint32_t i = threadIdx.x; i < nel; i += TPB) finish(w.row + i / GW, 0.0);
     }
 
     block_reduce_and_publish<GW>(p, dsum, csum, Tw, false);
@@ -411,9 +480,11 @@ int pick_gw(int k) {
 void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
                 uint32_t& seg_edges) {
     const uint32_t NSLOT = 64 / gw;
-    const uint32_t T_SEG = 32 * NSLOT;      // longer rows: block(s) per row
-    const uint32_t T_WAVE = 2 * NSLOT;      // longer rows: wave per row
-    seg_edges = 128 * NSLOT;
+    // gw == 16: rows above T_SEG in-edges get block(s) of their own, everything else is walked in
+    // 16-edge chunks by lane groups (W_ROWS).  gw < 16: wave-per-row / group-per-row classes.
+    const uint32_t T_SEG = gw == 16 ? 512 : 32 * NSLOT;
+    const uint32_t T_WAVE = 2 * NSLOT;
+    seg_edges = gw == 16 ? 2048 : 128 * NSLOT;
     nsegs = 0;
     nmulti = 0;
     std::vector<WorkItem> seg, wav, grp, zer;
@@ -422,9 +493,7 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
         // deg is sorted descending: find class boundaries
         uint32_t a = 0;
         while (a < cnt && deg[a] > T_SEG) a++;
-        uint32_t b = a;
-        while (b < cnt && deg[b] > T_WAVE) b++;
-        uint32_t c = b;
+        uint32_t c = a;
         while (c < cnt && deg[c] > 0) c++;
         for (uint32_t r = 0; r < a; r++) {
             const uint32_t ns = (deg[r] + seg_edges - 1) / seg_edges;
@@ -432,9 +501,23 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
             for (uint32_t s = 0; s < ns; s++) seg.push_back({W_SEG, row0 + r, s, ns, nsegs, tix});
             nsegs += ns;
         }
-        for (uint32_t r = a; r < b; r += WAVES) wav.push_back({W_WAVE, row0 + r, std::min<uint32_t>(WAVES, b - r), 0, 0, 0});
-        const uint32_t GROUP_ROWS = WAVES * NSLOT * 4;   // 4 rows per lane group per block
-        for (uint32_t r = b; r < c; r += GROUP_ROWS) grp.push_back({W_GROUP, row0 + r, std::min<uint32_t>(GROUP_ROWS, c - r), 0, 0, 0});
+        if (gw == 16) {
+            // items of ~4096 in-edges, at most 1024 rows (64 per lane group)
+            uint32_t r = a;
+            while (r < c) {
+                uint32_t rows = 0;
+                uint64_t edges = 0;
+                while (r + rows < c && rows < 1024 && edges < 4096) edges += deg[r + rows++];
+                wav.push_back({W_ROWS, row0 + r, rows, 0, 0, 0});
+                r += rows;
+            }
+        } else {
+            uint32_t b = a;
+            while (b < c && deg[b] > T_WAVE) b++;
+            for (uint32_t r = a; r < b; r += WAVES) wav.push_back({W_WAVE, row0 + r, std::min<uint32_t>(WAVES, b - r), 0, 0, 0});
+            const uint32_t GROUP_ROWS = WAVES * NSLOT * 4;   // 4 rows per lane group per block
+            for (uint32_t r = b; r < c; r += GROUP_ROWS) grp.push_back({W_GROUP, row0 + r, std::min<uint32_t>(GROUP_ROWS, c - r), 0, 0, 0});
+        }
         const uint32_t ZERO_ROWS = (TPB * 8) / gw;       // 8 elements per thread
         for (uint32_t r = c; r < cnt; r += ZERO_ROWS) zer.push_back({W_ZERO, row0 + r, std::min<uint32_t>(ZERO_ROWS, cnt - r), 0, 0, 0});
     };
@@ -509,7 +592,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     uint32_t nsegs = 0, nmulti = 0, seg_edges = 0;
     build_work(g, GW, items, nsegs, nmulti, seg_edges);
     if (items.empty()) items.push_back({W_ZERO, 0, 0, 0, 0, 0});
-    pr->nblocks = (unsigned)items.size();
+    // persistent grid: 8 blocks per CU at most, each walks the work table round-robin
+    pr->nblocks = (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
 
     SS_HIP(ctx, pr->x.alloc(n_local * GW));
     SS_HIP(ctx, pr->tab0.alloc((size_t)g->nd_int * GW));
@@ -567,6 +651,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     p.sl_d = g->sl_d;
     p.cnt_d = g->cnt_d;
     p.seg_edges = seg_edges;
+    p.n_items = (uint32_t)items.size();
     *out = guard.release();
     return SS_OK;
 }
