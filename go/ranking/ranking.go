@@ -1,0 +1,224 @@
+// Package ranking — drop-in for the reference's package of the same name.
+//
+// Same exported signatures as ranking/pagerank.go:14 and ranking/term_weighting.go:10; the
+// bodies flatten the BadgerDB tables to dense-id arrays, make ONE call into the HIP library per
+// function (not per iteration / per term) and write the results back in the reference's
+// table formats (forw[3]: map[category]float64, forw[4]: map{"title","body"}float64,
+// inv[*]: map[docHash][]float32 with listPos[0] replaced).
+//
+// Call order is the reference's (cmd/crawl/start_crawl.go:175-177): PageRank first, then
+// title, then body — UpdateTermWeights reads len(forw[3]) (term_weighting.go:13-17, Q7).
+package ranking
+
+import (
+	"context"
+	"encoding/json"
+	"log"
+	"sort"
+
+	db "github.com/nwihardjo/SpaghettiSearch/database"
+
+	"github.com/nwihardjo/SpaghettiSearch/go/spaghetti"
+)
+
+// denseIDs assigns 0..n-1 to md5-hex hashes in sorted order (deterministic, unlike Go map order).
+type denseIDs struct {
+	id   map[string]uint32
+	name []string
+}
+
+func newDenseIDs(keys map[string]struct{}) *denseIDs {
+	d := &denseIDs{id: make(map[string]uint32, len(keys)), name: make([]string, 0, len(keys))}
+	for k := range keys {
+		d.name = append(d.name, k)
+	}
+	sort.Strings(d.name)
+	for i, k := range d.name {
+		d.id[k] = uint32(i)
+	}
+	return d
+}
+
+func UpdateTopicSensitivePagerank(ctx context.Context, dampingFactor float64, convergenceCriterion float64, forward []db.DB) {
+	log.Printf("Ranking with damping factor='%f', convergence_criteria='%f'", dampingFactor, convergenceCriterion)
+
+	// pagerank.go:17-44 — node set = parents U children (frontier pages are nodes without children)
+	nodesCompressed, err := forward[2].Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	all := make(map[string]struct{})
+	children := make(map[string][]string, len(nodesCompressed.KV))
+	for _, kv := range nodesCompressed.KV {
+		var c []string
+		if err = json.Unmarshal(kv.Value, &c); err != nil {
+			panic(err)
+		}
+		for _, h := range c {
+			all[h] = struct{}{}
+		}
+		children[string(kv.Key)] = c
+		all[string(kv.Key)] = struct{}{}
+	}
+	ids := newDenseIDs(all)
+	n := len(ids.name)
+
+	// out-edge CSR over dense ids
+	outPtr := make([]uint64, n+1)
+	for p, c := range children {
+		outPtr[ids.id[p]+1] = uint64(len(c))
+	}
+	for i := 0; i < n; i++ {
+		outPtr[i+1] += outPtr[i]
+	}
+	outDst := make([]uint32, outPtr[n])
+	for p, c := range children {
+		base := outPtr[ids.id[p]]
+		for j, h := range c {
+			outDst[base+uint64(j)] = ids.id[h]
+		}
+	}
+
+	// pagerank.go:46-63 — one power iteration per category, differing by numPages only
+	categoryCompressed, err := forward[5].Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	cats := make([]string, 0, len(categoryCompressed.KV))
+	nTopic := make([]int32, 0, len(categoryCompressed.KV))
+	for _, kv := range categoryCompressed.KV {
+		val := make(map[string]float64, 2)
+		if err = json.Unmarshal(kv.Value, &val); err != nil {
+			panic(err)
+		}
+		log.Printf("number of webnodes in %s is %d", string(kv.Key), int(val["numPages"]))
+		cats = append(cats, string(kv.Key))
+		nTopic = append(nTopic, int32(int(val["numPages"])))
+	}
+
+	g := spaghetti.Default().NewGraph(outPtr, outDst)
+	defer g.Close()
+	rank, _ := g.PageRank(dampingFactor, convergenceCriterion, nTopic) // all categories, device-resident loop
+
+	// pagerank.go:65-82 — forw[3][doc] = map[category]rank
+	bw := forward[3].BatchWrite_init(ctx)
+	defer bw.Cancel(ctx)
+	for v, name := range ids.name {
+		PR := make(map[string]float64, len(cats))
+		for k, c := range cats {
+			PR[c] = rank[k*n+v]
+		}
+		if err := bw.BatchSet(ctx, name, PR); err != nil {
+			panic(err)
+		}
+	}
+	if err = bw.Flush(ctx); err != nil {
+		panic(err)
+	}
+}
+
+func UpdateTermWeights(ctx context.Context, inv *db.DB, forw []db.DB, info string) {
+	// term_weighting.go:12-17 — N = number of PageRank nodes
+	nodes, err := forw[3].Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	totalDocs := uint64(len(nodes.KV))
+	docSet := make(map[string]struct{}, len(nodes.KV))
+	for _, kv := range nodes.KV {
+		docSet[string(kv.Key)] = struct{}{}
+	}
+
+	comp, err := (*inv).Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	// decode every row once; keep the positional tails for the write-back
+	rows := make([]map[string][]float32, len(comp.KV))
+	for i := range comp.KV {
+		if err = json.Unmarshal(comp.KV[i].Value, &rows[i]); err != nil {
+			panic(err)
+		}
+		for h := range rows[i] {
+			docSet[h] = struct{}{}
+		}
+	}
+	docs := newDenseIDs(docSet)
+
+	// term-major CSR, postings sorted by dense doc id
+	termPtr := make([]uint64, len(rows)+1)
+	for i, r := range rows {
+		termPtr[i+1] = termPtr[i] + uint64(len(r))
+	}
+	postDoc := make([]uint32, termPtr[len(rows)])
+	postTf := make([]float32, termPtr[len(rows)])
+	for i, r := range rows {
+		seg := postDoc[termPtr[i]:termPtr[i+1]]
+		j := 0
+		for h := range r {
+			seg[j] = docs.id[h]
+			j++
+		}
+		sort.Slice(seg, func(a, b int) bool { return seg[a] < seg[b] })
+		for j, d := range seg {
+			postTf[termPtr[i]+uint64(j)] = r[docs.name[d]][0] // listPos[0] = normalised tf
+		}
+	}
+
+	ix := spaghetti.Default().NewIndex(uint64(len(docs.name)), termPtr, postDoc, postTf)
+	defer ix.Close()
+	w, mag := ix.TfIdfBuild(totalDocs) // idf, w = tf*idf, mag = sqrt(sum w^2)   (term_weighting.go:37-44,72)
+
+	// term_weighting.go:42,47 — write the weights back in place
+	bw := (*inv).BatchWrite_init(ctx)
+	defer bw.Cancel(ctx)
+	for i, r := range rows {
+		for j := termPtr[i]; j < termPtr[i+1]; j++ {
+			r[docs.name[postDoc[j]]][0] = w[j]
+		}
+		if err = bw.BatchSet(ctx, string(comp.KV[i].Key), r); err != nil {
+			panic(err)
+		}
+	}
+	if err = bw.Flush(ctx); err != nil {
+		panic(err)
+	}
+
+	// term_weighting.go:59-123 (saveMagnitude): only docs that occur in this table get a value
+	pageMagnitude := make(map[string]float64)
+	for _, d := range postDoc {
+		pageMagnitude[docs.name[d]] = mag[d]
+	}
+	saveMagnitude(ctx, pageMagnitude, &forw[4], info)
+}
+
+// saveMagnitude merges the (already square-rooted) magnitudes into forw[4][doc][info], keeping the
+// other key — same table semantics as term_weighting.go:59-123.
+func saveMagnitude(ctx context.Context, pageMagnitude map[string]float64, forw *db.DB, info string) {
+	comp, err := (*forw).Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	bw := (*forw).BatchWrite_init(ctx)
+	defer bw.Cancel(ctx)
+	for i := range comp.KV {
+		key := string(comp.KV[i].Key)
+		var v map[string]float64
+		if err = json.Unmarshal(comp.KV[i].Value, &v); err != nil {
+			panic(err)
+		}
+		v[info] = pageMagnitude[key] // missing => 0, like math.Sqrt(0) at term_weighting.go:97
+		delete(pageMagnitude, key)
+		if err = bw.BatchSet(ctx, key, v); err != nil {
+			panic(err)
+		}
+	}
+	for h, m := range pageMagnitude {
+		if err = bw.BatchSet(ctx, h, map[string]float64{info: m}); err != nil {
+			panic(err)
+		}
+	}
+	if err = bw.Flush(ctx); err != nil {
+		panic(err)
+	}
+}

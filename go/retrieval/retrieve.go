@@ -1,0 +1,161 @@
+// Package retrieval — drop-in for retrieval.Retrieve (retrieval/main_retrieve.go:15).
+//
+// The query-time index lives on the GPU: on first use the tables are flattened once
+// (inv[0]/inv[1] postings, forw[4] magnitudes, forw[3] ranks) and uploaded; every Retrieve then
+// costs string parsing on the host plus ONE library call, and only the k winners are decorated
+// (the reference builds DocInfo + summary for every candidate, get_metadata.go:21-28).
+// Rank_combined (util.go:25-36), getPhrase (util.go:151-160), getDocInfo/getSummary
+// (get_metadata.go:79-235) and parser.Laundry stay as in the reference and are not repeated here.
+package retrieval
+
+import (
+	"context"
+	"crypto/md5"
+	"encoding/hex"
+	"encoding/json"
+	"sort"
+	"strings"
+	"sync"
+
+	db "github.com/nwihardjo/SpaghettiSearch/database"
+	"github.com/nwihardjo/SpaghettiSearch/parser"
+
+	"github.com/nwihardjo/SpaghettiSearch/go/spaghetti"
+)
+
+const topK = 50 // main_retrieve.go:99-100
+
+type deviceIndex struct {
+	scorer  *spaghetti.Scorer
+	termID  map[string]uint32 // md5-hex(word) -> dense term id
+	docName []string          // dense doc id -> md5-hex(url)
+}
+
+var (
+	warm sync.Once
+	dev  *deviceIndex
+)
+
+func flatten(ctx context.Context, inv db.DB, termID map[string]uint32, docID map[string]uint32) (ptr []uint64, doc []uint32, w []float32) {
+	comp, err := inv.Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	rows := make([]map[string][]float32, len(termID))
+	for i := range comp.KV {
+		var r map[string][]float32
+		if err = json.Unmarshal(comp.KV[i].Value, &r); err != nil {
+			panic(err)
+		}
+		rows[termID[string(comp.KV[i].Key)]] = r
+	}
+	ptr = make([]uint64, len(rows)+1)
+	for i, r := range rows {
+		ptr[i+1] = ptr[i] + uint64(len(r))
+	}
+	doc = make([]uint32, ptr[len(rows)])
+	w = make([]float32, ptr[len(rows)])
+	for i, r := range rows {
+		type pw struct {
+			d uint32
+			w float32
+		}
+		tmp := make([]pw, 0, len(r))
+		for h, listPos := range r {
+			tmp = append(tmp, pw{docID[h], listPos[0]}) // first entry = norm_tf*idf (main_retrieve.go:227,236)
+		}
+		sort.Slice(tmp, func(a, b int) bool { return tmp[a].d < tmp[b].d })
+		for j, e := range tmp {
+			doc[ptr[i]+uint64(j)], w[ptr[i]+uint64(j)] = e.d, e.w
+		}
+	}
+	return
+}
+
+func load(ctx context.Context, forw []db.DB, inv []db.DB) *deviceIndex {
+	// dense ids: docs = keys of forw[3] (every PageRank node), terms = keys of inv[0] U inv[1]
+	ranks, err := forw[3].Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	d := &deviceIndex{termID: map[string]uint32{}}
+	docID := make(map[string]uint32, len(ranks.KV))
+	for _, kv := range ranks.KV {
+		docID[string(kv.Key)] = uint32(len(d.docName))
+		d.docName = append(d.docName, string(kv.Key))
+	}
+	for t := 0; t < 2; t++ {
+		comp, err := inv[t].Iterate(ctx)
+		if err != nil {
+			panic(err)
+		}
+		for _, kv := range comp.KV {
+			if _, ok := d.termID[string(kv.Key)]; !ok {
+				d.termID[string(kv.Key)] = uint32(len(d.termID))
+			}
+		}
+	}
+	n := uint64(len(d.docName))
+	c := spaghetti.Default()
+	tPtr, tDoc, tW := flatten(ctx, inv[0], d.termID, docID)
+	bPtr, bDoc, bW := flatten(ctx, inv[1], d.termID, docID)
+	title := c.NewIndex(n, tPtr, tDoc, tW)
+	body := c.NewIndex(n, bPtr, bDoc, bW)
+	// forw[4]: a missing "title"/"body" key reads as 0 (get_metadata.go:57-58, Q8)
+	magT, magB := make([]float64, n), make([]float64, n)
+	mags, err := forw[4].Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	for _, kv := range mags.KV {
+		var m map[string]float64
+		if err = json.Unmarshal(kv.Value, &m); err != nil {
+			panic(err)
+		}
+		if id, ok := docID[string(kv.Key)]; ok {
+			magT[id], magB[id] = m["title"], m["body"]
+		}
+	}
+	title.SetWeighted(magT)
+	body.SetWeighted(magB)
+	d.scorer = c.NewScorer(title, body)
+	return d
+}
+
+func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Rank_combined {
+	warm.Do(func() { dev = load(ctx, forw, inv) })
+
+	// main_retrieve.go:17-36 — query parsing, unchanged
+	phrases := getPhrase(query)
+	for _, term := range phrases {
+		query = strings.Replace(query, "\""+string(term)+"\"", "", 1)
+	}
+	queryTokenised := parser.Laundry(strings.Join(strings.Fields(query), " "))
+	phraseTokenised := parser.Laundry(strings.Join(phrases, " "))
+
+	qTerms := make([]uint32, len(queryTokenised))
+	for i, tok := range queryTokenised {
+		sum := md5.Sum([]byte(tok))
+		if id, ok := dev.termID[hex.EncodeToString(sum[:])]; ok {
+			qTerms[i] = id
+		} else {
+			qTerms[i] = 0xFFFFFFFF // badger.ErrKeyNotFound: no postings (main_retrieve.go:193,218)
+		}
+	}
+	qPtr := []uint32{0, uint32(len(qTerms))}
+	qLen := []int32{int32(len(queryTokenised) + len(phraseTokenised))} // main_retrieve.go:90
+	// topicProbs stays nil as in the shipped reference (main_retrieve.go:40,87-88): sqd = 0.
+	// Phrase search (retrieval/phrase.go) is the next row of the scope table (SURVEY.md §8f-1).
+	hits, _ := dev.scorer.ScoreTopK(qPtr, qTerms, qLen, nil, topK)
+
+	out := make([]Rank_combined, 0, len(hits[0]))
+	for _, h := range hits[0] {
+		docHash := dev.docName[h.Doc]
+		meta := <-getDocInfo(ctx, docHash, forw) // get_metadata.go:211-235, for the winners only
+		meta.PageRank = h.PageRank               // get_metadata.go:68
+		meta.FinalRank = h.Final                 // get_metadata.go:69
+		meta.Summary = <-getSummary(docHash, query, phrases)
+		out = append(out, meta)
+	}
+	return out
+}

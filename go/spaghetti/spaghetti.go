@@ -1,0 +1,178 @@
+// Package spaghetti is the cgo binding of libspaghetti_rank.so (include/spaghetti_rank.h).
+//
+// It is the ONLY file that touches C.  go/ranking and go/retrieval keep the reference's
+// exported signatures (ranking/pagerank.go:14, ranking/term_weighting.go:10,
+// retrieval/main_retrieve.go:15) and call into this package.
+//
+// NOTE: written against the header but NOT compiled in the build image (no Go toolchain
+// there, SURVEY.md §8c); the same entry points are exercised through Python ctypes
+// (spaghettisearch_amd/_lib.py) by the test-suite.
+//
+// Error policy: every non-zero status becomes panic(err), like the reference
+// (pagerank.go:20,29,49,57,76,81; term_weighting.go:14,23,34,48,52).
+package spaghetti
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../spaghettisearch_amd -lspaghetti_rank -Wl,-rpath,${SRCDIR}/../../spaghettisearch_amd
+#include <stdlib.h>
+#include "spaghetti_rank.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"sync"
+	"unsafe"
+)
+
+// Hit mirrors ss_hit.
+type Hit struct {
+	Doc      uint32
+	Title    float64
+	Body     float64
+	PageRank float64
+	Final    float64
+}
+
+type Ctx struct{ h *C.ss_ctx }
+type Graph struct {
+	h   *C.ss_graph
+	ctx *Ctx
+	N   uint64
+}
+type Index struct {
+	h      *C.ss_index
+	ctx    *Ctx
+	NDocs  uint64
+	NTerms uint64
+	NPost  uint64
+}
+type Scorer struct {
+	h   *C.ss_scorer
+	ctx *Ctx
+}
+
+var (
+	once   sync.Once
+	global *Ctx
+)
+
+func check(c *Ctx, rc C.int32_t, what string) {
+	if rc != C.SS_OK {
+		var h *C.ss_ctx
+		if c != nil {
+			h = c.h
+		}
+		panic(fmt.Errorf("%s: status %d: %s", what, int(rc), C.GoString(C.ss_last_error(h))))
+	}
+}
+
+// Default returns the process-wide context on GPU 0 (one process per GPU).
+func Default() *Ctx {
+	once.Do(func() {
+		var h *C.ss_ctx
+		check(nil, C.ss_init(0, &h), "ss_init")
+		global = &Ctx{h}
+	})
+	return global
+}
+
+func u64p(s []uint64) *C.uint64_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+}
+func u32p(s []uint32) *C.uint32_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.uint32_t)(unsafe.Pointer(&s[0]))
+}
+func i32p(s []int32) *C.int32_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.int32_t)(unsafe.Pointer(&s[0]))
+}
+func f32p(s []float32) *C.float {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.float)(unsafe.Pointer(&s[0]))
+}
+func f64p(s []float64) *C.double {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.double)(unsafe.Pointer(&s[0]))
+}
+
+// NewGraph uploads the out-edge CSR of forw[2] (parent -> children).  The library copies the
+// slices before returning (cgo pointer rules), so they may be garbage collected afterwards.
+func (c *Ctx) NewGraph(outPtr []uint64, outDst []uint32) *Graph {
+	n := uint64(len(outPtr) - 1)
+	var h *C.ss_graph
+	check(c, C.ss_graph_create(c.h, C.uint64_t(n), C.uint64_t(len(outDst)), u64p(outPtr), u32p(outDst), 0, 1, &h), "ss_graph_create")
+	return &Graph{h, c, n}
+}
+func (g *Graph) Close() { C.ss_graph_destroy(g.h) }
+
+// PageRank runs all topics to convergence: rank[k*N+v], iters[k].
+func (g *Graph) PageRank(d, eps float64, nTopic []int32) ([]float64, []int32) {
+	k := len(nTopic)
+	rank := make([]float64, uint64(k)*g.N)
+	iters := make([]int32, k)
+	check(g.ctx, C.ss_pagerank_run(g.h, C.double(d), C.double(eps), 0, C.int32_t(k), i32p(nTopic), f64p(rank), i32p(iters)), "ss_pagerank_run")
+	return rank, iters
+}
+
+func (c *Ctx) NewIndex(nDocs uint64, termPtr []uint64, postDoc []uint32, postTf []float32) *Index {
+	var h *C.ss_index
+	nT := uint64(len(termPtr) - 1)
+	check(c, C.ss_index_create(c.h, C.uint64_t(nDocs), C.uint64_t(nT), u64p(termPtr), u32p(postDoc), f32p(postTf), &h), "ss_index_create")
+	return &Index{h, c, nDocs, nT, uint64(len(postDoc))}
+}
+func (ix *Index) Close() { check(ix.ctx, C.ss_index_destroy(ix.h), "ss_index_destroy") }
+
+// TfIdfBuild = ranking.UpdateTermWeights' arithmetic; returns the new weights and magnitudes.
+func (ix *Index) TfIdfBuild(totalDocs uint64) (w []float32, mag []float64) {
+	w = make([]float32, ix.NPost)
+	mag = make([]float64, ix.NDocs)
+	check(ix.ctx, C.ss_tfidf_build(ix.h, C.uint64_t(totalDocs), f32p(w), f64p(mag), nil), "ss_tfidf_build")
+	return
+}
+func (ix *Index) SetWeighted(mag []float64) {
+	check(ix.ctx, C.ss_index_set_weighted(ix.h, f64p(mag)), "ss_index_set_weighted")
+}
+
+func (c *Ctx) NewScorer(title, body *Index) *Scorer {
+	var h *C.ss_scorer
+	check(c, C.ss_scorer_create(c.h, title.h, body.h, &h), "ss_scorer_create")
+	return &Scorer{h, c}
+}
+func (s *Scorer) Close() { C.ss_scorer_destroy(s.h) }
+func (s *Scorer) SetPrior(kTopics int, rank []float64) {
+	check(s.ctx, C.ss_scorer_set_prior(s.h, C.int32_t(kTopics), f64p(rank)), "ss_scorer_set_prior")
+}
+
+// ScoreTopK scores a batch of OR queries; safe to call from many goroutines (the library
+// serialises calls on one context).  topicProbs may be nil (reference default: sqd = 0).
+func (s *Scorer) ScoreTopK(qPtr, qTerms []uint32, queryLen []int32, topicProbs []float64, k int) ([][]Hit, error) {
+	nq := len(qPtr) - 1
+	raw := make([]C.ss_hit, nq*k)
+	nHits := make([]int32, nq)
+	rc := C.ss_score_topk(s.h, C.int32_t(nq), u32p(qPtr), u32p(qTerms), i32p(queryLen), f64p(topicProbs), C.int32_t(k),
+		(*C.ss_hit)(unsafe.Pointer(&raw[0])), i32p(nHits))
+	check(s.ctx, rc, "ss_score_topk")
+	out := make([][]Hit, nq)
+	for q := 0; q < nq; q++ {
+		out[q] = make([]Hit, nHits[q])
+		for i := range out[q] {
+			r := raw[q*k+i]
+			out[q][i] = Hit{uint32(r.doc), float64(r.title), float64(r.body), float64(r.pagerank), float64(r.final)}
+		}
+	}
+	return out, nil
+}

@@ -1,0 +1,122 @@
+"""CPU model of ONE shard of the doc-range-sharded PageRank (test infrastructure).
+
+It follows the same layout and exchange protocol as the HIP library
+(spaghettisearch_amd/csrc/graph.hip + pagerank.hip): nodes ordered
+[non-dangling | dangling], in-degree descending inside a class, dealt round-robin
+to the ranks; every rank's all-gather piece = its non-dangling contribution rows +
+two tail rows (contribution sum, L1 delta).  Used by the gloo world_size-2 test to
+drive spaghettisearch_amd.sharding exactly the way the GPU path does.
+"""
+import numpy as np
+import torch
+
+
+class NumpyShardState:
+    def __init__(self, n_nodes, out_ptr, out_dst, d, eps, n_topic, rank, world, max_iter=0):
+        self.n_nodes, self.rank, self.world = int(n_nodes), rank, world
+        self.d, self.eps, self.max_iter = d, eps, max_iter
+        self.x0 = 1.0 / np.asarray(n_topic, dtype=np.float64)
+        self.k = len(self.x0)
+        out_ptr = np.asarray(out_ptr, dtype=np.int64)
+        out_dst = np.asarray(out_dst, dtype=np.int64)
+        N = self.n_nodes
+        outdeg = np.diff(out_ptr)
+        indeg = np.bincount(out_dst, minlength=N)
+        cls = (outdeg == 0).astype(np.int64)
+        order = np.lexsort((np.arange(N), -indeg, cls))            # class, in-degree desc, id asc
+        n_nd = int((outdeg > 0).sum())
+        tails = 2 if world > 1 else 0
+        self.sl_nd = -(-n_nd // world) + tails
+        nd_sorted, d_sorted = order[:n_nd], order[n_nd:]
+        # internal (table) id of every non-dangling node
+        tab_id = np.full(N, -1, dtype=np.int64)
+        i = np.arange(n_nd)
+        tab_id[nd_sorted] = (i % world) * self.sl_nd + i // world
+        self.own_nd = nd_sorted[rank::world]
+        self.own_d = d_sorted[rank::world]
+        self.own = np.concatenate([self.own_nd, self.own_d])
+        self.outdeg_nd = outdeg[self.own_nd].astype(np.float64)
+        # in-edges of the own rows, sources as table ids
+        src = np.repeat(np.arange(N), outdeg)
+        pos = np.full(N, -1, dtype=np.int64)
+        pos[self.own] = np.arange(len(self.own))
+        m = pos[out_dst] >= 0
+        self.e_row = pos[out_dst[m]]
+        self.e_src = tab_id[src[m]]
+        assert (self.e_src >= 0).all()
+        self.send = np.zeros((self.sl_nd, self.k))
+        self.table = np.zeros((world * self.sl_nd, self.k))
+        self.x = np.zeros((len(self.own), self.k))
+        self.S = np.ones(self.k)
+        self.active = np.ones(self.k, dtype=bool)
+        self.iters = np.zeros(self.k, dtype=np.int32)
+        self.delta = np.zeros(self.k)
+        self.sweep = 0
+        self._begin_pending = False
+
+    # --- state protocol -------------------------------------------------------
+    def exchange_tensors(self):
+        return torch.from_numpy(self.send.reshape(-1)), torch.from_numpy(self.table.reshape(-1))
+
+    def begin(self):
+        self.x[:] = self.x0
+        c = self.d * self.x[:len(self.own_nd)] / self.outdeg_nd[:, None]
+        self._publish(c, np.zeros(self.k))
+        self._begin_pending = True
+
+    def step(self, n=1):
+        assert n == 1
+        if not self.active.any():
+            return
+        y = np.zeros_like(self.x)
+        np.add.at(y, self.e_row, self.table[self.e_src])
+        if self.sweep == 0:
+            y += self.x0                                            # Q4
+        xn = (y + (1.0 - self.d)) / self.S
+        xn[:, ~self.active] = self.x[:, ~self.active]
+        dl = np.abs(xn - self.x).sum(axis=0)
+        dl[~self.active] = 0.0
+        self.x = xn
+        c = self.d * xn[:len(self.own_nd)] / self.outdeg_nd[:, None]
+        self._publish(c, dl)
+
+    def _publish(self, c, dl):
+        self.send[:len(self.own_nd)] = c
+        if self.world > 1:
+            self.send[self.sl_nd - 2] = c.sum(axis=0)
+            self.send[self.sl_nd - 1] = dl
+        else:
+            self.table[:] = self.send
+            self._local = (c.sum(axis=0), dl)
+
+    def finalize(self):
+        if self.world > 1:
+            t = self.table.reshape(self.world, self.sl_nd, self.k)
+            cs, dl = t[:, -2].sum(axis=0), t[:, -1].sum(axis=0)
+        else:
+            cs, dl = self._local
+        tele_n = (1.0 - self.d) * self.n_nodes
+        if self._begin_pending:
+            self.S = cs + tele_n
+            self._begin_pending = False
+            return
+        if not self.active.any():
+            return
+        it = self.sweep + 1
+        for k in range(self.k):
+            if self.active[k]:
+                self.iters[k] = it
+                self.delta[k] = dl[k]
+                cont = dl[k] > self.eps
+                if self.max_iter > 0 and it >= self.max_iter:
+                    cont = False
+                self.active[k] = cont
+                self.S[k] = cs[k] + tele_n
+        self.sweep = it
+
+    def status(self):
+        return {"iters": self.iters.copy(), "n_active": int(self.active.sum()), "sweeps": self.sweep,
+                "delta": self.delta.copy(), "total": self.S.copy()}
+
+    def read_local(self):
+        return self.own.astype(np.uint32), np.ascontiguousarray(self.x.T)
