@@ -12,17 +12,24 @@
 //                               Final = (0.33*sqd+0.38*Title+0.29*Body)*100 (:69)
 //   appendSort + cut util.go:48-54, main_retrieve.go:99-103  descending FinalRank, first k
 //
-// Device design (HBM-bound: 8 B per posting streamed once, 16 B magnitudes per candidate):
-//   * postings stay resident, term-major, doc-sorted; the host plans (it keeps df per term)
-//     and cuts every query's doc range into slices of ~SLICE_TARGET postings -> one workgroup
-//     per (query, slice), thousands of workgroups per 1024-query batch;
-//   * k_score_slices: the workgroup walks its slice in windows of <= CAP postings taken
-//     proportionally from all (term, field) lists, stages the doc ids in LDS, cuts the window at a
-//     common doc bound so that every posting of a doc lands in the same window, accumulates
-//     (title, body) per doc in an LDS hash table with ds atomics (float32 addends summed in float64
-//     are exact, so order does not matter), then scores every touched doc in registers and keeps a
-//     running top-k in LDS (threshold filter + bitonic compaction);
-//   * k_merge_topk: one workgroup per query merges its slices' top-k lists, then re-derives
+// Device design (HBM-bound streaming of posting records):
+//   * scoring layout: one 16-byte record per posting {doc u32, w f32, mag f64}; the document's
+//     field magnitude travels with the posting, so a candidate needs NO random gather (a separate
+//     magnitude table costs a 64-byte line per candidate: 8x the posting bytes at config 3).
+//     A magnitude only matters when the doc has a posting of that field among the query terms
+//     (0/(m*q) is 0 or NaN->0 for every m), so nothing else is needed.
+//   * the host plans (it keeps df per term): duplicates -> multiplicities, unknown terms dropped,
+//     each query's doc range cut into slices of ~SLICE_TARGET postings, longest first;
+//     one workgroup per (query, slice).
+//   * k_score_slices walks its slice in windows of <= CAP postings taken proportionally from all
+//     (term, field) lists; window w+1's records are loaded (one coalesced 16-byte load per lane)
+//     while window w is processed.  Per window: doc ids -> LDS, wave 0 cuts the window at a common
+//     doc bound (every posting of a doc lands in one window), all waves accumulate (title, body)
+//     per doc in an LDS hash table with ds_add_f64 (float32 addends in float64 are exact, so order
+//     is irrelevant), then every touched doc is scored in registers and filtered into a running
+//     top-k (threshold + bitonic compaction).  With a PageRank blend the 128-byte prior row of a
+//     doc is only fetched if an upper bound of its score can still enter the top-k.
+//   * k_merge_topk: one workgroup per query merges its slices' top-k lists, re-derives
 //     title/body/pagerank of the k winners by binary search and writes ss_hit rows.
 //   Ties: ascending doc id (Q10); NaN finals last.
 #include "index.hpp"
@@ -35,36 +42,42 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int CAP = 1024;          // postings per window
-constexpr int HT = 2048;           // hash slots (load factor <= 0.5)
-constexpr int CB = 2048;           // candidate buffer entries (>= 2*k_max... k <= 1024)
+constexpr int PPT = CAP / TPB;     // staged postings per thread
+constexpr int HT = 1536;           // hash slots (load factor <= 0.67)
+constexpr int EPT = HT / TPB;      // hash entries per thread in the scan
 constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS;   // (term, field) lists per query
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr uint64_t SLICE_TARGET = 32768;
+constexpr uint64_t SLICE_TARGET = 65536;
 constexpr uint32_t MAX_SLICES_PER_Q = 256;
+
+struct __attribute__((aligned(16))) Post {
+    uint32_t doc;
+    float w;
+    double mag;
+};
 
 struct SliceDesc {
     uint32_t q;
-    uint32_t dlo, dhi;   // doc range [dlo, dhi)
+    uint32_t dlo, dhi;   // doc range [dlo, dhi); dhi = 0xFFFFFFFF: to the end
     uint32_t pad;
 };
 
 struct ScoreParams {
-    // index
-    const uint64_t* t_ptr; const uint32_t* t_doc; const float* t_w;
-    const uint64_t* b_ptr; const uint32_t* b_doc; const float* b_w;
-    const double* mag2;        // [n_docs][2] = (title, body)
+    const uint64_t* t_ptr; const Post* t_post;
+    const uint64_t* b_ptr; const Post* b_post;
     const double* prior;       // [n_docs][k_topics] or null
     int32_t k_topics;
-    // batch
     const uint32_t* q_off;     // [n_q+1] into dterm/dmult
     const uint32_t* dterm;     // distinct known terms per query, first-occurrence order
     const uint32_t* dmult;     // multiplicity of each
     const double* qmag;        // [n_q] sqrt(queryLength)
     const double* probs;       // [n_q][k_topics] or null
-    const uint32_t* slice_base;// [n_q+1]
-    const SliceDesc* slices;
+    const double* sqd_ub;      // [n_q] upper bound of sqd over all docs (when probs)
+    const uint32_t* slice_base;// [n_q+1] (query order)
+    const SliceDesc* slices;   // query order
+    const uint32_t* order;     // launch order -> slice index (longest first)
     int32_t k;
-    // scratch / outputs
+    int32_t cb;                // candidate buffer entries (power of two >= 2k)
     uint64_t* so_key; uint32_t* so_doc; uint32_t* so_cnt;   // per slice top-k
     ss_hit* hits; int32_t* n_hits;
 };
@@ -79,10 +92,10 @@ __device__ __forceinline__ bool better(uint64_t ka, uint32_t da, uint64_t kb, ui
     return ka > kb || (ka == kb && da < db);
 }
 
-__device__ __forceinline__ uint64_t lower_bound_g(const uint32_t* __restrict__ a, uint64_t lo, uint64_t hi, uint32_t v) {
+__device__ __forceinline__ uint64_t lower_bound_post(const Post* __restrict__ a, uint64_t lo, uint64_t hi, uint32_t v) {
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1; else hi = mid;
+        if (a[mid].doc < v) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -106,16 +119,17 @@ __device__ __forceinline__ double topic_dot(const double* __restrict__ prior, co
 
 // ---- running top-k in LDS ------------------------------------------------------
 struct TopK {
-    uint64_t* key;    // [CB]
-    uint32_t* doc;    // [CB]
-    uint32_t* count;  // shared scalar
+    uint64_t* key;    // [cb]
+    uint32_t* doc;    // [cb]
+    uint32_t* count;  // shared scalar (may run past cb while an overflow is pending)
     uint64_t* thr;    // shared scalar: admit keys >= thr
+    uint32_t cb;
 };
 
-// Sort the candidate buffer descending (better first) and keep the k best. All threads call.
+// Sort the candidate buffer best-first and keep the k best. All threads call.
 __device__ void topk_compact(const TopK& tk, int k) {
     __syncthreads();
-    const uint32_t n = min(*tk.count, (uint32_t)CB);
+    const uint32_t n = min(*tk.count, tk.cb);
     uint32_t n2 = 64;
     while (n2 < n) n2 <<= 1;
     for (uint32_t i = n + threadIdx.x; i < n2; i += TPB) { tk.key[i] = 0ull; tk.doc[i] = EMPTY; }   // worst sentinels
@@ -142,224 +156,279 @@ __device__ void topk_compact(const TopK& tk, int k) {
     __syncthreads();
 }
 
-__device__ __forceinline__ void topk_admit(const TopK& tk, uint64_t key, uint32_t doc) {
-    if (key >= *tk.thr) {
-        const uint32_t i = atomicAdd(tk.count, 1u);
-        if (i < (uint32_t)CB) { tk.key[i] = key; tk.doc[i] = doc; }   // room is guaranteed by the callers
-    }
-}
-
 // ---- K4: score one (query, doc-range slice) --------------------------------------
 __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ht_T = reinterpret_cast<double*>(smem);                    // [HT]
     double* ht_B = ht_T + HT;                                          // [HT]
-    uint64_t* cd_key = reinterpret_cast<uint64_t*>(ht_B + HT);         // [CB]
-    uint64_t* l_cur = cd_key + CB;                                     // [MAXL]
-    uint64_t* l_end = l_cur + MAXL;                                    // [MAXL]
-    double* l_mult = reinterpret_cast<double*>(l_end + MAXL);          // [MAXL]
-    const uint32_t** l_docp = reinterpret_cast<const uint32_t**>(l_mult + MAXL);   // [MAXL]
-    const float** l_wp = reinterpret_cast<const float**>(l_docp + MAXL);           // [MAXL]
-    uint64_t* sc64 = reinterpret_cast<uint64_t*>(l_wp + MAXL);         // [4] scalars: total_rem, thr
-    uint32_t* ht_key = reinterpret_cast<uint32_t*>(sc64 + 4);          // [HT]
-    uint32_t* cd_doc = ht_key + HT;                                    // [CB]
-    uint32_t* s_doc = cd_doc + CB;                                     // [CAP]
-    uint32_t* l_off = s_doc + CAP;                                     // [MAXL+4]
-    uint32_t* l_share = l_off + MAXL + 4;                              // [MAXL]
-    uint32_t* l_cnt = l_share + MAXL;                                  // [MAXL]
+    double* ht_mT = ht_B + HT;                                         // [HT] title magnitude of the doc
+    double* ht_mB = ht_mT + HT;                                        // [HT] body magnitude
+    uint64_t* l_cur = reinterpret_cast<uint64_t*>(ht_mB + HT);         // [MAXL] cursor at the start of the staged window
+    double* l_mult = reinterpret_cast<double*>(l_cur + MAXL);          // [MAXL]
+    const Post** l_post = reinterpret_cast<const Post**>(l_mult + MAXL);   // [MAXL]
+    uint64_t* sc64 = reinterpret_cast<uint64_t*>(l_post + MAXL);       // [2]: thr
+    uint64_t* cd_key = sc64 + 2;                                       // [cb]
+    uint32_t* cd_doc = reinterpret_cast<uint32_t*>(cd_key + p.cb);     // [cb]
+    uint32_t* ht_key = cd_doc + p.cb;                                  // [HT]
+    uint32_t* s_doc = ht_key + HT;                                     // [CAP]
+    uint32_t* l_off = s_doc + CAP;                                     // [2][MAXL+1] plan (double-buffered)
+    uint32_t* l_cnt = l_off + 2 * (MAXL + 1);                          // [MAXL]
     uint32_t* l_field = l_cnt + MAXL;                                  // [MAXL]
     uint32_t* sc32 = l_field + MAXL;                                   // [8] scalars
 
-    uint64_t& total_rem = sc64[0];
     uint32_t& cand_count = sc32[0];
-    uint32_t& dw = sc32[1];
-    uint32_t& wave0_total = sc32[2];
-    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[1]};
+    uint32_t& overflow = sc32[1];
+    uint32_t* n_stage_s = &sc32[2];                                    // [2]
+    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], (uint32_t)p.cb};
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const SliceDesc sd = p.slices[blockIdx.x];
+    const SliceDesc sd = p.slices[p.order[blockIdx.x]];
+    const uint32_t slice_id = p.order[blockIdx.x];
     const uint32_t q = sd.q;
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
     const int L = (int)(2 * nd);
     const double qmag = p.qmag[q];
     const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
+    const double sqd_ub = probs ? p.sqd_ub[q] : 0.0;
 
-    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_T[i] = 0.0; ht_B[i] = 0.0; }
-    if (tid == 0) { cand_count = 0; sc64[1] = 0ull; }
-    if (tid < L) {
-        const uint32_t term = p.dterm[t0 + (tid >> 1)];
-        const int field = tid & 1;                     // 0 = body, 1 = title
-        const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-        const uint32_t* docs = field ? p.t_doc : p.b_doc;
-        const uint64_t p0 = ptr[term], p1 = ptr[term + 1];
-        l_cur[tid] = lower_bound_g(docs, p0, p1, sd.dlo);
-        l_end[tid] = sd.dhi == 0xFFFFFFFFu ? p1 : lower_bound_g(docs, p0, p1, sd.dhi);
-        l_mult[tid] = (double)p.dmult[t0 + (tid >> 1)];
-        l_docp[tid] = docs;
-        l_wp[tid] = field ? p.t_w : p.b_w;
-        l_field[tid] = field;
+    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_T[i] = 0.0; ht_B[i] = 0.0; ht_mT[i] = 1.0; ht_mB[i] = 1.0; }
+    if (tid == 0) { cand_count = 0; overflow = 0; sc64[0] = 0ull; }
+
+    // wave 0 owns the cursors of all lists in registers: lane l -> lists l and l+64
+    uint64_t cur0 = 0, end0 = 0, cur1 = 0, end1 = 0;
+    if (wave == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int l = lane + 64 * h;
+            uint64_t c = 0, e = 0;
+            if (l < L) {
+                const uint32_t term = p.dterm[t0 + (l >> 1)];
+                const int field = l & 1;                   // 0 = body, 1 = title
+                const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
+                const Post* post = field ? p.t_post : p.b_post;
+                const uint64_t p0 = ptr[term], p1 = ptr[term + 1];
+                c = lower_bound_post(post, p0, p1, sd.dlo);
+                e = sd.dhi == 0xFFFFFFFFu ? p1 : lower_bound_post(post, p0, p1, sd.dhi);
+                l_mult[l] = (double)p.dmult[t0 + (l >> 1)];
+                l_post[l] = post;
+                l_field[l] = field;
+            }
+            if (h == 0) { cur0 = c; end0 = e; } else { cur1 = c; end1 = e; }
+        }
     }
+
+    // plan the window that starts at the current cursors into plan buffer `buf` (wave 0 only)
+    auto plan = [&](int buf) {
+        const uint64_t r0 = end0 - cur0, r1 = end1 - cur1;
+        uint64_t tot = r0 + r1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((unsigned long long)tot, off, 64);
+        uint32_t s0 = 0, s1 = 0;
+        if (tot) {
+            if (r0) s0 = (uint32_t)min(r0, 1ull + ((uint64_t)(CAP - L) * r0) / tot);
+            if (r1) s1 = (uint32_t)min(r1, 1ull + ((uint64_t)(CAP - L) * r1) / tot);
+        }
+        uint32_t i0 = s0, i1 = s1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v0 = __shfl_up(i0, off, 64), v1 = __shfl_up(i1, off, 64);
+            if (lane >= off) { i0 += v0; i1 += v1; }
+        }
+        const uint32_t tot0 = __shfl(i0, 63, 64), tot1 = __shfl(i1, 63, 64);
+        uint32_t* off_b = l_off + buf * (MAXL + 1);
+        if (lane < L) { off_b[lane] = i0 - s0; l_cur[lane] = cur0; }
+        if (lane + 64 < L) { off_b[lane + 64] = tot0 + i1 - s1; l_cur[lane + 64] = cur1; }
+        if (lane == 0) { off_b[L] = tot0 + tot1; n_stage_s[buf] = tot0 + tot1; }
+        return s0 | ((uint64_t)s1 << 32);
+    };
+
+    uint64_t shares = 0;    // wave 0: this lane's two shares of the window being processed
+    if (wave == 0) shares = plan(0);
     __syncthreads();
 
-    for (;;) {
-        // (1) remaining postings per list, proportional shares of the window
-        if (tid == 0) { total_rem = 0ull; dw = sd.dhi; }
-        __syncthreads();
-        uint64_t rem = 0;
-        if (tid < L) {
-            rem = l_end[tid] - l_cur[tid];
-            if (rem) atomicAdd(reinterpret_cast<unsigned long long*>(&total_rem), (unsigned long long)rem);
-        }
-        __syncthreads();
-        const uint64_t tot = total_rem;
-        if (tot == 0) break;
-        uint32_t share = 0;
-        if (tid < L && rem) share = (uint32_t)min(rem, 1ull + ((uint64_t)(CAP - L) * rem) / tot);
-        // (2) exclusive prefix of the shares over the (<=128) lists: two waves scan
-        uint32_t incl = share;
-        if (wave < 2) {
+    // records of the window in flight (raw 16-byte vectors: one global_load_dwordx4 per posting)
+    uint4 rec[PPT];
+    uint32_t rl[PPT];
+    auto issue_loads = [&](int buf, uint4 (&r)[PPT], uint32_t (&ll)[PPT]) {
+        const uint32_t* off_b = l_off + buf * (MAXL + 1);
+        const uint32_t n_stage = n_stage_s[buf];
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += v;
-            }
-            if (wave == 0 && lane == 63) wave0_total = incl;
-        }
-        __syncthreads();
-        if (wave == 1) incl += wave0_total;
-        if (tid < MAXL) {
-            if (tid < L) { l_share[tid] = share; l_off[tid] = incl - share; }
-            if (tid == L - 1 || (L == 0 && tid == 0)) l_off[L] = incl;
-        }
-        __syncthreads();
-        const uint32_t n_stage = l_off[L];
-
-        // (3) stage doc ids in LDS (weights stay in registers)
-        uint32_t my_l[CAP / TPB], my_doc[CAP / TPB];
-        float my_w[CAP / TPB];
-#pragma unroll
-        for (int j = 0; j < CAP / TPB; j++) {
+        for (int j = 0; j < PPT; j++) {
             const uint32_t i = tid + j * TPB;
-            my_l[j] = EMPTY;
+            ll[j] = EMPTY;
             if (i < n_stage) {
-                int lo = 0, hi = L;            // largest l with l_off[l] <= i
+                int lo = 0, hi = L;            // largest l with off[l] <= i
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if (l_off[mid] <= i) lo = mid; else hi = mid;
+                    if (off_b[mid] <= i) lo = mid; else hi = mid;
                 }
-                const uint64_t pp = l_cur[lo] + (i - l_off[lo]);
-                const uint32_t d = l_docp[lo][pp];
-                my_l[j] = lo;
-                my_doc[j] = d;
-                my_w[j] = l_wp[lo][pp];
-                s_doc[i] = d;
+                const Post* base = l_field[lo] ? p.t_post : p.b_post;     // kernel-argument pointers: global loads, not flat
+                r[j] = *reinterpret_cast<const uint4*>(base + (l_cur[lo] + (i - off_b[lo])));
+                ll[j] = lo;
             }
         }
-        __syncthreads();
-        // (4) common doc bound: the window holds every posting with doc < dw
-        if (tid < L && l_share[tid]) {
-            const uint64_t e = l_cur[tid] + l_share[tid];
-            if (e < l_end[tid]) atomicMin(&dw, s_doc[l_off[tid] + l_share[tid] - 1] + 1u);
-        }
-        __syncthreads();
-        const uint32_t bound = dw;
-        // (5) how much of each staged chunk is inside the window; advance the cursors
-        if (tid < L) {
-            const uint32_t o = l_off[tid];
-            uint32_t lo = 0, hi = l_share[tid];
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_doc[o + mid] < bound) lo = mid + 1; else hi = mid;
-            }
-            l_cnt[tid] = lo;
-            l_cur[tid] += lo;
-        }
-        __syncthreads();
-        // (6) accumulate per doc (main_retrieve.go:61-69,170-187); float32 addends in float64: exact
+    };
+    issue_loads(0, rec, rl);
+
+    for (int w = 0;; w++) {
+        const int cur = w & 1;
+        const uint32_t n_stage = n_stage_s[cur];
+        if (n_stage == 0) break;
+        const uint32_t* off_c = l_off + cur * (MAXL + 1);
+        // (1) doc ids of the staged records -> LDS
 #pragma unroll
-        for (int j = 0; j < CAP / TPB; j++) {
-            const uint32_t l = my_l[j];
-            if (l != EMPTY && (tid + j * TPB - l_off[l]) < l_cnt[l]) {
-                const uint32_t d = my_doc[j];
-                uint32_t h = (d * 2654435761u) >> (32 - 11);
+        for (int j = 0; j < PPT; j++)
+            if (rl[j] != EMPTY) s_doc[tid + j * TPB] = rec[j].x;
+        __syncthreads();
+        // (2) wave 0: common doc bound, per-list counts, advance cursors, plan the next window
+        if (wave == 0) {
+            const uint32_t s0 = (uint32_t)shares, s1 = (uint32_t)(shares >> 32);
+            uint32_t b = sd.dhi;
+            if (s0 && cur0 + s0 < end0) b = min(b, s_doc[off_c[lane] + s0 - 1] + 1u);
+            if (s1 && cur1 + s1 < end1) b = min(b, s_doc[off_c[lane + 64] + s1 - 1] + 1u);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) b = min(b, (uint32_t)__shfl_xor((int)b, off, 64));
+            if (lane < L) {
+                const uint32_t o = off_c[lane];
+                uint32_t lo = 0, hi = s0;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_doc[o + mid] < b) lo = mid + 1; else hi = mid; }
+                l_cnt[lane] = lo;
+                cur0 += lo;
+            }
+            if (lane + 64 < L) {
+                const uint32_t o = off_c[lane + 64];
+                uint32_t lo = 0, hi = s1;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_doc[o + mid] < b) lo = mid + 1; else hi = mid; }
+                l_cnt[lane + 64] = lo;
+                cur1 += lo;
+            }
+            shares = plan(cur ^ 1);
+        }
+        __syncthreads();
+        // (3) next window's records start to fly; accumulate this window per doc
+        uint4 nrec[PPT];
+        uint32_t nrl[PPT];
+        issue_loads(cur ^ 1, nrec, nrl);
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const uint32_t l = rl[j];
+            if (l != EMPTY && (tid + j * TPB - off_c[l]) < l_cnt[l]) {
+                const uint32_t d = rec[j].x;
+                const double mag = __hiloint2double((int)rec[j].w, (int)rec[j].z);
+                uint32_t h = (((d * 2654435761u) >> 21) * 3u) >> 2;   // [0, 1536)
                 for (;;) {
                     const uint32_t prev = atomicCAS(&ht_key[h], EMPTY, d);
                     if (prev == EMPTY || prev == d) break;
-                    h = (h + 1) & (HT - 1);
+                    h = h + 1 == HT ? 0 : h + 1;
                 }
-                const double v = (double)my_w[j] * l_mult[l];
-                atomicAdd(l_field[l] ? &ht_T[h] : &ht_B[h], v);
+                const double v = (double)__uint_as_float(rec[j].y) * l_mult[l];   // main_retrieve.go:61-69,176-182
+                if (l_field[l]) { atomicAdd(&ht_T[h], v); ht_mT[h] = mag; }
+                else { atomicAdd(&ht_B[h], v); ht_mB[h] = mag; }
             }
         }
-        // (7) room for every doc of this window in the candidate buffer?
-        if (cand_count > (uint32_t)(CB - CAP)) topk_compact(tk, p.k);
         __syncthreads();
-        // (8) score every touched doc (get_metadata.go:31-69), filter, reset the table
-        uint32_t e_doc[HT / TPB];
-        double e_mt[HT / TPB], e_mb[HT / TPB];
+        // (4) score every touched doc (get_metadata.go:31-69), reset the table
+        uint64_t e_key[EPT];
+        uint32_t e_doc[EPT];
+        const uint64_t thr0 = *tk.thr;
 #pragma unroll
-        for (int j = 0; j < HT / TPB; j++) {
-            const uint32_t d = ht_key[tid + j * TPB];
+        for (int j = 0; j < EPT; j++) {
+            const int h = tid + j * TPB;
+            const uint32_t d = ht_key[h];
             e_doc[j] = d;
+            e_key[j] = 0;
             if (d != EMPTY) {
-                const double2 m = *reinterpret_cast<const double2*>(p.mag2 + 2 * (size_t)d);
-                e_mt[j] = m.x;
-                e_mb[j] = m.y;
+                const double T = ht_T[h], B = ht_B[h], mt = ht_mT[h], mb = ht_mB[h];
+                ht_key[h] = EMPTY; ht_T[h] = 0.0; ht_B[h] = 0.0; ht_mT[h] = 1.0; ht_mB[h] = 1.0;
+                double title, body, fin;
+                if (probs) {
+                    // the prior row (128 B) is only fetched if the doc can still make the top-k:
+                    // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
+                    final_rank(T, B, mt, mb, qmag, sqd_ub, title, body, fin);
+                    if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, qmag, topic_dot(p.prior, probs, p.k_topics, d), title, body, fin);
+                    else e_doc[j] = EMPTY;
+                } else {
+                    final_rank(T, B, mt, mb, qmag, 0.0, title, body, fin);
+                }
+                e_key[j] = fkey(fin);
             }
+        }
+        // (5) threshold filter into the candidate buffer; overflow -> compact and retry
+        for (;;) {
+            const uint64_t thr = *tk.thr;
+#pragma unroll
+            for (int j = 0; j < EPT; j++) {
+                if (e_doc[j] != EMPTY) {
+                    if (e_key[j] >= thr) {
+                        const uint32_t i = atomicAdd(tk.count, 1u);
+                        if (i < tk.cb) { tk.key[i] = e_key[j]; tk.doc[i] = e_doc[j]; e_doc[j] = EMPTY; }
+                        else overflow = 1;
+                    } else {
+                        e_doc[j] = EMPTY;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!overflow) break;
+            topk_compact(tk, p.k);         // raises thr; count back to <= k
+            if (tid == 0) overflow = 0;
+            __syncthreads();
         }
 #pragma unroll
-        for (int j = 0; j < HT / TPB; j++) {
-            const uint32_t d = e_doc[j];
-            if (d != EMPTY) {
-                const int h = tid + j * TPB;
-                const double T = ht_T[h], B = ht_B[h];
-                ht_key[h] = EMPTY; ht_T[h] = 0.0; ht_B[h] = 0.0;
-                const double sqd = probs ? topic_dot(p.prior, probs, p.k_topics, d) : 0.0;
-                double title, body, fin;
-                final_rank(T, B, e_mt[j], e_mb[j], qmag, sqd, title, body, fin);
-                topk_admit(tk, fkey(fin), d);
-            }
-        }
-        __syncthreads();
+        for (int j = 0; j < PPT; j++) { rec[j] = nrec[j]; rl[j] = nrl[j]; }
     }
 
     topk_compact(tk, p.k);
     const uint32_t n_out = cand_count;
     for (uint32_t i = tid; i < n_out; i += TPB) {
-        p.so_key[(size_t)blockIdx.x * p.k + i] = cd_key[i];
-        p.so_doc[(size_t)blockIdx.x * p.k + i] = cd_doc[i];
+        p.so_key[(size_t)slice_id * p.k + i] = cd_key[i];
+        p.so_doc[(size_t)slice_id * p.k + i] = cd_doc[i];
     }
-    if (tid == 0) p.so_cnt[blockIdx.x] = n_out;
+    if (tid == 0) p.so_cnt[slice_id] = n_out;
 }
 
-constexpr size_t SCORE_LDS = (size_t)HT * 16 + (size_t)CB * 8 + (size_t)MAXL * 8 * 5 + 4 * 8 +
-                             ((size_t)HT + CB + CAP + (MAXL + 4) + 4 * (size_t)MAXL + 8) * 4;
+size_t score_lds_bytes(int cb) {
+    return (size_t)HT * 8 * 4 + (size_t)MAXL * 8 * 3 + 2 * 8 + (size_t)cb * 12 +
+           ((size_t)HT + CAP + 2 * (MAXL + 1) + 2 * MAXL + 8) * 4 + 16;
+}
 
 // ---- K5: merge a query's slices, explain the winners ------------------------------
 __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
-    __shared__ uint64_t cd_key[CB];
-    __shared__ uint32_t cd_doc[CB];
-    __shared__ double accT[SS_MAX_TOPK], accB[SS_MAX_TOPK];
-    __shared__ uint32_t sc32[2];
-    __shared__ uint64_t sc64[1];
-    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0]};
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* accT = reinterpret_cast<double*>(smem);                    // [k]
+    double* accB = accT + p.k;                                         // [k]
+    double* mgT = accB + p.k;                                          // [k]
+    double* mgB = mgT + p.k;                                           // [k]
+    uint64_t* cd_key = reinterpret_cast<uint64_t*>(mgB + p.k);         // [cb]
+    uint64_t* sc64 = cd_key + p.cb;                                    // [1]
+    uint32_t* cd_doc = reinterpret_cast<uint32_t*>(sc64 + 1);          // [cb]
+    uint32_t* sc32 = cd_doc + p.cb;                                    // [2]
+    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], (uint32_t)p.cb};
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const int k = p.k;
     if (tid == 0) { sc32[0] = 0; sc64[0] = 0ull; }
     __syncthreads();
     for (uint32_t s = p.slice_base[q]; s < p.slice_base[q + 1]; s++) {
-        if (sc32[0] > (uint32_t)(CB - k)) topk_compact(tk, k);
+        const uint32_t n = p.so_cnt[s];                  // <= k, and cb >= 2k: room after a compaction
+        if (sc32[0] + n > tk.cb) topk_compact(tk, k);
         __syncthreads();
-        const uint32_t n = p.so_cnt[s];
-        for (uint32_t i = tid; i < n; i += TPB) topk_admit(tk, p.so_key[(size_t)s * k + i], p.so_doc[(size_t)s * k + i]);
+        const uint64_t thr = *tk.thr;
+        for (uint32_t i = tid; i < n; i += TPB) {
+            const uint64_t key = p.so_key[(size_t)s * k + i];
+            if (key >= thr) {
+                const uint32_t j = atomicAdd(tk.count, 1u);
+                tk.key[j] = key;
+                tk.doc[j] = p.so_doc[(size_t)s * k + i];
+            }
+        }
         __syncthreads();
     }
     topk_compact(tk, k);
     const uint32_t n_out = sc32[0];
 
     // explain: TitleRank/BodyRank of the winners, re-derived from the posting lists
-    for (uint32_t i = tid; i < n_out; i += TPB) { accT[i] = 0.0; accB[i] = 0.0; }
+    for (uint32_t i = tid; i < n_out; i += TPB) { accT[i] = 0.0; accB[i] = 0.0; mgT[i] = 1.0; mgB[i] = 1.0; }
     __syncthreads();
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
     const uint32_t L = 2 * nd;
@@ -368,13 +437,17 @@ __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
         const uint32_t term = p.dterm[t0 + (l >> 1)];
         const int field = l & 1;
         const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-        const uint32_t* docs = field ? p.t_doc : p.b_doc;
+        const Post* post = field ? p.t_post : p.b_post;
         const uint32_t d = cd_doc[i];
         const uint64_t p1 = ptr[term + 1];
-        const uint64_t pos = lower_bound_g(docs, ptr[term], p1, d);
-        if (pos < p1 && docs[pos] == d) {
-            const double v = (double)(field ? p.t_w : p.b_w)[pos] * (double)p.dmult[t0 + (l >> 1)];
-            atomicAdd(field ? &accT[i] : &accB[i], v);
+        const uint64_t pos = lower_bound_post(post, ptr[term], p1, d);
+        if (pos < p1) {
+            const Post r = post[pos];
+            if (r.doc == d) {
+                const double v = (double)r.w * (double)p.dmult[t0 + (l >> 1)];
+                if (field) { atomicAdd(&accT[i], v); mgT[i] = r.mag; }
+                else { atomicAdd(&accB[i], v); mgB[i] = r.mag; }
+            }
         }
     }
     __syncthreads();
@@ -387,7 +460,7 @@ __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
             const uint32_t d = cd_doc[i];
             const double sqd = probs ? topic_dot(p.prior, probs, p.k_topics, d) : 0.0;
             double title, body, fin;
-            final_rank(accT[i], accB[i], p.mag2[2 * (size_t)d], p.mag2[2 * (size_t)d + 1], qmag, sqd, title, body, fin);
+            final_rank(accT[i], accB[i], mgT[i], mgB[i], qmag, sqd, title, body, fin);
             h.doc = d; h.title = title; h.body = body; h.pagerank = sqd; h.final = fin;
         }
         p.hits[(size_t)q * k + i] = h;
@@ -395,9 +468,20 @@ __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
     if (tid == 0) p.n_hits[q] = (int32_t)n_out;
 }
 
-__global__ void k_pack_mag(const double* __restrict__ mt, const double* __restrict__ mb, uint64_t n, double* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { out[2 * i] = mt[i]; out[2 * i + 1] = mb[i]; }
+size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 8 + 16; }
+
+// scoring layout: {doc, w, mag[doc]} per posting
+__global__ void k_pack_posts(const uint32_t* __restrict__ doc, const float* __restrict__ w, const double* __restrict__ mag,
+                             uint64_t n, Post* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        Post r;
+        r.doc = doc[i];
+        r.w = w[i];
+        r.mag = mag[r.doc];
+        out[i] = r;
+    }
 }
 // rank [K][N] topic-major -> prior [N][K] node-major
 __global__ void k_transpose_prior(const double* __restrict__ in, uint64_t n, int K, double* __restrict__ out) {
@@ -407,6 +491,29 @@ __global__ void k_transpose_prior(const double* __restrict__ in, uint64_t n, int
     const int t = (int)(i % K);
     out[i] = in[(uint64_t)t * n + doc];
 }
+// per-topic max / min of the prior (for the score upper bound)
+__global__ void k_prior_extrema(const double* __restrict__ prior, uint64_t n, int K, unsigned long long* __restrict__ mx,
+                                unsigned long long* __restrict__ mn) {
+    const int t = blockIdx.y;
+    double a = -INFINITY, b = INFINITY;
+    bool nan = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const double v = prior[i * K + t];
+        if (v != v) nan = true;
+        a = fmax(a, v);
+        b = fmin(b, v);
+    }
+    if (nan) { a = INFINITY; b = -INFINITY; }
+    atomicMax(&mx[t], (unsigned long long)fkey(a));
+    atomicMin(&mn[t], (unsigned long long)fkey(b));
+}
+
+double unkey(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    double d;
+    std::memcpy(&d, &b, 8);
+    return d;
+}
 
 }  // namespace
 
@@ -415,16 +522,23 @@ struct ss_scorer {
     ss_index* title = nullptr;
     ss_index* body = nullptr;
     uint64_t n_docs = 0, n_terms = 0;
-    ss::DevBuf<double> mag2;
+    ss::DevBuf<Post> t_post, b_post;
     ss::DevBuf<double> prior;
+    std::vector<double> prior_max, prior_min;   // per topic
     int k_topics = 0;
+    int lds_attr = 0;
     // per-call workspaces, grow-only (no hipMalloc/hipFree on the steady-state query path)
-    ss::DevBuf<uint32_t> d_qoff, d_dterm, d_dmult, d_sbase, d_so_doc, d_so_cnt;
-    ss::DevBuf<double> d_qmag, d_probs;
-    ss::DevBuf<SliceDesc> d_slices;
+    ss::DevBuf<unsigned char> d_plan;
+    unsigned char* h_plan = nullptr;            // pinned staging for the plan
+    size_t h_plan_cap = 0;
+    ss::DevBuf<double> d_probs;
     ss::DevBuf<uint64_t> d_so_key;
+    ss::DevBuf<uint32_t> d_so_doc, d_so_cnt;
     ss::DevBuf<ss_hit> d_hits;
     ss::DevBuf<int32_t> d_nhits;
+    ~ss_scorer() {
+        if (h_plan) (void)hipHostFree(h_plan);
+    }
 };
 
 namespace {
@@ -433,6 +547,7 @@ hipError_t ensure(ss::DevBuf<T>& b, size_t n) {
     if (b.p && b.n >= n) return hipSuccess;
     return b.alloc(n + n / 2 + 16);
 }
+size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 }  // namespace
 
 extern "C" {
@@ -456,12 +571,17 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     s->body = body;
     s->n_docs = title->n_docs;
     s->n_terms = title->n_terms;
-    SS_HIP(ctx, s->mag2.alloc(2 * s->n_docs));
-    hipLaunchKernelGGL(k_pack_mag, dim3(ss::div_up(s->n_docs, TPB)), dim3(TPB), 0, ctx->stream, (const double*)title->mag.p,
-                       (const double*)body->mag.p, s->n_docs, s->mag2.p);
+    SS_HIP(ctx, s->t_post.alloc(title->n_post));
+    SS_HIP(ctx, s->b_post.alloc(body->n_post));
+    if (title->n_post)
+        hipLaunchKernelGGL(k_pack_posts, dim3(std::min<unsigned>(ss::div_up(title->n_post, TPB), 16384u)), dim3(TPB), 0, ctx->stream,
+                           (const uint32_t*)title->post_doc.p, (const float*)title->post_w.p, (const double*)title->mag.p,
+                           title->n_post, s->t_post.p);
+    if (body->n_post)
+        hipLaunchKernelGGL(k_pack_posts, dim3(std::min<unsigned>(ss::div_up(body->n_post, TPB), 16384u)), dim3(TPB), 0, ctx->stream,
+                           (const uint32_t*)body->post_doc.p, (const float*)body->post_w.p, (const double*)body->mag.p,
+                           body->n_post, s->b_post.p);
     SS_HIP(ctx, hipGetLastError());
-    SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_slices), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)SCORE_LDS));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     title->users++;
     body->users++;
@@ -495,13 +615,27 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank) 
     }
     const uint64_t n = s->n_docs * (uint64_t)k_topics;
     ss::DevBuf<double> tmp;
+    ss::DevBuf<unsigned long long> ext;
     SS_HIP(ctx, tmp.alloc(n));
+    SS_HIP(ctx, ext.alloc(2 * (size_t)k_topics));
     SS_HIP(ctx, hipMemcpyAsync(tmp.p, rank, n * sizeof(double), hipMemcpyDefault, ctx->stream));
     SS_HIP(ctx, s->prior.alloc(n));
     hipLaunchKernelGGL(k_transpose_prior, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, ctx->stream, (const double*)tmp.p, s->n_docs,
                        k_topics, s->prior.p);
+    SS_HIP(ctx, hipMemsetAsync(ext.p, 0x00, k_topics * sizeof(unsigned long long), ctx->stream));                 // max keys
+    SS_HIP(ctx, hipMemsetAsync(ext.p + k_topics, 0xFF, k_topics * sizeof(unsigned long long), ctx->stream));      // min keys
+    hipLaunchKernelGGL(k_prior_extrema, dim3(std::min<unsigned>(ss::div_up(s->n_docs, TPB), 1024u), k_topics), dim3(TPB), 0,
+                       ctx->stream, (const double*)s->prior.p, s->n_docs, k_topics, ext.p, ext.p + k_topics);
     SS_HIP(ctx, hipGetLastError());
+    std::vector<unsigned long long> h_ext(2 * (size_t)k_topics);
+    SS_HIP(ctx, hipMemcpyAsync(h_ext.data(), ext.p, h_ext.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->prior_max.resize(k_topics);
+    s->prior_min.resize(k_topics);
+    for (int t = 0; t < k_topics; t++) {
+        s->prior_max[t] = unkey(h_ext[t]);
+        s->prior_min[t] = unkey(h_ext[k_topics + t]);
+    }
     s->k_topics = k_topics;
     return SS_OK;
 }
@@ -531,12 +665,19 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
     std::vector<int32_t> h_qlen(n_q);
     if (query_len) SS_HIP(ctx, hipMemcpy(h_qlen.data(), query_len, n_q * sizeof(int32_t), hipMemcpyDefault));
     else for (int q = 0; q < n_q; q++) h_qlen[q] = (int32_t)(h_qptr[q + 1] - h_qptr[q]);
+    std::vector<double> h_probs;
+    const int K = s->k_topics;
+    if (topic_probs) {
+        h_probs.resize((size_t)n_q * K);
+        SS_HIP(ctx, hipMemcpy(h_probs.data(), topic_probs, h_probs.size() * sizeof(double), hipMemcpyDefault));
+    }
 
     const std::vector<uint64_t>& tp = s->title->h_term_ptr;
     const std::vector<uint64_t>& bp = s->body->h_term_ptr;
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
-    std::vector<double> h_qmag(n_q);
+    std::vector<double> h_qmag(n_q), h_ub(n_q, 0.0);
     std::vector<SliceDesc> h_slices;
+    std::vector<uint64_t> h_slice_cost;
     h_dterm.reserve(n_tok);
     h_dmult.reserve(n_tok);
     for (int q = 0; q < n_q; q++) {
@@ -556,6 +697,15 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
             return ctx->fail(SS_ERR_UNSUPPORTED, "ss_score_topk: query %d has more than %d distinct terms", q, SS_MAX_QUERY_TERMS);
         h_qoff[q + 1] = (uint32_t)h_dterm.size();
         h_qmag[q] = std::sqrt((double)h_qlen[q]);               // get_metadata.go:53
+        if (topic_probs) {
+            // upper bound of sqd over all docs, same operation order as topic_dot (monotone)
+            double ub = 0.0;
+            for (int t = 0; t < K; t++) {
+                const double pt = h_probs[(size_t)q * K + t];
+                ub += pt * (pt >= 0.0 ? s->prior_max[t] : s->prior_min[t]);
+            }
+            h_ub[q] = ub != ub ? INFINITY : ub;
+        }
         uint64_t ns = std::max<uint64_t>(1, (tot + SLICE_TARGET - 1) / SLICE_TARGET);
         ns = std::min<uint64_t>(ns, std::min<uint64_t>(MAX_SLICES_PER_Q, s->n_docs));
         for (uint64_t j = 0; j < ns; j++) {
@@ -565,62 +715,96 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
             sd.dhi = j + 1 == ns ? 0xFFFFFFFFu : (uint32_t)(s->n_docs * (j + 1) / ns);
             sd.pad = 0;
             h_slices.push_back(sd);
+            h_slice_cost.push_back(tot / ns);
         }
         h_sbase[q + 1] = (uint32_t)h_slices.size();
     }
     const size_t n_slices = h_slices.size();
     const size_t n_d = h_dterm.size();
+    std::vector<uint32_t> h_order(n_slices);
+    for (size_t i = 0; i < n_slices; i++) h_order[i] = (uint32_t)i;
+    std::stable_sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b) { return h_slice_cost[a] > h_slice_cost[b]; });
 
-    // ---- device buffers for this call ------------------------------------------------
-    auto& d_qoff = s->d_qoff; auto& d_dterm = s->d_dterm; auto& d_dmult = s->d_dmult; auto& d_sbase = s->d_sbase;
-    auto& d_so_doc = s->d_so_doc; auto& d_so_cnt = s->d_so_cnt; auto& d_qmag = s->d_qmag; auto& d_probs = s->d_probs;
-    auto& d_slices = s->d_slices; auto& d_so_key = s->d_so_key; auto& d_hits = s->d_hits; auto& d_nhits = s->d_nhits;
-    SS_HIP(ctx, ensure(d_qoff, n_q + 1));
-    SS_HIP(ctx, ensure(d_dterm, n_d));
-    SS_HIP(ctx, ensure(d_dmult, n_d));
-    SS_HIP(ctx, ensure(d_sbase, n_q + 1));
-    SS_HIP(ctx, ensure(d_qmag, n_q));
-    SS_HIP(ctx, ensure(d_slices, n_slices));
-    SS_HIP(ctx, ensure(d_so_key, n_slices * k));
-    SS_HIP(ctx, ensure(d_so_doc, n_slices * k));
-    SS_HIP(ctx, ensure(d_so_cnt, n_slices));
-    SS_HIP(ctx, ensure(d_hits, (size_t)n_q * k));
-    SS_HIP(ctx, ensure(d_nhits, n_q));
-    SS_HIP(ctx, hipMemcpyAsync(d_qoff.p, h_qoff.data(), (n_q + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    int cb = 512;
+    while (cb < 2 * k) cb <<= 1;
+
+    // ---- one pinned staging buffer, one H2D copy -------------------------------------
+    size_t o = 0;
+    const size_t o_qoff = o;   o = align16(o + (n_q + 1) * sizeof(uint32_t));
+    const size_t o_dterm = o;  o = align16(o + n_d * sizeof(uint32_t));
+    const size_t o_dmult = o;  o = align16(o + n_d * sizeof(uint32_t));
+    const size_t o_sbase = o;  o = align16(o + (n_q + 1) * sizeof(uint32_t));
+    const size_t o_order = o;  o = align16(o + n_slices * sizeof(uint32_t));
+    const size_t o_qmag = o;   o = align16(o + n_q * sizeof(double));
+    const size_t o_ub = o;     o = align16(o + n_q * sizeof(double));
+    const size_t o_slices = o; o = align16(o + n_slices * sizeof(SliceDesc));
+    const size_t plan_bytes = o;
+    if (s->h_plan_cap < plan_bytes) {
+        if (s->h_plan) (void)hipHostFree(s->h_plan);
+        s->h_plan = nullptr;
+        s->h_plan_cap = 0;
+        SS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_plan), plan_bytes * 2, hipHostMallocDefault));
+        s->h_plan_cap = plan_bytes * 2;
+    }
+    SS_HIP(ctx, ensure(s->d_plan, plan_bytes));
+    unsigned char* hp = s->h_plan;
+    std::memcpy(hp + o_qoff, h_qoff.data(), (n_q + 1) * sizeof(uint32_t));
     if (n_d) {
-        SS_HIP(ctx, hipMemcpyAsync(d_dterm.p, h_dterm.data(), n_d * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        SS_HIP(ctx, hipMemcpyAsync(d_dmult.p, h_dmult.data(), n_d * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        std::memcpy(hp + o_dterm, h_dterm.data(), n_d * sizeof(uint32_t));
+        std::memcpy(hp + o_dmult, h_dmult.data(), n_d * sizeof(uint32_t));
     }
-    SS_HIP(ctx, hipMemcpyAsync(d_sbase.p, h_sbase.data(), (n_q + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    SS_HIP(ctx, hipMemcpyAsync(d_qmag.p, h_qmag.data(), n_q * sizeof(double), hipMemcpyHostToDevice, st));
-    SS_HIP(ctx, hipMemcpyAsync(d_slices.p, h_slices.data(), n_slices * sizeof(SliceDesc), hipMemcpyHostToDevice, st));
+    std::memcpy(hp + o_sbase, h_sbase.data(), (n_q + 1) * sizeof(uint32_t));
+    std::memcpy(hp + o_order, h_order.data(), n_slices * sizeof(uint32_t));
+    std::memcpy(hp + o_qmag, h_qmag.data(), n_q * sizeof(double));
+    std::memcpy(hp + o_ub, h_ub.data(), n_q * sizeof(double));
+    std::memcpy(hp + o_slices, h_slices.data(), n_slices * sizeof(SliceDesc));
+    SS_HIP(ctx, hipMemcpyAsync(s->d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, st));
+    SS_HIP(ctx, ensure(s->d_so_key, n_slices * k));
+    SS_HIP(ctx, ensure(s->d_so_doc, n_slices * k));
+    SS_HIP(ctx, ensure(s->d_so_cnt, n_slices));
+    SS_HIP(ctx, ensure(s->d_hits, (size_t)n_q * k));
+    SS_HIP(ctx, ensure(s->d_nhits, n_q));
     if (topic_probs) {
-        SS_HIP(ctx, ensure(d_probs, (size_t)n_q * s->k_topics));
-        SS_HIP(ctx, hipMemcpyAsync(d_probs.p, topic_probs, (size_t)n_q * s->k_topics * sizeof(double), hipMemcpyDefault, st));
+        SS_HIP(ctx, ensure(s->d_probs, (size_t)n_q * K));
+        SS_HIP(ctx, hipMemcpyAsync(s->d_probs.p, topic_probs, (size_t)n_q * K * sizeof(double), hipMemcpyDefault, st));
     }
 
+    const unsigned char* dp = s->d_plan.p;
     ScoreParams p{};
-    p.t_ptr = s->title->term_ptr.p; p.t_doc = s->title->post_doc.p; p.t_w = s->title->post_w.p;
-    p.b_ptr = s->body->term_ptr.p; p.b_doc = s->body->post_doc.p; p.b_w = s->body->post_w.p;
-    p.mag2 = s->mag2.p;
-    p.prior = s->k_topics ? s->prior.p : nullptr;
-    p.k_topics = s->k_topics;
-    p.q_off = d_qoff.p; p.dterm = d_dterm.p; p.dmult = d_dmult.p; p.qmag = d_qmag.p;
-    p.probs = topic_probs ? d_probs.p : nullptr;
-    p.slice_base = d_sbase.p; p.slices = d_slices.p;
+    p.t_ptr = s->title->term_ptr.p; p.t_post = s->t_post.p;
+    p.b_ptr = s->body->term_ptr.p; p.b_post = s->b_post.p;
+    p.prior = K ? s->prior.p : nullptr;
+    p.k_topics = K;
+    p.q_off = reinterpret_cast<const uint32_t*>(dp + o_qoff);
+    p.dterm = reinterpret_cast<const uint32_t*>(dp + o_dterm);
+    p.dmult = reinterpret_cast<const uint32_t*>(dp + o_dmult);
+    p.qmag = reinterpret_cast<const double*>(dp + o_qmag);
+    p.probs = topic_probs ? s->d_probs.p : nullptr;
+    p.sqd_ub = reinterpret_cast<const double*>(dp + o_ub);
+    p.slice_base = reinterpret_cast<const uint32_t*>(dp + o_sbase);
+    p.slices = reinterpret_cast<const SliceDesc*>(dp + o_slices);
+    p.order = reinterpret_cast<const uint32_t*>(dp + o_order);
     p.k = k;
-    p.so_key = d_so_key.p; p.so_doc = d_so_doc.p; p.so_cnt = d_so_cnt.p;
-    p.hits = d_hits.p; p.n_hits = d_nhits.p;
+    p.cb = cb;
+    p.so_key = s->d_so_key.p; p.so_doc = s->d_so_doc.p; p.so_cnt = s->d_so_cnt.p;
+    p.hits = s->d_hits.p; p.n_hits = s->d_nhits.p;
 
+    const size_t lds_score = score_lds_bytes(cb), lds_merge = merge_lds_bytes(k, cb);
+    if (s->lds_attr < cb) {
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_slices), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_score));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_topk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)merge_lds_bytes(SS_MAX_TOPK, cb)));
+        s->lds_attr = cb;
+    }
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
-    hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_slices), dim3(TPB), SCORE_LDS, st, p);
-    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB), 0, st, p);
+    hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_slices), dim3(TPB), lds_score, st, p);
+    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB), lds_merge, st, p);
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
     ctx->ev_valid[1] = true;
     SS_HIP(ctx, hipGetLastError());
-    SS_HIP(ctx, hipMemcpyAsync(hits_out, d_hits.p, (size_t)n_q * k * sizeof(ss_hit), hipMemcpyDefault, st));
-    SS_HIP(ctx, hipMemcpyAsync(n_hits_out, d_nhits.p, n_q * sizeof(int32_t), hipMemcpyDefault, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));   // the host plan vectors above are released on return
+    SS_HIP(ctx, hipMemcpyAsync(hits_out, s->d_hits.p, (size_t)n_q * k * sizeof(ss_hit), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipMemcpyAsync(n_hits_out, s->d_nhits.p, n_q * sizeof(int32_t), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));   // the pinned plan buffer is reused by the next call
     return SS_OK;
 }
 

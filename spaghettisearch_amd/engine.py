@@ -220,13 +220,22 @@ class Scorer:
         self.k_topics = int(rank.shape[0])
         check(self.ctx.lib.ss_scorer_set_prior(self.h, self.k_topics, _ptr(rank)), self.ctx.h)
 
-    def score_topk(self, q_ptr, q_terms, k: int, query_len=None, topic_probs=None):
-        """-> (hits [n_q][k] HIT_DTYPE, n_hits [n_q] int32)."""
+    def score_topk(self, q_ptr, q_terms, k: int, query_len=None, topic_probs=None, out=None):
+        """-> (hits [n_q][k] HIT_DTYPE, n_hits [n_q] int32).
+        out=(hits_buf, n_hits_buf): optional device-resident outputs (torch uint8 tensor of
+        n_q*k*40 bytes and int32 tensor of n_q) — results stay in HBM and `out` is returned."""
         q_ptr = _as(q_ptr, "uint32")
         q_terms = _as(q_terms, "uint32")
         query_len = _as(query_len, "int32")
         topic_probs = _as(topic_probs, "float64")
         n_q = int(q_ptr.shape[0]) - 1
+        if out is not None:
+            hits, n_hits = out
+            if hits.numel() * hits.element_size() < n_q * k * HIT_DTYPE.itemsize or n_hits.numel() < n_q:
+                raise ValueError("output buffers too small")
+            check(self.ctx.lib.ss_score_topk(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(query_len), _ptr(topic_probs), k,
+                                             _ptr(hits), _ptr(n_hits)), self.ctx.h)
+            return hits, n_hits
         hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
         n_hits = np.zeros(n_q, dtype=np.int32)
         check(self.ctx.lib.ss_score_topk(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(query_len), _ptr(topic_probs), k,
