@@ -40,12 +40,17 @@
 
 namespace {
 
-constexpr int TPB = 256;
-constexpr int CAP = 1024;          // postings per window
-constexpr int PPT = CAP / TPB;     // staged postings per thread
+constexpr int TPB = 512;           // k_score_slices workgroup
+constexpr int TPB_M = 256;         // k_merge_topk workgroup
+constexpr int CAP = 1024;          // postings per window (capacity)
+constexpr int TARGET = 880;        // planned postings per window (head-room for the spread around the plan)
+constexpr int PPT = CAP / TPB;     // records per thread
 constexpr int HT = 1536;           // hash slots (load factor <= 0.67)
 constexpr int EPT = HT / TPB;      // hash entries per thread in the scan
 constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS;   // (term, field) lists per query
+constexpr int TBL_CAP = 4096;      // window-cursor table entries: (n_win+1) * L <= TBL_CAP
+constexpr int OFF_CAP = 4864;      // window-offset table entries: n_win * (L+1) <= OFF_CAP
+constexpr int MAX_WIN = 1023;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint64_t SLICE_TARGET = 65536;
 constexpr uint32_t MAX_SLICES_PER_Q = 256;
@@ -88,6 +93,10 @@ __device__ __forceinline__ uint64_t fkey(double f) {
     const uint64_t b = (uint64_t)__double_as_longlong(f);
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
+__device__ __forceinline__ double funkey(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
 __device__ __forceinline__ bool better(uint64_t ka, uint32_t da, uint64_t kb, uint32_t db) {
     return ka > kb || (ka == kb && da < db);
 }
@@ -117,26 +126,33 @@ __device__ __forceinline__ double topic_dot(const double* __restrict__ prior, co
     return sqd;
 }
 
+// Workgroup barrier that does NOT drain the vector-memory counter: the next window's records stay
+// in flight across it (a __syncthreads() would emit s_waitcnt vmcnt(0), cdna_hip_programming.md §5
+// "Pipelining across barriers").  LDS traffic is complete after lgkmcnt(0).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- running top-k in LDS ------------------------------------------------------
 struct TopK {
     uint64_t* key;    // [cb]
     uint32_t* doc;    // [cb]
     uint32_t* count;  // shared scalar (may run past cb while an overflow is pending)
     uint64_t* thr;    // shared scalar: admit keys >= thr
+    float* thr_f;     // shared scalar: float lower bound of the threshold score (-inf while fewer than k)
     uint32_t cb;
 };
 
 // Sort the candidate buffer best-first and keep the k best. All threads call.
 __device__ void topk_compact(const TopK& tk, int k) {
-    __syncthreads();
+    lds_barrier();
+    const uint32_t nthr = blockDim.x;
     const uint32_t n = min(*tk.count, tk.cb);
     uint32_t n2 = 64;
     while (n2 < n) n2 <<= 1;
-    for (uint32_t i = n + threadIdx.x; i < n2; i += TPB) { tk.key[i] = 0ull; tk.doc[i] = EMPTY; }   // worst sentinels
-    __syncthreads();
+    for (uint32_t i = n + threadIdx.x; i < n2; i += nthr) { tk.key[i] = 0ull; tk.doc[i] = EMPTY; }   // worst sentinels
+    lds_barrier();
     for (uint32_t size = 2; size <= n2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t i = threadIdx.x; i < (n2 >> 1); i += TPB) {
+            for (uint32_t i = threadIdx.x; i < (n2 >> 1); i += nthr) {
                 const uint32_t lo = 2 * i - (i & (stride - 1));
                 const uint32_t hi = lo + stride;
                 const bool desc = ((lo & size) == 0);     // this run sorted best-first
@@ -145,237 +161,284 @@ __device__ void topk_compact(const TopK& tk, int k) {
                 const bool swap = desc ? better(kb, db, ka, da) : better(ka, da, kb, db);
                 if (swap) { tk.key[lo] = kb; tk.key[hi] = ka; tk.doc[lo] = db; tk.doc[hi] = da; }
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
     if (threadIdx.x == 0) {
         const uint32_t keep = min(n, (uint32_t)k);
         *tk.count = keep;
-        *tk.thr = keep == (uint32_t)k ? tk.key[k - 1] : 0ull;
+        const bool full = keep == (uint32_t)k;
+        *tk.thr = full ? tk.key[k - 1] : 0ull;
+        float tf = -INFINITY;
+        if (full && tk.key[k - 1] != 0ull) tf = __double2float_rd(funkey(tk.key[k - 1]));
+        *tk.thr_f = tf;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // ---- K4: score one (query, doc-range slice) --------------------------------------
 __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* ht_T = reinterpret_cast<double*>(smem);                    // [HT]
-    double* ht_B = ht_T + HT;                                          // [HT]
-    double* ht_mT = ht_B + HT;                                         // [HT] title magnitude of the doc
-    double* ht_mB = ht_mT + HT;                                        // [HT] body magnitude
-    uint64_t* l_cur = reinterpret_cast<uint64_t*>(ht_mB + HT);         // [MAXL] cursor at the start of the staged window
-    double* l_mult = reinterpret_cast<double*>(l_cur + MAXL);          // [MAXL]
-    const Post** l_post = reinterpret_cast<const Post**>(l_mult + MAXL);   // [MAXL]
-    uint64_t* sc64 = reinterpret_cast<uint64_t*>(l_post + MAXL);       // [2]: thr
+    double* ht_T = reinterpret_cast<double*>(smem);                    // [HT] TitleRank accumulators
+    double* ht_B = ht_T + HT;                                          // [HT] BodyRank accumulators
+    double* s_mag = ht_B + HT;                                         // [CAP] field magnitude carried by record i of the window
+    uint64_t* l_base = reinterpret_cast<uint64_t*>(s_mag + CAP);       // [MAXL] start of the term's list in its record array
+    double* l_mult = reinterpret_cast<double*>(l_base + MAXL);         // [MAXL]
+    uint64_t* sc64 = reinterpret_cast<uint64_t*>(l_mult + MAXL);       // [2]: thr
     uint64_t* cd_key = sc64 + 2;                                       // [cb]
     uint32_t* cd_doc = reinterpret_cast<uint32_t*>(cd_key + p.cb);     // [cb]
     uint32_t* ht_key = cd_doc + p.cb;                                  // [HT]
-    uint32_t* s_doc = ht_key + HT;                                     // [CAP]
-    uint32_t* l_off = s_doc + CAP;                                     // [2][MAXL+1] plan (double-buffered)
-    uint32_t* l_cnt = l_off + 2 * (MAXL + 1);                          // [MAXL]
-    uint32_t* l_field = l_cnt + MAXL;                                  // [MAXL]
-    uint32_t* sc32 = l_field + MAXL;                                   // [8] scalars
+    uint32_t* tbl = ht_key + HT;                                       // [TBL_CAP] cursor of list l at the start of window j: tbl[j*L+l]
+    uint32_t* l_field = tbl + TBL_CAP;                                 // [MAXL]
+    uint32_t* f_cur = l_field + MAXL;                                  // [MAXL] oversize fallback: sub-window start
+    uint32_t* f_nxt = f_cur + MAXL;                                    // [MAXL] oversize fallback: sub-window end
+    uint32_t* sc32 = f_nxt + MAXL;                                     // [8] scalars
+    uint16_t* ht_iT = reinterpret_cast<uint16_t*>(sc32 + 8);           // [HT] a title record of the doc in this window, 0xFFFF = none
+    uint16_t* ht_iB = ht_iT + HT;                                      // [HT] a body record of the doc
+    uint16_t* off = ht_iB + HT;                                        // [OFF_CAP] offset of list l inside window j: off[j*(L+1)+l]
 
     uint32_t& cand_count = sc32[0];
     uint32_t& overflow = sc32[1];
-    uint32_t* n_stage_s = &sc32[2];                                    // [2]
-    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], (uint32_t)p.cb};
+    float* thr_f_s = reinterpret_cast<float*>(&sc32[2]);
+    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], thr_f_s, (uint32_t)p.cb};
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const SliceDesc sd = p.slices[p.order[blockIdx.x]];
+    const int tid = threadIdx.x;
     const uint32_t slice_id = p.order[blockIdx.x];
+    const SliceDesc sd = p.slices[slice_id];
     const uint32_t q = sd.q;
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
     const int L = (int)(2 * nd);
     const double qmag = p.qmag[q];
     const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
     const double sqd_ub = probs ? p.sqd_ub[q] : 0.0;
+    const float sqd_ub_f = probs ? __double2float_ru(sqd_ub) : 0.0f;
+    const float qmag_f = (float)qmag;
 
-    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_T[i] = 0.0; ht_B[i] = 0.0; ht_mT[i] = 1.0; ht_mB[i] = 1.0; }
-    if (tid == 0) { cand_count = 0; overflow = 0; sc64[0] = 0ull; }
+    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_T[i] = 0.0; ht_B[i] = 0.0; ht_iT[i] = 0xFFFFu; ht_iB[i] = 0xFFFFu; }
+    if (tid == 0) { cand_count = 0; overflow = 0; sc64[0] = 0ull; *thr_f_s = -INFINITY; }
 
-    // wave 0 owns the cursors of all lists in registers: lane l -> lists l and l+64
-    uint64_t cur0 = 0, end0 = 0, cur1 = 0, end1 = 0;
-    if (wave == 0) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int l = lane + 64 * h;
-            uint64_t c = 0, e = 0;
-            if (l < L) {
-                const uint32_t term = p.dterm[t0 + (l >> 1)];
-                const int field = l & 1;                   // 0 = body, 1 = title
-                const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-                const Post* post = field ? p.t_post : p.b_post;
-                const uint64_t p0 = ptr[term], p1 = ptr[term + 1];
-                c = lower_bound_post(post, p0, p1, sd.dlo);
-                e = sd.dhi == 0xFFFFFFFFu ? p1 : lower_bound_post(post, p0, p1, sd.dhi);
-                l_mult[l] = (double)p.dmult[t0 + (l >> 1)];
-                l_post[l] = post;
-                l_field[l] = field;
-            }
-            if (h == 0) { cur0 = c; end0 = e; } else { cur1 = c; end1 = e; }
-        }
+    // ---- slice set-up: where every list enters and leaves the slice's doc range ----
+    uint32_t* t_lo = tbl;                   // row 0 of the table
+    uint32_t* t_hi = f_nxt;                 // parked here until n_win is known
+    if (tid < L) {
+        const uint32_t term = p.dterm[t0 + (tid >> 1)];
+        const int field = tid & 1;                     // 0 = body, 1 = title
+        const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
+        const Post* post = field ? p.t_post : p.b_post;
+        const uint64_t p0 = ptr[term], p1 = ptr[term + 1];
+        l_base[tid] = p0;
+        t_lo[tid] = (uint32_t)(lower_bound_post(post, p0, p1, sd.dlo) - p0);
+        t_hi[tid] = (uint32_t)((sd.dhi == 0xFFFFFFFFu ? p1 : lower_bound_post(post, p0, p1, sd.dhi)) - p0);
+        l_mult[tid] = (double)p.dmult[t0 + (tid >> 1)];
+        l_field[tid] = field;
     }
-
-    // plan the window that starts at the current cursors into plan buffer `buf` (wave 0 only)
-    auto plan = [&](int buf) {
-        const uint64_t r0 = end0 - cur0, r1 = end1 - cur1;
-        uint64_t tot = r0 + r1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((unsigned long long)tot, off, 64);
-        uint32_t s0 = 0, s1 = 0;
-        if (tot) {
-            if (r0) s0 = (uint32_t)min(r0, 1ull + ((uint64_t)(CAP - L) * r0) / tot);
-            if (r1) s1 = (uint32_t)min(r1, 1ull + ((uint64_t)(CAP - L) * r1) / tot);
+    __syncthreads();
+    // every thread: total, driver (longest list in the slice), number of windows
+    uint32_t tot = 0, drv = 0, drv_len = 0;
+    for (int l = 0; l < L; l++) {
+        const uint32_t len = t_hi[l] - t_lo[l];
+        tot += len;
+        if (len > drv_len) { drv_len = len; drv = l; }
+    }
+    int n_win = 0;
+    if (tot) {
+        n_win = (int)((tot + TARGET - 1) / TARGET);
+        n_win = min(n_win, min(MAX_WIN, min(TBL_CAP / L - 1, OFF_CAP / (L + 1))));
+        n_win = max(n_win, 1);
+    }
+    // window j covers docs [b_j, b_{j+1}), b_j = doc of the driver's record at j/n_win of its run:
+    // all cursors are known up front (no per-window serial planning; windows fill evenly because
+    // the other lists simply contribute whatever falls into the driver's doc range)
+    const Post* drv_post = l_field[drv] ? p.t_post : p.b_post;
+    const uint64_t drv_base = l_base[drv] + t_lo[drv];
+    for (int idx = tid; idx < (n_win - 1) * L; idx += TPB) {
+        const int j = idx / L + 1, l = idx - (j - 1) * L;
+        const uint32_t b = drv_post[drv_base + (uint64_t)j * drv_len / n_win].doc;
+        const Post* post = l_field[l] ? p.t_post : p.b_post;
+        tbl[j * L + l] = (uint32_t)(lower_bound_post(post, l_base[l] + t_lo[l], l_base[l] + t_hi[l], b) - l_base[l]);
+    }
+    __syncthreads();
+    if (tid < L && n_win) tbl[n_win * L + tid] = t_hi[tid];
+    __syncthreads();
+    for (int j = tid; j < n_win; j += TPB) {
+        uint32_t run = 0;
+        for (int l = 0; l < L; l++) {
+            off[j * (L + 1) + l] = (uint16_t)min(run, 0xFFFFu);
+            run += tbl[(j + 1) * L + l] - tbl[j * L + l];
         }
-        uint32_t i0 = s0, i1 = s1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v0 = __shfl_up(i0, off, 64), v1 = __shfl_up(i1, off, 64);
-            if (lane >= off) { i0 += v0; i1 += v1; }
-        }
-        const uint32_t tot0 = __shfl(i0, 63, 64), tot1 = __shfl(i1, 63, 64);
-        uint32_t* off_b = l_off + buf * (MAXL + 1);
-        if (lane < L) { off_b[lane] = i0 - s0; l_cur[lane] = cur0; }
-        if (lane + 64 < L) { off_b[lane + 64] = tot0 + i1 - s1; l_cur[lane + 64] = cur1; }
-        if (lane == 0) { off_b[L] = tot0 + tot1; n_stage_s[buf] = tot0 + tot1; }
-        return s0 | ((uint64_t)s1 << 32);
-    };
-
-    uint64_t shares = 0;    // wave 0: this lane's two shares of the window being processed
-    if (wave == 0) shares = plan(0);
+        off[j * (L + 1) + L] = (uint16_t)min(run, 0xFFFFu);      // > CAP: oversize window (fallback below)
+    }
     __syncthreads();
 
-    // records of the window in flight (raw 16-byte vectors: one global_load_dwordx4 per posting)
+    // records of one window: raw 16-byte vectors (one global_load_dwordx4 per posting)
     uint4 rec[PPT];
     uint32_t rl[PPT];
-    auto issue_loads = [&](int buf, uint4 (&r)[PPT], uint32_t (&ll)[PPT]) {
-        const uint32_t* off_b = l_off + buf * (MAXL + 1);
-        const uint32_t n_stage = n_stage_s[buf];
+    auto load_window = [&](int j) {
+        const uint16_t* off_j = off + j * (L + 1);
+        const uint32_t* tbl_j = tbl + j * L;
+        const uint32_t n = off_j[L];
 #pragma unroll
-        for (int j = 0; j < PPT; j++) {
-            const uint32_t i = tid + j * TPB;
-            ll[j] = EMPTY;
-            if (i < n_stage) {
+        for (int r = 0; r < PPT; r++) {
+            const uint32_t i = tid + r * TPB;
+            rl[r] = EMPTY;
+            if (i < n) {
                 int lo = 0, hi = L;            // largest l with off[l] <= i
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if (off_b[mid] <= i) lo = mid; else hi = mid;
+                    if (off_j[mid] <= i) lo = mid; else hi = mid;
                 }
                 const Post* base = l_field[lo] ? p.t_post : p.b_post;     // kernel-argument pointers: global loads, not flat
-                r[j] = *reinterpret_cast<const uint4*>(base + (l_cur[lo] + (i - off_b[lo])));
-                ll[j] = lo;
+                rec[r] = *reinterpret_cast<const uint4*>(base + (l_base[lo] + tbl_j[lo] + (i - off_j[lo])));
+                rl[r] = lo;
             }
         }
     };
-    issue_loads(0, rec, rl);
-
-    for (int w = 0;; w++) {
-        const int cur = w & 1;
-        const uint32_t n_stage = n_stage_s[cur];
-        if (n_stage == 0) break;
-        const uint32_t* off_c = l_off + cur * (MAXL + 1);
-        // (1) doc ids of the staged records -> LDS
+    // accumulate the loaded records per doc (main_retrieve.go:61-69,170-187); float32 addends in float64: exact
+    auto insert_records = [&]() {
 #pragma unroll
-        for (int j = 0; j < PPT; j++)
-            if (rl[j] != EMPTY) s_doc[tid + j * TPB] = rec[j].x;
-        __syncthreads();
-        // (2) wave 0: common doc bound, per-list counts, advance cursors, plan the next window
-        if (wave == 0) {
-            const uint32_t s0 = (uint32_t)shares, s1 = (uint32_t)(shares >> 32);
-            uint32_t b = sd.dhi;
-            if (s0 && cur0 + s0 < end0) b = min(b, s_doc[off_c[lane] + s0 - 1] + 1u);
-            if (s1 && cur1 + s1 < end1) b = min(b, s_doc[off_c[lane + 64] + s1 - 1] + 1u);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) b = min(b, (uint32_t)__shfl_xor((int)b, off, 64));
-            if (lane < L) {
-                const uint32_t o = off_c[lane];
-                uint32_t lo = 0, hi = s0;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_doc[o + mid] < b) lo = mid + 1; else hi = mid; }
-                l_cnt[lane] = lo;
-                cur0 += lo;
-            }
-            if (lane + 64 < L) {
-                const uint32_t o = off_c[lane + 64];
-                uint32_t lo = 0, hi = s1;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_doc[o + mid] < b) lo = mid + 1; else hi = mid; }
-                l_cnt[lane + 64] = lo;
-                cur1 += lo;
-            }
-            shares = plan(cur ^ 1);
-        }
-        __syncthreads();
-        // (3) next window's records start to fly; accumulate this window per doc
-        uint4 nrec[PPT];
-        uint32_t nrl[PPT];
-        issue_loads(cur ^ 1, nrec, nrl);
-#pragma unroll
-        for (int j = 0; j < PPT; j++) {
-            const uint32_t l = rl[j];
-            if (l != EMPTY && (tid + j * TPB - off_c[l]) < l_cnt[l]) {
-                const uint32_t d = rec[j].x;
-                const double mag = __hiloint2double((int)rec[j].w, (int)rec[j].z);
+        for (int r = 0; r < PPT; r++) {
+            const uint32_t l = rl[r];
+            if (l != EMPTY) {
+                const uint32_t i = tid + r * TPB;
+                const uint32_t d = rec[r].x;
                 uint32_t h = (((d * 2654435761u) >> 21) * 3u) >> 2;   // [0, 1536)
                 for (;;) {
                     const uint32_t prev = atomicCAS(&ht_key[h], EMPTY, d);
                     if (prev == EMPTY || prev == d) break;
                     h = h + 1 == HT ? 0 : h + 1;
                 }
-                const double v = (double)__uint_as_float(rec[j].y) * l_mult[l];   // main_retrieve.go:61-69,176-182
-                if (l_field[l]) { atomicAdd(&ht_T[h], v); ht_mT[h] = mag; }
-                else { atomicAdd(&ht_B[h], v); ht_mB[h] = mag; }
+                const double v = (double)__uint_as_float(rec[r].y) * l_mult[l];
+                s_mag[i] = __hiloint2double((int)rec[r].w, (int)rec[r].z);
+                // all records of one (doc, field) carry the same magnitude: any writer may win
+                if (l_field[l]) { atomicAdd(&ht_T[h], v); ht_iT[h] = (uint16_t)i; }
+                else { atomicAdd(&ht_B[h], v); ht_iB[h] = (uint16_t)i; }
             }
         }
-        __syncthreads();
-        // (4) score every touched doc (get_metadata.go:31-69), reset the table
+    };
+    // score every touched doc (get_metadata.go:31-69), reset the table, filter into the running top-k
+    auto scan_table = [&]() {
         uint64_t e_key[EPT];
         uint32_t e_doc[EPT];
         const uint64_t thr0 = *tk.thr;
+        const float thr_f = *tk.thr_f;
 #pragma unroll
-        for (int j = 0; j < EPT; j++) {
-            const int h = tid + j * TPB;
+        for (int r = 0; r < EPT; r++) {
+            const int h = tid + r * TPB;
             const uint32_t d = ht_key[h];
-            e_doc[j] = d;
-            e_key[j] = 0;
+            e_doc[r] = d;
+            e_key[r] = 0;
             if (d != EMPTY) {
-                const double T = ht_T[h], B = ht_B[h], mt = ht_mT[h], mb = ht_mB[h];
-                ht_key[h] = EMPTY; ht_T[h] = 0.0; ht_B[h] = 0.0; ht_mT[h] = 1.0; ht_mB[h] = 1.0;
+                const double T = ht_T[h], B = ht_B[h];
+                const uint32_t it = ht_iT[h], ib = ht_iB[h];
+                // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
+                const double mt = it != 0xFFFFu ? s_mag[it] : 1.0;
+                const double mb = ib != 0xFFFFu ? s_mag[ib] : 1.0;
+                ht_key[h] = EMPTY; ht_T[h] = 0.0; ht_B[h] = 0.0; ht_iT[h] = 0xFFFFu; ht_iB[h] = 0xFFFFu;
+                // cheap float estimate first: almost every doc is far below the running threshold.
+                // Skipped only if the estimate, with a 1e-4 relative margin, is clearly below; anything
+                // non-finite falls through to the exact path.
+                const float ea = 38.0f * __fdividef((float)T, (float)mt * qmag_f), eb = 29.0f * __fdividef((float)B, (float)mb * qmag_f),
+                            ec = 33.0f * sqd_ub_f;
+                if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) { e_doc[r] = EMPTY; continue; }
                 double title, body, fin;
                 if (probs) {
                     // the prior row (128 B) is only fetched if the doc can still make the top-k:
                     // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
                     final_rank(T, B, mt, mb, qmag, sqd_ub, title, body, fin);
                     if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, qmag, topic_dot(p.prior, probs, p.k_topics, d), title, body, fin);
-                    else e_doc[j] = EMPTY;
+                    else e_doc[r] = EMPTY;
                 } else {
                     final_rank(T, B, mt, mb, qmag, 0.0, title, body, fin);
                 }
-                e_key[j] = fkey(fin);
+                e_key[r] = fkey(fin);
             }
         }
-        // (5) threshold filter into the candidate buffer; overflow -> compact and retry
+        // threshold filter into the candidate buffer; overflow -> compact and retry
         for (;;) {
             const uint64_t thr = *tk.thr;
 #pragma unroll
-            for (int j = 0; j < EPT; j++) {
-                if (e_doc[j] != EMPTY) {
-                    if (e_key[j] >= thr) {
+            for (int r = 0; r < EPT; r++) {
+                if (e_doc[r] != EMPTY) {
+                    if (e_key[r] >= thr) {
                         const uint32_t i = atomicAdd(tk.count, 1u);
-                        if (i < tk.cb) { tk.key[i] = e_key[j]; tk.doc[i] = e_doc[j]; e_doc[j] = EMPTY; }
+                        if (i < tk.cb) { tk.key[i] = e_key[r]; tk.doc[i] = e_doc[r]; e_doc[r] = EMPTY; }
                         else overflow = 1;
                     } else {
-                        e_doc[j] = EMPTY;
+                        e_doc[r] = EMPTY;
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (!overflow) break;
             topk_compact(tk, p.k);         // raises thr; count back to <= k
             if (tid == 0) overflow = 0;
-            __syncthreads();
+            lds_barrier();
         }
+    };
+
+    if (n_win > 0 && off[L] <= CAP) load_window(0);
+    for (int j = 0; j < n_win; j++) {
+        const uint32_t n = off[j * (L + 1) + L];
+        if (n <= CAP) {
+            insert_records();                                   // waits for window j's records
+            lds_barrier();
+            if (j + 1 < n_win && off[(j + 1) * (L + 1) + L] <= CAP) load_window(j + 1);   // in flight during the scan
+            scan_table();
+        } else {
+            // ---- oversize window (a list is locally much denser than planned): bisect its doc range
+            //      until a piece fits, process the piece, continue.  Rare; no prefetch here. ----
+            if (tid < L) f_cur[tid] = tbl[j * L + tid];
+            uint32_t flo = j == 0 ? sd.dlo : drv_post[l_base[drv] + tbl[j * L + drv]].doc;
+            const uint32_t fend = j + 1 == n_win ? sd.dhi : drv_post[l_base[drv] + tbl[(j + 1) * L + drv]].doc;
+            __syncthreads();
+            for (;;) {
+                uint32_t fhi = fend;
+                uint32_t cnt;
+                for (;;) {
+                    if (tid < L) {
+                        const Post* post = l_field[tid] ? p.t_post : p.b_post;
+                        const uint64_t e = l_base[tid] + tbl[(j + 1) * L + tid];
+                        f_nxt[tid] = fhi == fend ? tbl[(j + 1) * L + tid]
+                                                 : (uint32_t)(lower_bound_post(post, l_base[tid] + f_cur[tid], e, fhi) - l_base[tid]);
+                    }
+                    __syncthreads();
+                    cnt = 0;
+                    for (int l = 0; l < L; l++) cnt += f_nxt[l] - f_cur[l];
+                    if (cnt <= (uint32_t)CAP) break;
+                    // a single doc has at most L <= 128 postings, so the bisection ends
+                    fhi = flo + (uint32_t)(((uint64_t)fhi - flo) >> 1);
+                    __syncthreads();
+                }
 #pragma unroll
-        for (int j = 0; j < PPT; j++) { rec[j] = nrec[j]; rl[j] = nrl[j]; }
+                for (int r = 0; r < PPT; r++) {
+                    const uint32_t i = tid + r * TPB;
+                    rl[r] = EMPTY;
+                    if (i < cnt) {
+                        uint32_t run = 0;
+                        int l = 0;
+                        for (; l < L; l++) {
+                            const uint32_t len = f_nxt[l] - f_cur[l];
+                            if (i < run + len) break;
+                            run += len;
+                        }
+                        const Post* base = l_field[l] ? p.t_post : p.b_post;
+                        rec[r] = *reinterpret_cast<const uint4*>(base + (l_base[l] + f_cur[l] + (i - run)));
+                        rl[r] = l;
+                    }
+                }
+                insert_records();
+                lds_barrier();
+                scan_table();
+                bool done = true;
+                for (int l = 0; l < L; l++) done = done && f_nxt[l] == tbl[(j + 1) * L + l];
+                __syncthreads();
+                if (done) break;
+                if (tid < L) f_cur[tid] = f_nxt[tid];
+                flo = fhi;
+                __syncthreads();
+            }
+            if (j + 1 < n_win && off[(j + 1) * (L + 1) + L] <= CAP) load_window(j + 1);
+        }
     }
 
     topk_compact(tk, p.k);
@@ -388,12 +451,12 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
 }
 
 size_t score_lds_bytes(int cb) {
-    return (size_t)HT * 8 * 4 + (size_t)MAXL * 8 * 3 + 2 * 8 + (size_t)cb * 12 +
-           ((size_t)HT + CAP + 2 * (MAXL + 1) + 2 * MAXL + 8) * 4 + 16;
+    return (size_t)HT * 8 * 2 + (size_t)CAP * 8 + (size_t)MAXL * 8 * 2 + 2 * 8 + (size_t)cb * 12 +
+           ((size_t)HT + TBL_CAP + 3 * MAXL + 8) * 4 + ((size_t)2 * HT + OFF_CAP) * 2 + 16;
 }
 
 // ---- K5: merge a query's slices, explain the winners ------------------------------
-__global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
+__global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* accT = reinterpret_cast<double*>(smem);                    // [k]
     double* accB = accT + p.k;                                         // [k]
@@ -402,8 +465,8 @@ __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
     uint64_t* cd_key = reinterpret_cast<uint64_t*>(mgB + p.k);         // [cb]
     uint64_t* sc64 = cd_key + p.cb;                                    // [1]
     uint32_t* cd_doc = reinterpret_cast<uint32_t*>(sc64 + 1);          // [cb]
-    uint32_t* sc32 = cd_doc + p.cb;                                    // [2]
-    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], (uint32_t)p.cb};
+    uint32_t* sc32 = cd_doc + p.cb;                                    // [4]
+    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), (uint32_t)p.cb};
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const int k = p.k;
@@ -414,7 +477,7 @@ __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
         if (sc32[0] + n > tk.cb) topk_compact(tk, k);
         __syncthreads();
         const uint64_t thr = *tk.thr;
-        for (uint32_t i = tid; i < n; i += TPB) {
+        for (uint32_t i = tid; i < n; i += TPB_M) {
             const uint64_t key = p.so_key[(size_t)s * k + i];
             if (key >= thr) {
                 const uint32_t j = atomicAdd(tk.count, 1u);
@@ -428,11 +491,11 @@ __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
     const uint32_t n_out = sc32[0];
 
     // explain: TitleRank/BodyRank of the winners, re-derived from the posting lists
-    for (uint32_t i = tid; i < n_out; i += TPB) { accT[i] = 0.0; accB[i] = 0.0; mgT[i] = 1.0; mgB[i] = 1.0; }
+    for (uint32_t i = tid; i < n_out; i += TPB_M) { accT[i] = 0.0; accB[i] = 0.0; mgT[i] = 1.0; mgB[i] = 1.0; }
     __syncthreads();
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
     const uint32_t L = 2 * nd;
-    for (uint32_t task = tid; task < n_out * L; task += TPB) {
+    for (uint32_t task = tid; task < n_out * L; task += TPB_M) {
         const uint32_t i = task / L, l = task % L;
         const uint32_t term = p.dterm[t0 + (l >> 1)];
         const int field = l & 1;
@@ -453,7 +516,7 @@ __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
     __syncthreads();
     const double qmag = p.qmag[q];
     const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
-    for (uint32_t i = tid; i < (uint32_t)k; i += TPB) {
+    for (uint32_t i = tid; i < (uint32_t)k; i += TPB_M) {
         ss_hit h;
         h.doc = 0; h._pad = 0; h.title = 0.0; h.body = 0.0; h.pagerank = 0.0; h.final = 0.0;
         if (i < n_out) {
@@ -468,7 +531,7 @@ __global__ __launch_bounds__(TPB) void k_merge_topk(ScoreParams p) {
     if (tid == 0) p.n_hits[q] = (int32_t)n_out;
 }
 
-size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 8 + 16; }
+size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 16 + 16; }
 
 // scoring layout: {doc, w, mag[doc]} per posting
 __global__ void k_pack_posts(const uint32_t* __restrict__ doc, const float* __restrict__ w, const double* __restrict__ mag,
@@ -574,11 +637,11 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     SS_HIP(ctx, s->t_post.alloc(title->n_post));
     SS_HIP(ctx, s->b_post.alloc(body->n_post));
     if (title->n_post)
-        hipLaunchKernelGGL(k_pack_posts, dim3(std::min<unsigned>(ss::div_up(title->n_post, TPB), 16384u)), dim3(TPB), 0, ctx->stream,
+        hipLaunchKernelGGL(k_pack_posts, dim3(std::min<unsigned>(ss::div_up(title->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
                            (const uint32_t*)title->post_doc.p, (const float*)title->post_w.p, (const double*)title->mag.p,
                            title->n_post, s->t_post.p);
     if (body->n_post)
-        hipLaunchKernelGGL(k_pack_posts, dim3(std::min<unsigned>(ss::div_up(body->n_post, TPB), 16384u)), dim3(TPB), 0, ctx->stream,
+        hipLaunchKernelGGL(k_pack_posts, dim3(std::min<unsigned>(ss::div_up(body->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
                            (const uint32_t*)body->post_doc.p, (const float*)body->post_w.p, (const double*)body->mag.p,
                            body->n_post, s->b_post.p);
     SS_HIP(ctx, hipGetLastError());
@@ -620,11 +683,11 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank) 
     SS_HIP(ctx, ext.alloc(2 * (size_t)k_topics));
     SS_HIP(ctx, hipMemcpyAsync(tmp.p, rank, n * sizeof(double), hipMemcpyDefault, ctx->stream));
     SS_HIP(ctx, s->prior.alloc(n));
-    hipLaunchKernelGGL(k_transpose_prior, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, ctx->stream, (const double*)tmp.p, s->n_docs,
+    hipLaunchKernelGGL(k_transpose_prior, dim3(ss::div_up(n, 256)), dim3(256), 0, ctx->stream, (const double*)tmp.p, s->n_docs,
                        k_topics, s->prior.p);
     SS_HIP(ctx, hipMemsetAsync(ext.p, 0x00, k_topics * sizeof(unsigned long long), ctx->stream));                 // max keys
     SS_HIP(ctx, hipMemsetAsync(ext.p + k_topics, 0xFF, k_topics * sizeof(unsigned long long), ctx->stream));      // min keys
-    hipLaunchKernelGGL(k_prior_extrema, dim3(std::min<unsigned>(ss::div_up(s->n_docs, TPB), 1024u), k_topics), dim3(TPB), 0,
+    hipLaunchKernelGGL(k_prior_extrema, dim3(std::min<unsigned>(ss::div_up(s->n_docs, 256), 1024u), k_topics), dim3(256), 0,
                        ctx->stream, (const double*)s->prior.p, s->n_docs, k_topics, ext.p, ext.p + k_topics);
     SS_HIP(ctx, hipGetLastError());
     std::vector<unsigned long long> h_ext(2 * (size_t)k_topics);
@@ -798,7 +861,7 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
     hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_slices), dim3(TPB), lds_score, st, p);
-    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB), lds_merge, st, p);
+    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
     ctx->ev_valid[1] = true;
     SS_HIP(ctx, hipGetLastError());

@@ -123,6 +123,38 @@ def test_three_term_or_batch_like_config3(ss_ctx, oracle):
         close_all(sc, ti, bi)
 
 
+def test_oversize_window_fallback(ss_ctx, oracle):
+    # a short list that is locally far denser than the driver list: the planned window overflows its
+    # capacity and the kernel has to bisect the window's doc range (score.hip oversize path)
+    n_docs = 1_000_000
+    rng = np.random.default_rng(12)
+    a = np.sort(rng.choice(n_docs, 9000, replace=False)).astype(np.uint32)            # driver: spread out
+    b = (500_000 + np.sort(rng.choice(6000, 4000, replace=False))).astype(np.uint32)  # 4000 docs inside 6000 ids
+    c = np.sort(rng.choice(n_docs, 300, replace=False)).astype(np.uint32)
+    one = np.uint32(777_777)
+    body_docs = [a, b, c, np.array([one], dtype=np.uint32)]
+    title_docs = [a[::7], b[::3], np.zeros(0, np.uint32), np.array([one], dtype=np.uint32)]
+
+    def table(lists, seed):
+        ptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+        doc = np.concatenate(lists).astype(np.uint32)
+        return ptr, doc, synth.make_tf(len(doc), np.random.default_rng(seed))
+    bt, tt = table(body_docs, 1), table(title_docs, 2)
+    wb, mb, _ = oracle.tfidf(*bt, n_docs, n_docs)
+    wt, mt, _ = oracle.tfidf(*tt, n_docs, n_docs)
+    title, body = (tt[0], tt[1], wt), (bt[0], bt[1], wb)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        q_terms = np.array([0, 1, 1, 0, 2, 1, 2, 3, 1, 3], dtype=np.uint32)
+        q_ptr = np.array([0, 2, 5, 7, 8, 10], dtype=np.uint32)
+        for k in (10, 300):
+            hits, n_hits = sc.score_topk(q_ptr, q_terms, k)
+            ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, k)
+            assert_same_hits(hits, n_hits, ref, ref_n)
+    finally:
+        close_all(sc, ti, bi)
+
+
 def test_pagerank_blend(ss_ctx, oracle):
     # Q9: sqd = sum_t topicProbs[t]*PR[doc][t], weight 0.33 (get_metadata.go:39-42,69); nil probs => 0
     n_docs, n_terms, K = 20000, 1000, 16
