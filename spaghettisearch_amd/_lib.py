@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspaghetti_rank.so")
+LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_HERE, "libspaghetti_rank.so")   # SS_LIB_PATH: A/B builds
 
 SS_OK = 0
 SS_MAX_TOPK = 1024

@@ -40,13 +40,16 @@
 
 namespace {
 
-constexpr int TPB = 512;           // k_score_slices workgroup
+#ifndef SS_TPB
+#define SS_TPB 512
+#endif
+constexpr int TPB = SS_TPB;        // k_score_slices workgroup
 constexpr int TPB_M = 256;         // k_merge_topk workgroup
 constexpr int CAP = 1024;          // postings per window (capacity)
 constexpr int TARGET = 880;        // planned postings per window (head-room for the spread around the plan)
 constexpr int PPT = CAP / TPB;     // records per thread
 constexpr int HT = 1536;           // hash slots (load factor <= 0.67)
-constexpr int EPT = HT / TPB;      // hash entries per thread in the scan
+constexpr int EPT = (HT + TPB - 1) / TPB;   // hash entries per thread in the scan
 constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS;   // (term, field) lists per query
 constexpr int TBL_CAP = 4096;      // window-cursor table entries: (n_win+1) * L <= TBL_CAP
 constexpr int OFF_CAP = 4864;      // window-offset table entries: n_win * (L+1) <= OFF_CAP
@@ -126,6 +129,14 @@ __device__ __forceinline__ double topic_dot(const double* __restrict__ prior, co
     return sqd;
 }
 
+#ifdef SS_DIAG
+// Diagnostic build only (make DIAG=1): per-phase s_memtime sums of one wave per block, printed by ss_scorer_destroy.
+__device__ unsigned long long g_stamps[16];
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
 // Workgroup barrier that does NOT drain the vector-memory counter: the next window's records stay
 // in flight across it (a __syncthreads() would emit s_waitcnt vmcnt(0), cdna_hip_programming.md §5
 // "Pipelining across barriers").  LDS traffic is complete after lgkmcnt(0).
@@ -179,9 +190,8 @@ __device__ void topk_compact(const TopK& tk, int k) {
 // ---- K4: score one (query, doc-range slice) --------------------------------------
 __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* ht_T = reinterpret_cast<double*>(smem);                    // [HT] TitleRank accumulators
-    double* ht_B = ht_T + HT;                                          // [HT] BodyRank accumulators
-    double* s_mag = ht_B + HT;                                         // [CAP] field magnitude carried by record i of the window
+    double* ht_TB = reinterpret_cast<double*>(smem);                   // [HT][2] (BodyRank, TitleRank) accumulators of a doc
+    double* s_mag = ht_TB + 2 * HT;                                    // [CAP] field magnitude carried by record i of the window
     uint64_t* l_base = reinterpret_cast<uint64_t*>(s_mag + CAP);       // [MAXL] start of the term's list in its record array
     double* l_mult = reinterpret_cast<double*>(l_base + MAXL);         // [MAXL]
     uint64_t* sc64 = reinterpret_cast<uint64_t*>(l_mult + MAXL);       // [2]: thr
@@ -193,9 +203,8 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     uint32_t* f_cur = l_field + MAXL;                                  // [MAXL] oversize fallback: sub-window start
     uint32_t* f_nxt = f_cur + MAXL;                                    // [MAXL] oversize fallback: sub-window end
     uint32_t* sc32 = f_nxt + MAXL;                                     // [8] scalars
-    uint16_t* ht_iT = reinterpret_cast<uint16_t*>(sc32 + 8);           // [HT] a title record of the doc in this window, 0xFFFF = none
-    uint16_t* ht_iB = ht_iT + HT;                                      // [HT] a body record of the doc
-    uint16_t* off = ht_iB + HT;                                        // [OFF_CAP] offset of list l inside window j: off[j*(L+1)+l]
+    uint32_t* ht_idx = sc32 + 8;                                       // [HT] (body record | title record << 16) of the doc in this window, 0xFFFF = none
+    uint16_t* off = reinterpret_cast<uint16_t*>(ht_idx + HT);          // [OFF_CAP] offset of list l inside window j: off[j*OS+l], count at [j*OS+OS-1]
 
     uint32_t& cand_count = sc32[0];
     uint32_t& overflow = sc32[1];
@@ -203,6 +212,9 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], thr_f_s, (uint32_t)p.cb};
 
     const int tid = threadIdx.x;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)ts; (void)acc;
+    STAMP(ts[7]);
     const uint32_t slice_id = p.order[blockIdx.x];
     const SliceDesc sd = p.slices[slice_id];
     const uint32_t q = sd.q;
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     const float sqd_ub_f = probs ? __double2float_ru(sqd_ub) : 0.0f;
     const float qmag_f = (float)qmag;
 
-    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_T[i] = 0.0; ht_B[i] = 0.0; ht_iT[i] = 0xFFFFu; ht_iB[i] = 0xFFFFu; }
+    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_TB[2 * i] = 0.0; ht_TB[2 * i + 1] = 0.0; ht_idx[i] = 0xFFFFFFFFu; }
     if (tid == 0) { cand_count = 0; overflow = 0; sc64[0] = 0ull; *thr_f_s = -INFINITY; }
 
     // ---- slice set-up: where every list enters and leaves the slice's doc range ----
@@ -243,9 +255,10 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     int n_win = 0;
     if (tot) {
         n_win = (int)((tot + TARGET - 1) / TARGET);
-        n_win = min(n_win, min(MAX_WIN, min(TBL_CAP / L - 1, OFF_CAP / (L + 1))));
+        n_win = min(n_win, min(MAX_WIN, min(TBL_CAP / L - 1, OFF_CAP / (L <= 6 ? 8 : L + 1))));
         n_win = max(n_win, 1);
     }
+    const int OS = L <= 6 ? 8 : L + 1;      // row stride of `off`; the window's record count sits in the row's last entry
     // window j covers docs [b_j, b_{j+1}), b_j = doc of the driver's record at j/n_win of its run:
     // all cursors are known up front (no per-window serial planning; windows fill evenly because
     // the other lists simply contribute whatever falls into the driver's doc range)
@@ -262,11 +275,11 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     __syncthreads();
     for (int j = tid; j < n_win; j += TPB) {
         uint32_t run = 0;
-        for (int l = 0; l < L; l++) {
-            off[j * (L + 1) + l] = (uint16_t)min(run, 0xFFFFu);
-            run += tbl[(j + 1) * L + l] - tbl[j * L + l];
+        for (int l = 0; l < OS - 1; l++) {
+            off[j * OS + l] = l < L ? (uint16_t)min(run, 0xFFFFu) : (uint16_t)0xFFFFu;
+            if (l < L) run += tbl[(j + 1) * L + l] - tbl[j * L + l];
         }
-        off[j * (L + 1) + L] = (uint16_t)min(run, 0xFFFFu);      // > CAP: oversize window (fallback below)
+        off[j * OS + OS - 1] = (uint16_t)min(run, 0xFFFFu);      // > CAP: oversize window (fallback below)
     }
     __syncthreads();
 
@@ -274,81 +287,137 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
     uint4 rec[PPT];
     uint32_t rl[PPT];
     auto load_window = [&](int j) {
-        const uint16_t* off_j = off + j * (L + 1);
         const uint32_t* tbl_j = tbl + j * L;
-        const uint32_t n = off_j[L];
+        if (L <= 6) {
+            // the whole offset row in one 16-byte LDS read; list of record i by comparisons in registers
+            const uint4 o = *reinterpret_cast<const uint4*>(off + j * 8);
+            const uint32_t o1 = o.x >> 16, o2 = o.y & 0xFFFFu, o3 = o.y >> 16, o4 = o.z & 0xFFFFu, o5 = o.z >> 16, n = o.w >> 16;
 #pragma unroll
-        for (int r = 0; r < PPT; r++) {
-            const uint32_t i = tid + r * TPB;
-            rl[r] = EMPTY;
-            if (i < n) {
-                int lo = 0, hi = L;            // largest l with off[l] <= i
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (off_j[mid] <= i) lo = mid; else hi = mid;
+            for (int r = 0; r < PPT; r++) {
+                const uint32_t i = tid + r * TPB;
+                rl[r] = EMPTY;
+                if (i < n) {
+                    uint32_t l = 0, ol = 0;     // padding entries are 0xFFFF: never <= i
+                    if (i >= o1) { l = 1; ol = o1; }
+                    if (i >= o2) { l = 2; ol = o2; }
+                    if (i >= o3) { l = 3; ol = o3; }
+                    if (i >= o4) { l = 4; ol = o4; }
+                    if (i >= o5) { l = 5; ol = o5; }
+                    const Post* base = (l & 1) ? p.t_post : p.b_post;         // kernel-argument pointers: global loads, not flat
+                    rec[r] = *reinterpret_cast<const uint4*>(base + (l_base[l] + tbl_j[l] + (i - ol)));
+                    rl[r] = l;
                 }
-                const Post* base = l_field[lo] ? p.t_post : p.b_post;     // kernel-argument pointers: global loads, not flat
-                rec[r] = *reinterpret_cast<const uint4*>(base + (l_base[lo] + tbl_j[lo] + (i - off_j[lo])));
-                rl[r] = lo;
+            }
+        } else {
+            const uint16_t* off_j = off + j * OS;
+            const uint32_t n = off_j[OS - 1];
+#pragma unroll
+            for (int r = 0; r < PPT; r++) {
+                const uint32_t i = tid + r * TPB;
+                rl[r] = EMPTY;
+                if (i < n) {
+                    int lo = 0, hi = L;            // largest l with off[l] <= i
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (off_j[mid] <= i) lo = mid; else hi = mid;
+                    }
+                    const Post* base = (lo & 1) ? p.t_post : p.b_post;
+                    rec[r] = *reinterpret_cast<const uint4*>(base + (l_base[lo] + tbl_j[lo] + (i - off_j[lo])));
+                    rl[r] = lo;
+                }
             }
         }
     };
-    // accumulate the loaded records per doc (main_retrieve.go:61-69,170-187); float32 addends in float64: exact
+    // accumulate the loaded records per doc (main_retrieve.go:61-69,170-187); float32 addends in float64: exact.
+    // (probing a thread's records one after the other measured 27 % faster than issuing their CAS together)
     auto insert_records = [&]() {
+        uint32_t h[PPT];
+        bool pend[PPT];
+#pragma unroll
+        for (int r = 0; r < PPT; r++) {
+            pend[r] = rl[r] != EMPTY;
+            h[r] = (((rec[r].x * 2654435761u) >> 21) * 3u) >> 2;      // [0, 1536)
+        }
+#pragma unroll
+        for (int r = 0; r < PPT; r++) {
+            if (pend[r]) {
+                for (;;) {
+                    const uint32_t prev = atomicCAS(&ht_key[h[r]], EMPTY, rec[r].x);
+                    if (prev == EMPTY || prev == rec[r].x) break;
+                    h[r] = h[r] + 1 == HT ? 0 : h[r] + 1;
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < PPT; r++) {
             const uint32_t l = rl[r];
             if (l != EMPTY) {
                 const uint32_t i = tid + r * TPB;
-                const uint32_t d = rec[r].x;
-                uint32_t h = (((d * 2654435761u) >> 21) * 3u) >> 2;   // [0, 1536)
-                for (;;) {
-                    const uint32_t prev = atomicCAS(&ht_key[h], EMPTY, d);
-                    if (prev == EMPTY || prev == d) break;
-                    h = h + 1 == HT ? 0 : h + 1;
-                }
+                const uint32_t field = l & 1;          // 0 = body, 1 = title
                 const double v = (double)__uint_as_float(rec[r].y) * l_mult[l];
                 s_mag[i] = __hiloint2double((int)rec[r].w, (int)rec[r].z);
+                atomicAdd(&ht_TB[2 * h[r] + field], v);
                 // all records of one (doc, field) carry the same magnitude: any writer may win
-                if (l_field[l]) { atomicAdd(&ht_T[h], v); ht_iT[h] = (uint16_t)i; }
-                else { atomicAdd(&ht_B[h], v); ht_iB[h] = (uint16_t)i; }
+                reinterpret_cast<uint16_t*>(ht_idx)[2 * h[r] + field] = (uint16_t)i;
             }
         }
     };
-    // score every touched doc (get_metadata.go:31-69), reset the table, filter into the running top-k
+    // score every touched doc (get_metadata.go:31-69), reset the table, filter into the running top-k.
+    // All LDS reads of a thread's entries are issued together; empty slots read as zero sums and drop out.
     auto scan_table = [&]() {
         uint64_t e_key[EPT];
         uint32_t e_doc[EPT];
+        double2 tb[EPT];
+        uint32_t ix[EPT];
         const uint64_t thr0 = *tk.thr;
         const float thr_f = *tk.thr_f;
 #pragma unroll
         for (int r = 0; r < EPT; r++) {
-            const int h = tid + r * TPB;
-            const uint32_t d = ht_key[h];
-            e_doc[r] = d;
+            const int hh = tid + r * TPB;
+            e_doc[r] = EMPTY;
+            tb[r] = make_double2(0.0, 0.0);
+            ix[r] = 0xFFFFFFFFu;
+            if (HT % TPB == 0 || hh < HT) {
+                e_doc[r] = ht_key[hh];
+                tb[r] = *reinterpret_cast<const double2*>(ht_TB + 2 * hh);
+                ix[r] = ht_idx[hh];
+            }
+        }
+        double mt[EPT], mb[EPT];
+#pragma unroll
+        for (int r = 0; r < EPT; r++) {
+            const int hh = tid + r * TPB;
+            const uint32_t ib = ix[r] & 0xFFFFu, it = ix[r] >> 16;
+            // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
+            const double mb_ = s_mag[ib != 0xFFFFu ? ib : 0], mt_ = s_mag[it != 0xFFFFu ? it : 0];
+            mb[r] = ib != 0xFFFFu ? mb_ : 1.0;
+            mt[r] = it != 0xFFFFu ? mt_ : 1.0;
+            if (HT % TPB == 0 || hh < HT) {
+                ht_key[hh] = EMPTY;
+                *reinterpret_cast<double2*>(ht_TB + 2 * hh) = make_double2(0.0, 0.0);
+                ht_idx[hh] = 0xFFFFFFFFu;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < EPT; r++) {
             e_key[r] = 0;
-            if (d != EMPTY) {
-                const double T = ht_T[h], B = ht_B[h];
-                const uint32_t it = ht_iT[h], ib = ht_iB[h];
-                // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
-                const double mt = it != 0xFFFFu ? s_mag[it] : 1.0;
-                const double mb = ib != 0xFFFFu ? s_mag[ib] : 1.0;
-                ht_key[h] = EMPTY; ht_T[h] = 0.0; ht_B[h] = 0.0; ht_iT[h] = 0xFFFFu; ht_iB[h] = 0xFFFFu;
+            if (e_doc[r] != EMPTY) {
+                const double B = tb[r].x, T = tb[r].y;
                 // cheap float estimate first: almost every doc is far below the running threshold.
                 // Skipped only if the estimate, with a 1e-4 relative margin, is clearly below; anything
                 // non-finite falls through to the exact path.
-                const float ea = 38.0f * __fdividef((float)T, (float)mt * qmag_f), eb = 29.0f * __fdividef((float)B, (float)mb * qmag_f),
+                const float ea = 38.0f * __fdividef((float)T, (float)mt[r] * qmag_f), eb = 29.0f * __fdividef((float)B, (float)mb[r] * qmag_f),
                             ec = 33.0f * sqd_ub_f;
                 if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) { e_doc[r] = EMPTY; continue; }
                 double title, body, fin;
                 if (probs) {
                     // the prior row (128 B) is only fetched if the doc can still make the top-k:
                     // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
-                    final_rank(T, B, mt, mb, qmag, sqd_ub, title, body, fin);
-                    if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, qmag, topic_dot(p.prior, probs, p.k_topics, d), title, body, fin);
+                    final_rank(T, B, mt[r], mb[r], qmag, sqd_ub, title, body, fin);
+                    if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt[r], mb[r], qmag, topic_dot(p.prior, probs, p.k_topics, e_doc[r]), title, body, fin);
                     else e_doc[r] = EMPTY;
                 } else {
-                    final_rank(T, B, mt, mb, qmag, 0.0, title, body, fin);
+                    final_rank(T, B, mt[r], mb[r], qmag, 0.0, title, body, fin);
                 }
                 e_key[r] = fkey(fin);
             }
@@ -376,14 +445,22 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
         }
     };
 
-    if (n_win > 0 && off[L] <= CAP) load_window(0);
+    if (n_win > 0 && off[OS - 1] <= CAP) load_window(0);
+    STAMP(ts[0]);
+    acc[6] += ts[0] - ts[7];
     for (int j = 0; j < n_win; j++) {
-        const uint32_t n = off[j * (L + 1) + L];
+        const uint32_t n = off[j * OS + OS - 1];
         if (n <= CAP) {
+            STAMP(ts[0]);
             insert_records();                                   // waits for window j's records
+            STAMP(ts[1]);
             lds_barrier();
-            if (j + 1 < n_win && off[(j + 1) * (L + 1) + L] <= CAP) load_window(j + 1);   // in flight during the scan
+            STAMP(ts[2]);
+            if (j + 1 < n_win && off[(j + 1) * OS + OS - 1] <= CAP) load_window(j + 1);   // in flight during the scan
+            STAMP(ts[3]);
             scan_table();
+            STAMP(ts[4]);
+            acc[0] += ts[1] - ts[0]; acc[1] += ts[2] - ts[1]; acc[2] += ts[3] - ts[2]; acc[3] += ts[4] - ts[3]; acc[7] += 1;
         } else {
             // ---- oversize window (a list is locally much denser than planned): bisect its doc range
             //      until a piece fits, process the piece, continue.  Rare; no prefetch here. ----
@@ -437,7 +514,7 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
                 flo = fhi;
                 __syncthreads();
             }
-            if (j + 1 < n_win && off[(j + 1) * (L + 1) + L] <= CAP) load_window(j + 1);
+            if (j + 1 < n_win && off[(j + 1) * OS + OS - 1] <= CAP) load_window(j + 1);
         }
     }
 
@@ -448,11 +525,19 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
         p.so_doc[(size_t)slice_id * p.k + i] = cd_doc[i];
     }
     if (tid == 0) p.so_cnt[slice_id] = n_out;
+#ifdef SS_DIAG
+    STAMP(ts[1]);
+    if ((tid & 63) == 0 && (tid >> 6) == 3) {
+        for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i], acc[i]);
+        atomicAdd(&g_stamps[8], ts[1] - ts[7]);
+        atomicAdd(&g_stamps[9], 1ull);
+    }
+#endif
 }
 
 size_t score_lds_bytes(int cb) {
     return (size_t)HT * 8 * 2 + (size_t)CAP * 8 + (size_t)MAXL * 8 * 2 + 2 * 8 + (size_t)cb * 12 +
-           ((size_t)HT + TBL_CAP + 3 * MAXL + 8) * 4 + ((size_t)2 * HT + OFF_CAP) * 2 + 16;
+           ((size_t)2 * HT + TBL_CAP + 3 * MAXL + 8) * 4 + (size_t)OFF_CAP * 2 + 16;
 }
 
 // ---- K5: merge a query's slices, explain the winners ------------------------------
@@ -658,6 +743,17 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+#ifdef SS_DIAG
+    {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
+            const char* names[10] = {"insert(+wait)", "barrier", "issue_loads", "scan+admit", "-", "-", "slice_init", "windows", "block_total", "blocks"};
+            fprintf(stderr, "[ss diag] k_score_slices wave 3 cycles:");
+            for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     s->title->users--;
     s->body->users--;
     delete s;
