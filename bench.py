@@ -36,6 +36,28 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+def profiled_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_hbm_bytes.json: FETCH_SIZE and WRITE_SIZE in KB, separate passes).  FETCH_SIZE counts
+    128-byte requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section; checked on k_weight here), so the
+    read side is doubled for these wide-request kernels.  None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_bytes.json")))
+    if not files:
+        return None
+    try:
+        rows = json.load(open(files[-1]))
+        rd = [r for r in rows if r["counter"] == "FETCH_SIZE" and kernel in r["kernel"]]
+        wr = [r for r in rows if r["counter"] == "WRITE_SIZE" and kernel in r["kernel"]]
+        if not rd or not wr:
+            return None
+        return {"bytes": 2.0 * rd[0]["median_KB"] * 1024 + wr[0]["median_KB"] * 1024,
+                "fetch_size_raw_bytes": rd[0]["median_KB"] * 1024, "write_size_bytes": wr[0]["median_KB"] * 1024,
+                "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def log(msg: str) -> None:
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
@@ -73,11 +95,27 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    # SS_BENCH_REHEARSAL=1: rehearse the N>1 code path on ONE GPU (all ranks on cuda:0, gloo, host-staged
+    # exchange).  Numbers from a rehearsal are meaningless; it only checks the multi-process flow.
+    rehearsal = os.environ.get("SS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def bcast(t):
+        if rehearsal:
+            h = t.cpu()
+            dist.broadcast(h, 0)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, 0)
 
     def barrier():
         if world > 1:
@@ -87,7 +125,7 @@ def main() -> None:
     def max_over_ranks(x: float) -> float:
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -108,8 +146,8 @@ def main() -> None:
                 out_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
                 out_dst = torch.empty(e, dtype=torch.int32, device=dev)
             if world > 1:
-                dist.broadcast(out_ptr, 0)
-                dist.broadcast(out_dst, 0)
+                bcast(out_ptr)
+                bcast(out_dst)
             torch.cuda.synchronize()
             log(f"graph generated: N={n} E={e} in {time.time() - t0:.1f}s")
             t0 = time.time()
@@ -120,7 +158,7 @@ def main() -> None:
             n_topic = synth.topic_sizes(n, kt)
             d = 0.75                                   # start_crawl.go:175
             pr = engine.PageRankState(g, d, -1.0, n_topic, max_iter=0)   # eps<0: fixed-iteration mode
-            exchange = sharding.DistExchange(pr, dev) if world > 1 else None
+            exchange = sharding.DistExchange(pr, dev, host_staged=rehearsal) if world > 1 else None
 
             def sweeps(m: int) -> None:
                 if world == 1:
@@ -159,15 +197,19 @@ def main() -> None:
             })
             if world == 1:
                 ach = algo_bytes / (kern_ms * 1e-3) / 1e9
+                tr = profiled_traffic("k_pr_step") if (n, e, kt) == (10_000_000, 50_000_000, 16) else None
                 result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_pr_step<16>",
+                                      "frac": ach / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
+                                      "kernel": f"k_pr_step<{kt if kt in (1, 2, 4, 8, 16) else 16}>",
                                       "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes}
+                if tr:
+                    result["roofline"]["traffic_detail"] = tr
             else:
                 sp, sb, rp, rb = pr.exchange_buffers()
                 result["exchange"] = {"allgather_recv_bytes_per_sweep": rb, "send_bytes_per_rank": sb}
             # to-convergence run at the BASELINE eps (not timed into `value`)
             prc = engine.PageRankState(g, d, 1e-6, n_topic)
-            exc = sharding.DistExchange(prc, dev) if world > 1 else None
+            exc = sharding.DistExchange(prc, dev, host_staged=rehearsal) if world > 1 else None
             barrier()
             t0 = time.perf_counter()
             if world == 1:
@@ -198,6 +240,15 @@ def main() -> None:
                 result["cpu_baseline"] = {"value": m / cdt, "unit": "topic-iterations/s", "cores": 1, "kind": "port",
                                           "sample": f"{m} iterations of topic 0 on the same graph, flat-array single-thread C "
                                                     f"restatement of pagerank.go:85-145 (oracle/oracle.c); host has {os.cpu_count()} cores"}
+                # "reference-shaped" variant: the same arithmetic keyed by 32-char hex strings
+                # in hash maps, the way pagerank.go keys Go maps by md5-hex docHash; one topic, 2 iterations
+                if args.cpu_seconds >= 10:
+                    t0 = time.perf_counter()
+                    pyoracle.pagerank(n, h_ptr, h_dst, d, -1.0, [int(n_topic[0])], max_iter=2, hashed=True)
+                    hdt = time.perf_counter() - t0
+                    result["cpu_baseline"]["reference_shaped"] = {
+                        "value": 2 / hdt, "unit": "topic-iterations/s", "cores": 1,
+                        "sample": "2 iterations, string-keyed hash maps (incl. building them), oracle/oracle.c:orc_pagerank_topic_hashed"}
                 # parity spot check of the timed state against the oracle at the same iteration count
                 chk = engine.PageRankState(g, d, -1.0, [int(n_topic[0])], max_iter=m)
                 chk.begin()
@@ -270,7 +321,9 @@ def main() -> None:
                                "postings_per_query": sum_df / nq,
                                "parallelism": "single GPU" if world == 1 else f"query-split replicas x{world}"},
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_score_slices+k_merge_topk",
+                                 "frac": ach / HBM_PEAK_GBS,
+                                 "traffic": (profiled_traffic("k_score_slices") or {}).get("bytes") if (nd, nt, nq, k) == (10_000_000, 1_000_000, 1024, 100) else None,
+                                 "kernel": "k_score_slices+k_merge_topk",
                                  "kernel_ms": kern_ms, "algorithmic_bytes": algo_q},
                     "tfidf_build_ms": tfidf_ms, "queries_per_sec_host_in_host_out": nq * K / dt_pcie}
             if keep_host:

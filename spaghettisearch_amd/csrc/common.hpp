@@ -87,6 +87,17 @@ struct DevBuf {
         if (count == 0) count = 1;
         return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     }
+    // streamed-once data: uncached memory type, so it does not occupy L2 lines
+    hipError_t alloc_streaming(size_t count) {
+#ifdef SS_UNCACHED_STREAMS
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        return hipExtMallocWithFlags(reinterpret_cast<void**>(&p), count * sizeof(T), hipDeviceMallocUncached);
+#else
+        return alloc(count);
+#endif
+    }
     size_t bytes() const { return n * sizeof(T); }
 };
 

@@ -255,7 +255,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
 
     const uint32_t n_local = g->n_local();
     SS_HIP(ctx, g->in_ptr.alloc((size_t)n_local + 1));
-    SS_HIP(ctx, g->in_src.alloc(g->e_local));
+    SS_HIP(ctx, g->in_src.alloc_streaming(g->e_local));
     SS_HIP(ctx, g->outdeg.alloc(g->sl_nd));
     hipLaunchKernelGGL(k_local_ptr, dim3(ss::div_up((uint64_t)n_local + 1, TPB)), dim3(TPB), 0, st, in_ptr_int.p, g->sl_nd,
                        g->sl_d, id0_nd, id0_d, h_ptr[0], h_ptr[2], e_nd, g->in_ptr.p);

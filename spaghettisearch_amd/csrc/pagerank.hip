@@ -197,6 +197,16 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
     }
 }
 
+// Streaming data (ranks, indices, next contributions) is touched once per sweep: mark it
+// non-temporal so that it does not push the randomly gathered table out of L2.
+#ifndef SS_PR_NO_NT
+#define NT_LOAD(p) __builtin_nontemporal_load(p)
+#define NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define NT_LOAD(p) (*(p))
+#define NT_STORE(v, p) (*(p) = (v))
+#endif
+
 // ---- gather ------------------------------------------------------------------
 constexpr uint32_t SRC_MASK = 0x7FFFFFFFu;   // in_src bit 31 = "last in-edge of its row" (graph.hip)
 constexpr int CH = 16;                       // edges per chunk of the GW=16 path
@@ -225,7 +235,7 @@ __device__ __forceinline__ double gather_sum(const double* __restrict__ T, const
 __device__ __forceinline__ uint32_t gather_chunk16(const double* __restrict__ T, const uint32_t* __restrict__ in_src,
                                                    size_t pos, uint32_t n, int lane, double (&v)[CH]) {
     const int t = lane & 15, gbase = lane & 48;
-    const uint32_t raw = (uint32_t)t < n ? in_src[pos + t] : 0u;
+    const uint32_t raw = (uint32_t)t < n ? NT_LOAD(&in_src[pos + t]) : 0u;
     const unsigned long long flags = __ballot(raw >> 31);
     const uint32_t src = raw & SRC_MASK;
 #pragma unroll
@@ -262,17 +272,17 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     auto finish = [&](uint32_t lrow, double y) {
         y += x0;
         const size_t xi = (size_t)lrow * GW + t;
-        const double xo = p.x[xi];
+        const double xo = NT_LOAD(&p.x[xi]);
         double xn = (y + p.teleport) / S;               // pagerank.go:117
         if (act) {
-            p.x[xi] = xn;
+            NT_STORE(xn, &p.x[xi]);
             dsum += fabs(xn - xo);                      // pagerank.go:118
         } else {
             xn = xo;                                    // converged topic: frozen
         }
         if (lrow < p.sl_nd) {                           // non-dangling row: next sweep's contribution
-            const double c = p.d * xn / (double)p.outdeg[lrow];   // pagerank.go:136
-            Tw[xi] = c;
+            const double c = p.d * xn / (double)NT_LOAD(&p.outdeg[lrow]);   // pagerank.go:136
+            NT_STORE(c, &Tw[xi]);
             csum += c;                                  // pagerank.go:137
         }
     };
@@ -595,7 +605,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     // persistent grid: 8 blocks per CU at most, each walks the work table round-robin
     pr->nblocks = (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
 
-    SS_HIP(ctx, pr->x.alloc(n_local * GW));
+    SS_HIP(ctx, pr->x.alloc_streaming(n_local * GW));
     SS_HIP(ctx, pr->tab0.alloc((size_t)g->nd_int * GW));
     SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, std::max<size_t>(pr->tab0.bytes(), 8), st));
     if (g->world == 1) {

@@ -47,9 +47,14 @@ def exchange_tensors(state, device):
 
 
 class DistExchange:
-    """One process per GPU: all-gather this rank's slice into the full table (RCCL / gloo)."""
+    """One process per GPU: all-gather this rank's slice into the full table (RCCL / gloo).
 
-    def __init__(self, state, device, group=None):
+    host_staged=True copies through pinned host buffers around the collective: only for
+    rehearsing the multi-process path with the gloo backend (several ranks on one GPU); the
+    production path hands the device buffers straight to RCCL."""
+
+    def __init__(self, state, device, group=None, host_staged: bool = False):
+        import torch
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -58,8 +63,19 @@ class DistExchange:
         if self.recv.numel() != world * self.send.numel():
             raise ValueError(f"exchange buffers do not match world size {world}: "
                              f"send {self.send.numel()} recv {self.recv.numel()}")
+        self.host_staged = host_staged and self.send.is_cuda
+        if self.host_staged:
+            self.h_send = torch.empty(self.send.shape, dtype=self.send.dtype, pin_memory=True)
+            self.h_recv = torch.empty(self.recv.shape, dtype=self.recv.dtype, pin_memory=True)
 
     def __call__(self) -> None:
+        if self.host_staged:
+            import torch
+            self.h_send.copy_(self.send, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            self.dist.all_gather_into_tensor(self.h_recv, self.h_send, group=self.group)
+            self.recv.copy_(self.h_recv, non_blocking=True)
+            return
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
 
 

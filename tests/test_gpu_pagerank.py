@@ -173,3 +173,53 @@ def test_sharded_layout_single_process(ss_ctx, oracle):
     finally:
         torch.cuda.synchronize()
         ss_ctx.set_stream(None)
+
+
+def _mp_worker(rank, world, port, n, e, n_topic, out_path):
+    """One process per shard, all on cuda:0: the production driver (sharding.iterate + DistExchange +
+    gather_ranks) with the real HIP states; gloo + host-staged exchange stand in for RCCL."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from spaghettisearch_amd import engine, sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ctx = engine.Context(0)
+        stream = torch.cuda.Stream()
+        ctx.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            ptr, dst = synth.rmat_graph(n, e, seed=31)
+            g = engine.Graph(ctx, n, ptr, dst, rank=rank, world=world)
+            st = engine.PageRankState(g, D, 1e-9, n_topic)
+            ex = sharding.DistExchange(st, torch.device("cuda:0"), host_staged=True)
+            final = sharding.iterate([st], ex, batch=3)
+            ranks = sharding.gather_ranks(st)
+            st.close()
+            g.close()
+        torch.cuda.synchronize()
+        ctx.set_stream(None)
+        ctx.close()
+        if rank == 0:
+            np.savez(out_path, rank=ranks, iters=final["iters"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_rehearsal(tmp_path, oracle):
+    import socket
+    import torch.multiprocessing as mp
+    n, e = 20000, 110000
+    n_topic = synth.topic_sizes(n, 16)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "mp.npz")
+    mp.spawn(_mp_worker, args=(2, port, n, e, n_topic, out), nprocs=2, join=True)
+    got = np.load(out)
+    ptr, dst = synth.rmat_graph(n, e, seed=31)
+    ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-9, n_topic)
+    assert got["iters"].tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(got["rank"], ref, rtol=1e-12)
