@@ -1,0 +1,77 @@
+// pybind.cpp — Python binding of the C++ host layer (module spaghettisearch_amd._host), so that the
+// pytest parity tests can drive the reference-shaped entry points:
+//   ranking.UpdateTopicSensitivePagerank / ranking.UpdateTermWeights / retrieval.Retrieve
+// over in-memory tables holding the reference's JSON row formats.
+#include <pybind11/functional.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "retrieval.hpp"
+
+namespace py = pybind11;
+
+PYBIND11_MODULE(_host, m) {
+    m.doc() = "C++ host mirror of SpaghettiSearch's ranking/retrieval entry points above the HIP C ABI";
+    py::class_<db::MemDB>(m, "MemDB")
+        .def(py::init<>())
+        .def("set", [](db::MemDB& d, const std::string& k, const std::string& v) { d.rows[k] = v; })
+        .def("get", [](db::MemDB& d, const std::string& k) {
+            auto it = d.rows.find(k);
+            if (it == d.rows.end()) throw py::key_error(k);
+            return it->second;
+        })
+        .def("keys", [](db::MemDB& d) {
+            std::vector<std::string> out;
+            for (auto& kv : d.rows) out.push_back(kv.first);
+            return out;
+        })
+        .def("__len__", [](db::MemDB& d) { return d.rows.size(); })
+        .def("clear", [](db::MemDB& d) { d.rows.clear(); });
+
+    py::class_<retrieval::Rank_combined>(m, "Rank_combined")
+        .def_readonly("DocHash", &retrieval::Rank_combined::DocHash)
+        .def_readonly("PageRank", &retrieval::Rank_combined::PageRank)
+        .def_readonly("FinalRank", &retrieval::Rank_combined::FinalRank)
+        .def_readonly("TitleRank", &retrieval::Rank_combined::TitleRank)
+        .def_readonly("BodyRank", &retrieval::Rank_combined::BodyRank);
+
+    auto as_dbs = [](std::vector<db::MemDB*>& v) {
+        std::vector<db::DB*> out;
+        for (auto* p : v) out.push_back(p);
+        return out;
+    };
+    m.def("UpdateTopicSensitivePagerank", [as_dbs](double d, double eps, std::vector<db::MemDB*> forward) {
+        db::Context ctx;
+        auto f = as_dbs(forward);
+        ranking::UpdateTopicSensitivePagerank(ctx, d, eps, f);
+    }, py::arg("dampingFactor"), py::arg("convergenceCriterion"), py::arg("forward"));
+    m.def("UpdateTermWeights", [as_dbs](db::MemDB* inv, std::vector<db::MemDB*> forw, const std::string& info) {
+        db::Context ctx;
+        auto f = as_dbs(forw);
+        db::DB* i = inv;
+        ranking::UpdateTermWeights(ctx, &i, f, info);
+    }, py::arg("inv"), py::arg("forw"), py::arg("info"));
+    m.def("md5_hex", &md5::hex);
+
+    py::class_<retrieval::DeviceIndex>(m, "DeviceIndex")
+        .def(py::init<>())
+        .def("load", [as_dbs](retrieval::DeviceIndex& di, std::vector<db::MemDB*> forw, std::vector<db::MemDB*> inv) {
+            db::Context ctx;
+            auto f = as_dbs(forw), i = as_dbs(inv);
+            di.load(ctx, f, i);
+        })
+        .def("RetrieveBatch", [](retrieval::DeviceIndex& di, const std::vector<std::string>& queries, int k,
+                                 py::object topic_probs) {
+            if (topic_probs.is_none()) return di.RetrieveBatch(queries, k, nullptr);
+            auto tp = topic_probs.cast<std::vector<std::map<std::string, double>>>();
+            return di.RetrieveBatch(queries, k, &tp);
+        }, py::arg("queries"), py::arg("k") = 50, py::arg("topic_probs") = py::none())
+        .def_readonly("categories", &retrieval::DeviceIndex::categories);
+    m.def("Retrieve", [as_dbs](const std::string& query, std::vector<db::MemDB*> forw, std::vector<db::MemDB*> inv) {
+        db::Context ctx;
+        auto f = as_dbs(forw), i = as_dbs(inv);
+        retrieval::DeviceIndex di;          // the binding keeps no global state: load per call
+        di.load(ctx, f, i);
+        return di.RetrieveBatch({query}, 50)[0];
+    });
+}

@@ -1,0 +1,201 @@
+// retrieval.hpp — host-side mirror of retrieval.Retrieve (retrieval/main_retrieve.go:15) above the C ABI.
+//
+// The query-time state lives on the GPU: DeviceIndex::load flattens inv[0]/inv[1] (already weighted by
+// UpdateTermWeights), forw[4] magnitudes and forw[3] ranks once; Retrieve then parses the query on the
+// host, makes ONE library call and maps the k winners into Rank_combined (util.go:25-36).
+// Text normalisation (parser.Laundry: Porter2 stemming + stop words) and result decoration
+// (get_metadata.go:79-235) are host-side Go in the reference and stay out of scope: `laundry` is a
+// hook (default: lower-cased alphanumeric tokens), decoration fills DocHash/PageRank/FinalRank only.
+#pragma once
+#include <cctype>
+#include <functional>
+
+#include "md5.hpp"
+#include "ranking.hpp"
+
+namespace retrieval {
+
+struct Rank_combined {          // util.go:25-36 (decoration fields are left to the caller)
+    std::string DocHash;
+    double PageRank = 0;
+    double FinalRank = 0;
+    double TitleRank = 0, BodyRank = 0;   // diagnostics: the cosine-normalised parts
+};
+
+// util.go:151-160: quoted phrases `".*?"`
+inline std::vector<std::string> getPhrase(const std::string& s) {
+    std::vector<std::string> out;
+    size_t i = 0;
+    while ((i = s.find('"', i)) != std::string::npos) {
+        const size_t j = s.find('"', i + 1);
+        if (j == std::string::npos) break;
+        out.push_back(s.substr(i + 1, j - i - 1));
+        i = j + 1;
+    }
+    return out;
+}
+
+// parser.go:177-193 without stemming / stop words (those stay host-side Go)
+inline std::vector<std::string> defaultLaundry(const std::string& s) {
+    std::vector<std::string> out;
+    std::string cur;
+    for (unsigned char c : s) {
+        if (std::isalnum(c)) cur += (char)std::tolower(c);
+        else if (!cur.empty()) { out.push_back(cur); cur.clear(); }
+    }
+    if (!cur.empty()) out.push_back(cur);
+    return out;
+}
+
+class DeviceIndex {
+public:
+    spaghetti::DenseIds docs, terms;
+    ss_index* title = nullptr;
+    ss_index* body = nullptr;
+    ss_scorer* scorer = nullptr;
+    std::vector<std::string> categories;
+    std::function<std::vector<std::string>(const std::string&)> laundry = defaultLaundry;
+
+    ~DeviceIndex() {
+        if (scorer) ss_scorer_destroy(scorer);
+        if (title) ss_index_destroy(title);
+        if (body) ss_index_destroy(body);
+    }
+
+    void load(db::Context& ctx, std::vector<db::DB*>& forw, std::vector<db::DB*>& inv) {
+        using namespace spaghetti;
+        const std::vector<db::KV> ranks = forw[3]->Iterate(ctx);
+        std::vector<std::map<std::string, std::vector<float>>> trow, brow;
+        std::vector<std::string> all_docs, all_terms;
+        for (auto& kv : ranks) all_docs.push_back(kv.first);
+        const std::vector<db::KV> tcomp = inv[0]->Iterate(ctx), bcomp = inv[1]->Iterate(ctx);
+        for (auto& kv : tcomp) { all_terms.push_back(kv.first); trow.push_back(jsonmini::parse_map_f32list(kv.second)); }
+        for (auto& kv : bcomp) { all_terms.push_back(kv.first); brow.push_back(jsonmini::parse_map_f32list(kv.second)); }
+        for (auto& r : trow) for (auto& kv : r) all_docs.push_back(kv.first);
+        for (auto& r : brow) for (auto& kv : r) all_docs.push_back(kv.first);
+        docs.build(all_docs.begin(), all_docs.end());
+        terms.build(all_terms.begin(), all_terms.end());
+        const size_t n = docs.name.size(), T = terms.name.size();
+        auto flatten = [&](const std::vector<db::KV>& comp, std::vector<std::map<std::string, std::vector<float>>>& rows,
+                           std::vector<uint64_t>& ptr, std::vector<uint32_t>& doc, std::vector<float>& w) {
+            std::vector<const std::map<std::string, std::vector<float>>*> by_term(T, nullptr);
+            for (size_t i = 0; i < comp.size(); i++) by_term[terms.id[comp[i].first]] = &rows[i];
+            ptr.assign(T + 1, 0);
+            for (size_t t = 0; t < T; t++) ptr[t + 1] = ptr[t] + (by_term[t] ? by_term[t]->size() : 0);
+            doc.resize(ptr[T]);
+            w.resize(ptr[T]);
+            for (size_t t = 0; t < T; t++) {
+                if (!by_term[t]) continue;
+                uint64_t j = ptr[t];
+                for (auto& kv : *by_term[t]) { doc[j] = docs.id[kv.first]; w[j] = kv.second.at(0); j++; }   // first entry = norm_tf*idf (main_retrieve.go:227,236)
+            }
+        };
+        std::vector<uint64_t> tp, bp;
+        std::vector<uint32_t> td, bd;
+        std::vector<float> tw, bw;
+        flatten(tcomp, trow, tp, td, tw);
+        flatten(bcomp, brow, bp, bd, bw);
+        check(ss_index_create(default_ctx(), n, T, tp.data(), td.data(), tw.data(), &title), "ss_index_create(title)");
+        check(ss_index_create(default_ctx(), n, T, bp.data(), bd.data(), bw.data(), &body), "ss_index_create(body)");
+        // forw[4]: a missing "title"/"body" key reads as 0 (get_metadata.go:57-58, Q8)
+        std::vector<double> magT(n, 0.0), magB(n, 0.0);
+        for (auto& kv : forw[4]->Iterate(ctx)) {
+            auto it = docs.id.find(kv.first);
+            if (it == docs.id.end()) continue;
+            auto m = jsonmini::parse_map_f64(kv.second);
+            magT[it->second] = m.count("title") ? m["title"] : 0.0;
+            magB[it->second] = m.count("body") ? m["body"] : 0.0;
+        }
+        check(ss_index_set_weighted(title, magT.data()), "ss_index_set_weighted(title)");
+        check(ss_index_set_weighted(body, magB.data()), "ss_index_set_weighted(body)");
+        check(ss_scorer_create(default_ctx(), title, body, &scorer), "ss_scorer_create");
+        // forw[3]: ranks per category, for the PageRank blend (get_metadata.go:31-42)
+        std::vector<std::string> cat;
+        for (auto& kv : ranks) for (auto& c : jsonmini::parse_map_f64(kv.second)) cat.push_back(c.first);
+        std::sort(cat.begin(), cat.end());
+        cat.erase(std::unique(cat.begin(), cat.end()), cat.end());
+        categories = cat;
+        const size_t K = cat.size();
+        if (K > 0 && K <= SS_MAX_TOPICS) {
+            std::vector<double> prior(K * n, 0.0);
+            for (auto& kv : ranks) {
+                const uint32_t d = docs.id[kv.first];
+                for (auto& c : jsonmini::parse_map_f64(kv.second)) {
+                    const size_t k = std::lower_bound(cat.begin(), cat.end(), c.first) - cat.begin();
+                    prior[k * n + d] = c.second;
+                }
+            }
+            check(ss_scorer_set_prior(scorer, (int32_t)K, prior.data()), "ss_scorer_set_prior");
+        }
+    }
+
+    // A batch of queries in one library call (additive API).  topicProbs: per query
+    // category -> probability, or empty (nil map in the shipped reference, main_retrieve.go:88: sqd = 0).
+    std::vector<std::vector<Rank_combined>> RetrieveBatch(const std::vector<std::string>& queries, int k = 50,
+                                                          const std::vector<std::map<std::string, double>>* topicProbs = nullptr) {
+        using namespace spaghetti;
+        std::vector<uint32_t> q_ptr{0}, q_terms;
+        std::vector<int32_t> q_len;
+        for (std::string query : queries) {
+            // main_retrieve.go:17-36
+            const std::vector<std::string> phrases = getPhrase(query);
+            for (auto& ph : phrases) {
+                const size_t pos = query.find("\"" + ph + "\"");
+                if (pos != std::string::npos) query.erase(pos, ph.size() + 2);
+            }
+            std::string joined;
+            for (auto& ph : phrases) joined += ph + " ";
+            const std::vector<std::string> queryTokenised = laundry(query), phraseTokenised = laundry(joined);
+            for (auto& tok : queryTokenised) {
+                auto it = terms.id.find(md5::hex(tok));
+                q_terms.push_back(it == terms.id.end() ? SS_UNKNOWN_TERM : it->second);   // ErrKeyNotFound tolerated (:193,:218)
+            }
+            q_ptr.push_back((uint32_t)q_terms.size());
+            q_len.push_back((int32_t)(queryTokenised.size() + phraseTokenised.size()));   // :90
+            // phrase search itself (retrieval/phrase.go) is the next row of the scope table
+        }
+        const int nq = (int)queries.size();
+        std::vector<double> probs;
+        const size_t K = categories.size();
+        if (topicProbs && K) {
+            probs.assign((size_t)nq * K, 0.0);
+            for (int q = 0; q < nq; q++)
+                for (auto& kv : (*topicProbs)[q]) {
+                    auto it = std::lower_bound(categories.begin(), categories.end(), kv.first);
+                    if (it != categories.end() && *it == kv.first) probs[(size_t)q * K + (it - categories.begin())] = kv.second;
+                }
+        }
+        std::vector<ss_hit> hits((size_t)nq * k);
+        std::vector<int32_t> n_hits(nq);
+        check(ss_score_topk(scorer, nq, q_ptr.data(), q_terms.data(), q_len.data(), probs.empty() ? nullptr : probs.data(), k, hits.data(),
+                            n_hits.data()), "ss_score_topk");
+        std::vector<std::vector<Rank_combined>> out(nq);
+        for (int q = 0; q < nq; q++)
+            for (int i = 0; i < n_hits[q]; i++) {
+                const ss_hit& h = hits[(size_t)q * k + i];
+                Rank_combined r;
+                r.DocHash = docs.name[h.doc];
+                r.PageRank = h.pagerank;      // get_metadata.go:68
+                r.FinalRank = h.final;        // get_metadata.go:69
+                r.TitleRank = h.title;
+                r.BodyRank = h.body;
+                out[q].push_back(r);
+            }
+        return out;
+    }
+};
+
+// retrieval.Retrieve(query, ctx, forw, inv) []Rank_combined — main_retrieve.go:15; first 50 (:99-103)
+inline std::vector<Rank_combined> Retrieve(const std::string& query, db::Context& ctx, std::vector<db::DB*>& forw, std::vector<db::DB*>& inv) {
+    static DeviceIndex* dev = nullptr;      // loaded on first use, like the server's long-lived tables
+    static std::vector<db::DB*>* loaded_for = nullptr;
+    if (!dev || loaded_for != &inv) {
+        delete dev;
+        dev = new DeviceIndex();
+        dev->load(ctx, forw, inv);
+        loaded_for = &inv;
+    }
+    return dev->RetrieveBatch({query}, 50)[0];
+}
+
+}  // namespace retrieval
