@@ -48,14 +48,26 @@ constexpr int TPB_M = 256;         // k_merge_topk workgroup
 constexpr int CAP = 1024;          // postings per window (capacity)
 constexpr int TARGET = 880;        // planned postings per window (head-room for the spread around the plan)
 constexpr int PPT = CAP / TPB;     // records per thread
-constexpr int HT = 1536;           // hash slots (load factor <= 0.67)
+#ifndef SS_HT
+#define SS_HT 1536
+#endif
+constexpr int HT = SS_HT;           // hash slots (1536: load factor <= 0.67; must be 2048*m/8)
 constexpr int EPT = (HT + TPB - 1) / TPB;   // hash entries per thread in the scan
 constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS;   // (term, field) lists per query
-constexpr int TBL_CAP = 4096;      // window-cursor table entries: (n_win+1) * L <= TBL_CAP
-constexpr int OFF_CAP = 4864;      // window-offset table entries: n_win * (L+1) <= OFF_CAP
+#ifndef SS_TBL_CAP
+#define SS_TBL_CAP 4096
+#endif
+constexpr int TBL_CAP = SS_TBL_CAP;      // window-cursor table entries: (n_win+1) * L <= TBL_CAP
+constexpr int OFF_CAP = TBL_CAP + TBL_CAP / 4 - (TBL_CAP + TBL_CAP / 4) % 8;   // window-offset table entries: n_win * OS <= OFF_CAP
 constexpr int MAX_WIN = 1023;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr uint64_t SLICE_TARGET = 65536;
+#ifndef SS_CB_MIN
+#define SS_CB_MIN 512
+#endif
+#ifndef SS_SLICE_TARGET
+#define SS_SLICE_TARGET 262144
+#endif
+constexpr uint64_t SLICE_TARGET = SS_SLICE_TARGET;
 constexpr uint32_t MAX_SLICES_PER_Q = 256;
 
 struct __attribute__((aligned(16))) Post {
@@ -188,7 +200,10 @@ __device__ void topk_compact(const TopK& tk, int k) {
 }
 
 // ---- K4: score one (query, doc-range slice) --------------------------------------
-__global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
+#ifndef SS_WAVES_PER_SIMD
+#define SS_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ht_TB = reinterpret_cast<double*>(smem);                   // [HT][2] (BodyRank, TitleRank) accumulators of a doc
     double* s_mag = ht_TB + 2 * HT;                                    // [CAP] field magnitude carried by record i of the window
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(TPB) void k_score_slices(ScoreParams p) {
 #pragma unroll
         for (int r = 0; r < PPT; r++) {
             pend[r] = rl[r] != EMPTY;
-            h[r] = (((rec[r].x * 2654435761u) >> 21) * 3u) >> 2;      // [0, 1536)
+            h[r] = (((rec[r].x * 2654435761u) >> 21) * (uint32_t)(HT / 256)) >> 3;      // [0, HT)
         }
 #pragma unroll
         for (int r = 0; r < PPT; r++) {
@@ -884,7 +899,7 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
     for (size_t i = 0; i < n_slices; i++) h_order[i] = (uint32_t)i;
     std::stable_sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b) { return h_slice_cost[a] > h_slice_cost[b]; });
 
-    int cb = 512;
+    int cb = SS_CB_MIN;
     while (cb < 2 * k) cb <<= 1;
 
     // ---- one pinned staging buffer, one H2D copy -------------------------------------
