@@ -36,7 +36,7 @@ var (
 	dev  *deviceIndex
 )
 
-func flatten(ctx context.Context, inv db.DB, termID map[string]uint32, docID map[string]uint32) (ptr []uint64, doc []uint32, w []float32) {
+func flatten(ctx context.Context, inv db.DB, termID map[string]uint32, docID map[string]uint32) (ptr []uint64, doc []uint32, w []float32, posPtr []uint64, pos []float32) {
 	comp, err := inv.Iterate(ctx)
 	if err != nil {
 		panic(err)
@@ -49,6 +49,7 @@ func flatten(ctx context.Context, inv db.DB, termID map[string]uint32, docID map
 		}
 		rows[termID[string(comp.KV[i].Key)]] = r
 	}
+	posPtr = []uint64{0}
 	ptr = make([]uint64, len(rows)+1)
 	for i, r := range rows {
 		ptr[i+1] = ptr[i] + uint64(len(r))
@@ -57,16 +58,19 @@ func flatten(ctx context.Context, inv db.DB, termID map[string]uint32, docID map
 	w = make([]float32, ptr[len(rows)])
 	for i, r := range rows {
 		type pw struct {
-			d uint32
-			w float32
+			d   uint32
+			w   float32
+			pos []float32
 		}
 		tmp := make([]pw, 0, len(r))
 		for h, listPos := range r {
-			tmp = append(tmp, pw{docID[h], listPos[0]}) // first entry = norm_tf*idf (main_retrieve.go:227,236)
+			tmp = append(tmp, pw{docID[h], listPos[0], listPos[1:]}) // [norm_tf*idf, positions...] (main_retrieve.go:227, phrase.go:144)
 		}
 		sort.Slice(tmp, func(a, b int) bool { return tmp[a].d < tmp[b].d })
 		for j, e := range tmp {
 			doc[ptr[i]+uint64(j)], w[ptr[i]+uint64(j)] = e.d, e.w
+			pos = append(pos, e.pos...)
+			posPtr = append(posPtr, uint64(len(pos)))
 		}
 	}
 	return
@@ -97,10 +101,12 @@ func load(ctx context.Context, forw []db.DB, inv []db.DB) *deviceIndex {
 	}
 	n := uint64(len(d.docName))
 	c := spaghetti.Default()
-	tPtr, tDoc, tW := flatten(ctx, inv[0], d.termID, docID)
-	bPtr, bDoc, bW := flatten(ctx, inv[1], d.termID, docID)
+	tPtr, tDoc, tW, tPosPtr, tPos := flatten(ctx, inv[0], d.termID, docID)
+	bPtr, bDoc, bW, bPosPtr, bPos := flatten(ctx, inv[1], d.termID, docID)
 	title := c.NewIndex(n, tPtr, tDoc, tW)
 	body := c.NewIndex(n, bPtr, bDoc, bW)
+	title.SetPositions(tPosPtr, tPos)
+	body.SetPositions(bPosPtr, bPos)
 	// forw[4]: a missing "title"/"body" key reads as 0 (get_metadata.go:57-58, Q8)
 	magT, magB := make([]float64, n), make([]float64, n)
 	mags, err := forw[4].Iterate(ctx)
@@ -143,10 +149,21 @@ func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Ra
 		}
 	}
 	qPtr := []uint32{0, uint32(len(qTerms))}
+	// all quoted phrases form ONE phrase (main_retrieve.go:26); it is matched on the device from the
+	// positional part of the postings (retrieval/phrase.go -> ss_score_topk_phrase)
+	pTerms := make([]uint32, len(phraseTokenised))
+	for i, tok := range phraseTokenised {
+		sum := md5.Sum([]byte(tok))
+		if id, ok := dev.termID[hex.EncodeToString(sum[:])]; ok {
+			pTerms[i] = id
+		} else {
+			pTerms[i] = 0xFFFFFFFF
+		}
+	}
+	pPtr := []uint32{0, uint32(len(pTerms))}
 	qLen := []int32{int32(len(queryTokenised) + len(phraseTokenised))} // main_retrieve.go:90
 	// topicProbs stays nil as in the shipped reference (main_retrieve.go:40,87-88): sqd = 0.
-	// Phrase search (retrieval/phrase.go) is the next row of the scope table (SURVEY.md §8f-1).
-	hits, _ := dev.scorer.ScoreTopK(qPtr, qTerms, qLen, nil, topK)
+	hits, _ := dev.scorer.ScoreTopKPhrase(qPtr, qTerms, pPtr, pTerms, qLen, nil, topK)
 
 	out := make([]Rank_combined, 0, len(hits[0]))
 	for _, h := range hits[0] {

@@ -143,6 +143,9 @@ func (ix *Index) TfIdfBuild(totalDocs uint64) (w []float32, mag []float64) {
 	check(ix.ctx, C.ss_tfidf_build(ix.h, C.uint64_t(totalDocs), f32p(w), f64p(mag), nil), "ss_tfidf_build")
 	return
 }
+func (ix *Index) SetPositions(posPtr []uint64, pos []float32) {
+	check(ix.ctx, C.ss_index_set_positions(ix.h, u64p(posPtr), f32p(pos)), "ss_index_set_positions")
+}
 func (ix *Index) SetWeighted(mag []float64) {
 	check(ix.ctx, C.ss_index_set_weighted(ix.h, f64p(mag)), "ss_index_set_weighted")
 }
@@ -155,6 +158,25 @@ func (c *Ctx) NewScorer(title, body *Index) *Scorer {
 func (s *Scorer) Close() { C.ss_scorer_destroy(s.h) }
 func (s *Scorer) SetPrior(kTopics int, rank []float64) {
 	check(s.ctx, C.ss_scorer_set_prior(s.h, C.int32_t(kTopics), f64p(rank)), "ss_scorer_set_prior")
+}
+
+// ScoreTopKPhrase = ScoreTopK plus one (concatenated) quoted phrase per query (retrieval/phrase.go).
+func (s *Scorer) ScoreTopKPhrase(qPtr, qTerms, pPtr, pTerms []uint32, queryLen []int32, topicProbs []float64, k int) ([][]Hit, error) {
+	nq := len(qPtr) - 1
+	raw := make([]C.ss_hit, nq*k)
+	nHits := make([]int32, nq)
+	rc := C.ss_score_topk_phrase(s.h, C.int32_t(nq), u32p(qPtr), u32p(qTerms), u32p(pPtr), u32p(pTerms), i32p(queryLen),
+		f64p(topicProbs), C.int32_t(k), (*C.ss_hit)(unsafe.Pointer(&raw[0])), i32p(nHits))
+	check(s.ctx, rc, "ss_score_topk_phrase")
+	out := make([][]Hit, nq)
+	for q := 0; q < nq; q++ {
+		out[q] = make([]Hit, nHits[q])
+		for i := range out[q] {
+			r := raw[q*k+i]
+			out[q][i] = Hit{uint32(r.doc), float64(r.title), float64(r.body), float64(r.pagerank), float64(r.final)}
+		}
+	}
+	return out, nil
 }
 
 // ScoreTopK scores a batch of OR queries; safe to call from many goroutines (the library

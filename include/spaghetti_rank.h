@@ -161,6 +161,9 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs,
                        float* w_out, double* mag_out, float* idf_out);
 /* Load precomputed weights/magnitudes instead (tables already weighted). */
 int32_t ss_index_set_weighted(ss_index* idx, const double* mag /*[n_docs]*/);
+/* Positional postings for phrase search: listPos[1:] of every posting (parser/parser.go:195-207:
+ * float32 positions, -100 for anchor/meta text), pos_ptr[n_postings+1] into pos[]. */
+int32_t ss_index_set_positions(ss_index* idx, const uint64_t* pos_ptr, const float* pos);
 
 /* ---- scoring: retrieval/main_retrieve.go:50-103, get_metadata.go:31-69 -- */
 int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer** out);
@@ -178,6 +181,18 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank);
 int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
                       const int32_t* query_len, const double* topic_probs, int32_t k,
                       ss_hit* hits_out, int32_t* n_hits_out);
+
+/* ss_score_topk plus the quoted-phrase part of retrieval.Retrieve (retrieval/phrase.go:11-170,
+ * util.go:162-203, merged at main_retrieve.go:73-78).  p_ptr[n_q+1] into p_terms: the tokens of ALL quoted
+ * phrases of a query, concatenated into one phrase as the reference does (main_retrieve.go:26); a doc
+ * matches if it holds every phrase term (body or title) and, per field, the term positions shifted by
+ * the term's index intersect; its float32 weight sums are added to TitleRank/BodyRank.  query_len NULL =
+ * len(query tokens)+len(phrase tokens) (main_retrieve.go:90).  At most SS_MAX_PHRASE_TERMS per phrase.
+ * Needs ss_index_set_positions on both tables. */
+#define SS_MAX_PHRASE_TERMS 16
+int32_t ss_score_topk_phrase(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
+                             const uint32_t* p_ptr, const uint32_t* p_terms, const int32_t* query_len,
+                             const double* topic_probs, int32_t k, ss_hit* hits_out, int32_t* n_hits_out);
 
 /* Timing hook for bench.py: milliseconds between the start and end HIP events
  * recorded on the ctx stream around the LAST compute call of the given kind

@@ -53,7 +53,7 @@ constexpr int PPT = CAP / TPB;     // records per thread
 #endif
 constexpr int HT = SS_HT;           // hash slots (1536: load factor <= 0.67; must be 2048*m/8)
 constexpr int EPT = (HT + TPB - 1) / TPB;   // hash entries per thread in the scan
-constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS;   // (term, field) lists per query
+constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS + 4;   // (term, field) lists per query + 4 phrase result lists
 #ifndef SS_TBL_CAP
 #define SS_TBL_CAP 4096
 #endif
@@ -85,6 +85,16 @@ struct SliceDesc {
 struct ScoreParams {
     const uint64_t* t_ptr; const Post* t_post;
     const uint64_t* b_ptr; const Post* b_post;
+    // positional postings (phrase search, retrieval/phrase.go): pos_ptr[P+1] into pos[] per table, or null
+    const uint64_t* t_pos_ptr; const float* t_pos;
+    const uint64_t* b_pos_ptr; const float* b_pos;
+    // phrase part of the batch: ph_off[n_q+1] into ph_terms (all quoted phrases of a query concatenated,
+    // main_retrieve.go:26), driver = index of the phrase's rarest term; outputs of k_phrase_match:
+    // four doc-sorted record lists per query (body/title sums found via the driver's body/title postings)
+    const uint32_t* ph_off; const uint32_t* ph_terms; const uint32_t* ph_drv;
+    const uint32_t* x_off;     // [n_q+1] capacity offsets of the phrase result lists
+    Post* x_list[4];           // 0: body sums (driver body pass), 1: title sums (driver body pass), 2: body (title pass), 3: title (title pass)
+    uint32_t* x_cnt;           // [n_q][4]
     const double* prior;       // [n_docs][k_topics] or null
     int32_t k_topics;
     const uint32_t* q_off;     // [n_q+1] into dterm/dmult
@@ -120,6 +130,20 @@ __device__ __forceinline__ uint64_t lower_bound_post(const Post* __restrict__ a,
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
         if (a[mid].doc < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// Lists are addressed by the absolute address of their first record (regular posting lists and the
+// per-query phrase result lists alike); explicit global address space keeps the loads global_load_*.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: loads as one global_load_dwordx4
+typedef const u32x4 __attribute__((address_space(1)))* gptr_u4;
+typedef const uint32_t __attribute__((address_space(1)))* gptr_u32;
+__device__ __forceinline__ u32x4 load_rec(uint64_t list_addr, uint64_t idx) { return *(gptr_u4)(list_addr + idx * sizeof(Post)); }
+__device__ __forceinline__ uint32_t load_doc(uint64_t list_addr, uint64_t idx) { return *(gptr_u32)(list_addr + idx * sizeof(Post)); }
+__device__ __forceinline__ uint32_t lower_bound_addr(uint64_t list_addr, uint32_t lo, uint32_t hi, uint32_t v) {
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (load_doc(list_addr, mid) < v) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ht_TB = reinterpret_cast<double*>(smem);                   // [HT][2] (BodyRank, TitleRank) accumulators of a doc
     double* s_mag = ht_TB + 2 * HT;                                    // [CAP] field magnitude carried by record i of the window
-    uint64_t* l_base = reinterpret_cast<uint64_t*>(s_mag + CAP);       // [MAXL] start of the term's list in its record array
+    uint64_t* l_base = reinterpret_cast<uint64_t*>(s_mag + CAP);       // [MAXL] address of the list's first record
     double* l_mult = reinterpret_cast<double*>(l_base + MAXL);         // [MAXL]
     uint64_t* sc64 = reinterpret_cast<uint64_t*>(l_mult + MAXL);       // [2]: thr
     uint64_t* cd_key = sc64 + 2;                                       // [cb]
@@ -234,7 +258,8 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
     const SliceDesc sd = p.slices[slice_id];
     const uint32_t q = sd.q;
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
-    const int L = (int)(2 * nd);
+    const bool has_phrase = p.ph_off && p.ph_off[q + 1] > p.ph_off[q];
+    const int L = (int)(2 * nd) + (has_phrase ? 4 : 0);
     const double qmag = p.qmag[q];
     const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
     const double sqd_ub = probs ? p.sqd_ub[q] : 0.0;
@@ -248,15 +273,28 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
     uint32_t* t_lo = tbl;                   // row 0 of the table
     uint32_t* t_hi = f_nxt;                 // parked here until n_win is known
     if (tid < L) {
-        const uint32_t term = p.dterm[t0 + (tid >> 1)];
-        const int field = tid & 1;                     // 0 = body, 1 = title
-        const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-        const Post* post = field ? p.t_post : p.b_post;
-        const uint64_t p0 = ptr[term], p1 = ptr[term + 1];
-        l_base[tid] = p0;
-        t_lo[tid] = (uint32_t)(lower_bound_post(post, p0, p1, sd.dlo) - p0);
-        t_hi[tid] = (uint32_t)((sd.dhi == 0xFFFFFFFFu ? p1 : lower_bound_post(post, p0, p1, sd.dhi)) - p0);
-        l_mult[tid] = (double)p.dmult[t0 + (tid >> 1)];
+        const int field = tid & 1;                     // 0 = body, 1 = title (also for the phrase lists)
+        uint64_t addr;
+        uint32_t len;
+        double mult;
+        if (tid < (int)(2 * nd)) {
+            const uint32_t term = p.dterm[t0 + (tid >> 1)];
+            const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
+            const uint64_t p0 = ptr[term];
+            addr = (uint64_t)((field ? p.t_post : p.b_post) + p0);
+            len = (uint32_t)(ptr[term + 1] - p0);
+            mult = (double)p.dmult[t0 + (tid >> 1)];
+        } else {
+            // phrase contributions are appended once, after the terms (main_retrieve.go:73-78)
+            const int x = tid - (int)(2 * nd);
+            addr = (uint64_t)(p.x_list[x] + p.x_off[q]);
+            len = p.x_cnt[(size_t)q * 4 + x];
+            mult = 1.0;
+        }
+        l_base[tid] = addr;
+        t_lo[tid] = lower_bound_addr(addr, 0, len, sd.dlo);
+        t_hi[tid] = sd.dhi == 0xFFFFFFFFu ? len : lower_bound_addr(addr, 0, len, sd.dhi);
+        l_mult[tid] = mult;
         l_field[tid] = field;
     }
     __syncthreads();
@@ -277,13 +315,11 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
     // window j covers docs [b_j, b_{j+1}), b_j = doc of the driver's record at j/n_win of its run:
     // all cursors are known up front (no per-window serial planning; windows fill evenly because
     // the other lists simply contribute whatever falls into the driver's doc range)
-    const Post* drv_post = l_field[drv] ? p.t_post : p.b_post;
-    const uint64_t drv_base = l_base[drv] + t_lo[drv];
+    const uint64_t drv_addr = l_base[drv];
     for (int idx = tid; idx < (n_win - 1) * L; idx += TPB) {
         const int j = idx / L + 1, l = idx - (j - 1) * L;
-        const uint32_t b = drv_post[drv_base + (uint64_t)j * drv_len / n_win].doc;
-        const Post* post = l_field[l] ? p.t_post : p.b_post;
-        tbl[j * L + l] = (uint32_t)(lower_bound_post(post, l_base[l] + t_lo[l], l_base[l] + t_hi[l], b) - l_base[l]);
+        const uint32_t b = load_doc(drv_addr, t_lo[drv] + (uint64_t)j * drv_len / n_win);
+        tbl[j * L + l] = lower_bound_addr(l_base[l], t_lo[l], t_hi[l], b);
     }
     __syncthreads();
     if (tid < L && n_win) tbl[n_win * L + tid] = t_hi[tid];
@@ -299,7 +335,7 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
     __syncthreads();
 
     // records of one window: raw 16-byte vectors (one global_load_dwordx4 per posting)
-    uint4 rec[PPT];
+    u32x4 rec[PPT];
     uint32_t rl[PPT];
     auto load_window = [&](int j) {
         const uint32_t* tbl_j = tbl + j * L;
@@ -318,8 +354,7 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
                     if (i >= o3) { l = 3; ol = o3; }
                     if (i >= o4) { l = 4; ol = o4; }
                     if (i >= o5) { l = 5; ol = o5; }
-                    const Post* base = (l & 1) ? p.t_post : p.b_post;         // kernel-argument pointers: global loads, not flat
-                    rec[r] = *reinterpret_cast<const uint4*>(base + (l_base[l] + tbl_j[l] + (i - ol)));
+                    rec[r] = load_rec(l_base[l], (uint64_t)tbl_j[l] + (i - ol));
                     rl[r] = l;
                 }
             }
@@ -336,8 +371,7 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
                         const int mid = (lo + hi) >> 1;
                         if (off_j[mid] <= i) lo = mid; else hi = mid;
                     }
-                    const Post* base = (lo & 1) ? p.t_post : p.b_post;
-                    rec[r] = *reinterpret_cast<const uint4*>(base + (l_base[lo] + tbl_j[lo] + (i - off_j[lo])));
+                    rec[r] = load_rec(l_base[lo], (uint64_t)tbl_j[lo] + (i - off_j[lo]));
                     rl[r] = lo;
                 }
             }
@@ -480,18 +514,16 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
             // ---- oversize window (a list is locally much denser than planned): bisect its doc range
             //      until a piece fits, process the piece, continue.  Rare; no prefetch here. ----
             if (tid < L) f_cur[tid] = tbl[j * L + tid];
-            uint32_t flo = j == 0 ? sd.dlo : drv_post[l_base[drv] + tbl[j * L + drv]].doc;
-            const uint32_t fend = j + 1 == n_win ? sd.dhi : drv_post[l_base[drv] + tbl[(j + 1) * L + drv]].doc;
+            uint32_t flo = j == 0 ? sd.dlo : load_doc(drv_addr, tbl[j * L + drv]);
+            const uint32_t fend = j + 1 == n_win ? sd.dhi : load_doc(drv_addr, tbl[(j + 1) * L + drv]);
             __syncthreads();
             for (;;) {
                 uint32_t fhi = fend;
                 uint32_t cnt;
                 for (;;) {
                     if (tid < L) {
-                        const Post* post = l_field[tid] ? p.t_post : p.b_post;
-                        const uint64_t e = l_base[tid] + tbl[(j + 1) * L + tid];
                         f_nxt[tid] = fhi == fend ? tbl[(j + 1) * L + tid]
-                                                 : (uint32_t)(lower_bound_post(post, l_base[tid] + f_cur[tid], e, fhi) - l_base[tid]);
+                                                 : lower_bound_addr(l_base[tid], f_cur[tid], tbl[(j + 1) * L + tid], fhi);
                     }
                     __syncthreads();
                     cnt = 0;
@@ -513,8 +545,7 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
                             if (i < run + len) break;
                             run += len;
                         }
-                        const Post* base = l_field[l] ? p.t_post : p.b_post;
-                        rec[r] = *reinterpret_cast<const uint4*>(base + (l_base[l] + f_cur[l] + (i - run)));
+                        rec[r] = load_rec(l_base[l], (uint64_t)f_cur[l] + (i - run));
                         rl[r] = l;
                     }
                 }
@@ -548,6 +579,130 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
         atomicAdd(&g_stamps[9], 1ull);
     }
 #endif
+}
+
+// ---- K6: quoted-phrase matching (retrieval/phrase.go:11-170, util.go:162-203) --------------------
+// One workgroup per query with a phrase.  Candidates = the docs of the phrase's rarest term (its body
+// postings, then its title-only postings); a thread takes one candidate doc and
+//   * looks the doc up in the body and title lists of every phrase term (binary search): the doc must have
+//     an entry for EVERY term position, in body or title (phrase.go:63);
+//   * per field: every term must be present in that field, the float32 weights are summed in phrase
+//     order (phrase.go:59,69,73,83,90) and the position lists, shifted by the term's index
+//     (getPosTerm :145,:157: listPos[i] -= float32(pos)), must have a common value (intersect,
+//     util.go:179-203; bit-exact float32 equality as in the reference);
+//   * matches leave as 16-byte records {doc, float32 sum, field magnitude} in doc order (ordered
+//     compaction), i.e. as ordinary doc-sorted lists that k_score_slices merges like any term list
+//     (main_retrieve.go:73-78).
+constexpr int PH_TPB = 256;
+constexpr int PH_MAX = 16;       // phrase terms (SS_MAX_PHRASE_TERMS)
+
+__device__ __forceinline__ bool positions_chain(const uint64_t* const* pos_ptr2, const float* const* pos2, int field,
+                                                const int32_t* my_post, int m) {
+    // S = A_0; S = S ∩ (A_i - i) for i = 1..m-1; non-empty?
+    const uint64_t* pp = pos_ptr2[field];
+    const float* ps = pos2[field];
+    const uint64_t a_beg = pp[my_post[0]], a_end = pp[my_post[0] + 1];
+    for (uint64_t a = a_beg; a < a_end; a++) {
+        const float v = ps[a] - 0.0f;
+        bool alive = true;
+        for (int i = 1; i < m && alive; i++) {
+            const uint64_t b_beg = pp[my_post[i * PH_TPB]], b_end = pp[my_post[i * PH_TPB] + 1];
+            bool found = false;
+            for (uint64_t b = b_beg; b < b_end; b++)
+                if (ps[b] - (float)i == v) { found = true; break; }
+            alive = found;
+        }
+        if (alive) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
+    __shared__ int32_t s_pb[PH_MAX * PH_TPB];     // body posting index of term i for this thread's doc, -1 = none
+    __shared__ int32_t s_pt[PH_MAX * PH_TPB];
+    __shared__ uint32_t s_wave[2][PH_TPB / 64];
+    __shared__ uint32_t s_base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t q = blockIdx.x;
+    const uint32_t f0 = p.ph_off[q], m = p.ph_off[q + 1] - f0;
+    uint32_t* cnt = p.x_cnt + (size_t)q * 4;
+    if (tid < 4) cnt[tid] = 0;
+    if (m == 0 || p.ph_drv[q] == 0xFFFFFFFFu) return;       // no phrase / a phrase word unknown to the index
+    const uint32_t drv_term = p.ph_terms[f0 + p.ph_drv[q]];
+    const uint64_t* pos_ptr2[2] = {p.b_pos_ptr, p.t_pos_ptr};
+    const float* pos2[2] = {p.b_pos, p.t_pos};
+    int32_t* my_pb = s_pb + tid;
+    int32_t* my_pt = s_pt + tid;
+    if (tid < 2) s_base[tid] = 0;
+    __syncthreads();
+
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: driver's body postings; pass 1: driver's title postings whose doc has no driver body posting
+        const uint64_t c0 = pass == 0 ? p.b_ptr[drv_term] : p.t_ptr[drv_term];
+        const uint64_t c1 = pass == 0 ? p.b_ptr[drv_term + 1] : p.t_ptr[drv_term + 1];
+        const Post* cpost = pass == 0 ? p.b_post : p.t_post;
+        if (tid < 2) s_base[tid] = 0;
+        __syncthreads();
+        for (uint64_t cb = c0; cb < c1; cb += PH_TPB) {
+            const uint64_t ci = cb + tid;
+            bool body_ok = false, title_ok = false;
+            float sum_b = 0.0f, sum_t = 0.0f;
+            uint32_t d = 0;
+            if (ci < c1) {
+                d = cpost[ci].doc;
+                bool all = true, body_all = true, title_all = true;
+                if (pass == 1) {
+                    const uint64_t b0 = p.b_ptr[drv_term], b1 = p.b_ptr[drv_term + 1];
+                    const uint64_t pos = lower_bound_post(p.b_post, b0, b1, d);
+                    if (pos < b1 && p.b_post[pos].doc == d) all = false;       // already handled in pass 0
+                }
+                for (uint32_t i = 0; i < m && all; i++) {
+                    const uint32_t term = p.ph_terms[f0 + i];
+                    const uint64_t b0 = p.b_ptr[term], b1 = p.b_ptr[term + 1];
+                    const uint64_t t0 = p.t_ptr[term], t1 = p.t_ptr[term + 1];
+                    const uint64_t pb = lower_bound_post(p.b_post, b0, b1, d);
+                    const uint64_t pt = lower_bound_post(p.t_post, t0, t1, d);
+                    const bool hb = pb < b1 && p.b_post[pb].doc == d, ht = pt < t1 && p.t_post[pt].doc == d;
+                    my_pb[i * PH_TPB] = hb ? (int32_t)pb : -1;
+                    my_pt[i * PH_TPB] = ht ? (int32_t)pt : -1;
+                    if (!hb && !ht) all = false;                      // phrase.go:63
+                    if (hb) sum_b += p.b_post[pb].w; else body_all = false;     // phrase.go:69,80-84
+                    if (ht) sum_t += p.t_post[pt].w; else title_all = false;    // phrase.go:73,87-91
+                }
+                if (all) {
+                    if (body_all) body_ok = positions_chain(pos_ptr2, pos2, 0, my_pb, (int)m);
+                    if (title_all) title_ok = positions_chain(pos_ptr2, pos2, 1, my_pt, (int)m);
+                }
+            }
+            // ordered compaction of the matches of this chunk (keeps the lists doc-sorted)
+            const unsigned long long mb = __ballot(body_ok), mt = __ballot(title_ok);
+            if (lane == 0) { s_wave[0][wave] = (uint32_t)__popcll(mb); s_wave[1][wave] = (uint32_t)__popcll(mt); }
+            __syncthreads();
+            uint32_t ob = s_base[0], ot = s_base[1];
+            for (int w2 = 0; w2 < wave; w2++) { ob += s_wave[0][w2]; ot += s_wave[1][w2]; }
+            const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+            if (body_ok) {
+                Post r;
+                r.doc = d; r.w = sum_b; r.mag = p.b_post[my_pb[0]].mag;
+                p.x_list[pass == 0 ? 0 : 2][p.x_off[q] + ob + (uint32_t)__popcll(mb & below)] = r;
+            }
+            if (title_ok) {
+                Post r;
+                r.doc = d; r.w = sum_t; r.mag = p.t_post[my_pt[0]].mag;
+                p.x_list[pass == 0 ? 1 : 3][p.x_off[q] + ot + (uint32_t)__popcll(mt & below)] = r;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t tb = 0, tt = 0;
+                for (int w2 = 0; w2 < PH_TPB / 64; w2++) { tb += s_wave[0][w2]; tt += s_wave[1][w2]; }
+                s_base[0] += tb;
+                s_base[1] += tt;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { cnt[pass == 0 ? 0 : 2] = s_base[0]; cnt[pass == 0 ? 1 : 3] = s_base[1]; }
+        __syncthreads();
+    }
 }
 
 size_t score_lds_bytes(int cb) {
@@ -594,22 +749,34 @@ __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
     for (uint32_t i = tid; i < n_out; i += TPB_M) { accT[i] = 0.0; accB[i] = 0.0; mgT[i] = 1.0; mgB[i] = 1.0; }
     __syncthreads();
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
-    const uint32_t L = 2 * nd;
+    const bool has_phrase = p.ph_off && p.ph_off[q + 1] > p.ph_off[q];
+    const uint32_t L = 2 * nd + (has_phrase ? 4u : 0u);
     for (uint32_t task = tid; task < n_out * L; task += TPB_M) {
         const uint32_t i = task / L, l = task % L;
-        const uint32_t term = p.dterm[t0 + (l >> 1)];
         const int field = l & 1;
-        const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-        const Post* post = field ? p.t_post : p.b_post;
+        uint64_t addr;
+        uint32_t len;
+        double mult;
+        if (l < 2 * nd) {
+            const uint32_t term = p.dterm[t0 + (l >> 1)];
+            const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
+            addr = (uint64_t)((field ? p.t_post : p.b_post) + ptr[term]);
+            len = (uint32_t)(ptr[term + 1] - ptr[term]);
+            mult = (double)p.dmult[t0 + (l >> 1)];
+        } else {
+            addr = (uint64_t)(p.x_list[l - 2 * nd] + p.x_off[q]);
+            len = p.x_cnt[(size_t)q * 4 + (l - 2 * nd)];
+            mult = 1.0;
+        }
         const uint32_t d = cd_doc[i];
-        const uint64_t p1 = ptr[term + 1];
-        const uint64_t pos = lower_bound_post(post, ptr[term], p1, d);
-        if (pos < p1) {
-            const Post r = post[pos];
-            if (r.doc == d) {
-                const double v = (double)r.w * (double)p.dmult[t0 + (l >> 1)];
-                if (field) { atomicAdd(&accT[i], v); mgT[i] = r.mag; }
-                else { atomicAdd(&accB[i], v); mgB[i] = r.mag; }
+        const uint32_t pos = lower_bound_addr(addr, 0, len, d);
+        if (pos < len) {
+            const u32x4 raw = load_rec(addr, pos);
+            if (raw.x == d) {
+                const double v = (double)__uint_as_float(raw.y) * mult;
+                const double mag = __hiloint2double((int)raw.w, (int)raw.z);
+                if (field) { atomicAdd(&accT[i], v); mgT[i] = mag; }
+                else { atomicAdd(&accB[i], v); mgB[i] = mag; }
             }
         }
     }
@@ -695,6 +862,8 @@ struct ss_scorer {
     unsigned char* h_plan = nullptr;            // pinned staging for the plan
     size_t h_plan_cap = 0;
     ss::DevBuf<double> d_probs;
+    ss::DevBuf<Post> d_x[4];                    // phrase result lists
+    ss::DevBuf<uint32_t> d_xcnt;
     ss::DevBuf<uint64_t> d_so_key;
     ss::DevBuf<uint32_t> d_so_doc, d_so_cnt;
     ss::DevBuf<ss_hit> d_hits;
@@ -814,8 +983,25 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank) 
     return SS_OK;
 }
 
+static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const uint32_t* p_ptr,
+                          const uint32_t* p_terms, const int32_t* query_len, const double* topic_probs, int32_t k,
+                          ss_hit* hits_out, int32_t* n_hits_out);
+
 int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const int32_t* query_len,
                       const double* topic_probs, int32_t k, ss_hit* hits_out, int32_t* n_hits_out) {
+    return score_impl(s, n_q, q_ptr, q_terms, nullptr, nullptr, query_len, topic_probs, k, hits_out, n_hits_out);
+}
+
+int32_t ss_score_topk_phrase(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const uint32_t* p_ptr,
+                             const uint32_t* p_terms, const int32_t* query_len, const double* topic_probs, int32_t k,
+                             ss_hit* hits_out, int32_t* n_hits_out) {
+    if (s && !p_ptr) return s->ctx->fail(SS_ERR_INVALID, "ss_score_topk_phrase: p_ptr is NULL");
+    return score_impl(s, n_q, q_ptr, q_terms, p_ptr, p_terms, query_len, topic_probs, k, hits_out, n_hits_out);
+}
+
+static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const uint32_t* p_ptr,
+                          const uint32_t* p_terms, const int32_t* query_len, const double* topic_probs, int32_t k,
+                          ss_hit* hits_out, int32_t* n_hits_out) {
     if (!s) return SS_ERR_INVALID;
     ss_ctx* ctx = s->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -836,9 +1022,24 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
     if (n_tok && !q_terms) return ctx->fail(SS_ERR_INVALID, "ss_score_topk: q_terms is NULL");
     std::vector<uint32_t> h_terms(n_tok);
     if (n_tok) SS_HIP(ctx, hipMemcpy(h_terms.data(), q_terms, n_tok * sizeof(uint32_t), hipMemcpyDefault));
+    // phrase part (retrieval/phrase.go): tokens of all quoted phrases of a query, concatenated
+    std::vector<uint32_t> h_pptr(n_q + 1, 0), h_pterms, h_pdrv(n_q, 0xFFFFFFFFu), h_xoff(n_q + 1, 0);
+    if (p_ptr) {
+        if (!s->title->pos_ptr.p || !s->body->pos_ptr.p)
+            return ctx->fail(SS_ERR_STATE, "ss_score_topk_phrase: positional postings not loaded (ss_index_set_positions on both tables)");
+        SS_HIP(ctx, hipMemcpy(h_pptr.data(), p_ptr, (n_q + 1) * sizeof(uint32_t), hipMemcpyDefault));
+        for (int q = 0; q < n_q; q++)
+            if (h_pptr[q + 1] < h_pptr[q]) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_phrase: p_ptr not non-decreasing");
+        h_pterms.resize(h_pptr[n_q]);
+        if (h_pptr[n_q]) {
+            if (!p_terms) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_phrase: p_terms is NULL");
+            SS_HIP(ctx, hipMemcpy(h_pterms.data(), p_terms, h_pterms.size() * sizeof(uint32_t), hipMemcpyDefault));
+        }
+    }
     std::vector<int32_t> h_qlen(n_q);
     if (query_len) SS_HIP(ctx, hipMemcpy(h_qlen.data(), query_len, n_q * sizeof(int32_t), hipMemcpyDefault));
-    else for (int q = 0; q < n_q; q++) h_qlen[q] = (int32_t)(h_qptr[q + 1] - h_qptr[q]);
+    else for (int q = 0; q < n_q; q++)     // len(queryTokenised)+len(phraseTokenised), main_retrieve.go:90
+        h_qlen[q] = (int32_t)(h_qptr[q + 1] - h_qptr[q]) + (int32_t)(h_pptr[q + 1] - h_pptr[q]);
     std::vector<double> h_probs;
     const int K = s->k_topics;
     if (topic_probs) {
@@ -848,6 +1049,24 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
 
     const std::vector<uint64_t>& tp = s->title->h_term_ptr;
     const std::vector<uint64_t>& bp = s->body->h_term_ptr;
+    bool any_phrase = false;
+    for (int q = 0; q < n_q && p_ptr; q++) {
+        const uint32_t m = h_pptr[q + 1] - h_pptr[q];
+        h_xoff[q + 1] = h_xoff[q];
+        if (m == 0) continue;
+        any_phrase = true;
+        if (m > 16) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_score_topk_phrase: query %d has a phrase of %u terms (max 16)", q, m);
+        uint64_t best = ~0ull;
+        bool known = true;
+        for (uint32_t i = 0; i < m; i++) {
+            const uint32_t t = h_pterms[h_pptr[q] + i];
+            if ((uint64_t)t >= s->n_terms) { known = false; break; }    // a doc must contain EVERY phrase term (phrase.go:63)
+            const uint64_t df = (tp[t + 1] - tp[t]) + (bp[t + 1] - bp[t]);
+            if (df < best) { best = df; h_pdrv[q] = i; }
+        }
+        if (!known) { h_pdrv[q] = 0xFFFFFFFFu; continue; }
+        h_xoff[q + 1] = h_xoff[q] + (uint32_t)std::min<uint64_t>(best, 0x7FFFFFFFull);   // matches <= docs of the rarest term
+    }
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
     std::vector<double> h_qmag(n_q), h_ub(n_q, 0.0);
     std::vector<SliceDesc> h_slices;
@@ -912,6 +1131,10 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
     const size_t o_qmag = o;   o = align16(o + n_q * sizeof(double));
     const size_t o_ub = o;     o = align16(o + n_q * sizeof(double));
     const size_t o_slices = o; o = align16(o + n_slices * sizeof(SliceDesc));
+    const size_t o_pptr = o;   o = align16(o + (n_q + 1) * sizeof(uint32_t));
+    const size_t o_pterms = o; o = align16(o + h_pterms.size() * sizeof(uint32_t));
+    const size_t o_pdrv = o;   o = align16(o + n_q * sizeof(uint32_t));
+    const size_t o_xoff = o;   o = align16(o + (n_q + 1) * sizeof(uint32_t));
     const size_t plan_bytes = o;
     if (s->h_plan_cap < plan_bytes) {
         if (s->h_plan) (void)hipHostFree(s->h_plan);
@@ -932,7 +1155,15 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
     std::memcpy(hp + o_qmag, h_qmag.data(), n_q * sizeof(double));
     std::memcpy(hp + o_ub, h_ub.data(), n_q * sizeof(double));
     std::memcpy(hp + o_slices, h_slices.data(), n_slices * sizeof(SliceDesc));
+    std::memcpy(hp + o_pptr, h_pptr.data(), (n_q + 1) * sizeof(uint32_t));
+    if (!h_pterms.empty()) std::memcpy(hp + o_pterms, h_pterms.data(), h_pterms.size() * sizeof(uint32_t));
+    std::memcpy(hp + o_pdrv, h_pdrv.data(), n_q * sizeof(uint32_t));
+    std::memcpy(hp + o_xoff, h_xoff.data(), (n_q + 1) * sizeof(uint32_t));
     SS_HIP(ctx, hipMemcpyAsync(s->d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, st));
+    if (any_phrase) {
+        for (int x = 0; x < 4; x++) SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
+        SS_HIP(ctx, ensure(s->d_xcnt, (size_t)n_q * 4));
+    }
     SS_HIP(ctx, ensure(s->d_so_key, n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_doc, n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_cnt, n_slices));
@@ -947,6 +1178,16 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
     ScoreParams p{};
     p.t_ptr = s->title->term_ptr.p; p.t_post = s->t_post.p;
     p.b_ptr = s->body->term_ptr.p; p.b_post = s->b_post.p;
+    p.t_pos_ptr = s->title->pos_ptr.p; p.t_pos = s->title->pos.p;
+    p.b_pos_ptr = s->body->pos_ptr.p; p.b_pos = s->body->pos.p;
+    if (any_phrase) {
+        p.ph_off = reinterpret_cast<const uint32_t*>(dp + o_pptr);
+        p.ph_terms = reinterpret_cast<const uint32_t*>(dp + o_pterms);
+        p.ph_drv = reinterpret_cast<const uint32_t*>(dp + o_pdrv);
+        p.x_off = reinterpret_cast<const uint32_t*>(dp + o_xoff);
+        for (int x = 0; x < 4; x++) p.x_list[x] = s->d_x[x].p;
+        p.x_cnt = s->d_xcnt.p;
+    }
     p.prior = K ? s->prior.p : nullptr;
     p.k_topics = K;
     p.q_off = reinterpret_cast<const uint32_t*>(dp + o_qoff);
@@ -971,6 +1212,7 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
         s->lds_attr = cb;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
+    if (any_phrase) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
     hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_slices), dim3(TPB), lds_score, st, p);
     hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));

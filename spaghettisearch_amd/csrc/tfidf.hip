@@ -228,6 +228,28 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     return SS_OK;
 }
 
+int32_t ss_index_set_positions(ss_index* idx, const uint64_t* pos_ptr, const float* pos) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!pos_ptr) return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos_ptr is NULL");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t P = idx->n_post;
+    SS_HIP(ctx, idx->pos_ptr.alloc(P + 1));
+    SS_HIP(ctx, hipMemcpyAsync(idx->pos_ptr.p, pos_ptr, (P + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
+    uint64_t ends[2] = {0, 0};
+    SS_HIP(ctx, hipMemcpyAsync(&ends[0], idx->pos_ptr.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&ends[1], idx->pos_ptr.p + P, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (ends[0] != 0) return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos_ptr[0] != 0");
+    if (ends[1] && !pos) return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos is NULL");
+    SS_HIP(ctx, idx->pos.alloc(ends[1]));
+    if (ends[1]) SS_HIP(ctx, hipMemcpyAsync(idx->pos.p, pos, ends[1] * sizeof(float), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    return SS_OK;
+}
+
 int32_t ss_index_set_weighted(ss_index* idx, const double* mag) {
     if (!idx) return SS_ERR_INVALID;
     ss_ctx* ctx = idx->ctx;

@@ -189,6 +189,12 @@ class InvertedIndex:
         check(self.ctx.lib.ss_tfidf_build(self.h, int(total_docs), _ptr(w), _ptr(mag), _ptr(idf)), self.ctx.h)
         return w, mag, idf
 
+    def set_positions(self, pos_ptr, pos) -> None:
+        """Positional postings (listPos[1:] per posting) for phrase search."""
+        pos_ptr = _as(pos_ptr, "uint64")
+        pos = _as(pos, "float32")
+        check(self.ctx.lib.ss_index_set_positions(self.h, _ptr(pos_ptr), _ptr(pos)), self.ctx.h)
+
     def set_weighted(self, mag) -> None:
         mag = _as(mag, "float64")
         check(self.ctx.lib.ss_index_set_weighted(self.h, _ptr(mag)), self.ctx.h)
@@ -219,6 +225,21 @@ class Scorer:
         rank = _as(rank, "float64")
         self.k_topics = int(rank.shape[0])
         check(self.ctx.lib.ss_scorer_set_prior(self.h, self.k_topics, _ptr(rank)), self.ctx.h)
+
+    def score_topk_phrase(self, q_ptr, q_terms, p_ptr, p_terms, k: int, query_len=None, topic_probs=None):
+        """ss_score_topk_phrase: OR terms + one concatenated quoted phrase per query."""
+        q_ptr = _as(q_ptr, "uint32")
+        q_terms = _as(q_terms, "uint32")
+        p_ptr = _as(p_ptr, "uint32")
+        p_terms = _as(p_terms, "uint32")
+        query_len = _as(query_len, "int32")
+        topic_probs = _as(topic_probs, "float64")
+        n_q = int(q_ptr.shape[0]) - 1
+        hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
+        n_hits = np.zeros(n_q, dtype=np.int32)
+        check(self.ctx.lib.ss_score_topk_phrase(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(p_ptr), _ptr(p_terms),
+                                                _ptr(query_len), _ptr(topic_probs), k, hits.ctypes.data, _ptr(n_hits)), self.ctx.h)
+        return hits, n_hits
 
     def score_topk(self, q_ptr, q_terms, k: int, query_len=None, topic_probs=None, out=None):
         """-> (hits [n_q][k] HIT_DTYPE, n_hits [n_q] int32).

@@ -6,6 +6,7 @@
 // Text normalisation (parser.Laundry: Porter2 stemming + stop words) and result decoration
 // (get_metadata.go:79-235) are host-side Go in the reference and stay out of scope: `laundry` is a
 // hook (default: lower-cased alphanumeric tokens), decoration fills DocHash/PageRank/FinalRank only.
+// Quoted phrases (retrieval/phrase.go) are matched on the device from the positional part of the rows.
 #pragma once
 #include <cctype>
 #include <functional>
@@ -77,26 +78,37 @@ public:
         terms.build(all_terms.begin(), all_terms.end());
         const size_t n = docs.name.size(), T = terms.name.size();
         auto flatten = [&](const std::vector<db::KV>& comp, std::vector<std::map<std::string, std::vector<float>>>& rows,
-                           std::vector<uint64_t>& ptr, std::vector<uint32_t>& doc, std::vector<float>& w) {
+                           std::vector<uint64_t>& ptr, std::vector<uint32_t>& doc, std::vector<float>& w,
+                           std::vector<uint64_t>& pos_ptr, std::vector<float>& pos) {
             std::vector<const std::map<std::string, std::vector<float>>*> by_term(T, nullptr);
             for (size_t i = 0; i < comp.size(); i++) by_term[terms.id[comp[i].first]] = &rows[i];
             ptr.assign(T + 1, 0);
             for (size_t t = 0; t < T; t++) ptr[t + 1] = ptr[t] + (by_term[t] ? by_term[t]->size() : 0);
             doc.resize(ptr[T]);
             w.resize(ptr[T]);
+            pos_ptr.assign(1, 0);
+            pos.clear();
             for (size_t t = 0; t < T; t++) {
                 if (!by_term[t]) continue;
                 uint64_t j = ptr[t];
-                for (auto& kv : *by_term[t]) { doc[j] = docs.id[kv.first]; w[j] = kv.second.at(0); j++; }   // first entry = norm_tf*idf (main_retrieve.go:227,236)
+                for (auto& kv : *by_term[t]) {
+                    doc[j] = docs.id[kv.first];
+                    w[j] = kv.second.at(0);                                            // first entry = norm_tf*idf (main_retrieve.go:227,236)
+                    pos.insert(pos.end(), kv.second.begin() + 1, kv.second.end());     // listPos[1:] = positions (phrase.go:144-146)
+                    pos_ptr.push_back(pos.size());
+                    j++;
+                }
             }
         };
-        std::vector<uint64_t> tp, bp;
+        std::vector<uint64_t> tp, bp, tpp, bpp;
         std::vector<uint32_t> td, bd;
-        std::vector<float> tw, bw;
-        flatten(tcomp, trow, tp, td, tw);
-        flatten(bcomp, brow, bp, bd, bw);
+        std::vector<float> tw, bw, tps, bps;
+        flatten(tcomp, trow, tp, td, tw, tpp, tps);
+        flatten(bcomp, brow, bp, bd, bw, bpp, bps);
         check(ss_index_create(default_ctx(), n, T, tp.data(), td.data(), tw.data(), &title), "ss_index_create(title)");
         check(ss_index_create(default_ctx(), n, T, bp.data(), bd.data(), bw.data(), &body), "ss_index_create(body)");
+        check(ss_index_set_positions(title, tpp.data(), tps.data()), "ss_index_set_positions(title)");
+        check(ss_index_set_positions(body, bpp.data(), bps.data()), "ss_index_set_positions(body)");
         // forw[4]: a missing "title"/"body" key reads as 0 (get_metadata.go:57-58, Q8)
         std::vector<double> magT(n, 0.0), magB(n, 0.0);
         for (auto& kv : forw[4]->Iterate(ctx)) {
@@ -134,7 +146,7 @@ public:
     std::vector<std::vector<Rank_combined>> RetrieveBatch(const std::vector<std::string>& queries, int k = 50,
                                                           const std::vector<std::map<std::string, double>>* topicProbs = nullptr) {
         using namespace spaghetti;
-        std::vector<uint32_t> q_ptr{0}, q_terms;
+        std::vector<uint32_t> q_ptr{0}, q_terms, p_ptr{0}, p_terms;
         std::vector<int32_t> q_len;
         for (std::string query : queries) {
             // main_retrieve.go:17-36
@@ -151,8 +163,13 @@ public:
                 q_terms.push_back(it == terms.id.end() ? SS_UNKNOWN_TERM : it->second);   // ErrKeyNotFound tolerated (:193,:218)
             }
             q_ptr.push_back((uint32_t)q_terms.size());
+            // all quoted phrases form ONE phrase (main_retrieve.go:26), matched on the device (retrieval/phrase.go)
+            for (auto& tok : phraseTokenised) {
+                auto it = terms.id.find(md5::hex(tok));
+                p_terms.push_back(it == terms.id.end() ? SS_UNKNOWN_TERM : it->second);
+            }
+            p_ptr.push_back((uint32_t)p_terms.size());
             q_len.push_back((int32_t)(queryTokenised.size() + phraseTokenised.size()));   // :90
-            // phrase search itself (retrieval/phrase.go) is the next row of the scope table
         }
         const int nq = (int)queries.size();
         std::vector<double> probs;
@@ -167,8 +184,8 @@ public:
         }
         std::vector<ss_hit> hits((size_t)nq * k);
         std::vector<int32_t> n_hits(nq);
-        check(ss_score_topk(scorer, nq, q_ptr.data(), q_terms.data(), q_len.data(), probs.empty() ? nullptr : probs.data(), k, hits.data(),
-                            n_hits.data()), "ss_score_topk");
+        check(ss_score_topk_phrase(scorer, nq, q_ptr.data(), q_terms.data(), p_ptr.data(), p_terms.data(), q_len.data(),
+                                   probs.empty() ? nullptr : probs.data(), k, hits.data(), n_hits.data()), "ss_score_topk_phrase");
         std::vector<std::vector<Rank_combined>> out(nq);
         for (int q = 0; q < nq; q++)
             for (int i = 0; i < n_hits[q]; i++) {

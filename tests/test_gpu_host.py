@@ -106,6 +106,17 @@ def oracle_index(table, docs_sorted, terms_sorted):
     return np.array(ptr, np.uint64), np.array(pdoc, np.uint32), np.array(ptf, np.float32)
 
 
+def oracle_positions(table, docs_sorted, terms_sorted):
+    didx = {k: i for i, k in enumerate(docs_sorted)}
+    pos_ptr, pos = [0], []
+    for t in terms_sorted:
+        row = table.get(t, {})
+        for k in sorted(row, key=lambda k: didx[k]):
+            pos += row[k][1:]
+            pos_ptr.append(len(pos))
+    return np.array(pos_ptr, np.uint64), np.array(pos, np.float32)
+
+
 def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
     forw, inv = make_tables(host, corpus)
     # --- start_crawl.go:175 -------------------------------------------------------------
@@ -144,7 +155,7 @@ def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
     # --- server.go:47 ----------------------------------------------------------------------
     di = host.DeviceIndex()
     di.load(forw, inv)
-    queries = ["w3 w17 w40", "W5, w5!  w9", "w149 nosuchword", "zzz", 'w1 "w2 w3" w4']
+    queries = ["w3 w17 w40", "W5, w5!  w9", "w149 nosuchword", "zzz", 'w1 "w2 w3" w4', '"w0 w1"', '"w5" w6 "w0"']
     got = di.RetrieveBatch(queries, 50)
     # oracle on the tables as they are now (weighted), dense ids in sorted key order
     docs_sorted = sorted(set(forw[3].keys()))
@@ -152,8 +163,8 @@ def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
 
     def weighted(t):
         tab = {term: json.loads(t.get(term)) for term in t.keys()}
-        return oracle_index(tab, docs_sorted, terms)
-    title, body = weighted(inv[0]), weighted(inv[1])
+        return oracle_index(tab, docs_sorted, terms), oracle_positions(tab, docs_sorted, terms)
+    (title, tpos), (body, bpos) = weighted(inv[0]), weighted(inv[1])
     mt = np.zeros(len(docs_sorted))
     mb = np.zeros(len(docs_sorted))
     for d in forw[4].keys():
@@ -169,7 +180,10 @@ def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
         toks = re.findall(r"[a-z0-9]+", rest.lower())
         ptoks = re.findall(r"[a-z0-9]+", " ".join(phrases).lower())
         qt = np.array([tidx.get(h(t), 0xFFFFFFFF) for t in toks], dtype=np.uint32)
-        hits, _ = oracle.score_topk(len(docs_sorted), title, body, mt, mb, qt, 50, query_len=len(toks) + len(ptoks))
+        extra = None
+        if ptoks:      # quoted phrase: matched on positions (retrieval/phrase.go), merged at main_retrieve.go:73-78
+            extra = oracle.phrase(title, body, tpos, bpos, [tidx[h(t)] for t in ptoks])
+        hits, _ = oracle.score_topk(len(docs_sorted), title, body, mt, mb, qt, 50, query_len=len(toks) + len(ptoks), extra=extra)
         assert [r.DocHash for r in res] == [docs_sorted[int(x["doc"])] for x in hits], q
         assert [r.FinalRank for r in res] == hits["final"].tolist()
         assert all(r.PageRank == 0.0 for r in res)                                      # Q9: nil topicProbs
