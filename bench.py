@@ -207,6 +207,24 @@ def main() -> None:
             else:
                 sp, sb, rp, rb = pr.exchange_buffers()
                 result["exchange"] = {"allgather_recv_bytes_per_sweep": rb, "send_bytes_per_rank": sb}
+                # Alternative decomposition measured in the same run: the K topic vectors are independent power
+                # iterations (pagerank.go:54-63), so they can also be split across the ranks with NO collective
+                # (every rank holds the 240 MB graph, runs K/N topics).  Reported beside the doc-sharded `value`.
+                if kt % world == 0:
+                    g1 = engine.Graph(ctx, n, out_ptr, out_dst)
+                    mine = n_topic[rank * (kt // world):(rank + 1) * (kt // world)]
+                    pt = engine.PageRankState(g1, d, -1.0, mine, max_iter=0)
+                    pt.begin()
+                    pt.step(max(W, 1))
+                    barrier()
+                    t0 = time.perf_counter()
+                    pt.step(K)
+                    barrier()
+                    dtt = max_over_ranks(time.perf_counter() - t0)
+                    result["alt_topic_sharded"] = {"value": kt * K / dtt, "unit": "topic-iterations/s", "ms_per_step": dtt * 1e3 / K,
+                                                   "parallelism": f"{kt // world} topics per rank x{world}, full graph per rank, no collective"}
+                    pt.close()
+                    g1.close()
             # to-convergence run at the BASELINE eps (not timed into `value`)
             prc = engine.PageRankState(g, d, 1e-6, n_topic)
             exc = sharding.DistExchange(prc, dev, host_staged=rehearsal) if world > 1 else None
