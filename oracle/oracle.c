@@ -12,6 +12,9 @@
 
 #include <float.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -222,6 +225,67 @@ int orc_pagerank_topic_hashed(uint64_t n_nodes, const uint64_t* out_ptr, const u
     return 0;
 }
 
+/* --- "strong CPU" variant: flat in-edge lists, pull form, OpenMP over all cores. --- */
+/* Same arithmetic per node; the float64 sums run in a different order (in-edge order per node, per-   */
+/* thread partial sums), so it agrees with orc_pagerank_topic to ~1e-15, not bit for bit.              */
+/* CPU baseline only.                                                                                  */
+int orc_pagerank_topic_omp(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
+                           double d, double eps, int32_t max_iter, int32_t n_init,
+                           double* rank, int32_t* iters, int32_t* threads_used)
+{
+    const uint64_t N = n_nodes, E = out_ptr[N];
+    uint64_t* in_ptr = (uint64_t*)calloc(N + 2, sizeof(uint64_t));
+    uint32_t* in_src = (uint32_t*)malloc(sizeof(uint32_t) * (E ? E : 1));
+    double* cur = (double*)malloc(sizeof(double) * (N ? N : 1));
+    double* last = (double*)malloc(sizeof(double) * (N ? N : 1));
+    double* contrib = (double*)malloc(sizeof(double) * (N ? N : 1));
+    if (!in_ptr || !in_src || !cur || !last || !contrib) return -1;
+    /* transpose once (counting sort by destination) */
+    for (uint64_t e = 0; e < E; e++) in_ptr[out_dst[e] + 2]++;
+    for (uint64_t v = 0; v < N; v++) in_ptr[v + 2] += in_ptr[v + 1];
+    for (uint64_t p = 0; p < N; p++)
+        for (uint64_t e = out_ptr[p]; e < out_ptr[p + 1]; e++) in_src[in_ptr[out_dst[e] + 1]++] = (uint32_t)p;
+    const double teleport = 1.0 - d;
+    const double u = 1.0 / (double)n_init;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    #pragma omp parallel for schedule(static)
+    for (uint64_t v = 0; v < N; v++) last[v] = u;
+    double last_change = DBL_MAX;
+    int32_t iteration = 1;
+    for (; last_change > eps; iteration++) {
+        double total = 0.0;
+        #pragma omp parallel for schedule(static) reduction(+ : total)
+        for (uint64_t p = 0; p < N; p++) {
+            const uint64_t deg = out_ptr[p + 1] - out_ptr[p];
+            double w = 0.0;
+            if (deg) { w = d * last[p] / (double)deg; total += w; }
+            contrib[p] = w;
+        }
+        total += teleport * (double)N;
+        const double first = iteration == 1 ? u : 0.0;
+        double change = 0.0;
+        #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : change)
+        for (uint64_t v = 0; v < N; v++) {
+            double y = first;
+            for (uint64_t e = in_ptr[v]; e < in_ptr[v + 1]; e++) y += contrib[in_src[e]];
+            const double x = (y + teleport) / total;
+            change += fabs(x - last[v]);
+            cur[v] = x;
+        }
+        last_change = change;
+        double* t = cur; cur = last; last = t;
+        if (max_iter > 0 && iteration >= max_iter) { iteration++; break; }
+    }
+    memcpy(rank, last, sizeof(double) * N);
+    if (iters) *iters = iteration - 1;
+    if (threads_used) *threads_used = nthreads;
+    free(in_ptr); free(in_src); free(cur); free(last); free(contrib);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* TF-IDF build — ranking/term_weighting.go:10-57                             */
 /* ------------------------------------------------------------------------- */
@@ -396,6 +460,46 @@ int orc_score_topk(uint64_t n_docs, uint64_t n_terms,
                        k, hits, n_hits, n_cand);
     ws_free(&w);
     return rc;
+}
+
+/* "strong CPU" scoring (B2): the same per-query code, queries spread over all cores (the reference fans
+ * out goroutines per term and per candidate, main_retrieve.go:55-57, get_metadata.go:21-23). */
+int orc_score_topk_batch_omp(uint64_t n_docs, uint64_t n_terms,
+                             const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+                             const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+                             const double* mag_title, const double* mag_body,
+                             int32_t k_topics, const double* prior, const double* topic_probs,
+                             int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
+                             const int32_t* query_len, int32_t k, orc_hit* hits, int32_t* n_hits, int32_t* threads_used)
+{
+    int rc_all = 0;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+    if (nthreads > n_q) nthreads = n_q > 0 ? n_q : 1;
+#endif
+    if (threads_used) *threads_used = nthreads;
+    #pragma omp parallel num_threads(nthreads)
+    {
+        score_ws w;
+        int rc = ws_init(&w, n_docs);
+        #pragma omp for schedule(dynamic, 1)
+        for (int32_t q = 0; q < n_q; q++) {
+            if (rc) continue;
+            const int32_t nt = (int32_t)(q_ptr[q + 1] - q_ptr[q]);
+            const int32_t ql = query_len ? query_len[q] : nt;
+            rc = score_one(&w, n_terms, t_ptr, t_doc, t_w, b_ptr, b_doc, b_w, mag_title, mag_body,
+                           k_topics, prior, topic_probs ? topic_probs + (uint64_t)q * k_topics : NULL,
+                           q_terms + q_ptr[q], nt, ql, 0, NULL, NULL, NULL, NULL,
+                           k, hits + (uint64_t)q * k, n_hits + q, NULL);
+        }
+        ws_free(&w);
+        if (rc) {
+            #pragma omp critical
+            rc_all = rc;
+        }
+    }
+    return rc_all;
 }
 
 int orc_score_topk_batch(uint64_t n_docs, uint64_t n_terms,

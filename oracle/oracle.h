@@ -67,6 +67,19 @@ int orc_pagerank_topic_hashed(uint64_t n_nodes, const uint64_t* out_ptr, const u
                               double d, double eps, int32_t max_iter, int32_t n_init,
                               double* rank, int32_t* iters);
 
+/* "Strong CPU" baselines: same arithmetic, flat arrays, OpenMP over all host cores.
+ * PageRank in pull form over in-edge lists (sums in a different order: agrees to ~1e-15). */
+int orc_pagerank_topic_omp(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
+                           double d, double eps, int32_t max_iter, int32_t n_init,
+                           double* rank, int32_t* iters, int32_t* threads_used);
+int orc_score_topk_batch_omp(uint64_t n_docs, uint64_t n_terms,
+                             const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+                             const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+                             const double* mag_title, const double* mag_body,
+                             int32_t k_topics, const double* prior, const double* topic_probs,
+                             int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
+                             const int32_t* query_len, int32_t k, orc_hit* hits, int32_t* n_hits, int32_t* threads_used);
+
 /*
  * ranking/term_weighting.go:10-57 for one inverted table (term-major CSR).
  *   post_w: in = normalised tf (indexer.go:362), out = tf*idf (float32, :42)

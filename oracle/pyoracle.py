@@ -91,6 +91,21 @@ def pagerank(n_nodes, out_ptr, out_dst, d, eps, n_topic, max_iter=0, hashed=Fals
     return rank, iters
 
 
+def pagerank_omp(n_nodes, out_ptr, out_dst, d, eps, n_init, max_iter=0):
+    """Strong-CPU baseline (all cores, pull form).  -> (rank[N], iters, threads)"""
+    out_ptr = _c(out_ptr, np.uint64)
+    out_dst = _c(out_dst, np.uint32)
+    rank = np.zeros(n_nodes, dtype=np.float64)
+    it = C.c_int32(0)
+    th = C.c_int32(0)
+    rc = lib().orc_pagerank_topic_omp(C.c_uint64(n_nodes), _p(out_ptr, C.c_uint64), _p(out_dst, C.c_uint32),
+                                      C.c_double(d), C.c_double(eps), C.c_int32(max_iter), C.c_int32(n_init),
+                                      _p(rank, C.c_double), C.byref(it), C.byref(th))
+    if rc:
+        raise RuntimeError(f"orc_pagerank_topic_omp rc={rc}")
+    return rank, it.value, th.value
+
+
 def pagerank_topic_detail(n_nodes, out_ptr, out_dst, d, eps, n_init, max_iter=0):
     """-> (rank[N], iters, last_change, last_total)"""
     out_ptr = _c(out_ptr, np.uint64)
@@ -125,7 +140,7 @@ def tfidf(term_ptr, post_doc, post_tf, total_docs, n_docs):
 
 
 def score_topk_batch(n_docs, title, body, mag_title, mag_body, q_ptr, q_terms, k,
-                     prior=None, topic_probs=None, query_len=None):
+                     prior=None, topic_probs=None, query_len=None, omp=False):
     """title/body = (term_ptr u64, post_doc u32, post_w f32).  -> (hits [n_q][k] HIT_DTYPE, n_hits [n_q])"""
     t_ptr, t_doc, t_w = _c(title[0], np.uint64), _c(title[1], np.uint32), _c(title[2], np.float32)
     b_ptr, b_doc, b_w = _c(body[0], np.uint64), _c(body[1], np.uint32), _c(body[2], np.float32)
@@ -146,14 +161,20 @@ def score_topk_batch(n_docs, title, body, mag_title, mag_body, q_ptr, q_terms, k
     query_len = _c(query_len, np.int32)
     hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
     n_hits = np.zeros(n_q, dtype=np.int32)
-    rc = lib().orc_score_topk_batch(
-        C.c_uint64(n_docs), C.c_uint64(n_terms),
-        _p(t_ptr, C.c_uint64), _p(t_doc, C.c_uint32), _p(t_w, C.c_float),
-        _p(b_ptr, C.c_uint64), _p(b_doc, C.c_uint32), _p(b_w, C.c_float),
-        _p(mag_title, C.c_double), _p(mag_body, C.c_double),
-        C.c_int32(K), _p(prior, C.c_double), _p(topic_probs, C.c_double),
-        C.c_int32(n_q), _p(q_ptr, C.c_uint32), _p(q_terms, C.c_uint32), _p(query_len, C.c_int32),
-        C.c_int32(k), hits.ctypes.data_as(C.POINTER(OrcHit)), _p(n_hits, C.c_int32))
+    args = [C.c_uint64(n_docs), C.c_uint64(n_terms),
+            _p(t_ptr, C.c_uint64), _p(t_doc, C.c_uint32), _p(t_w, C.c_float),
+            _p(b_ptr, C.c_uint64), _p(b_doc, C.c_uint32), _p(b_w, C.c_float),
+            _p(mag_title, C.c_double), _p(mag_body, C.c_double),
+            C.c_int32(K), _p(prior, C.c_double), _p(topic_probs, C.c_double),
+            C.c_int32(n_q), _p(q_ptr, C.c_uint32), _p(q_terms, C.c_uint32), _p(query_len, C.c_int32),
+            C.c_int32(k), hits.ctypes.data_as(C.POINTER(OrcHit)), _p(n_hits, C.c_int32)]
+    if omp:
+        th = C.c_int32(0)
+        rc = lib().orc_score_topk_batch_omp(*args, C.byref(th))
+        if rc:
+            raise RuntimeError(f"orc_score_topk_batch_omp rc={rc}")
+        return hits, n_hits, th.value
+    rc = lib().orc_score_topk_batch(*args)
     if rc:
         raise RuntimeError(f"orc_score_topk_batch rc={rc}")
     return hits, n_hits
