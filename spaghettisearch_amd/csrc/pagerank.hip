@@ -229,21 +229,32 @@ __device__ __forceinline__ double gather_sum(const double* __restrict__ T, const
     return (a0 + a1) + (a2 + a3);
 }
 
-// GW=16: one lane group (16 lanes = 16 topics) takes CH=16 consecutive in-edges: ONE coalesced
-// 64-byte index load, then 16 independent 128-byte gathers in flight (one table row each).
+// One lane group (GW lanes = GW topics of one node) takes CH=16 consecutive in-edges: the group's lanes
+// load the 16 indices between them (GW=16: ONE coalesced 64-byte load), then 16 independent gathers are
+// in flight per group, each one table row (128 bytes at GW=16).  Used for GW >= 8; narrower groups keep
+// the wave-per-row / group-per-row classes (measured faster there: 0.71 vs 1.42 ms per sweep at K=1).
 // v[j] = T[src_j][t] for j < n, 0 otherwise; returns the group's 16 "last edge of row" flags.
-__device__ __forceinline__ uint32_t gather_chunk16(const double* __restrict__ T, const uint32_t* __restrict__ in_src,
-                                                   size_t pos, uint32_t n, int lane, double (&v)[CH]) {
-    const int t = lane & 15, gbase = lane & 48;
-    const uint32_t raw = (uint32_t)t < n ? NT_LOAD(&in_src[pos + t]) : 0u;
-    const unsigned long long flags = __ballot(raw >> 31);
-    const uint32_t src = raw & SRC_MASK;
+template <int GW>
+__device__ __forceinline__ uint32_t gather_chunk(const double* __restrict__ T, const uint32_t* __restrict__ in_src,
+                                                 size_t pos, uint32_t n, int lane, double (&v)[CH]) {
+    constexpr int R = CH / GW;                 // indices per lane
+    const int t = lane % GW, gbase = lane - t;
+    uint32_t src[R];
+    uint32_t last = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t j = (uint32_t)(r * GW + t);
+        const uint32_t raw = j < n ? NT_LOAD(&in_src[pos + j]) : 0u;
+        const unsigned long long flags = __ballot(raw >> 31);
+        last |= ((uint32_t)(flags >> gbase) & ((1u << GW) - 1u)) << (r * GW);
+        src[r] = raw & SRC_MASK;
+    }
 #pragma unroll
     for (int j = 0; j < CH; j++) {
-        const uint32_t sj = (uint32_t)__shfl((int)src, gbase + j, 64);
-        v[j] = (uint32_t)j < n ? T[(size_t)sj * 16 + t] : 0.0;
+        const uint32_t sj = (uint32_t)__shfl((int)src[j / GW], gbase + (j % GW), 64);
+        v[j] = (uint32_t)j < n ? T[(size_t)sj * GW + t] : 0.0;
     }
-    return (uint32_t)(flags >> gbase) & 0xFFFFu;
+    return last & 0xFFFFu;
 }
 
 // ---- the sweep ---------------------------------------------------------------
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     constexpr int NSLOT = 64 / GW;
     __shared__ double rowred[WAVES][MAXK];
     __shared__ int s_rowlast;
-    __shared__ double rowsum[GW == 16 ? WAVES * CH * 64 : 1];   // GW=16: finished row sums of a chunk
+    __shared__ double rowsum[GW >= 8 ? WAVES * CH * 64 : 1];   // GW>=8: finished row sums of a chunk, [wave][k-th finished row][lane]
 
     PrCtl* ctl = p.ctl;
     if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
@@ -296,11 +307,11 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
             const size_t beg = rbeg + (size_t)w.count * p.seg_edges;
             const size_t end = min(rend, beg + (size_t)p.seg_edges);
             double acc = 0.0;
-            if constexpr (GW == 16) {
-                // the block's 16 lane groups take 16-edge chunks round-robin
+            if constexpr (GW >= 8) {
+                // the block's lane groups take 16-edge chunks round-robin
                 for (size_t pos = beg + (size_t)(wave * NSLOT + slot) * CH; pos < end; pos += (size_t)WAVES * NSLOT * CH) {
                     double v[CH];
-                    gather_chunk16(T, p.in_src, pos, (uint32_t)min((size_t)CH, end - pos), lane, v);
+                    gather_chunk<GW>(T, p.in_src, pos, (uint32_t)min((size_t)CH, end - pos), lane, v);
                     double a = 0.0;
 #pragma unroll
                     for (int j = 0; j < CH; j++) a += v[j];
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
                 }
             }
         } else if (w.kind == W_ROWS) {
-            if constexpr (GW == 16) {
+            if constexpr (GW >= 8) {
                 // every lane group owns a contiguous run of rows (and so of in-edges) and walks it
                 // in 16-edge chunks; row ends come from the flag bit, finished sums go through LDS
                 const uint32_t gi = wave * NSLOT + slot;
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
                 while (pos < end) {
                     const uint32_t n = (uint32_t)min((size_t)CH, end - pos);
                     double v[CH];
-                    const uint32_t last = gather_chunk16(T, p.in_src, pos, n, lane, v);
+                    const uint32_t last = gather_chunk<GW>(T, p.in_src, pos, n, lane, v);
                     uint32_t nfin = 0;
 #pragma unroll
                     for (int j = 0; j < CH; j++) {
@@ -490,11 +501,11 @@ int pick_gw(int k) {
 void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
                 uint32_t& seg_edges) {
     const uint32_t NSLOT = 64 / gw;
-    // gw == 16: rows above T_SEG in-edges get block(s) of their own, everything else is walked in
-    // 16-edge chunks by lane groups (W_ROWS).  gw < 16: wave-per-row / group-per-row classes.
-    const uint32_t T_SEG = gw == 16 ? 512 : 32 * NSLOT;
+    // gw >= 8: rows above T_SEG in-edges get block(s) of their own, everything else is walked in
+    // 16-edge chunks by lane groups (W_ROWS).  gw < 8: wave-per-row / group-per-row classes.
+    const uint32_t T_SEG = gw >= 8 ? 512 : 32 * NSLOT;
     const uint32_t T_WAVE = 2 * NSLOT;
-    seg_edges = gw == 16 ? 2048 : 128 * NSLOT;
+    seg_edges = gw >= 8 ? 2048 : 128 * NSLOT;
     nsegs = 0;
     nmulti = 0;
     std::vector<WorkItem> seg, wav, grp, zer;
@@ -511,13 +522,13 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
             for (uint32_t s = 0; s < ns; s++) seg.push_back({W_SEG, row0 + r, s, ns, nsegs, tix});
             nsegs += ns;
         }
-        if (gw == 16) {
-            // items of ~4096 in-edges, at most 1024 rows (64 per lane group)
+        if (gw >= 8) {
+            // items of ~256 in-edges and at most 64 rows per lane group
             uint32_t r = a;
             while (r < c) {
                 uint32_t rows = 0;
                 uint64_t edges = 0;
-                while (r + rows < c && rows < 1024 && edges < 4096) edges += deg[r + rows++];
+                while (r + rows < c && rows < 64 * WAVES * NSLOT && edges < 256ull * WAVES * NSLOT) edges += deg[r + rows++];
                 wav.push_back({W_ROWS, row0 + r, rows, 0, 0, 0});
                 r += rows;
             }
