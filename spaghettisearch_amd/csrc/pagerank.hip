@@ -40,6 +40,7 @@ struct PrCtl {
     double S[MAXK];       // normaliser (`totalValue`) for the next sweep
     double delta[MAXK];   // last L1 change
     double csum[MAXK];    // last contribution sum (diagnostics)
+    double xz[MAXK];      // rank of EVERY row without in-edges (they all share one value per topic)
     int32_t active[MAXK];
     int32_t iters[MAXK];
     int32_t sweep;        // sweeps completed
@@ -75,6 +76,7 @@ struct PrParams {
     double d, teleport, eps, tele_n;
     int32_t max_iter, k_topics, world;
     uint32_t sl_nd, cnt_nd, sl_d, cnt_d, seg_edges, n_items;
+    uint32_t pos_nd, pos_d;   // rows WITH in-edges per class (they come first: rows are in-degree sorted)
 };
 
 // ---- reductions --------------------------------------------------------------
@@ -87,11 +89,18 @@ __device__ __forceinline__ double wave_sum_topic(double v) {
     return v;
 }
 
+// Rows without in-edges inherit nothing: cur = (1/n if first sweep) + 0, so after the normalise they ALL
+// hold the same value per topic.  They are never stored or streamed; this is that shared value.
+__device__ __forceinline__ double zero_row_rank(const PrParams& p, int sweep, double S, double x0) {
+    return ((sweep == 0 ? x0 : 0.0) + p.teleport) / S;            // pagerank.go:104,117
+}
+
 __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl, const double* cs, bool is_begin) {
     PrCtl* ctl = p.ctl;
     if (is_begin) {
         for (int k = 0; k < MAXK; k++) {
             const bool real = k < p.k_topics;
+            ctl->xz[k] = real ? p.x0[k] : 0.0;
             ctl->S[k] = real ? cs[k] + p.tele_n : 1.0;
             ctl->csum[k] = real ? cs[k] : 0.0;
             ctl->delta[k] = 0.0;
@@ -107,7 +116,8 @@ __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl
     for (int k = 0; k < p.k_topics; k++) {
         if (ctl->active[k]) {
             ctl->iters[k] = it;
-            ctl->delta[k] = dl[k];
+            ctl->delta[k] = dl[k];                          // includes the rows without in-edges (added by the caller)
+            ctl->xz[k] = zero_row_rank(p, ctl->sweep, ctl->S[k], p.x0[k]);
             bool cont = dl[k] > p.eps;                      // pagerank.go:93
             if (p.max_iter > 0 && it >= p.max_iter) cont = false;
             ctl->active[k] = cont ? 1 : 0;
@@ -175,6 +185,13 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
         double v = 0.0;
         for (int q = 0; q < NPART; q++) v += colsum[q * NCOL + threadIdx.x];
         tot[threadIdx.x / GW][threadIdx.x % GW] = v;
+    }
+    __syncthreads();
+    // rows without in-edges: all equal, so their L1 change is count * |new - old| (not streamed, see zero_row_rank)
+    if (!is_begin && threadIdx.x < GW && p.ctl->active[threadIdx.x]) {
+        const double n_zero = (double)((p.cnt_nd - p.pos_nd) + (p.cnt_d - p.pos_d));
+        const double xz_new = zero_row_rank(p, p.ctl->sweep, p.ctl->S[threadIdx.x], p.x0[threadIdx.x]);
+        tot[0][threadIdx.x] += n_zero * fabs(xz_new - p.ctl->xz[threadIdx.x]);
     }
     __syncthreads();
     if (p.world == 1) {
@@ -407,9 +424,16 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
                 finish(lrow, acc);
             }
         } else {
-            // rows without in-edges: pure streaming update
+            // non-dangling rows without in-edges: their rank is the shared value xz, only the next
+            // contribution d*xz/outdeg has to be written (dangling ones need nothing at all)
+            const double xz = act ? zero_row_rank(p, sweep, S, p.x0[t]) : ctl->xz[t];
             const uint32_t nel = w.count * GW;
-            for (uint32_t i = threadIdx.x; i < nel; i += TPB) finish(w.row + i / GW, 0.0);
+            for (uint32_t i = threadIdx.x; i < nel; i += TPB) {
+                const uint32_t lrow = w.row + i / GW;
+                const double c = p.d * xz / (double)NT_LOAD(&p.outdeg[lrow]);   // pagerank.go:136
+                NT_STORE(c, &Tw[(size_t)lrow * GW + t]);
+                csum += c;                                                        // pagerank.go:137
+            }
         }
     }
 
@@ -457,8 +481,9 @@ __global__ void k_pr_finalize(PrParams p, const double* __restrict__ table, int 
 }
 
 template <int GW>
-__global__ void k_pr_read(const double* __restrict__ x, const uint32_t* __restrict__ old_id, uint32_t sl_nd, uint32_t cnt_nd,
-                          uint32_t sl_d, uint32_t cnt_d, uint64_t id0_nd, uint64_t id0_d, int k_topics, uint64_t out_stride,
+__global__ void k_pr_read(const double* __restrict__ x, const PrCtl* __restrict__ ctl, const uint32_t* __restrict__ old_id,
+                          uint32_t sl_nd, uint32_t cnt_nd, uint32_t pos_nd, uint32_t sl_d, uint32_t cnt_d, uint32_t pos_d,
+                          uint64_t id0_nd, uint64_t id0_d, int k_topics, uint64_t out_stride,
                           int by_original_id, uint32_t* __restrict__ ids_out, double* __restrict__ out) {
     const size_t n_rows = (size_t)cnt_nd + cnt_d;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,7 +493,9 @@ __global__ void k_pr_read(const double* __restrict__ x, const uint32_t* __restri
     const uint32_t orig = old_id[iid];
     const size_t o = by_original_id ? (size_t)orig : i;
     if (ids_out) ids_out[i] = orig;
-    for (int k = 0; k < k_topics; k++) out[(size_t)k * out_stride + o] = x[(size_t)lrow * GW + k];
+    // rows without in-edges are not stored: they all hold ctl->xz
+    const bool zero = lrow < sl_nd ? lrow >= pos_nd : (lrow - sl_nd) >= pos_d;
+    for (int k = 0; k < k_topics; k++) out[(size_t)k * out_stride + o] = zero ? ctl->xz[k] : x[(size_t)lrow * GW + k];
 }
 
 }  // namespace
@@ -499,7 +526,7 @@ int pick_gw(int k) {
 }
 
 void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
-                uint32_t& seg_edges) {
+                uint32_t& seg_edges, uint32_t& pos_nd, uint32_t& pos_d) {
     const uint32_t NSLOT = 64 / gw;
     // gw >= 8: rows above T_SEG in-edges get block(s) of their own, everything else is walked in
     // 16-edge chunks by lane groups (W_ROWS).  gw < 8: wave-per-row / group-per-row classes.
@@ -509,7 +536,7 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     nsegs = 0;
     nmulti = 0;
     std::vector<WorkItem> seg, wav, grp, zer;
-    auto emit = [&](const std::vector<uint32_t>& deg, uint32_t row0) {
+    auto emit = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
         // deg is sorted descending: find class boundaries
         uint32_t a = 0;
@@ -539,11 +566,15 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
             const uint32_t GROUP_ROWS = WAVES * NSLOT * 4;   // 4 rows per lane group per block
             for (uint32_t r = b; r < c; r += GROUP_ROWS) grp.push_back({W_GROUP, row0 + r, std::min<uint32_t>(GROUP_ROWS, c - r), 0, 0, 0});
         }
-        const uint32_t ZERO_ROWS = (TPB * 8) / gw;       // 8 elements per thread
-        for (uint32_t r = c; r < cnt; r += ZERO_ROWS) zer.push_back({W_ZERO, row0 + r, std::min<uint32_t>(ZERO_ROWS, cnt - r), 0, 0, 0});
+        n_pos = c;
+        // rows without in-edges all share one rank (zero_row_rank): only the non-dangling ones have work
+        // (their next contribution); 8 elements per thread
+        const uint32_t ZERO_ROWS = (TPB * 8) / gw;
+        if (non_dangling)
+            for (uint32_t r = c; r < cnt; r += ZERO_ROWS) zer.push_back({W_ZERO, row0 + r, std::min<uint32_t>(ZERO_ROWS, cnt - r), 0, 0, 0});
     };
-    emit(g->h_indeg_nd, 0);
-    emit(g->h_indeg_d, g->sl_nd);
+    emit(g->h_indeg_nd, 0, true, pos_nd);
+    emit(g->h_indeg_d, g->sl_nd, false, pos_d);
     items.clear();
     items.reserve(seg.size() + wav.size() + grp.size() + zer.size());
     // heavy work first
@@ -571,7 +602,8 @@ void launch_read(ss_pr* pr, hipStream_t st, int by_orig, uint64_t stride, uint32
     const size_t n_rows = (size_t)g->cnt_nd + g->cnt_d;
     if (!n_rows) return;
     hipLaunchKernelGGL(k_pr_read<GW>, dim3(ss::div_up(n_rows, TPB)), dim3(TPB), 0, st, (const double*)pr->x.p,
-                       (const uint32_t*)g->old_id.p, g->sl_nd, g->cnt_nd, g->sl_d, g->cnt_d,
+                       (const PrCtl*)pr->ctl.p, (const uint32_t*)g->old_id.p, g->sl_nd, g->cnt_nd, pr->prm.pos_nd, g->sl_d, g->cnt_d,
+                       pr->prm.pos_d,
                        (uint64_t)g->rank * g->sl_nd, g->nd_int + (uint64_t)g->rank * g->sl_d, pr->k, stride, by_orig, ids, out);
 }
 
@@ -610,8 +642,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     const size_t n_local = g->n_local();
 
     std::vector<WorkItem> items;
-    uint32_t nsegs = 0, nmulti = 0, seg_edges = 0;
-    build_work(g, GW, items, nsegs, nmulti, seg_edges);
+    uint32_t nsegs = 0, nmulti = 0, seg_edges = 0, pos_nd = 0, pos_d = 0;
+    build_work(g, GW, items, nsegs, nmulti, seg_edges, pos_nd, pos_d);
     if (items.empty()) items.push_back({W_ZERO, 0, 0, 0, 0, 0});
     // persistent grid: 8 blocks per CU at most, each walks the work table round-robin
     pr->nblocks = (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
@@ -673,6 +705,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     p.cnt_d = g->cnt_d;
     p.seg_edges = seg_edges;
     p.n_items = (uint32_t)items.size();
+    p.pos_nd = pos_nd;
+    p.pos_d = pos_d;
     *out = guard.release();
     return SS_OK;
 }
