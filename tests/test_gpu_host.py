@@ -34,9 +34,9 @@ def host():
 
 @pytest.fixture(scope="module")
 def corpus():
-    """A crawl-shaped corpus (BASELINE config 1 shape): 600 crawled pages + uncrawled children."""
+    """A crawl-shaped corpus (BASELINE config 1: `start_crawl -numPages=1000`): 1000 crawled pages + uncrawled children."""
     rng = np.random.default_rng(2024)
-    n_crawled, n_all, n_words = 600, 900, 150
+    n_crawled, n_all, n_words = 1000, 1600, 150
     doc = [h(f"http://site/{i}") for i in range(n_all)]
     word = [f"w{i}" for i in range(n_words)]
     children = {}
@@ -188,6 +188,10 @@ def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
         assert [r.FinalRank for r in res] == hits["final"].tolist()
         assert all(r.PageRank == 0.0 for r in res)                                      # Q9: nil topicProbs
     assert len(got[3]) == 0 and len(got[0]) > 0
+    # BASELINE config 1: single query, top-10 = the first 10 of the top-50
+    top10 = di.RetrieveBatch([queries[0]], 10)[0]
+    assert [r.DocHash for r in top10] == [r.DocHash for r in got[0][:10]]
+    assert [r.FinalRank for r in top10] == [r.FinalRank for r in got[0][:10]]
     # PageRank blend with explicit topic probabilities (config 5 shape)
     probs = [{"Arts": 0.5, "Science": 0.25, "Sports": 0.25}] * len(queries)
     got_p = di.RetrieveBatch(queries, 50, probs)

@@ -240,3 +240,28 @@ def test_errors(ss_ctx, oracle):
     with pytest.raises(SpaghettiError):
         ti.close()                                    # still in use by the scorer
     close_all(sc, ti, bi)
+
+
+def test_fuzz_many_shapes_and_determinism(ss_ctx, oracle):
+    """Random query shapes (1-8 tokens, duplicates, unknown ids), several k, heavy and light lists; the
+    batch is scored three times: results must match the oracle bit for bit and be identical run to run."""
+    n_docs, n_terms = 120000, 800
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 2500000, 150000, seed=77)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        rng = np.random.default_rng(99)
+        n_q = 300
+        lens = rng.integers(1, 9, size=n_q)
+        q_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        q_terms = np.minimum(rng.geometric(0.01, size=int(lens.sum())) - 1, n_terms + 2).astype(np.uint32)
+        for k in (1, 7, 100, 513):
+            ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, k)
+            first = None
+            for _ in range(3):
+                hits, n_hits = sc.score_topk(q_ptr, q_terms, k)
+                assert_same_hits(hits, n_hits, ref, ref_n)
+                if first is None:
+                    first = hits.tobytes()
+                assert hits.tobytes() == first
+    finally:
+        close_all(sc, ti, bi)
