@@ -45,8 +45,11 @@ namespace {
 #endif
 constexpr int TPB = SS_TPB;        // k_score_slices workgroup
 constexpr int TPB_M = 256;         // k_merge_topk workgroup
-constexpr int CAP = 1024;          // postings per window (capacity)
-constexpr int TARGET = 880;        // planned postings per window (head-room for the spread around the plan)
+#ifndef SS_CAP
+#define SS_CAP 1024
+#endif
+constexpr int CAP = SS_CAP;        // postings per window (capacity)
+constexpr int TARGET = CAP * 55 / 64;   // planned postings per window (880 of 1024: head-room for the spread around the plan)
 constexpr int PPT = CAP / TPB;     // records per thread
 #ifndef SS_HT
 #define SS_HT 1536
@@ -224,10 +227,10 @@ __device__ void topk_compact(const TopK& tk, int k) {
 }
 
 // ---- K4: score one (query, doc-range slice) --------------------------------------
-#ifndef SS_WAVES_PER_SIMD
-#define SS_WAVES_PER_SIMD 4
+#ifndef SS_WGS_PER_CU
+#define SS_WGS_PER_CU 2
 #endif
-__global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScoreParams p) {
+__global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ht_TB = reinterpret_cast<double*>(smem);                   // [HT][2] (BodyRank, TitleRank) accumulators of a doc
     double* s_mag = ht_TB + 2 * HT;                                    // [CAP] field magnitude carried by record i of the window
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(TPB, SS_WAVES_PER_SIMD) void k_score_slices(ScorePa
 #pragma unroll
         for (int r = 0; r < PPT; r++) {
             pend[r] = rl[r] != EMPTY;
-            h[r] = (((rec[r].x * 2654435761u) >> 21) * (uint32_t)(HT / 256)) >> 3;      // [0, HT)
+            h[r] = (((rec[r].x * 2654435761u) >> 20) * (uint32_t)(HT / 256)) >> 4;      // 12 hash bits -> [0, HT)
         }
 #pragma unroll
         for (int r = 0; r < PPT; r++) {
