@@ -132,6 +132,7 @@ def main() -> None:
         return float(t.item())
 
     ctx = engine.Context(local_rank)
+    c4_ranks = None
     stream = torch.cuda.Stream(device=dev)       # library kernels, torch copies and RCCL share one stream
     ctx.set_stream(stream.cuda_stream)
     result: dict = {}
@@ -243,6 +244,8 @@ def main() -> None:
             barrier()
             result["config"]["to_convergence_eps1e-6"] = {"iters": [int(x) for x in stc["iters"]],
                                                           "seconds": time.perf_counter() - t0}
+            if world == 1 and args.workload == "both" and n == args.docs:
+                c4_ranks = prc.read()                   # [K][N] converged ranks: the prior of the blended top-k run (config 5)
             prc.close()
 
             # ---- CPU baseline: the oracle's literal port on the same graph, bounded sample
@@ -309,6 +312,20 @@ def main() -> None:
             if keep_host:
                 h_bdoc = b_doc.cpu().numpy().view(np.uint32)
                 h_tdoc = t_doc.cpu().numpy().view(np.uint32)
+            shard = None
+            if world > 1:
+                # doc-range shard of the same index: this rank's slice of every posting list
+                lo, hi = sharding.doc_range(nd, rank, world)
+                sb_arr = sharding.shard_index_by_docs(b_ptr, b_doc, b_tf, lo, hi)
+                st_arr = sharding.shard_index_by_docs(t_ptr, t_doc, t_tf, lo, hi)
+                sbi = engine.InvertedIndex(ctx, hi - lo, *sb_arr)
+                sti = engine.InvertedIndex(ctx, hi - lo, *st_arr)
+                sti.set_doc_freq(sharding.global_doc_freq(st_arr[0]))      # one all-reduce of int64[T] per table
+                sbi.set_doc_freq(sharding.global_doc_freq(sb_arr[0]))
+                del sb_arr, st_arr
+                sti.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
+                sbi.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
+                shard = (sti, sbi, engine.Scorer(ctx, sti, sbi))
             del b_ptr, b_doc, b_tf, t_ptr, t_doc, t_tf
             torch.cuda.empty_cache()
             wt, mt, _ = ti.tfidf_build(nd, want_w=keep_host, want_mag=keep_host, want_idf=False)   # title first (start_crawl.go:176)
@@ -353,6 +370,71 @@ def main() -> None:
                                  "kernel": "k_score_slices+k_merge_topk",
                                  "kernel_ms": kern_ms, "algorithmic_bytes": algo_q},
                     "tfidf_build_ms": tfidf_ms, "queries_per_sec_host_in_host_out": nq * K / dt_pcie}
+            def timed_batches(fn):
+                for _ in range(max(W, 1)):
+                    fn()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(K):
+                    fn()
+                barrier()
+                return max_over_ranks(time.perf_counter() - t0)
+
+            # ---- tail queries: term ranks uniform over the whole vocabulary, reported separately
+            tq_ptr, tq_terms = synth.make_queries(nq, 3, nt, seed=1045 + rank)
+            d_tq = (torch.from_numpy(tq_ptr.view(np.int32)).to(dev), torch.from_numpy(tq_terms.view(np.int32)).to(dev))
+            dtt = timed_batches(lambda: sc.score_topk(d_tq[0], d_tq[1], k, out=(d_hits, d_nhits)))
+            tail_df = int(sum((h_bptr[t + 1] - h_bptr[t]) + (h_tptr[t + 1] - h_tptr[t]) for t in tq_terms.astype(np.int64)))
+            topk["tail_queries"] = {"value": world * nq * K / dtt, "unit": "queries/s", "ms_per_step": dtt * 1e3 / K,
+                                    "workload": f"{nq} x 3-term OR queries, term ranks U[1,{nt}]", "postings_per_query": tail_df / nq}
+
+            # ---- blended run (BASELINE config 5): same index and queries + PageRank prior, per-query topicProbs
+            kt5 = args.topics
+            if c4_ranks is not None:
+                prior5, prior_src = c4_ranks, "converged ranks of the PageRank half (config 4 graph, node i = doc i)"
+            else:
+                g5 = torch.Generator(device="cpu").manual_seed(46)
+                prior5 = (torch.rand((kt5, nd), generator=g5, dtype=torch.float64) * 1e-6).numpy()
+                prior_src = "synthetic uniform ranks (the PageRank half did not run in this process)"
+            sc.set_prior(prior5)
+            probs5 = np.random.default_rng(46 + rank).dirichlet(np.ones(kt5), size=nq)
+            d_probs = torch.from_numpy(probs5).to(dev)
+            dt5 = timed_batches(lambda: sc.score_topk(d_qptr, d_qterms, k, topic_probs=d_probs, out=(d_hits, d_nhits)))
+            topk["blended_config5"] = {"value": world * nq * K / dt5, "unit": "queries/s", "ms_per_step": dt5 * 1e3 / K,
+                                       "k_topics": kt5, "prior": prior_src, "topic_probs": "Dirichlet(1) per query"}
+            if keep_host:
+                from oracle import pyoracle
+                nb = 16
+                h5, n5 = sc.score_topk(q_ptr[:nb + 1], q_terms[:3 * nb], k, topic_probs=probs5[:nb])
+                r5, rn5 = pyoracle.score_topk_batch(nd, (h_tptr, h_tdoc, wt), (h_bptr, h_bdoc, wb), mt, mb, q_ptr[:nb + 1], q_terms[:3 * nb], k,
+                                                    prior=np.ascontiguousarray(prior5.T), topic_probs=probs5[:nb])
+                same5 = all(h5["doc"][q, :n5[q]].tolist() == r5["doc"][q, :rn5[q]].tolist() and
+                            np.array_equal(h5["final"][q, :n5[q]], r5["final"][q, :rn5[q]]) for q in range(nb))
+                topk["blended_config5"]["gpu_matches_oracle"] = bool(same5)
+                assert same5
+                del r5
+            sc.set_prior(None)
+            del prior5
+
+            # ---- doc-range-sharded scoring (N>1): one batch replicated, local top-k, one all-gather, merge
+            if shard is not None:
+                sti, sbi, ssc = shard
+                dsc = sharding.DocShardedScorer(ssc, ctx.merge_hits, nd, rank, world, device=dev, host_staged=rehearsal)
+                g_qptr, g_qterms = synth.make_queries(nq, 3, min(10_000, nt), seed=45)       # rank 0's batch on every rank
+                dg = (torch.from_numpy(g_qptr.view(np.int32)).to(dev), torch.from_numpy(g_qterms.view(np.int32)).to(dev))
+                m_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev)
+                m_n = torch.empty(nq, dtype=torch.int32, device=dev)
+                dts = timed_batches(lambda: dsc.score_topk(dg[0], dg[1], k, out=(m_hits, m_n)))
+                sc.score_topk(dg[0], dg[1], k, out=(d_hits, d_nhits))                         # the full replica, same batch
+                same_s = bool(torch.equal(m_hits, d_hits) and torch.equal(m_n, d_nhits))
+                topk["doc_sharded"] = {"value": nq * K / dts, "unit": "queries/s", "ms_per_step": dts * 1e3 / K, "scaling": "strong",
+                                       "parallelism": f"doc-range shards x{world}: batch replicated, local top-{k}, 1 all-gather of "
+                                                      f"{nq * k * 40} B/rank + merge", "matches_unsharded_replica": same_s}
+                assert same_s
+                ssc.close()
+                sti.close()
+                sbi.close()
+
             if keep_host:
                 from oracle import pyoracle
                 ns = 64

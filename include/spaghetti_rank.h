@@ -159,6 +159,13 @@ int32_t ss_index_destroy(ss_index* idx);
  * them back to inv[*] / forw[4]).  Not idempotent, like the reference. */
 int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs,
                        float* w_out, double* mag_out, float* idf_out);
+/* Doc-range sharding (one shard of the table per GPU): a term's list here is only the
+ * slice of its postings that falls into this shard's doc range, but len(docs) in
+ * term_weighting.go:37 is the length of the WHOLE list.  df [n_terms] = whole-corpus document
+ * frequencies (the host sums the shards' list lengths, one all-reduce); call before
+ * ss_tfidf_build.  NULL restores df = local list length.  A doc's postings all live in its own
+ * shard, so magnitudes need no exchange. */
+int32_t ss_index_set_doc_freq(ss_index* idx, const uint64_t* df /*[n_terms]*/);
 /* Load precomputed weights/magnitudes instead (tables already weighted). */
 int32_t ss_index_set_weighted(ss_index* idx, const double* mag /*[n_docs]*/);
 /* Positional postings for phrase search: listPos[1:] of every posting (parser/parser.go:195-207:
@@ -193,6 +200,17 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
 int32_t ss_score_topk_phrase(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
                              const uint32_t* p_ptr, const uint32_t* p_terms, const int32_t* query_len,
                              const double* topic_probs, int32_t k, ss_hit* hits_out, int32_t* n_hits_out);
+
+/* Doc-range-sharded scoring: every shard scores the same query batch against its own doc range
+ * (ss_score_topk, local doc ids) and the host gathers the lists.  ss_merge_hits returns the k best
+ * of the union per query in the order of appendSort (util.go:48-54) and the cut of
+ * main_retrieve.go:99-103 — identical to scoring the unsharded index.
+ * parts [n_parts][n_q][k], n_hits [n_parts][n_q] (the all-gathered outputs of ss_score_topk),
+ * doc_base [n_parts] first corpus doc id of each shard (NULL = ids already global);
+ * hits_out [n_q][k], n_hits_out [n_q].  All pointers host or device. */
+#define SS_MAX_SHARDS 64
+int32_t ss_merge_hits(ss_ctx* ctx, int32_t n_q, int32_t n_parts, int32_t k, const ss_hit* parts,
+                      const int32_t* n_hits, const uint32_t* doc_base, ss_hit* hits_out, int32_t* n_hits_out);
 
 /* Timing hook for bench.py: milliseconds between the start and end HIP events
  * recorded on the ctx stream around the LAST compute call of the given kind

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "ss_index_create": (_i32, [_vp, _u64, _u64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "ss_index_destroy": (_i32, [_vp]),
     "ss_tfidf_build": (_i32, [_vp, _u64, _vp, _vp, _vp]),
+    "ss_index_set_doc_freq": (_i32, [_vp, _vp]),
     "ss_index_set_weighted": (_i32, [_vp, _vp]),
     "ss_index_set_positions": (_i32, [_vp, _vp, _vp]),
     "ss_scorer_create": (_i32, [_vp, _vp, _vp, C.POINTER(_vp)]),
@@ -73,6 +74,7 @@ PROTOTYPES = {
     "ss_scorer_set_prior": (_i32, [_vp, _i32, _vp]),
     "ss_score_topk": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ss_score_topk_phrase": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "ss_merge_hits": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ss_last_kernel_ms": (_i32, [_vp, _i32, C.POINTER(C.c_float)]),
 }
 

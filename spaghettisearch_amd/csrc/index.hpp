@@ -16,6 +16,8 @@ struct ss_index {
     ss::DevBuf<double> mag;        // sqrt(sum w^2) per doc, valid once `weighted`
     ss::DevBuf<uint64_t> pos_ptr;  // [P+1] positional postings (phrase search), optional
     ss::DevBuf<float> pos;         // positions as stored by the reference: float32, -100 = anchor/meta text
+    ss::DevBuf<uint64_t> df_global; // [T] whole-corpus document frequencies when this table is one doc-range shard (optional)
+    bool has_df_global = false;
     std::vector<uint64_t> h_term_ptr;  // host copy for query planning
     bool weighted = false;
     int users = 0;                 // scorers holding this index

@@ -33,6 +33,7 @@
 //     title/body/pagerank of the k winners by binary search and writes ss_hit rows.
 //   Ties: ascending doc id (Q10); NaN finals last.
 #include "index.hpp"
+#include "order.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -115,19 +116,9 @@ struct ScoreParams {
     ss_hit* hits; int32_t* n_hits;
 };
 
-// total order: larger key = better; NaN lowest
-__device__ __forceinline__ uint64_t fkey(double f) {
-    if (f != f) return 0ull;
-    const uint64_t b = (uint64_t)__double_as_longlong(f);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double funkey(uint64_t k) {
-    const uint64_t b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-    return __longlong_as_double((long long)b);
-}
-__device__ __forceinline__ bool better(uint64_t ka, uint32_t da, uint64_t kb, uint32_t db) {
-    return ka > kb || (ka == kb && da < db);
-}
+using ss::fkey;
+using ss::funkey;
+using ss::better;
 
 __device__ __forceinline__ uint64_t lower_bound_post(const Post* __restrict__ a, uint64_t lo, uint64_t hi, uint32_t v) {
     while (lo < hi) {

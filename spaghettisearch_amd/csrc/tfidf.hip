@@ -50,10 +50,13 @@ __device__ __forceinline__ double go_log2(double x) {
     return go_log(frac) * InvLn2 + (double)e;
 }
 
-__global__ void k_idf(const uint64_t* __restrict__ term_ptr, uint64_t n_terms, double total_docs, float* __restrict__ idf) {
+// df_global != nullptr: this table is one doc-range shard and len(docs) of term_weighting.go:37 is the length of
+// the term's WHOLE list, summed over the shards by the host (one all-reduce)
+__global__ void k_idf(const uint64_t* __restrict__ term_ptr, const uint64_t* __restrict__ df_global, uint64_t n_terms,
+                      double total_docs, float* __restrict__ idf) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_terms) return;
-    const double df = (double)(term_ptr[t + 1] - term_ptr[t]);
+    const double df = df_global ? (double)df_global[t] : (double)(term_ptr[t + 1] - term_ptr[t]);
     idf[t] = (float)go_log2(total_docs / df);                       // term_weighting.go:37
 }
 
@@ -66,6 +69,12 @@ __global__ void k_check_ptr(const uint64_t* __restrict__ term_ptr, uint64_t n_te
     if (b < a) { atomicOr(err, 1u); return; }
     // a legitimate descent can only sit at the start of a non-empty list
     if (b > a && a > 0 && post_doc[a] <= post_doc[a - 1]) atomicAdd(n_boundary_desc, 1ull);
+}
+__global__ void k_check_df(const uint64_t* __restrict__ term_ptr, const uint64_t* __restrict__ df, uint64_t n_terms,
+                           uint32_t* __restrict__ err) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_terms) return;
+    if (df[t] < term_ptr[t + 1] - term_ptr[t]) atomicOr(err, 1u);
 }
 __global__ void k_check_docs(const uint32_t* __restrict__ post_doc, uint64_t n_post, uint64_t n_docs,
                              unsigned long long* __restrict__ n_desc, uint32_t* __restrict__ err) {
@@ -213,7 +222,8 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     SS_HIP(ctx, idf.alloc(T));
     SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
     SS_HIP(ctx, hipEventRecord(ctx->ev[2][0], st));
-    if (T) hipLaunchKernelGGL(k_idf, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p, T, (double)total_docs, idf.p);
+    if (T) hipLaunchKernelGGL(k_idf, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p,
+                              idx->has_df_global ? idx->df_global.p : nullptr, T, (double)total_docs, idf.p);
     if (P) hipLaunchKernelGGL(k_weight, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p,
                               idx->post_w.p, idf.p, P, idx->mag.p);
     hipLaunchKernelGGL(k_sqrt, dim3(ss::div_up(N, TPB)), dim3(TPB), 0, st, idx->mag.p, N);
@@ -225,6 +235,35 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     if (mag_out) SS_HIP(ctx, hipMemcpyAsync(mag_out, idx->mag.p, N * sizeof(double), hipMemcpyDefault, st));
     if (idf_out && T) SS_HIP(ctx, hipMemcpyAsync(idf_out, idf.p, T * sizeof(float), hipMemcpyDefault, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
+    return SS_OK;
+}
+
+int32_t ss_index_set_doc_freq(ss_index* idx, const uint64_t* df) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (idx->weighted) return ctx->fail(SS_ERR_STATE, "ss_index_set_doc_freq: table is already weighted");
+    if (!df) { idx->has_df_global = false; idx->df_global.release(); return SS_OK; }
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t T = idx->n_terms;
+    SS_HIP(ctx, idx->df_global.alloc(T));
+    ss::DevBuf<uint32_t> err;
+    SS_HIP(ctx, err.alloc(1));
+    SS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(uint32_t), st));
+    if (T) {
+        SS_HIP(ctx, hipMemcpyAsync(idx->df_global.p, df, T * sizeof(uint64_t), hipMemcpyDefault, st));
+        hipLaunchKernelGGL(k_check_df, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p, idx->df_global.p, T, err.p);
+    }
+    uint32_t h_err = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&h_err, err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (h_err) {
+        idx->df_global.release();
+        idx->has_df_global = false;
+        return ctx->fail(SS_ERR_INVALID, "ss_index_set_doc_freq: a document frequency is smaller than the local list");
+    }
+    idx->has_df_global = true;
     return SS_OK;
 }
 

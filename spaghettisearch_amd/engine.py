@@ -59,6 +59,31 @@ class Context:
     def set_stream(self, hip_stream: Optional[int]) -> None:
         check(self.lib.ss_set_stream(self.h, C.c_void_p(hip_stream)), self.h)
 
+    def merge_hits(self, parts, n_hits, k: int, doc_base=None, out=None):
+        """ss_merge_hits: parts [n_parts][n_q][k] hits (numpy HIT_DTYPE, or a torch uint8 tensor of the same bytes),
+        n_hits [n_parts][n_q] int32, doc_base uint32[n_parts] | None -> (hits [n_q][k], n_hits [n_q]).
+        out=(hits_buf, n_hits_buf) keeps the result in the given (device) buffers."""
+        n_hits = _as(n_hits, "int32")
+        n_parts, n_q = int(n_hits.shape[0]), int(n_hits.shape[1])
+        doc_base = _as(doc_base, "uint32")
+        if _is_torch(parts):
+            parts = parts.contiguous()
+            have = parts.numel() * parts.element_size()
+        else:
+            parts = np.ascontiguousarray(parts, dtype=HIT_DTYPE)
+            have = parts.nbytes
+        if have != n_parts * n_q * k * HIT_DTYPE.itemsize:
+            raise ValueError("parts does not hold n_parts*n_q*k hits")
+        if out is not None:
+            hits, n_out = out
+            if hits.numel() * hits.element_size() < n_q * k * HIT_DTYPE.itemsize or n_out.numel() < n_q:
+                raise ValueError("output buffers too small")
+        else:
+            hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
+            n_out = np.zeros(n_q, dtype=np.int32)
+        check(self.lib.ss_merge_hits(self.h, n_q, n_parts, k, _ptr(parts), _ptr(n_hits), _ptr(doc_base), _ptr(hits), _ptr(n_out)), self.h)
+        return hits, n_out
+
     def synchronize(self) -> None:
         check(self.lib.ss_synchronize(self.h), self.h)
 
@@ -188,6 +213,14 @@ class InvertedIndex:
         idf = np.zeros(self.n_terms, dtype=np.float32) if want_idf else None
         check(self.ctx.lib.ss_tfidf_build(self.h, int(total_docs), _ptr(w), _ptr(mag), _ptr(idf)), self.ctx.h)
         return w, mag, idf
+
+    def set_doc_freq(self, df) -> None:
+        """ss_index_set_doc_freq: whole-corpus document frequencies when this table is one doc-range shard
+        (uint64[n_terms]; None = local list lengths).  Call before tfidf_build."""
+        df = _as(df, "uint64")
+        if df is not None and int(df.shape[0]) != self.n_terms:
+            raise ValueError("df must hold one entry per term")
+        check(self.ctx.lib.ss_index_set_doc_freq(self.h, _ptr(df)), self.ctx.h)
 
     def set_positions(self, pos_ptr, pos) -> None:
         """Positional postings (listPos[1:] per posting) for phrase search."""

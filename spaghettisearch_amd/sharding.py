@@ -1,4 +1,5 @@
-"""Multi-GPU host logic for the doc-range-sharded PageRank.
+"""Multi-GPU host logic: doc-range-sharded PageRank, and the doc-range-sharded index
+(TF-IDF build + scoring) further down.
 
 One process per GPU.  Rank r owns the destination rows of shard r (the library
 deals degree-sorted rows round-robin to the ranks, so shards are edge-balanced);
@@ -146,3 +147,152 @@ def gather_ranks(state, group=None):
     objs: List = [None] * world
     dist.all_gather_object(objs, (np.asarray(ids), np.asarray(r)), group=group)
     return assemble(objs, n_nodes, state.k)
+
+
+# --------------------------------------------------------------------------------------------------
+# Doc-range-sharded inverted index: TF-IDF build and scoring.
+#
+# Rank r holds, for EVERY term, the slice of the posting list whose docs fall into its contiguous doc range
+# [lo_r, hi_r), with local doc ids (doc - lo_r), plus its slice of the magnitudes and of the PageRank prior.
+#   * build: idf needs the length of a term's WHOLE list (term_weighting.go:37) -> one all-reduce(sum) of the
+#     local list lengths (int64[T]) -> ss_index_set_doc_freq; weights and magnitudes are then shard-local
+#     (all postings of a doc live in its shard), no further exchange;
+#   * query: the batch is replicated, every rank returns its own top-k (ss_score_topk), ONE all-gather of the
+#     n_q*k hits (+ the counts) and ss_merge_hits on every rank give the corpus top-k — identical to the
+#     unsharded result, because the k best of the union of per-shard top-k lists are the k best overall.
+# The alternative for an index that fits one GPU — query-split replicas, no collective — is what bench.py's
+# primary top-k number uses; both are reported.
+
+
+def doc_range(n_docs: int, rank: int, world: int):
+    """Contiguous doc range [lo, hi) of shard `rank`."""
+    return rank * n_docs // world, (rank + 1) * n_docs // world
+
+
+def _xp(a):
+    if type(a).__module__.startswith("torch"):
+        import torch
+        return torch
+    return np
+
+
+def shard_index_by_docs(term_ptr, post_doc, post_tf, lo: int, hi: int, pos_ptr=None, pos=None):
+    """Restrict a term-major CSR table to the docs [lo, hi): -> (term_ptr, post_doc - lo, post_tf[, pos_ptr, pos]).
+    numpy arrays, or torch tensors (int64/int32 bit-views of the u64/u32 arrays) which stay on their device.
+    Pure data movement (select + prefix sum); lists stay ascending by doc."""
+    xp = _xp(post_doc)
+    if xp is np:
+        doc = np.asarray(post_doc).astype(np.int64)
+        mask = (doc >= lo) & (doc < hi)
+        csum = np.concatenate([[0], np.cumsum(mask, dtype=np.int64)])
+        new_ptr = csum[np.asarray(term_ptr).astype(np.int64)].astype(np.uint64)
+        out = [new_ptr, (doc[mask] - lo).astype(np.uint32), np.asarray(post_tf)[mask]]
+        if pos_ptr is not None:
+            pp = np.asarray(pos_ptr).astype(np.int64)
+            lens = np.diff(pp)
+            out += [np.concatenate([[0], np.cumsum(lens[mask])]).astype(np.uint64), np.asarray(pos)[np.repeat(mask, lens)]]
+        return tuple(out)
+    import torch
+    if hi > 2 ** 31:
+        raise ValueError("torch path holds doc ids in int32 views: n_docs must stay below 2^31")
+    mask = (post_doc >= lo) & (post_doc < hi)
+    csum = torch.cumsum(mask, 0, dtype=torch.int64)
+    tp = term_ptr.to(torch.int64)
+    new_ptr = torch.where(tp > 0, csum[(tp - 1).clamp(min=0)], torch.zeros_like(tp)) if csum.numel() else torch.zeros_like(tp)
+    del csum
+    out = [new_ptr, (post_doc[mask] - lo).to(torch.int32), post_tf[mask]]
+    if pos_ptr is not None:
+        lens = pos_ptr[1:] - pos_ptr[:-1]
+        zero = torch.zeros(1, dtype=torch.int64, device=lens.device)
+        out += [torch.cat([zero, torch.cumsum(lens[mask], 0)]), pos[torch.repeat_interleave(mask, lens)]]
+    return tuple(out)
+
+
+def local_doc_freq(term_ptr):
+    """Local list lengths (int64[T]) of a shard's term_ptr."""
+    xp = _xp(term_ptr)
+    if xp is np:
+        return np.diff(np.asarray(term_ptr).astype(np.int64))
+    return (term_ptr[1:] - term_ptr[:-1]).to(xp.int64)
+
+
+def global_doc_freq(term_ptr, group=None):
+    """Whole-corpus document frequencies: all-reduce(sum) of the shards' local list lengths.
+    -> uint64 numpy array, or an int64 torch tensor on the input's device."""
+    import torch
+    import torch.distributed as dist
+    df = local_doc_freq(term_ptr)
+    if _xp(df) is np:
+        t = torch.from_numpy(np.ascontiguousarray(df))
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy().astype(np.uint64)
+    if df.is_cuda and dist.get_backend(group) != "nccl":         # rehearsal: device data, gloo collective
+        h = df.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        return h.to(df.device)
+    dist.all_reduce(df, op=dist.ReduceOp.SUM, group=group)
+    return df
+
+
+HIT_BYTES = 40      # sizeof(ss_hit)
+
+
+class DocShardedScorer:
+    """One doc-range shard per process: replicate the query batch, score locally, all-gather, merge.
+
+    `scorer`  local shard scorer: score_topk(q_ptr, q_terms, k, query_len=, topic_probs=[, out=]) with LOCAL doc ids
+              (engine.Scorer in the product);
+    `merge`   callable(parts, n_hits [world][n_q], k, doc_base) -> (hits, n_hits) (engine.Context.merge_hits);
+    `device`  torch device of the exchange buffers (None: host buffers, the gloo tests);
+    host_staged: device results, gloo collective (single-GPU rehearsal only).
+    """
+
+    def __init__(self, scorer, merge, n_docs: int, rank: int, world: int, device=None, group=None, host_staged: bool = False):
+        self.scorer, self.merge = scorer, merge
+        self.rank, self.world, self.group = rank, world, group
+        self.device, self.host_staged = device, host_staged
+        self.doc_base = np.asarray([doc_range(n_docs, r, world)[0] for r in range(world)], dtype=np.uint32)
+        self._bufs = None
+
+    def _buffers(self, n_q: int, k: int):
+        import torch
+        key = (n_q, k)
+        if self._bufs is None or self._bufs[0] != key:
+            dev = self.device if self.device is not None else "cpu"
+            mk = lambda n, dt: torch.empty(n, dtype=dt, device=dev)
+            self._bufs = (key, mk(n_q * k * HIT_BYTES, torch.uint8), mk(n_q, torch.int32),
+                          mk(self.world * n_q * k * HIT_BYTES, torch.uint8), mk(self.world * n_q, torch.int32))
+        return self._bufs[1:]
+
+    def score_topk(self, q_ptr, q_terms, k: int, query_len=None, topic_probs=None, out=None):
+        """-> (hits [n_q][k], n_hits [n_q]) over the whole corpus, identical on every rank."""
+        import torch
+        import torch.distributed as dist
+        n_q = int(q_ptr.shape[0]) - 1
+        loc_h, loc_n, all_h, all_n = self._buffers(n_q, k)
+        if self.device is not None:
+            self.scorer.score_topk(q_ptr, q_terms, k, query_len=query_len, topic_probs=topic_probs, out=(loc_h, loc_n))
+        else:
+            h, n = self.scorer.score_topk(q_ptr, q_terms, k, query_len=query_len, topic_probs=topic_probs)
+            loc_h.copy_(torch.from_numpy(np.ascontiguousarray(h).view(np.uint8).reshape(-1)))
+            loc_n.copy_(torch.from_numpy(np.ascontiguousarray(n, dtype=np.int32)))
+        if self.host_staged:
+            hh, hn = loc_h.cpu(), loc_n.cpu()
+            ah, an = torch.empty(all_h.shape, dtype=torch.uint8), torch.empty(all_n.shape, dtype=torch.int32)
+            dist.all_gather_into_tensor(ah, hh, group=self.group)
+            dist.all_gather_into_tensor(an, hn, group=self.group)
+            all_h.copy_(ah)
+            all_n.copy_(an)
+        else:
+            dist.all_gather_into_tensor(all_h, loc_h, group=self.group)
+            dist.all_gather_into_tensor(all_n, loc_n, group=self.group)
+        if self.device is not None:
+            return self.merge(all_h, all_n.view(self.world, n_q), k, self.doc_base, out=out)
+        parts = all_h.numpy().view(_hit_dtype()).reshape(self.world, n_q, k)
+        return self.merge(parts, all_n.numpy().reshape(self.world, n_q), k, self.doc_base)
+
+
+def _hit_dtype():
+    return np.dtype([("doc", "<u4"), ("_pad", "<u4"), ("title", "<f8"), ("body", "<f8"), ("pagerank", "<f8"), ("final", "<f8")])

@@ -120,3 +120,56 @@ class NumpyShardState:
 
     def read_local(self):
         return self.own.astype(np.uint32), np.ascontiguousarray(self.x.T)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU model of ONE doc-range shard of the inverted index (test infrastructure): the oracle's arithmetic
+# applied to the shard's slice, with the idf taken from whole-corpus document frequencies — what
+# ss_index_set_doc_freq + ss_tfidf_build + ss_score_topk do on the GPU.
+
+class CpuIndexShard:
+    def __init__(self, n_docs_local, title, body, df_title, df_body, total_docs):
+        from oracle import pyoracle
+        self.n = int(n_docs_local)
+        self.tables = []
+        self.mags = []
+        for (ptr, doc, tf), df in ((title, df_title), (body, df_body)):
+            ptr = np.asarray(ptr, dtype=np.uint64)
+            idf = np.array([np.float32(pyoracle.go_log2(float(total_docs) / float(x))) if x else np.float32(np.inf)
+                            for x in np.asarray(df, dtype=np.uint64)], dtype=np.float32)          # term_weighting.go:37
+            w = (np.asarray(tf, dtype=np.float32) * np.repeat(idf, np.diff(ptr.astype(np.int64)))).astype(np.float32)   # :42
+            sq = (w * w).astype(np.float32).astype(np.float64)                                   # :44
+            mag2 = np.zeros(self.n)
+            np.add.at(mag2, np.asarray(doc, dtype=np.int64), sq)                                 # posting order, like the Go loop
+            self.tables.append((ptr, np.asarray(doc, dtype=np.uint32), w))
+            self.mags.append(np.sqrt(mag2))
+        self.prior = None
+
+    def set_prior(self, rank_local):
+        """rank_local [K][n_local] topic-major -> node-major like forw[3] rows."""
+        self.prior = None if rank_local is None else np.ascontiguousarray(np.asarray(rank_local).T)
+
+    def score_topk(self, q_ptr, q_terms, k, query_len=None, topic_probs=None):
+        from oracle import pyoracle
+        return pyoracle.score_topk_batch(self.n, self.tables[0], self.tables[1], self.mags[0], self.mags[1], q_ptr, q_terms, k,
+                                         prior=self.prior, topic_probs=topic_probs, query_len=query_len)
+
+
+def merge_hits_model(parts, n_hits, k, doc_base):
+    """numpy restatement of the merge order: final descending, equal finals by ascending corpus doc id, NaN last."""
+    n_parts, n_q = n_hits.shape
+    out = np.zeros((n_q, k), dtype=parts.dtype)
+    n_out = np.zeros(n_q, dtype=np.int32)
+    for q in range(n_q):
+        rows = []
+        for p in range(n_parts):
+            r = parts[p, q, :n_hits[p, q]].copy()
+            r["doc"] += np.uint32(doc_base[p])
+            rows.append(r)
+        allr = np.concatenate(rows)
+        nan = np.isnan(allr["final"])
+        order = np.lexsort((allr["doc"], -np.where(nan, 0.0, allr["final"]), nan))
+        allr = allr[order][:k]
+        out[q, :len(allr)] = allr
+        n_out[q] = len(allr)
+    return out, n_out
