@@ -395,7 +395,7 @@ def main() -> None:
             else:
                 g5 = torch.Generator(device="cpu").manual_seed(46)
                 prior5 = (torch.rand((kt5, nd), generator=g5, dtype=torch.float64) * 1e-6).numpy()
-                prior_src = "synthetic uniform ranks (the PageRank half did not run in this process)"
+                prior_src = "synthetic uniform ranks (N>1, or the PageRank half did not run)"
             sc.set_prior(prior5)
             probs5 = np.random.default_rng(46 + rank).dirichlet(np.ones(kt5), size=nq)
             d_probs = torch.from_numpy(probs5).to(dev)
