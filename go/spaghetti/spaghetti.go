@@ -146,6 +146,12 @@ func (ix *Index) TfIdfBuild(totalDocs uint64) (w []float32, mag []float64) {
 func (ix *Index) SetPositions(posPtr []uint64, pos []float32) {
 	check(ix.ctx, C.ss_index_set_positions(ix.h, u64p(posPtr), f32p(pos)), "ss_index_set_positions")
 }
+
+// SetDocFreq: multi-GPU doc-range shards only — df[t] = length of term t's whole posting list
+// (term_weighting.go:37 len(docs)), summed over the shards by the caller.  Call before TfIdfBuild.
+func (ix *Index) SetDocFreq(df []uint64) {
+	check(ix.ctx, C.ss_index_set_doc_freq(ix.h, u64p(df)), "ss_index_set_doc_freq")
+}
 func (ix *Index) SetWeighted(mag []float64) {
 	check(ix.ctx, C.ss_index_set_weighted(ix.h, f64p(mag)), "ss_index_set_weighted")
 }
@@ -197,4 +203,36 @@ func (s *Scorer) ScoreTopK(qPtr, qTerms []uint32, queryLen []int32, topicProbs [
 		}
 	}
 	return out, nil
+}
+
+// MergeHits: multi-GPU doc-range shards only — parts[p] holds shard p's rows of one query batch as returned
+// by ScoreTopK (local doc ids), docBase[p] the shard's first corpus doc id.  Returns the k best of the union
+// per query in the order of appendSort (util.go:48-54).
+func (c *Ctx) MergeHits(parts [][][]Hit, docBase []uint32, k int) [][]Hit {
+	np := len(parts)
+	nq := len(parts[0])
+	raw := make([]C.ss_hit, np*nq*k)
+	nHits := make([]int32, np*nq)
+	for p := range parts {
+		for q := range parts[p] {
+			nHits[p*nq+q] = int32(len(parts[p][q]))
+			for i, h := range parts[p][q] {
+				r := &raw[(p*nq+q)*k+i]
+				r.doc, r.title, r.body, r.pagerank, r.final = C.uint32_t(h.Doc), C.double(h.Title), C.double(h.Body), C.double(h.PageRank), C.double(h.Final)
+			}
+		}
+	}
+	out := make([]C.ss_hit, nq*k)
+	nOut := make([]int32, nq)
+	check(c, C.ss_merge_hits(c.h, C.int32_t(nq), C.int32_t(np), C.int32_t(k), (*C.ss_hit)(unsafe.Pointer(&raw[0])), i32p(nHits),
+		u32p(docBase), (*C.ss_hit)(unsafe.Pointer(&out[0])), i32p(nOut)), "ss_merge_hits")
+	res := make([][]Hit, nq)
+	for q := 0; q < nq; q++ {
+		res[q] = make([]Hit, nOut[q])
+		for i := range res[q] {
+			r := out[q*k+i]
+			res[q][i] = Hit{uint32(r.doc), float64(r.title), float64(r.body), float64(r.pagerank), float64(r.final)}
+		}
+	}
+	return res
 }
