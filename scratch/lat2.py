@@ -1,0 +1,20 @@
+import time, numpy as np, torch, sys, os
+sys.path.insert(0, '.')
+from spaghettisearch_amd import engine, synth
+dev = torch.device('cuda', 0)
+ctx = engine.Context(0)
+nd, nt = 10_000_000, 1_000_000
+b = synth.zipf_index_torch(nd, nt, 640_000_000, seed=44, device=dev)
+t = synth.zipf_index_torch(nd, nt, 40_000_000, seed=144, device=dev)
+bi = engine.InvertedIndex(ctx, nd, *b); ti = engine.InvertedIndex(ctx, nd, *t)
+del b, t
+ti.tfidf_build(nd, False, False, False); bi.tfidf_build(nd, False, False, False)
+sc = engine.Scorer(ctx, ti, bi)
+k = 100
+nq = int(os.environ.get("NQ", "1"))
+q_ptr, q_terms = synth.make_queries(nq, 3, 10_000, seed=5)
+dq = (torch.from_numpy(q_ptr.view(np.int32)).to(dev), torch.from_numpy(q_terms.view(np.int32)).to(dev))
+d_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev); d_n = torch.empty(nq, dtype=torch.int32, device=dev)
+for _ in range(20): sc.score_topk(dq[0], dq[1], k, out=(d_hits, d_n))
+torch.cuda.synchronize()
+sc.close()
