@@ -114,9 +114,7 @@ struct ScoreParams {
     const double* sqd_ub;      // [n_q] upper bound of sqd over all docs (when probs)
     const uint32_t* slice_base;// [n_q+1] (query order)
     const SliceDesc* slices;   // query order
-    const uint32_t* order;     // launch order -> slice index (longest first), slices of k_score_slices
-    const uint32_t* order_w;   // same for the slices of k_score_waves
-    uint64_t n_docs;
+    const uint32_t* order;     // launch order -> slice index (longest first)
     int32_t k;
     int32_t cb;                // candidate buffer entries (power of two >= 2k)
     uint64_t* so_key; uint32_t* so_doc; uint32_t* so_cnt;   // per slice top-k
@@ -621,463 +619,6 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
 #endif
 }
 
-// ---- K4w: wave-autonomous variant of K4 (queries of <= WV_MAXL lists, k <= WV_KMAX) ------------------
-// K4 above pays two workgroup barriers per window and parks its 16 waves on them ~40 % of the time.  Here
-// a workgroup is just four independent waves: each walks a quarter of the slice's doc range with its own
-// small hash table and its own candidate buffer; the only workgroup barriers are the one after the set-up
-// and the one before the four sorted top-k lists are merged.  Inside a wave everything is wave-synchronous
-// (ballots, DPP reductions; the LDS operations of one wave execute in order).
-//
-// A wave cuts its range into WV_S sub-ranges and walks them round-robin, one window of sub-range 0, one of
-// sub-range 1, ...: the loads of a sub-range's next window are issued right after its window was scored and
-// land while the other sub-ranges take their turn, so WV_S windows (WV_S * 2 KiB) are in flight per wave and
-// the memory latency is off the critical path.  The loads are unconditional (clamped addresses), so that the
-// compiler can count them: the wait before a window is `vmcnt((WV_S-1)*WV_RPL)`, not `vmcnt(0)`.
-//
-// A window of a sub-range: every list has a fixed share of the W load slots (its expected share of a window
-// plus two standard deviations, so that a sparse list rarely limits the window).  The window is cut at the
-// smallest "last loaded doc" over the lists that continue beyond their chunk: every list is complete up to
-// that doc.  The lanes whose record falls into the window insert it (CAS claim of the doc's slot + f64 add);
-// the lane whose CAS claimed the slot is the doc's owner: it reads the sums back, scores
-// (get_metadata.go:31-69), clears the slot and admits against the running threshold.  Thresholds are shared
-// through LDS (atomicMax): a wave that holds k docs >= t proves that the slice's k-th best is >= t, so the
-// other waves may drop anything below t.
-#ifndef SS_WV_S
-#define SS_WV_S 4
-#endif
-#ifndef SS_WV_WGS_PER_CU
-#define SS_WV_WGS_PER_CU 4
-#endif
-constexpr int WV_WAVES = 4;
-constexpr int WV_TPB = 64 * WV_WAVES;
-constexpr int WV_S = SS_WV_S;                // sub-ranges walked round-robin by one wave
-constexpr int WV_RPL = 2;                    // records per lane and window
-constexpr int WV_W = 64 * WV_RPL;            // load slots of a window
-constexpr int WV_HT = WV_W * 3 / 2;          // hash slots (load <= 0.67)
-constexpr int WV_CB = 256;                   // candidate buffer of a wave
-constexpr int WV_KMAX = 128;                 // k <= WV_CB / 2
-constexpr int WV_MAXL = 8;
-constexpr size_t WV_LDS_WAVE = (size_t)WV_W * 32 + (size_t)WV_CB * 8 + (size_t)WV_MAXL * 16 +
-                               ((size_t)2 * WV_HT + WV_CB + (size_t)(2 * WV_S + 1) * WV_MAXL + WV_MAXL) * 4;
-constexpr size_t WV_LDS_BLOCK = 64 + WV_WAVES * WV_LDS_WAVE;
-static_assert(WV_LDS_WAVE % 16 == 0, "per-wave LDS image must keep 16-byte alignment");
-static_assert((WV_S + 1) * WV_MAXL <= 64, "one lane per (boundary, list) search");
-
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m));
-    return v;
-}
-
-// wave-synchronous bitonic sort of the wave's candidate buffer, best first; keeps the k best
-__device__ void wave_compact(uint64_t* c_key, uint32_t* c_doc, uint32_t& count, int k, int lane) {
-    uint32_t n2 = 64;
-    while (n2 < count) n2 <<= 1;
-    for (uint32_t i = count + lane; i < n2; i += 64) { c_key[i] = 0ull; c_doc[i] = EMPTY; }
-    wave_lds_fence();
-    for (uint32_t size = 2; size <= n2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t i = lane; i < (n2 >> 1); i += 64) {
-                const uint32_t lo = 2 * i - (i & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const uint64_t ka = c_key[lo], kb = c_key[hi];
-                const uint32_t da = c_doc[lo], db = c_doc[hi];
-                const bool swap = desc ? better(kb, db, ka, da) : better(ka, da, kb, db);
-                if (swap) { c_key[lo] = kb; c_key[hi] = ka; c_doc[lo] = db; c_doc[hi] = da; }
-            }
-            wave_lds_fence();
-        }
-    }
-    count = min(count, (uint32_t)k);
-}
-
-__global__ __launch_bounds__(WV_TPB, SS_WV_WGS_PER_CU) void k_score_waves(ScoreParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned long long* blk_thr = reinterpret_cast<unsigned long long*>(smem);   // best proven lower bound of the slice's k-th key
-    uint32_t* blk_cnt = reinterpret_cast<uint32_t*>(smem + 16);                  // [WV_WAVES] final list lengths
-    uint32_t* w_bmin = reinterpret_cast<uint32_t*>(smem + 32) + (threadIdx.x >> 6);   // this wave's window cut (LDS min over a few lanes)
-    auto wave_base = [&](int w) { return smem + 64 + (size_t)w * WV_LDS_WAVE; };
-    constexpr size_t OFF_CKEY = (size_t)WV_W * 32;
-    constexpr size_t OFF_CDOC = OFF_CKEY + (size_t)WV_CB * 8 + (size_t)WV_MAXL * 16 + (size_t)2 * WV_HT * 4;
-    unsigned char* wb = wave_base(wv);
-    double* xTB = reinterpret_cast<double*>(wb);                         // [WV_W][2] exact (BodyRank, TitleRank) sums of the hot doc owned by load slot s
-    double* xMG = xTB + 2 * WV_W;                                        // [WV_W][2] its (body, title) magnitudes
-    uint64_t* c_key = reinterpret_cast<uint64_t*>(wb + OFF_CKEY);        // [WV_CB]
-    uint64_t* l_base = c_key + WV_CB;                                    // [WV_MAXL]
-    double* l_mult = reinterpret_cast<double*>(l_base + WV_MAXL);        // [WV_MAXL]
-    uint32_t* hkey = reinterpret_cast<uint32_t*>(l_mult + WV_MAXL);      // [WV_HT]
-    float* hest = reinterpret_cast<float*>(hkey + WV_HT);                // [WV_HT] float upper estimate of the doc's text score; hot docs: owner's load slot
-    uint32_t* c_doc = reinterpret_cast<uint32_t*>(wb + OFF_CDOC);        // [WV_CB]
-    uint32_t* st_bnd = c_doc + WV_CB;                                    // [WV_S+1][WV_MAXL] where list l enters sub-range s (row s+1 = where it leaves)
-    uint32_t* st_cur = st_bnd + (WV_S + 1) * WV_MAXL;                    // [WV_S][WV_MAXL] cursor of list l in sub-range s
-    uint32_t* l_len = st_cur + WV_S * WV_MAXL;                           // [WV_MAXL] whole list length
-
-    const uint32_t slice_id = p.order_w[blockIdx.x];
-    const SliceDesc sd = p.slices[slice_id];
-    const uint32_t q = sd.q;
-    const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
-    const bool has_phrase = p.ph_off && p.ph_off[q + 1] > p.ph_off[q];
-    const int L = (int)(2 * nd) + (has_phrase ? 4 : 0);                  // <= WV_MAXL (host)
-    const int k = p.k;
-    const double qmag = p.qmag[q];
-    const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
-    const double sqd_ub = probs ? p.sqd_ub[q] : 0.0;
-    const float sqd_ub_f = probs ? __double2float_ru(sqd_ub) : 0.0f;
-    const float qmag_f = (float)qmag;
-
-    if (tid == 0) *blk_thr = 0ull;
-    for (int i = lane; i < WV_HT; i += 64) { hkey[i] = EMPTY; hest[i] = 0.0f; }
-    for (int i = lane; i < 2 * WV_W; i += 64) { xTB[i] = 0.0; xMG[i] = 1.0; }
-    if (lane < L) {
-        const int field = lane & 1;          // 0 = body, 1 = title (also for the phrase lists)
-        uint64_t addr;
-        uint32_t len;
-        double mult;
-        if (lane < (int)(2 * nd)) {
-            const uint32_t term = p.dterm[t0 + (lane >> 1)];
-            const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-            const uint64_t p0 = ptr[term];
-            addr = (uint64_t)((field ? p.t_post : p.b_post) + p0);
-            len = (uint32_t)(ptr[term + 1] - p0);
-            mult = (double)p.dmult[t0 + (lane >> 1)];
-        } else {
-            const int x = lane - (int)(2 * nd);
-            addr = (uint64_t)(p.x_list[x] + p.x_off[q]);
-            len = p.x_cnt[(size_t)q * 4 + x];
-            mult = 1.0;
-        }
-        l_base[lane] = addr;
-        l_mult[lane] = mult;
-        l_len[lane] = len;
-    }
-    __syncthreads();                         // the shared threshold is initialised before any wave reads or raises it
-    // sub-range boundaries of this wave's quarter of the slice: one lane per (boundary, list)
-    {
-        const uint64_t dhi_eff = sd.dhi == 0xFFFFFFFFu ? p.n_docs : (uint64_t)sd.dhi;
-        const int bi = lane / WV_MAXL, l = lane % WV_MAXL;      // boundary 0..WV_S
-        if (bi <= WV_S && l < L) {
-            const uint32_t part = (uint32_t)(wv * WV_S + bi);   // of WV_WAVES*WV_S equal parts
-            const uint64_t d = sd.dlo + (dhi_eff - sd.dlo) * (uint64_t)part / (uint64_t)(WV_WAVES * WV_S);
-            const uint32_t len = l_len[l];
-            uint32_t bound;
-            if (part == (uint32_t)(WV_WAVES * WV_S) && sd.dhi == 0xFFFFFFFFu) bound = len;
-            else if (d == 0) bound = 0;
-            else bound = lower_bound_interp(l_base[l], 0, len, (uint32_t)d);
-            st_bnd[bi * WV_MAXL + l] = bound;
-            if (bi < WV_S) st_cur[bi * WV_MAXL + l] = bound;
-        }
-        wave_lds_fence();
-    }
-    // Window quotas from the wave's whole range: list l expects mu_l = M*len_l/tot of a window's M records and is
-    // given mu_l + 2*sqrt(mu_l) + 1 load slots; the largest M that fits W is used, spare slots go to the longest list.
-    uint32_t quota[WV_MAXL], qoff[WV_MAXL + 1];
-    uint32_t tot = 0;
-    {
-        uint32_t len[WV_MAXL], longest = 0, longest_len = 0;
-#pragma unroll
-        for (int l = 0; l < WV_MAXL; l++) {
-            len[l] = l < L ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(st_bnd[WV_S * WV_MAXL + l] - st_bnd[l])) : 0u;
-            tot += len[l];
-            if (len[l] > longest_len) { longest_len = len[l]; longest = l; }
-        }
-        float Mlo = 0.0f, Mhi = (float)WV_W;
-        const float inv = tot ? 1.0f / (float)tot : 0.0f;
-        for (int it = 0; it < 10; it++) {
-            const float M = 0.5f * (Mlo + Mhi);
-            uint32_t sum = 0;
-#pragma unroll
-            for (int l = 0; l < WV_MAXL; l++)
-                if (len[l]) { const float mu = M * (float)len[l] * inv; sum += (uint32_t)(mu + 2.0f * __fsqrt_rn(mu)) + 1u; }
-            if (sum <= (uint32_t)WV_W) Mlo = M; else Mhi = M;
-        }
-        uint32_t sum = 0;
-#pragma unroll
-        for (int l = 0; l < WV_MAXL; l++) {
-            quota[l] = 0;
-            if (len[l]) { const float mu = Mlo * (float)len[l] * inv; quota[l] = (uint32_t)(mu + 2.0f * __fsqrt_rn(mu)) + 1u; }
-            quota[l] = (uint32_t)__builtin_amdgcn_readfirstlane((int)quota[l]);
-            sum += quota[l];
-        }
-#pragma unroll
-        for (int l = 0; l < WV_MAXL; l++) if ((uint32_t)l == longest && tot) quota[l] += (uint32_t)WV_W - sum;
-        qoff[0] = 0;
-#pragma unroll
-        for (int l = 0; l < WV_MAXL; l++) qoff[l + 1] = qoff[l] + quota[l];
-    }
-    // what this lane loads in every window: slot s = r*64+lane belongs to list my_l[r], record my_off[r] of its chunk
-    uint32_t my_l[WV_RPL], my_off[WV_RPL], my_last[WV_RPL], my_quota[WV_RPL];
-    uint64_t my_base[WV_RPL];
-    double my_mult[WV_RPL];
-    float my_cm[WV_RPL];                     // text-score weight of the list's field (get_metadata.go:69) * multiplicity / |query|
-    bool my_is_last[WV_RPL];
-#pragma unroll
-    for (int r = 0; r < WV_RPL; r++) {
-        const uint32_t s = (uint32_t)(r * 64 + lane);
-        uint32_t l = 0;
-#pragma unroll
-        for (int j = 1; j < WV_MAXL; j++) if (s >= qoff[j]) l = j;
-        uint32_t o = 0, qt = 0;
-#pragma unroll
-        for (int j = 0; j < WV_MAXL; j++) if (l == (uint32_t)j) { o = qoff[j]; qt = quota[j]; }
-        my_l[r] = l;
-        my_off[r] = s - o;
-        my_quota[r] = qt;
-        my_is_last[r] = tot != 0 && s + 1 == o + qt;
-        my_base[r] = tot ? l_base[l] : 0ull;
-        my_mult[r] = tot ? l_mult[l] : 0.0;
-        my_cm[r] = ((l & 1) ? 38.0f : 29.0f) * (float)my_mult[r] / qmag_f;
-        my_last[r] = tot ? l_len[l] - 1u : 0u;          // lists with load slots are not empty
-    }
-
-    uint32_t count = 0;                      // candidates held by this wave
-    unsigned long long thr = 0ull;           // admit keys >= thr
-    float thr_f = -INFINITY;
-
-    u32x4 rec[WV_S][WV_RPL];
-    uint32_t my_end[WV_S][WV_RPL];           // where this lane's list leaves sub-range sb
-#pragma unroll
-    for (int sb = 0; sb < WV_S; sb++)
-#pragma unroll
-        for (int r = 0; r < WV_RPL; r++) my_end[sb][r] = tot ? st_bnd[(sb + 1) * WV_MAXL + my_l[r]] : 0u;
-    if (lane == 0) *w_bmin = 0xFFFFFFFFu;
-    wave_lds_fence();
-    auto issue = [&](int sb, u32x4* rc) {    // unconditional: past a chunk's end the (clamped) record is loaded and ignored
-        const uint32_t* c = st_cur + sb * WV_MAXL;
-#pragma unroll
-        for (int r = 0; r < WV_RPL; r++) {
-            const uint32_t idx = min(c[my_l[r]] + my_off[r], my_last[r]);
-            rc[r] = load_rec(my_base[r], idx);
-        }
-    };
-    unsigned long long dg_win = 0, dg_hotwin = 0, dg_hot = 0, dg_cas = 0, dg_valid = 0, dg_compact = 0;
-    (void)dg_win; (void)dg_hotwin; (void)dg_hot; (void)dg_cas; (void)dg_valid; (void)dg_compact;
-    // one window of sub-range sb, then the loads of its next window; returns true while the sub-range has records left
-    auto window = [&](int sb, u32x4* rc, const uint32_t* me) -> bool {
-        uint32_t* c = st_cur + sb * WV_MAXL;
-        uint32_t cl[WV_RPL];
-        bool in[WV_RPL];
-#pragma unroll
-        for (int r = 0; r < WV_RPL; r++) cl[r] = c[my_l[r]];
-#pragma unroll
-        for (int r = 0; r < WV_RPL; r++) {
-            in[r] = cl[r] + my_off[r] < me[r];
-            // the list continues beyond its chunk: its last loaded doc bounds the window (LDS min: a handful of lanes)
-            if (my_is_last[r] && cl[r] + my_quota[r] < me[r]) atomicMin(w_bmin, rc[r].x);
-        }
-        wave_lds_fence();
-        const uint32_t bmin = *w_bmin;
-        if (lane == 0) *w_bmin = 0xFFFFFFFFu;
-        bool valid[WV_RPL];
-#pragma unroll
-        for (int r = 0; r < WV_RPL; r++) {
-            valid[r] = in[r] && rc[r].x <= bmin;
-            // a list's valid records are a prefix of its chunk: the furthest one moves the cursor
-            if (valid[r]) atomicMax(&c[my_l[r]], cl[r] + my_off[r] + 1u);
-        }
-        // ---- insert: claim the doc's slot (the claiming lane owns the doc) and add this record's share of a float
-        //      upper estimate of the text score, 100*(0.38*T/(mt*|q|) + 0.29*B/(mb*|q|)) = sum over the doc's records of
-        //      w/mag * weight * multiplicity / |q|.  Only docs whose estimate reaches the threshold are scored exactly.
-        uint32_t h[WV_RPL];
-        bool owner[WV_RPL];
-#pragma unroll
-        for (int r = 0; r < WV_RPL; r++) {
-            owner[r] = false;
-            h[r] = ((((rc[r].x * 2654435761u) >> 16) & 0xFFFFu) * (uint32_t)WV_HT) >> 16;
-#ifdef SS_DIAG
-            dg_valid += __popcll(__ballot(valid[r]));
-#endif
-            if (valid[r]) {
-                for (;;) {
-#ifdef SS_DIAG
-                    dg_cas++;
-#endif
-                    const uint32_t prev = atomicCAS(&hkey[h[r]], EMPTY, rc[r].x);
-                    if (prev == EMPTY) { owner[r] = true; break; }
-                    if (prev == rc[r].x) break;
-                    h[r] = h[r] + 1 == WV_HT ? 0 : h[r] + 1;
-                }
-                // |w| / (magnitude rounded down): never below the record's true share, whatever the weight's sign
-                const float mag_f = __double2float_rd(__hiloint2double((int)rc[r].w, (int)rc[r].z));
-                atomicAdd(&hest[h[r]], fabsf(__uint_as_float(rc[r].y)) * __frcp_rn(mag_f) * my_cm[r]);     // 0*inf = NaN: scored exactly
-            }
-        }
-        wave_lds_fence();
-        {
-            const unsigned long long shared = *blk_thr;
-            if (shared > thr) { thr = shared; thr_f = __double2float_rd(funkey(thr)); }
-        }
-        // ---- owners: a doc whose estimate (with a 1e-4 relative margin, anything non-finite included) cannot be
-        //      excluded is hot; the slot of a hot doc stays, tagged with the owner's load slot; the others are cleared
-        bool hot[WV_RPL];
-        bool any_hot = false;
-#pragma unroll
-        for (int r = 0; r < WV_RPL; r++) {
-            hot[r] = false;
-            if (owner[r]) {
-                const float et = hest[h[r]], ec = 33.0f * sqd_ub_f;
-                hot[r] = !((et + ec) + (et + fabsf(ec)) * 1e-4f + 1e-30f < thr_f);
-                if (hot[r]) {
-                    hest[h[r]] = __uint_as_float((uint32_t)(r * 64 + lane));
-                } else {
-                    hkey[h[r]] = EMPTY;
-                    hest[h[r]] = 0.0f;
-                }
-            }
-            any_hot = any_hot || __ballot(hot[r]) != 0ull;
-        }
-#ifdef SS_DIAG
-        dg_win++;
-        if (any_hot) dg_hotwin++;
-        for (int r = 0; r < WV_RPL; r++) dg_hot += __popcll(__ballot(hot[r]));
-#endif
-        if (any_hot) {
-            wave_lds_fence();
-            // every record of a hot doc adds its exact share (float32 weights in float64: exact, order-free)
-#pragma unroll
-            for (int r = 0; r < WV_RPL; r++) {
-                if (valid[r] && hkey[h[r]] == rc[r].x) {
-                    const uint32_t os = __float_as_uint(hest[h[r]]);
-                    const uint32_t field = my_l[r] & 1;
-                    atomicAdd(&xTB[2 * os + field], (double)__uint_as_float(rc[r].y) * my_mult[r]);
-                    xMG[2 * os + field] = __hiloint2double((int)rc[r].w, (int)rc[r].z);   // same value from every record of (doc, field)
-                }
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int r = 0; r < WV_RPL; r++) {
-                bool cand = false;
-                uint64_t e_key = 0;
-                if (hot[r]) {
-                    const uint32_t os = (uint32_t)(r * 64 + lane);
-                    const double2 tb = *reinterpret_cast<const double2*>(xTB + 2 * os);
-                    const double2 mg = *reinterpret_cast<const double2*>(xMG + 2 * os);
-                    *reinterpret_cast<double2*>(xTB + 2 * os) = make_double2(0.0, 0.0);
-                    *reinterpret_cast<double2*>(xMG + 2 * os) = make_double2(1.0, 1.0);   // no posting of a field: sum 0, 0/(1*q) = 0
-                    hkey[h[r]] = EMPTY;
-                    hest[h[r]] = 0.0f;
-                    const double B = tb.x, T = tb.y, mb = mg.x, mt = mg.y;
-                    double title, body, fin;
-                    bool keep = true;
-                    if (probs) {
-                        // the prior row (128 B) is only fetched if the doc can still make the top-k:
-                        // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
-                        final_rank(T, B, mt, mb, qmag, sqd_ub, title, body, fin);
-                        if (fkey(fin) >= thr || fin != fin) final_rank(T, B, mt, mb, qmag, topic_dot(p.prior, probs, p.k_topics, rc[r].x), title, body, fin);
-                        else keep = false;
-                    } else {
-                        final_rank(T, B, mt, mb, qmag, 0.0, title, body, fin);
-                    }
-                    e_key = fkey(fin);
-                    cand = keep && e_key >= thr;
-                }
-                unsigned long long mask = __ballot(cand);
-                if (mask == 0ull) continue;
-                if (count + (uint32_t)__popcll(mask) > (uint32_t)WV_CB) {
-                    wave_lds_fence();
-                    wave_compact(c_key, c_doc, count, k, lane);
-                    if (count == (uint32_t)k) {
-                        const unsigned long long kth = c_key[k - 1];
-                        if (kth > thr) { thr = kth; thr_f = kth != 0ull ? __double2float_rd(funkey(kth)) : -INFINITY; }
-                        if (lane == 0) atomicMax(blk_thr, kth);
-                    }
-                    cand = cand && e_key >= thr;
-                    mask = __ballot(cand);
-                }
-                if (cand) {
-                    const uint32_t at = count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    c_key[at] = e_key;
-                    c_doc[at] = rc[r].x;
-                }
-                count += (uint32_t)__popcll(mask);
-            }
-        }
-        wave_lds_fence();
-        // next window of this sub-range: in flight while the other sub-ranges take their turn
-        bool left = false;
-#pragma unroll
-        for (int r = 0; r < WV_RPL; r++) {
-            const uint32_t nc = c[my_l[r]] + my_off[r];
-            left = left || nc < me[r];
-            rc[r] = load_rec(my_base[r], min(nc, my_last[r]));
-        }
-        return __ballot(left) != 0ull;
-    };
-
-    bool live[WV_S];
-    bool any = false;
-#pragma unroll
-    for (int sb = 0; sb < WV_S; sb++) {
-        live[sb] = false;
-        if (tot) {
-            bool l = false;
-            if (lane < WV_MAXL && lane < L) l = st_bnd[sb * WV_MAXL + lane] < st_bnd[(sb + 1) * WV_MAXL + lane];
-            live[sb] = __ballot(l) != 0ull;
-        }
-        any = any || live[sb];
-    }
-    if (any) {
-#pragma unroll
-        for (int sb = 0; sb < WV_S; sb++) issue(sb, rec[sb]);
-    }
-    while (any) {
-        any = false;
-#pragma unroll
-        for (int sb = 0; sb < WV_S; sb++) {
-            if (live[sb]) live[sb] = window(sb, rec[sb], my_end[sb]);
-            else issue(sb, rec[sb]);         // finished sub-range: the same number of loads, so that the waits stay countable
-            any = any || live[sb];
-        }
-    }
-#ifdef SS_DIAG
-    {
-        unsigned long long mx = dg_cas;      // slowest lane's CAS count = loop rounds
-        for (int m = 32; m > 0; m >>= 1) { const unsigned long long o = __shfl_xor(mx, m); mx = o > mx ? o : mx; }
-        if (lane == 0) {
-            atomicAdd(&g_stamps[10], dg_win); atomicAdd(&g_stamps[11], dg_hotwin); atomicAdd(&g_stamps[12], dg_hot);
-            atomicAdd(&g_stamps[13], mx); atomicAdd(&g_stamps[14], dg_valid);
-        }
-    }
-#endif
-    wave_lds_fence();
-    wave_compact(c_key, c_doc, count, k, lane);
-    if (lane == 0) blk_cnt[wv] = count;
-    __syncthreads();
-    // ---- merge the four sorted lists: every entry's slot = its index + the number of entries of the other
-    //      waves that precede it (distinct docs: a total order)
-    uint32_t total = 0;
-#pragma unroll
-    for (int w = 0; w < WV_WAVES; w++) total += blk_cnt[w];
-    const uint32_t keep = min(total, (uint32_t)k);
-    for (uint32_t e = tid; e < (uint32_t)(WV_WAVES * WV_KMAX); e += WV_TPB) {
-        const uint32_t w = e / WV_KMAX, i = e % WV_KMAX;
-        if (i >= blk_cnt[w]) continue;
-        const uint64_t* mk = reinterpret_cast<const uint64_t*>(wave_base((int)w) + OFF_CKEY);
-        const uint32_t* md = reinterpret_cast<const uint32_t*>(wave_base((int)w) + OFF_CDOC);
-        const uint64_t key = mk[i];
-        const uint32_t doc = md[i];
-        uint32_t at = i;
-        for (uint32_t o = 0; o < (uint32_t)WV_WAVES && at < keep; o++) {
-            if (o == w) continue;
-            const uint64_t* ok = reinterpret_cast<const uint64_t*>(wave_base((int)o) + OFF_CKEY);
-            const uint32_t* od = reinterpret_cast<const uint32_t*>(wave_base((int)o) + OFF_CDOC);
-            uint32_t lo = 0, hi = blk_cnt[o];
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (better(ok[mid], od[mid], key, doc)) lo = mid + 1; else hi = mid;
-            }
-            at += lo;
-        }
-        if (at < keep) {
-            p.so_key[(size_t)slice_id * k + at] = key;
-            p.so_doc[(size_t)slice_id * k + at] = doc;
-        }
-    }
-    if (tid == 0) p.so_cnt[slice_id] = keep;
-}
-
 // ---- K6: quoted-phrase matching (retrieval/phrase.go:11-170, util.go:162-203) --------------------
 // One workgroup per query with a phrase.  Candidates = the docs of the phrase's rarest term (its body
 // postings, then its title-only postings); a thread takes one candidate doc and
@@ -1431,7 +972,7 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
             const char* names[10] = {"insert(+wait)", "barrier", "issue_loads", "scan+admit", "-", "-", "slice_init", "windows", "block_total", "blocks"};
             fprintf(stderr, "[ss diag] k_score_slices wave 3 cycles:");
             for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
-            fprintf(stderr, "\n[ss diag] k_score_waves: windows=%llu hot_windows=%llu hot_docs=%llu cas_rounds=%llu valid_records=%llu\n", h[10], h[11], h[12], h[13], h[14]);
+            fprintf(stderr, "\n");
         }
     }
 #endif
@@ -1634,17 +1175,6 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     for (size_t i = 0; i < n_slices; i++) h_order[i] = (uint32_t)i;
     std::stable_sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b) { return h_slice_cost[a] > h_slice_cost[b]; });
 
-    // queries with few lists and a small k go to the wave-autonomous kernel, the rest to the general one
-    // (experimental, slower than k_score_slices on the benchmark batch: opt-in only, SS_WAVE_KERNEL=1)
-    static const bool no_wave = [] { const char* e = std::getenv("SS_WAVE_KERNEL"); return !(e && *e == '1'); }();
-    std::vector<uint32_t> h_order_b, h_order_w;
-    for (uint32_t si : h_order) {
-        const uint32_t q = h_slices[si].q;
-        const uint32_t Lq = 2 * (h_qoff[q + 1] - h_qoff[q]) + ((p_ptr && h_pptr[q + 1] > h_pptr[q]) ? 4u : 0u);
-        if (!no_wave && k <= WV_KMAX && Lq <= (uint32_t)WV_MAXL) h_order_w.push_back(si); else h_order_b.push_back(si);
-    }
-    const size_t n_b = h_order_b.size(), n_w = h_order_w.size();
-
     int cb = SS_CB_MIN;
     while (cb < 2 * k) cb <<= 1;
 
@@ -1654,8 +1184,7 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     const size_t o_dterm = o;  o = align16(o + n_d * sizeof(uint32_t));
     const size_t o_dmult = o;  o = align16(o + n_d * sizeof(uint32_t));
     const size_t o_sbase = o;  o = align16(o + (n_q + 1) * sizeof(uint32_t));
-    const size_t o_order = o;  o = align16(o + n_b * sizeof(uint32_t));
-    const size_t o_order_w = o; o = align16(o + n_w * sizeof(uint32_t));
+    const size_t o_order = o;  o = align16(o + n_slices * sizeof(uint32_t));
     const size_t o_qmag = o;   o = align16(o + n_q * sizeof(double));
     const size_t o_ub = o;     o = align16(o + n_q * sizeof(double));
     const size_t o_slices = o; o = align16(o + n_slices * sizeof(SliceDesc));
@@ -1679,8 +1208,7 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
         std::memcpy(hp + o_dmult, h_dmult.data(), n_d * sizeof(uint32_t));
     }
     std::memcpy(hp + o_sbase, h_sbase.data(), (n_q + 1) * sizeof(uint32_t));
-    if (n_b) std::memcpy(hp + o_order, h_order_b.data(), n_b * sizeof(uint32_t));
-    if (n_w) std::memcpy(hp + o_order_w, h_order_w.data(), n_w * sizeof(uint32_t));
+    std::memcpy(hp + o_order, h_order.data(), n_slices * sizeof(uint32_t));
     std::memcpy(hp + o_qmag, h_qmag.data(), n_q * sizeof(double));
     std::memcpy(hp + o_ub, h_ub.data(), n_q * sizeof(double));
     std::memcpy(hp + o_slices, h_slices.data(), n_slices * sizeof(SliceDesc));
@@ -1728,8 +1256,6 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     p.slice_base = reinterpret_cast<const uint32_t*>(dp + o_sbase);
     p.slices = reinterpret_cast<const SliceDesc*>(dp + o_slices);
     p.order = reinterpret_cast<const uint32_t*>(dp + o_order);
-    p.order_w = reinterpret_cast<const uint32_t*>(dp + o_order_w);
-    p.n_docs = s->n_docs;
     p.k = k;
     p.cb = cb;
     p.so_key = s->d_so_key.p; p.so_doc = s->d_so_doc.p; p.so_cnt = s->d_so_cnt.p;
@@ -1738,15 +1264,13 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     const size_t lds_score = score_lds_bytes(cb), lds_merge = merge_lds_bytes(k, cb);
     if (s->lds_attr < cb) {
         SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_slices), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_score));
-        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_waves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WV_LDS_BLOCK));
         SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_topk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)merge_lds_bytes(SS_MAX_TOPK, cb)));
         s->lds_attr = cb;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
     if (any_phrase) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
-    if (n_w) hipLaunchKernelGGL(k_score_waves, dim3((unsigned)n_w), dim3(WV_TPB), WV_LDS_BLOCK, st, p);
-    if (n_b) hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_b), dim3(TPB), lds_score, st, p);
+    hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_slices), dim3(TPB), lds_score, st, p);
     hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
     ctx->ev_valid[1] = true;

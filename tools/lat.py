@@ -11,7 +11,7 @@ del b, t
 ti.tfidf_build(nd, False, False, False); bi.tfidf_build(nd, False, False, False)
 sc = engine.Scorer(ctx, ti, bi)
 k = 100
-for label, maxr in (("head", 10_000),):
+for label, maxr in (("head", 10_000), ("tail", nt)):
     for nq in (1, 8, 64, 256, 512, 1024, 2048, 4096):
         q_ptr, q_terms = synth.make_queries(nq, 3, maxr, seed=5)
         dq = (torch.from_numpy(q_ptr.view(np.int32)).to(dev), torch.from_numpy(q_terms.view(np.int32)).to(dev))

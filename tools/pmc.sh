@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: scratch/pmc.sh "<counters>" tag  -- runs lat2.py (NQ=1024) under rocprofv3 --pmc, prints per-kernel counter sums for k_score_*
+# usage: tools/pmc.sh "<counters>" tag  -- runs lat2.py (NQ=1024) under rocprofv3 --pmc, prints per-kernel counter sums for k_score_*
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc_$2
 rm -rf $out
-NQ=1024 timeout -k 10 250 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $out -o pmc -- python3 scratch/lat2.py > $out.log 2>&1
+NQ=1024 timeout -k 10 250 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $out -o pmc -- python3 tools/lat2.py > $out.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
