@@ -265,3 +265,35 @@ def test_fuzz_many_shapes_and_determinism(ss_ctx, oracle):
                 assert hits.tobytes() == first
     finally:
         close_all(sc, ti, bi)
+
+
+def test_concurrent_callers_share_one_scorer(ss_ctx, oracle):
+    # retrieval.Retrieve runs on one goroutine per HTTP request (cmd/server/server.go:47): many threads score
+    # against the same resident index at once; every caller must get exactly its own query's serial result
+    import threading
+    n_docs, n_terms = 60000, 4000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 900000, 70000, seed=12)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        batches = [synth.make_queries(1 + 3 * i, 3, 800, seed=100 + i) for i in range(8)]
+        serial = [sc.score_topk(qp, qt, 50) for qp, qt in batches]
+        got = [None] * len(batches)
+        errors = []
+
+        def worker(i):
+            try:
+                for _ in range(5):
+                    got[i] = sc.score_topk(batches[i][0], batches[i][1], 50)
+            except Exception as exc:                # noqa: BLE001 - reported below
+                errors.append(exc)
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(batches))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for (h, n), (rh, rn) in zip(got, serial):
+            assert n.tolist() == rn.tolist() and h.tobytes() == rh.tobytes()
+    finally:
+        close_all(sc, ti, bi)
