@@ -859,21 +859,31 @@ __global__ void k_transpose_prior(const double* __restrict__ in, uint64_t n, int
     const int t = (int)(i % K);
     out[i] = in[(uint64_t)t * n + doc];
 }
-// per-topic max / min of the prior (for the score upper bound)
-__global__ void k_prior_extrema(const double* __restrict__ prior, uint64_t n, int K, unsigned long long* __restrict__ mx,
+// per-topic max / min of the prior (for the score upper bound), read from the topic-major input: one contiguous,
+// coalesced row per topic (blockIdx.y); a wave reduces with DPP shuffles, one atomic pair per wave
+__global__ void k_prior_extrema(const double* __restrict__ rank_topic_major, uint64_t n, unsigned long long* __restrict__ mx,
                                 unsigned long long* __restrict__ mn) {
     const int t = blockIdx.y;
+    const double* row = rank_topic_major + (uint64_t)t * n;
     double a = -INFINITY, b = INFINITY;
     bool nan = false;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const double v = prior[i * K + t];
+        const double v = row[i];
         if (v != v) nan = true;
         a = fmax(a, v);
         b = fmin(b, v);
     }
     if (nan) { a = INFINITY; b = -INFINITY; }
-    atomicMax(&mx[t], (unsigned long long)fkey(a));
-    atomicMin(&mn[t], (unsigned long long)fkey(b));
+    unsigned long long ka = fkey(a), kb = fkey(b);
+    for (int m = 32; m > 0; m >>= 1) {
+        const unsigned long long oa = __shfl_xor(ka, m), ob = __shfl_xor(kb, m);
+        ka = oa > ka ? oa : ka;
+        kb = ob < kb ? ob : kb;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&mx[t], ka);
+        atomicMin(&mn[t], kb);
+    }
 }
 
 double unkey(uint64_t k) {
@@ -1006,7 +1016,7 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank) 
     SS_HIP(ctx, hipMemsetAsync(ext.p, 0x00, k_topics * sizeof(unsigned long long), ctx->stream));                 // max keys
     SS_HIP(ctx, hipMemsetAsync(ext.p + k_topics, 0xFF, k_topics * sizeof(unsigned long long), ctx->stream));      // min keys
     hipLaunchKernelGGL(k_prior_extrema, dim3(std::min<unsigned>(ss::div_up(s->n_docs, 256), 1024u), k_topics), dim3(256), 0,
-                       ctx->stream, (const double*)s->prior.p, s->n_docs, k_topics, ext.p, ext.p + k_topics);
+                       ctx->stream, (const double*)tmp.p, s->n_docs, ext.p, ext.p + k_topics);
     SS_HIP(ctx, hipGetLastError());
     std::vector<unsigned long long> h_ext(2 * (size_t)k_topics);
     SS_HIP(ctx, hipMemcpyAsync(h_ext.data(), ext.p, h_ext.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
