@@ -493,7 +493,8 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
                 // cheap float estimate first: almost every doc is far below the running threshold.
                 // Skipped only if the estimate, with a 1e-4 relative margin, is clearly below; anything
                 // non-finite falls through to the exact path.
-                const float ea = 38.0f * __fdividef((float)T, (float)mt[r] * qmag_f), eb = 29.0f * __fdividef((float)B, (float)mb[r] * qmag_f),
+                // v_rcp_f32 (1 ulp) instead of an IEEE division: the 1e-4 margin below covers it; 0*inf = NaN falls through
+                const float ea = 38.0f * ((float)T * __builtin_amdgcn_rcpf((float)mt[r] * qmag_f)), eb = 29.0f * ((float)B * __builtin_amdgcn_rcpf((float)mb[r] * qmag_f)),
                             ec = 33.0f * sqd_ub_f;
                 if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) { e_doc[r] = EMPTY; continue; }
                 double title, body, fin;
