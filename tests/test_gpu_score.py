@@ -297,3 +297,22 @@ def test_concurrent_callers_share_one_scorer(ss_ctx, oracle):
             assert n.tolist() == rn.tolist() and h.tobytes() == rh.tobytes()
     finally:
         close_all(sc, ti, bi)
+
+
+def test_long_queries_many_lists(ss_ctx, oracle):
+    # up to SS_MAX_QUERY_TERMS distinct terms: 2*64 posting lists per query (window plan rows of 129 cursors,
+    # general offset search, oversize-window bisection when the plan cannot hold enough windows)
+    n_docs, n_terms = 120000, 3000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 2500000, 200000, seed=3)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        rng = np.random.default_rng(8)
+        lens = [64, 40, 17, 7, 64]
+        q_terms = np.concatenate([rng.choice(400, size=n, replace=False) for n in lens]).astype(np.uint32)
+        q_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        for k in (10, 100, 300):
+            hits, n_hits = sc.score_topk(q_ptr, q_terms, k)
+            ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, k)
+            assert_same_hits(hits, n_hits, ref, ref_n)
+    finally:
+        close_all(sc, ti, bi)
