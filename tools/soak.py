@@ -81,6 +81,59 @@ def round_scoring(ctx, rng):
         same_hits(hits, n_hits, ref, ref_n, ("sharded", n_docs, world, k))
 
 
+def positional_table(n_docs, n_terms, n_post, seed, max_pos, anchor_frac):
+    tp, pd, _ = synth.zipf_index(n_docs, n_terms, n_post, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    pos_ptr = [0]; pos = []
+    tf = np.zeros(len(pd), dtype=np.float32)
+    for i in range(len(pd)):
+        c = int(rng.integers(1, 6))
+        ps = sorted(rng.choice(max_pos, size=min(c, max_pos), replace=False).astype(float).tolist())
+        if rng.random() < anchor_frac:
+            ps.append(-100.0)
+        pos += ps; pos_ptr.append(len(pos))
+        tf[i] = np.float32(len(ps)) / np.float32(8)
+    return (tp, pd, tf), (np.array(pos_ptr, np.uint64), np.array(pos, np.float32))
+
+
+def round_phrase(ctx, rng):
+    n_docs = int(rng.choice([5, 200, 3000])); n_terms = int(rng.integers(2, 40))
+    (bt, bpos) = positional_table(n_docs, n_terms, int(min(n_docs * n_terms // 2 + 1, rng.integers(1, 30000))), int(rng.integers(1 << 30)),
+                                  int(rng.choice([4, 12, 60])), float(rng.choice([0.0, 0.1, 0.5])))
+    (tt, tpos) = positional_table(n_docs, n_terms, int(min(n_docs * n_terms // 2 + 1, rng.integers(1, 4000))), int(rng.integers(1 << 30)),
+                                  int(rng.choice([3, 8])), float(rng.choice([0.0, 0.5])))
+    wb, mb, _ = pyoracle.tfidf(*bt, n_docs, n_docs); wt, mt, _ = pyoracle.tfidf(*tt, n_docs, n_docs)
+    title, body = (tt[0], tt[1], wt), (bt[0], bt[1], wb)
+    ti = engine.InvertedIndex(ctx, n_docs, *title); bi = engine.InvertedIndex(ctx, n_docs, *body)
+    ti.set_weighted(mt); bi.set_weighted(mb); ti.set_positions(*tpos); bi.set_positions(*bpos)
+    sc = engine.Scorer(ctx, ti, bi)
+    cases = []
+    for _ in range(int(rng.integers(1, 12))):
+        q = rng.integers(0, n_terms + 1, size=int(rng.integers(0, 4))).tolist()
+        ph = rng.integers(0, n_terms + (1 if rng.random() < 0.1 else 0), size=int(rng.choice([0, 1, 2, 2, 3, 5]))).tolist()
+        cases.append((q, ph))
+    q_terms = np.array([t for q, _ in cases for t in q], dtype=np.uint32)
+    q_ptr = np.concatenate([[0], np.cumsum([len(q) for q, _ in cases])]).astype(np.uint32)
+    p_terms = np.array([t for _, ph in cases for t in ph], dtype=np.uint32)
+    p_ptr = np.concatenate([[0], np.cumsum([len(ph) for _, ph in cases])]).astype(np.uint32)
+    k = int(rng.choice([1, 20, 200]))
+    hits, n_hits = sc.score_topk_phrase(q_ptr, q_terms, p_ptr, p_terms, k)
+    for qi, (q, ph) in enumerate(cases):
+        extra = None
+        if ph:
+            if all(t < n_terms for t in ph):
+                extra = pyoracle.phrase(title, body, tpos, bpos, ph)
+            else:
+                extra = (np.zeros(0, np.uint32), np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.uint8))
+        ref, _ = pyoracle.score_topk(n_docs, title, body, mt, mb, np.array(q, np.uint32), k, query_len=len(q) + len(ph), extra=extra)
+        n = int(n_hits[qi])
+        assert n == len(ref), ("phrase n", qi, n, len(ref), q, ph)
+        assert hits["doc"][qi, :n].tolist() == ref["doc"].tolist(), ("phrase docs", qi, q, ph)
+        for f in ("title", "body", "final"):
+            assert np.array_equal(hits[f][qi, :n], ref[f], equal_nan=True), ("phrase", qi, f)
+    sc.close(); ti.close(); bi.close()
+
+
 def round_pagerank(ctx, rng):
     n = int(rng.choice([1, 2, 5, 64, 1000, 30000, 200000]))
     e = int(rng.integers(0, max(1, min(n * n, 8 * n)) + 1))
@@ -113,8 +166,11 @@ def main():
     rng = np.random.default_rng(a.seed)
     t0 = time.time(); n = [0, 0]; last = t0
     while time.time() - t0 < a.seconds:
-        if rng.random() < 0.7:
+        u = rng.random()
+        if u < 0.55:
             round_scoring(ctx, rng); n[0] += 1
+        elif u < 0.75:
+            round_phrase(ctx, rng); n[0] += 1
         else:
             round_pagerank(ctx, rng); n[1] += 1
         if time.time() - last > 30:
