@@ -55,3 +55,21 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f), encoding="utf-8", errors="replace").read()
                 code = "\n".join(l for l in src.splitlines() if not l.strip().startswith(("#", "//", "*", "/*")))
                 assert "pyoracle" not in code and "liboracle" not in code and "oracle_np" not in code, f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 (what cgo feeds to the C compiler) and a plain C
+    program links against the library and calls it (no compute: ss_abi_version; ss_init may report no device)."""
+    import subprocess
+    from spaghettisearch_amd import _lib
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", HEADER], check=True)
+    src = tmp_path / "c_caller.c"
+    src.write_text('#include <stdio.h>\n#include "spaghetti_rank.h"\n'
+                   'int main(void) { ss_ctx* c = 0; int v = ss_abi_version(); int rc = ss_init(0, &c);\n'
+                   '  printf("abi=%d init=%d\\n", v, rc); if (rc == SS_OK) ss_shutdown(c); return v == 1 ? 0 : 1; }\n')
+    exe = tmp_path / "c_caller"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
+                    "-lspaghetti_rank", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("abi=1 init=")
