@@ -81,7 +81,9 @@ int32_t ss_abi_version(void);
 int32_t ss_init(int32_t device_id, ss_ctx** out);
 int32_t ss_shutdown(ss_ctx* ctx);
 /* Use the caller's HIP stream (e.g. torch's current stream) for all work of this ctx.
- * NULL = the library's own stream (default). */
+ * NULL = the library's own non-blocking stream (default).  DEVICE pointers passed to any entry
+ * point must hold their final contents with respect to the ctx stream: share the producer's
+ * stream here, or synchronise the producer first.  Host pointers need nothing. */
 int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream);
 int32_t ss_synchronize(ss_ctx* ctx);
 const char* ss_last_error(ss_ctx* ctx); /* ctx may be NULL: last global error */

@@ -58,6 +58,19 @@ class Context:
 
     def set_stream(self, hip_stream: Optional[int]) -> None:
         check(self.lib.ss_set_stream(self.h, C.c_void_p(hip_stream)), self.h)
+        self._shared_stream = bool(hip_stream)
+
+    def ready(self, *arrays) -> None:
+        """Device arrays handed to the library must hold their final contents with respect to the context's stream.
+        While the context runs on its own (non-blocking) stream, wait for torch's current stream if any argument is a
+        CUDA tensor; with a shared stream (set_stream) ordering is the stream's and nothing is done."""
+        if getattr(self, "_shared_stream", False):
+            return
+        for a in arrays:
+            if a is not None and _is_torch(a) and a.is_cuda:
+                import torch
+                torch.cuda.current_stream(a.device).synchronize()
+                return
 
     def merge_hits(self, parts, n_hits, k: int, doc_base=None, out=None):
         """ss_merge_hits: parts [n_parts][n_q][k] hits (numpy HIT_DTYPE, or a torch uint8 tensor of the same bytes),
@@ -81,6 +94,7 @@ class Context:
         else:
             hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
             n_out = np.zeros(n_q, dtype=np.int32)
+        self.ready(parts, n_hits, doc_base)
         check(self.lib.ss_merge_hits(self.h, n_q, n_parts, k, _ptr(parts), _ptr(n_hits), _ptr(doc_base), _ptr(hits), _ptr(n_out)), self.h)
         return hits, n_out
 
@@ -109,6 +123,7 @@ class Graph:
         self.e = int(out_dst.shape[0]) if out_dst is not None else 0
         if out_ptr.shape[0] != self.n + 1:
             raise ValueError("out_ptr must have n_nodes+1 entries")
+        ctx.ready(out_ptr, out_dst)
         h = C.c_void_p()
         check(ctx.lib.ss_graph_create(ctx.h, self.n, self.e, _ptr(out_ptr), _ptr(out_dst), rank, world, C.byref(h)), ctx.h)
         self.h = h
@@ -201,6 +216,7 @@ class InvertedIndex:
         post_tf = _as(post_tf, "float32")
         self.n_terms = int(term_ptr.shape[0]) - 1
         self.n_post = int(post_doc.shape[0])
+        ctx.ready(term_ptr, post_doc, post_tf)
         h = C.c_void_p()
         check(ctx.lib.ss_index_create(ctx.h, self.n_docs, self.n_terms, _ptr(term_ptr), _ptr(post_doc), _ptr(post_tf),
                                       C.byref(h)), ctx.h)
@@ -220,16 +236,19 @@ class InvertedIndex:
         df = _as(df, "uint64")
         if df is not None and int(df.shape[0]) != self.n_terms:
             raise ValueError("df must hold one entry per term")
+        self.ctx.ready(df)
         check(self.ctx.lib.ss_index_set_doc_freq(self.h, _ptr(df)), self.ctx.h)
 
     def set_positions(self, pos_ptr, pos) -> None:
         """Positional postings (listPos[1:] per posting) for phrase search."""
         pos_ptr = _as(pos_ptr, "uint64")
         pos = _as(pos, "float32")
+        self.ctx.ready(pos_ptr, pos)
         check(self.ctx.lib.ss_index_set_positions(self.h, _ptr(pos_ptr), _ptr(pos)), self.ctx.h)
 
     def set_weighted(self, mag) -> None:
         mag = _as(mag, "float64")
+        self.ctx.ready(mag)
         check(self.ctx.lib.ss_index_set_weighted(self.h, _ptr(mag)), self.ctx.h)
 
     def close(self) -> None:
@@ -257,6 +276,7 @@ class Scorer:
             return
         rank = _as(rank, "float64")
         self.k_topics = int(rank.shape[0])
+        self.ctx.ready(rank)
         check(self.ctx.lib.ss_scorer_set_prior(self.h, self.k_topics, _ptr(rank)), self.ctx.h)
 
     def score_topk_phrase(self, q_ptr, q_terms, p_ptr, p_terms, k: int, query_len=None, topic_probs=None):
@@ -268,6 +288,7 @@ class Scorer:
         query_len = _as(query_len, "int32")
         topic_probs = _as(topic_probs, "float64")
         n_q = int(q_ptr.shape[0]) - 1
+        self.ctx.ready(q_ptr, q_terms, p_ptr, p_terms, query_len, topic_probs)
         hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
         n_hits = np.zeros(n_q, dtype=np.int32)
         check(self.ctx.lib.ss_score_topk_phrase(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(p_ptr), _ptr(p_terms),
@@ -283,6 +304,7 @@ class Scorer:
         query_len = _as(query_len, "int32")
         topic_probs = _as(topic_probs, "float64")
         n_q = int(q_ptr.shape[0]) - 1
+        self.ctx.ready(q_ptr, q_terms, query_len, topic_probs)
         if out is not None:
             hits, n_hits = out
             if hits.numel() * hits.element_size() < n_q * k * HIT_DTYPE.itemsize or n_hits.numel() < n_q:
