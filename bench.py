@@ -258,6 +258,19 @@ def main() -> None:
                                                           "seconds": time.perf_counter() - t0}
             if world == 1 and args.workload == "both" and n == args.docs:
                 c4_ranks = prc.read()                   # [K][N] converged ranks: the prior of the blended top-k run (config 5)
+            if world == 1:
+                # the other damping factor SURVEY.md §8d asks for (a sweep costs the same; only the iteration counts move)
+                p85 = engine.PageRankState(g, 0.85, 1e-6, n_topic)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                p85.begin()
+                s85 = p85.status()
+                while s85["n_active"] > 0:
+                    p85.step(4)
+                    s85 = p85.status()
+                torch.cuda.synchronize()
+                result["config"]["to_convergence_eps1e-6_d0.85"] = {"iters": [int(x) for x in s85["iters"]], "seconds": time.perf_counter() - t0}
+                p85.close()
             prc.close()
 
             # ---- CPU baseline: the oracle's literal port on the same graph, bounded sample
