@@ -271,6 +271,18 @@ def main() -> None:
                 torch.cuda.synchronize()
                 result["config"]["to_convergence_eps1e-6_d0.85"] = {"iters": [int(x) for x in s85["iters"]], "seconds": time.perf_counter() - t0}
                 p85.close()
+                # the reference's own call (start_crawl.go:175: d=0.75, eps=1e-20 — to the floating-point fixed point)
+                pref = engine.PageRankState(g, 0.75, 1e-20, n_topic, max_iter=500)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pref.begin()
+                sref = pref.status()
+                while sref["n_active"] > 0:
+                    pref.step(4)
+                    sref = pref.status()
+                torch.cuda.synchronize()
+                result["config"]["to_convergence_reference_eps1e-20"] = {"iters": [int(x) for x in sref["iters"]], "seconds": time.perf_counter() - t0}
+                pref.close()
             prc.close()
 
             # ---- CPU baseline: the oracle's literal port on the same graph, bounded sample
