@@ -54,9 +54,9 @@ constexpr int CAP = SS_CAP;        // postings per window (capacity)
 constexpr int TARGET = CAP * 55 / 64;   // planned postings per window (880 of 1024: head-room for the spread around the plan)
 constexpr int PPT = CAP / TPB;     // records per thread
 #ifndef SS_HT
-#define SS_HT 1536
+#define SS_HT 2048
 #endif
-constexpr int HT = SS_HT;           // hash slots (1536: load factor <= 0.67; must be 2048*m/8)
+constexpr int HT = SS_HT;           // hash slots (multiple of 256; 2048: load factor <= 0.5, measured best of 1536..3072)
 constexpr int EPT = (HT + TPB - 1) / TPB;   // hash entries per thread in the scan
 constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS + 4;   // (term, field) lists per query + 4 phrase result lists
 #ifndef SS_TBL_CAP
@@ -262,9 +262,13 @@ __device__ void topk_compact(const TopK& tk, int k) {
 #endif
 __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* ht_TB = reinterpret_cast<double*>(smem);                   // [HT][2] (BodyRank, TitleRank) accumulators of a doc
-    double* s_mag = ht_TB + 2 * HT;                                    // [CAP] field magnitude carried by record i of the window
-    uint64_t* l_base = reinterpret_cast<uint64_t*>(s_mag + CAP);       // [MAXL] address of the list's first record
+    // Every record of the window parks {its addend float64(w)*multiplicity, its doc's field magnitude} at its own index
+    // (a stride-1 store).  A table slot names, per field, the FIRST record of that doc and field (one 32-bit CAS each);
+    // the rare later records of the same (doc, field) add their addend into the first one's.  So the 95 % of docs with
+    // one record per field cost no float64 atomic (the dearest LDS operation) and there is no per-slot
+    // accumulator array.
+    double2* s_rec = reinterpret_cast<double2*>(smem);                 // [CAP] {addend (summed: BodyRank/TitleRank of the doc), magnitude}
+    uint64_t* l_base = reinterpret_cast<uint64_t*>(s_rec + CAP);       // [MAXL] address of the list's first record
     double* l_mult = reinterpret_cast<double*>(l_base + MAXL);         // [MAXL]
     uint64_t* sc64 = reinterpret_cast<uint64_t*>(l_mult + MAXL);       // [2]: thr
     uint64_t* cd_key = sc64 + 2;                                       // [cb]
@@ -275,8 +279,8 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     uint32_t* f_cur = l_field + MAXL;                                  // [MAXL] oversize fallback: sub-window start
     uint32_t* f_nxt = f_cur + MAXL;                                    // [MAXL] oversize fallback: sub-window end
     uint32_t* sc32 = f_nxt + MAXL;                                     // [8] scalars
-    uint32_t* ht_idx = sc32 + 8;                                       // [HT] (body record | title record << 16) of the doc in this window, 0xFFFF = none
-    uint16_t* off = reinterpret_cast<uint16_t*>(ht_idx + HT);          // [OFF_CAP] offset of list l inside window j: off[j*OS+l], count at [j*OS+OS-1]
+    uint32_t* ht_rec = sc32 + 8;                                       // [HT][2] first body record, first title record of the slot's doc (EMPTY = none)
+    uint16_t* off = reinterpret_cast<uint16_t*>(ht_rec + 2 * HT);      // [OFF_CAP] offset of list l inside window j: off[j*OS+l], count at [j*OS+OS-1]
 
     uint32_t& cand_count = sc32[0];
     uint32_t& overflow = sc32[1];
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     const float sqd_ub_f = probs ? __double2float_ru(sqd_ub) : 0.0f;
     const float qmag_f = (float)qmag;
 
-    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_TB[2 * i] = 0.0; ht_TB[2 * i + 1] = 0.0; ht_idx[i] = 0xFFFFFFFFu; }
+    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_rec[2 * i] = EMPTY; ht_rec[2 * i + 1] = EMPTY; }
     if (tid == 0) { cand_count = 0; overflow = 0; sc64[0] = 0ull; *thr_f_s = -INFINITY; }
 
     // ---- slice set-up: where every list enters and leaves the slice's doc range ----
@@ -442,10 +446,11 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
                 const uint32_t i = tid + r * TPB;
                 const uint32_t field = l & 1;          // 0 = body, 1 = title
                 const double v = (double)__uint_as_float(rec[r].y) * l_mult[l];
-                s_mag[i] = __hiloint2double((int)rec[r].w, (int)rec[r].z);
-                atomicAdd(&ht_TB[2 * h[r] + field], v);
-                // all records of one (doc, field) carry the same magnitude: any writer may win
-                reinterpret_cast<uint16_t*>(ht_idx)[2 * h[r] + field] = (uint16_t)i;
+                s_rec[i] = make_double2(v, __hiloint2double((int)rec[r].w, (int)rec[r].z));
+                asm volatile("" ::: "memory");         // program order: parked before it can be named (LDS runs a wave's operations in order)
+                const uint32_t first = atomicCAS(&ht_rec[2 * h[r] + field], EMPTY, i);
+                // float32 addends in float64: exact, so the order of these rare adds does not matter
+                if (first != EMPTY) atomicAdd(&s_rec[first].x, v);
             }
         }
     };
@@ -455,34 +460,36 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
         uint64_t e_key[EPT];
         uint32_t e_doc[EPT];
         double2 tb[EPT];
-        uint32_t ix[EPT];
+        uint32_t ib[EPT], it[EPT];
         const uint64_t thr0 = *tk.thr;
         const float thr_f = *tk.thr_f;
 #pragma unroll
         for (int r = 0; r < EPT; r++) {
             const int hh = tid + r * TPB;
             e_doc[r] = EMPTY;
-            tb[r] = make_double2(0.0, 0.0);
-            ix[r] = 0xFFFFFFFFu;
+            ib[r] = EMPTY;
+            it[r] = EMPTY;
             if (HT % TPB == 0 || hh < HT) {
                 e_doc[r] = ht_key[hh];
-                tb[r] = *reinterpret_cast<const double2*>(ht_TB + 2 * hh);
-                ix[r] = ht_idx[hh];
+                const uint2 fr = *reinterpret_cast<const uint2*>(ht_rec + 2 * hh);
+                ib[r] = fr.x;
+                it[r] = fr.y;
             }
         }
         double mt[EPT], mb[EPT];
 #pragma unroll
         for (int r = 0; r < EPT; r++) {
             const int hh = tid + r * TPB;
-            const uint32_t ib = ix[r] & 0xFFFFu, it = ix[r] >> 16;
             // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
-            const double mb_ = s_mag[ib != 0xFFFFu ? ib : 0], mt_ = s_mag[it != 0xFFFFu ? it : 0];
-            mb[r] = ib != 0xFFFFu ? mb_ : 1.0;
-            mt[r] = it != 0xFFFFu ? mt_ : 1.0;
+            double2 rb = make_double2(0.0, 1.0), rt = make_double2(0.0, 1.0);
+            if (ib[r] != EMPTY) rb = s_rec[ib[r]];
+            if (it[r] != EMPTY) rt = s_rec[it[r]];
+            tb[r] = make_double2(rb.x, rt.x);
+            mb[r] = rb.y;
+            mt[r] = rt.y;
             if (HT % TPB == 0 || hh < HT) {
                 ht_key[hh] = EMPTY;
-                *reinterpret_cast<double2*>(ht_TB + 2 * hh) = make_double2(0.0, 0.0);
-                ht_idx[hh] = 0xFFFFFFFFu;
+                *reinterpret_cast<uint2*>(ht_rec + 2 * hh) = make_uint2(EMPTY, EMPTY);
             }
         }
 #pragma unroll
@@ -745,8 +752,8 @@ __global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
 }
 
 size_t score_lds_bytes(int cb) {
-    return (size_t)HT * 8 * 2 + (size_t)CAP * 8 + (size_t)MAXL * 8 * 2 + 2 * 8 + (size_t)cb * 12 +
-           ((size_t)2 * HT + TBL_CAP + 3 * MAXL + 8) * 4 + (size_t)OFF_CAP * 2 + 16;
+    return (size_t)CAP * 16 + (size_t)MAXL * 8 * 2 + 2 * 8 + (size_t)cb * 12 +
+           ((size_t)3 * HT + TBL_CAP + 3 * MAXL + 8) * 4 + (size_t)OFF_CAP * 2 + 16;
 }
 
 // ---- K5: merge a query's slices, explain the winners ------------------------------
