@@ -51,7 +51,10 @@ constexpr int TPB_M = 256;         // k_merge_topk workgroup
 #define SS_CAP 1024
 #endif
 constexpr int CAP = SS_CAP;        // postings per window (capacity)
-constexpr int TARGET = CAP * 55 / 64;   // planned postings per window (880 of 1024: head-room for the spread around the plan)
+#ifndef SS_TARGET_64THS
+#define SS_TARGET_64THS 59
+#endif
+constexpr int TARGET = CAP * SS_TARGET_64THS / 64;   // planned postings per window (944 of 1024; measured best of 832..1008: beyond 960 oversize windows start to cost more than the fewer windows save)
 constexpr int PPT = CAP / TPB;     // records per thread
 #ifndef SS_HT
 #define SS_HT 2048
