@@ -19,16 +19,21 @@
 //     A magnitude only matters when the doc has a posting of that field among the query terms
 //     (0/(m*q) is 0 or NaN->0 for every m), so nothing else is needed.
 //   * the host plans (it keeps df per term): duplicates -> multiplicities, unknown terms dropped,
-//     each query's doc range cut into slices of ~SLICE_TARGET postings, longest first;
-//     one workgroup per (query, slice).
-//   * k_score_slices walks its slice in windows of <= CAP postings taken proportionally from all
-//     (term, field) lists; window w+1's records are loaded (one coalesced 16-byte load per lane)
-//     while window w is processed.  Per window: doc ids -> LDS, wave 0 cuts the window at a common
-//     doc bound (every posting of a doc lands in one window), all waves accumulate (title, body)
-//     per doc in an LDS hash table with ds_add_f64 (float32 addends in float64 are exact, so order
-//     is irrelevant), then every touched doc is scored in registers and filtered into a running
-//     top-k (threshold + bitonic compaction).  With a PageRank blend the 128-byte prior row of a
-//     doc is only fetched if an upper bound of its score can still enter the top-k.
+//     each query's doc range cut into slices (size follows the batch: ~1.5x the batch's postings per
+//     resident workgroup slot, 16k..256k postings), longest first; one workgroup per (query, slice).
+//   * k_score_slices first builds the slice's whole window plan in LDS (window j = docs between the
+//     j-th and (j+1)-th cut of the longest list; every other list's cursor at each cut by an
+//     interpolating search), then walks the windows (<= CAP postings, every posting of a doc in one
+//     window); window j+1's records are loaded (one coalesced 16-byte load per lane) while window j
+//     is processed.  Per window: every record parks {float64(w)*multiplicity, magnitude} at its own
+//     index (stride-1 store), claims its doc's slot in an LDS hash table (32-bit CAS, linear
+//     probing) and the slot's per-field "first record" word (32-bit CAS); later records of the
+//     same (doc, field) add into the first one's addend (float32 addends in float64 are exact, so
+//     order is irrelevant) — single-record docs need no float64 atomic.  After one barrier the table
+//     is scanned stride-1: a float pre-filter drops almost every doc against the running
+//     threshold, survivors are scored exactly in float64 and go to the running top-k (threshold
+//     filter + bitonic compaction).  With a PageRank blend the 128-byte prior row of a doc is only
+//     fetched if an upper bound of its score can still enter the top-k.
 //   * k_merge_topk: one workgroup per query merges its slices' top-k lists, re-derives
 //     title/body/pagerank of the k winners by binary search and writes ss_hit rows.
 //   Ties: ascending doc id (Q10); NaN finals last.
