@@ -79,6 +79,21 @@ class DistExchange:
             return
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
 
+    def start(self):
+        """Begin the all-gather without waiting for it: work queued afterwards on the current stream (another
+        state's sweep) overlaps with the collective.  -> handle for finish().  The host-staged rehearsal path has
+        nothing to overlap and completes here."""
+        if self.host_staged:
+            self()
+            return None
+        return self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
+
+    @staticmethod
+    def finish(handle) -> None:
+        """Make the current stream (RCCL) or the host (gloo) wait for a started all-gather."""
+        if handle is not None:
+            handle.wait()
+
 
 class LocalExchange:
     """All shards live in ONE process (tests on a single GPU / CPU): plays the all-gather by copies."""
@@ -117,6 +132,35 @@ def iterate(states: Sequence, exchange, batch: int = 8, max_sweeps: Optional[int
         if st["n_active"] == 0:
             return st
     return states[0].status()
+
+
+def sweep_pipelined(states: Sequence, exchanges: Sequence, handles: list, n_sweeps: int) -> None:
+    """Topic-block pipelining of the doc-range-sharded sweep: `states` are this rank's shard states of disjoint
+    topic blocks over the same graph; while block b's contribution slices travel, block b+1 is finalized and swept.
+    `handles` holds one in-flight all-gather per block (see prime_pipelined) and is updated in place."""
+    for _ in range(n_sweeps):
+        for b, (st, ex) in enumerate(zip(states, exchanges)):
+            ex.finish(handles[b])
+            st.finalize()
+            st.step(1)
+            handles[b] = ex.start()
+
+
+def prime_pipelined(states: Sequence, exchanges: Sequence) -> list:
+    """begin() every block and leave its first all-gather in flight."""
+    handles = []
+    for st, ex in zip(states, exchanges):
+        st.begin()
+        handles.append(ex.start())
+    return handles
+
+
+def drain_pipelined(states: Sequence, exchanges: Sequence, handles: list) -> None:
+    """Complete the in-flight all-gathers and apply them (the states are then consistent, as after iterate())."""
+    for b, (st, ex) in enumerate(zip(states, exchanges)):
+        ex.finish(handles[b])
+        handles[b] = None
+        st.finalize()
 
 
 def assemble(parts: Sequence, n_nodes: int, k: int) -> np.ndarray:

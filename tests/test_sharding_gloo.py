@@ -73,3 +73,36 @@ def test_single_process_local_exchange_model():
     # shards are edge-balanced by the round-robin deal of degree-sorted rows
     sizes = [len(s.e_row) for s in states]
     assert max(sizes) < 1.25 * e / 5
+
+
+def _worker_pipelined(rank, world, port, n, e, n_topic, sweeps, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ptr, dst = synth.rmat_graph(n, e, seed=21)
+        half = len(n_topic) // 2
+        blocks = [n_topic[:half], n_topic[half:]]
+        states = [NumpyShardState(n, ptr, dst, D, -1.0, b, rank, world) for b in blocks]     # eps < 0: fixed number of sweeps
+        exs = [sharding.DistExchange(s, torch.device("cpu")) for s in states]
+        handles = sharding.prime_pipelined(states, exs)
+        sharding.sweep_pipelined(states, exs, handles, sweeps)
+        sharding.drain_pipelined(states, exs, handles)
+        ranks = np.concatenate([sharding.gather_ranks(s) for s in states])
+        if rank == 0:
+            np.savez(out_path, rank=ranks)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_topic_blocks_gloo_match_oracle(tmp_path, world):
+    # two topic blocks per rank, the all-gather of one block in flight while the other block is swept
+    n, e, sweeps = 3000, 16000, 6
+    n_topic = synth.topic_sizes(n, 4)
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker_pipelined, args=(world, _free_port(), n, e, n_topic, sweeps, out), nprocs=world, join=True)
+    got = np.load(out)
+    ptr, dst = synth.rmat_graph(n, e, seed=21)
+    ref, _ = pyoracle.pagerank(n, ptr, dst, D, -1.0, n_topic, max_iter=sweeps)
+    np.testing.assert_allclose(got["rank"], ref, rtol=1e-12)
