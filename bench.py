@@ -142,6 +142,34 @@ def main() -> None:
     result: dict = {}
     K, W = args.steps, args.warmup
 
+    def emit() -> None:
+        if rank != 0:
+            return
+        res = dict(result)
+        scaling = res.pop("scaling", "weak") if args.workload == "topk" else "strong"   # fixed graph: total work constant as N grows
+        out = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"),
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": res.pop("ms_per_step"),
+               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic"}
+        out.update(res)
+        print(json.dumps(out), flush=True)
+
+
+    if world > 1:
+        # Multi-GPU runs execute collectives this one-GPU development box could only rehearse: whatever has been measured
+        # is printed if the run ever stalls (all ranks arm the same timer).
+        import threading
+
+        def _stalled() -> None:
+            if "metric" in result:
+                result["stalled"] = "watchdog: the run did not finish within 900 s; partial line"
+                emit()
+            os._exit(0 if "metric" in result else 3)
+
+        _dog = threading.Timer(900.0, _stalled)
+        _dog.daemon = True
+        _dog.start()
+
     with torch.cuda.stream(stream):
         # ------------------------------------------------------------------ PageRank half
         if args.workload in ("both", "pagerank"):
@@ -164,45 +192,28 @@ def main() -> None:
                 f"local rows {gi.n_rows_local}, local edges {gi.n_edges_local}, max in-degree {gi.max_indeg}")
             n_topic = synth.topic_sizes(n, kt)
             d = 0.75                                   # start_crawl.go:175
-            pr = engine.PageRankState(g, d, -1.0, n_topic, max_iter=0)   # eps<0: fixed-iteration mode
-            exchange = sharding.DistExchange(pr, dev, host_staged=rehearsal) if world > 1 else None
-
-            def sweeps(m: int) -> None:
-                if world == 1:
-                    pr.step(m)
-                else:
-                    for _ in range(m):
-                        pr.step(1)
-                        exchange()
-                        pr.finalize()
-
-            pr.begin()
-            if world > 1:
-                exchange()
-                pr.finalize()
-            sweeps(max(W, 1))
-            barrier()
-            t0 = time.perf_counter()
-            sweeps(K)
-            barrier()
-            dt = max_over_ranks(time.perf_counter() - t0)
-            ms_step = dt * 1e3 / K
-            st = pr.status()
-            assert st["sweeps"] == max(W, 1) + K, st
-            kern_ms = None
-            if world == 1:
-                kern_ms = ctx.last_kernel_ms(0) / K     # HIP events on the library's stream around the K launches
             algo_bytes = 4 * e + 8 * n + 16 * kt * n    # 4E + 8N + 16*K*N per sweep
-            value = kt * K / dt
-            result.update({
-                "metric": "pagerank_iters_per_sec", "value": value, "unit": "topic-iterations/s",
-                "ms_per_step": ms_step,
-                "config": {"workload": f"R-MAT {n} nodes / {e} edges, {kt} topic vectors, d=0.75, fixed-iteration sweeps "
-                                       f"(BASELINE config 4 graph)", "nodes": n, "edges": e, "topics": kt,
-                           "sweeps_per_sec": K / dt,
-                           "parallelism": "single GPU" if world == 1 else f"doc-range shards x{world}, 1 RCCL all-gather/sweep"},
-            })
+            workload = (f"R-MAT {n} nodes / {e} edges, {kt} topic vectors, d=0.75, fixed-iteration sweeps "
+                        f"(BASELINE config 4 graph)")
+            pr = None
             if world == 1:
+                pr = engine.PageRankState(g, d, -1.0, n_topic, max_iter=0)   # eps<0: fixed-iteration mode
+                pr.begin()
+                pr.step(max(W, 1))
+                barrier()
+                t0 = time.perf_counter()
+                pr.step(K)
+                barrier()
+                dt = time.perf_counter() - t0
+                st = pr.status()
+                assert st["sweeps"] == max(W, 1) + K, st
+                kern_ms = ctx.last_kernel_ms(0) / K     # HIP events on the library's stream around the K launches
+                result.update({
+                    "metric": "pagerank_iters_per_sec", "value": kt * K / dt, "unit": "topic-iterations/s",
+                    "ms_per_step": dt * 1e3 / K,
+                    "config": {"workload": workload, "nodes": n, "edges": e, "topics": kt, "sweeps_per_sec": K / dt,
+                               "parallelism": "single GPU"},
+                })
                 ach = algo_bytes / (kern_ms * 1e-3) / 1e9
                 tr = profiled_traffic("k_pr_step") if (n, e, kt) == (10_000_000, 50_000_000, 16) else None
                 result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -212,15 +223,11 @@ def main() -> None:
                 if tr:
                     result["roofline"]["traffic_detail"] = tr
             else:
-                sp, sb, rp, rb = pr.exchange_buffers()
-                result["exchange"] = {"allgather_recv_bytes_per_sweep": rb, "send_bytes_per_rank": sb}
-                # Second decomposition, measured in the same run: the K topic vectors are independent power iterations
-                # (pagerank.go:54-63 loops over the categories), so they can also be split across the ranks with NO
-                # collective (every rank holds the 240 MB graph and runs K/N topics).  The doc-range split pays one
-                # all-gather of the contribution table per sweep (xGMI point-to-point: 1/N of the table per link), the
-                # topic split pays the narrower kernel; `value` is the faster of the two on this node, both are kept.
-                decomp = {"doc_range_shards": {"value": value, "unit": "topic-iterations/s", "ms_per_step": ms_step,
-                                               "parallelism": f"doc-range shards x{world}, 1 RCCL all-gather/sweep"}}
+                # Several GPUs: the fixed graph and K are measured in up to three decompositions (the third, pipelined one
+                # at the very end); `value` is the fastest on this node, all are kept under "decompositions".
+                decomp = {}
+                # (a) topic shards: the K topic vectors are independent power iterations (pagerank.go:54-63 loops over the
+                #     categories): K/N of them per rank on a full copy of the 240 MB graph, NO collective on the data path
                 if kt % world == 0:
                     g1 = engine.Graph(ctx, n, out_ptr, out_dst)
                     mine = n_topic[rank * (kt // world):(rank + 1) * (kt // world)]
@@ -236,28 +243,67 @@ def main() -> None:
                                               "parallelism": f"{kt // world} topics per rank x{world}, full graph per rank, no collective"}
                     pt.close()
                     g1.close()
+                # (b) doc-range shards: every rank sweeps its rows, ONE all-gather of the contribution slices per sweep
+                #     (xGMI point-to-point: 1/N of the table per link)
+                try:
+                    pr = engine.PageRankState(g, d, -1.0, n_topic, max_iter=0)
+                    exchange = sharding.DistExchange(pr, dev, host_staged=rehearsal)
+                    pr.begin()
+                    exchange()
+                    pr.finalize()
+
+                    def sweeps(m: int) -> None:
+                        for _ in range(m):
+                            pr.step(1)
+                            exchange()
+                            pr.finalize()
+
+                    sweeps(max(W, 1))
+                    barrier()
+                    t0 = time.perf_counter()
+                    sweeps(K)
+                    barrier()
+                    dt = max_over_ranks(time.perf_counter() - t0)
+                    st = pr.status()
+                    assert st["sweeps"] == max(W, 1) + K, st
+                    decomp["doc_range_shards"] = {"value": kt * K / dt, "unit": "topic-iterations/s", "ms_per_step": dt * 1e3 / K,
+                                                  "parallelism": f"doc-range shards x{world}, 1 RCCL all-gather/sweep"}
+                    sp, sb, rp, rb = pr.exchange_buffers()
+                    result["exchange"] = {"allgather_recv_bytes_per_sweep": rb, "send_bytes_per_rank": sb}
+                except Exception as exc:              # the topic-shard number must survive a failing collective
+                    result["doc_range_error"] = repr(exc)
+                if not decomp:
+                    raise SystemExit("no multi-GPU PageRank decomposition could be measured")
                 best = max(decomp, key=lambda name: decomp[name]["value"])
-                result["decompositions"] = decomp
-                result["value"] = decomp[best]["value"]
-                result["ms_per_step"] = decomp[best]["ms_per_step"]
-                result["config"]["parallelism"] = decomp[best]["parallelism"]
-                result["config"]["sweeps_per_sec"] = result["value"] / kt
+                result.update({
+                    "metric": "pagerank_iters_per_sec", "value": decomp[best]["value"], "unit": "topic-iterations/s",
+                    "ms_per_step": decomp[best]["ms_per_step"],
+                    "config": {"workload": workload, "nodes": n, "edges": e, "topics": kt,
+                               "sweeps_per_sec": decomp[best]["value"] / kt, "parallelism": decomp[best]["parallelism"]},
+                    "decompositions": decomp,
+                })
             # to-convergence run at the BASELINE eps (not timed into `value`)
-            prc = engine.PageRankState(g, d, 1e-6, n_topic)
-            exc = sharding.DistExchange(prc, dev, host_staged=rehearsal) if world > 1 else None
-            barrier()
-            t0 = time.perf_counter()
-            if world == 1:
-                prc.begin()
-                stc = prc.status()
-                while stc["n_active"] > 0:
-                    prc.step(4)
+            try:
+                prc = engine.PageRankState(g, d, 1e-6, n_topic)
+                exc = sharding.DistExchange(prc, dev, host_staged=rehearsal) if world > 1 else None
+                barrier()
+                t0 = time.perf_counter()
+                if world == 1:
+                    prc.begin()
                     stc = prc.status()
-            else:
-                stc = sharding.iterate([prc], exc, batch=4)
-            barrier()
-            result["config"]["to_convergence_eps1e-6"] = {"iters": [int(x) for x in stc["iters"]],
-                                                          "seconds": time.perf_counter() - t0}
+                    while stc["n_active"] > 0:
+                        prc.step(4)
+                        stc = prc.status()
+                else:
+                    stc = sharding.iterate([prc], exc, batch=4)
+                barrier()
+                result["config"]["to_convergence_eps1e-6"] = {"iters": [int(x) for x in stc["iters"]],
+                                                              "seconds": time.perf_counter() - t0}
+            except Exception as exc_:
+                if world == 1:
+                    raise
+                result["to_convergence_error"] = repr(exc_)
+                prc = None
             if world == 1 and args.workload == "both" and n == args.docs:
                 c4_ranks = prc.read()                   # [K][N] converged ranks: the prior of the blended top-k run (config 5)
             if world == 1:
@@ -285,7 +331,8 @@ def main() -> None:
                 torch.cuda.synchronize()
                 result["config"]["to_convergence_reference_eps1e-20"] = {"iters": [int(x) for x in sref["iters"]], "seconds": time.perf_counter() - t0}
                 pref.close()
-            prc.close()
+            if prc is not None:
+                prc.close()
 
             # ---- CPU baseline: the oracle's literal port on the same graph, bounded sample
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -328,7 +375,8 @@ def main() -> None:
                 result["cpu_baseline"]["gpu_vs_oracle_max_rel_err"] = err
                 assert err < 1e-6, err
                 del h_ptr, h_dst, ref
-            pr.close()
+            if pr is not None:
+                pr.close()
             g.close()
             if world == 1:
                 del out_ptr, out_dst
@@ -355,19 +403,23 @@ def main() -> None:
                 h_bdoc = b_doc.cpu().numpy().view(np.uint32)
                 h_tdoc = t_doc.cpu().numpy().view(np.uint32)
             shard = None
+            shard_error = None
             if world > 1:
-                # doc-range shard of the same index: this rank's slice of every posting list
-                lo, hi = sharding.doc_range(nd, rank, world)
-                sb_arr = sharding.shard_index_by_docs(b_ptr, b_doc, b_tf, lo, hi)
-                st_arr = sharding.shard_index_by_docs(t_ptr, t_doc, t_tf, lo, hi)
-                sbi = engine.InvertedIndex(ctx, hi - lo, *sb_arr)
-                sti = engine.InvertedIndex(ctx, hi - lo, *st_arr)
-                sti.set_doc_freq(sharding.global_doc_freq(st_arr[0]))      # one all-reduce of int64[T] per table
-                sbi.set_doc_freq(sharding.global_doc_freq(sb_arr[0]))
-                del sb_arr, st_arr
-                sti.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
-                sbi.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
-                shard = (sti, sbi, engine.Scorer(ctx, sti, sbi))
+                try:
+                    # doc-range shard of the same index: this rank's slice of every posting list
+                    lo, hi = sharding.doc_range(nd, rank, world)
+                    sb_arr = sharding.shard_index_by_docs(b_ptr, b_doc, b_tf, lo, hi)
+                    st_arr = sharding.shard_index_by_docs(t_ptr, t_doc, t_tf, lo, hi)
+                    sbi = engine.InvertedIndex(ctx, hi - lo, *sb_arr)
+                    sti = engine.InvertedIndex(ctx, hi - lo, *st_arr)
+                    sti.set_doc_freq(sharding.global_doc_freq(st_arr[0]))      # one all-reduce of int64[T] per table
+                    sbi.set_doc_freq(sharding.global_doc_freq(sb_arr[0]))
+                    del sb_arr, st_arr
+                    sti.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
+                    sbi.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
+                    shard = (sti, sbi, engine.Scorer(ctx, sti, sbi))
+                except Exception as exc_:
+                    shard, shard_error = None, repr(exc_)
             del b_ptr, b_doc, b_tf, t_ptr, t_doc, t_tf
             torch.cuda.empty_cache()
             wt, mt, _ = ti.tfidf_build(nd, want_w=keep_host, want_mag=keep_host, want_idf=False)   # title first (start_crawl.go:176)
@@ -460,22 +512,25 @@ def main() -> None:
 
             # ---- doc-range-sharded scoring (N>1): one batch replicated, local top-k, one all-gather, merge
             if shard is not None:
-                sti, sbi, ssc = shard
-                dsc = sharding.DocShardedScorer(ssc, ctx.merge_hits, nd, rank, world, device=dev, host_staged=rehearsal)
-                g_qptr, g_qterms = synth.make_queries(nq, 3, min(10_000, nt), seed=45)       # rank 0's batch on every rank
-                dg = (torch.from_numpy(g_qptr.view(np.int32)).to(dev), torch.from_numpy(g_qterms.view(np.int32)).to(dev))
-                m_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev)
-                m_n = torch.empty(nq, dtype=torch.int32, device=dev)
-                dts = timed_batches(lambda: dsc.score_topk(dg[0], dg[1], k, out=(m_hits, m_n)))
-                sc.score_topk(dg[0], dg[1], k, out=(d_hits, d_nhits))                         # the full replica, same batch
-                same_s = bool(torch.equal(m_hits, d_hits) and torch.equal(m_n, d_nhits))
-                topk["doc_sharded"] = {"value": nq * K / dts, "unit": "queries/s", "ms_per_step": dts * 1e3 / K, "scaling": "strong",
-                                       "parallelism": f"doc-range shards x{world}: batch replicated, local top-{k}, 1 all-gather of "
-                                                      f"{nq * k * 40} B/rank + merge", "matches_unsharded_replica": same_s}
-                assert same_s
-                ssc.close()
-                sti.close()
-                sbi.close()
+                try:
+                    sti, sbi, ssc = shard
+                    dsc = sharding.DocShardedScorer(ssc, ctx.merge_hits, nd, rank, world, device=dev, host_staged=rehearsal)
+                    g_qptr, g_qterms = synth.make_queries(nq, 3, min(10_000, nt), seed=45)       # rank 0's batch on every rank
+                    dg = (torch.from_numpy(g_qptr.view(np.int32)).to(dev), torch.from_numpy(g_qterms.view(np.int32)).to(dev))
+                    m_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev)
+                    m_n = torch.empty(nq, dtype=torch.int32, device=dev)
+                    dts = timed_batches(lambda: dsc.score_topk(dg[0], dg[1], k, out=(m_hits, m_n)))
+                    sc.score_topk(dg[0], dg[1], k, out=(d_hits, d_nhits))                         # the full replica, same batch
+                    same_s = bool(torch.equal(m_hits, d_hits) and torch.equal(m_n, d_nhits))
+                    topk["doc_sharded"] = {"value": nq * K / dts, "unit": "queries/s", "ms_per_step": dts * 1e3 / K, "scaling": "strong",
+                                           "parallelism": f"doc-range shards x{world}: batch replicated, local top-{k}, 1 all-gather of "
+                                                          f"{nq * k * 40} B/rank + merge", "matches_unsharded_replica": same_s}
+                    assert same_s
+                    ssc.close()
+                    sti.close()
+                    sbi.close()
+                except Exception as exc_:            # the replica number must survive a failing collective
+                    topk["doc_sharded_error"] = repr(exc_)
 
             if keep_host:
                 from oracle import pyoracle
@@ -502,6 +557,8 @@ def main() -> None:
                 same &= all(np.array_equal(hits["final"][q, :n_hits[q]], ref["final"][q, :ref_n[q]]) for q in range(ns))
                 topk["cpu_baseline"]["gpu_matches_oracle"] = bool(same)
                 assert same
+            if shard_error:
+                topk["doc_sharded_error"] = shard_error
             if result:
                 result["topk"] = topk
             else:
@@ -509,18 +566,6 @@ def main() -> None:
             sc.close()
             ti.close()
             bi.close()
-
-    def emit() -> None:
-        if rank != 0:
-            return
-        res = dict(result)
-        scaling = res.pop("scaling", "weak") if args.workload == "topk" else "strong"   # fixed graph: total work constant as N grows
-        out = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"),
-               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": res.pop("ms_per_step"),
-               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic"}
-        out.update(res)
-        print(json.dumps(out), flush=True)
 
     # ------------------------------------------------------------------ N>1, last: pipelined doc-range sweep
     # The doc-range split with its exchange hidden behind compute — two topic blocks of K/2, the all-gather of one
