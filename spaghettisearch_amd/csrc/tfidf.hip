@@ -8,6 +8,8 @@
 //   mag   = sqrt(mag2)                                                (:72)
 // HBM-bound: 12 B/posting (doc id, read w, write w) + 8 B per doc and term.
 #include "index.hpp"
+#include <cstdlib>
+#include <algorithm>
 
 #include <algorithm>
 #include <memory>
@@ -130,12 +132,151 @@ __global__ __launch_bounds__(TPB) void k_weight(const uint64_t* __restrict__ ter
     }
 }
 
+// ---- bucketed magnitude pass (large tables) -----------------------------------------------------------------
+// One float64 atomic per posting into a random 8-byte word of mag2 costs a memory-side read-modify-write each
+// (26 G/s on this part: 24.8 ms for the 641M-posting body table).  Instead the postings are partitioned once by
+// doc range ("bucket" = 2^shift consecutive docs) and every bucket is summed in LDS:
+//   k_weight_count   w = tf*idf in place, per-block LDS histogram of the buckets, one global add per touched bucket
+//   k_bucket_offsets exclusive scan of the <= 4096 bucket counts
+//   k_scatter        {doc, float32(w*w)} of every posting to its bucket's region (block claims a run per bucket,
+//                    LDS ticket per posting)
+//   k_bucket_sum     one workgroup per bucket: float64 LDS accumulators, sqrt, write mag
+// float32 squares summed in float64 are exact, so the order inside a bucket does not matter (same as the atomics).
+constexpr int NB_MAX = 4096;                 // most buckets (LDS histogram of a block)
+constexpr int PER_THREAD = CH / TPB;         // postings per thread and block
+
+__device__ __forceinline__ void chunk_term_range(const uint64_t* __restrict__ term_ptr, uint64_t n_terms, uint64_t base, uint64_t last,
+                                                 uint64_t* s_t) {
+    if (threadIdx.x < 2) {
+        const uint64_t target = threadIdx.x == 0 ? base : last;      // largest t with term_ptr[t] <= target
+        uint64_t lo = 0, hi = n_terms;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (term_ptr[mid] <= target) lo = mid; else hi = mid;
+        }
+        s_t[threadIdx.x] = lo;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_weight_count(const uint64_t* __restrict__ term_ptr, uint64_t n_terms,
+                                                      const uint32_t* __restrict__ post_doc, float* __restrict__ post_w,
+                                                      const float* __restrict__ idf, uint64_t n_post, int shift, uint32_t nb,
+                                                      uint32_t* __restrict__ cnt) {
+    __shared__ uint64_t s_t[2];
+    __shared__ uint32_t s_hist[NB_MAX];
+    const uint64_t base = (uint64_t)blockIdx.x * CH;
+    const uint64_t last = min(base + CH, n_post) - 1;
+    for (uint32_t b = threadIdx.x; b < nb; b += TPB) s_hist[b] = 0;
+    chunk_term_range(term_ptr, n_terms, base, last, s_t);
+    __syncthreads();
+    const uint64_t t_lo = s_t[0], t_hi = s_t[1];
+#pragma unroll 4
+    for (int j = 0; j < PER_THREAD; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        if (i >= n_post) break;
+        uint64_t lo = t_lo, hi = t_hi + 1;   // term_ptr[lo] <= i < term_ptr[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (term_ptr[mid] <= i) lo = mid; else hi = mid;
+        }
+        post_w[i] = post_w[i] * idf[lo];                              // term_weighting.go:42
+        atomicAdd(&s_hist[post_doc[i] >> shift], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += TPB)
+        if (s_hist[b]) atomicAdd(&cnt[b], s_hist[b]);
+}
+
+// off[b] = sum of cnt[< b] (off[nb] = total); cursor[b] = off[b].  One block, nb <= NB_MAX.
+__global__ __launch_bounds__(1024) void k_bucket_offsets(const uint32_t* __restrict__ cnt, uint32_t nb, uint32_t* __restrict__ off,
+                                                         uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t s[NB_MAX];
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nb + 1023) / 1024;                          // consecutive buckets per thread
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t b = threadIdx.x * per + j;
+        const uint32_t c = b < nb ? cnt[b] : 0;
+        if (b < nb) s[b] = sum;
+        sum += c;
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 1024; t++) { const uint32_t v = part[t]; part[t] = run; run += v; }
+        off[nb] = run;
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t b = threadIdx.x * per + j;
+        if (b < nb) { const uint32_t o = s[b] + part[threadIdx.x]; off[b] = o; cursor[b] = o; }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_scatter(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post,
+                                                 int shift, uint32_t nb, uint32_t* __restrict__ cursor, uint2* __restrict__ out) {
+    __shared__ uint32_t s_hist[NB_MAX];
+    __shared__ uint32_t s_base[NB_MAX];
+    const uint64_t base = (uint64_t)blockIdx.x * CH;
+    for (uint32_t b = threadIdx.x; b < nb; b += TPB) s_hist[b] = 0;
+    __syncthreads();
+    uint32_t doc[PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        doc[j] = 0xFFFFFFFFu;
+        if (i < n_post) {
+            doc[j] = post_doc[i];
+            atomicAdd(&s_hist[doc[j] >> shift], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += TPB) {
+        const uint32_t c = s_hist[b];
+        if (c) { s_base[b] = atomicAdd(&cursor[b], c); s_hist[b] = 0; }    // this block's run inside bucket b
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        if (doc[j] != 0xFFFFFFFFu) {
+            const uint32_t b = doc[j] >> shift;
+            const float w = post_w[i];
+            const float sq = w * w;                                    // term_weighting.go:44 (float32 product)
+            const uint32_t r = atomicAdd(&s_hist[b], 1u);
+            out[(uint64_t)s_base[b] + r] = make_uint2(doc[j], __float_as_uint(sq));
+        }
+    }
+}
+
+constexpr int TPB_B = 512;
+__global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ packed, const uint32_t* __restrict__ off, uint64_t n_docs,
+                                                      int shift, double* __restrict__ mag) {
+    extern __shared__ double acc[];                                    // [1 << shift]
+    const uint32_t bd = 1u << shift, b = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) acc[i] = 0.0;
+    __syncthreads();
+    const uint32_t lo = off[b], hi = off[b + 1];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += TPB_B) {
+        const uint2 r = packed[i];
+        atomicAdd(&acc[r.x & (bd - 1)], (double)__uint_as_float(r.y)); // :44 (float64 accumulate; LDS)
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) {
+        const uint64_t d = (uint64_t)b * bd + i;
+        if (d < n_docs) mag[d] = sqrt(acc[i]);                         // term_weighting.go:72
+    }
+}
+
 __global__ void k_sqrt(double* __restrict__ v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = sqrt(v[i]);                                     // term_weighting.go:72
 }
 
 }  // namespace
+
+static int s_bucket_lds = 0;
 
 extern "C" {
 
@@ -224,9 +365,37 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     SS_HIP(ctx, hipEventRecord(ctx->ev[2][0], st));
     if (T) hipLaunchKernelGGL(k_idf, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p,
                               idx->has_df_global ? idx->df_global.p : nullptr, T, (double)total_docs, idf.p);
-    if (P) hipLaunchKernelGGL(k_weight, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p,
-                              idx->post_w.p, idf.p, P, idx->mag.p);
-    hipLaunchKernelGGL(k_sqrt, dim3(ss::div_up(N, TPB)), dim3(TPB), 0, st, idx->mag.p, N);
+    // large tables: bucketed magnitude pass (no global float64 atomics); small ones: one atomic per posting
+    int shift = 13;                                                   // 8192 docs per bucket = 64 KB of float64 LDS accumulators
+    if ((N >> shift) >= (uint64_t)NB_MAX) shift = 14;
+    const uint64_t nb64 = ss::div_up(std::max<uint64_t>(N, 1), (uint64_t)1 << shift);
+    // SS_TFIDF_BUCKET_MIN (tests, A/B): smallest table that takes the bucketed pass; a huge value forces the atomics
+    uint64_t min_p = (uint64_t)1 << 22;
+    if (const char* e = std::getenv("SS_TFIDF_BUCKET_MIN")) min_p = std::strtoull(e, nullptr, 10);
+    const bool bucketed = P >= std::max<uint64_t>(min_p, 1) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
+    ss::DevBuf<uint32_t> b_cnt, b_off, b_cur;
+    ss::DevBuf<uint2> b_packed;
+    if (bucketed) {
+        const uint32_t nb = (uint32_t)nb64;
+        SS_HIP(ctx, b_cnt.alloc(nb));
+        SS_HIP(ctx, b_off.alloc(nb + 1));
+        SS_HIP(ctx, b_cur.alloc(nb));
+        SS_HIP(ctx, b_packed.alloc(P));
+        SS_HIP(ctx, hipMemsetAsync(b_cnt.p, 0, nb * sizeof(uint32_t), st));
+        if (s_bucket_lds < (1 << shift) * 8) {
+            SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
+            s_bucket_lds = (1 << shift) * 8;
+        }
+        hipLaunchKernelGGL(k_weight_count, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
+                           idf.p, P, shift, nb, b_cnt.p);
+        hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, b_cnt.p, nb, b_off.p, b_cur.p);
+        hipLaunchKernelGGL(k_scatter, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->post_doc.p, idx->post_w.p, P, shift, nb, b_cur.p, b_packed.p);
+        hipLaunchKernelGGL(k_bucket_sum, dim3(nb), dim3(TPB_B), (size_t)(1 << shift) * 8, st, b_packed.p, b_off.p, N, shift, idx->mag.p);
+    } else {
+        if (P) hipLaunchKernelGGL(k_weight, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p,
+                                  idx->post_w.p, idf.p, P, idx->mag.p);
+        hipLaunchKernelGGL(k_sqrt, dim3(ss::div_up(N, TPB)), dim3(TPB), 0, st, idx->mag.p, N);
+    }
     SS_HIP(ctx, hipEventRecord(ctx->ev[2][1], st));
     ctx->ev_valid[2] = true;
     SS_HIP(ctx, hipGetLastError());

@@ -72,3 +72,21 @@ def test_rejects_unsorted_and_out_of_range(ss_ctx):
     assert ei.value.code == 5                                 # duplicate doc inside a term
     with pytest.raises(SpaghettiError):
         engine.InvertedIndex(ss_ctx, 5, tp, np.array([0, 2, 9, 1, 3], dtype=np.uint32), np.ones(5, np.float32))
+
+
+@pytest.mark.parametrize("n_docs,n_terms,n_post,total", [(1, 1, 1, 1), (9000, 300, 120000, 9000), (70000, 5000, 900000, 80000),
+                                                          (20000, 40, 400000, 20000)])
+def test_bucketed_magnitude_pass(ss_ctx, oracle, monkeypatch, n_docs, n_terms, n_post, total):
+    # large tables sum the squares per doc-range bucket in LDS instead of one global float64 atomic per posting;
+    # SS_TFIDF_BUCKET_MIN=1 sends these small tables down that path (several buckets, a partial last bucket, one doc)
+    from spaghettisearch_amd import engine
+    tp, pd, tf = synth.zipf_index(n_docs, n_terms, min(n_post, n_docs * n_terms // 2 + 1), seed=n_docs)
+    w_ref, mag_ref, idf_ref = oracle.tfidf(tp, pd, tf, total, n_docs)
+    for knob in ("1", str(1 << 62)):                                  # bucketed, then the atomic pass: same bits
+        monkeypatch.setenv("SS_TFIDF_BUCKET_MIN", knob)
+        ix = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
+        w, mag, idf = ix.tfidf_build(total)
+        ix.close()
+        assert np.array_equal(w.view(np.uint32), w_ref.view(np.uint32))
+        assert np.array_equal(idf.view(np.uint32), idf_ref.view(np.uint32))
+        assert np.array_equal(mag, mag_ref)
