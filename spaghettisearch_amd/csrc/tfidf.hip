@@ -214,17 +214,22 @@ __global__ __launch_bounds__(1024) void k_bucket_offsets(const uint32_t* __restr
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_scatter(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post,
+#ifndef SS_SC_TPB
+#define SS_SC_TPB 1024
+#endif
+constexpr int SC_TPB = SS_SC_TPB;             // bigger blocks: longer runs per bucket where short lists spread a block over many buckets
+constexpr int SC_CH = SC_TPB * PER_THREAD;
+__global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post,
                                                  int shift, uint32_t nb, uint32_t* __restrict__ cursor, uint2* __restrict__ out) {
     __shared__ uint32_t s_hist[NB_MAX];
     __shared__ uint32_t s_base[NB_MAX];
-    const uint64_t base = (uint64_t)blockIdx.x * CH;
-    for (uint32_t b = threadIdx.x; b < nb; b += TPB) s_hist[b] = 0;
+    const uint64_t base = (uint64_t)blockIdx.x * SC_CH;
+    for (uint32_t b = threadIdx.x; b < nb; b += SC_TPB) s_hist[b] = 0;
     __syncthreads();
     uint32_t doc[PER_THREAD];
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++) {
-        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        const uint64_t i = base + (uint64_t)j * SC_TPB + threadIdx.x;
         doc[j] = 0xFFFFFFFFu;
         if (i < n_post) {
             doc[j] = post_doc[i];
@@ -232,14 +237,14 @@ __global__ __launch_bounds__(TPB) void k_scatter(const uint32_t* __restrict__ po
         }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += TPB) {
+    for (uint32_t b = threadIdx.x; b < nb; b += SC_TPB) {
         const uint32_t c = s_hist[b];
         if (c) { s_base[b] = atomicAdd(&cursor[b], c); s_hist[b] = 0; }    // this block's run inside bucket b
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++) {
-        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        const uint64_t i = base + (uint64_t)j * SC_TPB + threadIdx.x;
         if (doc[j] != 0xFFFFFFFFu) {
             const uint32_t b = doc[j] >> shift;
             const float w = post_w[i];
@@ -389,7 +394,7 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
         hipLaunchKernelGGL(k_weight_count, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
                            idf.p, P, shift, nb, b_cnt.p);
         hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, b_cnt.p, nb, b_off.p, b_cur.p);
-        hipLaunchKernelGGL(k_scatter, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->post_doc.p, idx->post_w.p, P, shift, nb, b_cur.p, b_packed.p);
+        hipLaunchKernelGGL(k_scatter, dim3(ss::div_up(P, SC_CH)), dim3(SC_TPB), 0, st, idx->post_doc.p, idx->post_w.p, P, shift, nb, b_cur.p, b_packed.p);
         hipLaunchKernelGGL(k_bucket_sum, dim3(nb), dim3(TPB_B), (size_t)(1 << shift) * 8, st, b_packed.p, b_off.p, N, shift, idx->mag.p);
     } else {
         if (P) hipLaunchKernelGGL(k_weight, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p,
