@@ -31,6 +31,7 @@ struct ss_ctx {
     bool ev_valid[3] = {false, false, false};
     int cu_count = 256;
     size_t total_mem = 0;
+    int tfidf_bucket_lds = 0;          // dynamic LDS size already granted to k_bucket_sum on this device
 
     int32_t fail(int32_t code, const char* fmt, ...) {
         char buf[1024];

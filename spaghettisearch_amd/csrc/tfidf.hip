@@ -281,8 +281,6 @@ __global__ void k_sqrt(double* __restrict__ v, uint64_t n) {
 
 }  // namespace
 
-static int s_bucket_lds = 0;
-
 extern "C" {
 
 int32_t ss_index_create(ss_ctx* ctx, uint64_t n_docs, uint64_t n_terms, const uint64_t* term_ptr,
@@ -387,9 +385,9 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
         SS_HIP(ctx, b_cur.alloc(nb));
         SS_HIP(ctx, b_packed.alloc(P));
         SS_HIP(ctx, hipMemsetAsync(b_cnt.p, 0, nb * sizeof(uint32_t), st));
-        if (s_bucket_lds < (1 << shift) * 8) {
+        if (ctx->tfidf_bucket_lds < (1 << shift) * 8) {
             SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
-            s_bucket_lds = (1 << shift) * 8;
+            ctx->tfidf_bucket_lds = (1 << shift) * 8;
         }
         hipLaunchKernelGGL(k_weight_count, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
                            idf.p, P, shift, nb, b_cnt.p);
