@@ -186,7 +186,10 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank);
  * count); topic_probs [n_q][k_topics] or NULL (nil map => sqd = 0,
  * main_retrieve.go:88).  hits_out [n_q][k], n_hits_out [n_q] (host or device).
  * Order: FinalRank descending (util.go:48-54), ties ascending doc id, NaN last;
- * reference k = 50 (main_retrieve.go:99-100). */
+ * reference k = 50 (main_retrieve.go:99-100). 
+ * Results in HOST memory: the call returns when they are there.  Results in DEVICE memory (both
+ * pointers): the kernels write them directly and the call returns once the work is enqueued on the
+ * ctx stream — later work on that stream sees them; ss_synchronize waits for them. */
 int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
                       const int32_t* query_len, const double* topic_probs, int32_t k,
                       ss_hit* hits_out, int32_t* n_hits_out);

@@ -923,8 +923,13 @@ struct ss_scorer {
     int lds_attr = 0;
     // per-call workspaces, grow-only (no hipMalloc/hipFree on the steady-state query path)
     ss::DevBuf<unsigned char> d_plan;
-    unsigned char* h_plan = nullptr;            // pinned staging for the plan
-    size_t h_plan_cap = 0;
+    // pinned staging for the plan, double-buffered: a call that returns results in device memory does not wait
+    // for the GPU, so the next call plans (and fills the other buffer) while this one's copy and kernels run
+    unsigned char* h_plan[2] = {nullptr, nullptr};
+    size_t h_plan_cap[2] = {0, 0};
+    hipEvent_t plan_ev[2] = {nullptr, nullptr}; // recorded after the H2D copy of the buffer
+    bool plan_ev_pending[2] = {false, false};
+    int plan_turn = 0;
     ss::DevBuf<double> d_probs;
     ss::DevBuf<Post> d_x[4];                    // phrase result lists
     ss::DevBuf<uint32_t> d_xcnt;
@@ -933,7 +938,10 @@ struct ss_scorer {
     ss::DevBuf<ss_hit> d_hits;
     ss::DevBuf<int32_t> d_nhits;
     ~ss_scorer() {
-        if (h_plan) (void)hipHostFree(h_plan);
+        for (int i = 0; i < 2; i++) {
+            if (h_plan[i]) (void)hipHostFree(h_plan[i]);
+            if (plan_ev[i]) (void)hipEventDestroy(plan_ev[i]);
+        }
     }
 };
 
@@ -1219,15 +1227,22 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     const size_t o_pdrv = o;   o = align16(o + n_q * sizeof(uint32_t));
     const size_t o_xoff = o;   o = align16(o + (n_q + 1) * sizeof(uint32_t));
     const size_t plan_bytes = o;
-    if (s->h_plan_cap < plan_bytes) {
-        if (s->h_plan) (void)hipHostFree(s->h_plan);
-        s->h_plan = nullptr;
-        s->h_plan_cap = 0;
-        SS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_plan), plan_bytes * 2, hipHostMallocDefault));
-        s->h_plan_cap = plan_bytes * 2;
+    const int pb = s->plan_turn;
+    s->plan_turn ^= 1;
+    if (!s->plan_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->plan_ev[pb], hipEventDisableTiming));
+    if (s->plan_ev_pending[pb]) {                // the copy that last read this buffer (two calls ago) must be over
+        SS_HIP(ctx, hipEventSynchronize(s->plan_ev[pb]));
+        s->plan_ev_pending[pb] = false;
+    }
+    if (s->h_plan_cap[pb] < plan_bytes) {
+        if (s->h_plan[pb]) (void)hipHostFree(s->h_plan[pb]);
+        s->h_plan[pb] = nullptr;
+        s->h_plan_cap[pb] = 0;
+        SS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_plan[pb]), plan_bytes * 2, hipHostMallocDefault));
+        s->h_plan_cap[pb] = plan_bytes * 2;
     }
     SS_HIP(ctx, ensure(s->d_plan, plan_bytes));
-    unsigned char* hp = s->h_plan;
+    unsigned char* hp = s->h_plan[pb];
     std::memcpy(hp + o_qoff, h_qoff.data(), (n_q + 1) * sizeof(uint32_t));
     if (n_d) {
         std::memcpy(hp + o_dterm, h_dterm.data(), n_d * sizeof(uint32_t));
@@ -1243,6 +1258,8 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     std::memcpy(hp + o_pdrv, h_pdrv.data(), n_q * sizeof(uint32_t));
     std::memcpy(hp + o_xoff, h_xoff.data(), (n_q + 1) * sizeof(uint32_t));
     SS_HIP(ctx, hipMemcpyAsync(s->d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, st));
+    SS_HIP(ctx, hipEventRecord(s->plan_ev[pb], st));
+    s->plan_ev_pending[pb] = true;
     if (any_phrase) {
         for (int x = 0; x < 4; x++) SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
         SS_HIP(ctx, ensure(s->d_xcnt, (size_t)n_q * 4));
@@ -1285,7 +1302,17 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     p.k = k;
     p.cb = cb;
     p.so_key = s->d_so_key.p; p.so_doc = s->d_so_doc.p; p.so_cnt = s->d_so_cnt.p;
-    p.hits = s->d_hits.p; p.n_hits = s->d_nhits.p;
+    // results straight into the caller's buffers when both live in device memory (then the call does not wait either)
+    bool dev_out = false;
+    {
+        hipPointerAttribute_t a1{}, a2{};
+        const bool d1 = hipPointerGetAttributes(&a1, hits_out) == hipSuccess && a1.type == hipMemoryTypeDevice;
+        const bool d2 = hipPointerGetAttributes(&a2, n_hits_out) == hipSuccess && a2.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();                 // plain host memory is reported as an error: not one
+        dev_out = d1 && d2;
+    }
+    p.hits = dev_out ? hits_out : s->d_hits.p;
+    p.n_hits = dev_out ? n_hits_out : s->d_nhits.p;
 
     const size_t lds_score = score_lds_bytes(cb), lds_merge = merge_lds_bytes(k, cb);
     if (s->lds_attr < cb) {
@@ -1301,9 +1328,10 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
     ctx->ev_valid[1] = true;
     SS_HIP(ctx, hipGetLastError());
+    if (dev_out) return SS_OK;                   // ordered on the ctx stream; ss_synchronize (or the stream's owner) waits
     SS_HIP(ctx, hipMemcpyAsync(hits_out, s->d_hits.p, (size_t)n_q * k * sizeof(ss_hit), hipMemcpyDefault, st));
     SS_HIP(ctx, hipMemcpyAsync(n_hits_out, s->d_nhits.p, n_q * sizeof(int32_t), hipMemcpyDefault, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));   // the pinned plan buffer is reused by the next call
+    SS_HIP(ctx, hipStreamSynchronize(st));
     return SS_OK;
 }
 

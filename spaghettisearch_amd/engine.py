@@ -311,6 +311,10 @@ class Scorer:
                 raise ValueError("output buffers too small")
             check(self.ctx.lib.ss_score_topk(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(query_len), _ptr(topic_probs), k,
                                              _ptr(hits), _ptr(n_hits)), self.ctx.h)
+            # device outputs: the library only enqueues (results are ordered on the context's stream).  On a stream shared
+            # with the caller that is all that is needed; on the context's own stream wait here.
+            if not getattr(self.ctx, "_shared_stream", False):
+                self.ctx.synchronize()
             return hits, n_hits
         hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
         n_hits = np.zeros(n_q, dtype=np.int32)
