@@ -69,6 +69,53 @@ double orc_go_log2(double x)
     return orc_go_log(frac) * InvLn2 + (double)e;
 }
 
+/* Oracle hardening (no reference line: a check ON the restatement above).
+ * term_weighting.go:37 narrows math.Log2(total/df) to float32.  go1.12/amd64 dispatches
+ * math.Log to log_amd64.s, a hand transcription of the same FreeBSD algorithm as log.go;
+ * whether or not the two agree to the last bit, the float32 idf is the same for every
+ * input whose float64 log2 is not within a couple of ulps of a float32 rounding boundary.
+ * For df in [df_lo, df_hi] and x = total_docs/df (rounded to float64 as Go does) this counts
+ *   out[0]  float32(orc_go_log2(x)) != float32(log2 correctly rounded, via 80-bit log2l)
+ *   out[1]  orc_go_log2(x) within `margin_ulps` x (ulp(result) + ulp(Log(frac))/Ln2) of a float32 rounding boundary
+ *           ("sensitive": a last-ulp difference between two libm paths could flip the idf)
+ *   out[2]  the long double value itself too close to a boundary to decide (2^-58 relative)
+ *   out[3]  max |orc_go_log2 - log2l| in float64 ulps, rounded up
+ * first_bad_df (nullable): the first df counted in out[0] or out[1], 0 if none. */
+int orc_log2_sensitivity(double total_docs, uint64_t df_lo, uint64_t df_hi, double margin_ulps,
+                         uint64_t out[4], uint64_t* first_bad_df)
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (first_bad_df) *first_bad_df = 0;
+    for (uint64_t df = df_lo; df <= df_hi && df != 0; df++) {
+        const double x = total_docs / (double)df;                 /* term_weighting.go:37 argument */
+        const double y = orc_go_log2(x);
+        const long double yl = log2l((long double)x);
+        const float f = (float)y;
+        const float fl = (float)yl;
+        int bad = 0;
+        if (!(f == fl) && !(isnan(f) && isnan(fl))) { out[0]++; bad = 1; }
+        if (isfinite(y) && y != 0.0) {
+            const double ulp = fabs(nextafter(y, INFINITY) - y);
+            /* Log2 = Log(frac)*(1/Ln2) + exp cancels for x near a power of two: a last-ulp difference in
+             * Log(frac) reaches y as an ABSOLUTE error of ulp(Log(frac))/Ln2, however small y is */
+            int e2;
+            const double lg = fabs(orc_go_log(frexp(x, &e2)));
+            const double ulp_in = (nextafter(lg, INFINITY) - lg) * 1.4426950408889634;
+            const double up = ((double)f + (double)nextafterf(f, INFINITY)) * 0.5;
+            const double dn = ((double)f + (double)nextafterf(f, -INFINITY)) * 0.5;
+            const double dist = fmin(fabs(y - up), fabs(y - dn));
+            if (dist <= margin_ulps * (ulp + ulp_in)) { out[1]++; bad = 1; }
+            const long double distl = fminl(fabsl(yl - (long double)up), fabsl(yl - (long double)dn));
+            if (distl <= fabsl(yl) * 0x1p-58L) out[2]++;
+            const long double err = fabsl((long double)y - yl) / (long double)ulp;
+            const uint64_t e = (uint64_t)ceill(err);
+            if (e > out[3]) out[3] = e;
+        }
+        if (bad && first_bad_df && *first_bad_df == 0) *first_bad_df = df;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* PageRank — ranking/pagerank.go:85-145                                      */
 /* ------------------------------------------------------------------------- */

@@ -40,6 +40,11 @@ typedef struct orc_hit {
  * src/math/log10.go).  Used by term_weighting.go:37. */
 double orc_go_log(double x);
 double orc_go_log2(double x);
+/* Sensitivity of float32(orc_go_log2(total_docs/df)) to last-ulp differences between libm
+ * implementations (see oracle.c); out[0..3] = mismatches vs correctly rounded, sensitive inputs,
+ * undecidable inputs, max ulp error. */
+int orc_log2_sensitivity(double total_docs, uint64_t df_lo, uint64_t df_hi, double margin_ulps,
+                         uint64_t out[4], uint64_t* first_bad_df);
 
 /*
  * ranking/pagerank.go:85-145 (updatePagerank + computeRankInherited) for ONE

@@ -65,6 +65,18 @@ def go_log(x: float) -> float:
     return lib().orc_go_log(float(x))
 
 
+def log2_sensitivity(total_docs: float, df_lo: int, df_hi: int, margin_ulps: float = 2.0):
+    """orc_log2_sensitivity -> dict(mismatch, sensitive, undecidable, max_ulp_err, first_bad_df)."""
+    out = (C.c_uint64 * 4)()
+    bad = C.c_uint64(0)
+    fn = lib().orc_log2_sensitivity
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64 * 4, C.POINTER(C.c_uint64)]
+    fn(float(total_docs), int(df_lo), int(df_hi), float(margin_ulps), out, C.byref(bad))
+    return {"mismatch": int(out[0]), "sensitive": int(out[1]), "undecidable": int(out[2]), "max_ulp_err": int(out[3]),
+            "first_bad_df": int(bad.value)}
+
+
 def pagerank(n_nodes, out_ptr, out_dst, d, eps, n_topic, max_iter=0, hashed=False):
     """-> (rank [K][N] float64, iters [K] int32)"""
     out_ptr = _c(out_ptr, np.uint64)
