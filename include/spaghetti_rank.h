@@ -146,6 +146,13 @@ int32_t ss_pr_read_local(ss_pr* pr, uint32_t* ids_out, double* rank_out);
 /* world==1 only: rank_out[k_topics][n_nodes] in original id order. */
 int32_t ss_pr_read(ss_pr* pr, double* rank_out);
 
+/* Diagnostic (bench.py roofline.gather_ceiling_ms; no reference counterpart): average milliseconds of a gather-ONLY
+ * pass over this state's in-edge stream and contribution table with the sweep's own load shape — what the access
+ * pattern of computeRankInherited (pagerank.go:126-145) costs on this chip with every other part of the sweep
+ * removed.  mode 0 = the graph's index stream, 1 = uniformly random rows (no hub reuse), 2 = consecutive rows.
+ * k_topics >= 5 only. */
+int32_t ss_pr_probe(ss_pr* pr, int32_t mode, int32_t n_reps, float* ms_out);
+
 /* ---- inverted index + TF-IDF: ranking/term_weighting.go:10-123 --------- */
 /* One inverted table (inv[0] title or inv[1] body), term-major CSR over dense
  * term/doc ids; post_tf = listPos[0] (normalised tf, indexer.go:362).  Each

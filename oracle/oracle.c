@@ -572,6 +572,169 @@ int orc_score_topk_batch(uint64_t n_docs, uint64_t n_terms,
     return rc;
 }
 
+/* --- "reference-shaped" scoring (CPU baseline only) ------------------------------------- */
+/* The same arithmetic as score_one, but with the reference's data structures: documents are keyed by their  */
+/* 32-character hex docHash in hash maps (aggregatedDocs map[string]Rank_term, main_retrieve.go:61-69; the    */
+/* magnitudes behind forw[4].Get(docHash), get_metadata.go:46-50), the per-document weight slices are         */
+/* appended then summed (main_retrieve.go:64-66,176-182), and the result list is built by appendSort          */
+/* (util.go:48-54): binary search + memmove of Rank_combined-sized rows (util.go:25-36: 152 bytes), cut to    */
+/* k at the end (main_retrieve.go:99-103).  Ties stay in arrival order as in the reference (here: map order), */
+/* so only the FinalRank sequence — not the order of equal-score docs — is comparable with orc_score_topk.   */
+
+typedef struct { char key[32]; double title, body; uint8_t used; } mag_slot;      /* forw[4] row */
+struct orc_magmap { mag_slot* s; uint64_t mask; };
+
+orc_magmap* orc_magmap_build(uint64_t n_docs, const double* mag_title, const double* mag_body)
+{
+    orc_magmap* m = (orc_magmap*)calloc(1, sizeof(orc_magmap));
+    if (!m) return NULL;
+    uint64_t cap = 16;
+    while (cap < n_docs * 2) cap <<= 1;
+    m->s = (mag_slot*)calloc(cap, sizeof(mag_slot));
+    if (!m->s) { free(m); return NULL; }
+    m->mask = cap - 1;
+    char key[32];
+    for (uint64_t d = 0; d < n_docs; d++) {
+        id_to_key((uint32_t)d, key);
+        uint64_t i = hm_hash(key) & m->mask;
+        while (m->s[i].used) i = (i + 1) & m->mask;
+        memcpy(m->s[i].key, key, 32);
+        m->s[i].title = mag_title[d];
+        m->s[i].body = mag_body[d];
+        m->s[i].used = 1;
+    }
+    return m;
+}
+void orc_magmap_free(orc_magmap* m) { if (m) { free(m->s); free(m); } }
+static const mag_slot* magmap_get(const orc_magmap* m, const char* key)
+{
+    uint64_t i = hm_hash(key) & m->mask;
+    for (;;) {
+        const mag_slot* s = &m->s[i];
+        if (!s->used) return NULL;                                   /* missing key: zero values (Q8) */
+        if (memcmp(s->key, key, 32) == 0) return s;
+        i = (i + 1) & m->mask;
+    }
+}
+
+#define AGG_INLINE 6
+typedef struct {
+    char key[32];
+    uint32_t doc;                      /* carried for the output row only; never used as a key */
+    uint16_t nt, nb;
+    float tw[AGG_INLINE], bw[AGG_INLINE];   /* TitleWeights / BodyWeights (appended, util.go:11-17) */
+    double t_run, b_run;               /* weights beyond the inline capacity, folded in arrival order */
+    uint8_t used;
+} agg_slot;
+typedef struct { unsigned char bytes[152 - 16]; uint32_t doc; uint32_t pad; double final; } ref_row;   /* sizeof(Rank_combined) */
+
+static int score_one_hashed(const orc_magmap* mags, uint64_t n_terms,
+                            const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+                            const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+                            const uint32_t* q_terms, int32_t n_q_terms, int32_t query_len,
+                            int32_t k, orc_hit* hits, int32_t* n_hits)
+{
+    uint64_t tot = 0;
+    for (int32_t i = 0; i < n_q_terms; i++) {
+        const uint32_t t = q_terms[i];
+        if ((uint64_t)t >= n_terms) continue;
+        tot += (b_ptr[t + 1] - b_ptr[t]) + (t_ptr[t + 1] - t_ptr[t]);
+    }
+    uint64_t cap = 16;
+    while (cap < tot * 2) cap <<= 1;
+    agg_slot* agg = (agg_slot*)calloc(cap, sizeof(agg_slot));        /* aggregatedDocs (main_retrieve.go:60) */
+    if (!agg) return -1;
+    const uint64_t mask = cap - 1;
+    uint64_t n_cand = 0;
+    char key[32];
+    for (int32_t i = 0; i < n_q_terms; i++) {                        /* one getFromInverted result per token (:55-69) */
+        const uint32_t t = q_terms[i];
+        if ((uint64_t)t >= n_terms) continue;
+        for (int field = 0; field < 2; field++) {                    /* body postings (:226-232), then title (:234-239) */
+            const uint64_t* ptr = field ? t_ptr : b_ptr;
+            const uint32_t* docs = field ? t_doc : b_doc;
+            const float* ws = field ? t_w : b_w;
+            for (uint64_t p = ptr[t]; p < ptr[t + 1]; p++) {
+                id_to_key(docs[p], key);
+                uint64_t h = hm_hash(key) & mask;
+                agg_slot* a;
+                for (;;) {
+                    a = &agg[h];
+                    if (!a->used) { memcpy(a->key, key, 32); a->used = 1; a->doc = docs[p]; n_cand++; break; }
+                    if (memcmp(a->key, key, 32) == 0) break;
+                    h = (h + 1) & mask;
+                }
+                if (field) { if (a->nt < AGG_INLINE) a->tw[a->nt++] = ws[p]; else a->t_run += (double)ws[p]; }
+                else       { if (a->nb < AGG_INLINE) a->bw[a->nb++] = ws[p]; else a->b_run += (double)ws[p]; }
+            }
+        }
+    }
+    ref_row* res = (ref_row*)malloc(sizeof(ref_row) * (n_cand ? n_cand : 1));   /* finalResult (:93) */
+    if (!res) { free(agg); return -1; }
+    uint64_t n_res = 0;
+    const double qmag = sqrt((double)query_len);                     /* get_metadata.go:53 */
+    for (uint64_t s = 0; s < cap; s++) {                             /* range aggregatedDocs: map order */
+        const agg_slot* a = &agg[s];
+        if (!a->used) continue;
+        double title = 0.0, body = 0.0;                              /* genAggrDocsPipeline :176-182 */
+        for (int i = 0; i < a->nt; i++) title += (double)a->tw[i];
+        title += a->t_run;      /* exact either way: float32 addends in float64 */
+        for (int i = 0; i < a->nb; i++) body += (double)a->bw[i];
+        body += a->b_run;
+        const mag_slot* m = magmap_get(mags, a->key);                /* forw[4].Get(docHash), get_metadata.go:46-50 */
+        body /= ((m ? m->body : 0.0) * qmag);                        /* :57 */
+        title /= ((m ? m->title : 0.0) * qmag);                      /* :58 */
+        if (isnan(body)) body = 0;                                   /* :61-63 */
+        if (isnan(title)) title = 0;                                 /* :64-66 */
+        ref_row el;
+        memset(&el, 0, sizeof(el));
+        el.doc = a->doc;
+        el.final = (0.33 * 0.0 + 0.38 * title + 0.29 * body) * 100.0; /* :69, topicProbs nil => sqd = 0 (main_retrieve.go:88) */
+        /* appendSort, util.go:48-54: first index whose FinalRank < el.FinalRank, shift the tail, insert */
+        uint64_t lo = 0, hi = n_res;
+        while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (!(res[mid].final < el.final)) lo = mid + 1; else hi = mid; }
+        memmove(&res[lo + 1], &res[lo], sizeof(ref_row) * (n_res - lo));
+        res[lo] = el;
+        n_res++;
+    }
+    const uint64_t nh = n_res < (uint64_t)k ? n_res : (uint64_t)k;   /* main_retrieve.go:99-103 */
+    for (uint64_t i = 0; i < nh; i++) {
+        memset(&hits[i], 0, sizeof(orc_hit));
+        hits[i].doc = res[i].doc;
+        hits[i].final = res[i].final;
+    }
+    *n_hits = (int32_t)nh;
+    free(res);
+    free(agg);
+    return 0;
+}
+
+int orc_score_topk_batch_hashed(const orc_magmap* mags, uint64_t n_terms,
+                                const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+                                const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+                                int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const int32_t* query_len,
+                                int32_t k, int32_t use_threads, orc_hit* hits, int32_t* n_hits, int32_t* threads_used)
+{
+    int rc_all = 0;
+    int nthreads = 1;
+#ifdef _OPENMP
+    if (use_threads) nthreads = omp_get_max_threads();
+    if (nthreads > n_q) nthreads = n_q > 0 ? n_q : 1;
+#endif
+    if (threads_used) *threads_used = nthreads;
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int32_t q = 0; q < n_q; q++) {
+        const int32_t nt = (int32_t)(q_ptr[q + 1] - q_ptr[q]);
+        const int rc = score_one_hashed(mags, n_terms, t_ptr, t_doc, t_w, b_ptr, b_doc, b_w, q_terms + q_ptr[q], nt,
+                                        query_len ? query_len[q] : nt, k, hits + (uint64_t)q * k, n_hits + q);
+        if (rc) {
+            #pragma omp critical
+            rc_all = rc;
+        }
+    }
+    return rc_all;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Phrase search — retrieval/phrase.go:11-170, util.go:162-203                 */
 /* ------------------------------------------------------------------------- */

@@ -136,6 +136,20 @@ int orc_score_topk_batch(uint64_t n_docs, uint64_t n_terms,
                          int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
                          const int32_t* query_len, int32_t k, orc_hit* hits, int32_t* n_hits);
 
+/* "Reference-shaped" scoring baseline: main_retrieve.go:61-97 + get_metadata.go:46-69 +
+ * util.go:48-54 with the reference's data structures — string-keyed hash maps, appended weight slices,
+ * insertion-sort appendSort of Rank_combined-sized rows.  No PageRank blend (topicProbs is nil in the reference,
+ * main_retrieve.go:88).  hits[].doc/.final only; equal finals in map order (not comparable with orc_score_topk).
+ * orc_magmap = forw[4] as a docHash-keyed map, built once outside the timed region. */
+typedef struct orc_magmap orc_magmap;
+orc_magmap* orc_magmap_build(uint64_t n_docs, const double* mag_title, const double* mag_body);
+void orc_magmap_free(orc_magmap* m);
+int orc_score_topk_batch_hashed(const orc_magmap* mags, uint64_t n_terms,
+                                const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
+                                const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
+                                int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const int32_t* query_len,
+                                int32_t k, int32_t use_threads, orc_hit* hits, int32_t* n_hits, int32_t* threads_used);
+
 /*
  * retrieval/phrase.go:11-170 + util.go:162-203 for one phrase (all quoted
  * phrases of a query are concatenated into ONE phrase, main_retrieve.go:26).

@@ -192,6 +192,51 @@ def score_topk_batch(n_docs, title, body, mag_title, mag_body, q_ptr, q_terms, k
     return hits, n_hits
 
 
+class MagMap:
+    """forw[4] as a docHash-keyed hash map (orc_magmap) for the reference-shaped scoring baseline."""
+
+    def __init__(self, mag_title, mag_body):
+        mag_title = _c(mag_title, np.float64)
+        mag_body = _c(mag_body, np.float64)
+        fn = lib().orc_magmap_build
+        fn.restype = C.c_void_p
+        fn.argtypes = [C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        self.h = fn(len(mag_title), _p(mag_title, C.c_double), _p(mag_body, C.c_double))
+        if not self.h:
+            raise MemoryError("orc_magmap_build")
+
+    def close(self):
+        if self.h:
+            fn = lib().orc_magmap_free
+            fn.restype = None
+            fn.argtypes = [C.c_void_p]
+            fn(self.h)
+            self.h = None
+
+
+def score_topk_batch_hashed(magmap: MagMap, title, body, q_ptr, q_terms, k, query_len=None, threads=False):
+    """Reference-shaped baseline (B1).  -> (hits [n_q][k] (doc, final only), n_hits, threads_used)"""
+    t_ptr, t_doc, t_w = _c(title[0], np.uint64), _c(title[1], np.uint32), _c(title[2], np.float32)
+    b_ptr, b_doc, b_w = _c(body[0], np.uint64), _c(body[1], np.uint32), _c(body[2], np.float32)
+    q_ptr = _c(q_ptr, np.uint32)
+    q_terms = _c(q_terms, np.uint32)
+    query_len = _c(query_len, np.int32)
+    n_q = len(q_ptr) - 1
+    hits = np.zeros((n_q, k), dtype=HIT_DTYPE)
+    n_hits = np.zeros(n_q, dtype=np.int32)
+    th = C.c_int32(0)
+    fn = lib().orc_score_topk_batch_hashed
+    fn.restype = C.c_int
+    fn.argtypes = None
+    rc = fn(C.c_void_p(magmap.h), C.c_uint64(len(b_ptr) - 1), _p(t_ptr, C.c_uint64), _p(t_doc, C.c_uint32), _p(t_w, C.c_float),
+            _p(b_ptr, C.c_uint64), _p(b_doc, C.c_uint32), _p(b_w, C.c_float), C.c_int32(n_q), _p(q_ptr, C.c_uint32),
+            _p(q_terms, C.c_uint32), _p(query_len, C.c_int32), C.c_int32(k), C.c_int32(1 if threads else 0),
+            hits.ctypes.data_as(C.POINTER(OrcHit)), _p(n_hits, C.c_int32), C.byref(th))
+    if rc:
+        raise RuntimeError(f"orc_score_topk_batch_hashed rc={rc}")
+    return hits, n_hits, th.value
+
+
 def score_topk(n_docs, title, body, mag_title, mag_body, q_terms, k, query_len=None,
                prior=None, topic_probs=None, extra=None):
     """Single query with optional phrase contributions extra=(docs u32, title f32, body f32, flags u8)."""

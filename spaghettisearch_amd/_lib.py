@@ -63,6 +63,7 @@ PROTOTYPES = {
     "ss_pr_status": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]),
     "ss_pr_read_local": (_i32, [_vp, _vp, _vp]),
     "ss_pr_read": (_i32, [_vp, _vp]),
+    "ss_pr_probe": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_float)]),
     "ss_index_create": (_i32, [_vp, _u64, _u64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "ss_index_destroy": (_i32, [_vp]),
     "ss_tfidf_build": (_i32, [_vp, _u64, _vp, _vp, _vp]),

@@ -498,6 +498,51 @@ __global__ void k_pr_read(const double* __restrict__ x, const PrCtl* __restrict_
     for (int k = 0; k < k_topics; k++) out[(size_t)k * out_stride + o] = zero ? ctl->xz[k] : x[(size_t)lrow * GW + k];
 }
 
+// ---- diagnostic: the ceiling of the sweep's access pattern (ss_pr_probe) -----------------------------------------
+// Gather-only pass over THIS graph's in-edge stream with the sweep's own load shape (one coalesced 64-byte index
+// load per lane group, 16 independent whole-row gathers in flight) and nothing else: no row ends, no rank read or
+// write, no contribution write, no reductions.  mode 0 = the real index stream, 1 = indices hashed to uniformly
+// random rows (no hub reuse), 2 = consecutive rows (a streamed table).  Each lane group keeps one running sum and
+// stores it once, so the loads cannot be dropped.
+template <int GW>
+__global__ __launch_bounds__(TPB) void k_pr_probe(const double* __restrict__ T, const uint32_t* __restrict__ in_src, size_t n_edges,
+                                                  uint32_t n_rows, int mode, double* __restrict__ sink) {
+    if constexpr (GW >= 8) {
+        constexpr int NSLOT = 64 / GW;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int t = lane % GW, slot = lane / GW, gbase = lane - t;
+        const size_t groups = (size_t)gridDim.x * WAVES * NSLOT;
+        const size_t gi = ((size_t)blockIdx.x * WAVES + wave) * NSLOT + slot;
+        // contiguous span of 16-edge chunks per lane group, like a W_ROWS item
+        const size_t n_chunks = n_edges / CH;
+        const size_t per = (n_chunks + groups - 1) / groups;
+        size_t c = min(gi * per, n_chunks);
+        const size_t c_hi = min(c + per, n_chunks);
+        double acc = 0.0;
+        for (; c < c_hi; c++) {
+            constexpr int R = CH / GW;
+            uint32_t src[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const size_t e = c * CH + (size_t)(r * GW + t);
+                uint32_t v = NT_LOAD(&in_src[e]) & SRC_MASK;
+                if (mode == 1) v = (uint32_t)(((uint64_t)(v * 2654435761u + (uint32_t)e * 40503u) * n_rows) >> 32);
+                if (mode == 2) v = (uint32_t)(e % n_rows);
+                src[r] = v;
+            }
+            double v[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const uint32_t sj = (uint32_t)__shfl((int)src[j / GW], gbase + (j % GW), 64);
+                v[j] = T[(size_t)sj * GW + t];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; j++) acc += v[j];
+        }
+        sink[((size_t)blockIdx.x * TPB + threadIdx.x)] = acc;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------
@@ -836,6 +881,38 @@ int32_t ss_pr_read(ss_pr* pr, double* rank_out) {
     SS_HIP(ctx, hipGetLastError());
     SS_HIP(ctx, hipMemcpyAsync(rank_out, d_out.p, (size_t)g->n * pr->k * sizeof(double), hipMemcpyDefault, ctx->stream));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+int32_t ss_pr_probe(ss_pr* pr, int32_t mode, int32_t n_reps, float* ms_out) {
+    if (!pr || !ms_out) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    if (pr->gw < 8) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_probe: the probe mirrors the chunked gather of the K >= 5 kernels");
+    if (mode < 0 || mode > 2 || n_reps < 1) return ctx->fail(SS_ERR_INVALID, "ss_pr_probe: mode 0..2, n_reps >= 1");
+    const ss_graph* g = pr->g;
+    const unsigned nb = (unsigned)ctx->cu_count * 8;
+    ss::DevBuf<double> sink;
+    SS_HIP(ctx, sink.alloc((size_t)nb * TPB));
+    hipEvent_t e0, e1;
+    SS_HIP(ctx, hipEventCreate(&e0));
+    SS_HIP(ctx, hipEventCreate(&e1));
+    hipStream_t st = ctx->stream;
+    const double* T = pr->tab0.p;
+    for (int r = 0; r < n_reps + 1; r++) {
+        if (r == 1) SS_HIP(ctx, hipEventRecord(e0, st));          // first launch = warm-up
+        if (pr->gw == 8) hipLaunchKernelGGL(k_pr_probe<8>, dim3(nb), dim3(TPB), 0, st, T, (const uint32_t*)g->in_src.p, (size_t)g->e_local, (uint32_t)g->nd_int, mode, sink.p);
+        else hipLaunchKernelGGL(k_pr_probe<16>, dim3(nb), dim3(TPB), 0, st, T, (const uint32_t*)g->in_src.p, (size_t)g->e_local, (uint32_t)g->nd_int, mode, sink.p);
+    }
+    SS_HIP(ctx, hipEventRecord(e1, st));
+    SS_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    SS_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    SS_HIP(ctx, hipGetLastError());
+    *ms_out = ms / (float)n_reps;
     return SS_OK;
 }
 

@@ -78,6 +78,14 @@ __global__ void k_check_df(const uint64_t* __restrict__ term_ptr, const uint64_t
     if (t >= n_terms) return;
     if (df[t] < term_ptr[t + 1] - term_ptr[t]) atomicOr(err, 1u);
 }
+// positional postings: pos_ptr must be non-decreasing (k_phrase_match reads pos[pos_ptr[i] .. pos_ptr[i+1]))
+__global__ void k_check_pos(const uint64_t* __restrict__ pos_ptr, uint64_t n_post, uint32_t* __restrict__ err) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (; i < n_post; i += stride) bad = bad || pos_ptr[i + 1] < pos_ptr[i];
+    if (bad) atomicOr(err, 1u);
+}
 __global__ void k_check_docs(const uint32_t* __restrict__ post_doc, uint64_t n_post, uint64_t n_docs,
                              unsigned long long* __restrict__ n_desc, uint32_t* __restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,12 +370,10 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     SS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint64_t P = idx->n_post, T = idx->n_terms, N = idx->n_docs;
+    // every allocation happens BEFORE the start event: ss_last_kernel_ms(2) brackets device work only
+    // (a 5 GB hipMalloc inside the window once put ~1 s of host-side allocator time into the "kernel" time)
     ss::DevBuf<float> idf;
     SS_HIP(ctx, idf.alloc(T));
-    SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
-    SS_HIP(ctx, hipEventRecord(ctx->ev[2][0], st));
-    if (T) hipLaunchKernelGGL(k_idf, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p,
-                              idx->has_df_global ? idx->df_global.p : nullptr, T, (double)total_docs, idf.p);
     // large tables: bucketed magnitude pass (no global float64 atomics); small ones: one atomic per posting
     int shift = 13;                                                   // 8192 docs per bucket = 64 KB of float64 LDS accumulators
     if ((N >> shift) >= (uint64_t)NB_MAX) shift = 14;
@@ -376,19 +382,26 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     uint64_t min_p = (uint64_t)1 << 22;
     if (const char* e = std::getenv("SS_TFIDF_BUCKET_MIN")) min_p = std::strtoull(e, nullptr, 10);
     const bool bucketed = P >= std::max<uint64_t>(min_p, 1) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
+    const uint32_t nb = (uint32_t)nb64;
     ss::DevBuf<uint32_t> b_cnt, b_off, b_cur;
     ss::DevBuf<uint2> b_packed;
     if (bucketed) {
-        const uint32_t nb = (uint32_t)nb64;
         SS_HIP(ctx, b_cnt.alloc(nb));
         SS_HIP(ctx, b_off.alloc(nb + 1));
         SS_HIP(ctx, b_cur.alloc(nb));
         SS_HIP(ctx, b_packed.alloc(P));
-        SS_HIP(ctx, hipMemsetAsync(b_cnt.p, 0, nb * sizeof(uint32_t), st));
         if (ctx->tfidf_bucket_lds < (1 << shift) * 8) {
             SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
             ctx->tfidf_bucket_lds = (1 << shift) * 8;
         }
+    }
+    SS_HIP(ctx, hipStreamSynchronize(st));       // allocator work (and anything queued before) is over when the clock starts
+    SS_HIP(ctx, hipEventRecord(ctx->ev[2][0], st));
+    SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
+    if (T) hipLaunchKernelGGL(k_idf, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p,
+                              idx->has_df_global ? idx->df_global.p : nullptr, T, (double)total_docs, idf.p);
+    if (bucketed) {
+        SS_HIP(ctx, hipMemsetAsync(b_cnt.p, 0, nb * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_weight_count, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
                            idf.p, P, shift, nb, b_cnt.p);
         hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, b_cnt.p, nb, b_off.p, b_cur.p);
@@ -453,8 +466,19 @@ int32_t ss_index_set_positions(ss_index* idx, const uint64_t* pos_ptr, const flo
     SS_HIP(ctx, hipMemcpyAsync(&ends[0], idx->pos_ptr.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&ends[1], idx->pos_ptr.p + P, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
-    if (ends[0] != 0) return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos_ptr[0] != 0");
-    if (ends[1] && !pos) return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos is NULL");
+    if (ends[0] != 0) { idx->pos_ptr.release(); return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos_ptr[0] != 0"); }
+    if (P) {
+        // monotone + first 0 + last = total  =>  every range lies inside pos[0, total)
+        ss::DevBuf<uint32_t> err;
+        SS_HIP(ctx, err.alloc(1));
+        SS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_check_pos, dim3(std::min<unsigned>(ss::div_up(P, TPB), 16384u)), dim3(TPB), 0, st, idx->pos_ptr.p, P, err.p);
+        uint32_t h_err = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&h_err, err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        if (h_err) { idx->pos_ptr.release(); return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos_ptr is not non-decreasing"); }
+    }
+    if (ends[1] && !pos) { idx->pos_ptr.release(); return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos is NULL"); }
     SS_HIP(ctx, idx->pos.alloc(ends[1]));
     if (ends[1]) SS_HIP(ctx, hipMemcpyAsync(idx->pos.p, pos, ends[1] * sizeof(float), hipMemcpyDefault, st));
     SS_HIP(ctx, hipStreamSynchronize(st));

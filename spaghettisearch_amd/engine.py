@@ -187,6 +187,12 @@ class PageRankState:
         check(self.ctx.lib.ss_pr_status(self.h, _ptr(iters), C.byref(na), C.byref(sw), _ptr(delta), _ptr(total)), self.ctx.h)
         return {"iters": iters, "n_active": na.value, "sweeps": sw.value, "delta": delta, "total": total}
 
+    def probe(self, mode: int = 0, n_reps: int = 5) -> float:
+        """ss_pr_probe: ms per gather-only pass over this graph's index stream (diagnostic)."""
+        ms = C.c_float(0)
+        check(self.ctx.lib.ss_pr_probe(self.h, mode, n_reps, C.byref(ms)), self.ctx.h)
+        return float(ms.value)
+
     def read(self) -> np.ndarray:
         out = np.zeros((self.k, self.g.n), dtype=np.float64)
         check(self.ctx.lib.ss_pr_read(self.h, _ptr(out)), self.ctx.h)

@@ -1,5 +1,5 @@
-"""GPU parity at BASELINE.json's full sizes (config 3: 10M docs / 1M terms / 641M+41M postings; config 4's
-graph: 10M nodes / 50M edges, 16 topics), through the oracle where it finishes in seconds and through
+"""GPU parity at BASELINE.json's full sizes (config 2: 2^20 nodes / 5M edges, one vector, to eps 1e-6; config 3: 10M docs /
+1M terms / 641M+41M postings; config 4's graph: 10M nodes / 50M edges, 16 topics; config 5: config 3 blended with config 4's ranks), through the oracle where it finishes in seconds and through
 size-independent properties elsewhere.  Inputs are generated on the device (nothing is shipped)."""
 import numpy as np
 import pytest
@@ -71,6 +71,46 @@ def test_pagerank_config4_graph(ss_ctx, oracle):
     torch.cuda.empty_cache()
 
 
+def test_pagerank_config2_to_convergence(ss_ctx, oracle):
+    """BASELINE config 2: R-MAT scale 20 (N = 2^20), 5M unique edges (seed 42, id permutation seed 43), ONE topic
+    vector (the K=1 kernel classes W_WAVE / W_GROUP), d = 0.75, PageRank to eps = 1e-6 — the whole vector against
+    the oracle (pagerank.go:85-145): iteration count equal, x to 1e-12, inherited part y = x*S-(1-d) to 1e-6."""
+    import torch
+    from spaghettisearch_amd import engine
+    n, e = 1 << 20, 5_000_000
+    dev = torch.device("cuda", 0)
+    out_ptr, out_dst = synth.rmat_graph_torch(n, e, seed=42, device=dev)
+    h_ptr = out_ptr.cpu().numpy().view(np.uint64)
+    h_dst = out_dst.cpu().numpy().view(np.uint32)
+    assert int(h_ptr[-1]) == e
+    n_topic = synth.topic_sizes(n, 1)
+    g = engine.Graph(ss_ctx, n, out_ptr, out_dst)
+    rank, iters = g.pagerank(D, 1e-6, n_topic)
+    ref, ref_it, change, total = oracle.pagerank_topic_detail(n, h_ptr, h_dst, D, 1e-6, int(n_topic[0]))
+    assert int(iters[0]) == int(ref_it) and ref_it > 1
+    np.testing.assert_allclose(rank[0], ref, rtol=1e-12)
+    y, y_ref = rank[0] * total - (1.0 - D), ref * total - (1.0 - D)
+    nz = y_ref > 1e-12
+    np.testing.assert_allclose(y[nz], y_ref[nz], rtol=1e-6)
+    np.testing.assert_allclose(y, y_ref, atol=1e-9 * y_ref.max())
+    # the reference's own stop threshold (start_crawl.go:175: eps = 1e-20): iteration counts equal or off by one at the last bit
+    rank20, it20 = g.pagerank(D, 1e-20, n_topic, max_iter=500)
+    ref20, rit20 = oracle.pagerank(n, h_ptr, h_dst, D, 1e-20, n_topic, max_iter=500)
+    assert abs(int(it20[0]) - int(rit20[0])) <= 1
+    np.testing.assert_allclose(rank20[0], ref20[0], rtol=1e-12)
+    # fixed-iteration state == the oracle after the same number of sweeps (the mode bench.py times)
+    st = engine.PageRankState(g, D, -1.0, n_topic, max_iter=0)
+    st.begin()
+    st.step(10)
+    x10 = st.read()[0]
+    st.close()
+    ref10, _ = oracle.pagerank(n, h_ptr, h_dst, D, -1.0, n_topic, max_iter=10)
+    np.testing.assert_allclose(x10, ref10[0], rtol=1e-12)
+    g.close()
+    del out_ptr, out_dst
+    torch.cuda.empty_cache()
+
+
 def test_index_config3_build_and_topk(ss_ctx, oracle):
     import torch
     from spaghettisearch_amd import engine
@@ -126,6 +166,34 @@ def test_index_config3_build_and_topk(ss_ctx, oracle):
     # a batch of one (small slices spread over the chip) and the full batch agree
     one, _ = sc.score_topk(q_ptr[:2], q_terms[:3], 100)
     assert one.tobytes() == hits[:1].tobytes()
+    # ---- BASELINE config 5 at full size: the same index and batch blended with a 16-topic PageRank prior and per-query
+    #      topicProbs (get_metadata.go:31-42,68-69), against the oracle on a sample of the batch
+    out_ptr, out_dst = synth.rmat_graph_torch(N, E, seed=42, device=dev)
+    g = engine.Graph(ss_ctx, N, out_ptr, out_dst)
+    prior, _ = g.pagerank(D, 1e-6, synth.topic_sizes(N, K))          # [K][N]: node i = doc i
+    g.close()
+    del out_ptr, out_dst
+    torch.cuda.empty_cache()
+    sc.set_prior(prior)
+    probs = np.random.default_rng(46).dirichlet(np.ones(K), size=1024)
+    h5, n5 = sc.score_topk(q_ptr, q_terms, 100, topic_probs=probs)
+    n5s = 16
+    r5, rn5 = oracle.score_topk_batch(ND, (h_tptr, h_tdoc, wt), (h_bptr, h_bdoc, wb), mt, mb, q_ptr[:n5s + 1], q_terms[:3 * n5s], 100,
+                                      prior=np.ascontiguousarray(prior.T), topic_probs=probs[:n5s])
+    assert n5[:n5s].tolist() == rn5.tolist()
+    for f in ("doc", "title", "body", "pagerank", "final"):
+        assert np.array_equal(h5[f][:n5s], r5[f]), f
+    assert (n5 == 100).all() and (np.diff(h5["final"], axis=1) <= 0).all()
+    # the blend is 0.33*sqd*100 on top of the cosine part: recompute every row's final from its own fields
+    fin5 = (0.33 * h5["pagerank"] + 0.38 * h5["title"] + 0.29 * h5["body"]) * 100.0
+    assert np.array_equal(fin5, h5["final"])
+    sqd = np.einsum("qkt,qt->qk", prior.T[h5["doc"].astype(np.int64)], probs)
+    np.testing.assert_allclose(h5["pagerank"], sqd, rtol=1e-12)
+    # nil topicProbs with a prior loaded (main_retrieve.go:88): identical to the unblended run
+    h0, _ = sc.score_topk(q_ptr, q_terms, 100)
+    assert h0.tobytes() == hits.tobytes()
+    sc.set_prior(None)
+    del prior, sqd
     # ---- two doc-range shards + ss_merge_hits = the unsharded result
     sc.close()
     parts = np.zeros((2, 1024, 100), dtype=engine.HIT_DTYPE)

@@ -300,3 +300,33 @@ def test_phrase_by_hand(oracle):
     # single-term phrase: any position list non-empty matches
     docs, ot, ob, fl = oracle.phrase((t_ptr, t_doc, t_w), (b_ptr, b_doc, b_w), (tpp, tp), (bpp, bp), [1])
     assert docs.tolist() == [0, 1, 2] and fl.tolist() == [2, 3, 2]
+
+
+def test_reference_shaped_scoring_baseline_matches_the_flat_oracle(oracle):
+    """SURVEY.md §8d B1 (string-keyed maps, appended weight slices, insertion-sort appendSort, util.go:48-54) is only a
+    timed baseline, but it must compute the same FinalRank sequence as the flat restatement; equal finals may come
+    in another order (the reference leaves ties in arrival order), so docs are compared per distinct final."""
+    from spaghettisearch_amd import synth
+    nd, nt = 6000, 400
+    t = synth.zipf_index(nd, nt, 9000, seed=1)
+    b = synth.zipf_index(nd, nt, 120000, seed=2)
+    tw, tm, _ = oracle.tfidf(*t, nd, nd)
+    bw, bm, _ = oracle.tfidf(*b, nd, nd)
+    q_ptr, q_terms = synth.make_queries(40, 3, 150, seed=3)
+    q_terms[4] = q_terms[3]                        # duplicate token (Q8)
+    q_terms[9] = 0xFFFFFFFF                        # unknown word
+    ref, rn = oracle.score_topk_batch(nd, (t[0], t[1], tw), (b[0], b[1], bw), tm, bm, q_ptr, q_terms, 50)
+    mm = oracle.MagMap(tm, bm)
+    try:
+        for threads in (False, True):
+            h, n, _ = oracle.score_topk_batch_hashed(mm, (t[0], t[1], tw), (b[0], b[1], bw), q_ptr, q_terms, 50, threads=threads)
+            assert n.tolist() == rn.tolist()
+            assert np.array_equal(h["final"], ref["final"])
+            for q in range(len(n)):
+                # the cut at k may split a group of equal finals: compare the groups strictly above the last final
+                last = ref["final"][q, n[q] - 1] if n[q] else 0.0
+                a = sorted((f, d) for f, d in zip(h["final"][q, :n[q]], h["doc"][q, :n[q]]) if f > last)
+                r = sorted((f, d) for f, d in zip(ref["final"][q, :n[q]], ref["doc"][q, :n[q]]) if f > last)
+                assert a == r
+    finally:
+        mm.close()
