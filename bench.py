@@ -6,39 +6,44 @@ synthetic index.  One JSON line; the primary `value` is PageRank topic-iteration
 on the 10M-node / 50M-edge R-MAT graph with 16 topic vectors (BASELINE config 4's
 graph; one K-wide sweep = 16 topic-iterations = one "step"), the top-k half
 (BASELINE config 3: 10M docs / 1M terms, 1024 x 3-term OR queries, cosine top-100;
-one batch = one step) is reported under "topk" in the same line.
+one batch = one step) is reported under "topk" in the same line, BASELINE config 2
+(2^20 nodes / 5M edges, one vector, to eps 1e-6) under "config2".
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-N>1: one process per GPU.  PageRank (strong scaling, fixed graph and K) is measured in two
-decompositions — doc-range shards with ONE RCCL all-gather of the non-dangling contribution
-slices per sweep (plain, and with the exchange of one topic block overlapped with the sweep of
-the other), and topic shards (K/N independent topic vectors per rank, no collective) —
-`value` is the fastest on the node, all are in the line; top-k runs as query-split
-replicas (every rank scores its own 1024-query batch on a full index copy; no collective)
-and, beside it, as doc-range shards with one all-gather of the hits.
+N>1: one process per GPU.  Started without a launcher (WORLD_SIZE unset) this script spawns the N
+ranks itself with torch.distributed.run — before it touches the GPU — relays rank 0's line and exits
+with the children's status; started by a launcher it is one of the ranks.
+PageRank (strong scaling: fixed graph and K) shards the doc range: every rank sweeps its destination
+rows, ONE RCCL all-gather of the non-dangling contribution slices per sweep (plain, and with the
+exchange of one topic block overlapped with the sweep of the other) — that is `value`; the
+collective-free topic split (K/N vectors per rank) is reported beside it under "decompositions" only.
+Top-k runs as query-split replicas (every rank scores its own 1024-query batch on a full index copy;
+no collective) and, beside it, as doc-range shards with one all-gather of the hits.
 
-The CPU baseline (oracle/, a restatement of the reference's arithmetic — the Go
-reference cannot be built) is timed on rank 0 at N=1 on a bounded
-sample of the same workload and reported beside the GPU numbers.
+The CPU baseline (oracle/, a restatement of the reference's arithmetic — the Go reference cannot be
+built) is timed on rank 0 at N=1 on a bounded sample of the same workload:
+`cpu_baseline.value` is the reference-SHAPED restatement (string-keyed hash maps like the Go code,
+SURVEY.md §8d B1), the flat single-thread port and the OpenMP version are reported beside it.
 """
 from __future__ import annotations
 
 import argparse
 import json
-import math
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# the "strong CPU" baseline (OpenMP) is sized to the GPU box's CPU share for one GPU
+# the OpenMP baselines are sized to the GPU box's CPU share for one GPU
 os.environ.setdefault("OMP_NUM_THREADS", "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+N_BLOCKS = 5            # timed blocks of --steps per measurement: the first is `value`, all give min/median
 
 
 def profiled_traffic(kernel: str):
@@ -48,24 +53,43 @@ def profiled_traffic(kernel: str):
     read side is doubled for these wide-request kernels.  None if no profile is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_bytes.json")))
-    if not files:
-        return None
-    try:
-        rows = json.load(open(files[-1]))
-        rd = [r for r in rows if r["counter"] == "FETCH_SIZE" and kernel in r["kernel"]]
-        wr = [r for r in rows if r["counter"] == "WRITE_SIZE" and kernel in r["kernel"]]
-        if not rd or not wr:
-            return None
-        return {"bytes": 2.0 * rd[0]["median_KB"] * 1024 + wr[0]["median_KB"] * 1024,
-                "fetch_size_raw_bytes": rd[0]["median_KB"] * 1024, "write_size_bytes": wr[0]["median_KB"] * 1024,
-                "source": os.path.relpath(files[-1], ROOT)}
-    except Exception:
-        return None
+    for path in reversed(files):
+        try:
+            rows = json.load(open(path))
+            rd = [r for r in rows if r["counter"] == "FETCH_SIZE" and kernel in r["kernel"]]
+            wr = [r for r in rows if r["counter"] == "WRITE_SIZE" and kernel in r["kernel"]]
+            if not rd or not wr:
+                continue
+            return {"bytes": 2.0 * rd[0]["median_KB"] * 1024 + wr[0]["median_KB"] * 1024,
+                    "fetch_size_raw_bytes": rd[0]["median_KB"] * 1024, "write_size_bytes": wr[0]["median_KB"] * 1024,
+                    "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
 
 
 def log(msg: str) -> None:
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes.  Nothing in this
+    process has touched the GPU (torch is not even imported), and it never execs: it waits and passes the status on."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"no launcher in the environment: starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
+
+
+def summarize(samples_ms):
+    return {"n_blocks": len(samples_ms), "min": min(samples_ms), "median": statistics.median(samples_ms), "max": max(samples_ms)}
 
 
 def main() -> None:
@@ -84,8 +108,12 @@ def main() -> None:
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--workload", choices=["both", "pagerank", "topk"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config2", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per half")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -96,10 +124,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
     # SS_BENCH_REHEARSAL=1: rehearse the N>1 code path on ONE GPU (all ranks on cuda:0, gloo, host-staged
     # exchange).  Numbers from a rehearsal are meaningless; it only checks the multi-process flow.
     rehearsal = os.environ.get("SS_BENCH_REHEARSAL") == "1"
@@ -134,13 +159,28 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    K, W = args.steps, args.warmup
+
+    def timed_blocks(step_k, warm=None, n_blocks=N_BLOCKS):
+        """W untimed warm-up steps, then N_BLOCKS blocks of EXACTLY K steps, each bracketed by barrier + synchronize on
+        both sides and reduced with max over ranks.  -> (seconds of the first block, [ms per step of every block])."""
+        (warm or step_k)(max(W, 1))
+        secs = []
+        for _ in range(n_blocks):
+            barrier()
+            t0 = time.perf_counter()
+            step_k(K)
+            barrier()
+            secs.append(max_over_ranks(time.perf_counter() - t0))
+        return secs[0], [s * 1e3 / K for s in secs]
+
     ctx = engine.Context(local_rank)
     c4_ranks = None
     pr_inputs = None
     stream = torch.cuda.Stream(device=dev)       # library kernels, torch copies and RCCL share one stream
     ctx.set_stream(stream.cuda_stream)
     result: dict = {}
-    K, W = args.steps, args.warmup
+    invalid: list = []
 
     def emit() -> None:
         if rank != 0:
@@ -152,19 +192,21 @@ def main() -> None:
                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
                "data": "synthetic"}
         out.update(res)
+        if invalid:
+            out["valid"] = False
+            out["invalid_because"] = invalid
         print(json.dumps(out), flush=True)
 
-
     if world > 1:
-        # Multi-GPU runs execute collectives this one-GPU development box could only rehearse: whatever has been measured
-        # is printed if the run ever stalls (all ranks arm the same timer).
+        # Multi-GPU runs execute collectives a one-GPU development box could only rehearse: if the run ever stalls,
+        # whatever has been measured is printed, marked, and the process exits NON-ZERO (all ranks arm the same timer).
         import threading
 
         def _stalled() -> None:
+            invalid.append("watchdog: the run did not finish within 900 s (stalled collective?)")
             if "metric" in result:
-                result["stalled"] = "watchdog: the run did not finish within 900 s; partial line"
                 emit()
-            os._exit(0 if "metric" in result else 3)
+            os._exit(3)
 
         _dog = threading.Timer(900.0, _stalled)
         _dog.daemon = True
@@ -199,18 +241,13 @@ def main() -> None:
             if world == 1:
                 pr = engine.PageRankState(g, d, -1.0, n_topic, max_iter=0)   # eps<0: fixed-iteration mode
                 pr.begin()
-                pr.step(max(W, 1))
-                barrier()
-                t0 = time.perf_counter()
-                pr.step(K)
-                barrier()
-                dt = time.perf_counter() - t0
+                dt, blocks = timed_blocks(pr.step)
                 st = pr.status()
-                assert st["sweeps"] == max(W, 1) + K, st
-                kern_ms = ctx.last_kernel_ms(0) / K     # HIP events on the library's stream around the K launches
+                assert st["sweeps"] == max(W, 1) + N_BLOCKS * K, st
+                kern_ms = ctx.last_kernel_ms(0) / K     # HIP events on the library's stream around the K launches of the last block
                 result.update({
                     "metric": "pagerank_iters_per_sec", "value": kt * K / dt, "unit": "topic-iterations/s",
-                    "ms_per_step": dt * 1e3 / K,
+                    "ms_per_step": dt * 1e3 / K, "ms_per_step_blocks": summarize(blocks),
                     "config": {"workload": workload, "nodes": n, "edges": e, "topics": kt, "sweeps_per_sec": K / dt,
                                "parallelism": "single GPU"},
                 })
@@ -222,29 +259,32 @@ def main() -> None:
                                       "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes}
                 if tr:
                     result["roofline"]["traffic_detail"] = tr
+                if kt >= 5:
+                    # what the sweep's access pattern alone costs on this chip: gather-only passes over the same index
+                    # stream and table (ss_pr_probe), beside a hub-free and a streamed variant
+                    gc = {name: pr.probe(mode, 5) for mode, name in ((0, "graph_index_stream"), (1, "uniform_random_rows"), (2, "consecutive_rows"))}
+                    result["roofline"]["gather_ceiling_ms"] = gc["graph_index_stream"]
+                    result["roofline"]["gather_probe_ms"] = gc
+                    result["roofline"]["kernel_over_gather_ceiling"] = kern_ms / gc["graph_index_stream"]
             else:
-                # Several GPUs: the fixed graph and K are measured in up to three decompositions (the third, pipelined one
-                # at the very end); `value` is the fastest on this node, all are kept under "decompositions".
+                # Several GPUs.  The headline is the doc-range split with its per-sweep RCCL exchange (BASELINE config 4);
+                # the collective-free topic split is kept under "decompositions" for comparison only.
                 decomp = {}
-                # (a) topic shards: the K topic vectors are independent power iterations (pagerank.go:54-63 loops over the
-                #     categories): K/N of them per rank on a full copy of the 240 MB graph, NO collective on the data path
                 if kt % world == 0:
-                    g1 = engine.Graph(ctx, n, out_ptr, out_dst)
-                    mine = n_topic[rank * (kt // world):(rank + 1) * (kt // world)]
-                    pt = engine.PageRankState(g1, d, -1.0, mine, max_iter=0)
-                    pt.begin()
-                    pt.step(max(W, 1))
-                    barrier()
-                    t0 = time.perf_counter()
-                    pt.step(K)
-                    barrier()
-                    dtt = max_over_ranks(time.perf_counter() - t0)
-                    decomp["topic_shards"] = {"value": kt * K / dtt, "unit": "topic-iterations/s", "ms_per_step": dtt * 1e3 / K,
-                                              "parallelism": f"{kt // world} topics per rank x{world}, full graph per rank, no collective"}
-                    pt.close()
-                    g1.close()
-                # (b) doc-range shards: every rank sweeps its rows, ONE all-gather of the contribution slices per sweep
-                #     (xGMI point-to-point: 1/N of the table per link)
+                    try:
+                        g1 = engine.Graph(ctx, n, out_ptr, out_dst)
+                        mine = n_topic[rank * (kt // world):(rank + 1) * (kt // world)]
+                        pt = engine.PageRankState(g1, d, -1.0, mine, max_iter=0)
+                        pt.begin()
+                        dtt, _ = timed_blocks(pt.step, n_blocks=1)
+                        decomp["topic_shards"] = {"value": kt * K / dtt, "unit": "topic-iterations/s", "ms_per_step": dtt * 1e3 / K,
+                                                  "parallelism": f"{kt // world} topics per rank x{world}, full graph per rank, no collective"}
+                        pt.close()
+                        g1.close()
+                    except Exception as exc_:
+                        decomp["topic_shards"] = {"value": 0.0, "error": repr(exc_)}
+                # doc-range shards: every rank sweeps its rows, ONE all-gather of the contribution slices per sweep
+                # (xGMI point-to-point: 1/N of the table per link)
                 try:
                     pr = engine.PageRankState(g, d, -1.0, n_topic, max_iter=0)
                     exchange = sharding.DistExchange(pr, dev, host_staged=rehearsal)
@@ -258,28 +298,24 @@ def main() -> None:
                             exchange()
                             pr.finalize()
 
-                    sweeps(max(W, 1))
-                    barrier()
-                    t0 = time.perf_counter()
-                    sweeps(K)
-                    barrier()
-                    dt = max_over_ranks(time.perf_counter() - t0)
+                    dt, blocks = timed_blocks(sweeps)
                     st = pr.status()
-                    assert st["sweeps"] == max(W, 1) + K, st
+                    assert st["sweeps"] == max(W, 1) + N_BLOCKS * K, st
                     decomp["doc_range_shards"] = {"value": kt * K / dt, "unit": "topic-iterations/s", "ms_per_step": dt * 1e3 / K,
+                                                  "ms_per_step_blocks": summarize(blocks),
                                                   "parallelism": f"doc-range shards x{world}, 1 RCCL all-gather/sweep"}
                     sp, sb, rp, rb = pr.exchange_buffers()
                     result["exchange"] = {"allgather_recv_bytes_per_sweep": rb, "send_bytes_per_rank": sb}
-                except Exception as exc:              # the topic-shard number must survive a failing collective
-                    result["doc_range_error"] = repr(exc)
-                if not decomp:
-                    raise SystemExit("no multi-GPU PageRank decomposition could be measured")
-                best = max(decomp, key=lambda name: decomp[name]["value"])
+                except Exception as exc:
+                    decomp["doc_range_shards"] = {"value": 0.0, "ms_per_step": None, "error": repr(exc),
+                                                  "parallelism": f"doc-range shards x{world}, 1 RCCL all-gather/sweep"}
+                    invalid.append(f"doc-range-sharded sweep failed: {exc!r}")
+                head = decomp["doc_range_shards"]
                 result.update({
-                    "metric": "pagerank_iters_per_sec", "value": decomp[best]["value"], "unit": "topic-iterations/s",
-                    "ms_per_step": decomp[best]["ms_per_step"],
+                    "metric": "pagerank_iters_per_sec", "value": head["value"], "unit": "topic-iterations/s",
+                    "ms_per_step": head["ms_per_step"],
                     "config": {"workload": workload, "nodes": n, "edges": e, "topics": kt,
-                               "sweeps_per_sec": decomp[best]["value"] / kt, "parallelism": decomp[best]["parallelism"]},
+                               "sweeps_per_sec": head["value"] / kt, "parallelism": head["parallelism"]},
                     "decompositions": decomp,
                 })
             # to-convergence run at the BASELINE eps (not timed into `value`)
@@ -334,7 +370,7 @@ def main() -> None:
             if prc is not None:
                 prc.close()
 
-            # ---- CPU baseline: the oracle's literal port on the same graph, bounded sample
+            # ---- CPU baseline: the oracle on the same graph, bounded sample
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 from oracle import pyoracle
                 h_ptr = out_ptr.cpu().numpy().view(np.uint64)
@@ -346,18 +382,19 @@ def main() -> None:
                 t0 = time.perf_counter()
                 ref, _ = pyoracle.pagerank(n, h_ptr, h_dst, d, -1.0, [int(n_topic[0])], max_iter=m)
                 cdt = time.perf_counter() - t0
-                result["cpu_baseline"] = {"value": m / cdt, "unit": "topic-iterations/s", "cores": 1, "kind": "port",
-                                          "sample": f"{m} iterations of topic 0 on the same graph, flat-array single-thread C "
-                                                    f"restatement of pagerank.go:85-145 (oracle/oracle.c); host has {os.cpu_count()} cores"}
-                # "reference-shaped" variant: the same arithmetic keyed by 32-char hex strings
-                # in hash maps, the way pagerank.go keys Go maps by md5-hex docHash; one topic, 2 iterations
-                if args.cpu_seconds >= 10:
-                    t0 = time.perf_counter()
-                    pyoracle.pagerank(n, h_ptr, h_dst, d, -1.0, [int(n_topic[0])], max_iter=1, hashed=True)
-                    hdt = time.perf_counter() - t0
-                    result["cpu_baseline"]["reference_shaped"] = {
-                        "value": 1 / hdt, "unit": "topic-iterations/s", "cores": 1,
-                        "sample": "1 iteration, string-keyed hash maps (incl. building them), oracle/oracle.c:orc_pagerank_topic_hashed"}
+                flat = {"value": m / cdt, "unit": "topic-iterations/s", "cores": 1,
+                        "sample": f"{m} iterations of topic 0 on the same graph, flat-array single-thread C restatement of "
+                                  f"pagerank.go:85-145 (oracle/oracle.c:orc_pagerank_topic)"}
+                # "reference-shaped" (SURVEY.md §8d B1): the same arithmetic keyed by 32-char hex strings in hash maps, the way
+                # pagerank.go keys Go maps by md5-hex docHash; single-threaded like the reference (pagerank.go:52)
+                t0 = time.perf_counter()
+                pyoracle.pagerank(n, h_ptr, h_dst, d, -1.0, [int(n_topic[0])], max_iter=1, hashed=True)
+                hdt = time.perf_counter() - t0
+                result["cpu_baseline"] = {
+                    "value": 1 / hdt, "unit": "topic-iterations/s", "cores": 1, "kind": "port",
+                    "sample": f"reference-shaped restatement (B1): 1 iteration of topic 0 on the same graph with string-keyed hash maps "
+                              f"(incl. building them), oracle/oracle.c:orc_pagerank_topic_hashed; host has {os.cpu_count()} cores",
+                    "flat_port": flat}
                 # "strong CPU" variant (B2): flat pull-form SpMV, OpenMP
                 t0 = time.perf_counter()
                 _, it_omp, th = pyoracle.pagerank_omp(n, h_ptr, h_dst, d, -1.0, int(n_topic[0]), max_iter=10)
@@ -383,6 +420,46 @@ def main() -> None:
             else:
                 pr_inputs = (n, kt, d, n_topic, out_ptr, out_dst)
             torch.cuda.empty_cache()
+
+            # ---- BASELINE config 2: 2^20 nodes / 5M edges, ONE vector (the K=1 kernel classes), to eps = 1e-6
+            if world == 1 and not args.no_config2:
+                n2, e2 = 1 << 20, 5_000_000
+                o2p, o2d = synth.rmat_graph_torch(n2, e2, seed=42, device=dev)
+                g2 = engine.Graph(ctx, n2, o2p, o2d)
+                nt2 = synth.topic_sizes(n2, 1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r2, it2 = g2.pagerank(d, 1e-6, nt2)                       # the reference's loop; stop rule on the device
+                conv_s = time.perf_counter() - t0
+                p2 = engine.PageRankState(g2, d, -1.0, nt2, max_iter=0)
+                p2.begin()
+                dt2, blocks2 = timed_blocks(p2.step)
+                k2_ms = ctx.last_kernel_ms(0) / K
+                p2.close()
+                b2 = 4 * e2 + 8 * n2 + 16 * n2                            # 44 MB per iteration
+                a2 = b2 / (k2_ms * 1e-3) / 1e9
+                c2 = {"workload": f"R-MAT scale 20: {n2} nodes / {e2} edges, 1 vector, d=0.75 (BASELINE config 2)",
+                      "value": K / dt2, "unit": "iterations/s", "ms_per_step": dt2 * 1e3 / K, "ms_per_step_blocks": summarize(blocks2),
+                      "to_convergence_eps1e-6": {"iters": int(it2[0]), "seconds": conv_s},
+                      "roofline": {"bound": "hbm", "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS,
+                                   "traffic": None, "kernel": "k_pr_step<1>", "kernel_ms": k2_ms, "algorithmic_bytes": b2}}
+                if not args.no_cpu_baseline:
+                    from oracle import pyoracle
+                    h2p = o2p.cpu().numpy().view(np.uint64)
+                    h2d = o2d.cpu().numpy().view(np.uint32)
+                    t0 = time.perf_counter()
+                    ref2, rit2 = pyoracle.pagerank(n2, h2p, h2d, d, 1e-6, nt2)
+                    cdt2 = time.perf_counter() - t0
+                    err2 = float(np.max(np.abs(r2[0] - ref2[0]) / ref2[0]))
+                    c2["gpu_vs_oracle"] = {"iters_equal": bool(int(it2[0]) == int(rit2[0])), "max_rel_err": err2}
+                    c2["cpu_baseline"] = {"value": int(rit2[0]) / cdt2, "unit": "iterations/s", "cores": 1, "kind": "port",
+                                          "sample": f"the whole run to eps 1e-6 ({int(rit2[0])} iterations), flat single-thread port"}
+                    assert int(it2[0]) == int(rit2[0]) and err2 < 1e-6, c2["gpu_vs_oracle"]
+                    del h2p, h2d, ref2
+                result["config2"] = c2
+                g2.close()
+                del o2p, o2d, r2
+                torch.cuda.empty_cache()
 
         # ------------------------------------------------------------------ top-k half
         if args.workload in ("both", "topk"):
@@ -423,6 +500,7 @@ def main() -> None:
             del b_ptr, b_doc, b_tf, t_ptr, t_doc, t_tf
             torch.cuda.empty_cache()
             wt, mt, _ = ti.tfidf_build(nd, want_w=keep_host, want_mag=keep_host, want_idf=False)   # title first (start_crawl.go:176)
+            tfidf_title_ms = ctx.last_kernel_ms(2)
             wb, mb, _ = bi.tfidf_build(nd, want_w=keep_host, want_mag=keep_host, want_idf=False)
             tfidf_ms = ctx.last_kernel_ms(2)
             sc = engine.Scorer(ctx, ti, bi)
@@ -435,51 +513,66 @@ def main() -> None:
             # results stay in HBM inside the timed region (PCIe-inclusive rate reported separately)
             d_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev)
             d_nhits = torch.empty(nq, dtype=torch.int32, device=dev)
-            for _ in range(max(W, 1)):
-                sc.score_topk(d_qptr, d_qterms, k, out=(d_hits, d_nhits))
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(K):                       # device in, device out: calls only enqueue, host planning of batch i+1
-                sc.score_topk(d_qptr, d_qterms, k, out=(d_hits, d_nhits))     # overlaps the kernels of batch i
-            barrier()
-            dt = max_over_ranks(time.perf_counter() - t0)
-            kms = 0.0                                # kernel time (HIP events on the library's stream), outside the timed region
+
+            def batches(m, qp=d_qptr, qt=d_qterms, **kw):
+                for _ in range(m):                   # device in, device out: calls only enqueue, host planning of batch i+1
+                    sc.score_topk(qp, qt, k, out=(d_hits, d_nhits), **kw)     # overlaps the kernels of batch i
+
+            dt, blocks = timed_blocks(batches)
+            kms = []                                 # kernel time (HIP events on the library's stream), outside the timed region
             for _ in range(min(K, 10)):
                 sc.score_topk(d_qptr, d_qterms, k, out=(d_hits, d_nhits))
-                kms += ctx.last_kernel_ms(1)
-            kern_ms = kms / min(K, 10)
+                kms.append(ctx.last_kernel_ms(1))
+            kern_ms = sum(kms) / len(kms)
             t0 = time.perf_counter()
             for _ in range(K):
                 hits, n_hits = sc.score_topk(q_ptr, q_terms, k)      # host in, host out: PCIe-inclusive
             dt_pcie = time.perf_counter() - t0
             algo_q = 8 * sum_df + 36 * k * nq           # SURVEY.md §8d B_q without the per-candidate magnitude term
             ach = algo_q / (kern_ms * 1e-3) / 1e9
+            full = (nd, nt, nq, k) == (10_000_000, 1_000_000, 1024, 100)
+            algo_tw = 12 * Pb + 8 * nt + 8 * nd         # SURVEY.md §8d B_tw = 12P + 8T + 8N (body table)
+            ach_tw = algo_tw / (tfidf_ms * 1e-3) / 1e9
+            tw_traffic = None
+            if full:
+                parts = [profiled_traffic(kn) for kn in ("k_weight_count", "k_scatter", "k_bucket_sum")]
+                if all(parts):
+                    tw_traffic = sum(p["bytes"] for p in parts)
             topk = {"metric": "topk_queries_per_sec", "value": world * nq * K / dt, "unit": "queries/s",
-                    "ms_per_step": dt * 1e3 / K, "scaling": "weak",
+                    "ms_per_step": dt * 1e3 / K, "ms_per_step_blocks": summarize(blocks), "scaling": "weak",
                     "config": {"workload": f"{nd} docs / {nt} terms, body P={Pb}, title P={Pt}, {nq} x 3-term OR queries "
                                            f"(term ranks U[1,10000]), cosine top-{k} (BASELINE config 3)",
                                "postings_per_query": sum_df / nq,
                                "parallelism": "single GPU" if world == 1 else f"query-split replicas x{world}"},
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": (profiled_traffic("k_score_slices") or {}).get("bytes") if (nd, nt, nq, k) == (10_000_000, 1_000_000, 1024, 100) else None,
-                                 "kernel": "k_score_slices+k_merge_topk",
-                                 "kernel_ms": kern_ms, "algorithmic_bytes": algo_q},
+                                 "traffic": (profiled_traffic("k_score") or {}).get("bytes") if full else None,
+                                 "kernel": "scoring kernels of one batch (slices + merge)",
+                                 "kernel_ms": kern_ms, "kernel_ms_min": min(kms), "algorithmic_bytes": algo_q},
+                    "tfidf": {"ms": tfidf_ms, "title_ms": tfidf_title_ms,
+                              "what": "ss_tfidf_build of the body table: device time between HIP events (allocations outside)",
+                              "roofline": {"bound": "hbm", "achieved": ach_tw, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_tw / HBM_PEAK_GBS,
+                                           "traffic": tw_traffic, "kernel": "k_idf+k_weight_count+k_scatter+k_bucket_sum",
+                                           "kernel_ms": tfidf_ms, "algorithmic_bytes": algo_tw}},
                     "tfidf_build_ms": tfidf_ms, "queries_per_sec_host_in_host_out": nq * K / dt_pcie}
-            def timed_batches(fn):
-                for _ in range(max(W, 1)):
-                    fn()
-                barrier()
+
+            # ---- one query through the ABI, host in / host out (the reference's call shape: one Retrieve per request,
+            #      k = 50, main_retrieve.go:99-100)
+            lat = []
+            for i in range(40):
+                q1p = np.array([0, 3], dtype=np.uint32)
+                q1t = q_terms[3 * (i % nq):3 * (i % nq) + 3]
                 t0 = time.perf_counter()
-                for _ in range(K):
-                    fn()
-                barrier()
-                return max_over_ranks(time.perf_counter() - t0)
+                sc.score_topk(q1p, q1t, 50)
+                lat.append((time.perf_counter() - t0) * 1e3)
+            lat = lat[5:]
+            topk["latency_single_query_ms"] = {"median": statistics.median(lat), "min": min(lat), "p90": sorted(lat)[int(len(lat) * 0.9)],
+                                               "what": "one 3-term OR query, k=50, host buffers in and out through ss_score_topk"}
 
             # ---- tail queries: term ranks uniform over the whole vocabulary, reported separately
             tq_ptr, tq_terms = synth.make_queries(nq, 3, nt, seed=1045 + rank)
             d_tq = (torch.from_numpy(tq_ptr.view(np.int32)).to(dev), torch.from_numpy(tq_terms.view(np.int32)).to(dev))
-            dtt = timed_batches(lambda: sc.score_topk(d_tq[0], d_tq[1], k, out=(d_hits, d_nhits)))
+            dtt, _ = timed_blocks(lambda m: batches(m, d_tq[0], d_tq[1]), n_blocks=1)
             tail_df = int(sum((h_bptr[t + 1] - h_bptr[t]) + (h_tptr[t + 1] - h_tptr[t]) for t in tq_terms.astype(np.int64)))
             topk["tail_queries"] = {"value": world * nq * K / dtt, "unit": "queries/s", "ms_per_step": dtt * 1e3 / K,
                                     "workload": f"{nq} x 3-term OR queries, term ranks U[1,{nt}]", "postings_per_query": tail_df / nq}
@@ -495,8 +588,9 @@ def main() -> None:
             sc.set_prior(prior5)
             probs5 = np.random.default_rng(46 + rank).dirichlet(np.ones(kt5), size=nq)
             d_probs = torch.from_numpy(probs5).to(dev)
-            dt5 = timed_batches(lambda: sc.score_topk(d_qptr, d_qterms, k, topic_probs=d_probs, out=(d_hits, d_nhits)))
+            dt5, blocks5 = timed_blocks(lambda m: batches(m, topic_probs=d_probs))
             topk["blended_config5"] = {"value": world * nq * K / dt5, "unit": "queries/s", "ms_per_step": dt5 * 1e3 / K,
+                                       "ms_per_step_blocks": summarize(blocks5),
                                        "k_topics": kt5, "prior": prior_src, "topic_probs": "Dirichlet(1) per query"}
             if keep_host:
                 from oracle import pyoracle
@@ -521,7 +615,12 @@ def main() -> None:
                     dg = (torch.from_numpy(g_qptr.view(np.int32)).to(dev), torch.from_numpy(g_qterms.view(np.int32)).to(dev))
                     m_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev)
                     m_n = torch.empty(nq, dtype=torch.int32, device=dev)
-                    dts = timed_batches(lambda: dsc.score_topk(dg[0], dg[1], k, out=(m_hits, m_n)))
+
+                    def sharded(m):
+                        for _ in range(m):
+                            dsc.score_topk(dg[0], dg[1], k, out=(m_hits, m_n))
+
+                    dts, _ = timed_blocks(sharded, n_blocks=1)
                     sc.score_topk(dg[0], dg[1], k, out=(d_hits, d_nhits))                         # the full replica, same batch
                     same_s = bool(torch.equal(m_hits, d_hits) and torch.equal(m_n, d_nhits))
                     topk["doc_sharded"] = {"value": nq * K / dts, "unit": "queries/s", "ms_per_step": dts * 1e3 / K, "scaling": "strong",
@@ -536,9 +635,9 @@ def main() -> None:
 
             if keep_host:
                 from oracle import pyoracle
-                ns = 64
                 title = (h_tptr, h_tdoc, wt)
                 body = (h_bptr, h_bdoc, wb)
+                ns = 64
                 t0 = time.perf_counter()
                 ref, ref_n = pyoracle.score_topk_batch(nd, title, body, mt, mb, q_ptr[:ns + 1], q_terms[:3 * ns], k)
                 cdt = time.perf_counter() - t0
@@ -547,9 +646,32 @@ def main() -> None:
                     t0 = time.perf_counter()
                     ref, ref_n = pyoracle.score_topk_batch(nd, title, body, mt, mb, q_ptr[:ns + 1], q_terms[:3 * ns], k)
                     cdt = time.perf_counter() - t0
-                topk["cpu_baseline"] = {"value": ns / cdt, "unit": "queries/s", "cores": 1, "kind": "port",
-                                        "sample": f"first {ns} queries of the same batch, single-thread C restatement of "
-                                                  f"main_retrieve.go:50-103 + get_metadata.go:31-69 (oracle/oracle.c)"}
+                flat = {"value": ns / cdt, "unit": "queries/s", "cores": 1,
+                        "sample": f"first {ns} queries of the same batch, flat-array single-thread C restatement of "
+                                  f"main_retrieve.go:50-103 + get_metadata.go:31-69 (oracle/oracle.c:orc_score_topk_batch)"}
+                # reference-shaped: string-keyed maps, appended weight slices, insertion-sort appendSort; the
+                # reference fans goroutines out per term and per candidate, so B1 may use every core (one query per thread)
+                mm = pyoracle.MagMap(mt, mb)
+                nb1 = 32
+                t0 = time.perf_counter()
+                pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=True)
+                bdt = time.perf_counter() - t0
+                nb1 = int(max(32, min(nq, nb1 * args.cpu_seconds / max(bdt, 1e-3) / 2)))
+                t0 = time.perf_counter()
+                hb1, nb1n, th1 = pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=True)
+                bdt = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:9], q_terms[:24], k, threads=False)
+                b1s = time.perf_counter() - t0
+                mm.close()
+                chk = min(nb1, ns)
+                b1_same = bool(np.array_equal(hb1["final"][:chk], ref["final"][:chk]))
+                topk["cpu_baseline"] = {"value": nb1 / bdt, "unit": "queries/s", "cores": th1, "kind": "port",
+                                        "sample": f"reference-shaped restatement (B1) of main_retrieve.go:61-97 + get_metadata.go:46-69 + "
+                                                  f"util.go:48-54 on the first {nb1} queries of the same batch, one query per thread "
+                                                  f"(oracle/oracle.c:orc_score_topk_batch_hashed); forw[4] map built outside the timing",
+                                        "single_thread": {"value": 8 / b1s, "unit": "queries/s", "cores": 1, "sample": "first 8 queries"},
+                                        "final_ranks_match_flat_port": b1_same, "flat_port": flat}
                 t0 = time.perf_counter()
                 _, _, th = pyoracle.score_topk_batch(nd, title, body, mt, mb, q_ptr, q_terms, k, omp=True)
                 odt = time.perf_counter() - t0
@@ -558,7 +680,7 @@ def main() -> None:
                 same = all(hits["doc"][q, :n_hits[q]].tolist() == ref["doc"][q, :ref_n[q]].tolist() for q in range(ns))
                 same &= all(np.array_equal(hits["final"][q, :n_hits[q]], ref["final"][q, :ref_n[q]]) for q in range(ns))
                 topk["cpu_baseline"]["gpu_matches_oracle"] = bool(same)
-                assert same
+                assert same and b1_same
             if shard_error:
                 topk["doc_sharded_error"] = shard_error
             if result:
@@ -572,14 +694,16 @@ def main() -> None:
     # ------------------------------------------------------------------ N>1, last: pipelined doc-range sweep
     # The doc-range split with its exchange hidden behind compute — two topic blocks of K/2, the all-gather of one
     # block in flight (async_op) while the other block is finalized and swept (sharding.sweep_pipelined).  It runs
-    # last and under a watchdog: if this optional variant ever stalls, the line measured so far is still printed.
+    # last and under a watchdog: if this optional variant ever stalls, the line measured so far is printed, marked,
+    # and the process exits non-zero.
     if pr_inputs is not None and pr_inputs[1] % 2 == 0 and os.environ.get("SS_BENCH_NO_PIPELINE") != "1":
         import threading
 
         def bail() -> None:
             result["pipelined_error"] = "watchdog: no result after 150 s"
+            invalid.append("pipelined doc-range sweep stalled")
             emit()
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(150.0, bail)
         dog.daemon = True
@@ -592,32 +716,32 @@ def main() -> None:
                 pst = [engine.PageRankState(g2, d, -1.0, b, max_iter=0) for b in blocks]
                 pex = [sharding.DistExchange(s_, dev, host_staged=rehearsal) for s_ in pst]
                 hnd = sharding.prime_pipelined(pst, pex)
-                sharding.sweep_pipelined(pst, pex, hnd, max(W, 1))
-                barrier()
-                t0 = time.perf_counter()
-                sharding.sweep_pipelined(pst, pex, hnd, K)
-                barrier()
-                dtp = max_over_ranks(time.perf_counter() - t0)
+                dtp, pblocks = timed_blocks(lambda m: sharding.sweep_pipelined(pst, pex, hnd, m))
                 sharding.drain_pipelined(pst, pex, hnd)
                 # the same number of plain sweeps: the ranks must agree (other kernel width: 1e-12, not bitwise)
                 pu = engine.PageRankState(g2, d, -1.0, n_topic, max_iter=0)
-                sharding.iterate([pu], sharding.DistExchange(pu, dev, host_staged=rehearsal), batch=4, max_sweeps=max(W, 1) + K)
+                sharding.iterate([pu], sharding.DistExchange(pu, dev, host_staged=rehearsal), batch=4, max_sweeps=max(W, 1) + N_BLOCKS * K)
                 ids_p, x_p = pst[0].read_local()
                 ids_u, x_u = pu.read_local()
                 ok = bool(np.array_equal(ids_p, ids_u) and np.allclose(x_p, x_u[:kt // 2], rtol=1e-12, atol=0))
                 decomp = result["decompositions"]
                 decomp["doc_range_shards_pipelined"] = {
                     "value": kt * K / dtp if ok else 0.0, "unit": "topic-iterations/s", "ms_per_step": dtp * 1e3 / K, "matches_unpipelined": ok,
+                    "ms_per_step_blocks": summarize(pblocks),
                     "parallelism": f"doc-range shards x{world}, 2 topic blocks, all-gather of one block overlapped with the sweep of the other"}
-                best = max(decomp, key=lambda name: decomp[name]["value"])
-                result["value"] = decomp[best]["value"]
-                result["ms_per_step"] = decomp[best]["ms_per_step"]
-                result["config"]["parallelism"] = decomp[best]["parallelism"]
-                result["config"]["sweeps_per_sec"] = result["value"] / kt
+                # headline = the faster of the two doc-range variants (both run the per-sweep RCCL exchange)
+                best = max(("doc_range_shards", "doc_range_shards_pipelined"), key=lambda name: decomp[name]["value"])
+                if decomp[best]["value"] > 0:
+                    result["value"] = decomp[best]["value"]
+                    result["ms_per_step"] = decomp[best]["ms_per_step"]
+                    result["config"]["parallelism"] = decomp[best]["parallelism"]
+                    result["config"]["sweeps_per_sec"] = result["value"] / kt
+                    if best == "doc_range_shards_pipelined" and invalid:
+                        invalid[:] = [m for m in invalid if not m.startswith("doc-range-sharded sweep failed")]
                 for s_ in pst + [pu]:
                     s_.close()
                 g2.close()
-        except Exception as exc:                       # never lose the bench line to the optional variant
+        except Exception as exc:
             result["pipelined_error"] = repr(exc)
         dog.cancel()
 
@@ -628,6 +752,8 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if invalid:
+        sys.exit(4)
 
 
 if __name__ == "__main__":
