@@ -12,28 +12,31 @@
 //                               Final = (0.33*sqd+0.38*Title+0.29*Body)*100 (:69)
 //   appendSort + cut util.go:48-54, main_retrieve.go:99-103  descending FinalRank, first k
 //
-// Device design (HBM-bound streaming of posting records):
-//   * scoring layout: one 16-byte record per posting {doc u32, w f32, mag f64}; the document's
-//     field magnitude travels with the posting, so a candidate needs NO random gather (a separate
-//     magnitude table costs a 64-byte line per candidate: 8x the posting bytes at config 3).
-//     A magnitude only matters when the doc has a posting of that field among the query terms
-//     (0/(m*q) is 0 or NaN->0 for every m), so nothing else is needed.
-//   * the host plans (it keeps df per term): duplicates -> multiplicities, unknown terms dropped,
-//     each query's doc range cut into slices (size follows the batch: ~1.5x the batch's postings per
-//     resident workgroup slot, 16k..256k postings), longest first; one workgroup per (query, slice).
-//   * k_score_slices first builds the slice's whole window plan in LDS (window j = docs between the
-//     j-th and (j+1)-th cut of the longest list; every other list's cursor at each cut by an
-//     interpolating search), then walks the windows (<= CAP postings, every posting of a doc in one
-//     window); window j+1's records are loaded (one coalesced 16-byte load per lane) while window j
-//     is processed.  Per window: every record parks {float64(w)*multiplicity, magnitude} at its own
-//     index (stride-1 store), claims its doc's slot in an LDS hash table (32-bit CAS, linear
-//     probing) and the slot's per-field "first record" word (32-bit CAS); later records of the
-//     same (doc, field) add into the first one's addend (float32 addends in float64 are exact, so
-//     order is irrelevant) — single-record docs need no float64 atomic.  After one barrier the table
-//     is scanned stride-1: a float pre-filter drops almost every doc against the running
-//     threshold, survivors are scored exactly in float64 and go to the running top-k (threshold
-//     filter + bitonic compaction).  With a PageRank blend the 128-byte prior row of a doc is only
-//     fetched if an upper bound of its score can still enter the top-k.
+// Device design (HBM-bound streaming of 8-byte posting records — exactly SURVEY.md §8d's 8 bytes per posting):
+//   * scoring layout: one 8-byte record per posting {doc u32, impact f32}, impact = float32 UPPER bound of
+//     w / magnitude(doc, field).  The float32 weights and float64 magnitudes stay in the index's own arrays and
+//     are only read for documents that can still enter the top-k.
+//   * the host plans (it keeps df per term): duplicates -> multiplicities, unknown terms dropped, each query's
+//     doc range cut into slices, longest first; one 512-thread workgroup per (query, slice).
+//   * k_score_slices builds the slice's window plan in LDS (window = a doc range holding <= CAP records; every
+//     record of a doc lies in one window), then streams the windows, window j+1's records in flight while window
+//     j is processed.  Per window TWO stages:
+//       1. FILTER (every record; one LDS float atomic, one LDS read, one barrier per window, no probing, no keys):
+//          c = impact * coef(list) is added into slot hash(doc) of a small float table ("sketch": collisions only
+//          make the sum larger); after the barrier every record reads its slot back: the value is an upper bound
+//          of its document's FinalRank.  If it is below the running threshold the record is dropped.  Three
+//          tables rotate so that clearing the slots a window touched needs no second barrier.
+//       2. EXACT (survivors only, batched): surviving records are appended to a pending list {doc, index in
+//          list, list}; when the list fills (or the slice ends) all threads gather the survivors' float32
+//          weights and float64 magnitudes from the index (one round of HBM latency for the whole batch), aggregate
+//          them per document in an LDS hash table (float32 addends in float64: exact, order-free), compute the
+//          reference's float64 arithmetic literally, and feed the running top-k (exact keys, bitonic compaction).
+//     The running threshold starts at a bound known before any posting is read: the index keeps, per term and
+//     field, the k'-th largest impact for k' = 1,2,4..1024, and k' >= k postings of ONE list are k' distinct
+//     documents whose FinalRank is at least their own contribution.
+//     Inputs outside the filter's assumptions (negative or non-finite weights, priors or probabilities, zero
+//     magnitudes under non-zero weights, queryLength <= 0) switch the filter off for the call: every record
+//     survives and stage 2 alone decides — same results, no separate code path.
 //   * k_merge_topk: one workgroup per query merges its slices' top-k lists, re-derives
 //     title/body/pagerank of the k winners by binary search and writes ss_hit rows.
 //   Ties: ascending doc id (Q10); NaN finals last.
@@ -44,6 +47,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <new>
 
 namespace {
 
@@ -55,25 +59,35 @@ constexpr int TPB_M = 256;         // k_merge_topk workgroup
 #ifndef SS_CAP
 #define SS_CAP 1024
 #endif
-constexpr int CAP = SS_CAP;        // postings per window (capacity)
+constexpr int CAP = SS_CAP;        // records per window (capacity)
 #ifndef SS_TARGET_64THS
 #define SS_TARGET_64THS 59
 #endif
-constexpr int TARGET = CAP * SS_TARGET_64THS / 64;   // planned postings per window (944 of 1024; measured best of 832..1008: beyond 960 oversize windows start to cost more than the fewer windows save)
-constexpr int PPT = CAP / TPB;     // records per thread
+constexpr int TARGET = CAP * SS_TARGET_64THS / 64;   // planned records per window
+constexpr int PPT = CAP / TPB;     // records per thread and window
+#ifndef SS_SK_BITS
+#define SS_SK_BITS 11
+#endif
+constexpr int SK = 1 << SS_SK_BITS;                  // slots of one filter table (three rotate)
+#ifndef SS_PC
+#define SS_PC 1152
+#endif
+constexpr int PC = SS_PC;          // pending survivor records = capacity of the exact stage (>= CAP)
+constexpr int PPX = (PC + TPB - 1) / TPB;            // pending records per thread in a flush
 #ifndef SS_HT
 #define SS_HT 2048
 #endif
-constexpr int HT = SS_HT;           // hash slots (multiple of 256; 2048: load factor <= 0.5, measured best of 1536..3072)
-constexpr int EPT = (HT + TPB - 1) / TPB;   // hash entries per thread in the scan
-constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS + 4;   // (term, field) lists per query + 4 phrase result lists
+constexpr int HT = SS_HT;          // exact-stage hash slots (load <= PC/HT)
+constexpr int EPT = (HT + TPB - 1) / TPB;            // hash entries per thread in the scan
+constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS + 4;     // (term, field) lists per query + 4 phrase result lists
 #ifndef SS_TBL_CAP
-#define SS_TBL_CAP 4096
+#define SS_TBL_CAP 2048
 #endif
-constexpr int TBL_CAP = SS_TBL_CAP;      // window-cursor table entries: (n_win+1) * L <= TBL_CAP
+constexpr int TBL_CAP = SS_TBL_CAP;                  // window-cursor table entries: (n_win+1) * L <= TBL_CAP
 constexpr int OFF_CAP = TBL_CAP + TBL_CAP / 4 - (TBL_CAP + TBL_CAP / 4) % 8;   // window-offset table entries: n_win * OS <= OFF_CAP
 constexpr int MAX_WIN = 1023;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t NOREC = 0xFFFFu;                  // "no first record" in a packed ht_rec half
 #ifndef SS_CB_MIN
 #define SS_CB_MIN 512
 #endif
@@ -85,12 +99,14 @@ constexpr uint32_t MAX_SLICES_PER_Q = 256;
 #ifndef SS_SLICE_MIN
 #define SS_SLICE_MIN 16384
 #endif
-constexpr uint64_t SLICE_MIN = SS_SLICE_MIN;     // smallest adaptive slice (postings)
+constexpr uint64_t SLICE_MIN = SS_SLICE_MIN;         // smallest adaptive slice (postings)
+constexpr int KTH_N = 11;                            // k'-th largest impact per term for k' = 2^0 .. 2^10
+static_assert(PC >= CAP && PC < 0xFFFF, "the exact stage must hold one whole window; record indices are 16-bit");
+static_assert(CAP % TPB == 0 && HT % 256 == 0, "sizes");
 
-struct __attribute__((aligned(16))) Post {
+struct __attribute__((aligned(8))) Rec {   // scoring layout: 8 bytes per posting
     uint32_t doc;
-    float w;
-    double mag;
+    float imp;                               // float32 upper bound of w / magnitude(doc, field); 0 where the weight is 0
 };
 
 struct SliceDesc {
@@ -100,8 +116,9 @@ struct SliceDesc {
 };
 
 struct ScoreParams {
-    const uint64_t* t_ptr; const Post* t_post;
-    const uint64_t* b_ptr; const Post* b_post;
+    // per table: term_ptr, scoring records, the index's float32 weights and float64 magnitudes, k'-th largest impacts
+    const uint64_t* t_ptr; const Rec* t_rec; const float* t_w; const double* t_mag; const float* t_kth;
+    const uint64_t* b_ptr; const Rec* b_rec; const float* b_w; const double* b_mag; const float* b_kth;
     // positional postings (phrase search, retrieval/phrase.go): pos_ptr[P+1] into pos[] per table, or null
     const uint64_t* t_pos_ptr; const float* t_pos;
     const uint64_t* b_pos_ptr; const float* b_pos;
@@ -110,7 +127,8 @@ struct ScoreParams {
     // four doc-sorted record lists per query (body/title sums found via the driver's body/title postings)
     const uint32_t* ph_off; const uint32_t* ph_terms; const uint32_t* ph_drv;
     const uint32_t* x_off;     // [n_q+1] capacity offsets of the phrase result lists
-    Post* x_list[4];           // 0: body sums (driver body pass), 1: title sums (driver body pass), 2: body (title pass), 3: title (title pass)
+    Rec* x_rec[4];             // 0: body sums (driver body pass), 1: title sums (driver body pass), 2: body (title pass), 3: title (title pass)
+    float* x_w[4];             // the float32 weight sums themselves (phrase.go:59,69,73,83,90)
     uint32_t* x_cnt;           // [n_q][4]
     const double* prior;       // [n_docs][k_topics] or null
     int32_t k_topics;
@@ -125,6 +143,8 @@ struct ScoreParams {
     const uint32_t* order;     // launch order -> slice index (longest first)
     int32_t k;
     int32_t cb;                // candidate buffer entries (power of two >= 2k)
+    int32_t kth_j;             // smallest j with 2^j >= k
+    int32_t exact_all;         // 1: the filter's assumptions do not hold for this call: every record goes to the exact stage
     uint64_t* so_key; uint32_t* so_doc; uint32_t* so_cnt;   // per slice top-k
     ss_hit* hits; int32_t* n_hits;
 };
@@ -133,20 +153,26 @@ using ss::fkey;
 using ss::funkey;
 using ss::better;
 
-__device__ __forceinline__ uint64_t lower_bound_post(const Post* __restrict__ a, uint64_t lo, uint64_t hi, uint32_t v) {
+// kernel arguments stay in scalar registers only while they are never indexed with a run-time value
+__device__ __forceinline__ Rec* x_rec_of(const ScoreParams& p, int x) { return x == 0 ? p.x_rec[0] : x == 1 ? p.x_rec[1] : x == 2 ? p.x_rec[2] : p.x_rec[3]; }
+__device__ __forceinline__ float* x_w_of(const ScoreParams& p, int x) { return x == 0 ? p.x_w[0] : x == 1 ? p.x_w[1] : x == 2 ? p.x_w[2] : p.x_w[3]; }
+
+// Lists are addressed by the absolute address of their first record (regular posting lists and the
+// per-query phrase result lists alike); explicit global address space keeps the loads global_load_*.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // native vector: loads as one global_load_dwordx2
+typedef const u32x2 __attribute__((address_space(1)))* gptr_u2;
+typedef const uint32_t __attribute__((address_space(1)))* gptr_u32;
+typedef const float __attribute__((address_space(1)))* gptr_f32;
+__device__ __forceinline__ u32x2 load_rec(uint64_t list_addr, uint64_t idx) { return *(gptr_u2)(list_addr + idx * sizeof(Rec)); }
+__device__ __forceinline__ uint32_t load_doc(uint64_t list_addr, uint64_t idx) { return *(gptr_u32)(list_addr + idx * sizeof(Rec)); }
+__device__ __forceinline__ float load_w(uint64_t w_addr, uint64_t idx) { return *(gptr_f32)(w_addr + idx * sizeof(float)); }
+__device__ __forceinline__ uint64_t lower_bound_rec(const Rec* __restrict__ a, uint64_t lo, uint64_t hi, uint32_t v) {
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
         if (a[mid].doc < v) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
-// Lists are addressed by the absolute address of their first record (regular posting lists and the
-// per-query phrase result lists alike); explicit global address space keeps the loads global_load_*.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: loads as one global_load_dwordx4
-typedef const u32x4 __attribute__((address_space(1)))* gptr_u4;
-typedef const uint32_t __attribute__((address_space(1)))* gptr_u32;
-__device__ __forceinline__ u32x4 load_rec(uint64_t list_addr, uint64_t idx) { return *(gptr_u4)(list_addr + idx * sizeof(Post)); }
-__device__ __forceinline__ uint32_t load_doc(uint64_t list_addr, uint64_t idx) { return *(gptr_u32)(list_addr + idx * sizeof(Post)); }
 __device__ __forceinline__ uint32_t lower_bound_addr(uint64_t list_addr, uint32_t lo, uint32_t hi, uint32_t v) {
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -204,18 +230,20 @@ __device__ __forceinline__ double topic_dot(const double* __restrict__ prior, co
     return sqd;
 }
 
-#ifdef SS_DIAG
-// Diagnostic build only (make DIAG=1): per-phase s_memtime sums of one wave per block, printed by ss_scorer_destroy.
-__device__ unsigned long long g_stamps[16];
-#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define STAMP(var) do { } while (0)
-#endif
-
 // Workgroup barrier that does NOT drain the vector-memory counter: the next window's records stay
 // in flight across it (a __syncthreads() would emit s_waitcnt vmcnt(0), cdna_hip_programming.md §5
 // "Pipelining across barriers").  LDS traffic is complete after lgkmcnt(0).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifdef SS_DIAG
+// Diagnostic build only (make DIAG=1): event counts and s_memtime sums of wave 0 of every slice, printed by ss_scorer_destroy.
+__device__ unsigned long long g_diag[24];
+#define DIAG_ADD(i, v) do { if ((threadIdx.x) == 0) atomicAdd(&g_diag[i], (unsigned long long)(v)); } while (0)
+#define DIAG_NOW(var) unsigned long long var; do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DIAG_ADD(i, v) do { } while (0)
+#define DIAG_NOW(var) do { } while (0)
+#endif
 
 // ---- running top-k in LDS ------------------------------------------------------
 struct TopK {
@@ -223,7 +251,9 @@ struct TopK {
     uint32_t* doc;    // [cb]
     uint32_t* count;  // shared scalar (may run past cb while an overflow is pending)
     uint64_t* thr;    // shared scalar: admit keys >= thr
-    float* thr_f;     // shared scalar: float lower bound of the threshold score (-inf while fewer than k)
+    float* thr_f;     // shared scalar: float lower bound of the threshold score (-inf: no threshold)
+    uint64_t thr0;    // floor of the threshold known before any posting was read (0 = none)
+    float thr0_f;
     uint32_t cb;
 };
 
@@ -231,6 +261,7 @@ struct TopK {
 // (An enumeration sort — every entry counts the entries that precede it, 2 barriers instead of 38 — measured
 // 25 % slower end to end: 65k broadcast LDS reads cost more than the bitonic network's barriers.)
 __device__ void topk_compact(const TopK& tk, int k) {
+    DIAG_ADD(4, 1);
     lds_barrier();
     const uint32_t nthr = blockDim.x;
     const uint32_t n = min(*tk.count, tk.cb);
@@ -256,9 +287,12 @@ __device__ void topk_compact(const TopK& tk, int k) {
         const uint32_t keep = min(n, (uint32_t)k);
         *tk.count = keep;
         const bool full = keep == (uint32_t)k;
-        *tk.thr = full ? tk.key[k - 1] : 0ull;
+        uint64_t t = full ? tk.key[k - 1] : 0ull;
         float tf = -INFINITY;
-        if (full && tk.key[k - 1] != 0ull) tf = __double2float_rd(funkey(tk.key[k - 1]));
+        if (full && t != 0ull) tf = __double2float_rd(funkey(t));
+        if (tk.thr0 > t) { t = tk.thr0; tf = tk.thr0_f; }
+        else if (tk.thr0_f > tf) tf = tk.thr0_f;
+        *tk.thr = t;
         *tk.thr_f = tf;
     }
     lds_barrier();
@@ -268,86 +302,356 @@ __device__ void topk_compact(const TopK& tk, int k) {
 #ifndef SS_WGS_PER_CU
 #define SS_WGS_PER_CU 2
 #endif
+struct ScoreLds {                     // byte offsets into the dynamic LDS block
+    size_t s_rec, l_rec, l_w, sc64, cd_key, cd_doc, ht_key, ht_rec, sk, tbl, l_mult, l_field, f_cur, f_nxt, l_coef, sc32, off, total;
+};
+__host__ __device__ inline ScoreLds score_lds_layout(int cb) {
+    ScoreLds o{};
+    size_t p = 0;
+    o.s_rec = p;   p += (size_t)PC * 16;            // pending survivors {doc, index, list, -}; rewritten in place as {addend f64, magnitude f64}
+    o.l_rec = p;   p += (size_t)MAXL * 8;
+    o.l_w = p;     p += (size_t)MAXL * 8;
+    o.sc64 = p;    p += 4 * 8;
+    o.cd_key = p;  p += (size_t)cb * 8;
+    o.cd_doc = p;  p += (size_t)cb * 4;
+    o.ht_key = p;  p += (size_t)HT * 4;
+    o.ht_rec = p;  p += (size_t)HT * 4;
+    o.sk = p;      p += (size_t)3 * SK * 4;
+    o.tbl = p;     p += (size_t)TBL_CAP * 4;
+    o.l_mult = p;  p += (size_t)MAXL * 4;
+    o.l_field = p; p += (size_t)MAXL * 4;
+    o.f_cur = p;   p += (size_t)MAXL * 4;
+    o.f_nxt = p;   p += (size_t)MAXL * 4;
+    o.l_coef = p;  p += (size_t)MAXL * 4;
+    o.sc32 = p;    p += 16 * 4;
+    o.off = p;     p += (size_t)OFF_CAP * 2;
+    o.total = (p + 15) & ~(size_t)15;
+    return o;
+}
+
+// The workgroup's LDS arrays as typed pointers (passed by reference into force-inlined helpers: after inlining they
+// are plain SSA values derived from the LDS block, so every access stays a ds_* instruction).
+struct SliceLds {
+    double2* s_rec;      // [PC] exact stage: {addend (summed: BodyRank/TitleRank of the doc), magnitude}
+    uint4* pend;         // [PC] the same bytes while pending: {doc, index in list, list, -}
+    uint64_t* l_rec;     // [MAXL] address of the list's first record
+    uint64_t* l_w;       // [MAXL] address of the list's first float32 weight
+    uint32_t* ht_key;    // [HT]
+    uint32_t* ht_rec;    // [HT] first body record (low 16 bits) and first title record (high 16) of the slot's doc
+    float* sk;           // [3][SK] filter tables
+    uint32_t* tbl;       // [TBL_CAP] cursor of list l at the start of window j: tbl[j*L+l]
+    uint32_t* l_mult;    // [MAXL] multiplicity of the term in the query
+    uint32_t* l_field;   // [MAXL] 0 = body, 1 = title
+    uint32_t* f_cur;     // [MAXL] oversize fallback: sub-window start
+    uint32_t* f_nxt;     // [MAXL] oversize fallback: sub-window end
+    float* l_coef;       // [MAXL] filter coefficient: upper bound of (38|29)*mult/sqrt(queryLength)
+    uint16_t* off;       // [OFF_CAP] offset of list l inside window j: off[j*OS+l], count at [j*OS+OS-1]
+    uint32_t* overflow;  // shared scalar
+};
+struct SliceQuery {      // per-query constants of the exact stage
+    double qmag, sqd_ub;
+    float qmag_f, sqd_ub_f;
+    const double* probs;
+};
+
+// records of one window: raw 8-byte vectors (one global_load_dwordx2 per posting), their list, index in the list
+// and filter coefficient.  L <= 6: the lists' coefficients come in registers (cf).
+struct Coef6 { float c0, c1, c2, c3, c4, c5; };
+__device__ __forceinline__ void load_window(const SliceLds& S, int j, int L, int OS, int tid, const Coef6 cf,
+                                            u32x2 (&rec)[PPT], uint32_t (&rl)[PPT], uint32_t (&ri)[PPT], float (&rc)[PPT]) {
+    const uint32_t* tbl_j = S.tbl + j * L;
+    if (L <= 6) {
+        // the whole offset row in one 16-byte LDS read; list of record i by comparisons in registers
+        const uint4 o = *reinterpret_cast<const uint4*>(S.off + j * 8);
+        const uint32_t o1 = o.x >> 16, o2 = o.y & 0xFFFFu, o3 = o.y >> 16, o4 = o.z & 0xFFFFu, o5 = o.z >> 16, n = o.w >> 16;
+#pragma unroll
+        for (int r = 0; r < PPT; r++) {
+            const uint32_t i = tid + r * TPB;
+            rl[r] = EMPTY;
+            if (i < n) {
+                uint32_t l = 0, ol = 0;     // padding entries are 0xFFFF: never <= i
+                float c = cf.c0;
+                if (i >= o1) { l = 1; ol = o1; c = cf.c1; }
+                if (i >= o2) { l = 2; ol = o2; c = cf.c2; }
+                if (i >= o3) { l = 3; ol = o3; c = cf.c3; }
+                if (i >= o4) { l = 4; ol = o4; c = cf.c4; }
+                if (i >= o5) { l = 5; ol = o5; c = cf.c5; }
+                ri[r] = tbl_j[l] + (i - ol);
+                rec[r] = load_rec(S.l_rec[l], ri[r]);
+                rl[r] = l;
+                rc[r] = c;
+            }
+        }
+    } else {
+        const uint16_t* off_j = S.off + j * OS;
+        const uint32_t n = off_j[OS - 1];
+#pragma unroll
+        for (int r = 0; r < PPT; r++) {
+            const uint32_t i = tid + r * TPB;
+            rl[r] = EMPTY;
+            if (i < n) {
+                int lo = 0, hi = L;            // largest l with off[l] <= i
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (off_j[mid] <= i) lo = mid; else hi = mid;
+                }
+                ri[r] = tbl_j[lo] + (i - off_j[lo]);
+                rec[r] = load_rec(S.l_rec[lo], ri[r]);
+                rl[r] = lo;
+                rc[r] = S.l_coef[lo];
+            }
+        }
+    }
+}
+
+// ---- exact stage -----------------------------------------------------------------------------------------------
+// score every touched doc (get_metadata.go:31-69), reset the table, filter into the running top-k.
+// All LDS reads of a thread's entries are issued together; empty slots read as zero sums and drop out.
+__device__ __forceinline__ void scan_table(const SliceLds& S, const TopK& tk, const SliceQuery& Q, const ScoreParams& p, int tid) {
+    uint64_t e_key[EPT];
+    uint32_t e_doc[EPT];
+    double2 tb[EPT];
+    uint32_t fr[EPT];
+    const uint64_t thr0 = *tk.thr;
+    const float thr_f = *tk.thr_f;
+#pragma unroll
+    for (int r = 0; r < EPT; r++) {
+        const int hh = tid + r * TPB;
+        e_doc[r] = EMPTY;
+        fr[r] = EMPTY;
+        if (HT % TPB == 0 || hh < HT) {
+            e_doc[r] = S.ht_key[hh];
+            fr[r] = S.ht_rec[hh];
+        }
+    }
+    double mt[EPT], mb[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; r++) {
+        const int hh = tid + r * TPB;
+        // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
+        double2 rb = make_double2(0.0, 1.0), rt = make_double2(0.0, 1.0);
+        const uint32_t ib = fr[r] & 0xFFFFu, it = fr[r] >> 16;
+        if (e_doc[r] != EMPTY) {
+            if (ib != NOREC) rb = S.s_rec[ib];
+            if (it != NOREC) rt = S.s_rec[it];
+            S.ht_key[hh] = EMPTY;
+            S.ht_rec[hh] = EMPTY;
+        }
+        tb[r] = make_double2(rb.x, rt.x);
+        mb[r] = rb.y;
+        mt[r] = rt.y;
+    }
+#pragma unroll
+    for (int r = 0; r < EPT; r++) {
+        e_key[r] = 0;
+        if (e_doc[r] != EMPTY) {
+            const double B = tb[r].x, T = tb[r].y;
+            // cheap float estimate first: most docs of a batch are below the running threshold by now.
+            // Skipped only if the estimate, with a 1e-4 relative margin, is clearly below; anything
+            // non-finite falls through to the exact path.
+            // v_rcp_f32 (1 ulp) instead of an IEEE division: the 1e-4 margin below covers it; 0*inf = NaN falls through
+            const float ea = 38.0f * ((float)T * __builtin_amdgcn_rcpf((float)mt[r] * Q.qmag_f)), eb = 29.0f * ((float)B * __builtin_amdgcn_rcpf((float)mb[r] * Q.qmag_f)),
+                        ec = 33.0f * Q.sqd_ub_f;
+            if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) { e_doc[r] = EMPTY; continue; }
+            double title, body, fin;
+            if (Q.probs) {
+                // the prior row (128 B) is only fetched if the doc can still make the top-k:
+                // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
+                final_rank(T, B, mt[r], mb[r], Q.qmag, Q.sqd_ub, title, body, fin);
+                if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt[r], mb[r], Q.qmag, topic_dot(p.prior, Q.probs, p.k_topics, e_doc[r]), title, body, fin);
+                else e_doc[r] = EMPTY;
+            } else {
+                final_rank(T, B, mt[r], mb[r], Q.qmag, 0.0, title, body, fin);
+            }
+            e_key[r] = fkey(fin);
+        }
+    }
+    // threshold filter into the candidate buffer; overflow -> compact and retry
+    for (;;) {
+        const uint64_t thr = *tk.thr;
+#pragma unroll
+        for (int r = 0; r < EPT; r++) {
+            if (e_doc[r] != EMPTY) {
+                if (e_key[r] >= thr) {
+                    const uint32_t i = atomicAdd(tk.count, 1u);
+                    if (i < tk.cb) { tk.key[i] = e_key[r]; tk.doc[i] = e_doc[r]; e_doc[r] = EMPTY; }
+                    else *S.overflow = 1;
+                } else {
+                    e_doc[r] = EMPTY;
+                }
+            }
+        }
+        lds_barrier();
+        if (!*S.overflow) break;
+        topk_compact(tk, p.k);         // raises thr; count back to <= k
+        if (tid == 0) *S.overflow = 0;
+        lds_barrier();
+    }
+}
+
+// The pending survivors pend[0, n) -> per-document sums -> FinalRank -> running top-k.  All threads call with the
+// same n (<= PC).  On return the pending list is empty and the hash table clean.
+__device__ __forceinline__ void flush_pending(const SliceLds& S, const TopK& tk, const SliceQuery& Q, const ScoreParams& p, int tid, uint32_t n) {
+    DIAG_ADD(2, 1);
+    DIAG_ADD(3, n);
+    DIAG_NOW(t_f0);
+    uint32_t pdoc[PPX], pl[PPX];
+    float pw[PPX];
+    double pm[PPX];
+#pragma unroll
+    for (int r = 0; r < PPX; r++) {
+        const uint32_t i = tid + r * TPB;
+        pl[r] = EMPTY;
+        if (i < n) {
+            const uint4 e = S.pend[i];
+            pdoc[r] = e.x;
+            pl[r] = e.z;
+            // one round of memory latency for the whole batch: the survivor's float32 weight and its doc's float64 magnitude
+            pw[r] = load_w(S.l_w[e.z], e.y);
+            pm[r] = (S.l_field[e.z] ? p.t_mag : p.b_mag)[e.x];
+        }
+    }
+    lds_barrier();                                  // every pending entry has been read: the bytes may be rewritten
+    // accumulate per doc (main_retrieve.go:61-69,170-187); float32 addends in float64: exact, any order.
+    // A table slot names, per field, the FIRST record of its doc (one 32-bit CAS on the packed word); the rare later
+    // records of the same (doc, field) add their addend into the first one's.
+#pragma unroll
+    for (int r = 0; r < PPX; r++) {
+        const uint32_t l = pl[r];
+        if (l != EMPTY) {
+            const uint32_t i = tid + r * TPB;
+            uint32_t h = (((pdoc[r] * 2654435761u) >> 20) * (uint32_t)(HT / 256)) >> 4;      // 12 hash bits -> [0, HT)
+            for (;;) {
+                const uint32_t prev = atomicCAS(&S.ht_key[h], EMPTY, pdoc[r]);
+                if (prev == EMPTY || prev == pdoc[r]) break;
+                h = h + 1 == HT ? 0 : h + 1;
+            }
+            const uint32_t field = S.l_field[l];        // 0 = body (low half), 1 = title (high half)
+            const double v = (double)pw[r] * (double)S.l_mult[l];
+            S.s_rec[i] = make_double2(v, pm[r]);
+            asm volatile("" ::: "memory");         // program order: parked before it can be named (LDS runs a wave's operations in order)
+            uint32_t old = S.ht_rec[h], first;
+            for (;;) {
+                first = field ? old >> 16 : old & 0xFFFFu;
+                if (first != NOREC) break;
+                const uint32_t want = field ? (old & 0xFFFFu) | (i << 16) : (old & 0xFFFF0000u) | i;
+                const uint32_t prev = atomicCAS(&S.ht_rec[h], old, want);
+                if (prev == old) break;            // first stays NOREC: this record is the first of its (doc, field)
+                old = prev;
+            }
+            if (first != NOREC) atomicAdd(&S.s_rec[first].x, v);
+        }
+    }
+    lds_barrier();
+    scan_table(S, tk, Q, p, tid);
+    DIAG_NOW(t_f1);
+    DIAG_ADD(8, t_f1 - t_f0);
+}
+
 __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // Every record of the window parks {its addend float64(w)*multiplicity, its doc's field magnitude} at its own index
-    // (a stride-1 store).  A table slot names, per field, the FIRST record of that doc and field (one 32-bit CAS each);
-    // the rare later records of the same (doc, field) add their addend into the first one's.  So the 95 % of docs with
-    // one record per field cost no float64 atomic (the dearest LDS operation) and there is no per-slot
-    // accumulator array.
-    double2* s_rec = reinterpret_cast<double2*>(smem);                 // [CAP] {addend (summed: BodyRank/TitleRank of the doc), magnitude}
-    uint64_t* l_base = reinterpret_cast<uint64_t*>(s_rec + CAP);       // [MAXL] address of the list's first record
-    double* l_mult = reinterpret_cast<double*>(l_base + MAXL);         // [MAXL]
-    uint64_t* sc64 = reinterpret_cast<uint64_t*>(l_mult + MAXL);       // [2]: thr
-    uint64_t* cd_key = sc64 + 2;                                       // [cb]
-    uint32_t* cd_doc = reinterpret_cast<uint32_t*>(cd_key + p.cb);     // [cb]
-    uint32_t* ht_key = cd_doc + p.cb;                                  // [HT]
-    uint32_t* tbl = ht_key + HT;                                       // [TBL_CAP] cursor of list l at the start of window j: tbl[j*L+l]
-    uint32_t* l_field = tbl + TBL_CAP;                                 // [MAXL]
-    uint32_t* f_cur = l_field + MAXL;                                  // [MAXL] oversize fallback: sub-window start
-    uint32_t* f_nxt = f_cur + MAXL;                                    // [MAXL] oversize fallback: sub-window end
-    uint32_t* sc32 = f_nxt + MAXL;                                     // [8] scalars
-    uint32_t* ht_rec = sc32 + 8;                                       // [HT][2] first body record, first title record of the slot's doc (EMPTY = none)
-    uint16_t* off = reinterpret_cast<uint16_t*>(ht_rec + 2 * HT);      // [OFF_CAP] offset of list l inside window j: off[j*OS+l], count at [j*OS+OS-1]
+    const ScoreLds lo_ = score_lds_layout(p.cb);
+    uint64_t* sc64 = reinterpret_cast<uint64_t*>(smem + lo_.sc64);        // [0]: thr
+    uint64_t* cd_key = reinterpret_cast<uint64_t*>(smem + lo_.cd_key);    // [cb]
+    uint32_t* cd_doc = reinterpret_cast<uint32_t*>(smem + lo_.cd_doc);    // [cb]
+    uint32_t* sc32 = reinterpret_cast<uint32_t*>(smem + lo_.sc32);        // [16] scalars
+    SliceLds S;
+    S.s_rec = reinterpret_cast<double2*>(smem + lo_.s_rec);
+    S.pend = reinterpret_cast<uint4*>(smem + lo_.s_rec);
+    S.l_rec = reinterpret_cast<uint64_t*>(smem + lo_.l_rec);
+    S.l_w = reinterpret_cast<uint64_t*>(smem + lo_.l_w);
+    S.ht_key = reinterpret_cast<uint32_t*>(smem + lo_.ht_key);
+    S.ht_rec = reinterpret_cast<uint32_t*>(smem + lo_.ht_rec);
+    S.sk = reinterpret_cast<float*>(smem + lo_.sk);
+    S.tbl = reinterpret_cast<uint32_t*>(smem + lo_.tbl);
+    S.l_mult = reinterpret_cast<uint32_t*>(smem + lo_.l_mult);
+    S.l_field = reinterpret_cast<uint32_t*>(smem + lo_.l_field);
+    S.f_cur = reinterpret_cast<uint32_t*>(smem + lo_.f_cur);
+    S.f_nxt = reinterpret_cast<uint32_t*>(smem + lo_.f_nxt);
+    S.l_coef = reinterpret_cast<float*>(smem + lo_.l_coef);
+    S.off = reinterpret_cast<uint16_t*>(smem + lo_.off);
+    S.overflow = &sc32[1];
 
     uint32_t& cand_count = sc32[0];
-    uint32_t& overflow = sc32[1];
     float* thr_f_s = reinterpret_cast<float*>(&sc32[2]);
-    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], thr_f_s, (uint32_t)p.cb};
+    uint32_t* surv_cnt = &sc32[4];                  // [3] survivors appended by window j: surv_cnt[j % 3]
+    uint32_t* thr0_bits = &sc32[8];                 // slice set-up: max of the lists' bounds (non-negative floats order like their bits)
 
-    const int tid = threadIdx.x;
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)ts; (void)acc;
-    STAMP(ts[7]);
+    const int tid = threadIdx.x, lane = tid & 63;
+    DIAG_NOW(t_k0);
     const uint32_t slice_id = p.order[blockIdx.x];
     const SliceDesc sd = p.slices[slice_id];
     const uint32_t q = sd.q;
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
     const bool has_phrase = p.ph_off && p.ph_off[q + 1] > p.ph_off[q];
     const int L = (int)(2 * nd) + (has_phrase ? 4 : 0);
-    const double qmag = p.qmag[q];
-    const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
-    const double sqd_ub = probs ? p.sqd_ub[q] : 0.0;
-    const float sqd_ub_f = probs ? __double2float_ru(sqd_ub) : 0.0f;
-    const float qmag_f = (float)qmag;
+    SliceQuery Q;
+    Q.qmag = p.qmag[q];
+    Q.probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
+    Q.sqd_ub = Q.probs ? p.sqd_ub[q] : 0.0;
+    Q.sqd_ub_f = Q.probs ? __double2float_ru(Q.sqd_ub) : 0.0f;
+    Q.qmag_f = (float)Q.qmag;
+    // filter: upper bound of the prior's share of FinalRank, 0.33*sqd*100 (get_metadata.go:69), with the filter's margin
+    const float r_ub = Q.probs ? __double2float_ru(33.0 * Q.sqd_ub * (1.0 + 0x1p-12)) : 0.0f;
+    const bool exact_all = p.exact_all != 0;
 
-    for (int i = tid; i < HT; i += TPB) { ht_key[i] = EMPTY; ht_rec[2 * i] = EMPTY; ht_rec[2 * i + 1] = EMPTY; }
-    if (tid == 0) { cand_count = 0; overflow = 0; sc64[0] = 0ull; *thr_f_s = -INFINITY; }
+    for (int i = tid; i < HT; i += TPB) { S.ht_key[i] = EMPTY; S.ht_rec[i] = EMPTY; }
+    for (int i = tid; i < 3 * SK; i += TPB) S.sk[i] = 0.0f;
+    if (tid == 0) { cand_count = 0; *S.overflow = 0; sc64[0] = 0ull; *thr_f_s = -INFINITY; surv_cnt[0] = surv_cnt[1] = surv_cnt[2] = 0; *thr0_bits = 0; }
 
     // ---- slice set-up: where every list enters and leaves the slice's doc range ----
-    uint32_t* t_lo = tbl;                   // row 0 of the table
-    uint32_t* t_hi = f_nxt;                 // parked here until n_win is known
+    uint32_t* t_lo = S.tbl;                 // row 0 of the table
+    uint32_t* t_hi = S.f_nxt;               // parked here until n_win is known
+    __syncthreads();
     if (tid < L) {
         const int field = tid & 1;                     // 0 = body, 1 = title (also for the phrase lists)
-        uint64_t addr;
-        uint32_t len;
-        double mult;
+        uint64_t addr, waddr;
+        uint32_t len, mult;
+        float kth = 0.0f;
         if (tid < (int)(2 * nd)) {
             const uint32_t term = p.dterm[t0 + (tid >> 1)];
             const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
             const uint64_t p0 = ptr[term];
-            addr = (uint64_t)((field ? p.t_post : p.b_post) + p0);
+            addr = (uint64_t)((field ? p.t_rec : p.b_rec) + p0);
+            waddr = (uint64_t)((field ? p.t_w : p.b_w) + p0);
             len = (uint32_t)(ptr[term + 1] - p0);
-            mult = (double)p.dmult[t0 + (tid >> 1)];
+            mult = p.dmult[t0 + (tid >> 1)];
+            kth = (field ? p.t_kth : p.b_kth)[(size_t)term * KTH_N + p.kth_j];
         } else {
             // phrase contributions are appended once, after the terms (main_retrieve.go:73-78)
             const int x = tid - (int)(2 * nd);
-            addr = (uint64_t)(p.x_list[x] + p.x_off[q]);
+            addr = (uint64_t)(x_rec_of(p, x) + p.x_off[q]);
+            waddr = (uint64_t)(x_w_of(p, x) + p.x_off[q]);
             len = p.x_cnt[(size_t)q * 4 + x];
-            mult = 1.0;
+            mult = 1;
         }
-        l_base[tid] = addr;
-        l_mult[tid] = mult;
-        l_field[tid] = field;
-        f_cur[tid] = len;
+        S.l_rec[tid] = addr;
+        S.l_w[tid] = waddr;
+        S.l_mult[tid] = mult;
+        S.l_field[tid] = field;
+        S.f_cur[tid] = len;
+        // FinalRank's share of one record is (38|29) * mult * (w/mag) / sqrt(queryLength) (get_metadata.go:57-58,69).
+        // Filter coefficient: rounded up with a 2^-12 margin that covers every float rounding of the filter's sums;
+        // threshold floor: the same rounded down, times the list's k'-th largest impact (k' >= k distinct documents
+        // score at least their own contribution when every other addend is >= 0).
+        const double share = (field ? 38.0 : 29.0) * (double)mult / Q.qmag;
+        S.l_coef[tid] = __double2float_ru(share * (1.0 + 0x1p-12));
+        if (!exact_all && kth > 0.0f) {
+            const float floor_l = __double2float_rd(share * (1.0 - 0x1p-12) * (double)kth);
+            if (floor_l > 0.0f) atomicMax(thr0_bits, __float_as_uint(floor_l));
+        }
     }
     __syncthreads();
     if (tid < 2 * L) {                      // the two bounds of a list by two threads: independent search chains
         const int l = tid >> 1;
-        if (tid & 1) t_hi[l] = sd.dhi == 0xFFFFFFFFu ? f_cur[l] : lower_bound_interp(l_base[l], 0, f_cur[l], sd.dhi);
-        else t_lo[l] = sd.dlo == 0 ? 0u : lower_bound_interp(l_base[l], 0, f_cur[l], sd.dlo);
+        if (tid & 1) t_hi[l] = sd.dhi == 0xFFFFFFFFu ? S.f_cur[l] : lower_bound_interp(S.l_rec[l], 0, S.f_cur[l], sd.dhi);
+        else t_lo[l] = sd.dlo == 0 ? 0u : lower_bound_interp(S.l_rec[l], 0, S.f_cur[l], sd.dlo);
     }
     __syncthreads();
+    const float thr0_f = __uint_as_float(*thr0_bits);
+    const uint64_t thr0_key = thr0_f > 0.0f ? fkey((double)thr0_f) : 0ull;
+    const TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], thr_f_s, thr0_key, thr0_f > 0.0f ? thr0_f : -INFINITY, (uint32_t)p.cb};
+    if (tid == 0 && thr0_f > 0.0f) { sc64[0] = thr0_key; *thr_f_s = thr0_f; }
     // every thread: total, driver (longest list in the slice), number of windows
     uint32_t tot = 0, drv = 0, drv_len = 0;
     for (int l = 0; l < L; l++) {
@@ -365,258 +669,168 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     // window j covers docs [b_j, b_{j+1}), b_j = doc of the driver's record at j/n_win of its run:
     // all cursors are known up front (no per-window serial planning; windows fill evenly because
     // the other lists simply contribute whatever falls into the driver's doc range)
-    const uint64_t drv_addr = l_base[drv];
+    const uint64_t drv_addr = S.l_rec[drv];
     for (int idx = tid; idx < (n_win - 1) * L; idx += TPB) {
         const int j = idx / L + 1, l = idx - (j - 1) * L;
         const uint32_t b = load_doc(drv_addr, t_lo[drv] + (uint64_t)j * drv_len / n_win);
-        tbl[j * L + l] = lower_bound_interp(l_base[l], t_lo[l], t_hi[l], b);
+        S.tbl[j * L + l] = lower_bound_interp(S.l_rec[l], t_lo[l], t_hi[l], b);
     }
     __syncthreads();
-    if (tid < L && n_win) tbl[n_win * L + tid] = t_hi[tid];
+    if (tid < L && n_win) S.tbl[n_win * L + tid] = t_hi[tid];
     __syncthreads();
     for (int j = tid; j < n_win; j += TPB) {
         uint32_t run = 0;
         for (int l = 0; l < OS - 1; l++) {
-            off[j * OS + l] = l < L ? (uint16_t)min(run, 0xFFFFu) : (uint16_t)0xFFFFu;
-            if (l < L) run += tbl[(j + 1) * L + l] - tbl[j * L + l];
+            S.off[j * OS + l] = l < L ? (uint16_t)min(run, 0xFFFFu) : (uint16_t)0xFFFFu;
+            if (l < L) run += S.tbl[(j + 1) * L + l] - S.tbl[j * L + l];
         }
-        off[j * OS + OS - 1] = (uint16_t)min(run, 0xFFFFu);      // > CAP: oversize window (fallback below)
+        S.off[j * OS + OS - 1] = (uint16_t)min(run, 0xFFFFu);      // > CAP: oversize window (fallback below)
     }
     __syncthreads();
 
-    // records of one window: raw 16-byte vectors (one global_load_dwordx4 per posting)
-    u32x4 rec[PPT];
-    uint32_t rl[PPT];
-    auto load_window = [&](int j) {
-        const uint32_t* tbl_j = tbl + j * L;
-        if (L <= 6) {
-            // the whole offset row in one 16-byte LDS read; list of record i by comparisons in registers
-            const uint4 o = *reinterpret_cast<const uint4*>(off + j * 8);
-            const uint32_t o1 = o.x >> 16, o2 = o.y & 0xFFFFu, o3 = o.y >> 16, o4 = o.z & 0xFFFFu, o5 = o.z >> 16, n = o.w >> 16;
+    u32x2 rec[PPT];
+    uint32_t rl[PPT], ri[PPT];
+    float rc[PPT];
+    Coef6 cf{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (L <= 6) {           // entries past L are never selected (their offsets are 0xFFFF)
+        cf.c0 = S.l_coef[0]; cf.c1 = S.l_coef[1]; cf.c2 = S.l_coef[2];
+        cf.c3 = S.l_coef[3]; cf.c4 = S.l_coef[4]; cf.c5 = S.l_coef[5];
+    }
 #pragma unroll
-            for (int r = 0; r < PPT; r++) {
-                const uint32_t i = tid + r * TPB;
-                rl[r] = EMPTY;
-                if (i < n) {
-                    uint32_t l = 0, ol = 0;     // padding entries are 0xFFFF: never <= i
-                    if (i >= o1) { l = 1; ol = o1; }
-                    if (i >= o2) { l = 2; ol = o2; }
-                    if (i >= o3) { l = 3; ol = o3; }
-                    if (i >= o4) { l = 4; ol = o4; }
-                    if (i >= o5) { l = 5; ol = o5; }
-                    rec[r] = load_rec(l_base[l], (uint64_t)tbl_j[l] + (i - ol));
-                    rl[r] = l;
-                }
-            }
-        } else {
-            const uint16_t* off_j = off + j * OS;
-            const uint32_t n = off_j[OS - 1];
-#pragma unroll
-            for (int r = 0; r < PPT; r++) {
-                const uint32_t i = tid + r * TPB;
-                rl[r] = EMPTY;
-                if (i < n) {
-                    int lo = 0, hi = L;            // largest l with off[l] <= i
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (off_j[mid] <= i) lo = mid; else hi = mid;
-                    }
-                    rec[r] = load_rec(l_base[lo], (uint64_t)tbl_j[lo] + (i - off_j[lo]));
-                    rl[r] = lo;
-                }
-            }
-        }
-    };
-    // accumulate the loaded records per doc (main_retrieve.go:61-69,170-187); float32 addends in float64: exact.
-    // (probing a thread's records one after the other measured 27 % faster than issuing their CAS together)
-    auto insert_records = [&]() {
-        uint32_t h[PPT];
-        bool pend[PPT];
-#pragma unroll
-        for (int r = 0; r < PPT; r++) {
-            pend[r] = rl[r] != EMPTY;
-            h[r] = (((rec[r].x * 2654435761u) >> 20) * (uint32_t)(HT / 256)) >> 4;      // 12 hash bits -> [0, HT)
-        }
-#pragma unroll
-        for (int r = 0; r < PPT; r++) {
-            if (pend[r]) {
-                for (;;) {
-                    const uint32_t prev = atomicCAS(&ht_key[h[r]], EMPTY, rec[r].x);
-                    if (prev == EMPTY || prev == rec[r].x) break;
-                    h[r] = h[r] + 1 == HT ? 0 : h[r] + 1;
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < PPT; r++) {
-            const uint32_t l = rl[r];
-            if (l != EMPTY) {
-                const uint32_t i = tid + r * TPB;
-                const uint32_t field = l & 1;          // 0 = body, 1 = title
-                const double v = (double)__uint_as_float(rec[r].y) * l_mult[l];
-                s_rec[i] = make_double2(v, __hiloint2double((int)rec[r].w, (int)rec[r].z));
-                asm volatile("" ::: "memory");         // program order: parked before it can be named (LDS runs a wave's operations in order)
-                const uint32_t first = atomicCAS(&ht_rec[2 * h[r] + field], EMPTY, i);
-                // float32 addends in float64: exact, so the order of these rare adds does not matter
-                if (first != EMPTY) atomicAdd(&s_rec[first].x, v);
-            }
-        }
-    };
-    // score every touched doc (get_metadata.go:31-69), reset the table, filter into the running top-k.
-    // All LDS reads of a thread's entries are issued together; empty slots read as zero sums and drop out.
-    auto scan_table = [&]() {
-        uint64_t e_key[EPT];
-        uint32_t e_doc[EPT];
-        double2 tb[EPT];
-        uint32_t ib[EPT], it[EPT];
-        const uint64_t thr0 = *tk.thr;
-        const float thr_f = *tk.thr_f;
-#pragma unroll
-        for (int r = 0; r < EPT; r++) {
-            const int hh = tid + r * TPB;
-            e_doc[r] = EMPTY;
-            ib[r] = EMPTY;
-            it[r] = EMPTY;
-            if (HT % TPB == 0 || hh < HT) {
-                e_doc[r] = ht_key[hh];
-                const uint2 fr = *reinterpret_cast<const uint2*>(ht_rec + 2 * hh);
-                ib[r] = fr.x;
-                it[r] = fr.y;
-            }
-        }
-        double mt[EPT], mb[EPT];
-#pragma unroll
-        for (int r = 0; r < EPT; r++) {
-            const int hh = tid + r * TPB;
-            // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
-            double2 rb = make_double2(0.0, 1.0), rt = make_double2(0.0, 1.0);
-            if (ib[r] != EMPTY) rb = s_rec[ib[r]];
-            if (it[r] != EMPTY) rt = s_rec[it[r]];
-            tb[r] = make_double2(rb.x, rt.x);
-            mb[r] = rb.y;
-            mt[r] = rt.y;
-            if (HT % TPB == 0 || hh < HT) {
-                ht_key[hh] = EMPTY;
-                *reinterpret_cast<uint2*>(ht_rec + 2 * hh) = make_uint2(EMPTY, EMPTY);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < EPT; r++) {
-            e_key[r] = 0;
-            if (e_doc[r] != EMPTY) {
-                const double B = tb[r].x, T = tb[r].y;
-                // cheap float estimate first: almost every doc is far below the running threshold.
-                // Skipped only if the estimate, with a 1e-4 relative margin, is clearly below; anything
-                // non-finite falls through to the exact path.
-                // v_rcp_f32 (1 ulp) instead of an IEEE division: the 1e-4 margin below covers it; 0*inf = NaN falls through
-                const float ea = 38.0f * ((float)T * __builtin_amdgcn_rcpf((float)mt[r] * qmag_f)), eb = 29.0f * ((float)B * __builtin_amdgcn_rcpf((float)mb[r] * qmag_f)),
-                            ec = 33.0f * sqd_ub_f;
-                if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) { e_doc[r] = EMPTY; continue; }
-                double title, body, fin;
-                if (probs) {
-                    // the prior row (128 B) is only fetched if the doc can still make the top-k:
-                    // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
-                    final_rank(T, B, mt[r], mb[r], qmag, sqd_ub, title, body, fin);
-                    if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt[r], mb[r], qmag, topic_dot(p.prior, probs, p.k_topics, e_doc[r]), title, body, fin);
-                    else e_doc[r] = EMPTY;
-                } else {
-                    final_rank(T, B, mt[r], mb[r], qmag, 0.0, title, body, fin);
-                }
-                e_key[r] = fkey(fin);
-            }
-        }
-        // threshold filter into the candidate buffer; overflow -> compact and retry
-        for (;;) {
-            const uint64_t thr = *tk.thr;
-#pragma unroll
-            for (int r = 0; r < EPT; r++) {
-                if (e_doc[r] != EMPTY) {
-                    if (e_key[r] >= thr) {
-                        const uint32_t i = atomicAdd(tk.count, 1u);
-                        if (i < tk.cb) { tk.key[i] = e_key[r]; tk.doc[i] = e_doc[r]; e_doc[r] = EMPTY; }
-                        else overflow = 1;
-                    } else {
-                        e_doc[r] = EMPTY;
-                    }
-                }
-            }
-            lds_barrier();
-            if (!overflow) break;
-            topk_compact(tk, p.k);         // raises thr; count back to <= k
-            if (tid == 0) overflow = 0;
-            lds_barrier();
-        }
-    };
+    for (int r = 0; r < PPT; r++) { rl[r] = EMPTY; ri[r] = 0; rc[r] = 0.f; rec[r] = u32x2{0u, 0u}; }
 
-    if (n_win > 0 && off[OS - 1] <= CAP) load_window(0);
-    STAMP(ts[0]);
-    acc[6] += ts[0] - ts[7];
+    DIAG_NOW(t_k1);
+    DIAG_ADD(0, 1);
+    DIAG_ADD(1, n_win);
+    DIAG_ADD(5, tot);
+    DIAG_ADD(9, t_k1 - t_k0);
+    // ---- the windows ----
+    uint32_t pbase = 0;                     // pending survivors of the windows before this one (same value in every thread)
+    uint32_t hprev[PPT];                    // filter slots this thread touched in the previous window (EMPTY: none)
+#pragma unroll
+    for (int r = 0; r < PPT; r++) hprev[r] = EMPTY;
+    int cur = 0, prv = 2;                   // j % 3, (j - 1) % 3
+    bool have = false;                      // window j's records are in flight / in registers
     for (int j = 0; j < n_win; j++) {
-        const uint32_t n = off[j * OS + OS - 1];
-        if (n <= CAP) {
-            STAMP(ts[0]);
-            insert_records();                                   // waits for window j's records
-            STAMP(ts[1]);
-            lds_barrier();
-            STAMP(ts[2]);
-            if (j + 1 < n_win && off[(j + 1) * OS + OS - 1] <= CAP) load_window(j + 1);   // in flight during the scan
-            STAMP(ts[3]);
-            scan_table();
-            STAMP(ts[4]);
-            acc[0] += ts[1] - ts[0]; acc[1] += ts[2] - ts[1]; acc[2] += ts[3] - ts[2]; acc[3] += ts[4] - ts[3]; acc[7] += 1;
+        const uint32_t n = S.off[j * OS + OS - 1];
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        const bool normal = n <= (uint32_t)CAP;
+        if (normal && !have) load_window(S, j, L, OS, tid, cf, rec, rl, ri, rc);     // first window, or the one after an oversize window
+        have = false;
+        uint32_t h[PPT];
+        u32x2 mine[PPT];
+        uint32_t ml[PPT], mi[PPT];
+        float* sk_cur = S.sk + cur * SK;
+        if (normal) {
+            // stage 1a: every record adds its share into its doc's slot (waits for window j's records)
+#pragma unroll
+            for (int r = 0; r < PPT; r++) {
+                h[r] = EMPTY;
+                if (rl[r] != EMPTY) {
+                    h[r] = (rec[r].x * 2654435761u) >> (32 - SS_SK_BITS);
+                    atomicAdd(&sk_cur[h[r]], __uint_as_float(rec[r].y) * rc[r]);
+                }
+                mine[r] = rec[r]; ml[r] = rl[r]; mi[r] = ri[r];
+            }
         } else {
-            // ---- oversize window (a list is locally much denser than planned): bisect its doc range
-            //      until a piece fits, process the piece, continue.  Rare; no prefetch here. ----
-            if (tid < L) f_cur[tid] = tbl[j * L + tid];
-            uint32_t flo = j == 0 ? sd.dlo : load_doc(drv_addr, tbl[j * L + drv]);
-            const uint32_t fend = j + 1 == n_win ? sd.dhi : load_doc(drv_addr, tbl[(j + 1) * L + drv]);
+#pragma unroll
+            for (int r = 0; r < PPT; r++) { h[r] = EMPTY; ml[r] = EMPTY; mi[r] = 0; mine[r] = u32x2{0u, 0u}; }
+        }
+        lds_barrier();
+        // survivors of window j-1 are all appended now; their count is stable until window j+2 re-uses the counter
+        pbase += surv_cnt[prv];
+        if (tid == 0) surv_cnt[nxt] = 0;
+        if (!normal || pbase + n > (uint32_t)PC) {
+            if (pbase) flush_pending(S, tk, Q, p, tid, pbase);
+            pbase = 0;
+        }
+        if (!normal) {
+            // ---- oversize window (a list is locally much denser than planned): bisect its doc range until a
+            //      piece fits and hand every record of the piece to the exact stage.  Rare; no filter. ----
+            if (tid < L) S.f_cur[tid] = S.tbl[j * L + tid];
+            uint32_t flo = j == 0 ? sd.dlo : load_doc(drv_addr, S.tbl[j * L + drv]);
+            const uint32_t fend = j + 1 == n_win ? sd.dhi : load_doc(drv_addr, S.tbl[(j + 1) * L + drv]);
             __syncthreads();
             for (;;) {
                 uint32_t fhi = fend;
                 uint32_t cnt;
                 for (;;) {
                     if (tid < L) {
-                        f_nxt[tid] = fhi == fend ? tbl[(j + 1) * L + tid]
-                                                 : lower_bound_addr(l_base[tid], f_cur[tid], tbl[(j + 1) * L + tid], fhi);
+                        S.f_nxt[tid] = fhi == fend ? S.tbl[(j + 1) * L + tid]
+                                                   : lower_bound_addr(S.l_rec[tid], S.f_cur[tid], S.tbl[(j + 1) * L + tid], fhi);
                     }
                     __syncthreads();
                     cnt = 0;
-                    for (int l = 0; l < L; l++) cnt += f_nxt[l] - f_cur[l];
+                    for (int l = 0; l < L; l++) cnt += S.f_nxt[l] - S.f_cur[l];
                     if (cnt <= (uint32_t)CAP) break;
-                    // a single doc has at most L <= 128 postings, so the bisection ends
+                    // a single doc has at most L <= 132 postings, so the bisection ends
                     fhi = flo + (uint32_t)(((uint64_t)fhi - flo) >> 1);
                     __syncthreads();
                 }
 #pragma unroll
                 for (int r = 0; r < PPT; r++) {
                     const uint32_t i = tid + r * TPB;
-                    rl[r] = EMPTY;
                     if (i < cnt) {
                         uint32_t run = 0;
                         int l = 0;
                         for (; l < L; l++) {
-                            const uint32_t len = f_nxt[l] - f_cur[l];
+                            const uint32_t len = S.f_nxt[l] - S.f_cur[l];
                             if (i < run + len) break;
                             run += len;
                         }
-                        rec[r] = load_rec(l_base[l], (uint64_t)f_cur[l] + (i - run));
-                        rl[r] = l;
+                        const uint32_t idx = S.f_cur[l] + (i - run);
+                        S.pend[i] = make_uint4(load_doc(S.l_rec[l], idx), idx, (uint32_t)l, 0u);
                     }
                 }
-                insert_records();
                 lds_barrier();
-                scan_table();
+                flush_pending(S, tk, Q, p, tid, cnt);
                 bool done = true;
-                for (int l = 0; l < L; l++) done = done && f_nxt[l] == tbl[(j + 1) * L + l];
+                for (int l = 0; l < L; l++) done = done && S.f_nxt[l] == S.tbl[(j + 1) * L + l];
                 __syncthreads();
                 if (done) break;
-                if (tid < L) f_cur[tid] = f_nxt[tid];
+                if (tid < L) S.f_cur[tid] = S.f_nxt[tid];
                 flo = fhi;
                 __syncthreads();
             }
-            if (j + 1 < n_win && off[(j + 1) * OS + OS - 1] <= CAP) load_window(j + 1);
         }
+        // put the next window's loads in flight
+        if (j + 1 < n_win && S.off[(j + 1) * OS + OS - 1] <= CAP) {
+            load_window(S, j + 1, L, OS, tid, cf, rec, rl, ri, rc);
+            have = true;
+        }
+        // stage 1b: the slot now bounds the doc's FinalRank from above; below the threshold -> drop.
+        // (An oversize window has no records here: only the previous window's slots are cleared.)
+        const float thr_f = exact_all ? -INFINITY : *thr_f_s;
+        float* sk_prv = S.sk + prv * SK;
+#pragma unroll
+        for (int r = 0; r < PPT; r++) {
+            bool surv = false;
+            if (ml[r] != EMPTY) {
+                const float ub = sk_cur[h[r]] + r_ub;
+                surv = !(ub < thr_f);                 // NaN survives
+            }
+            if (hprev[r] != EMPTY) sk_prv[hprev[r]] = 0.0f;
+            hprev[r] = h[r];
+            const unsigned long long m = __ballot(surv);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t b = 0;
+                if (lane == leader) b = atomicAdd(&surv_cnt[cur], (uint32_t)__popcll(m));
+                b = (uint32_t)__shfl((int)b, leader, 64);
+                if (surv) {
+                    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+                    S.pend[pbase + b + (uint32_t)__popcll(m & below)] = make_uint4(mine[r].x, mi[r], ml[r], 0u);
+                }
+            }
+        }
+        prv = cur;
+        cur = nxt;
     }
+    lds_barrier();
+    pbase += surv_cnt[prv];
+    if (pbase) flush_pending(S, tk, Q, p, tid, pbase);
+    DIAG_NOW(t_k2);
+    DIAG_ADD(10, t_k2 - t_k1);
 
     topk_compact(tk, p.k);
     const uint32_t n_out = cand_count;
@@ -625,14 +839,8 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
         p.so_doc[(size_t)slice_id * p.k + i] = cd_doc[i];
     }
     if (tid == 0) p.so_cnt[slice_id] = n_out;
-#ifdef SS_DIAG
-    STAMP(ts[1]);
-    if ((tid & 63) == 0 && (tid >> 6) == 3) {
-        for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i], acc[i]);
-        atomicAdd(&g_stamps[8], ts[1] - ts[7]);
-        atomicAdd(&g_stamps[9], 1ull);
-    }
-#endif
+    DIAG_NOW(t_k3);
+    DIAG_ADD(11, t_k3 - t_k0);
 }
 
 // ---- K6: quoted-phrase matching (retrieval/phrase.go:11-170, util.go:162-203) --------------------
@@ -644,7 +852,7 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
 //     order (phrase.go:59,69,73,83,90) and the position lists, shifted by the term's index
 //     (getPosTerm :145,:157: listPos[i] -= float32(pos)), must have a common value (intersect,
 //     util.go:179-203; bit-exact float32 equality as in the reference);
-//   * matches leave as 16-byte records {doc, float32 sum, field magnitude} in doc order (ordered
+//   * matches leave as scoring records {doc, impact of the float32 sum} + the sum itself, in doc order (ordered
 //     compaction), i.e. as ordinary doc-sorted lists that k_score_slices merges like any term list
 //     (main_retrieve.go:73-78).
 constexpr int PH_TPB = 256;
@@ -671,6 +879,12 @@ __device__ __forceinline__ bool positions_chain(const uint64_t* const* pos_ptr2,
     return false;
 }
 
+// float32 upper bound of w / mag for the filter; 0 where the weight is 0 (0/0 = NaN -> 0 in the reference too)
+__device__ __forceinline__ float impact_of(float w, double mag) {
+    if (w == 0.0f) return 0.0f;
+    return __double2float_ru((double)w / mag);
+}
+
 __global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
     __shared__ int32_t s_pb[PH_MAX * PH_TPB];     // body posting index of term i for this thread's doc, -1 = none
     __shared__ int32_t s_pt[PH_MAX * PH_TPB];
@@ -694,7 +908,7 @@ __global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
         // pass 0: driver's body postings; pass 1: driver's title postings whose doc has no driver body posting
         const uint64_t c0 = pass == 0 ? p.b_ptr[drv_term] : p.t_ptr[drv_term];
         const uint64_t c1 = pass == 0 ? p.b_ptr[drv_term + 1] : p.t_ptr[drv_term + 1];
-        const Post* cpost = pass == 0 ? p.b_post : p.t_post;
+        const Rec* crec = pass == 0 ? p.b_rec : p.t_rec;
         if (tid < 2) s_base[tid] = 0;
         __syncthreads();
         for (uint64_t cb = c0; cb < c1; cb += PH_TPB) {
@@ -703,25 +917,25 @@ __global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
             float sum_b = 0.0f, sum_t = 0.0f;
             uint32_t d = 0;
             if (ci < c1) {
-                d = cpost[ci].doc;
+                d = crec[ci].doc;
                 bool all = true, body_all = true, title_all = true;
                 if (pass == 1) {
                     const uint64_t b0 = p.b_ptr[drv_term], b1 = p.b_ptr[drv_term + 1];
-                    const uint64_t pos = lower_bound_post(p.b_post, b0, b1, d);
-                    if (pos < b1 && p.b_post[pos].doc == d) all = false;       // already handled in pass 0
+                    const uint64_t pos = lower_bound_rec(p.b_rec, b0, b1, d);
+                    if (pos < b1 && p.b_rec[pos].doc == d) all = false;       // already handled in pass 0
                 }
                 for (uint32_t i = 0; i < m && all; i++) {
                     const uint32_t term = p.ph_terms[f0 + i];
                     const uint64_t b0 = p.b_ptr[term], b1 = p.b_ptr[term + 1];
                     const uint64_t t0 = p.t_ptr[term], t1 = p.t_ptr[term + 1];
-                    const uint64_t pb = lower_bound_post(p.b_post, b0, b1, d);
-                    const uint64_t pt = lower_bound_post(p.t_post, t0, t1, d);
-                    const bool hb = pb < b1 && p.b_post[pb].doc == d, ht = pt < t1 && p.t_post[pt].doc == d;
+                    const uint64_t pb = lower_bound_rec(p.b_rec, b0, b1, d);
+                    const uint64_t pt = lower_bound_rec(p.t_rec, t0, t1, d);
+                    const bool hb = pb < b1 && p.b_rec[pb].doc == d, ht = pt < t1 && p.t_rec[pt].doc == d;
                     my_pb[i * PH_TPB] = hb ? (int32_t)pb : -1;
                     my_pt[i * PH_TPB] = ht ? (int32_t)pt : -1;
                     if (!hb && !ht) all = false;                      // phrase.go:63
-                    if (hb) sum_b += p.b_post[pb].w; else body_all = false;     // phrase.go:69,80-84
-                    if (ht) sum_t += p.t_post[pt].w; else title_all = false;    // phrase.go:73,87-91
+                    if (hb) sum_b += p.b_w[pb]; else body_all = false;          // phrase.go:69,80-84
+                    if (ht) sum_t += p.t_w[pt]; else title_all = false;         // phrase.go:73,87-91
                 }
                 if (all) {
                     if (body_all) body_ok = positions_chain(pos_ptr2, pos2, 0, my_pb, (int)m);
@@ -736,14 +950,20 @@ __global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
             for (int w2 = 0; w2 < wave; w2++) { ob += s_wave[0][w2]; ot += s_wave[1][w2]; }
             const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
             if (body_ok) {
-                Post r;
-                r.doc = d; r.w = sum_b; r.mag = p.b_post[my_pb[0]].mag;
-                p.x_list[pass == 0 ? 0 : 2][p.x_off[q] + ob + (uint32_t)__popcll(mb & below)] = r;
+                const uint32_t o = p.x_off[q] + ob + (uint32_t)__popcll(mb & below);
+                const int x = pass == 0 ? 0 : 2;
+                Rec r;
+                r.doc = d; r.imp = impact_of(sum_b, p.b_mag[d]);
+                p.x_rec[x][o] = r;
+                p.x_w[x][o] = sum_b;
             }
             if (title_ok) {
-                Post r;
-                r.doc = d; r.w = sum_t; r.mag = p.t_post[my_pt[0]].mag;
-                p.x_list[pass == 0 ? 1 : 3][p.x_off[q] + ot + (uint32_t)__popcll(mt & below)] = r;
+                const uint32_t o = p.x_off[q] + ot + (uint32_t)__popcll(mt & below);
+                const int x = pass == 0 ? 1 : 3;
+                Rec r;
+                r.doc = d; r.imp = impact_of(sum_t, p.t_mag[d]);
+                p.x_rec[x][o] = r;
+                p.x_w[x][o] = sum_t;
             }
             __syncthreads();
             if (tid == 0) {
@@ -759,10 +979,7 @@ __global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
     }
 }
 
-size_t score_lds_bytes(int cb) {
-    return (size_t)CAP * 16 + (size_t)MAXL * 8 * 2 + 2 * 8 + (size_t)cb * 12 +
-           ((size_t)3 * HT + TBL_CAP + 3 * MAXL + 8) * 4 + (size_t)OFF_CAP * 2 + 16;
-}
+size_t score_lds_bytes(int cb) { return score_lds_layout(cb).total; }
 
 // ---- K5: merge a query's slices, explain the winners ------------------------------
 __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
@@ -775,7 +992,7 @@ __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
     uint64_t* sc64 = cd_key + p.cb;                                    // [1]
     uint32_t* cd_doc = reinterpret_cast<uint32_t*>(sc64 + 1);          // [cb]
     uint32_t* sc32 = cd_doc + p.cb;                                    // [4]
-    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), (uint32_t)p.cb};
+    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), 0ull, -INFINITY, (uint32_t)p.cb};
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const int k = p.k;
@@ -808,30 +1025,29 @@ __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
     for (uint32_t task = tid; task < n_out * L; task += TPB_M) {
         const uint32_t i = task / L, l = task % L;
         const int field = l & 1;
-        uint64_t addr;
+        uint64_t addr, waddr;
         uint32_t len;
         double mult;
         if (l < 2 * nd) {
             const uint32_t term = p.dterm[t0 + (l >> 1)];
             const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-            addr = (uint64_t)((field ? p.t_post : p.b_post) + ptr[term]);
+            addr = (uint64_t)((field ? p.t_rec : p.b_rec) + ptr[term]);
+            waddr = (uint64_t)((field ? p.t_w : p.b_w) + ptr[term]);
             len = (uint32_t)(ptr[term + 1] - ptr[term]);
             mult = (double)p.dmult[t0 + (l >> 1)];
         } else {
-            addr = (uint64_t)(p.x_list[l - 2 * nd] + p.x_off[q]);
+            addr = (uint64_t)(x_rec_of(p, (int)(l - 2 * nd)) + p.x_off[q]);
+            waddr = (uint64_t)(x_w_of(p, (int)(l - 2 * nd)) + p.x_off[q]);
             len = p.x_cnt[(size_t)q * 4 + (l - 2 * nd)];
             mult = 1.0;
         }
         const uint32_t d = cd_doc[i];
         const uint32_t pos = lower_bound_interp(addr, 0, len, d);
-        if (pos < len) {
-            const u32x4 raw = load_rec(addr, pos);
-            if (raw.x == d) {
-                const double v = (double)__uint_as_float(raw.y) * mult;
-                const double mag = __hiloint2double((int)raw.w, (int)raw.z);
-                if (field) { atomicAdd(&accT[i], v); mgT[i] = mag; }
-                else { atomicAdd(&accB[i], v); mgB[i] = mag; }
-            }
+        if (pos < len && load_doc(addr, pos) == d) {
+            const double v = (double)load_w(waddr, pos) * mult;
+            const double mag = (field ? p.t_mag : p.b_mag)[d];
+            if (field) { atomicAdd(&accT[i], v); mgT[i] = mag; }
+            else { atomicAdd(&accB[i], v); mgB[i] = mag; }
         }
     }
     __syncthreads();
@@ -854,19 +1070,75 @@ __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
 
 size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 16 + 16; }
 
-// scoring layout: {doc, w, mag[doc]} per posting
-__global__ void k_pack_posts(const uint32_t* __restrict__ doc, const float* __restrict__ w, const double* __restrict__ mag,
-                             uint64_t n, Post* __restrict__ out) {
+// scoring layout: {doc, float32 upper bound of w/mag[doc]} per posting; flags: bit 0 = a weight is negative or not finite,
+// bit 1 = a magnitude is not a positive finite number under a non-zero weight (the filter's assumptions, see k_score_slices)
+__global__ void k_pack_recs(const uint32_t* __restrict__ doc, const float* __restrict__ w, const double* __restrict__ mag,
+                            uint64_t n, Rec* __restrict__ out, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t f = 0;
     for (; i < n; i += stride) {
-        Post r;
+        Rec r;
         r.doc = doc[i];
-        r.w = w[i];
-        r.mag = mag[r.doc];
+        const float wi = w[i];
+        const double m = mag[r.doc];
+        if (!(wi >= 0.0f) || isinf(wi)) f |= 1u;
+        if (wi != 0.0f && (!(m > 0.0) || isinf(m))) f |= 2u;
+        r.imp = impact_of(wi, m);
         out[i] = r;
     }
+    if (__ballot(f != 0)) {
+        for (int o = 32; o > 0; o >>= 1) f |= (uint32_t)__shfl_xor((int)f, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicOr(flags, f);
+    }
 }
+
+// k'-th largest impact of every term's list for k' = 2^0 .. 2^10 (0 where the list is shorter), as LOWER bounds:
+// a 4096-bin histogram over [2^-8, 1) (9 mantissa bits per binade: 0.2 % resolution; smaller impacts share bin 0,
+// whose edge is 0), suffix-summed from the top; the bin edge at which the count reaches k' is the bound.
+constexpr int KH_TPB = 256;
+constexpr int KH_BINS = 4096;
+constexpr uint32_t KH_B0 = 0x3B800000u;               // bits of 2^-8
+__global__ __launch_bounds__(KH_TPB) void k_kth_impact(const uint64_t* __restrict__ term_ptr, const Rec* __restrict__ rec,
+                                                        float* __restrict__ kth /*[T][KTH_N], zeroed*/) {
+    __shared__ uint32_t s_hist[KH_BINS];
+    __shared__ uint32_t s_part[KH_TPB];
+    const uint64_t t = blockIdx.x;
+    const uint64_t beg = term_ptr[t], end = term_ptr[t + 1];
+    if (end == beg) return;
+    for (int b = threadIdx.x; b < KH_BINS; b += KH_TPB) s_hist[b] = 0;
+    __syncthreads();
+    for (uint64_t i = beg + threadIdx.x; i < end; i += KH_TPB) {
+        // stored impacts are rounded UP from w/mag: step down two float ulps for a lower bound
+        const float lb = rec[i].imp * (1.0f - 0x1p-21f);
+        const uint32_t xb = __float_as_uint(lb);
+        uint32_t b = 0;
+        if (lb > 0.0f && xb >= KH_B0) b = min((xb - KH_B0) >> 14, (uint32_t)(KH_BINS - 1));
+        if (lb > 0.0f) atomicAdd(&s_hist[b], 1u);                    // NaN and non-positive impacts count for nothing
+    }
+    __syncthreads();
+    // thread x owns bins [16x, 16x+16): its sum, then the number of postings in bins ABOVE its range
+    constexpr int PER = KH_BINS / KH_TPB;
+    uint32_t own = 0;
+    for (int b = 0; b < PER; b++) own += s_hist[threadIdx.x * PER + b];
+    s_part[threadIdx.x] = own;
+    __syncthreads();
+    uint32_t above = 0;
+    for (int x = threadIdx.x + 1; x < KH_TPB; x++) above += s_part[x];
+    uint32_t run = above;
+    for (int b = PER - 1; b >= 0; b--) {
+        const uint32_t bin = threadIdx.x * PER + b;
+        const uint32_t c = s_hist[bin];
+        if (c) {
+            for (int j = 0; j < KTH_N; j++) {
+                const uint32_t kk = 1u << j;
+                if (run < kk && kk <= run + c) kth[t * KTH_N + j] = bin == 0 ? 0.0f : __uint_as_float(KH_B0 + (bin << 14));
+            }
+        }
+        run += c;
+    }
+}
+
 // rank [K][N] topic-major -> prior [N][K] node-major
 __global__ void k_transpose_prior(const double* __restrict__ in, uint64_t n, int K, double* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -916,7 +1188,10 @@ struct ss_scorer {
     ss_index* title = nullptr;
     ss_index* body = nullptr;
     uint64_t n_docs = 0, n_terms = 0;
-    ss::DevBuf<Post> t_post, b_post;
+    ss::DevBuf<Rec> t_rec, b_rec;              // scoring records {doc, impact}
+    ss::DevBuf<float> t_kth, b_kth;             // [T][KTH_N] k'-th largest impact per term (threshold floor)
+    bool clean = true;                          // weights >= 0 and finite, magnitudes positive and finite where a weight is not 0
+    bool prior_clean = true;                    // every prior value >= 0 and finite
     ss::DevBuf<double> prior;
     std::vector<double> prior_max, prior_min;   // per topic
     int k_topics = 0;
@@ -930,8 +1205,8 @@ struct ss_scorer {
     hipEvent_t plan_ev[2] = {nullptr, nullptr}; // recorded after the H2D copy of the buffer
     bool plan_ev_pending[2] = {false, false};
     int plan_turn = 0;
-    ss::DevBuf<double> d_probs;
-    ss::DevBuf<Post> d_x[4];                    // phrase result lists
+    ss::DevBuf<Rec> d_x[4];                     // phrase result lists: scoring records
+    ss::DevBuf<float> d_xw[4];                  // ... and their float32 weight sums
     ss::DevBuf<uint32_t> d_xcnt;
     ss::DevBuf<uint64_t> d_so_key;
     ss::DevBuf<uint32_t> d_so_doc, d_so_cnt;
@@ -975,18 +1250,35 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     s->body = body;
     s->n_docs = title->n_docs;
     s->n_terms = title->n_terms;
-    SS_HIP(ctx, s->t_post.alloc(title->n_post));
-    SS_HIP(ctx, s->b_post.alloc(body->n_post));
+    SS_HIP(ctx, s->t_rec.alloc(title->n_post));
+    SS_HIP(ctx, s->b_rec.alloc(body->n_post));
+    SS_HIP(ctx, s->t_kth.alloc((size_t)s->n_terms * KTH_N));
+    SS_HIP(ctx, s->b_kth.alloc((size_t)s->n_terms * KTH_N));
+    ss::DevBuf<uint32_t> flags;
+    SS_HIP(ctx, flags.alloc(1));
+    SS_HIP(ctx, hipMemsetAsync(flags.p, 0, sizeof(uint32_t), ctx->stream));
+    SS_HIP(ctx, hipMemsetAsync(s->t_kth.p, 0, std::max<size_t>(s->t_kth.bytes(), 4), ctx->stream));
+    SS_HIP(ctx, hipMemsetAsync(s->b_kth.p, 0, std::max<size_t>(s->b_kth.bytes(), 4), ctx->stream));
     if (title->n_post)
-        hipLaunchKernelGGL(k_pack_posts, dim3(std::min<unsigned>(ss::div_up(title->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_pack_recs, dim3(std::min<unsigned>(ss::div_up(title->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
                            (const uint32_t*)title->post_doc.p, (const float*)title->post_w.p, (const double*)title->mag.p,
-                           title->n_post, s->t_post.p);
+                           title->n_post, s->t_rec.p, flags.p);
     if (body->n_post)
-        hipLaunchKernelGGL(k_pack_posts, dim3(std::min<unsigned>(ss::div_up(body->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_pack_recs, dim3(std::min<unsigned>(ss::div_up(body->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
                            (const uint32_t*)body->post_doc.p, (const float*)body->post_w.p, (const double*)body->mag.p,
-                           body->n_post, s->b_post.p);
+                           body->n_post, s->b_rec.p, flags.p);
+    if (s->n_terms) {
+        hipLaunchKernelGGL(k_kth_impact, dim3((unsigned)s->n_terms), dim3(KH_TPB), 0, ctx->stream, (const uint64_t*)title->term_ptr.p,
+                           (const Rec*)s->t_rec.p, s->t_kth.p);
+        hipLaunchKernelGGL(k_kth_impact, dim3((unsigned)s->n_terms), dim3(KH_TPB), 0, ctx->stream, (const uint64_t*)body->term_ptr.p,
+                           (const Rec*)s->b_rec.p, s->b_kth.p);
+    }
     SS_HIP(ctx, hipGetLastError());
+    uint32_t h_flags = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&h_flags, flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->clean = h_flags == 0;
+    if (const char* e = std::getenv("SS_SCORE_EXACT_ALL")) s->clean = s->clean && std::atoi(e) == 0;   // tests: force the filter off
     title->users++;
     body->users++;
     *out = s.release();
@@ -1001,11 +1293,11 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     (void)hipStreamSynchronize(ctx->stream);
 #ifdef SS_DIAG
     {
-        unsigned long long h[16];
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
-            const char* names[10] = {"insert(+wait)", "barrier", "issue_loads", "scan+admit", "-", "-", "slice_init", "windows", "block_total", "blocks"};
-            fprintf(stderr, "[ss diag] k_score_slices wave 3 cycles:");
-            for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+        unsigned long long h[24];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h)) == hipSuccess) {
+            const char* names[12] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "-", "-", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total"};
+            fprintf(stderr, "[ss diag] k_score_slices (thread 0 of every slice):");
+            for (int i = 0; i < 12; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
             fprintf(stderr, "\n");
         }
     }
@@ -1052,6 +1344,9 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank) 
         s->prior_min[t] = unkey(h_ext[k_topics + t]);
     }
     s->k_topics = k_topics;
+    s->prior_clean = true;
+    for (int t = 0; t < k_topics; t++)          // a NaN anywhere shows as max = +inf, min = -inf (k_prior_extrema)
+        if (!(s->prior_min[t] >= 0.0) || !std::isfinite(s->prior_max[t])) s->prior_clean = false;
     return SS_OK;
 }
 
@@ -1071,10 +1366,27 @@ int32_t ss_score_topk_phrase(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, c
     return score_impl(s, n_q, q_ptr, q_terms, p_ptr, p_terms, query_len, topic_probs, k, hits_out, n_hits_out);
 }
 
+static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const uint32_t* p_ptr,
+                                const uint32_t* p_terms, const int32_t* query_len, const double* topic_probs, int32_t k,
+                                ss_hit* hits_out, int32_t* n_hits_out);
+
+// no C++ exception may cross the C ABI: host allocation failures come back as SS_ERR_OOM
 static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const uint32_t* p_ptr,
                           const uint32_t* p_terms, const int32_t* query_len, const double* topic_probs, int32_t k,
                           ss_hit* hits_out, int32_t* n_hits_out) {
     if (!s) return SS_ERR_INVALID;
+    try {
+        return score_impl_inner(s, n_q, q_ptr, q_terms, p_ptr, p_terms, query_len, topic_probs, k, hits_out, n_hits_out);
+    } catch (const std::bad_alloc&) {
+        return s->ctx->fail(SS_ERR_OOM, "ss_score_topk: host allocation failed");
+    } catch (const std::exception& e) {
+        return s->ctx->fail(SS_ERR_INVALID, "ss_score_topk: %s", e.what());
+    }
+}
+
+static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const uint32_t* p_ptr,
+                                const uint32_t* p_terms, const int32_t* query_len, const double* topic_probs, int32_t k,
+                                ss_hit* hits_out, int32_t* n_hits_out) {
     ss_ctx* ctx = s->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SS_HIP(ctx, hipSetDevice(ctx->device));
@@ -1118,6 +1430,15 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
         h_probs.resize((size_t)n_q * K);
         SS_HIP(ctx, hipMemcpy(h_probs.data(), topic_probs, h_probs.size() * sizeof(double), hipMemcpyDefault));
     }
+
+    // The filter of k_score_slices assumes non-negative finite addends (see there).  Anything else — tables or priors
+    // flagged at creation, a negative / non-finite topic probability, queryLength <= 0 — switches it off for this call:
+    // every record then goes through the exact stage, which restates the reference's arithmetic for any input.
+    bool exact_all = !s->clean || (topic_probs && !s->prior_clean);
+    for (int q = 0; q < n_q && !exact_all; q++) exact_all = h_qlen[q] <= 0;
+    for (size_t i = 0; i < h_probs.size() && !exact_all; i++) exact_all = !(h_probs[i] >= 0.0) || !std::isfinite(h_probs[i]);
+    int kth_j = 0;
+    while ((1 << kth_j) < k) kth_j++;
 
     const std::vector<uint64_t>& tp = s->title->h_term_ptr;
     const std::vector<uint64_t>& bp = s->body->h_term_ptr;
@@ -1190,7 +1511,11 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
             }
             h_ub[q] = ub != ub ? INFINITY : ub;
         }
-        uint64_t ns = std::max<uint64_t>(1, (tot + slice_target - 1) / slice_target);
+        // the window plan holds (n_win + 1) * L cursors: keep a slice within what the plan can cut into regular windows
+        const uint64_t n_lists = 2 * (h_dterm.size() - d0) + 4;
+        const uint64_t plan_cap = std::max<uint64_t>(TARGET, (uint64_t)(TBL_CAP / n_lists > 2 ? TBL_CAP / n_lists - 2 : 1) * TARGET * 7 / 8);
+        const uint64_t q_target = std::min<uint64_t>(slice_target, plan_cap);
+        uint64_t ns = std::max<uint64_t>(1, (tot + q_target - 1) / q_target);
         ns = std::min<uint64_t>(ns, std::min<uint64_t>(MAX_SLICES_PER_Q, s->n_docs));
         for (uint64_t j = 0; j < ns; j++) {
             SliceDesc sd;
@@ -1226,6 +1551,7 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     const size_t o_pterms = o; o = align16(o + h_pterms.size() * sizeof(uint32_t));
     const size_t o_pdrv = o;   o = align16(o + n_q * sizeof(uint32_t));
     const size_t o_xoff = o;   o = align16(o + (n_q + 1) * sizeof(uint32_t));
+    const size_t o_probs = o;  o = align16(o + h_probs.size() * sizeof(double));
     const size_t plan_bytes = o;
     const int pb = s->plan_turn;
     s->plan_turn ^= 1;
@@ -1257,11 +1583,15 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     if (!h_pterms.empty()) std::memcpy(hp + o_pterms, h_pterms.data(), h_pterms.size() * sizeof(uint32_t));
     std::memcpy(hp + o_pdrv, h_pdrv.data(), n_q * sizeof(uint32_t));
     std::memcpy(hp + o_xoff, h_xoff.data(), (n_q + 1) * sizeof(uint32_t));
+    if (!h_probs.empty()) std::memcpy(hp + o_probs, h_probs.data(), h_probs.size() * sizeof(double));
     SS_HIP(ctx, hipMemcpyAsync(s->d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, st));
     SS_HIP(ctx, hipEventRecord(s->plan_ev[pb], st));
     s->plan_ev_pending[pb] = true;
     if (any_phrase) {
-        for (int x = 0; x < 4; x++) SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
+        for (int x = 0; x < 4; x++) {
+            SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
+            SS_HIP(ctx, ensure(s->d_xw[x], (size_t)h_xoff[n_q]));
+        }
         SS_HIP(ctx, ensure(s->d_xcnt, (size_t)n_q * 4));
     }
     SS_HIP(ctx, ensure(s->d_so_key, n_slices * k));
@@ -1269,15 +1599,11 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     SS_HIP(ctx, ensure(s->d_so_cnt, n_slices));
     SS_HIP(ctx, ensure(s->d_hits, (size_t)n_q * k));
     SS_HIP(ctx, ensure(s->d_nhits, n_q));
-    if (topic_probs) {
-        SS_HIP(ctx, ensure(s->d_probs, (size_t)n_q * K));
-        SS_HIP(ctx, hipMemcpyAsync(s->d_probs.p, topic_probs, (size_t)n_q * K * sizeof(double), hipMemcpyDefault, st));
-    }
 
     const unsigned char* dp = s->d_plan.p;
     ScoreParams p{};
-    p.t_ptr = s->title->term_ptr.p; p.t_post = s->t_post.p;
-    p.b_ptr = s->body->term_ptr.p; p.b_post = s->b_post.p;
+    p.t_ptr = s->title->term_ptr.p; p.t_rec = s->t_rec.p; p.t_w = s->title->post_w.p; p.t_mag = s->title->mag.p; p.t_kth = s->t_kth.p;
+    p.b_ptr = s->body->term_ptr.p; p.b_rec = s->b_rec.p; p.b_w = s->body->post_w.p; p.b_mag = s->body->mag.p; p.b_kth = s->b_kth.p;
     p.t_pos_ptr = s->title->pos_ptr.p; p.t_pos = s->title->pos.p;
     p.b_pos_ptr = s->body->pos_ptr.p; p.b_pos = s->body->pos.p;
     if (any_phrase) {
@@ -1285,7 +1611,7 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
         p.ph_terms = reinterpret_cast<const uint32_t*>(dp + o_pterms);
         p.ph_drv = reinterpret_cast<const uint32_t*>(dp + o_pdrv);
         p.x_off = reinterpret_cast<const uint32_t*>(dp + o_xoff);
-        for (int x = 0; x < 4; x++) p.x_list[x] = s->d_x[x].p;
+        for (int x = 0; x < 4; x++) { p.x_rec[x] = s->d_x[x].p; p.x_w[x] = s->d_xw[x].p; }
         p.x_cnt = s->d_xcnt.p;
     }
     p.prior = K ? s->prior.p : nullptr;
@@ -1294,13 +1620,15 @@ static int32_t score_impl(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, cons
     p.dterm = reinterpret_cast<const uint32_t*>(dp + o_dterm);
     p.dmult = reinterpret_cast<const uint32_t*>(dp + o_dmult);
     p.qmag = reinterpret_cast<const double*>(dp + o_qmag);
-    p.probs = topic_probs ? s->d_probs.p : nullptr;
+    p.probs = topic_probs ? reinterpret_cast<const double*>(dp + o_probs) : nullptr;
     p.sqd_ub = reinterpret_cast<const double*>(dp + o_ub);
     p.slice_base = reinterpret_cast<const uint32_t*>(dp + o_sbase);
     p.slices = reinterpret_cast<const SliceDesc*>(dp + o_slices);
     p.order = reinterpret_cast<const uint32_t*>(dp + o_order);
     p.k = k;
     p.cb = cb;
+    p.kth_j = kth_j;
+    p.exact_all = exact_all ? 1 : 0;
     p.so_key = s->d_so_key.p; p.so_doc = s->d_so_doc.p; p.so_cnt = s->d_so_cnt.p;
     // results straight into the caller's buffers when both live in device memory (then the call does not wait either)
     bool dev_out = false;
