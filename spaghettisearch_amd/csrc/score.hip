@@ -70,7 +70,7 @@ constexpr int PPT = CAP / TPB;     // records per thread and window
 #endif
 constexpr int SK = 1 << SS_SK_BITS;                  // slots of one filter table (three rotate)
 #ifndef SS_PC
-#define SS_PC 1152
+#define SS_PC 1024
 #endif
 constexpr int PC = SS_PC;          // pending survivor records = capacity of the exact stage (>= CAP)
 constexpr int PPX = (PC + TPB - 1) / TPB;            // pending records per thread in a flush
@@ -89,7 +89,7 @@ constexpr int MAX_WIN = 1023;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t NOREC = 0xFFFFu;                  // "no first record" in a packed ht_rec half
 #ifndef SS_CB_MIN
-#define SS_CB_MIN 512
+#define SS_CB_MIN 256
 #endif
 #ifndef SS_SLICE_TARGET
 #define SS_SLICE_TARGET 262144
@@ -100,7 +100,21 @@ constexpr uint32_t MAX_SLICES_PER_Q = 256;
 #define SS_SLICE_MIN 16384
 #endif
 constexpr uint64_t SLICE_MIN = SS_SLICE_MIN;         // smallest adaptive slice (postings)
+constexpr int MAXCH = PC / 64;                       // chunked windows: most 64-record chunks per window (their records fit the exact stage)
+constexpr int WAVES = TPB / 64;
+constexpr int CPW = (MAXCH + WAVES - 1) / WAVES;     // chunk slots per wave and window
+constexpr int LCH = 12;                              // queries with at most this many lists take the chunked window loop
+constexpr int OSC = 16;                              // bytes per window row of cumulative chunk counts (LCH + 1 used)
+constexpr int DEPTH = 3;                             // windows whose records are in flight or in registers (= number of filter tables)
+// The filter sums in FIXED POINT: ds_add_u32 costs ~1/30 of ds_add_f32 on gfx950 (tools/micro/lds_ops.hip: 26 vs 880 ticks
+// per wave-instruction).  A record's share is scaled so that the largest coefficient maps to FX_ONE units, rounded up, and
+// clamped to FX_CLAMP; a slot that reaches FX_CLAMP counts as "unbounded" (its records survive).  PC records of
+// FX_CLAMP each stay below 2^32: the sums never wrap.
+constexpr uint32_t FX_ONE = 1u << 18;
+constexpr uint32_t FX_CLAMP = 1u << 21;
+static_assert((uint64_t)FX_CLAMP * SS_PC < (1ull << 32), "filter sums must not wrap");
 constexpr int KTH_N = 11;                            // k'-th largest impact per term for k' = 2^0 .. 2^10
+static_assert(DEPTH == 3, "ring slots, filter tables and survivor counters rotate together");
 static_assert(PC >= CAP && PC < 0xFFFF, "the exact stage must hold one whole window; record indices are 16-bit");
 static_assert(CAP % TPB == 0 && HT % 256 == 0, "sizes");
 
@@ -238,6 +252,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifdef SS_DIAG
 // Diagnostic build only (make DIAG=1): event counts and s_memtime sums of wave 0 of every slice, printed by ss_scorer_destroy.
 __device__ unsigned long long g_diag[24];
+__device__ unsigned long long g_slice[4096][4];      // per launch index: {start (realtime 100 MHz), end, windows, records}
 #define DIAG_ADD(i, v) do { if ((threadIdx.x) == 0) atomicAdd(&g_diag[i], (unsigned long long)(v)); } while (0)
 #define DIAG_NOW(var) unsigned long long var; do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -260,7 +275,8 @@ struct TopK {
 // Sort the candidate buffer best-first and keep the k best. All threads call.
 // (An enumeration sort — every entry counts the entries that precede it, 2 barriers instead of 38 — measured
 // 25 % slower end to end: 65k broadcast LDS reads cost more than the bitonic network's barriers.)
-__device__ void topk_compact(const TopK& tk, int k) {
+// (by value: a reference would force the struct into scratch memory for the out-of-line call)
+__device__ void topk_compact(const TopK tk, int k) {
     DIAG_ADD(4, 1);
     lds_barrier();
     const uint32_t nthr = blockDim.x;
@@ -338,13 +354,13 @@ struct SliceLds {
     uint64_t* l_w;       // [MAXL] address of the list's first float32 weight
     uint32_t* ht_key;    // [HT]
     uint32_t* ht_rec;    // [HT] first body record (low 16 bits) and first title record (high 16) of the slot's doc
-    float* sk;           // [3][SK] filter tables
+    uint32_t* sk;        // [3][SK] filter tables (fixed point)
     uint32_t* tbl;       // [TBL_CAP] cursor of list l at the start of window j: tbl[j*L+l]
     uint32_t* l_mult;    // [MAXL] multiplicity of the term in the query
     uint32_t* l_field;   // [MAXL] 0 = body, 1 = title
     uint32_t* f_cur;     // [MAXL] oversize fallback: sub-window start
     uint32_t* f_nxt;     // [MAXL] oversize fallback: sub-window end
-    float* l_coef;       // [MAXL] filter coefficient: upper bound of (38|29)*mult/sqrt(queryLength)
+    float* l_coef;       // [MAXL] filter coefficient in fixed-point units: upper bound of (38|29)*mult/sqrt(queryLength) * scale
     uint16_t* off;       // [OFF_CAP] offset of list l inside window j: off[j*OS+l], count at [j*OS+OS-1]
     uint32_t* overflow;  // shared scalar
 };
@@ -354,52 +370,27 @@ struct SliceQuery {      // per-query constants of the exact stage
     const double* probs;
 };
 
-// records of one window: raw 8-byte vectors (one global_load_dwordx2 per posting), their list, index in the list
-// and filter coefficient.  L <= 6: the lists' coefficients come in registers (cf).
-struct Coef6 { float c0, c1, c2, c3, c4, c5; };
-__device__ __forceinline__ void load_window(const SliceLds& S, int j, int L, int OS, int tid, const Coef6 cf,
+// generic window loop (L > LCH lists): records of one window as raw 8-byte vectors (one global_load_dwordx2 per posting)
+// with their list, index in the list and filter coefficient; the list of record i by binary search in the window's offsets
+__device__ __forceinline__ void load_window(const SliceLds& S, int j, int L, int OS, int tid,
                                             u32x2 (&rec)[PPT], uint32_t (&rl)[PPT], uint32_t (&ri)[PPT], float (&rc)[PPT]) {
     const uint32_t* tbl_j = S.tbl + j * L;
-    if (L <= 6) {
-        // the whole offset row in one 16-byte LDS read; list of record i by comparisons in registers
-        const uint4 o = *reinterpret_cast<const uint4*>(S.off + j * 8);
-        const uint32_t o1 = o.x >> 16, o2 = o.y & 0xFFFFu, o3 = o.y >> 16, o4 = o.z & 0xFFFFu, o5 = o.z >> 16, n = o.w >> 16;
+    const uint16_t* off_j = S.off + j * OS;
+    const uint32_t n = off_j[OS - 1];
 #pragma unroll
-        for (int r = 0; r < PPT; r++) {
-            const uint32_t i = tid + r * TPB;
-            rl[r] = EMPTY;
-            if (i < n) {
-                uint32_t l = 0, ol = 0;     // padding entries are 0xFFFF: never <= i
-                float c = cf.c0;
-                if (i >= o1) { l = 1; ol = o1; c = cf.c1; }
-                if (i >= o2) { l = 2; ol = o2; c = cf.c2; }
-                if (i >= o3) { l = 3; ol = o3; c = cf.c3; }
-                if (i >= o4) { l = 4; ol = o4; c = cf.c4; }
-                if (i >= o5) { l = 5; ol = o5; c = cf.c5; }
-                ri[r] = tbl_j[l] + (i - ol);
-                rec[r] = load_rec(S.l_rec[l], ri[r]);
-                rl[r] = l;
-                rc[r] = c;
+    for (int r = 0; r < PPT; r++) {
+        const uint32_t i = tid + r * TPB;
+        rl[r] = EMPTY;
+        if (i < n) {
+            int lo = 0, hi = L;            // largest l with off[l] <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (off_j[mid] <= i) lo = mid; else hi = mid;
             }
-        }
-    } else {
-        const uint16_t* off_j = S.off + j * OS;
-        const uint32_t n = off_j[OS - 1];
-#pragma unroll
-        for (int r = 0; r < PPT; r++) {
-            const uint32_t i = tid + r * TPB;
-            rl[r] = EMPTY;
-            if (i < n) {
-                int lo = 0, hi = L;            // largest l with off[l] <= i
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (off_j[mid] <= i) lo = mid; else hi = mid;
-                }
-                ri[r] = tbl_j[lo] + (i - off_j[lo]);
-                rec[r] = load_rec(S.l_rec[lo], ri[r]);
-                rl[r] = lo;
-                rc[r] = S.l_coef[lo];
-            }
+            ri[r] = tbl_j[lo] + (i - off_j[lo]);
+            rec[r] = load_rec(S.l_rec[lo], ri[r]);
+            rl[r] = lo;
+            rc[r] = S.l_coef[lo];
         }
     }
 }
@@ -408,84 +399,65 @@ __device__ __forceinline__ void load_window(const SliceLds& S, int j, int L, int
 // score every touched doc (get_metadata.go:31-69), reset the table, filter into the running top-k.
 // All LDS reads of a thread's entries are issued together; empty slots read as zero sums and drop out.
 __device__ __forceinline__ void scan_table(const SliceLds& S, const TopK& tk, const SliceQuery& Q, const ScoreParams& p, int tid) {
-    uint64_t e_key[EPT];
-    uint32_t e_doc[EPT];
-    double2 tb[EPT];
-    uint32_t fr[EPT];
-    const uint64_t thr0 = *tk.thr;
-    const float thr_f = *tk.thr_f;
-#pragma unroll
+    // one table entry per thread and pass (a real loop: the exact stage runs a few times per slice, and its registers
+    // must not crowd the window loop's)
+#pragma unroll 1
     for (int r = 0; r < EPT; r++) {
         const int hh = tid + r * TPB;
-        e_doc[r] = EMPTY;
-        fr[r] = EMPTY;
-        if (HT % TPB == 0 || hh < HT) {
-            e_doc[r] = S.ht_key[hh];
-            fr[r] = S.ht_rec[hh];
-        }
-    }
-    double mt[EPT], mb[EPT];
-#pragma unroll
-    for (int r = 0; r < EPT; r++) {
-        const int hh = tid + r * TPB;
-        // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
-        double2 rb = make_double2(0.0, 1.0), rt = make_double2(0.0, 1.0);
-        const uint32_t ib = fr[r] & 0xFFFFu, it = fr[r] >> 16;
-        if (e_doc[r] != EMPTY) {
+        uint32_t e_doc = EMPTY;
+        uint64_t e_key = 0;
+        if (HT % TPB == 0 || hh < HT) e_doc = S.ht_key[hh];
+        if (e_doc != EMPTY) {
+            const uint32_t fr = S.ht_rec[hh];
+            // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
+            double2 rb = make_double2(0.0, 1.0), rt = make_double2(0.0, 1.0);
+            const uint32_t ib = fr & 0xFFFFu, it = fr >> 16;
             if (ib != NOREC) rb = S.s_rec[ib];
             if (it != NOREC) rt = S.s_rec[it];
             S.ht_key[hh] = EMPTY;
             S.ht_rec[hh] = EMPTY;
-        }
-        tb[r] = make_double2(rb.x, rt.x);
-        mb[r] = rb.y;
-        mt[r] = rt.y;
-    }
-#pragma unroll
-    for (int r = 0; r < EPT; r++) {
-        e_key[r] = 0;
-        if (e_doc[r] != EMPTY) {
-            const double B = tb[r].x, T = tb[r].y;
-            // cheap float estimate first: most docs of a batch are below the running threshold by now.
-            // Skipped only if the estimate, with a 1e-4 relative margin, is clearly below; anything
-            // non-finite falls through to the exact path.
+            const double B = rb.x, T = rt.x, mb = rb.y, mt = rt.y;
+            const uint64_t thr0 = *tk.thr;
+            const float thr_f = *tk.thr_f;
+            // cheap float estimate first; skipped only if the estimate, with a 1e-4 relative margin, is clearly below the
+            // threshold; anything non-finite falls through to the exact path.
             // v_rcp_f32 (1 ulp) instead of an IEEE division: the 1e-4 margin below covers it; 0*inf = NaN falls through
-            const float ea = 38.0f * ((float)T * __builtin_amdgcn_rcpf((float)mt[r] * Q.qmag_f)), eb = 29.0f * ((float)B * __builtin_amdgcn_rcpf((float)mb[r] * Q.qmag_f)),
+            const float ea = 38.0f * ((float)T * __builtin_amdgcn_rcpf((float)mt * Q.qmag_f)), eb = 29.0f * ((float)B * __builtin_amdgcn_rcpf((float)mb * Q.qmag_f)),
                         ec = 33.0f * Q.sqd_ub_f;
-            if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) { e_doc[r] = EMPTY; continue; }
-            double title, body, fin;
-            if (Q.probs) {
-                // the prior row (128 B) is only fetched if the doc can still make the top-k:
-                // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
-                final_rank(T, B, mt[r], mb[r], Q.qmag, Q.sqd_ub, title, body, fin);
-                if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt[r], mb[r], Q.qmag, topic_dot(p.prior, Q.probs, p.k_topics, e_doc[r]), title, body, fin);
-                else e_doc[r] = EMPTY;
+            if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) {
+                e_doc = EMPTY;
             } else {
-                final_rank(T, B, mt[r], mb[r], Q.qmag, 0.0, title, body, fin);
+                double title, body, fin;
+                if (Q.probs) {
+                    // the prior row (128 B) is only fetched if the doc can still make the top-k:
+                    // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
+                    final_rank(T, B, mt, mb, Q.qmag, Q.sqd_ub, title, body, fin);
+                    if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, Q.qmag, topic_dot(p.prior, Q.probs, p.k_topics, e_doc), title, body, fin);
+                    else e_doc = EMPTY;
+                } else {
+                    final_rank(T, B, mt, mb, Q.qmag, 0.0, title, body, fin);
+                }
+                e_key = fkey(fin);
             }
-            e_key[r] = fkey(fin);
         }
-    }
-    // threshold filter into the candidate buffer; overflow -> compact and retry
-    for (;;) {
-        const uint64_t thr = *tk.thr;
-#pragma unroll
-        for (int r = 0; r < EPT; r++) {
-            if (e_doc[r] != EMPTY) {
-                if (e_key[r] >= thr) {
+        // threshold filter into the candidate buffer; overflow -> compact and retry
+        for (;;) {
+            const uint64_t thr = *tk.thr;
+            if (e_doc != EMPTY) {
+                if (e_key >= thr) {
                     const uint32_t i = atomicAdd(tk.count, 1u);
-                    if (i < tk.cb) { tk.key[i] = e_key[r]; tk.doc[i] = e_doc[r]; e_doc[r] = EMPTY; }
+                    if (i < tk.cb) { tk.key[i] = e_key; tk.doc[i] = e_doc; e_doc = EMPTY; }
                     else *S.overflow = 1;
                 } else {
-                    e_doc[r] = EMPTY;
+                    e_doc = EMPTY;
                 }
             }
+            lds_barrier();
+            if (!*S.overflow) break;
+            topk_compact(tk, p.k);         // raises thr; count back to <= k
+            if (tid == 0) *S.overflow = 0;
+            lds_barrier();
         }
-        lds_barrier();
-        if (!*S.overflow) break;
-        topk_compact(tk, p.k);         // raises thr; count back to <= k
-        if (tid == 0) *S.overflow = 0;
-        lds_barrier();
     }
 }
 
@@ -548,6 +520,171 @@ __device__ __forceinline__ void flush_pending(const SliceLds& S, const TopK& tk,
     DIAG_ADD(8, t_f1 - t_f0);
 }
 
+// ---- oversize window (a list is locally much denser than planned): bisect its doc range until a piece fits and hand
+//      every record of the piece to the exact stage.  Rare; no filter.  The pending list must be empty on entry. ----
+__device__ __forceinline__ void oversize_window(const SliceLds& S, const TopK& tk, const SliceQuery& Q, const ScoreParams& p, int tid, int L,
+                                                int j, int n_win, const SliceDesc& sd, uint32_t drv, uint64_t drv_addr) {
+    if (tid < L) S.f_cur[tid] = S.tbl[j * L + tid];
+    uint32_t flo = j == 0 ? sd.dlo : load_doc(drv_addr, S.tbl[j * L + drv]);
+    const uint32_t fend = j + 1 == n_win ? sd.dhi : load_doc(drv_addr, S.tbl[(j + 1) * L + drv]);
+    __syncthreads();
+    for (;;) {
+        uint32_t fhi = fend;
+        uint32_t cnt;
+        for (;;) {
+            if (tid < L) {
+                S.f_nxt[tid] = fhi == fend ? S.tbl[(j + 1) * L + tid]
+                                           : lower_bound_addr(S.l_rec[tid], S.f_cur[tid], S.tbl[(j + 1) * L + tid], fhi);
+            }
+            __syncthreads();
+            cnt = 0;
+            for (int l = 0; l < L; l++) cnt += S.f_nxt[l] - S.f_cur[l];
+            if (cnt <= (uint32_t)CAP) break;
+            // a single doc has at most L <= 132 postings, so the bisection ends
+            fhi = flo + (uint32_t)(((uint64_t)fhi - flo) >> 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < PPT; r++) {
+            const uint32_t i = tid + r * TPB;
+            if (i < cnt) {
+                uint32_t run = 0;
+                int l = 0;
+                for (; l < L; l++) {
+                    const uint32_t len = S.f_nxt[l] - S.f_cur[l];
+                    if (i < run + len) break;
+                    run += len;
+                }
+                const uint32_t idx = S.f_cur[l] + (i - run);
+                S.pend[i] = make_uint4(load_doc(S.l_rec[l], idx), idx, (uint32_t)l, 0u);
+            }
+        }
+        lds_barrier();
+        flush_pending(S, tk, Q, p, tid, cnt);
+        bool done = true;
+        for (int l = 0; l < L; l++) done = done && S.f_nxt[l] == S.tbl[(j + 1) * L + l];
+        __syncthreads();
+        if (done) break;
+        if (tid < L) S.f_cur[tid] = S.f_nxt[tid];
+        flo = fhi;
+        __syncthreads();
+    }
+}
+
+// ---- chunked windows (L <= LCH): a wave loads 64 consecutive records of ONE list per chunk ---------------------------
+// Everything that depends on the list — record address, filter coefficient, how many lanes hold a record — is then
+// wave-uniform and lives in scalar registers; a lane spends ~10 vector instructions per record.  A window is at most
+// MAXCH chunks (sum over the lists of ceil(len/64)); its row in S.off holds the cumulative chunk counts (one byte per list).
+struct ChunkRef { uint32_t l, start, cnt; };     // list, index of the chunk's first record in the list, records (0: no chunk)
+struct WaveLists { uint32_t rec_lo, rec_hi; float coef; };   // lane l < L keeps list l's record address and filter coefficient
+struct WinRow { uint32_t cum, t0, t1, n_ch; };   // lane l <= L: cumulative chunk count before list l, the list's cursors at both window ends
+
+// one row of the window plan, read lane-parallel (lanes past L repeat lane L: no divergence)
+__device__ __forceinline__ WinRow win_row(const SliceLds& S, int L, int j, int n_win, int lane) {
+    const int li = min(lane, L);
+    const int jr = min(j, n_win - 1);      // windows past the end: read the last row (stays in bounds), report no chunks
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(S.off) + jr * OSC;
+    WinRow w;
+    w.cum = row[li];
+    w.t0 = S.tbl[jr * L + li];           // lane L reads one entry past the row's lists: the next row's first cursor (unused)
+    w.t1 = S.tbl[(jr + 1) * L + min(li, L - 1)];
+    w.n_ch = j < n_win ? (uint32_t)__builtin_amdgcn_readlane((int)w.cum, L) : 0u;
+    return w;
+}
+
+__device__ __forceinline__ ChunkRef chunk_of(const WinRow& w, int L, uint32_t c, int lane) {
+    ChunkRef cr{0u, 0u, 0u};
+    if (c < w.n_ch && w.n_ch <= (uint32_t)MAXCH) {
+        // list = the last one whose cumulative count is <= c (cum_0 = 0; lists without chunks repeat their predecessor's count)
+        const unsigned long long m = __ballot(lane < L && w.cum <= c);
+        const int l = __builtin_amdgcn_readfirstlane(__popcll(m) - 1);
+        const uint32_t rem = c - (uint32_t)__builtin_amdgcn_readlane((int)w.cum, l);
+        cr.l = (uint32_t)l;
+        cr.start = (uint32_t)__builtin_amdgcn_readlane((int)w.t0, l) + rem * 64u;
+        cr.cnt = min(64u, (uint32_t)__builtin_amdgcn_readlane((int)w.t1, l) - cr.start);
+    }
+    return cr;
+}
+
+// Requests window j's records into ring slot S_.  ALWAYS CPW loads per wave — lanes past the chunk's end repeat its last
+// record, chunk slots without a chunk (and windows past the end) read a harmless dummy word — so that the number of loads
+// in flight behind any slot is a compile-time constant and the wait in front of chunk_add is a counted s_waitcnt vmcnt(N),
+// not a drain.  Address = wave-uniform list base + 32-bit lane offset (global_load saddr form: no 64-bit vector math).
+template <int S_>
+__device__ __forceinline__ void chunk_issue(const WinRow& w, const WaveLists& wl, int L, int wave, int lane, uint64_t dummy,
+                                            u32x2 (&rec)[DEPTH][CPW], uint32_t (&cnt)[DEPTH][CPW], float (&cf)[DEPTH][CPW]) {
+#pragma unroll
+    for (int r = 0; r < CPW; r++) {
+        const ChunkRef cr = chunk_of(w, L, (uint32_t)(wave + r * WAVES), lane);
+        cnt[S_][r] = cr.cnt;
+        uint64_t base = dummy;
+        uint32_t voff = 0;
+        cf[S_][r] = 0.f;
+        if (cr.cnt) {
+            base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wl.rec_hi, (int)cr.l) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane((int)wl.rec_lo, (int)cr.l);
+            cf[S_][r] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wl.coef), (int)cr.l));
+            voff = (cr.start + min((uint32_t)lane, cr.cnt - 1u)) * (uint32_t)sizeof(Rec);
+        }
+        rec[S_][r] = *(gptr_u2)(base + voff);
+    }
+}
+
+// the running threshold in the filter's units, rounded down: a slot below it cannot hold a doc of the top-k.
+// thr_f = -inf (no threshold yet) -> 0: everything survives; never above FX_CLAMP: clamped shares always survive.
+__device__ __forceinline__ uint32_t fx_threshold(float thr_f, float r_ub, float fx_scale) {
+    const float t = (thr_f - r_ub) * fx_scale * (1.0f - 0x1p-20f);
+    return t > 0.0f ? min((uint32_t)t, FX_CLAMP) : 0u;
+}
+
+// a record's share of FinalRank in fixed-point units, rounded up, clamped (NaN -> 1: only reachable with the filter off)
+__device__ __forceinline__ uint32_t fx_share(float imp, float coef_fx) {
+    return min((uint32_t)(imp * coef_fx), FX_CLAMP - 1u) + 1u;
+}
+// filter slot of a doc: doc ids inside a window are a narrow range, so folding the id's low bits spreads them
+__device__ __forceinline__ uint32_t fx_slot(uint32_t doc) { return (doc ^ (doc >> SS_SK_BITS)) & (uint32_t)(SK - 1); }
+
+template <int S_>
+__device__ __forceinline__ void chunk_add(uint32_t* sk_cur, int lane, const u32x2 (&rec)[DEPTH][CPW], const uint32_t (&cnt)[DEPTH][CPW],
+                                          const float (&cf)[DEPTH][CPW], uint32_t (&h)[CPW]) {
+#pragma unroll
+    for (int r = 0; r < CPW; r++) {
+        h[r] = EMPTY;
+        if (cnt[S_][r]) {                                        // wave-uniform
+            if ((uint32_t)lane < cnt[S_][r]) {
+                h[r] = fx_slot(rec[S_][r].x);
+                atomicAdd(&sk_cur[h[r]], fx_share(__uint_as_float(rec[S_][r].y), cf[S_][r]));
+            }
+        }
+    }
+}
+
+template <int S_>
+__device__ __forceinline__ void chunk_filter(const SliceLds& S, const uint32_t (&u)[CPW], uint32_t* sk_prv, uint32_t* surv_cnt_cur, int L, int j, int n_win, int wave, int lane,
+                                             uint32_t thr_fx, uint32_t pbase, const u32x2 (&rec)[DEPTH][CPW],
+                                             const uint32_t (&h)[CPW], uint32_t (&hprev)[CPW]) {
+#pragma unroll
+    for (int r = 0; r < CPW; r++) {
+        const bool surv = h[r] != EMPTY && u[r] >= thr_fx;
+        if (hprev[r] != EMPTY) sk_prv[hprev[r]] = 0u;
+        hprev[r] = h[r];
+        const unsigned long long m = __ballot(surv);
+        if (m) {
+            // rare: which list and where — looked up again instead of being carried through the pipeline
+            const WinRow w = win_row(S, L, j, n_win, lane);
+            const ChunkRef cr = chunk_of(w, L, (uint32_t)(wave + r * WAVES), lane);
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t b = 0;
+            if (lane == leader) b = atomicAdd(surv_cnt_cur, (uint32_t)__popcll(m));
+            b = (uint32_t)__shfl((int)b, leader, 64);
+            if (surv) {
+                const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+                S.pend[pbase + b + (uint32_t)__popcll(m & below)] = make_uint4(rec[S_][r].x, cr.start + (uint32_t)lane, cr.l, 0u);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ScoreLds lo_ = score_lds_layout(p.cb);
@@ -562,7 +699,7 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     S.l_w = reinterpret_cast<uint64_t*>(smem + lo_.l_w);
     S.ht_key = reinterpret_cast<uint32_t*>(smem + lo_.ht_key);
     S.ht_rec = reinterpret_cast<uint32_t*>(smem + lo_.ht_rec);
-    S.sk = reinterpret_cast<float*>(smem + lo_.sk);
+    S.sk = reinterpret_cast<uint32_t*>(smem + lo_.sk);
     S.tbl = reinterpret_cast<uint32_t*>(smem + lo_.tbl);
     S.l_mult = reinterpret_cast<uint32_t*>(smem + lo_.l_mult);
     S.l_field = reinterpret_cast<uint32_t*>(smem + lo_.l_field);
@@ -576,9 +713,13 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     float* thr_f_s = reinterpret_cast<float*>(&sc32[2]);
     uint32_t* surv_cnt = &sc32[4];                  // [3] survivors appended by window j: surv_cnt[j % 3]
     uint32_t* thr0_bits = &sc32[8];                 // slice set-up: max of the lists' bounds (non-negative floats order like their bits)
+    uint32_t* coef_max_bits = &sc32[9];             // slice set-up: largest filter coefficient of the query's lists
 
     const int tid = threadIdx.x, lane = tid & 63;
     DIAG_NOW(t_k0);
+#ifdef SS_DIAG
+    const unsigned long long t_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t slice_id = p.order[blockIdx.x];
     const SliceDesc sd = p.slices[slice_id];
     const uint32_t q = sd.q;
@@ -596,8 +737,8 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     const bool exact_all = p.exact_all != 0;
 
     for (int i = tid; i < HT; i += TPB) { S.ht_key[i] = EMPTY; S.ht_rec[i] = EMPTY; }
-    for (int i = tid; i < 3 * SK; i += TPB) S.sk[i] = 0.0f;
-    if (tid == 0) { cand_count = 0; *S.overflow = 0; sc64[0] = 0ull; *thr_f_s = -INFINITY; surv_cnt[0] = surv_cnt[1] = surv_cnt[2] = 0; *thr0_bits = 0; }
+    for (int i = tid; i < 3 * SK; i += TPB) S.sk[i] = 0u;
+    if (tid == 0) { cand_count = 0; *S.overflow = 0; sc64[0] = 0ull; *thr_f_s = -INFINITY; surv_cnt[0] = surv_cnt[1] = surv_cnt[2] = 0; *thr0_bits = 0; *coef_max_bits = 0; }
 
     // ---- slice set-up: where every list enters and leaves the slice's doc range ----
     uint32_t* t_lo = S.tbl;                 // row 0 of the table
@@ -635,7 +776,9 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
         // threshold floor: the same rounded down, times the list's k'-th largest impact (k' >= k distinct documents
         // score at least their own contribution when every other addend is >= 0).
         const double share = (field ? 38.0 : 29.0) * (double)mult / Q.qmag;
-        S.l_coef[tid] = __double2float_ru(share * (1.0 + 0x1p-12));
+        const float coef = __double2float_ru(share * (1.0 + 0x1p-12));
+        S.l_coef[tid] = coef;
+        if (coef > 0.0f && coef < INFINITY) atomicMax(coef_max_bits, __float_as_uint(coef));
         if (!exact_all && kth > 0.0f) {
             const float floor_l = __double2float_rd(share * (1.0 - 0x1p-12) * (double)kth);
             if (floor_l > 0.0f) atomicMax(thr0_bits, __float_as_uint(floor_l));
@@ -648,8 +791,12 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
         else t_lo[l] = sd.dlo == 0 ? 0u : lower_bound_interp(S.l_rec[l], 0, S.f_cur[l], sd.dlo);
     }
     __syncthreads();
+    // fixed-point scale of the filter: the largest coefficient (an impact of 1.0 in that list) = FX_ONE units
+    const float coef_max = __uint_as_float(*coef_max_bits);
+    const float fx_scale = coef_max > 0.0f ? (float)FX_ONE / coef_max : 1.0f;
     const float thr0_f = __uint_as_float(*thr0_bits);
     const uint64_t thr0_key = thr0_f > 0.0f ? fkey((double)thr0_f) : 0ull;
+    if (tid < L) S.l_coef[tid] = S.l_coef[tid] * fx_scale * (1.0f + 0x1p-20f);     // filter coefficients in fixed-point units from here on
     const TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], thr_f_s, thr0_key, thr0_f > 0.0f ? thr0_f : -INFINITY, (uint32_t)p.cb};
     if (tid == 0 && thr0_f > 0.0f) { sc64[0] = thr0_key; *thr_f_s = thr0_f; }
     // every thread: total, driver (longest list in the slice), number of windows
@@ -659,13 +806,24 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
         tot += len;
         if (len > drv_len) { drv_len = len; drv = l; }
     }
+    const bool chunked = L <= LCH;
     int n_win = 0;
     if (tot) {
-        n_win = (int)((tot + TARGET - 1) / TARGET);
-        n_win = min(n_win, min(MAX_WIN, min(TBL_CAP / L - 1, OFF_CAP / (L <= 6 ? 8 : L + 1))));
+        if (chunked) {
+            // mean 13.5 of the MAXCH = 16 chunks per window: every non-empty list wastes half a chunk per window on
+            // average, and the counts fluctuate (sigma ~0.6 chunks); more than MAXCH falls back to the oversize path
+            int l_ne = 0;
+            for (int l = 0; l < L; l++) l_ne += t_hi[l] != t_lo[l];
+            const uint32_t tgt = (uint32_t)max(192, (MAXCH * 64 * 27) / 32 - 34 * l_ne);
+            n_win = (int)((tot + tgt - 1) / tgt);
+            n_win = min(n_win, min(MAX_WIN, min(TBL_CAP / L - 1, (int)(OFF_CAP * 2 / OSC))));
+        } else {
+            n_win = (int)((tot + TARGET - 1) / TARGET);
+            n_win = min(n_win, min(MAX_WIN, min(TBL_CAP / L - 1, OFF_CAP / (L + 1))));
+        }
         n_win = max(n_win, 1);
     }
-    const int OS = L <= 6 ? 8 : L + 1;      // row stride of `off`; the window's record count sits in the row's last entry
+    const int OS = L + 1;                   // generic loop: row stride of `off`; the window's record count sits in the row's last entry
     // window j covers docs [b_j, b_{j+1}), b_j = doc of the driver's record at j/n_win of its run:
     // all cursors are known up front (no per-window serial planning; windows fill evenly because
     // the other lists simply contribute whatever falls into the driver's doc range)
@@ -678,26 +836,28 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     __syncthreads();
     if (tid < L && n_win) S.tbl[n_win * L + tid] = t_hi[tid];
     __syncthreads();
-    for (int j = tid; j < n_win; j += TPB) {
-        uint32_t run = 0;
-        for (int l = 0; l < OS - 1; l++) {
-            S.off[j * OS + l] = l < L ? (uint16_t)min(run, 0xFFFFu) : (uint16_t)0xFFFFu;
-            if (l < L) run += S.tbl[(j + 1) * L + l] - S.tbl[j * L + l];
+    if (chunked) {
+        uint8_t* off8 = reinterpret_cast<uint8_t*>(S.off);
+        for (int j = tid; j < n_win; j += TPB) {
+            uint32_t cum = 0;
+            for (int l = 0; l < L; l++) {
+                off8[j * OSC + l] = (uint8_t)min(cum, 255u);
+                const uint32_t len = S.tbl[(j + 1) * L + l] - S.tbl[j * L + l];
+                cum += (len + 63u) >> 6;
+            }
+            off8[j * OSC + L] = (uint8_t)min(cum, 255u);      // > MAXCH: oversize window
         }
-        S.off[j * OS + OS - 1] = (uint16_t)min(run, 0xFFFFu);      // > CAP: oversize window (fallback below)
+    } else {
+        for (int j = tid; j < n_win; j += TPB) {
+            uint32_t run = 0;
+            for (int l = 0; l < OS - 1; l++) {
+                S.off[j * OS + l] = (uint16_t)min(run, 0xFFFFu);
+                run += S.tbl[(j + 1) * L + l] - S.tbl[j * L + l];
+            }
+            S.off[j * OS + OS - 1] = (uint16_t)min(run, 0xFFFFu);      // > CAP: oversize window
+        }
     }
     __syncthreads();
-
-    u32x2 rec[PPT];
-    uint32_t rl[PPT], ri[PPT];
-    float rc[PPT];
-    Coef6 cf{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (L <= 6) {           // entries past L are never selected (their offsets are 0xFFFF)
-        cf.c0 = S.l_coef[0]; cf.c1 = S.l_coef[1]; cf.c2 = S.l_coef[2];
-        cf.c3 = S.l_coef[3]; cf.c4 = S.l_coef[4]; cf.c5 = S.l_coef[5];
-    }
-#pragma unroll
-    for (int r = 0; r < PPT; r++) { rl[r] = EMPTY; ri[r] = 0; rc[r] = 0.f; rec[r] = u32x2{0u, 0u}; }
 
     DIAG_NOW(t_k1);
     DIAG_ADD(0, 1);
@@ -705,126 +865,149 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     DIAG_ADD(5, tot);
     DIAG_ADD(9, t_k1 - t_k0);
     // ---- the windows ----
+    // the threshold in the filter's units: it only moves when the exact stage runs (recomputed after every flush)
+    uint32_t thr_fx = exact_all ? 0u : fx_threshold(*thr_f_s, r_ub, fx_scale);
     uint32_t pbase = 0;                     // pending survivors of the windows before this one (same value in every thread)
-    uint32_t hprev[PPT];                    // filter slots this thread touched in the previous window (EMPTY: none)
-#pragma unroll
-    for (int r = 0; r < PPT; r++) hprev[r] = EMPTY;
     int cur = 0, prv = 2;                   // j % 3, (j - 1) % 3
-    bool have = false;                      // window j's records are in flight / in registers
-    for (int j = 0; j < n_win; j++) {
-        const uint32_t n = S.off[j * OS + OS - 1];
-        const int nxt = cur == 2 ? 0 : cur + 1;
-        const bool normal = n <= (uint32_t)CAP;
-        if (normal && !have) load_window(S, j, L, OS, tid, cf, rec, rl, ri, rc);     // first window, or the one after an oversize window
-        have = false;
-        uint32_t h[PPT];
-        u32x2 mine[PPT];
-        uint32_t ml[PPT], mi[PPT];
-        float* sk_cur = S.sk + cur * SK;
-        if (normal) {
-            // stage 1a: every record adds its share into its doc's slot (waits for window j's records)
-#pragma unroll
-            for (int r = 0; r < PPT; r++) {
-                h[r] = EMPTY;
-                if (rl[r] != EMPTY) {
-                    h[r] = (rec[r].x * 2654435761u) >> (32 - SS_SK_BITS);
-                    atomicAdd(&sk_cur[h[r]], __uint_as_float(rec[r].y) * rc[r]);
-                }
-                mine[r] = rec[r]; ml[r] = rl[r]; mi[r] = ri[r];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < PPT; r++) { h[r] = EMPTY; ml[r] = EMPTY; mi[r] = 0; mine[r] = u32x2{0u, 0u}; }
+    if (chunked && n_win > 0) {
+        const int wave = tid >> 6;
+        WaveLists wl{0u, 0u, 0.f};
+        if (lane < L) {
+            const uint64_t a = S.l_rec[lane];
+            wl.rec_lo = (uint32_t)a;
+            wl.rec_hi = (uint32_t)(a >> 32);
+            wl.coef = S.l_coef[lane];
         }
-        lds_barrier();
-        // survivors of window j-1 are all appended now; their count is stable until window j+2 re-uses the counter
-        pbase += surv_cnt[prv];
-        if (tid == 0) surv_cnt[nxt] = 0;
-        if (!normal || pbase + n > (uint32_t)PC) {
-            if (pbase) flush_pending(S, tk, Q, p, tid, pbase);
-            pbase = 0;
+        u32x2 rec[DEPTH][CPW];
+        uint32_t cnt[DEPTH][CPW];
+        float cf[DEPTH][CPW];
+        uint32_t hprev[CPW];
+#pragma unroll
+        for (int r = 0; r < CPW; r++) {
+            hprev[r] = EMPTY;
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) { rec[d][r] = u32x2{0u, 0u}; cnt[d][r] = 0; cf[d][r] = 0.f; }
         }
-        if (!normal) {
-            // ---- oversize window (a list is locally much denser than planned): bisect its doc range until a
-            //      piece fits and hand every record of the piece to the exact stage.  Rare; no filter. ----
-            if (tid < L) S.f_cur[tid] = S.tbl[j * L + tid];
-            uint32_t flo = j == 0 ? sd.dlo : load_doc(drv_addr, S.tbl[j * L + drv]);
-            const uint32_t fend = j + 1 == n_win ? sd.dhi : load_doc(drv_addr, S.tbl[(j + 1) * L + drv]);
-            __syncthreads();
-            for (;;) {
-                uint32_t fhi = fend;
-                uint32_t cnt;
-                for (;;) {
-                    if (tid < L) {
-                        S.f_nxt[tid] = fhi == fend ? S.tbl[(j + 1) * L + tid]
-                                                   : lower_bound_addr(S.l_rec[tid], S.f_cur[tid], S.tbl[(j + 1) * L + tid], fhi);
-                    }
-                    __syncthreads();
-                    cnt = 0;
-                    for (int l = 0; l < L; l++) cnt += S.f_nxt[l] - S.f_cur[l];
-                    if (cnt <= (uint32_t)CAP) break;
-                    // a single doc has at most L <= 132 postings, so the bisection ends
-                    fhi = flo + (uint32_t)(((uint64_t)fhi - flo) >> 1);
-                    __syncthreads();
-                }
+        const uint8_t* off8 = reinterpret_cast<const uint8_t*>(S.off);
+        // windows 0 .. DEPTH-1 go in flight before the loop; window j + DEPTH is requested at the end of step j.
+        // The loop is unrolled by DEPTH so that ring slots and filter tables are compile-time constants; the window
+        // count is padded to a multiple of DEPTH with empty windows (no records, same instruction sequence).
+        const uint64_t dummy = (uint64_t)p.q_off;      // 8 readable bytes for lanes without a record
+        chunk_issue<0>(win_row(S, L, 0, n_win, lane), wl, L, wave, lane, dummy, rec, cnt, cf);
+        chunk_issue<1>(win_row(S, L, 1, n_win, lane), wl, L, wave, lane, dummy, rec, cnt, cf);
+        chunk_issue<2>(win_row(S, L, 2, n_win, lane), wl, L, wave, lane, dummy, rec, cnt, cf);
+#define SS_CHUNK_STEP(S_, JJ)                                                                                              \
+        {                                                                                                                  \
+            const int j_ = (JJ);                                                                                           \
+            constexpr int nxt_ = (S_ + 1) % 3, prv_ = (S_ + 2) % 3;                                                        \
+            const uint32_t n_ch = j_ < n_win ? off8[j_ * OSC + L] : 0u;                                                    \
+            const bool normal = n_ch <= (uint32_t)MAXCH;                                                                   \
+            uint32_t* sk_cur = S.sk + S_ * SK;                                                                             \
+            uint32_t* sk_prv = S.sk + prv_ * SK;                                                                           \
+            uint32_t h[CPW], u[CPW];                                                                                       \
+            /* stage 1a: every record adds its share into its doc's slot (waits for THIS window's records only) */        \
+            chunk_add<S_>(sk_cur, lane, rec, cnt, cf, h);                                                                  \
+            lds_barrier();                                                                                                 \
+            /* ONE round of LDS latency for everything the rest of the step needs: the survivor count of the previous */  \
+            /* window (complete now, stable until its counter is re-used), this window's slots, the plan row of the   */  \
+            /* window that is requested next                                                                          */  \
+            const uint32_t sc_ = surv_cnt[prv_];                                                                           \
+            _Pragma("unroll") for (int r = 0; r < CPW; r++) u[r] = sk_cur[h[r] & (uint32_t)(SK - 1)];                      \
+            const WinRow row_ = win_row(S, L, j_ + DEPTH, n_win, lane);                                                    \
+            pbase += sc_;                                                                                                  \
+            if (tid == 0) surv_cnt[nxt_] = 0;                                                                              \
+            if (!normal || pbase + n_ch * 64u > (uint32_t)PC) {                                                            \
+                if (pbase) flush_pending(S, tk, Q, p, tid, pbase);                                                         \
+                pbase = 0;                                                                                                 \
+                if (!normal) oversize_window(S, tk, Q, p, tid, L, j_, n_win, sd, drv, drv_addr);                           \
+                thr_fx = exact_all ? 0u : fx_threshold(*thr_f_s, r_ub, fx_scale);                                          \
+            }                                                                                                              \
+            /* stage 1b: the slot bounds the doc's FinalRank from above; below the threshold -> drop.  Then the records */ \
+            /* of window j + DEPTH are requested into the registers this window has just released.                    */ \
+            chunk_filter<S_>(S, u, sk_prv, &surv_cnt[S_], L, j_, n_win, wave, lane, thr_fx, pbase, rec, h, hprev);         \
+            chunk_issue<S_>(row_, wl, L, wave, lane, dummy, rec, cnt, cf);                                                 \
+        }
+        for (int j = 0; j < n_win; j += DEPTH) {
+            SS_CHUNK_STEP(0, j)
+            SS_CHUNK_STEP(1, j + 1)
+            SS_CHUNK_STEP(2, j + 2)
+        }
+#undef SS_CHUNK_STEP
+        prv = 2;                                // the padded window count is a multiple of 3: the last step used counter 2
+    } else if (!chunked) {
+        u32x2 rec[PPT];
+        uint32_t rl[PPT], ri[PPT];
+        float rc[PPT];
+#pragma unroll
+        for (int r = 0; r < PPT; r++) { rl[r] = EMPTY; ri[r] = 0; rc[r] = 0.f; rec[r] = u32x2{0u, 0u}; }
+        uint32_t hprev[PPT];                // filter slots this thread touched in the previous window (EMPTY: none)
+#pragma unroll
+        for (int r = 0; r < PPT; r++) hprev[r] = EMPTY;
+        bool have = false;                  // window j's records are in flight / in registers
+        for (int j = 0; j < n_win; j++) {
+            const uint32_t n = S.off[j * OS + OS - 1];
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            const bool normal = n <= (uint32_t)CAP;
+            if (normal && !have) load_window(S, j, L, OS, tid, rec, rl, ri, rc);     // first window, or the one after an oversize window
+            have = false;
+            uint32_t h[PPT];
+            u32x2 mine[PPT];
+            uint32_t ml[PPT], mi[PPT];
+            uint32_t* sk_cur = S.sk + cur * SK;
+            if (normal) {
+                // stage 1a: every record adds its share into its doc's slot (waits for window j's records)
 #pragma unroll
                 for (int r = 0; r < PPT; r++) {
-                    const uint32_t i = tid + r * TPB;
-                    if (i < cnt) {
-                        uint32_t run = 0;
-                        int l = 0;
-                        for (; l < L; l++) {
-                            const uint32_t len = S.f_nxt[l] - S.f_cur[l];
-                            if (i < run + len) break;
-                            run += len;
-                        }
-                        const uint32_t idx = S.f_cur[l] + (i - run);
-                        S.pend[i] = make_uint4(load_doc(S.l_rec[l], idx), idx, (uint32_t)l, 0u);
+                    h[r] = EMPTY;
+                    if (rl[r] != EMPTY) {
+                        h[r] = fx_slot(rec[r].x);
+                        atomicAdd(&sk_cur[h[r]], fx_share(__uint_as_float(rec[r].y), rc[r]));
+                    }
+                    mine[r] = rec[r]; ml[r] = rl[r]; mi[r] = ri[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < PPT; r++) { h[r] = EMPTY; ml[r] = EMPTY; mi[r] = 0; mine[r] = u32x2{0u, 0u}; }
+            }
+            lds_barrier();
+            // survivors of window j-1 are all appended now; their count is stable until window j+2 re-uses the counter
+            pbase += surv_cnt[prv];
+            if (tid == 0) surv_cnt[nxt] = 0;
+            if (!normal || pbase + n > (uint32_t)PC) {
+                if (pbase) flush_pending(S, tk, Q, p, tid, pbase);
+                pbase = 0;
+                if (!normal) oversize_window(S, tk, Q, p, tid, L, j, n_win, sd, drv, drv_addr);
+                thr_fx = exact_all ? 0u : fx_threshold(*thr_f_s, r_ub, fx_scale);
+            }
+            // put the next window's loads in flight
+            if (j + 1 < n_win && S.off[(j + 1) * OS + OS - 1] <= CAP) {
+                load_window(S, j + 1, L, OS, tid, rec, rl, ri, rc);
+                have = true;
+            }
+            // stage 1b: the slot now bounds the doc's FinalRank from above; below the threshold -> drop.
+            // (An oversize window has no records here: only the previous window's slots are cleared.)
+            uint32_t* sk_prv = S.sk + prv * SK;
+#pragma unroll
+            for (int r = 0; r < PPT; r++) {
+                bool surv = false;
+                if (ml[r] != EMPTY) surv = sk_cur[h[r]] >= thr_fx;
+                if (hprev[r] != EMPTY) sk_prv[hprev[r]] = 0u;
+                hprev[r] = h[r];
+                const unsigned long long m = __ballot(surv);
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    uint32_t b = 0;
+                    if (lane == leader) b = atomicAdd(&surv_cnt[cur], (uint32_t)__popcll(m));
+                    b = (uint32_t)__shfl((int)b, leader, 64);
+                    if (surv) {
+                        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+                        S.pend[pbase + b + (uint32_t)__popcll(m & below)] = make_uint4(mine[r].x, mi[r], ml[r], 0u);
                     }
                 }
-                lds_barrier();
-                flush_pending(S, tk, Q, p, tid, cnt);
-                bool done = true;
-                for (int l = 0; l < L; l++) done = done && S.f_nxt[l] == S.tbl[(j + 1) * L + l];
-                __syncthreads();
-                if (done) break;
-                if (tid < L) S.f_cur[tid] = S.f_nxt[tid];
-                flo = fhi;
-                __syncthreads();
             }
+            prv = cur;
+            cur = nxt;
         }
-        // put the next window's loads in flight
-        if (j + 1 < n_win && S.off[(j + 1) * OS + OS - 1] <= CAP) {
-            load_window(S, j + 1, L, OS, tid, cf, rec, rl, ri, rc);
-            have = true;
-        }
-        // stage 1b: the slot now bounds the doc's FinalRank from above; below the threshold -> drop.
-        // (An oversize window has no records here: only the previous window's slots are cleared.)
-        const float thr_f = exact_all ? -INFINITY : *thr_f_s;
-        float* sk_prv = S.sk + prv * SK;
-#pragma unroll
-        for (int r = 0; r < PPT; r++) {
-            bool surv = false;
-            if (ml[r] != EMPTY) {
-                const float ub = sk_cur[h[r]] + r_ub;
-                surv = !(ub < thr_f);                 // NaN survives
-            }
-            if (hprev[r] != EMPTY) sk_prv[hprev[r]] = 0.0f;
-            hprev[r] = h[r];
-            const unsigned long long m = __ballot(surv);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                uint32_t b = 0;
-                if (lane == leader) b = atomicAdd(&surv_cnt[cur], (uint32_t)__popcll(m));
-                b = (uint32_t)__shfl((int)b, leader, 64);
-                if (surv) {
-                    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-                    S.pend[pbase + b + (uint32_t)__popcll(m & below)] = make_uint4(mine[r].x, mi[r], ml[r], 0u);
-                }
-            }
-        }
-        prv = cur;
-        cur = nxt;
     }
     lds_barrier();
     pbase += surv_cnt[prv];
@@ -841,6 +1024,14 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     if (tid == 0) p.so_cnt[slice_id] = n_out;
     DIAG_NOW(t_k3);
     DIAG_ADD(11, t_k3 - t_k0);
+#ifdef SS_DIAG
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_slice[blockIdx.x][0] = t_r0;
+        g_slice[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        g_slice[blockIdx.x][2] = (unsigned long long)n_win;
+        g_slice[blockIdx.x][3] = tot;
+    }
+#endif
 }
 
 // ---- K6: quoted-phrase matching (retrieval/phrase.go:11-170, util.go:162-203) --------------------
@@ -1299,6 +1490,15 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
             fprintf(stderr, "[ss diag] k_score_slices (thread 0 of every slice):");
             for (int i = 0; i < 12; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
             fprintf(stderr, "\n");
+        }
+        static unsigned long long hs[4096][4];
+        if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_slice), sizeof(hs)) == hipSuccess) {
+            if (FILE* f = fopen("gpurun_out/ss_diag_slices.csv", "w")) {
+                fprintf(f, "launch,start,end,windows,records\n");
+                for (int i = 0; i < 4096; i++)
+                    if (hs[i][1]) fprintf(f, "%d,%llu,%llu,%llu,%llu\n", i, hs[i][0], hs[i][1], hs[i][2], hs[i][3]);
+                fclose(f);
+            }
         }
     }
 #endif

@@ -35,6 +35,12 @@ __global__ __launch_bounds__(TPB, 4) void k(uint32_t seed, unsigned long long* o
         if (OP == 10) u[h] = x;                                                   // random ds_write_b32
         if (OP == 11) atomicMax(&u[h], x);                                        // random ds_max_u32 (no return)
         if (OP == 12) atomicAdd(&d[2 * lin], 1.0);                                // stride-1 ds_add_f64
+        if (OP == 13) atomicAdd(&u[h], x & 255u);                                 // random ds_add_u32 (no return)
+        if (OP == 14) acc += atomicAdd(&u[h], x & 255u);                          // random ds_add_rtn_u32
+        if (OP == 15) acc += u[h];                                                // random ds_read_b32
+        if (OP == 16) atomicOr(&u[h], x);                                         // random ds_or_b32 (no return)
+        if (OP == 17) atomicAdd(reinterpret_cast<float*>(&u[lin]), 1.0f);         // stride-1 ds_add_f32
+        if (OP == 18) atomicAdd(&u[lin], 1u);                                     // stride-1 ds_add_u32
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (acc == 0x12345678u || accd == 1.2345) sink[0] = acc;
@@ -68,7 +74,13 @@ int main() {
     run<2>("random ds_cmpst_rtn_b32");
     run<9>("random ds_cmpst_rtn_b64");
     run<3>("random ds_add_f32");
+    run<17>("stride-1 ds_add_f32");
     run<11>("random ds_max_u32");
+    run<13>("random ds_add_u32");
+    run<18>("stride-1 ds_add_u32");
+    run<14>("random ds_add_rtn_u32");
+    run<16>("random ds_or_b32");
+    run<15>("random ds_read_b32");
     run<6>("random ds_read_b64");
     run<7>("random ds_read_b128");
     run<8>("stride-1 ds_read_b128");
