@@ -78,7 +78,6 @@ constexpr int PPX = (PC + TPB - 1) / TPB;            // pending records per thre
 #define SS_HT 2048
 #endif
 constexpr int HT = SS_HT;          // exact-stage hash slots (load <= PC/HT)
-constexpr int EPT = (HT + TPB - 1) / TPB;            // hash entries per thread in the scan
 constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS + 4;     // (term, field) lists per query + 4 phrase result lists
 #ifndef SS_TBL_CAP
 #define SS_TBL_CAP 2048
@@ -104,7 +103,7 @@ constexpr int MAXCH = PC / 64;                       // chunked windows: most 64
 constexpr int WAVES = TPB / 64;
 constexpr int CPW = (MAXCH + WAVES - 1) / WAVES;     // chunk slots per wave and window
 constexpr int LCH = 12;                              // queries with at most this many lists take the chunked window loop
-constexpr int OSC = 16;                              // bytes per window row of cumulative chunk counts (LCH + 1 used)
+constexpr int OSC = 16;                              // bytes per window row: LCH + 1 cumulative chunk counts, then the window's records / 8
 constexpr int DEPTH = 3;                             // windows whose records are in flight or in registers (= number of filter tables)
 // The filter sums in FIXED POINT: ds_add_u32 costs ~1/30 of ds_add_f32 on gfx950 (tools/micro/lds_ops.hip: 26 vs 880 ticks
 // per wave-instruction).  A record's share is scaled so that the largest coefficient maps to FX_ONE units, rounded up, and
@@ -396,68 +395,64 @@ __device__ __forceinline__ void load_window(const SliceLds& S, int j, int L, int
 }
 
 // ---- exact stage -----------------------------------------------------------------------------------------------
-// score every touched doc (get_metadata.go:31-69), reset the table, filter into the running top-k.
-// All LDS reads of a thread's entries are issued together; empty slots read as zero sums and drop out.
-__device__ __forceinline__ void scan_table(const SliceLds& S, const TopK& tk, const SliceQuery& Q, const ScoreParams& p, int tid) {
-    // one table entry per thread and pass (a real loop: the exact stage runs a few times per slice, and its registers
-    // must not crowd the window loop's)
-#pragma unroll 1
-    for (int r = 0; r < EPT; r++) {
-        const int hh = tid + r * TPB;
-        uint32_t e_doc = EMPTY;
-        uint64_t e_key = 0;
-        if (HT % TPB == 0 || hh < HT) e_doc = S.ht_key[hh];
-        if (e_doc != EMPTY) {
-            const uint32_t fr = S.ht_rec[hh];
-            // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
-            double2 rb = make_double2(0.0, 1.0), rt = make_double2(0.0, 1.0);
-            const uint32_t ib = fr & 0xFFFFu, it = fr >> 16;
-            if (ib != NOREC) rb = S.s_rec[ib];
-            if (it != NOREC) rt = S.s_rec[it];
-            S.ht_key[hh] = EMPTY;
-            S.ht_rec[hh] = EMPTY;
-            const double B = rb.x, T = rt.x, mb = rb.y, mt = rt.y;
-            const uint64_t thr0 = *tk.thr;
-            const float thr_f = *tk.thr_f;
-            // cheap float estimate first; skipped only if the estimate, with a 1e-4 relative margin, is clearly below the
-            // threshold; anything non-finite falls through to the exact path.
-            // v_rcp_f32 (1 ulp) instead of an IEEE division: the 1e-4 margin below covers it; 0*inf = NaN falls through
-            const float ea = 38.0f * ((float)T * __builtin_amdgcn_rcpf((float)mt * Q.qmag_f)), eb = 29.0f * ((float)B * __builtin_amdgcn_rcpf((float)mb * Q.qmag_f)),
-                        ec = 33.0f * Q.sqd_ub_f;
-            if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) {
-                e_doc = EMPTY;
+// score ONE doc of the exact stage's table (get_metadata.go:31-69) — the thread that claimed the doc's slot owns it —
+// reset its slot and offer it to the running top-k.  All threads call (slot = EMPTY: nothing to score): the admit
+// loop's barrier is workgroup-wide.
+__device__ __forceinline__ void score_owned(const SliceLds& S, const TopK& tk, const SliceQuery& Q, const ScoreParams& p, int tid,
+                                            uint32_t doc, uint32_t slot) {
+    uint32_t e_doc = EMPTY;
+    uint64_t e_key = 0;
+    if (slot != EMPTY) {
+        e_doc = doc;
+        const uint32_t fr = S.ht_rec[slot];
+        // no posting of a field => its sum is 0 and 0/(m*q) is 0 (or NaN -> 0) for every m
+        double2 rb = make_double2(0.0, 1.0), rt = make_double2(0.0, 1.0);
+        const uint32_t ib = fr & 0xFFFFu, it = fr >> 16;
+        if (ib != NOREC) rb = S.s_rec[ib];
+        if (it != NOREC) rt = S.s_rec[it];
+        S.ht_key[slot] = EMPTY;
+        S.ht_rec[slot] = EMPTY;
+        const double B = rb.x, T = rt.x, mb = rb.y, mt = rt.y;
+        const uint64_t thr0 = *tk.thr;
+        const float thr_f = *tk.thr_f;
+        // cheap float estimate first; skipped only if the estimate, with a 1e-4 relative margin, is clearly below the
+        // threshold; anything non-finite falls through to the exact path.
+        // v_rcp_f32 (1 ulp) instead of an IEEE division: the 1e-4 margin below covers it; 0*inf = NaN falls through
+        const float ea = 38.0f * ((float)T * __builtin_amdgcn_rcpf((float)mt * Q.qmag_f)), eb = 29.0f * ((float)B * __builtin_amdgcn_rcpf((float)mb * Q.qmag_f)),
+                    ec = 33.0f * Q.sqd_ub_f;
+        if ((ea + eb + ec) + (fabsf(ea) + fabsf(eb) + fabsf(ec)) * 1e-4f + 1e-30f < thr_f) {
+            e_doc = EMPTY;
+        } else {
+            double title, body, fin;
+            if (Q.probs) {
+                // the prior row (128 B) is only fetched if the doc can still make the top-k:
+                // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
+                final_rank(T, B, mt, mb, Q.qmag, Q.sqd_ub, title, body, fin);
+                if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, Q.qmag, topic_dot(p.prior, Q.probs, p.k_topics, e_doc), title, body, fin);
+                else e_doc = EMPTY;
             } else {
-                double title, body, fin;
-                if (Q.probs) {
-                    // the prior row (128 B) is only fetched if the doc can still make the top-k:
-                    // every operation of final_rank is monotone in sqd, so sqd_ub bounds the score
-                    final_rank(T, B, mt, mb, Q.qmag, Q.sqd_ub, title, body, fin);
-                    if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, Q.qmag, topic_dot(p.prior, Q.probs, p.k_topics, e_doc), title, body, fin);
-                    else e_doc = EMPTY;
-                } else {
-                    final_rank(T, B, mt, mb, Q.qmag, 0.0, title, body, fin);
-                }
-                e_key = fkey(fin);
+                final_rank(T, B, mt, mb, Q.qmag, 0.0, title, body, fin);
+            }
+            e_key = fkey(fin);
+        }
+    }
+    // threshold filter into the candidate buffer; overflow -> compact and retry
+    for (;;) {
+        const uint64_t thr = *tk.thr;
+        if (e_doc != EMPTY) {
+            if (e_key >= thr) {
+                const uint32_t i = atomicAdd(tk.count, 1u);
+                if (i < tk.cb) { tk.key[i] = e_key; tk.doc[i] = e_doc; e_doc = EMPTY; }
+                else *S.overflow = 1;
+            } else {
+                e_doc = EMPTY;
             }
         }
-        // threshold filter into the candidate buffer; overflow -> compact and retry
-        for (;;) {
-            const uint64_t thr = *tk.thr;
-            if (e_doc != EMPTY) {
-                if (e_key >= thr) {
-                    const uint32_t i = atomicAdd(tk.count, 1u);
-                    if (i < tk.cb) { tk.key[i] = e_key; tk.doc[i] = e_doc; e_doc = EMPTY; }
-                    else *S.overflow = 1;
-                } else {
-                    e_doc = EMPTY;
-                }
-            }
-            lds_barrier();
-            if (!*S.overflow) break;
-            topk_compact(tk, p.k);         // raises thr; count back to <= k
-            if (tid == 0) *S.overflow = 0;
-            lds_barrier();
-        }
+        lds_barrier();
+        if (!*S.overflow) break;
+        topk_compact(tk, p.k);         // raises thr; count back to <= k
+        if (tid == 0) *S.overflow = 0;
+        lds_barrier();
     }
 }
 
@@ -467,7 +462,7 @@ __device__ __forceinline__ void flush_pending(const SliceLds& S, const TopK& tk,
     DIAG_ADD(2, 1);
     DIAG_ADD(3, n);
     DIAG_NOW(t_f0);
-    uint32_t pdoc[PPX], pl[PPX];
+    uint32_t pdoc[PPX], pl[PPX], own[PPX];
     float pw[PPX];
     double pm[PPX];
 #pragma unroll
@@ -490,11 +485,13 @@ __device__ __forceinline__ void flush_pending(const SliceLds& S, const TopK& tk,
 #pragma unroll
     for (int r = 0; r < PPX; r++) {
         const uint32_t l = pl[r];
+        own[r] = EMPTY;
         if (l != EMPTY) {
             const uint32_t i = tid + r * TPB;
             uint32_t h = (((pdoc[r] * 2654435761u) >> 20) * (uint32_t)(HT / 256)) >> 4;      // 12 hash bits -> [0, HT)
             for (;;) {
                 const uint32_t prev = atomicCAS(&S.ht_key[h], EMPTY, pdoc[r]);
+                if (prev == EMPTY) own[r] = h;     // this thread claimed the doc's slot: it will score the doc
                 if (prev == EMPTY || prev == pdoc[r]) break;
                 h = h + 1 == HT ? 0 : h + 1;
             }
@@ -515,7 +512,8 @@ __device__ __forceinline__ void flush_pending(const SliceLds& S, const TopK& tk,
         }
     }
     lds_barrier();
-    scan_table(S, tk, Q, p, tid);
+#pragma unroll
+    for (int r = 0; r < PPX; r++) score_owned(S, tk, Q, p, tid, pdoc[r], own[r]);
     DIAG_NOW(t_f1);
     DIAG_ADD(8, t_f1 - t_f0);
 }
@@ -839,13 +837,15 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     if (chunked) {
         uint8_t* off8 = reinterpret_cast<uint8_t*>(S.off);
         for (int j = tid; j < n_win; j += TPB) {
-            uint32_t cum = 0;
+            uint32_t cum = 0, recs = 0;
             for (int l = 0; l < L; l++) {
                 off8[j * OSC + l] = (uint8_t)min(cum, 255u);
                 const uint32_t len = S.tbl[(j + 1) * L + l] - S.tbl[j * L + l];
                 cum += (len + 63u) >> 6;
+                recs += len;
             }
             off8[j * OSC + L] = (uint8_t)min(cum, 255u);      // > MAXCH: oversize window
+            off8[j * OSC + L + 1] = (uint8_t)min((recs + 7u) >> 3, 255u);   // records / 8, rounded up (<= MAXCH * 64 / 8 = 128 for a regular window)
         }
     } else {
         for (int j = tid; j < n_win; j += TPB) {
@@ -901,6 +901,7 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
             const int j_ = (JJ);                                                                                           \
             constexpr int nxt_ = (S_ + 1) % 3, prv_ = (S_ + 2) % 3;                                                        \
             const uint32_t n_ch = j_ < n_win ? off8[j_ * OSC + L] : 0u;                                                    \
+            const uint32_t n_rec = j_ < n_win ? 8u * off8[j_ * OSC + L + 1] : 0u;                                          \
             const bool normal = n_ch <= (uint32_t)MAXCH;                                                                   \
             uint32_t* sk_cur = S.sk + S_ * SK;                                                                             \
             uint32_t* sk_prv = S.sk + prv_ * SK;                                                                           \
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
             const WinRow row_ = win_row(S, L, j_ + DEPTH, n_win, lane);                                                    \
             pbase += sc_;                                                                                                  \
             if (tid == 0) surv_cnt[nxt_] = 0;                                                                              \
-            if (!normal || pbase + n_ch * 64u > (uint32_t)PC) {                                                            \
+            if (!normal || pbase + n_rec > (uint32_t)PC) {                                                                 \
                 if (pbase) flush_pending(S, tk, Q, p, tid, pbase);                                                         \
                 pbase = 0;                                                                                                 \
                 if (!normal) oversize_window(S, tk, Q, p, tid, L, j_, n_win, sd, drv, drv_addr);                           \
