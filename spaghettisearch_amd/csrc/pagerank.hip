@@ -49,7 +49,7 @@ struct PrCtl {
     uint32_t pad;
 };
 
-enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3, W_ROWS = 4 };
+enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3, W_ROWS = 4, W_ROWG = 5 };
 
 struct WorkItem {
     uint32_t kind;
@@ -225,6 +225,14 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
 #endif
 
 // ---- gather ------------------------------------------------------------------
+// T[row][t] addressed as table base (wave-uniform, scalar registers) + 32-bit byte offset: the contribution table of a rank
+// stays below 4 GiB (n_nd * GW * 8 bytes, checked in ss_pr_create), so no 64-bit vector address arithmetic is needed
+template <int GW>
+__device__ __forceinline__ double tab_at(const double* __restrict__ T, uint32_t row, int t) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(T) + (size_t)((row * (uint32_t)GW + (uint32_t)t) * 8u));
+}
+
+
 constexpr uint32_t SRC_MASK = 0x7FFFFFFFu;   // in_src bit 31 = "last in-edge of its row" (graph.hip)
 constexpr int CH = 16;                       // edges per chunk of the GW=16 path
 
@@ -269,9 +277,48 @@ __device__ __forceinline__ uint32_t gather_chunk(const double* __restrict__ T, c
 #pragma unroll
     for (int j = 0; j < CH; j++) {
         const uint32_t sj = (uint32_t)__shfl((int)src[j / GW], gbase + (j % GW), 64);
-        v[j] = (uint32_t)j < n ? T[(size_t)sj * GW + t] : 0.0;
+        v[j] = (uint32_t)j < n ? tab_at<GW>(T, sj, t) : 0.0;
     }
     return last & 0xFFFFu;
+}
+
+// gather_chunk in two steps (W_ROWS puts other loads between them): the index words + row-end flags, then the gathers
+template <int GW>
+__device__ __forceinline__ uint32_t chunk_head(const uint32_t* __restrict__ in_src, size_t pos, uint32_t n, int lane, uint32_t (&src)[CH / GW]) {
+    constexpr int R = CH / GW;
+    const int t = lane % GW, gbase = lane - t;
+    uint32_t last = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t j = (uint32_t)(r * GW + t);
+        const uint32_t raw = j < n ? NT_LOAD(&in_src[pos + j]) : 0u;
+        const unsigned long long flags = __ballot(raw >> 31);
+        last |= ((uint32_t)(flags >> gbase) & ((1u << GW) - 1u)) << (r * GW);
+        src[r] = raw & SRC_MASK;
+    }
+    return last & 0xFFFFu;
+}
+template <int GW>
+__device__ __forceinline__ void chunk_head_noflags(const uint32_t* __restrict__ in_src, size_t pos, uint32_t n, int lane, uint32_t (&src)[CH / GW]) {
+    constexpr int R = CH / GW;
+    const int t = lane % GW;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t j = (uint32_t)(r * GW + t);
+        src[r] = (j < n ? NT_LOAD(&in_src[pos + j]) : 0u) & SRC_MASK;
+    }
+}
+template <int GW>
+__device__ __forceinline__ void chunk_tail(const double* __restrict__ T, const uint32_t (&src)[CH / GW], uint32_t n, int lane, double (&v)[CH]) {
+    const int t = lane % GW, gbase = lane - t;
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        // edges past the chunk's end read row 0 (always there, always cached) and count as zero: sixteen unconditional
+        // loads instead of sixteen exec-mask branches
+        const uint32_t sj = (uint32_t)j < n ? (uint32_t)__shfl((int)src[j / GW], gbase + (j % GW), 64) : 0u;
+        const double x = tab_at<GW>(T, sj, t);
+        v[j] = (uint32_t)j < n ? x : 0.0;
+    }
 }
 
 // ---- the sweep ---------------------------------------------------------------
@@ -282,7 +329,10 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     constexpr int NSLOT = 64 / GW;
     __shared__ double rowred[WAVES][MAXK];
     __shared__ int s_rowlast;
-    __shared__ double rowsum[GW >= 8 ? WAVES * CH * 64 : 1];   // GW>=8: finished row sums of a chunk, [wave][k-th finished row][lane]
+#ifndef SS_PR_EXP_LDSX
+#define SS_PR_EXP_LDSX 1
+#endif
+    __shared__ double rowsum[GW >= 8 ? WAVES * CH * 64 * SS_PR_EXP_LDSX : 1];   // GW>=8: finished row sums of a chunk, [wave][k-th finished row][lane]
 
     PrCtl* ctl = p.ctl;
     if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
@@ -297,22 +347,32 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
 
     double dsum = 0.0, csum = 0.0;
 
-    auto finish = [&](uint32_t lrow, double y) {
+    // xo / od: the row's old rank and out-degree, already loaded by the caller (W_ROWS requests them together with the
+    // gathers of the chunk in which the row ends, so that the row's epilogue costs no second memory latency)
+    auto finish_with = [&](uint32_t lrow, double y, double xo, uint32_t od) __attribute__((always_inline)) {
         y += x0;
         const size_t xi = (size_t)lrow * GW + t;
-        const double xo = NT_LOAD(&p.x[xi]);
         double xn = (y + p.teleport) / S;               // pagerank.go:117
         if (act) {
+#ifndef SS_PR_EXP_NOSTORE_X
             NT_STORE(xn, &p.x[xi]);
+#endif
             dsum += fabs(xn - xo);                      // pagerank.go:118
         } else {
             xn = xo;                                    // converged topic: frozen
         }
         if (lrow < p.sl_nd) {                           // non-dangling row: next sweep's contribution
-            const double c = p.d * xn / (double)NT_LOAD(&p.outdeg[lrow]);   // pagerank.go:136
+            const double c = p.d * xn / (double)od;     // pagerank.go:136
+#ifndef SS_PR_EXP_NOSTORE_T
             NT_STORE(c, &Tw[xi]);
+#endif
             csum += c;                                  // pagerank.go:137
         }
+    };
+    auto finish = [&](uint32_t lrow, double y) __attribute__((always_inline)) {
+        const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + t]);
+        const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
+        finish_with(lrow, y, xo, od);
     };
 
     for (uint32_t item = blockIdx.x; item < p.n_items; item += gridDim.x) {
@@ -389,20 +449,73 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
                 while (pos < end) {
                     const uint32_t n = (uint32_t)min((size_t)CH, end - pos);
                     double v[CH];
-                    const uint32_t last = gather_chunk<GW>(T, p.in_src, pos, n, lane, v);
+                    uint32_t src[CH / GW];
+                    const uint32_t last = chunk_head<GW>(p.in_src, pos, n, lane, src);
+                    // a row ends in this chunk: its old rank and out-degree travel with the gathers
+                    double xo0 = 0.0;
+                    uint32_t od0 = 1u;
+                    if (last) {
+                        xo0 = NT_LOAD(&p.x[(size_t)row * GW + t]);
+                        if (row < p.sl_nd) od0 = NT_LOAD(&p.outdeg[row]);
+                    }
+                    chunk_tail<GW>(T, src, n, lane, v);
+                    // positions at which ANY lane group of the wave ends a row (scalar): everywhere else the edge is a plain add
+                    uint32_t any = 0;
+#pragma unroll
+                    for (int g = 0; g < 64; g += GW) any |= (uint32_t)__builtin_amdgcn_readlane((int)last, g);
                     uint32_t nfin = 0;
 #pragma unroll
                     for (int j = 0; j < CH; j++) {
                         acc += v[j];
-                        if ((last >> j) & 1u) {
-                            my[nfin * 64] = acc;
-                            nfin++;
-                            acc = 0.0;
+                        if (j == CH - 1) {
+                            // pin: the old rank / out-degree requested BEFORE the gathers are consumed here, after them (they
+                            // have landed by now: loads return in order) — keeps the compiler from sinking the request into
+                            // the row epilogue below, where it would cost a second memory latency per chunk
+                            asm volatile("" : "+v"(xo0), "+v"(od0));
+                        }
+                        if (any & (1u << j)) {
+                            if ((last >> j) & 1u) {
+                                my[nfin * 64] = acc;
+                                nfin++;
+                                acc = 0.0;
+                            }
                         }
                     }
-                    for (uint32_t r = 0; r < nfin; r++) finish(row + r, my[r * 64]);
+#if defined(SS_PR_EXP_NOFINISH)
+                    for (uint32_t r = 0; r < nfin; r++) dsum += my[r * 64] + xo0;      // experiment: no row epilogue
+#elif defined(SS_PR_EXP_NODIV)
+                    if (nfin) { NT_STORE(my[0] + xo0, &p.x[(size_t)row * GW + t]); if (row < p.sl_nd) NT_STORE(my[0] * (double)od0, &Tw[(size_t)row * GW + t]); }
+                    for (uint32_t r = 1; r < nfin; r++) { NT_STORE(my[r * 64], &p.x[(size_t)(row + r) * GW + t]); if (row + r < p.sl_nd) NT_STORE(my[r * 64], &Tw[(size_t)(row + r) * GW + t]); }
+#else
+                    if (nfin) finish_with(row, my[0], xo0, od0);
+                    for (uint32_t r = 1; r < nfin; r++) finish(row + r, my[r * 64]);
+#endif
                     row += nfin;
                     pos += n;
+                }
+            }
+        } else if (w.kind == W_ROWG) {
+            if constexpr (GW >= 8) {
+                // mid-degree rows (T_ROWG < in-edges <= T_SEG, most of the graph's edges): one lane group per ROW, rows dealt
+                // round-robin to the groups (they are degree-sorted, so the groups of a wave run about equally long).  The row's
+                // in-edges go by in 16-edge chunks, row ends come from in_ptr: no flags, no LDS, the running sum stays in a
+                // register; the row's old rank and out-degree are requested before its first gathers.
+                for (uint32_t r = wave * NSLOT + slot; r < w.count; r += WAVES * NSLOT) {
+                    const uint32_t lrow = w.row + r;
+                    const size_t beg = p.in_ptr[lrow], end = p.in_ptr[lrow + 1];
+                    const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + t]);
+                    const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
+                    double acc = 0.0;
+                    for (size_t pos = beg; pos < end; pos += CH) {
+                        const uint32_t n = (uint32_t)min((size_t)CH, end - pos);
+                        uint32_t src[CH / GW];
+                        double v[CH];
+                        chunk_head_noflags<GW>(p.in_src, pos, n, lane, src);
+                        chunk_tail<GW>(T, src, n, lane, v);
+#pragma unroll
+                        for (int j = 0; j < CH; j++) acc += v[j];
+                    }
+                    finish_with(lrow, acc, xo, od);
                 }
             }
         } else if (w.kind == W_WAVE) {
@@ -580,7 +693,8 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     seg_edges = gw >= 8 ? 2048 : 128 * NSLOT;
     nsegs = 0;
     nmulti = 0;
-    std::vector<WorkItem> seg, wav, grp, zer;
+    std::vector<WorkItem> seg, rwg, wav, grp, zer;
+    const uint32_t T_ROWG = 24;         // gw >= 8: rows with more in-edges than this (and <= T_SEG) take the row-per-lane-group class
     auto emit = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
         // deg is sorted descending: find class boundaries
@@ -595,8 +709,12 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
             nsegs += ns;
         }
         if (gw >= 8) {
-            // items of ~256 in-edges and at most 64 rows per lane group
-            uint32_t r = a;
+            // mid-degree rows: a lane group per row, 2 rows per group and item
+            uint32_t g = a;
+            while (g < c && deg[g] > T_ROWG) g++;
+            for (uint32_t r = a; r < g; r += 2 * WAVES * NSLOT) rwg.push_back({W_ROWG, row0 + r, std::min<uint32_t>(2 * WAVES * NSLOT, g - r), 0, 0, 0});
+            // the rest: items of ~256 in-edges and at most 64 rows per lane group
+            uint32_t r = g;
             while (r < c) {
                 uint32_t rows = 0;
                 uint64_t edges = 0;
@@ -621,9 +739,10 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     emit(g->h_indeg_nd, 0, true, pos_nd);
     emit(g->h_indeg_d, g->sl_nd, false, pos_d);
     items.clear();
-    items.reserve(seg.size() + wav.size() + grp.size() + zer.size());
+    items.reserve(seg.size() + rwg.size() + wav.size() + grp.size() + zer.size());
     // heavy work first
     items.insert(items.end(), seg.begin(), seg.end());
+    items.insert(items.end(), rwg.begin(), rwg.end());
     items.insert(items.end(), wav.begin(), wav.end());
     items.insert(items.end(), grp.begin(), grp.end());
     items.insert(items.end(), zer.begin(), zer.end());
@@ -693,6 +812,9 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     // persistent grid: 8 blocks per CU at most, each walks the work table round-robin
     pr->nblocks = (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
 
+    if ((uint64_t)g->nd_int * GW * 8 >= (1ull << 32))
+        return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_create: contribution table of %llu rows x %d topics exceeds 4 GiB (shard the graph over more ranks)",
+                         (unsigned long long)g->nd_int, GW);
     SS_HIP(ctx, pr->x.alloc_streaming(n_local * GW));
     SS_HIP(ctx, pr->tab0.alloc((size_t)g->nd_int * GW));
     SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, std::max<size_t>(pr->tab0.bytes(), 8), st));

@@ -1,0 +1,23 @@
+"""Config-4 sweep timing for kernel experiments: kernel ms per K-wide sweep (HIP events), median of R blocks of 20 sweeps.
+    [SS_LIB_PATH=...] K=16 python tools/pr_exp.py"""
+import os, statistics, sys
+import numpy as np, torch
+sys.path.insert(0, '.')
+from spaghettisearch_amd import engine, synth
+dev = torch.device('cuda', 0)
+ctx = engine.Context(0)
+n, e = int(os.environ.get("N", 10_000_000)), int(os.environ.get("E", 50_000_000))
+kt = int(os.environ.get("K", "16"))
+out_ptr, out_dst = synth.rmat_graph_torch(n, e, seed=42, device=dev)
+g = engine.Graph(ctx, n, out_ptr, out_dst)
+pr = engine.PageRankState(g, 0.75, -1.0, synth.topic_sizes(n, kt), max_iter=0)
+pr.begin()
+pr.step(5)
+ms = []
+for _ in range(int(os.environ.get("R", "7"))):
+    pr.step(20)
+    ctx.synchronize()
+    ms.append(ctx.last_kernel_ms(0) / 20)
+probe = [pr.probe(m, 5) for m in (0, 1, 2)] if kt >= 5 else []
+print(f"lib={os.path.basename(os.environ.get('SS_LIB_PATH', 'product'))} N={n} E={e} K={kt}: sweep median {statistics.median(ms):.4f} ms  min {min(ms):.4f} ms  probe {probe}", flush=True)
+pr.close(); g.close(); ctx.close()
