@@ -175,6 +175,12 @@ def main() -> None:
         return secs[0], [s * 1e3 / K for s in secs]
 
     ctx = engine.Context(local_rank)
+    lib_comm_error = None
+    if world > 1 and not rehearsal:
+        try:                                     # RCCL communicator INSIDE the library: torch only carries the 128-byte id
+            sharding.init_lib_comm(ctx, rank, world)
+        except Exception as exc_:
+            lib_comm_error = repr(exc_)
     c4_ranks = None
     pr_inputs = None
     stream = torch.cuda.Stream(device=dev)       # library kernels, torch copies and RCCL share one stream
@@ -283,34 +289,58 @@ def main() -> None:
                         g1.close()
                     except Exception as exc_:
                         decomp["topic_shards"] = {"value": 0.0, "error": repr(exc_)}
-                # doc-range shards: every rank sweeps its rows, ONE all-gather of the contribution slices per sweep
-                # (xGMI point-to-point: 1/N of the table per link)
-                try:
-                    pr = engine.PageRankState(g, d, -1.0, n_topic, max_iter=0)
-                    exchange = sharding.DistExchange(pr, dev, host_staged=rehearsal)
-                    pr.begin()
-                    exchange()
-                    pr.finalize()
+                # doc-range shards: every rank sweeps its rows, ONE collective of the contribution slices per sweep
+                # (xGMI point-to-point: 1/N of the table per link).  Three forms of the same exchange:
+                #   doc_range_shards            RCCL all-gather INSIDE the library (ss_pr_exchange): no Python on the data path
+                #   doc_range_shards_allreduce  the all-reduce form the north star names (same result, ~2x the bytes)
+                #   doc_range_shards_torch      torch.distributed all_gather_into_tensor on the library's buffers
+                def doc_range(make_exchange, label):
+                    st_ = engine.PageRankState(g, d, -1.0, n_topic, max_iter=0)
+                    try:
+                        ex_ = make_exchange(st_)
+                        st_.begin()
+                        ex_()
+                        st_.finalize()
 
-                    def sweeps(m: int) -> None:
-                        for _ in range(m):
-                            pr.step(1)
-                            exchange()
-                            pr.finalize()
+                        def sweeps(m: int) -> None:
+                            for _ in range(m):
+                                st_.step(1)
+                                ex_()
+                                st_.finalize()
 
-                    dt, blocks = timed_blocks(sweeps)
-                    st = pr.status()
-                    assert st["sweeps"] == max(W, 1) + N_BLOCKS * K, st
-                    decomp["doc_range_shards"] = {"value": kt * K / dt, "unit": "topic-iterations/s", "ms_per_step": dt * 1e3 / K,
-                                                  "ms_per_step_blocks": summarize(blocks),
-                                                  "parallelism": f"doc-range shards x{world}, 1 RCCL all-gather/sweep"}
-                    sp, sb, rp, rb = pr.exchange_buffers()
-                    result["exchange"] = {"allgather_recv_bytes_per_sweep": rb, "send_bytes_per_rank": sb}
-                except Exception as exc:
-                    decomp["doc_range_shards"] = {"value": 0.0, "ms_per_step": None, "error": repr(exc),
-                                                  "parallelism": f"doc-range shards x{world}, 1 RCCL all-gather/sweep"}
-                    invalid.append(f"doc-range-sharded sweep failed: {exc!r}")
-                head = decomp["doc_range_shards"]
+                        dt_, blocks_ = timed_blocks(sweeps)
+                        stat = st_.status()
+                        assert stat["sweeps"] == max(W, 1) + N_BLOCKS * K, stat
+                        sp, sb, rp, rb = st_.exchange_buffers()
+                        result["exchange"] = {"allgather_recv_bytes_per_sweep": rb, "send_bytes_per_rank": sb}
+                        return {"value": kt * K / dt_, "unit": "topic-iterations/s", "ms_per_step": dt_ * 1e3 / K,
+                                "ms_per_step_blocks": summarize(blocks_), "parallelism": label}
+                    finally:
+                        st_.close()
+
+                variants = []
+                if lib_comm_error is None and not rehearsal:
+                    variants.append(("doc_range_shards", lambda st_: sharding.LibExchange(st_),
+                                     f"doc-range shards x{world}, 1 RCCL all-gather/sweep inside the library (ss_pr_exchange)"))
+                    variants.append(("doc_range_shards_allreduce", lambda st_: sharding.LibExchange(st_, allreduce=True),
+                                     f"doc-range shards x{world}, 1 RCCL all-reduce/sweep inside the library (north-star form)"))
+                else:
+                    result["lib_comm_error"] = lib_comm_error or "rehearsal: gloo, host-staged exchange"
+                variants.append(("doc_range_shards_torch" if variants else "doc_range_shards",
+                                 lambda st_: sharding.DistExchange(st_, dev, host_staged=rehearsal),
+                                 f"doc-range shards x{world}, 1 RCCL all-gather/sweep (torch.distributed on the library's buffers)"))
+                for name, mk, label in variants:
+                    try:
+                        decomp[name] = doc_range(mk, label)
+                    except Exception as exc:
+                        decomp[name] = {"value": 0.0, "ms_per_step": None, "error": repr(exc), "parallelism": label}
+                ok_ = [nm for nm, _, _ in variants if decomp[nm]["value"] > 0]
+                if not ok_:
+                    invalid.append("doc-range-sharded sweep failed: " + "; ".join(f"{nm}: {decomp[nm].get('error')}" for nm, _, _ in variants))
+                best_ = max(ok_, key=lambda nm: decomp[nm]["value"]) if ok_ else variants[0][0]
+                if best_ != "doc_range_shards":
+                    decomp["headline"] = best_
+                head = decomp[best_]
                 result.update({
                     "metric": "pagerank_iters_per_sec", "value": head["value"], "unit": "topic-iterations/s",
                     "ms_per_step": head["ms_per_step"],
@@ -730,7 +760,7 @@ def main() -> None:
                     "ms_per_step_blocks": summarize(pblocks),
                     "parallelism": f"doc-range shards x{world}, 2 topic blocks, all-gather of one block overlapped with the sweep of the other"}
                 # headline = the faster of the two doc-range variants (both run the per-sweep RCCL exchange)
-                best = max(("doc_range_shards", "doc_range_shards_pipelined"), key=lambda name: decomp[name]["value"])
+                best = max((nm for nm in decomp if nm.startswith("doc_range_shards") and isinstance(decomp[nm], dict)), key=lambda name: decomp[name]["value"])
                 if decomp[best]["value"] > 0:
                     result["value"] = decomp[best]["value"]
                     result["ms_per_step"] = decomp[best]["ms_per_step"]

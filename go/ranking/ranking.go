@@ -96,20 +96,49 @@ func UpdateTopicSensitivePagerank(ctx context.Context, dampingFactor float64, co
 		nTopic = append(nTopic, int32(int(val["numPages"])))
 	}
 
-	g := spaghetti.Default().NewGraph(outPtr, outDst)
-	defer g.Close()
-	rank, _ := g.PageRank(dampingFactor, convergenceCriterion, nTopic) // all categories, device-resident loop
-
-	// pagerank.go:65-82 — forw[3][doc] = map[category]rank
 	bw := forward[3].BatchWrite_init(ctx)
 	defer bw.Cancel(ctx)
-	for v, name := range ids.name {
-		PR := make(map[string]float64, len(cats))
-		for k, c := range cats {
-			PR[c] = rank[k*n+v]
+	if job := spaghetti.Job(); job.World > 1 {
+		// Several GPUs (one crawl process per GPU, SS_RANK/SS_WORLD): every process flattens the same tables to the same
+		// ids (sorted hashes), keeps the destination rows of ITS doc-range shard, runs its part of the sweep with one
+		// RCCL all-gather per iteration inside the library, and writes its own rows of forw[3].  K > 16 in groups of 16.
+		g := spaghetti.Default().NewGraphShard(outPtr, outDst, job.Rank, job.World)
+		defer g.Close()
+		var rows []uint32
+		ranks := make([][]float64, 0, (len(nTopic)+15)/16)
+		for k0 := 0; k0 < len(nTopic); k0 += 16 {
+			k1 := k0 + 16
+			if k1 > len(nTopic) {
+				k1 = len(nTopic)
+			}
+			r, rk, _ := g.PageRankSharded(dampingFactor, convergenceCriterion, nTopic[k0:k1])
+			rows = r
+			ranks = append(ranks, rk)
 		}
-		if err := bw.BatchSet(ctx, name, PR); err != nil {
-			panic(err)
+		for i, v := range rows {
+			PR := make(map[string]float64, len(cats))
+			for k, c := range cats {
+				blk := ranks[k/16]
+				PR[c] = blk[(k%16)*len(rows)+i]
+			}
+			if err := bw.BatchSet(ctx, ids.name[v], PR); err != nil {
+				panic(err)
+			}
+		}
+	} else {
+		g := spaghetti.Default().NewGraph(outPtr, outDst)
+		defer g.Close()
+		rank, _ := g.PageRank(dampingFactor, convergenceCriterion, nTopic) // all categories, device-resident loop
+
+		// pagerank.go:65-82 — forw[3][doc] = map[category]rank
+		for v, name := range ids.name {
+			PR := make(map[string]float64, len(cats))
+			for k, c := range cats {
+				PR[c] = rank[k*n+v]
+			}
+			if err := bw.BatchSet(ctx, name, PR); err != nil {
+				panic(err)
+			}
 		}
 	}
 	if err = bw.Flush(ctx); err != nil {

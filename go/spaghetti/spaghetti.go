@@ -22,7 +22,10 @@ import "C"
 
 import (
 	"fmt"
+	"os"
+	"strconv"
 	"sync"
+	"time"
 	"unsafe"
 )
 
@@ -68,12 +71,52 @@ func check(c *Ctx, rc C.int32_t, what string) {
 	}
 }
 
-// Default returns the process-wide context on GPU 0 (one process per GPU).
+// JobInfo is this process's place in a multi-GPU job (SS_RANK / SS_WORLD; absent = a job of one).
+type JobInfo struct{ Rank, World int }
+
+func Job() JobInfo {
+	w, _ := strconv.Atoi(os.Getenv("SS_WORLD"))
+	r, _ := strconv.Atoi(os.Getenv("SS_RANK"))
+	if w < 2 {
+		return JobInfo{0, 1}
+	}
+	return JobInfo{r, w}
+}
+
+// Default returns the process-wide context (one process per GPU; the launcher pins the GPU with HIP_VISIBLE_DEVICES, so the
+// device index is 0).  In a multi-GPU job it also joins the job's RCCL communicator: rank 0 writes the 128-byte id to
+// SS_COMM_ID_FILE (atomically: temp file + rename), the other ranks wait for the file.
 func Default() *Ctx {
 	once.Do(func() {
 		var h *C.ss_ctx
 		check(nil, C.ss_init(0, &h), "ss_init")
 		global = &Ctx{h}
+		if job := Job(); job.World > 1 {
+			path := os.Getenv("SS_COMM_ID_FILE")
+			if path == "" {
+				panic(fmt.Errorf("SS_WORLD=%d needs SS_COMM_ID_FILE", job.World))
+			}
+			var id []byte
+			if job.Rank == 0 {
+				id = CommUniqueID()
+				if err := os.WriteFile(path+".tmp", id, 0o600); err != nil {
+					panic(err)
+				}
+				if err := os.Rename(path+".tmp", path); err != nil {
+					panic(err)
+				}
+			} else {
+				for {
+					b, err := os.ReadFile(path)
+					if err == nil && len(b) == C.SS_COMM_ID_BYTES {
+						id = b
+						break
+					}
+					time.Sleep(50 * time.Millisecond)
+				}
+			}
+			global.CommInit(id, job.Rank, job.World)
+		}
 	})
 	return global
 }
@@ -118,6 +161,56 @@ func (c *Ctx) NewGraph(outPtr []uint64, outDst []uint32) *Graph {
 	return &Graph{h, c, n}
 }
 func (g *Graph) Close() { C.ss_graph_destroy(g.h) }
+
+// ---- several GPUs: one process (= one context) per GPU, collectives inside the library (RCCL over xGMI) ----
+//
+// SS_RANK / SS_WORLD / SS_COMM_ID_FILE in the environment describe the job (a launcher starts one crawl process per
+// GPU with SS_RANK = 0..SS_WORLD-1 and HIP_VISIBLE_DEVICES set to its GPU).  Rank 0 writes the 128-byte communicator
+// id to SS_COMM_ID_FILE, the others wait for the file.  Without SS_WORLD the process is the whole job (world 1).
+
+// CommInit joins this context to the job's communicator.  Blocks until every rank has joined.
+func (c *Ctx) CommInit(id []byte, rank, world int) {
+	if len(id) != C.SS_COMM_ID_BYTES {
+		panic(fmt.Errorf("communicator id must be %d bytes", int(C.SS_COMM_ID_BYTES)))
+	}
+	check(c, C.ss_comm_init(c.h, unsafe.Pointer(&id[0]), C.int32_t(rank), C.int32_t(world)), "ss_comm_init")
+}
+
+// CommUniqueID is called by rank 0 only.
+func CommUniqueID() []byte {
+	id := make([]byte, C.SS_COMM_ID_BYTES)
+	check(nil, C.ss_comm_unique_id(unsafe.Pointer(&id[0])), "ss_comm_unique_id")
+	return id
+}
+
+// AllReduceU64 sums buf over the ranks in place (whole-corpus document frequencies of a doc-range-sharded index).
+func (c *Ctx) AllReduceU64(buf []uint64) {
+	check(c, C.ss_comm_allreduce_u64(c.h, u64p(buf), C.uint64_t(len(buf))), "ss_comm_allreduce_u64")
+}
+
+// NewGraphShard uploads the WHOLE out-edge CSR and keeps the destination rows of shard `rank` of `world`.
+func (c *Ctx) NewGraphShard(outPtr []uint64, outDst []uint32, rank, world int) *Graph {
+	n := uint64(len(outPtr) - 1)
+	var h *C.ss_graph
+	check(c, C.ss_graph_create(c.h, C.uint64_t(n), C.uint64_t(len(outDst)), u64p(outPtr), u32p(outDst), C.int32_t(rank), C.int32_t(world), &h),
+		"ss_graph_create")
+	return &Graph{h, c, n}
+}
+
+// PageRankSharded runs this rank's part of the doc-range-sharded power iteration (one RCCL all-gather per sweep inside
+// the library): ids[r] = node id of local row r, rank[k*rows+r], iters[k].  Every process writes its own rows of forw[3].
+func (g *Graph) PageRankSharded(d, eps float64, nTopic []int32) ([]uint32, []float64, []int32) {
+	var info C.ss_graph_info
+	check(g.ctx, C.ss_graph_get_info(g.h, &info), "ss_graph_get_info")
+	rows := uint64(info.n_rows_local)
+	k := len(nTopic)
+	ids := make([]uint32, rows)
+	rank := make([]float64, uint64(k)*rows)
+	iters := make([]int32, k)
+	check(g.ctx, C.ss_pagerank_run_sharded(g.h, C.double(d), C.double(eps), 0, C.int32_t(k), i32p(nTopic), 0, u32p(ids), f64p(rank), i32p(iters)),
+		"ss_pagerank_run_sharded")
+	return ids, rank, iters
+}
 
 // PageRank runs all topics to convergence: rank[k*N+v], iters[k].
 func (g *Graph) PageRank(d, eps float64, nTopic []int32) ([]float64, []int32) {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2
 
 enum {
     SS_OK = 0,
@@ -41,7 +41,8 @@ enum {
     SS_ERR_OOM = 4,          /* device or host allocation failed */
     SS_ERR_UNSORTED = 5,     /* a posting list is not strictly ascending by doc id */
     SS_ERR_STATE = 6,        /* call sequence error (e.g. scoring before tfidf build) */
-    SS_ERR_UNSUPPORTED = 7   /* e.g. k > SS_MAX_TOPK, k_topics > SS_MAX_TOPICS */
+    SS_ERR_UNSUPPORTED = 7,  /* e.g. k > SS_MAX_TOPK, k_topics > SS_MAX_TOPICS */
+    SS_ERR_COMM = 8          /* RCCL error (text in ss_last_error) */
 };
 
 #define SS_MAX_TOPK 1024     /* largest k accepted by ss_score_topk */
@@ -88,6 +89,24 @@ int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream);
 int32_t ss_synchronize(ss_ctx* ctx);
 const char* ss_last_error(ss_ctx* ctx); /* ctx may be NULL: last global error */
 
+/* ---- multi-GPU: one context (= one GPU) per rank, collectives inside the library (RCCL over xGMI) -----------
+ * The reference has no distributed code; this is what parallelises the TODO at ranking/pagerank.go:52 across GPUs.
+ * Rank 0 makes the 128-byte id and hands it to every rank by any channel the host has (file, pipe, environment);
+ * every rank then joins with its own context.  ss_comm_init blocks until all `world` ranks have called it.  One
+ * process per GPU is the intended shape; a process holding several contexts calls ss_comm_init for each from its
+ * own thread.  Collectives run on the context's stream. */
+#define SS_COMM_ID_BYTES 128
+int32_t ss_comm_unique_id(void* id_out /*[SS_COMM_ID_BYTES]*/);
+int32_t ss_comm_init(ss_ctx* ctx, const void* id /*[SS_COMM_ID_BYTES]*/, int32_t rank, int32_t world);
+int32_t ss_comm_destroy(ss_ctx* ctx);
+int32_t ss_comm_info(ss_ctx* ctx, int32_t* rank_out /* -1: no communicator */, int32_t* world_out);
+/* The exchange steps of the index side: whole-corpus document frequencies = all-reduce(sum) of the
+ * shards' list lengths (feed the result to ss_index_set_doc_freq); corpus top-k = all-gather of the shards' hit
+ * lists (feed the result to ss_merge_hits).  Host or device buffers; recv holds world * bytes_per_rank, rank order.
+ * With host buffers the call returns when the result is there; with device buffers it only enqueues. */
+int32_t ss_comm_allreduce_u64(ss_ctx* ctx, uint64_t* buf, uint64_t n);
+int32_t ss_comm_allgather(ss_ctx* ctx, const void* send, void* recv, uint64_t bytes_per_rank);
+
 /* ---- link graph: ranking/pagerank.go:17-44 ---------------------------- */
 /* Graph as the reference holds it: forw[2] rows parent -> children, flattened
  * to an out-edge CSR over dense ids (node set = parents U children, Q1;
@@ -122,9 +141,9 @@ int32_t ss_pagerank_run(ss_graph* g, double damping, double eps, int32_t max_ite
  *                    :126-145 as a pull SpMV + fused normalise/delta :115-119)
  *   ss_pr_finalize : combine per-rank partial sums, apply the stop rule.
  *                    world==1: folded into begin/step, must not be called.
- *   exchange       : world>1: after begin/step the host all-gathers `send`
- *                    (send_bytes from every rank, rank order) into `recv`,
- *                    then calls ss_pr_finalize.
+ *   exchange       : world>1: after begin/step either ss_pr_exchange (RCCL inside the library) or the host
+ *                    all-gathers `send` (send_bytes from every rank, rank order) into `recv` itself,
+ *                    then ss_pr_finalize.
  * All calls enqueue on the ctx stream and return without waiting, except
  * ss_pr_status / ss_pr_read_*.
  */
@@ -136,6 +155,19 @@ int32_t ss_pr_step(ss_pr* pr, int32_t n_steps);
 int32_t ss_pr_finalize(ss_pr* pr);
 int32_t ss_pr_exchange_buffers(ss_pr* pr, void** send_dev, uint64_t* send_bytes,
                                void** recv_dev, uint64_t* recv_bytes);
+/* world>1, in-library exchange (needs ss_comm_init with the graph's rank/world): all-gather of the ranks' contribution
+ * slices into the full table on the context's stream — the per-iteration collective of the doc-range-sharded sweep.
+ * allreduce = 0: all-gather of the non-dangling slices (0.32*N*K*8 bytes received per rank and sweep at the benchmark
+ * graph); allreduce = 1: the form the north star names — every rank contributes its slice inside a zeroed full-size
+ * table and the tables are summed (all-reduce, ~2x the bytes on the wire, bit-identical result: x + 0 is exact).
+ * Call between ss_pr_begin/ss_pr_step and ss_pr_finalize.  Enqueues only. */
+int32_t ss_pr_exchange(ss_pr* pr, int32_t allreduce);
+/* The whole sharded power iteration of one rank: begin, {sweep, exchange, finalize} until the device-side stop rule
+ * (pagerank.go:93) has fired for every topic on every rank (the ranks agree: they finalize the same gathered sums).
+ * ids_out [n_rows_local] original node ids of this rank's rows, rank_out [k_topics][n_rows_local], iters_out [k_topics].
+ * Every rank writes its own rows of forw[3]; no gather of the result is needed.  k_topics <= 16 per call. */
+int32_t ss_pagerank_run_sharded(ss_graph* g, double damping, double eps, int32_t max_iter, int32_t k_topics,
+                                const int32_t* n_topic, int32_t allreduce, uint32_t* ids_out, double* rank_out, int32_t* iters_out);
 /* Waits for the stream; iters_out[k_topics] = iterations executed per topic,
  * *n_active = topics still iterating, *sweeps = K-wide sweeps executed. */
 int32_t ss_pr_status(ss_pr* pr, int32_t* iters_out, int32_t* n_active, int32_t* sweeps,

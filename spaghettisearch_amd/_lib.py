@@ -17,7 +17,8 @@ SS_MAX_TOPICS = 64
 SS_UNKNOWN_TERM = 0xFFFFFFFF
 
 ERR_NAMES = {0: "SS_OK", 1: "SS_ERR_INVALID", 2: "SS_ERR_NO_DEVICE", 3: "SS_ERR_HIP", 4: "SS_ERR_OOM",
-             5: "SS_ERR_UNSORTED", 6: "SS_ERR_STATE", 7: "SS_ERR_UNSUPPORTED"}
+             5: "SS_ERR_UNSORTED", 6: "SS_ERR_STATE", 7: "SS_ERR_UNSUPPORTED", 8: "SS_ERR_COMM"}
+SS_COMM_ID_BYTES = 128
 
 
 class SpaghettiError(RuntimeError):
@@ -50,6 +51,12 @@ PROTOTYPES = {
     "ss_set_stream": (_i32, [_vp, _vp]),
     "ss_synchronize": (_i32, [_vp]),
     "ss_last_error": (C.c_char_p, [_vp]),
+    "ss_comm_unique_id": (_i32, [_vp]),
+    "ss_comm_init": (_i32, [_vp, _vp, _i32, _i32]),
+    "ss_comm_destroy": (_i32, [_vp]),
+    "ss_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ss_comm_allreduce_u64": (_i32, [_vp, _vp, _u64]),
+    "ss_comm_allgather": (_i32, [_vp, _vp, _vp, _u64]),
     "ss_graph_create": (_i32, [_vp, _u64, _u64, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "ss_graph_get_info": (_i32, [_vp, C.POINTER(SsGraphInfo)]),
     "ss_graph_destroy": (_i32, [_vp]),
@@ -60,6 +67,8 @@ PROTOTYPES = {
     "ss_pr_step": (_i32, [_vp, _i32]),
     "ss_pr_finalize": (_i32, [_vp]),
     "ss_pr_exchange_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_vp), C.POINTER(_u64)]),
+    "ss_pr_exchange": (_i32, [_vp, _i32]),
+    "ss_pagerank_run_sharded": (_i32, [_vp, _f64, _f64, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "ss_pr_status": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]),
     "ss_pr_read_local": (_i32, [_vp, _vp, _vp]),
     "ss_pr_read": (_i32, [_vp, _vp]),

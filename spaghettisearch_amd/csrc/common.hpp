@@ -32,6 +32,8 @@ struct ss_ctx {
     int cu_count = 256;
     size_t total_mem = 0;
     int tfidf_bucket_lds = 0;          // dynamic LDS size already granted to k_bucket_sum on this device
+    void* comm = nullptr;              // RCCL communicator of this rank (ss_comm_init), ncclComm_t
+    int comm_rank = 0, comm_world = 1;
 
     int32_t fail(int32_t code, const char* fmt, ...) {
         char buf[1024];
@@ -103,5 +105,9 @@ struct DevBuf {
 };
 
 inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// comm.hip: collectives on the context's stream (enqueue only); SS_ERR_STATE without a communicator
+int32_t comm_allgather(ss_ctx* ctx, const void* send, void* recv, size_t bytes);
+int32_t comm_allreduce_f64(ss_ctx* ctx, const double* send, double* recv, size_t count);
 
 }  // namespace ss

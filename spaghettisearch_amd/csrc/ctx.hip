@@ -73,6 +73,7 @@ int32_t ss_init(int32_t device_id, ss_ctx** out) {
 
 int32_t ss_shutdown(ss_ctx* ctx) {
     if (!ctx) return SS_ERR_INVALID;
+    (void)ss_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 3; k++)

@@ -952,6 +952,59 @@ int32_t ss_pr_exchange_buffers(ss_pr* pr, void** send_dev, uint64_t* send_bytes,
     return SS_OK;
 }
 
+int32_t ss_pr_exchange(ss_pr* pr, int32_t allreduce) {
+    if (!pr) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    const ss_graph* g = pr->g;
+    if (g->world == 1) return ctx->fail(SS_ERR_STATE, "ss_pr_exchange: world==1 has no exchange");
+    if (!pr->need_finalize) return ctx->fail(SS_ERR_STATE, "ss_pr_exchange: nothing to exchange (call after ss_pr_begin / ss_pr_step)");
+    if (!ctx->comm || ctx->comm_world != g->world || ctx->comm_rank != g->rank)
+        return ctx->fail(SS_ERR_STATE, "ss_pr_exchange: the context's communicator (rank %d of %d) does not match the graph's shard (rank %d of %d)",
+                         ctx->comm ? ctx->comm_rank : -1, ctx->comm ? ctx->comm_world : 0, g->rank, g->world);
+    const size_t slice = (size_t)g->sl_nd * pr->gw;            // doubles per rank
+    if (!allreduce) return ss::comm_allgather(ctx, pr->send.p, pr->tab0.p, slice * sizeof(double));
+    // north-star form: own slice inside a zeroed full-size table, tables summed
+    SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, pr->tab0.bytes(), ctx->stream));
+    SS_HIP(ctx, hipMemcpyAsync(pr->tab0.p + (size_t)g->rank * slice, pr->send.p, slice * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ss::comm_allreduce_f64(ctx, pr->tab0.p, pr->tab0.p, slice * (size_t)g->world);
+}
+
+int32_t ss_pagerank_run_sharded(ss_graph* g, double damping, double eps, int32_t max_iter, int32_t k_topics,
+                                const int32_t* n_topic, int32_t allreduce, uint32_t* ids_out, double* rank_out, int32_t* iters_out) {
+    if (!g) return SS_ERR_INVALID;
+    ss_ctx* ctx = g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (g->world < 2) return ctx->fail(SS_ERR_STATE, "ss_pagerank_run_sharded: needs a sharded graph (world > 1); use ss_pagerank_run");
+    if (k_topics < 1 || k_topics > MAXK || !n_topic || !rank_out)
+        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_sharded: k_topics must be 1..%d, n_topic/rank_out not NULL", MAXK);
+    if (!(eps >= 0.0) && max_iter <= 0 && !(eps != eps))
+        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_sharded: eps < 0 (never converges) needs max_iter > 0");
+    ss_pr* pr = nullptr;
+    SS_TRY(ss_pr_create(g, damping, eps, max_iter, k_topics, n_topic, &pr));
+    int32_t rc = ss_pr_begin(pr);
+    if (rc == SS_OK) rc = ss_pr_exchange(pr, allreduce);
+    if (rc == SS_OK) rc = ss_pr_finalize(pr);
+    int32_t n_active = k_topics, sweeps = 0;
+    // the stop rule lives on the device and is evaluated identically on every rank (same gathered sums, same order):
+    // the host looks every BATCH sweeps, launches after convergence are no-ops on all ranks alike
+    const int BATCH = 8;
+    while (rc == SS_OK && n_active > 0) {
+        int todo = BATCH;
+        if (max_iter > 0) todo = std::min(BATCH, std::max(1, max_iter - sweeps));
+        for (int i = 0; i < todo && rc == SS_OK; i++) {
+            rc = ss_pr_step(pr, 1);
+            if (rc == SS_OK) rc = ss_pr_exchange(pr, allreduce);
+            if (rc == SS_OK) rc = ss_pr_finalize(pr);
+        }
+        if (rc == SS_OK) rc = ss_pr_status(pr, iters_out, &n_active, &sweeps, nullptr, nullptr);
+    }
+    if (rc == SS_OK) rc = ss_pr_read_local(pr, ids_out, rank_out);
+    ss_pr_destroy(pr);
+    return rc;
+}
+
 int32_t ss_pr_status(ss_pr* pr, int32_t* iters_out, int32_t* n_active, int32_t* sweeps, double* last_delta_out,
                      double* last_total_out) {
     if (!pr) return SS_ERR_INVALID;

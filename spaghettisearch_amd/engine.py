@@ -101,6 +101,37 @@ class Context:
     def synchronize(self) -> None:
         check(self.lib.ss_synchronize(self.h), self.h)
 
+    # ---- in-library collectives (RCCL over xGMI): one context per rank
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ss_comm_unique_id: rank 0 creates the 128-byte id, the host hands it to every rank."""
+        buf = C.create_string_buffer(_lib.SS_COMM_ID_BYTES)
+        check(_lib.load().ss_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, world: int) -> None:
+        if len(uid) != _lib.SS_COMM_ID_BYTES:
+            raise ValueError("communicator id must be SS_COMM_ID_BYTES long")
+        check(self.lib.ss_comm_init(self.h, C.c_char_p(uid), rank, world), self.h)
+
+    def comm_destroy(self) -> None:
+        check(self.lib.ss_comm_destroy(self.h), self.h)
+
+    def comm_info(self):
+        r, w = C.c_int32(), C.c_int32()
+        check(self.lib.ss_comm_info(self.h, C.byref(r), C.byref(w)), self.h)
+        return r.value, w.value
+
+    def comm_allreduce_u64(self, buf) -> None:
+        """In-place all-reduce(sum) of a uint64 array (numpy host array or torch int64 device tensor)."""
+        buf = _as(buf, "uint64")
+        self.ready(buf)
+        check(self.lib.ss_comm_allreduce_u64(self.h, _ptr(buf), int(buf.shape[0])), self.h)
+
+    def comm_allgather(self, send, recv, bytes_per_rank: int) -> None:
+        self.ready(send, recv)
+        check(self.lib.ss_comm_allgather(self.h, _ptr(send), _ptr(recv), int(bytes_per_rank)), self.h)
+
     def last_kernel_ms(self, kind: int) -> float:
         ms = C.c_float(0)
         check(self.lib.ss_last_kernel_ms(self.h, kind, C.byref(ms)), self.h)
@@ -133,6 +164,19 @@ class Graph:
         gi = SsGraphInfo()
         check(self.ctx.lib.ss_graph_get_info(self.h, C.byref(gi)), self.ctx.h)
         return gi
+
+    def pagerank_sharded(self, damping: float, eps: float, n_topic: Sequence[int], max_iter: int = 0, allreduce: bool = False):
+        """ss_pagerank_run_sharded (this rank's part of the doc-range-sharded loop, collectives inside the library):
+        -> (ids uint32[rows], rank [K][rows] float64, iters [K] int32)."""
+        n_topic = np.ascontiguousarray(np.atleast_1d(n_topic), dtype=np.int32)
+        K = len(n_topic)
+        rows = int(self.info().n_rows_local)
+        ids = np.zeros(rows, dtype=np.uint32)
+        rank = np.zeros((K, rows), dtype=np.float64)
+        iters = np.zeros(K, dtype=np.int32)
+        check(self.ctx.lib.ss_pagerank_run_sharded(self.h, damping, eps, max_iter, K, _ptr(n_topic), 1 if allreduce else 0,
+                                                   _ptr(ids), _ptr(rank), _ptr(iters)), self.ctx.h)
+        return ids, rank, iters
 
     def pagerank(self, damping: float, eps: float, n_topic: Sequence[int], max_iter: int = 0):
         """ss_pagerank_run: -> (rank [K][N] float64, iters [K] int32)."""
@@ -170,6 +214,10 @@ class PageRankState:
 
     def finalize(self) -> None:
         check(self.ctx.lib.ss_pr_finalize(self.h), self.ctx.h)
+
+    def exchange(self, allreduce: bool = False) -> None:
+        """ss_pr_exchange: the per-sweep collective inside the library (needs Context.comm_init)."""
+        check(self.ctx.lib.ss_pr_exchange(self.h, 1 if allreduce else 0), self.ctx.h)
 
     def exchange_buffers(self):
         """-> (send_ptr, send_bytes, recv_ptr, recv_bytes) device pointers."""

@@ -95,6 +95,35 @@ class DistExchange:
             handle.wait()
 
 
+class LibExchange:
+    """The production exchange: RCCL inside the library (ss_pr_exchange on the context's stream) — no Python, torch or
+    second communication stack on the data path.  `state` is an engine.PageRankState whose context has a communicator
+    (init_lib_comm).  allreduce=True runs the all-reduce form the north star names instead of the all-gather."""
+
+    def __init__(self, state, allreduce: bool = False):
+        self.state, self.allreduce = state, allreduce
+
+    def __call__(self) -> None:
+        self.state.exchange(self.allreduce)
+
+    def start(self):
+        self.state.exchange(self.allreduce)     # enqueued on the context's stream: later work on that stream is ordered behind it
+        return None
+
+    @staticmethod
+    def finish(handle) -> None:
+        return None
+
+
+def init_lib_comm(ctx, rank: int, world: int, group=None) -> None:
+    """Give `ctx` (engine.Context) its in-library communicator: rank 0 makes the id, torch.distributed only carries the
+    128 bytes to the other ranks (any channel would do — the Go shim uses a file)."""
+    import torch.distributed as dist
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.comm_init(box[0], rank, world)
+
+
 class LocalExchange:
     """All shards live in ONE process (tests on a single GPU / CPU): plays the all-gather by copies."""
 

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"not exported: {missing}"
     # the Python binding covers exactly the declared set
     assert sorted(_lib.PROTOTYPES) == declared_symbols()
-    assert _lib.load().ss_abi_version() == 1
+    assert _lib.load().ss_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device():
@@ -66,10 +66,10 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     src = tmp_path / "c_caller.c"
     src.write_text('#include <stdio.h>\n#include "spaghetti_rank.h"\n'
                    'int main(void) { ss_ctx* c = 0; int v = ss_abi_version(); int rc = ss_init(0, &c);\n'
-                   '  printf("abi=%d init=%d\\n", v, rc); if (rc == SS_OK) ss_shutdown(c); return v == 1 ? 0 : 1; }\n')
+                   '  printf("abi=%d init=%d\\n", v, rc); if (rc == SS_OK) ss_shutdown(c); return v == SS_ABI_VERSION ? 0 : 1; }\n')
     exe = tmp_path / "c_caller"
     libdir = os.path.dirname(_lib.LIB_PATH)
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
                     "-lspaghetti_rank", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
-    assert out.startswith("abi=1 init=")
+    assert out.startswith("abi=2 init=")

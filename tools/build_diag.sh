@@ -4,4 +4,4 @@
 set -e
 cd "$(dirname "$0")/../spaghettisearch_amd/csrc"
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
-    -I/opt/rocm/include -DSS_DIAG $EXTRA -shared -Wl,-soname,libspaghetti_rank.so -o ../libspaghetti_rank_diag.so *.hip
+    -I/opt/rocm/include -DSS_DIAG $EXTRA -shared -Wl,-soname,libspaghetti_rank.so -o ../libspaghetti_rank_diag.so *.hip -L/opt/rocm/lib -lrccl
