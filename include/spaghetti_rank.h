@@ -150,6 +150,14 @@ int32_t ss_pagerank_run(ss_graph* g, double damping, double eps, int32_t max_ite
 int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter,
                      int32_t k_topics, const int32_t* n_topic, ss_pr** out);
 int32_t ss_pr_destroy(ss_pr* pr);
+/* OPT-IN, beyond what the reference executes: true topic-sensitive PageRank.  The reference advertises
+ * Haveliwala's TSPR (README.md:9) but its topics differ only by the start value 1/numPages (pagerank.go:54-63,104): every
+ * node teleports with the absolute (1-d) (pagerank.go:117).  With a teleport set per topic — set_ptr[k_topics+1] into
+ * set_nodes (DISTINCT original node ids; an empty set keeps that topic on the reference's uniform teleport) — topic k's
+ * teleport mass (1-d)*N is spread over its set only: cur[v] = (cur[v] + (v in set_k ? (1-d)*N/|set_k| : 0)) / total,
+ * everything else (total, stop rule, start value) as in the reference.  Call after ss_pr_create, before ss_pr_begin;
+ * NULL restores the reference behaviour.  Sharded graphs: every rank passes the full sets. */
+int32_t ss_pr_set_teleport(ss_pr* pr, const uint64_t* set_ptr /*[k_topics+1]*/, const uint32_t* set_nodes);
 int32_t ss_pr_begin(ss_pr* pr);
 int32_t ss_pr_step(ss_pr* pr, int32_t n_steps);
 int32_t ss_pr_finalize(ss_pr* pr);

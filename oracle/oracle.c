@@ -171,6 +171,82 @@ int orc_pagerank_topic(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t
     return 0;
 }
 
+/* OPT-IN extension, no reference counterpart: the loop of pagerank.go:85-124 with a topic's teleport
+ * set.  member[v] != 0: node v is in the set (n_members of them).  The reference adds the absolute (1-d) to EVERY node
+ * (:117); here the same total mass (1-d)*N goes to the set's nodes only: (1-d)*N/n_members each.  `total` (:111-112),
+ * the start value 1/n_init (:104) and the stop rule (:93) are the reference's.  member == NULL: orc_pagerank_topic. */
+int orc_pagerank_topic_ts(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
+                          double d, double eps, int32_t max_iter, int32_t n_init,
+                          const uint8_t* member, uint64_t n_members,
+                          double* rank, int32_t* iters, double* last_change_out, double* last_total_out)
+{
+    if (!member || n_members == 0)
+        return orc_pagerank_topic(n_nodes, out_ptr, out_dst, d, eps, max_iter, n_init, rank, iters, last_change_out, last_total_out);
+    const uint64_t N = n_nodes;
+    double* a = (double*)malloc(sizeof(double) * (N ? N : 1));
+    double* b = (double*)malloc(sizeof(double) * (N ? N : 1));
+    if (!a || !b) { free(a); free(b); return -1; }
+    double* cur = a;
+    double* last = b;
+    const double teleport = 1.0 - d;                                 /* pagerank.go:90 */
+    const double tin = teleport * (double)N / (double)n_members;     /* a member's teleport */
+    double last_change = DBL_MAX;
+    double total = 0.0;
+    int32_t iteration = 1;
+    for (; last_change > eps; iteration++) {
+        double* t = cur; cur = last; last = t;
+        if (iteration > 1) {
+            for (uint64_t v = 0; v < N; v++) cur[v] = 0.0;
+        } else {
+            const double u = 1.0 / (double)n_init;
+            for (uint64_t v = 0; v < N; v++) { cur[v] = u; last[v] = u; }
+        }
+        total = 0.0;
+        for (uint64_t p = 0; p < N; p++) {
+            const uint64_t beg = out_ptr[p], end = out_ptr[p + 1];
+            if (end == beg) continue;
+            const double w = d * last[p] / (double)(end - beg);
+            total += w;
+            for (uint64_t e = beg; e < end; e++) cur[out_dst[e]] += w;
+        }
+        total += teleport * (double)N;
+        last_change = 0.0;
+        for (uint64_t v = 0; v < N; v++) {
+            cur[v] = (cur[v] + (member[v] ? tin : 0.0)) / total;
+            last_change += fabs(cur[v] - last[v]);
+        }
+        if (max_iter > 0 && iteration >= max_iter) { iteration++; break; }
+    }
+    memcpy(rank, cur, sizeof(double) * N);
+    if (iters) *iters = iteration - 1;
+    if (last_change_out) *last_change_out = last_change;
+    if (last_total_out) *last_total_out = total;
+    free(a); free(b);
+    return 0;
+}
+
+/* retrieval/main_retrieve.go:106-159 computeTopicProbs (disabled in the reference: :43 is commented out and :87 passes a nil
+ * map).  K categories of forw[5] with their wordCount (:144); query token i has the category->frequency map of inv[2]
+ * (tok_ptr[n_tok+1] into tok_cat / tok_freq; tok_missing[i] != 0: the word is not in inv[2] — the reference panics there,
+ * :120-121: returns -2).  mode 0 = AS WRITTEN: `var probs float64` starts at 0 and is only ever multiplied (:142-145), so
+ * every probability is 0; mode 1 = the evident intent: the product starts at 1 (multinomial naive Bayes, uniform prior
+ * 1/K, :148).  Topics no query word maps to get 0 (:149-151). */
+int orc_topic_probs(int32_t k_topics, const double* word_count, int32_t n_tok, const uint32_t* tok_ptr,
+                    const uint32_t* tok_cat, const double* tok_freq, const uint8_t* tok_missing, int32_t mode, double* probs_out)
+{
+    for (int32_t i = 0; i < n_tok; i++)
+        if (tok_missing && tok_missing[i]) return -2;                /* :120-121 panic(err) */
+    for (int32_t k = 0; k < k_topics; k++) {
+        double probs = mode ? 1.0 : 0.0;                             /* :142 `var probs float64` */
+        int any = 0;
+        for (int32_t i = 0; i < n_tok; i++)                          /* topicTF[topic] in token order (:118-135) */
+            for (uint32_t e = tok_ptr[i]; e < tok_ptr[i + 1]; e++)
+                if ((int32_t)tok_cat[e] == k) { probs *= (tok_freq[e] / word_count[k]); any = 1; }   /* :143-145 */
+        probs_out[k] = any ? probs / (double)k_topics : 0.0;         /* :148 / :150 */
+    }
+    return 0;
+}
+
 int orc_pagerank(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
                  double d, double eps, int32_t max_iter, int32_t k_topics,
                  const int32_t* n_topic, double* rank_out, int32_t* iters_out)
@@ -624,28 +700,66 @@ typedef struct {
     uint16_t nt, nb;
     float tw[AGG_INLINE], bw[AGG_INLINE];   /* TitleWeights / BodyWeights (appended, util.go:11-17) */
     double t_run, b_run;               /* weights beyond the inline capacity, folded in arrival order */
-    uint8_t used;
-} agg_slot;
+} agg_entry;
 typedef struct { unsigned char bytes[152 - 16]; uint32_t doc; uint32_t pad; double final; } ref_row;   /* sizeof(Rank_combined) */
+/* aggregatedDocs as a Go map grows: an index table (doubled when half full) over an entry array (doubled when full);
+ * one workspace per thread, re-used from query to query like a long-running server's allocator would */
+typedef struct {
+    uint32_t* idx; uint64_t idx_cap;   /* 0 = empty, else entry index + 1 */
+    agg_entry* ent; uint64_t ent_cap, n_ent;
+    ref_row* res; uint64_t res_cap;
+} agg_ws;
 
-static int score_one_hashed(const orc_magmap* mags, uint64_t n_terms,
+static void aggws_free(agg_ws* w) { free(w->idx); free(w->ent); free(w->res); memset(w, 0, sizeof(*w)); }
+static int aggws_grow_index(agg_ws* w)
+{
+    const uint64_t cap = w->idx_cap ? w->idx_cap * 2 : 1024;
+    uint32_t* ni = (uint32_t*)calloc(cap, sizeof(uint32_t));
+    if (!ni) return -1;
+    for (uint64_t e = 0; e < w->n_ent; e++) {
+        uint64_t h = hm_hash(w->ent[e].key) & (cap - 1);
+        while (ni[h]) h = (h + 1) & (cap - 1);
+        ni[h] = (uint32_t)e + 1;
+    }
+    free(w->idx);
+    w->idx = ni;
+    w->idx_cap = cap;
+    return 0;
+}
+static agg_entry* aggws_at(agg_ws* w, const char* key, uint32_t doc)
+{
+    if ((w->n_ent + 1) * 2 > w->idx_cap && aggws_grow_index(w)) return NULL;
+    uint64_t h = hm_hash(key) & (w->idx_cap - 1);
+    for (;;) {
+        const uint32_t e = w->idx[h];
+        if (!e) break;
+        if (memcmp(w->ent[e - 1].key, key, 32) == 0) return &w->ent[e - 1];
+        h = (h + 1) & (w->idx_cap - 1);
+    }
+    if (w->n_ent == w->ent_cap) {
+        const uint64_t cap = w->ent_cap ? w->ent_cap * 2 : 1024;
+        agg_entry* ne = (agg_entry*)realloc(w->ent, cap * sizeof(agg_entry));
+        if (!ne) return NULL;
+        w->ent = ne;
+        w->ent_cap = cap;
+    }
+    agg_entry* a = &w->ent[w->n_ent];
+    memset(a, 0, sizeof(*a));
+    memcpy(a->key, key, 32);
+    a->doc = doc;
+    w->idx[h] = (uint32_t)(++w->n_ent);
+    return a;
+}
+
+static int score_one_hashed(agg_ws* w, const orc_magmap* mags, uint64_t n_terms,
                             const uint64_t* t_ptr, const uint32_t* t_doc, const float* t_w,
                             const uint64_t* b_ptr, const uint32_t* b_doc, const float* b_w,
                             const uint32_t* q_terms, int32_t n_q_terms, int32_t query_len,
                             int32_t k, orc_hit* hits, int32_t* n_hits)
 {
-    uint64_t tot = 0;
-    for (int32_t i = 0; i < n_q_terms; i++) {
-        const uint32_t t = q_terms[i];
-        if ((uint64_t)t >= n_terms) continue;
-        tot += (b_ptr[t + 1] - b_ptr[t]) + (t_ptr[t + 1] - t_ptr[t]);
-    }
-    uint64_t cap = 16;
-    while (cap < tot * 2) cap <<= 1;
-    agg_slot* agg = (agg_slot*)calloc(cap, sizeof(agg_slot));        /* aggregatedDocs (main_retrieve.go:60) */
-    if (!agg) return -1;
-    const uint64_t mask = cap - 1;
-    uint64_t n_cand = 0;
+    /* a fresh map per query (main_retrieve.go:60): entries dropped, index cleared */
+    w->n_ent = 0;
+    if (w->idx) memset(w->idx, 0, w->idx_cap * sizeof(uint32_t));
     char key[32];
     for (int32_t i = 0; i < n_q_terms; i++) {                        /* one getFromInverted result per token (:55-69) */
         const uint32_t t = q_terms[i];
@@ -656,26 +770,26 @@ static int score_one_hashed(const orc_magmap* mags, uint64_t n_terms,
             const float* ws = field ? t_w : b_w;
             for (uint64_t p = ptr[t]; p < ptr[t + 1]; p++) {
                 id_to_key(docs[p], key);
-                uint64_t h = hm_hash(key) & mask;
-                agg_slot* a;
-                for (;;) {
-                    a = &agg[h];
-                    if (!a->used) { memcpy(a->key, key, 32); a->used = 1; a->doc = docs[p]; n_cand++; break; }
-                    if (memcmp(a->key, key, 32) == 0) break;
-                    h = (h + 1) & mask;
-                }
+                agg_entry* a = aggws_at(w, key, docs[p]);
+                if (!a) return -1;
                 if (field) { if (a->nt < AGG_INLINE) a->tw[a->nt++] = ws[p]; else a->t_run += (double)ws[p]; }
                 else       { if (a->nb < AGG_INLINE) a->bw[a->nb++] = ws[p]; else a->b_run += (double)ws[p]; }
             }
         }
     }
-    ref_row* res = (ref_row*)malloc(sizeof(ref_row) * (n_cand ? n_cand : 1));   /* finalResult (:93) */
-    if (!res) { free(agg); return -1; }
+    const uint64_t n_cand = w->n_ent;
+    if (n_cand > w->res_cap) {
+        ref_row* nr = (ref_row*)realloc(w->res, sizeof(ref_row) * n_cand * 2);
+        if (!nr) return -1;
+        w->res = nr;
+        w->res_cap = n_cand * 2;
+    }
+    ref_row* res = w->res;                                           /* finalResult (:93) */
     uint64_t n_res = 0;
     const double qmag = sqrt((double)query_len);                     /* get_metadata.go:53 */
-    for (uint64_t s = 0; s < cap; s++) {                             /* range aggregatedDocs: map order */
-        const agg_slot* a = &agg[s];
-        if (!a->used) continue;
+    for (uint64_t s = 0; s < w->idx_cap; s++) {                      /* range aggregatedDocs: map order */
+        if (!w->idx[s]) continue;
+        const agg_entry* a = &w->ent[w->idx[s] - 1];
         double title = 0.0, body = 0.0;                              /* genAggrDocsPipeline :176-182 */
         for (int i = 0; i < a->nt; i++) title += (double)a->tw[i];
         title += a->t_run;      /* exact either way: float32 addends in float64 */
@@ -704,8 +818,6 @@ static int score_one_hashed(const orc_magmap* mags, uint64_t n_terms,
         hits[i].final = res[i].final;
     }
     *n_hits = (int32_t)nh;
-    free(res);
-    free(agg);
     return 0;
 }
 
@@ -722,15 +834,21 @@ int orc_score_topk_batch_hashed(const orc_magmap* mags, uint64_t n_terms,
     if (nthreads > n_q) nthreads = n_q > 0 ? n_q : 1;
 #endif
     if (threads_used) *threads_used = nthreads;
-    #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-    for (int32_t q = 0; q < n_q; q++) {
-        const int32_t nt = (int32_t)(q_ptr[q + 1] - q_ptr[q]);
-        const int rc = score_one_hashed(mags, n_terms, t_ptr, t_doc, t_w, b_ptr, b_doc, b_w, q_terms + q_ptr[q], nt,
-                                        query_len ? query_len[q] : nt, k, hits + (uint64_t)q * k, n_hits + q);
-        if (rc) {
-            #pragma omp critical
-            rc_all = rc;
+    #pragma omp parallel num_threads(nthreads)
+    {
+        agg_ws w;
+        memset(&w, 0, sizeof(w));
+        #pragma omp for schedule(dynamic, 1)
+        for (int32_t q = 0; q < n_q; q++) {
+            const int32_t nt = (int32_t)(q_ptr[q + 1] - q_ptr[q]);
+            const int rc = score_one_hashed(&w, mags, n_terms, t_ptr, t_doc, t_w, b_ptr, b_doc, b_w, q_terms + q_ptr[q], nt,
+                                            query_len ? query_len[q] : nt, k, hits + (uint64_t)q * k, n_hits + q);
+            if (rc) {
+                #pragma omp critical
+                rc_all = rc;
+            }
         }
+        aggws_free(&w);
     }
     return rc_all;
 }

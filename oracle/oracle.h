@@ -60,6 +60,15 @@ int orc_pagerank_topic(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t
                        double d, double eps, int32_t max_iter, int32_t n_init,
                        double* rank, int32_t* iters, double* last_change, double* last_total);
 
+/* OPT-IN extensions, see oracle.c: a topic's teleport set; computeTopicProbs (main_retrieve.go:106-159)
+ * as written (mode 0: all zero, the `var probs float64` quirk) and as intended (mode 1). */
+int orc_pagerank_topic_ts(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
+                          double d, double eps, int32_t max_iter, int32_t n_init,
+                          const uint8_t* member, uint64_t n_members,
+                          double* rank, int32_t* iters, double* last_change, double* last_total);
+int orc_topic_probs(int32_t k_topics, const double* word_count, int32_t n_tok, const uint32_t* tok_ptr,
+                    const uint32_t* tok_cat, const double* tok_freq, const uint8_t* tok_missing, int32_t mode, double* probs_out);
+
 /* pagerank.go:54-63: the sequential per-category loop. rank_out is [K][N] (topic-major). */
 int orc_pagerank(uint64_t n_nodes, const uint64_t* out_ptr, const uint32_t* out_dst,
                  double d, double eps, int32_t max_iter, int32_t k_topics,

@@ -118,6 +118,59 @@ def pagerank_omp(n_nodes, out_ptr, out_dst, d, eps, n_init, max_iter=0):
     return rank, it.value, th.value
 
 
+def pagerank_topic_ts(n_nodes, out_ptr, out_dst, d, eps, n_init, members, max_iter=0):
+    """Opt-in topic-sensitive teleport (orc_pagerank_topic_ts).  members: array of node ids (empty/None = reference).
+    -> (rank[N], iters)"""
+    out_ptr = _c(out_ptr, np.uint64)
+    out_dst = _c(out_dst, np.uint32)
+    rank = np.zeros(n_nodes, dtype=np.float64)
+    it = C.c_int32(0)
+    mem = None
+    nm = 0
+    if members is not None and len(members):
+        mem = np.zeros(n_nodes, dtype=np.uint8)
+        mem[np.asarray(members, dtype=np.int64)] = 1
+        nm = int(mem.sum())
+    fn = lib().orc_pagerank_topic_ts
+    fn.restype = C.c_int
+    fn.argtypes = None
+    rc = fn(C.c_uint64(n_nodes), _p(out_ptr, C.c_uint64), _p(out_dst, C.c_uint32), C.c_double(d), C.c_double(eps), C.c_int32(max_iter),
+            C.c_int32(n_init), _p(mem, C.c_uint8), C.c_uint64(nm), _p(rank, C.c_double), C.byref(it), None, None)
+    if rc:
+        raise RuntimeError(f"orc_pagerank_topic_ts rc={rc}")
+    return rank, it.value
+
+
+def topic_probs(word_count, token_maps, mode=0):
+    """computeTopicProbs (main_retrieve.go:106-159).  word_count [K]; token_maps: per query token a dict {category: freq}
+    or None (word not in inv[2]: the reference panics -> KeyError here).  mode 0 = as written (all zero), 1 = intended."""
+    word_count = _c(word_count, np.float64)
+    K = len(word_count)
+    ptr = np.zeros(len(token_maps) + 1, dtype=np.uint32)
+    cats, freqs, missing = [], [], np.zeros(max(len(token_maps), 1), dtype=np.uint8)
+    for i, m in enumerate(token_maps):
+        if m is None:
+            missing[i] = 1
+        else:
+            for c in m:                      # map order is irrelevant: per topic at most one entry per token
+                cats.append(c)
+                freqs.append(float(m[c]))
+        ptr[i + 1] = len(cats)
+    cats = np.asarray(cats, dtype=np.uint32)
+    freqs = np.asarray(freqs, dtype=np.float64)
+    out = np.zeros(K, dtype=np.float64)
+    fn = lib().orc_topic_probs
+    fn.restype = C.c_int
+    fn.argtypes = None
+    rc = fn(C.c_int32(K), _p(word_count, C.c_double), C.c_int32(len(token_maps)), _p(ptr, C.c_uint32), _p(cats, C.c_uint32),
+            _p(freqs, C.c_double), _p(missing, C.c_uint8), C.c_int32(mode), _p(out, C.c_double))
+    if rc == -2:
+        raise KeyError("a query word is not in the keyword table inv[2] (the reference panics, main_retrieve.go:120-121)")
+    if rc:
+        raise RuntimeError(f"orc_topic_probs rc={rc}")
+    return out
+
+
 def pagerank_topic_detail(n_nodes, out_ptr, out_dst, d, eps, n_init, max_iter=0):
     """-> (rank[N], iters, last_change, last_total)"""
     out_ptr = _c(out_ptr, np.uint64)

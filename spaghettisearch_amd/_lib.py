@@ -63,6 +63,7 @@ PROTOTYPES = {
     "ss_pagerank_run": (_i32, [_vp, _f64, _f64, _i32, _i32, _vp, _vp, _vp]),
     "ss_pr_create": (_i32, [_vp, _f64, _f64, _i32, _i32, _vp, C.POINTER(_vp)]),
     "ss_pr_destroy": (_i32, [_vp]),
+    "ss_pr_set_teleport": (_i32, [_vp, _vp, _vp]),
     "ss_pr_begin": (_i32, [_vp]),
     "ss_pr_step": (_i32, [_vp, _i32]),
     "ss_pr_finalize": (_i32, [_vp]),

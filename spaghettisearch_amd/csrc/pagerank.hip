@@ -41,6 +41,7 @@ struct PrCtl {
     double delta[MAXK];   // last L1 change
     double csum[MAXK];    // last contribution sum (diagnostics)
     double xz[MAXK];      // rank of EVERY row without in-edges (they all share one value per topic)
+    double xz_in[MAXK];   // topic-sensitive teleport only: that rank for the rows INSIDE the topic's teleport set (xz: outside)
     int32_t active[MAXK];
     int32_t iters[MAXK];
     int32_t sweep;        // sweeps completed
@@ -77,6 +78,11 @@ struct PrParams {
     int32_t max_iter, k_topics, world;
     uint32_t sl_nd, cnt_nd, sl_d, cnt_d, seg_edges, n_items;
     uint32_t pos_nd, pos_d;   // rows WITH in-edges per class (they come first: rows are in-degree sorted)
+    // opt-in true topic-sensitive teleport (ss_pr_set_teleport; null = the reference's uniform teleport):
+    const uint32_t* memb;     // [n_local] bit k: the row's node is in topic k's teleport set
+    const double* tin;        // [MAXK] teleport of a member: (1-d) * N / |set_k|
+    const double* nz_in;      // [MAXK] rows without in-edges (this rank) inside topic k's set
+    uint32_t ts_mask;         // bit k: topic k has a teleport set (others keep the uniform teleport)
 };
 
 // ---- reductions --------------------------------------------------------------
@@ -94,6 +100,16 @@ __device__ __forceinline__ double wave_sum_topic(double v) {
 __device__ __forceinline__ double zero_row_rank(const PrParams& p, int sweep, double S, double x0) {
     return ((sweep == 0 ? x0 : 0.0) + p.teleport) / S;            // pagerank.go:104,117
 }
+// Teleport of (row, topic).  Reference: the absolute (1-d) for every node (pagerank.go:117).  With a teleport set
+// (Haveliwala's topic-sensitive PageRank, README.md:9 — opt-in) the same total mass (1-d)*N is spread
+// over the set's nodes only, so the normaliser S = sum w + (1-d)*N (pagerank.go:112) keeps its meaning.
+__device__ __forceinline__ double teleport_of(const PrParams& p, uint32_t lrow, int t) {
+    if (!p.memb || !((p.ts_mask >> t) & 1u)) return p.teleport;
+    return ((p.memb[lrow] >> t) & 1u) ? p.tin[t] : 0.0;
+}
+__device__ __forceinline__ double zero_row_rank_ts(const PrParams& p, int sweep, double S, double x0, double tele) {
+    return ((sweep == 0 ? x0 : 0.0) + tele) / S;
+}
 
 __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl, const double* cs, bool is_begin) {
     PrCtl* ctl = p.ctl;
@@ -101,6 +117,7 @@ __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl
         for (int k = 0; k < MAXK; k++) {
             const bool real = k < p.k_topics;
             ctl->xz[k] = real ? p.x0[k] : 0.0;
+            ctl->xz_in[k] = real ? p.x0[k] : 0.0;
             ctl->S[k] = real ? cs[k] + p.tele_n : 1.0;
             ctl->csum[k] = real ? cs[k] : 0.0;
             ctl->delta[k] = 0.0;
@@ -117,7 +134,13 @@ __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl
         if (ctl->active[k]) {
             ctl->iters[k] = it;
             ctl->delta[k] = dl[k];                          // includes the rows without in-edges (added by the caller)
-            ctl->xz[k] = zero_row_rank(p, ctl->sweep, ctl->S[k], p.x0[k]);
+            if (p.memb && ((p.ts_mask >> k) & 1u)) {
+                ctl->xz[k] = zero_row_rank_ts(p, ctl->sweep, ctl->S[k], p.x0[k], 0.0);
+                ctl->xz_in[k] = zero_row_rank_ts(p, ctl->sweep, ctl->S[k], p.x0[k], p.tin[k]);
+            } else {
+                ctl->xz[k] = zero_row_rank(p, ctl->sweep, ctl->S[k], p.x0[k]);
+                ctl->xz_in[k] = ctl->xz[k];
+            }
             bool cont = dl[k] > p.eps;                      // pagerank.go:93
             if (p.max_iter > 0 && it >= p.max_iter) cont = false;
             ctl->active[k] = cont ? 1 : 0;
@@ -190,8 +213,16 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
     // rows without in-edges: all equal, so their L1 change is count * |new - old| (not streamed, see zero_row_rank)
     if (!is_begin && threadIdx.x < GW && p.ctl->active[threadIdx.x]) {
         const double n_zero = (double)((p.cnt_nd - p.pos_nd) + (p.cnt_d - p.pos_d));
-        const double xz_new = zero_row_rank(p, p.ctl->sweep, p.ctl->S[threadIdx.x], p.x0[threadIdx.x]);
-        tot[0][threadIdx.x] += n_zero * fabs(xz_new - p.ctl->xz[threadIdx.x]);
+        if (p.memb && ((p.ts_mask >> threadIdx.x) & 1u)) {
+            // two values per topic: inside and outside the teleport set
+            const int k = threadIdx.x;
+            const double out_new = zero_row_rank_ts(p, p.ctl->sweep, p.ctl->S[k], p.x0[k], 0.0);
+            const double in_new = zero_row_rank_ts(p, p.ctl->sweep, p.ctl->S[k], p.x0[k], p.tin[k]);
+            tot[0][k] += (n_zero - p.nz_in[k]) * fabs(out_new - p.ctl->xz[k]) + p.nz_in[k] * fabs(in_new - p.ctl->xz_in[k]);
+        } else {
+            const double xz_new = zero_row_rank(p, p.ctl->sweep, p.ctl->S[threadIdx.x], p.x0[threadIdx.x]);
+            tot[0][threadIdx.x] += n_zero * fabs(xz_new - p.ctl->xz[threadIdx.x]);
+        }
     }
     __syncthreads();
     if (p.world == 1) {
@@ -352,7 +383,7 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     auto finish_with = [&](uint32_t lrow, double y, double xo, uint32_t od) __attribute__((always_inline)) {
         y += x0;
         const size_t xi = (size_t)lrow * GW + t;
-        double xn = (y + p.teleport) / S;               // pagerank.go:117
+        double xn = (y + teleport_of(p, lrow, t)) / S;  // pagerank.go:117
         if (act) {
 #ifndef SS_PR_EXP_NOSTORE_X
             NT_STORE(xn, &p.x[xi]);
@@ -539,10 +570,13 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
         } else {
             // non-dangling rows without in-edges: their rank is the shared value xz, only the next
             // contribution d*xz/outdeg has to be written (dangling ones need nothing at all)
-            const double xz = act ? zero_row_rank(p, sweep, S, p.x0[t]) : ctl->xz[t];
+            const bool ts = p.memb && ((p.ts_mask >> t) & 1u);
+            const double xz_out = act ? (ts ? zero_row_rank_ts(p, sweep, S, p.x0[t], 0.0) : zero_row_rank(p, sweep, S, p.x0[t])) : ctl->xz[t];
+            const double xz_inn = ts ? (act ? zero_row_rank_ts(p, sweep, S, p.x0[t], p.tin[t]) : ctl->xz_in[t]) : xz_out;
             const uint32_t nel = w.count * GW;
             for (uint32_t i = threadIdx.x; i < nel; i += TPB) {
                 const uint32_t lrow = w.row + i / GW;
+                const double xz = ts && ((p.memb[lrow] >> t) & 1u) ? xz_inn : xz_out;
                 const double c = p.d * xz / (double)NT_LOAD(&p.outdeg[lrow]);   // pagerank.go:136
                 NT_STORE(c, &Tw[(size_t)lrow * GW + t]);
                 csum += c;                                                        // pagerank.go:137
@@ -597,7 +631,8 @@ template <int GW>
 __global__ void k_pr_read(const double* __restrict__ x, const PrCtl* __restrict__ ctl, const uint32_t* __restrict__ old_id,
                           uint32_t sl_nd, uint32_t cnt_nd, uint32_t pos_nd, uint32_t sl_d, uint32_t cnt_d, uint32_t pos_d,
                           uint64_t id0_nd, uint64_t id0_d, int k_topics, uint64_t out_stride,
-                          int by_original_id, uint32_t* __restrict__ ids_out, double* __restrict__ out) {
+                          int by_original_id, uint32_t* __restrict__ ids_out, double* __restrict__ out,
+                          const uint32_t* __restrict__ memb, uint32_t ts_mask) {
     const size_t n_rows = (size_t)cnt_nd + cnt_d;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
@@ -608,7 +643,39 @@ __global__ void k_pr_read(const double* __restrict__ x, const PrCtl* __restrict_
     if (ids_out) ids_out[i] = orig;
     // rows without in-edges are not stored: they all hold ctl->xz
     const bool zero = lrow < sl_nd ? lrow >= pos_nd : (lrow - sl_nd) >= pos_d;
-    for (int k = 0; k < k_topics; k++) out[(size_t)k * out_stride + o] = zero ? ctl->xz[k] : x[(size_t)lrow * GW + k];
+    const uint32_t mb = memb ? memb[lrow] & ts_mask : 0u;     // inside a topic's teleport set: the zero rows' other shared value
+    for (int k = 0; k < k_topics; k++)
+        out[(size_t)k * out_stride + o] = zero ? (((mb >> k) & 1u) ? ctl->xz_in[k] : ctl->xz[k]) : x[(size_t)lrow * GW + k];
+}
+
+// ---- topic-sensitive teleport (opt-in): sets -> per-row membership bits of this rank's rows ------------------------
+__global__ void k_pr_memb(const uint64_t* __restrict__ set_ptr, const uint32_t* __restrict__ set_nodes, int k_topics, uint64_t n_nodes,
+                          const uint32_t* __restrict__ new_id, uint64_t nd_int, uint32_t sl_nd, uint32_t sl_d, int rank,
+                          uint32_t* __restrict__ memb, uint32_t* __restrict__ err) {
+    const uint64_t total = set_ptr[k_topics];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        int k = 0;
+        while (k + 1 < k_topics && set_ptr[k + 1] <= i) k++;
+        const uint32_t v = set_nodes[i];
+        if ((uint64_t)v >= n_nodes) { atomicOr(err, 1u); continue; }
+        const uint64_t iid = new_id[v];
+        uint32_t lrow;
+        int owner;
+        if (iid < nd_int) { owner = (int)(iid / sl_nd); lrow = (uint32_t)(iid % sl_nd); }
+        else { owner = (int)((iid - nd_int) / sl_d); lrow = sl_nd + (uint32_t)((iid - nd_int) % sl_d); }
+        if (owner == rank) atomicOr(&memb[lrow], 1u << k);
+    }
+}
+// members among the rows without in-edges (their L1 change is counted, not streamed)
+__global__ void k_pr_memb_zero_count(const uint32_t* __restrict__ memb, uint32_t sl_nd, uint32_t cnt_nd, uint32_t pos_nd, uint32_t cnt_d,
+                                     uint32_t pos_d, int k_topics, unsigned long long* __restrict__ cnt) {
+    const uint32_t z_nd = cnt_nd - pos_nd, n_zero = z_nd + (cnt_d - pos_d);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) {
+        const uint32_t lrow = i < z_nd ? pos_nd + i : sl_nd + pos_d + (i - z_nd);
+        const uint32_t mb = memb[lrow];
+        for (int k = 0; k < k_topics; k++)
+            if ((mb >> k) & 1u) atomicAdd(&cnt[k], 1ull);
+    }
 }
 
 // ---- diagnostic: the ceiling of the sweep's access pattern (ss_pr_probe) -----------------------------------------
@@ -668,6 +735,8 @@ struct ss_pr {
     unsigned nblocks = 0;
     ss::DevBuf<double> x, tab0, tab1, send, partials, segpart, x0;
     ss::DevBuf<uint32_t> rowticket;
+    ss::DevBuf<uint32_t> memb;          // topic-sensitive teleport (optional)
+    ss::DevBuf<double> tin, nz_in;
     ss::DevBuf<WorkItem> work;
     ss::DevBuf<PrCtl> ctl;
     bool begun = false;
@@ -768,7 +837,8 @@ void launch_read(ss_pr* pr, hipStream_t st, int by_orig, uint64_t stride, uint32
     hipLaunchKernelGGL(k_pr_read<GW>, dim3(ss::div_up(n_rows, TPB)), dim3(TPB), 0, st, (const double*)pr->x.p,
                        (const PrCtl*)pr->ctl.p, (const uint32_t*)g->old_id.p, g->sl_nd, g->cnt_nd, pr->prm.pos_nd, g->sl_d, g->cnt_d,
                        pr->prm.pos_d,
-                       (uint64_t)g->rank * g->sl_nd, g->nd_int + (uint64_t)g->rank * g->sl_d, pr->k, stride, by_orig, ids, out);
+                       (uint64_t)g->rank * g->sl_nd, g->nd_int + (uint64_t)g->rank * g->sl_d, pr->k, stride, by_orig, ids, out,
+                       pr->prm.memb, pr->prm.ts_mask);
 }
 
 #define SS_GW_DISPATCH(gw, fn, ...)          \
@@ -875,6 +945,79 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     p.pos_nd = pos_nd;
     p.pos_d = pos_d;
     *out = guard.release();
+    return SS_OK;
+}
+
+int32_t ss_pr_set_teleport(ss_pr* pr, const uint64_t* set_ptr, const uint32_t* set_nodes) {
+    if (!pr) return SS_ERR_INVALID;
+    ss_ctx* ctx = pr->g->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    if (pr->begun) return ctx->fail(SS_ERR_STATE, "ss_pr_set_teleport: call before ss_pr_begin");
+    hipStream_t st = ctx->stream;
+    PrParams& p = pr->prm;
+    if (!set_ptr) {                                  // back to the reference's uniform teleport
+        p.memb = nullptr; p.tin = nullptr; p.nz_in = nullptr; p.ts_mask = 0;
+        return SS_OK;
+    }
+    const ss_graph* g = pr->g;
+    const int K = pr->k;
+    std::vector<uint64_t> h_ptr(K + 1);
+    SS_HIP(ctx, hipMemcpy(h_ptr.data(), set_ptr, (K + 1) * sizeof(uint64_t), hipMemcpyDefault));
+    if (h_ptr[0] != 0) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: set_ptr[0] != 0");
+    for (int k = 0; k < K; k++)
+        if (h_ptr[k + 1] < h_ptr[k]) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: set_ptr not non-decreasing");
+    const uint64_t total = h_ptr[K];
+    if (total && !set_nodes) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: set_nodes is NULL");
+    double h_tin[MAXK];
+    uint32_t mask = 0;
+    for (int k = 0; k < MAXK; k++) {
+        h_tin[k] = 0.0;
+        if (k < K && h_ptr[k + 1] > h_ptr[k]) {
+            mask |= 1u << k;
+            h_tin[k] = p.teleport * (double)g->n / (double)(h_ptr[k + 1] - h_ptr[k]);     // the set shares the mass (1-d)*N
+        }
+    }
+    const size_t n_local = g->n_local();
+    ss::DevBuf<uint64_t> d_ptr;
+    ss::DevBuf<uint32_t> d_nodes, d_err;
+    ss::DevBuf<unsigned long long> d_cnt;
+    SS_HIP(ctx, d_ptr.alloc(K + 1));
+    SS_HIP(ctx, d_nodes.alloc(total));
+    SS_HIP(ctx, d_err.alloc(1));
+    SS_HIP(ctx, d_cnt.alloc(MAXK));
+    SS_HIP(ctx, pr->memb.alloc(n_local));
+    SS_HIP(ctx, pr->tin.alloc(MAXK));
+    SS_HIP(ctx, pr->nz_in.alloc(MAXK));
+    SS_HIP(ctx, hipMemcpyAsync(d_ptr.p, h_ptr.data(), (K + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    if (total) SS_HIP(ctx, hipMemcpyAsync(d_nodes.p, set_nodes, total * sizeof(uint32_t), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipMemsetAsync(pr->memb.p, 0, std::max<size_t>(pr->memb.bytes(), 4), st));
+    SS_HIP(ctx, hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), st));
+    SS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, MAXK * sizeof(unsigned long long), st));
+    if (total)
+        hipLaunchKernelGGL(k_pr_memb, dim3(std::min<unsigned>(ss::div_up(total, TPB), 4096u)), dim3(TPB), 0, st, (const uint64_t*)d_ptr.p,
+                           (const uint32_t*)d_nodes.p, K, g->n, (const uint32_t*)g->new_id.p, g->nd_int, std::max(g->sl_nd, 1u), std::max(g->sl_d, 1u),
+                           g->rank, pr->memb.p, d_err.p);
+    const uint32_t n_zero = (g->cnt_nd - p.pos_nd) + (g->cnt_d - p.pos_d);
+    if (n_zero)
+        hipLaunchKernelGGL(k_pr_memb_zero_count, dim3(std::min<unsigned>(ss::div_up(n_zero, TPB), 4096u)), dim3(TPB), 0, st,
+                           (const uint32_t*)pr->memb.p, g->sl_nd, g->cnt_nd, p.pos_nd, g->cnt_d, p.pos_d, K, d_cnt.p);
+    SS_HIP(ctx, hipGetLastError());
+    uint32_t h_err = 0;
+    unsigned long long h_cnt[MAXK];
+    SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (h_err) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: a teleport set holds a node id >= n_nodes");
+    double h_nz[MAXK];
+    for (int k = 0; k < MAXK; k++) h_nz[k] = (double)h_cnt[k];      // a node listed twice counts once (one bit per row)
+    SS_HIP(ctx, hipMemcpyAsync(pr->tin.p, h_tin, sizeof(h_tin), hipMemcpyHostToDevice, st));
+    SS_HIP(ctx, hipMemcpyAsync(pr->nz_in.p, h_nz, sizeof(h_nz), hipMemcpyHostToDevice, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    p.memb = pr->memb.p;
+    p.tin = pr->tin.p;
+    p.nz_in = pr->nz_in.p;
+    p.ts_mask = mask;
     return SS_OK;
 }
 

@@ -206,6 +206,19 @@ class PageRankState:
         check(self.ctx.lib.ss_pr_create(graph.h, damping, eps, max_iter, self.k, _ptr(n_topic), C.byref(h)), self.ctx.h)
         self.h = h
 
+    def set_teleport(self, sets) -> None:
+        """ss_pr_set_teleport: `sets` = one array of DISTINCT node ids per topic (empty = uniform teleport for that topic),
+        or None to restore the reference's uniform teleport.  Opt-in true topic-sensitive PageRank."""
+        if sets is None:
+            check(self.ctx.lib.ss_pr_set_teleport(self.h, None, None), self.ctx.h)
+            return
+        if len(sets) != self.k:
+            raise ValueError("one teleport set per topic")
+        ptr = np.zeros(self.k + 1, dtype=np.uint64)
+        ptr[1:] = np.cumsum([len(x) for x in sets])
+        nodes = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32) for x in sets]) if int(ptr[-1]) else np.zeros(0, np.uint32))
+        check(self.ctx.lib.ss_pr_set_teleport(self.h, _ptr(ptr), _ptr(nodes)), self.ctx.h)
+
     def begin(self) -> None:
         check(self.ctx.lib.ss_pr_begin(self.h), self.ctx.h)
 

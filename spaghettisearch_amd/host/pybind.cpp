@@ -52,6 +52,15 @@ PYBIND11_MODULE(_host, m) {
         ranking::UpdateTermWeights(ctx, &i, f, info);
     }, py::arg("inv"), py::arg("forw"), py::arg("info"));
     m.def("md5_hex", &md5::hex);
+    m.def("computeTopicProbs", [as_dbs](std::vector<db::MemDB*> inv, std::vector<db::MemDB*> forw, const std::vector<std::string>& tokens, bool as_written) {
+        db::Context ctx;
+        auto i = as_dbs(inv), f = as_dbs(forw);
+        try {
+            return retrieval::computeTopicProbs(ctx, i, f, tokens, as_written);
+        } catch (const db::KeyNotFound&) {
+            throw py::key_error("query word not in inv[2] (the reference panics, main_retrieve.go:120-121)");
+        }
+    }, py::arg("inv"), py::arg("forw"), py::arg("queryTokenised"), py::arg("as_written") = true);
 
     py::class_<retrieval::DeviceIndex>(m, "DeviceIndex")
         .def(py::init<>())

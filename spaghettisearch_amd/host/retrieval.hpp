@@ -48,6 +48,38 @@ inline std::vector<std::string> defaultLaundry(const std::string& s) {
     return out;
 }
 
+// computeTopicProbs, retrieval/main_retrieve.go:106-159 — DISABLED in the reference (the call at :43 is commented out and
+// :87 passes a nil map, so sqd = 0); restated so that the PageRank blend of get_metadata.go:39-42,69 can be switched on.
+//   queryTokenised: md5-hex word hashes as Retrieve makes them (:33-36);
+//   metadata = forw[5] rows {numPages, wordCount} (:110); inv[2][word] = map[category]frequency (:120-124) — a word
+//   that is not in inv[2] throws db::KeyNotFound, where the reference panics (:120-121);
+//   as_written = true reproduces `var probs float64` (:142): the product starts at 0, every probability is 0;
+//   as_written = false starts it at 1 (multinomial naive Bayes with max-likelihood estimates, uniform prior 1/K, :148).
+inline std::map<std::string, double> computeTopicProbs(db::Context& ctx, std::vector<db::DB*>& inv, std::vector<db::DB*>& forw,
+                                                       const std::vector<std::string>& queryTokenised, bool as_written) {
+    std::map<std::string, std::map<std::string, double>> metadata;                       // :110
+    for (auto& kv : forw[5]->Iterate(ctx)) metadata[kv.first] = jsonmini::parse_map_f64(kv.second);
+    std::map<std::string, std::vector<double>> topicTF;                                  // :118
+    for (auto& tok : queryTokenised) {
+        const std::map<std::string, double> topicFreq = jsonmini::parse_map_f64(inv[2]->Get(ctx, tok));   // :120-124 (throws = panic)
+        for (auto& tf : topicFreq) topicTF[tf.first].push_back(tf.second);               // :126-134
+    }
+    std::map<std::string, double> topicProbs;                                            // :137
+    for (auto& md : metadata) {
+        auto it = topicTF.find(md.first);
+        if (it != topicTF.end()) {
+            double probs = as_written ? 0.0 : 1.0;                                       // :142
+            auto wc = md.second.find("wordCount");
+            const double wordCount = wc == md.second.end() ? 0.0 : wc->second;           // missing key reads as 0 in Go
+            for (double tf : it->second) probs *= (tf / wordCount);                      // :143-145
+            topicProbs[md.first] = probs / (double)metadata.size();                      // :148
+        } else {
+            topicProbs[md.first] = 0;                                                    // :150
+        }
+    }
+    return topicProbs;
+}
+
 class DeviceIndex {
 public:
     spaghetti::DenseIds docs, terms;

@@ -1,0 +1,133 @@
+"""SURVEY.md §8f-3 (opt-in, beyond what the reference executes): true topic-sensitive teleport on the device against the
+oracle's restatement, the default path untouched by it, and computeTopicProbs (main_retrieve.go:106-159) in the host mirror
+— as written (all zero) and fixed — feeding the PageRank blend of get_metadata.go:39-42,69."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from spaghettisearch_amd import engine, sharding, synth
+
+pytestmark = pytest.mark.gpu
+D = 0.75
+
+
+def run_ts(ctx, n, ptr, dst, n_topic, sets, eps, max_iter=0):
+    g = engine.Graph(ctx, n, ptr, dst)
+    st = engine.PageRankState(g, D, eps, n_topic, max_iter=max_iter)
+    st.set_teleport(sets)
+    st.begin()
+    s = st.status()
+    while s["n_active"] > 0:
+        st.step(4)
+        s = st.status()
+    x = st.read()
+    st.close()
+    g.close()
+    return x, s["iters"]
+
+
+@pytest.mark.parametrize("k_topics", [1, 3, 16])
+def test_teleport_sets_match_oracle(ss_ctx, oracle, k_topics):
+    n, e = 30000, 150000
+    ptr, dst = synth.rmat_graph(n, e, seed=31 + k_topics)
+    n_topic = synth.topic_sizes(n, k_topics)
+    rng = np.random.default_rng(5)
+    sets = []
+    for k in range(k_topics):
+        if k == 1:
+            sets.append(np.zeros(0, dtype=np.uint32))                  # no set: this topic keeps the reference's uniform teleport
+        else:
+            sets.append(rng.choice(n, size=int(rng.integers(1, 400)), replace=False).astype(np.uint32))
+    x, iters = run_ts(ss_ctx, n, ptr, dst, n_topic, sets, 1e-10)
+    for k in range(k_topics):
+        ref, rit = oracle.pagerank_topic_ts(n, ptr, dst, D, 1e-10, int(n_topic[k]), sets[k])
+        assert int(iters[k]) == rit, k
+        np.testing.assert_allclose(x[k], ref, rtol=1e-12, atol=1e-300)
+    # the set's members hold visibly more rank than under the uniform teleport
+    base, _ = oracle.pagerank(n, ptr, dst, D, 1e-10, n_topic[:1])
+    assert x[0][sets[0].astype(np.int64)].mean() > 3 * base[0][sets[0].astype(np.int64)].mean()
+
+
+def test_default_path_is_untouched_and_clearable(ss_ctx, oracle):
+    n, e = 20000, 90000
+    ptr, dst = synth.rmat_graph(n, e, seed=77)
+    n_topic = synth.topic_sizes(n, 4)
+    ref, ref_it = oracle.pagerank(n, ptr, dst, D, 1e-10, n_topic)
+    g = engine.Graph(ss_ctx, n, ptr, dst)
+    st = engine.PageRankState(g, D, 1e-10, n_topic)
+    st.set_teleport([np.arange(5, dtype=np.uint32)] * 4)
+    st.set_teleport(None)                                                  # back to the reference's teleport
+    st.begin()
+    s = st.status()
+    while s["n_active"] > 0:
+        st.step(4)
+        s = st.status()
+    assert s["iters"].tolist() == ref_it.tolist()
+    x = st.read()
+    np.testing.assert_allclose(x, ref, rtol=1e-12)
+    with pytest.raises(Exception):                                         # not after begin
+        st.set_teleport(None if False else [np.arange(3, dtype=np.uint32)] * 4)
+    st.close()
+    st = engine.PageRankState(g, D, 1e-10, n_topic)
+    with pytest.raises(Exception):                                         # node id out of range
+        st.set_teleport([np.array([n], dtype=np.uint32)] * 4)
+    st.close()
+    g.close()
+
+
+def test_teleport_sets_on_doc_range_shards(ss_ctx, oracle):
+    """Two shards in one process (the all-gather played by copies): membership bits follow the rows to their shard."""
+    import torch
+    n, e = 24000, 120000
+    ptr, dst = synth.rmat_graph(n, e, seed=12)
+    n_topic = synth.topic_sizes(n, 3)
+    rng = np.random.default_rng(9)
+    sets = [rng.choice(n, size=200, replace=False).astype(np.uint32) for _ in range(3)]
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream()
+    ss_ctx.set_stream(stream.cuda_stream)
+    try:
+        with torch.cuda.stream(stream):
+            graphs = [engine.Graph(ss_ctx, n, ptr, dst, rank=r, world=2) for r in range(2)]
+            states = [engine.PageRankState(gr, D, 1e-10, n_topic) for gr in graphs]
+            for s in states:
+                s.set_teleport(sets)
+            srank, siters = sharding.run_sharded(states, sharding.LocalExchange(states, dev))
+            for s in states:
+                s.close()
+            for gr in graphs:
+                gr.close()
+    finally:
+        torch.cuda.synchronize()
+        ss_ctx.set_stream(None)
+    for k in range(3):
+        ref, rit = oracle.pagerank_topic_ts(n, ptr, dst, D, 1e-10, int(n_topic[k]), sets[k])
+        assert int(siters[k]) == rit
+        np.testing.assert_allclose(srank[k], ref, rtol=1e-12, atol=1e-300)
+
+
+def test_compute_topic_probs_host_mirror(oracle):
+    from spaghettisearch_amd import _lib
+    _lib.load()
+    from spaghettisearch_amd import _host
+    h = lambda s: hashlib.md5(s.encode()).hexdigest()
+    cats = {"Arts": {"numPages": 900.0, "wordCount": 10.0}, "Science": {"numPages": 412.0, "wordCount": 20.0},
+            "Sports": {"numPages": 77.0, "wordCount": 5.0}}
+    forw = [_host.MemDB() for _ in range(6)]
+    inv = [_host.MemDB() for _ in range(3)]
+    for c, md in cats.items():
+        forw[5].set(c, json.dumps(md))
+    inv[2].set(h("paint"), json.dumps({"Arts": 2, "Science": 4}))
+    inv[2].set(h("atom"), json.dumps({"Science": 5}))
+    toks = [h("paint"), h("atom")]
+    names = sorted(cats)                                                   # Arts, Science, Sports
+    wc = [cats[c]["wordCount"] for c in names]
+    maps = [{0: 2, 1: 4}, {1: 5}]
+    as_written = _host.computeTopicProbs(inv, forw, toks, True)
+    assert [as_written[c] for c in names] == oracle.topic_probs(wc, maps, mode=0).tolist() == [0.0, 0.0, 0.0]
+    fixed = _host.computeTopicProbs(inv, forw, toks, False)
+    assert [fixed[c] for c in names] == oracle.topic_probs(wc, maps, mode=1).tolist()
+    with pytest.raises(KeyError):
+        _host.computeTopicProbs(inv, forw, toks + [h("unknownword")], False)

@@ -330,3 +330,44 @@ def test_reference_shaped_scoring_baseline_matches_the_flat_oracle(oracle):
                 assert a == r
     finally:
         mm.close()
+
+
+# ---- opt-in extensions of SURVEY.md §8f-3 (beyond what the reference executes) ---------------------------------------
+def test_topic_teleport_kat_and_uniform_limit(oracle):
+    """Teleport set (Haveliwala's TSPR, README.md:9): 3-cycle 0->1->2->0, set {0}, d = 3/4, n_init = 3, one iteration, by hand:
+    w = d*(1/3)/1 = 1/4 per node, total = 3/4 + (1-d)*3 = 3/2, cur = 1/3 + 1/4 = 7/12 (the first iteration adds onto 1/n,
+    pagerank.go:104), member teleport = (1-d)*3/1 = 3/4  =>  x0 = (7/12+3/4)/(3/2) = 8/9, x1 = x2 = (7/12)/(3/2) = 7/18."""
+    from fractions import Fraction
+    ptr = np.array([0, 1, 2, 3], dtype=np.uint64)
+    dst = np.array([1, 2, 0], dtype=np.uint32)
+    r, it = oracle.pagerank_topic_ts(3, ptr, dst, 0.75, -1.0, 3, [0], max_iter=1)
+    assert it == 1
+    np.testing.assert_allclose(r, [float(Fraction(8, 9)), float(Fraction(7, 18)), float(Fraction(7, 18))], rtol=1e-15)
+    # the teleport mass is conserved: sum(x)*total = d*sum(w-sources) + (1-d)*N whatever the set
+    from spaghettisearch_amd import synth
+    n, e = 500, 2500
+    p2, d2 = synth.rmat_graph(n, e, seed=8)
+    base, _ = oracle.pagerank(n, p2, d2, 0.75, 1e-12, [n])
+    # a set holding EVERY node is the reference's uniform teleport
+    full, it_full = oracle.pagerank_topic_ts(n, p2, d2, 0.75, 1e-12, n, np.arange(n))
+    np.testing.assert_allclose(full, base[0], rtol=1e-13)
+    # no set at all: literally the reference function
+    none, _ = oracle.pagerank_topic_ts(n, p2, d2, 0.75, 1e-12, n, None)
+    assert np.array_equal(none, base[0])
+    # a small set pulls rank towards its members
+    sel = np.arange(10)
+    ts, _ = oracle.pagerank_topic_ts(n, p2, d2, 0.75, 1e-12, n, sel)
+    assert ts[sel].mean() > 3 * base[0][sel].mean()
+
+
+def test_compute_topic_probs_as_written_and_fixed(oracle):
+    """main_retrieve.go:106-159.  As written `var probs float64` starts at 0 and is only multiplied (:142-145): every
+    probability is 0.  With the product started at 1: naive Bayes with a uniform prior 1/K (:148)."""
+    wc = [10.0, 20.0, 5.0]
+    toks = [{0: 2, 1: 4}, {1: 5}]
+    assert oracle.topic_probs(wc, toks, mode=0).tolist() == [0.0, 0.0, 0.0]
+    fixed = oracle.topic_probs(wc, toks, mode=1)
+    assert fixed.tolist() == [(2 / 10.0) / 3.0, ((4 / 20.0) * (5 / 20.0)) / 3.0, 0.0]
+    with pytest.raises(KeyError):            # a word missing from inv[2]: the reference panics (:120-121)
+        oracle.topic_probs(wc, [{0: 1}, None], mode=1)
+    assert oracle.topic_probs(wc, [], mode=1).tolist() == [0.0, 0.0, 0.0]     # no tokens: no topic has a frequency list
