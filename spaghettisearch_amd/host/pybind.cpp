@@ -75,7 +75,19 @@ PYBIND11_MODULE(_host, m) {
             auto tp = topic_probs.cast<std::vector<std::map<std::string, double>>>();
             return di.RetrieveBatch(queries, k, &tp);
         }, py::arg("queries"), py::arg("k") = 50, py::arg("topic_probs") = py::none())
+        .def("save_snapshot", &retrieval::DeviceIndex::save_snapshot)
+        .def("load_snapshot", &retrieval::DeviceIndex::load_snapshot)
         .def_readonly("categories", &retrieval::DeviceIndex::categories);
+    py::class_<retrieval::RetrieveBatcher>(m, "RetrieveBatcher")
+        .def(py::init([](retrieval::DeviceIndex& di, int k, int max_wait_us, size_t max_batch) {
+                 return new retrieval::RetrieveBatcher(di, k, std::chrono::microseconds(max_wait_us), max_batch);
+             }), py::arg("index"), py::arg("k") = 50, py::arg("max_wait_us") = 1000, py::arg("max_batch") = 1024, py::keep_alive<1, 2>())
+        .def("Retrieve", [](retrieval::RetrieveBatcher& b, const std::string& q) {
+            py::gil_scoped_release rel;          // other Python threads queue their requests meanwhile
+            return b.Retrieve(q);
+        })
+        .def_property_readonly("batches", &retrieval::RetrieveBatcher::batches)
+        .def_property_readonly("largest_batch", &retrieval::RetrieveBatcher::largest_batch);
     m.def("Retrieve", [as_dbs](const std::string& query, std::vector<db::MemDB*> forw, std::vector<db::MemDB*> inv) {
         db::Context ctx;
         auto f = as_dbs(forw), i = as_dbs(inv);

@@ -9,7 +9,13 @@
 // Quoted phrases (retrieval/phrase.go) are matched on the device from the positional part of the rows.
 #pragma once
 #include <cctype>
+#include <chrono>
+#include <condition_variable>
+#include <fstream>
 #include <functional>
+#include <future>
+#include <mutex>
+#include <thread>
 
 #include "md5.hpp"
 #include "ranking.hpp"
@@ -80,9 +86,93 @@ inline std::map<std::string, double> computeTopicProbs(db::Context& ctx, std::ve
     return topicProbs;
 }
 
+// The query-time tables flattened to dense ids: what DeviceIndex::load decodes from the JSON rows and
+// uploads, and what a snapshot file holds — so that a server start does not pay the reference's dominant load cost
+// (json.Unmarshal of every posting map, database/noschema_schema.go:125-260) again.
+//   file = "SSNAP002" | u64 n_docs, n_terms, K | doc names, term names, categories (u32 length + bytes each) |
+//          per table (title, body): u64 P, u64 n_pos | term_ptr u64[T+1] | post_doc u32[P] | post_w f32[P] |
+//          pos_ptr u64[P+1] | pos f32[n_pos] | mag f64[n_docs]   |   prior f64[K][n_docs]
+struct FlatTable {
+    std::vector<uint64_t> term_ptr, pos_ptr;
+    std::vector<uint32_t> post_doc;
+    std::vector<float> post_w, pos;
+    std::vector<double> mag;
+};
+struct FlatCorpus {
+    std::vector<std::string> doc_names, term_names, categories;
+    FlatTable title, body;
+    std::vector<double> prior;       // [K][n_docs]
+
+    template <typename T>
+    static void put(std::ostream& f, const std::vector<T>& v) { f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(T))); }
+    template <typename T>
+    static void get(std::istream& f, std::vector<T>& v, size_t n) {
+        v.resize(n);
+        f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(T)));
+        if (!f) throw std::runtime_error("snapshot: file truncated");
+    }
+    static void put_u64(std::ostream& f, uint64_t x) { f.write(reinterpret_cast<const char*>(&x), 8); }
+    static uint64_t get_u64(std::istream& f) {
+        uint64_t x = 0;
+        f.read(reinterpret_cast<char*>(&x), 8);
+        if (!f) throw std::runtime_error("snapshot: file truncated");
+        return x;
+    }
+    static void put_names(std::ostream& f, const std::vector<std::string>& v) {
+        for (auto& s : v) { const uint32_t n = (uint32_t)s.size(); f.write(reinterpret_cast<const char*>(&n), 4); f.write(s.data(), n); }
+    }
+    static void get_names(std::istream& f, std::vector<std::string>& v, size_t count) {
+        v.resize(count);
+        for (auto& s : v) {
+            uint32_t n = 0;
+            f.read(reinterpret_cast<char*>(&n), 4);
+            if (!f || n > (1u << 20)) throw std::runtime_error("snapshot: bad name record");
+            s.resize(n);
+            f.read(&s[0], n);
+            if (!f) throw std::runtime_error("snapshot: file truncated");
+        }
+    }
+    void save(const std::string& path) const {
+        std::ofstream f(path, std::ios::binary | std::ios::trunc);
+        if (!f) throw std::runtime_error("snapshot: cannot open " + path + " for writing");
+        f.write("SSNAP002", 8);
+        put_u64(f, doc_names.size());
+        put_u64(f, term_names.size());
+        put_u64(f, categories.size());
+        put_names(f, doc_names);
+        put_names(f, term_names);
+        put_names(f, categories);
+        for (const FlatTable* t : {&title, &body}) {
+            put_u64(f, t->post_doc.size());
+            put_u64(f, t->pos.size());
+            put(f, t->term_ptr); put(f, t->post_doc); put(f, t->post_w); put(f, t->pos_ptr); put(f, t->pos); put(f, t->mag);
+        }
+        put(f, prior);
+        if (!f) throw std::runtime_error("snapshot: write to " + path + " failed");
+    }
+    void load(const std::string& path) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error("snapshot: cannot open " + path);
+        char magic[8];
+        f.read(magic, 8);
+        if (!f || std::string(magic, 8) != "SSNAP002") throw std::runtime_error("snapshot: " + path + " is not an SSNAP002 file");
+        const uint64_t n = get_u64(f), T = get_u64(f), K = get_u64(f);
+        get_names(f, doc_names, n);
+        get_names(f, term_names, T);
+        get_names(f, categories, K);
+        for (FlatTable* t : {&title, &body}) {
+            const uint64_t P = get_u64(f), np = get_u64(f);
+            get(f, t->term_ptr, T + 1); get(f, t->post_doc, P); get(f, t->post_w, P); get(f, t->pos_ptr, P + 1); get(f, t->pos, np); get(f, t->mag, n);
+            if (t->term_ptr[T] != P || t->pos_ptr[P] != np) throw std::runtime_error("snapshot: inconsistent table sizes");
+        }
+        get(f, prior, K * n);
+    }
+};
+
 class DeviceIndex {
 public:
     spaghetti::DenseIds docs, terms;
+    FlatCorpus flat;                 // kept for save_snapshot (host memory; drop with flat = {} when not needed)
     ss_index* title = nullptr;
     ss_index* body = nullptr;
     ss_scorer* scorer = nullptr;
@@ -132,45 +222,66 @@ public:
                 }
             }
         };
-        std::vector<uint64_t> tp, bp, tpp, bpp;
-        std::vector<uint32_t> td, bd;
-        std::vector<float> tw, bw, tps, bps;
-        flatten(tcomp, trow, tp, td, tw, tpp, tps);
-        flatten(bcomp, brow, bp, bd, bw, bpp, bps);
-        check(ss_index_create(default_ctx(), n, T, tp.data(), td.data(), tw.data(), &title), "ss_index_create(title)");
-        check(ss_index_create(default_ctx(), n, T, bp.data(), bd.data(), bw.data(), &body), "ss_index_create(body)");
-        check(ss_index_set_positions(title, tpp.data(), tps.data()), "ss_index_set_positions(title)");
-        check(ss_index_set_positions(body, bpp.data(), bps.data()), "ss_index_set_positions(body)");
+        flatten(tcomp, trow, flat.title.term_ptr, flat.title.post_doc, flat.title.post_w, flat.title.pos_ptr, flat.title.pos);
+        flatten(bcomp, brow, flat.body.term_ptr, flat.body.post_doc, flat.body.post_w, flat.body.pos_ptr, flat.body.pos);
         // forw[4]: a missing "title"/"body" key reads as 0 (get_metadata.go:57-58, Q8)
-        std::vector<double> magT(n, 0.0), magB(n, 0.0);
+        flat.title.mag.assign(n, 0.0);
+        flat.body.mag.assign(n, 0.0);
         for (auto& kv : forw[4]->Iterate(ctx)) {
             auto it = docs.id.find(kv.first);
             if (it == docs.id.end()) continue;
             auto m = jsonmini::parse_map_f64(kv.second);
-            magT[it->second] = m.count("title") ? m["title"] : 0.0;
-            magB[it->second] = m.count("body") ? m["body"] : 0.0;
+            flat.title.mag[it->second] = m.count("title") ? m["title"] : 0.0;
+            flat.body.mag[it->second] = m.count("body") ? m["body"] : 0.0;
         }
-        check(ss_index_set_weighted(title, magT.data()), "ss_index_set_weighted(title)");
-        check(ss_index_set_weighted(body, magB.data()), "ss_index_set_weighted(body)");
-        check(ss_scorer_create(default_ctx(), title, body, &scorer), "ss_scorer_create");
         // forw[3]: ranks per category, for the PageRank blend (get_metadata.go:31-42)
         std::vector<std::string> cat;
         for (auto& kv : ranks) for (auto& c : jsonmini::parse_map_f64(kv.second)) cat.push_back(c.first);
         std::sort(cat.begin(), cat.end());
         cat.erase(std::unique(cat.begin(), cat.end()), cat.end());
-        categories = cat;
+        flat.categories = cat;
         const size_t K = cat.size();
-        if (K > 0 && K <= SS_MAX_TOPICS) {
-            std::vector<double> prior(K * n, 0.0);
-            for (auto& kv : ranks) {
-                const uint32_t d = docs.id[kv.first];
-                for (auto& c : jsonmini::parse_map_f64(kv.second)) {
-                    const size_t k = std::lower_bound(cat.begin(), cat.end(), c.first) - cat.begin();
-                    prior[k * n + d] = c.second;
-                }
+        flat.prior.assign(K * n, 0.0);
+        for (auto& kv : ranks) {
+            const uint32_t d = docs.id[kv.first];
+            for (auto& c : jsonmini::parse_map_f64(kv.second)) {
+                const size_t k = std::lower_bound(cat.begin(), cat.end(), c.first) - cat.begin();
+                flat.prior[k * n + d] = c.second;
             }
-            check(ss_scorer_set_prior(scorer, (int32_t)K, prior.data()), "ss_scorer_set_prior");
         }
+        flat.doc_names = docs.name;
+        flat.term_names = terms.name;
+        upload();
+    }
+
+    // flat arrays -> device state (ss_index x2, positions, magnitudes, scorer, prior)
+    void upload() {
+        using namespace spaghetti;
+        const size_t n = flat.doc_names.size(), T = flat.term_names.size();
+        check(ss_index_create(default_ctx(), n, T, flat.title.term_ptr.data(), flat.title.post_doc.data(), flat.title.post_w.data(), &title), "ss_index_create(title)");
+        check(ss_index_create(default_ctx(), n, T, flat.body.term_ptr.data(), flat.body.post_doc.data(), flat.body.post_w.data(), &body), "ss_index_create(body)");
+        check(ss_index_set_positions(title, flat.title.pos_ptr.data(), flat.title.pos.data()), "ss_index_set_positions(title)");
+        check(ss_index_set_positions(body, flat.body.pos_ptr.data(), flat.body.pos.data()), "ss_index_set_positions(body)");
+        check(ss_index_set_weighted(title, flat.title.mag.data()), "ss_index_set_weighted(title)");
+        check(ss_index_set_weighted(body, flat.body.mag.data()), "ss_index_set_weighted(body)");
+        check(ss_scorer_create(default_ctx(), title, body, &scorer), "ss_scorer_create");
+        categories = flat.categories;
+        const size_t K = categories.size();
+        if (K > 0 && K <= SS_MAX_TOPICS) check(ss_scorer_set_prior(scorer, (int32_t)K, flat.prior.data()), "ss_scorer_set_prior");
+    }
+
+    // On-disk snapshot of the flattened tables with the md5-hex <-> dense-id maps: written once after
+    // the offline rank update, read at every server start instead of decoding the JSON tables.
+    void save_snapshot(const std::string& path) const { flat.save(path); }
+    void load_snapshot(const std::string& path) {
+        flat.load(path);
+        docs.name = flat.doc_names;
+        terms.name = flat.term_names;
+        docs.id.clear();
+        terms.id.clear();
+        for (size_t i = 0; i < docs.name.size(); i++) docs.id[docs.name[i]] = (uint32_t)i;
+        for (size_t i = 0; i < terms.name.size(); i++) terms.id[terms.name[i]] = (uint32_t)i;
+        upload();
     }
 
     // A batch of queries in one library call (additive API).  topicProbs: per query
@@ -232,6 +343,69 @@ public:
             }
         return out;
     }
+};
+
+// Request batching in front of the device.  The reference serves every HTTP request in its own
+// goroutine (cmd/server/server.go:47) and each runs its own Retrieve; here concurrent callers are collected for at most
+// `max_wait` (or until `max_batch` are waiting) and answered by ONE ss_score_topk_phrase call.  Retrieve() blocks its
+// caller like the reference's function does and returns that caller's own result.
+class RetrieveBatcher {
+public:
+    RetrieveBatcher(DeviceIndex& di, int k = 50, std::chrono::microseconds max_wait = std::chrono::microseconds(1000), size_t max_batch = 1024)
+        : di_(di), k_(k), max_wait_(max_wait), max_batch_(max_batch), worker_([this] { run(); }) {}
+    ~RetrieveBatcher() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        worker_.join();
+    }
+    std::vector<Rank_combined> Retrieve(const std::string& query) {
+        std::future<std::vector<Rank_combined>> fut;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            pending_.emplace_back(query, std::promise<std::vector<Rank_combined>>());
+            fut = pending_.back().second.get_future();
+        }
+        cv_.notify_all();
+        return fut.get();               // rethrows what the batch call threw (the reference panics)
+    }
+    size_t batches() const { return n_batches_; }
+    size_t largest_batch() const { return largest_; }
+
+private:
+    void run() {
+        for (;;) {
+            std::vector<std::pair<std::string, std::promise<std::vector<Rank_combined>>>> batch;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return stop_ || !pending_.empty(); });
+                if (stop_ && pending_.empty()) return;
+                // first request in: wait a little for company
+                const auto deadline = std::chrono::steady_clock::now() + max_wait_;
+                cv_.wait_until(lk, deadline, [this] { return stop_ || pending_.size() >= max_batch_; });
+                batch.swap(pending_);
+            }
+            std::vector<std::string> queries;
+            for (auto& p : batch) queries.push_back(p.first);
+            try {
+                auto res = di_.RetrieveBatch(queries, k_);
+                for (size_t i = 0; i < batch.size(); i++) batch[i].second.set_value(std::move(res[i]));
+            } catch (...) {
+                for (auto& p : batch) p.second.set_exception(std::current_exception());
+            }
+            n_batches_++;
+            largest_ = std::max(largest_, batch.size());
+        }
+    }
+    DeviceIndex& di_;
+    int k_;
+    std::chrono::microseconds max_wait_;
+    size_t max_batch_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::pair<std::string, std::promise<std::vector<Rank_combined>>>> pending_;
+    bool stop_ = false;
+    size_t n_batches_ = 0, largest_ = 0;
+    std::thread worker_;
 };
 
 // retrieval.Retrieve(query, ctx, forw, inv) []Rank_combined — main_retrieve.go:15; first 50 (:99-103)

@@ -204,3 +204,68 @@ def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
 def test_md5_matches_hashlib(host):
     for s in ("", "a", "spaghetti", "The quick brown fox jumps over the lazy dog", "x" * 200):
         assert host.md5_hex(s) == hashlib.md5(s.encode()).hexdigest()
+
+
+def _weighted_tables(host, corpus):
+    forw, inv = make_tables(host, corpus)
+    host.UpdateTopicSensitivePagerank(0.75, 1e-9, forw)
+    host.UpdateTermWeights(inv[0], forw, "title")
+    host.UpdateTermWeights(inv[1], forw, "body")
+    return forw, inv
+
+
+def test_snapshot_round_trip(host, corpus, tmp_path):
+    """the flattened tables + md5<->dense-id maps go to disk once and a server start loads them without
+    touching the JSON tables; answers are identical, field for field."""
+    forw, inv = _weighted_tables(host, corpus)
+    di = host.DeviceIndex()
+    di.load(forw, inv)
+    queries = ["w3 w17 w40", 'w1 "w2 w3" w4', "w149 nosuchword", '"w0 w1"']
+    probs = [{"Arts": 0.5, "Science": 0.25, "Sports": 0.25}] * len(queries)
+    want = di.RetrieveBatch(queries, 50, probs)
+    path = str(tmp_path / "corpus.ssnap")
+    di.save_snapshot(path)
+    assert open(path, "rb").read(8) == b"SSNAP002"
+    fresh = host.DeviceIndex()
+    fresh.load_snapshot(path)                       # no forw/inv tables involved
+    assert fresh.categories == di.categories
+    got = fresh.RetrieveBatch(queries, 50, probs)
+    for a, b in zip(want, got):
+        assert [(r.DocHash, r.FinalRank, r.PageRank, r.TitleRank, r.BodyRank) for r in a] == \
+               [(r.DocHash, r.FinalRank, r.PageRank, r.TitleRank, r.BodyRank) for r in b]
+    # a damaged file is refused, not half-loaded
+    blob = open(path, "rb").read()
+    bad = tmp_path / "bad.ssnap"
+    bad.write_bytes(b"NOTASNAP" + blob[8:])
+    with pytest.raises(RuntimeError):
+        host.DeviceIndex().load_snapshot(str(bad))
+    bad.write_bytes(blob[:len(blob) // 2])
+    with pytest.raises(RuntimeError):
+        host.DeviceIndex().load_snapshot(str(bad))
+
+
+def test_concurrent_requests_are_batched(host, corpus):
+    """cmd/server/server.go:47 serves one goroutine per request; the batching front-end answers concurrent callers with one
+    library call and hands every caller its own result."""
+    import threading
+    forw, inv = _weighted_tables(host, corpus)
+    di = host.DeviceIndex()
+    di.load(forw, inv)
+    queries = [f"w{i % 150} w{(7 * i + 3) % 150} w{(13 * i + 5) % 150}" for i in range(64)]
+    want = di.RetrieveBatch(queries, 50)
+    batcher = host.RetrieveBatcher(di, 50, 20000, 1024)      # generous window: the threads below all make it into few batches
+    got = [None] * len(queries)
+
+    def worker(i):
+        got[i] = batcher.Retrieve(queries[i])
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(queries))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for a, b in zip(want, got):
+        assert [(r.DocHash, r.FinalRank) for r in a] == [(r.DocHash, r.FinalRank) for r in b]
+    assert batcher.batches < len(queries) and batcher.largest_batch > 1
+    one = batcher.Retrieve(queries[0])                       # a lone caller is served after the window
+    assert [(r.DocHash, r.FinalRank) for r in one] == [(r.DocHash, r.FinalRank) for r in want[0]]
