@@ -16,6 +16,7 @@ import (
 	"sort"
 	"strings"
 	"sync"
+	"time"
 
 	db "github.com/nwihardjo/SpaghettiSearch/database"
 	"github.com/nwihardjo/SpaghettiSearch/parser"
@@ -31,10 +32,7 @@ type deviceIndex struct {
 	docName []string          // dense doc id -> md5-hex(url)
 }
 
-var (
-	warm sync.Once
-	dev  *deviceIndex
-)
+var dev *deviceIndex
 
 func flatten(ctx context.Context, inv db.DB, termID map[string]uint32, docID map[string]uint32) (ptr []uint64, doc []uint32, w []float32, posPtr []uint64, pos []float32) {
 	comp, err := inv.Iterate(ctx)
@@ -128,8 +126,79 @@ func load(ctx context.Context, forw []db.DB, inv []db.DB) *deviceIndex {
 	return d
 }
 
+// ---- request batching (INTEGRATION.md §4) ----------------------------------------------------------------------
+// net/http runs one goroutine per request (cmd/server/server.go:47) and each calls Retrieve.  Concurrent callers are
+// collected for at most batchWindow (or until maxBatch are waiting) and answered by ONE library call; every caller gets
+// its own rows back and decorates its own winners.  A lone request pays the window once (1 ms against ~0.15 ms of device
+// time); under load the device sees batches and runs at its batch throughput.
+const (
+	batchWindow = time.Millisecond
+	maxBatch    = 1024
+)
+
+type request struct {
+	qTerms, pTerms []uint32
+	qLen           int32
+	reply          chan []spaghetti.Hit
+}
+
+var (
+	reqs     = make(chan *request, 4*maxBatch)
+	batchers sync.Once
+)
+
+func batchLoop() {
+	for first := range reqs {
+		batch := []*request{first}
+		timer := time.NewTimer(batchWindow)
+	collect:
+		for len(batch) < maxBatch {
+			select {
+			case r := <-reqs:
+				batch = append(batch, r)
+			case <-timer.C:
+				break collect
+			}
+		}
+		timer.Stop()
+		qPtr, pPtr := []uint32{0}, []uint32{0}
+		var qTerms, pTerms []uint32
+		qLen := make([]int32, 0, len(batch))
+		for _, r := range batch {
+			qTerms = append(qTerms, r.qTerms...)
+			pTerms = append(pTerms, r.pTerms...)
+			qPtr = append(qPtr, uint32(len(qTerms)))
+			pPtr = append(pPtr, uint32(len(pTerms)))
+			qLen = append(qLen, r.qLen)
+		}
+		// topicProbs stays nil as in the shipped reference (main_retrieve.go:40,87-88): sqd = 0.
+		hits, _ := dev.scorer.ScoreTopKPhrase(qPtr, qTerms, pPtr, pTerms, qLen, nil, topK)
+		for i, r := range batch {
+			r.reply <- hits[i]
+		}
+	}
+}
+
+// Refresh drops the device copy of the tables; the next Retrieve flattens and uploads them again (call after a
+// re-crawl has rewritten inv[*]/forw[3..4]: the reference re-reads BadgerDB on every request and needs no such call).
+func Refresh() {
+	warmMu.Lock()
+	defer warmMu.Unlock()
+	if dev != nil {
+		dev.scorer.Close()
+		dev = nil
+	}
+}
+
+var warmMu sync.Mutex
+
 func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Rank_combined {
-	warm.Do(func() { dev = load(ctx, forw, inv) })
+	warmMu.Lock()
+	if dev == nil {
+		dev = load(ctx, forw, inv)
+	}
+	warmMu.Unlock()
+	batchers.Do(func() { go batchLoop() })
 
 	// main_retrieve.go:17-36 — query parsing, unchanged
 	phrases := getPhrase(query)
@@ -139,34 +208,28 @@ func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Ra
 	queryTokenised := parser.Laundry(strings.Join(strings.Fields(query), " "))
 	phraseTokenised := parser.Laundry(strings.Join(phrases, " "))
 
-	qTerms := make([]uint32, len(queryTokenised))
-	for i, tok := range queryTokenised {
-		sum := md5.Sum([]byte(tok))
-		if id, ok := dev.termID[hex.EncodeToString(sum[:])]; ok {
-			qTerms[i] = id
-		} else {
-			qTerms[i] = 0xFFFFFFFF // badger.ErrKeyNotFound: no postings (main_retrieve.go:193,218)
+	toIDs := func(tokens []string) []uint32 {
+		ids := make([]uint32, len(tokens))
+		for i, tok := range tokens {
+			sum := md5.Sum([]byte(tok))
+			if id, ok := dev.termID[hex.EncodeToString(sum[:])]; ok {
+				ids[i] = id
+			} else {
+				ids[i] = 0xFFFFFFFF // badger.ErrKeyNotFound: no postings (main_retrieve.go:193,218)
+			}
 		}
+		return ids
 	}
-	qPtr := []uint32{0, uint32(len(qTerms))}
 	// all quoted phrases form ONE phrase (main_retrieve.go:26); it is matched on the device from the
 	// positional part of the postings (retrieval/phrase.go -> ss_score_topk_phrase)
-	pTerms := make([]uint32, len(phraseTokenised))
-	for i, tok := range phraseTokenised {
-		sum := md5.Sum([]byte(tok))
-		if id, ok := dev.termID[hex.EncodeToString(sum[:])]; ok {
-			pTerms[i] = id
-		} else {
-			pTerms[i] = 0xFFFFFFFF
-		}
-	}
-	pPtr := []uint32{0, uint32(len(pTerms))}
-	qLen := []int32{int32(len(queryTokenised) + len(phraseTokenised))} // main_retrieve.go:90
-	// topicProbs stays nil as in the shipped reference (main_retrieve.go:40,87-88): sqd = 0.
-	hits, _ := dev.scorer.ScoreTopKPhrase(qPtr, qTerms, pPtr, pTerms, qLen, nil, topK)
+	r := &request{qTerms: toIDs(queryTokenised), pTerms: toIDs(phraseTokenised),
+		qLen:  int32(len(queryTokenised) + len(phraseTokenised)), // main_retrieve.go:90
+		reply: make(chan []spaghetti.Hit, 1)}
+	reqs <- r
+	hits := <-r.reply
 
-	out := make([]Rank_combined, 0, len(hits[0]))
-	for _, h := range hits[0] {
+	out := make([]Rank_combined, 0, len(hits))
+	for _, h := range hits {
 		docHash := dev.docName[h.Doc]
 		meta := <-getDocInfo(ctx, docHash, forw) // get_metadata.go:211-235, for the winners only
 		meta.PageRank = h.PageRank               // get_metadata.go:68
