@@ -245,6 +245,33 @@ func (ix *Index) SetPositions(posPtr []uint64, pos []float32) {
 func (ix *Index) SetDocFreq(df []uint64) {
 	check(ix.ctx, C.ss_index_set_doc_freq(ix.h, u64p(df)), "ss_index_set_doc_freq")
 }
+
+// Delta is what indexer.checkAndUpdate (indexer/indexer.go:420-641) and the re-index after it change in ONE inverted
+// table: DelDocs lose every posting (the changed page's old words, :455-531), the (DelTerm[i], DelDoc[i]) postings go
+// (anchor words of its children, :533-616), the (AddTerm[i], AddDoc[i], AddW[i]) postings arrive.
+type Delta struct {
+	DelDocs          []uint32
+	DelTerm, DelDoc  []uint32
+	AddTerm, AddDoc  []uint32
+	AddW             []float32
+}
+
+// ApplyDelta merges d into the resident table on the device (no BadgerDB row rewrite, no re-upload).  Scorers on this
+// table must be closed before and created again after; call RefreshMagnitudes or TfIdfBuild next, as
+// start_crawl.go:176-177 re-runs UpdateTermWeights after every crawl.
+func (ix *Index) ApplyDelta(d Delta) {
+	check(ix.ctx, C.ss_index_apply_delta(ix.h, C.uint64_t(len(d.DelDocs)), u32p(d.DelDocs),
+		C.uint64_t(len(d.DelTerm)), u32p(d.DelTerm), u32p(d.DelDoc),
+		C.uint64_t(len(d.AddTerm)), u32p(d.AddTerm), u32p(d.AddDoc), f32p(d.AddW)), "ss_index_apply_delta")
+	var nPost C.uint64_t
+	check(ix.ctx, C.ss_index_get_info(ix.h, nil, nil, &nPost), "ss_index_get_info")
+	ix.NPost = uint64(nPost)
+}
+func (ix *Index) RefreshMagnitudes() []float64 {
+	mag := make([]float64, ix.NDocs)
+	check(ix.ctx, C.ss_index_refresh_magnitudes(ix.h, f64p(mag)), "ss_index_refresh_magnitudes")
+	return mag
+}
 func (ix *Index) SetWeighted(mag []float64) {
 	check(ix.ctx, C.ss_index_set_weighted(ix.h, f64p(mag)), "ss_index_set_weighted")
 }

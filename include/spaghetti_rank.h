@@ -221,6 +221,26 @@ int32_t ss_index_set_weighted(ss_index* idx, const double* mag /*[n_docs]*/);
  * float32 positions, -100 for anchor/meta text), pos_ptr[n_postings+1] into pos[]. */
 int32_t ss_index_set_positions(ss_index* idx, const uint64_t* pos_ptr, const float* pos);
 
+/* Incremental update of a resident table (indexer/indexer.go:420-641 checkAndUpdate and the re-index
+ * that follows it): every posting of del_docs goes (the changed page's old title/body words, :455-531), the single
+ * postings (del_term[i], del_doc[i]) go (anchor words of the page's children in inv[0], :533-616; a pair that is not
+ * there is ignored like Go's delete on a missing key), the postings (add_term[i], add_doc[i], add_w[i]) arrive (the
+ * re-indexed page; a pair must not exist unless this delta deletes it).  The delta is merged into the resident CSR on
+ * the device — no re-flatten, no re-upload — and every list is re-validated to be strictly ascending by doc; on any
+ * error the table is unchanged.  Weights are taken as given (the reference stores whatever listPos[0] holds);
+ * magnitudes are NOT touched: call ss_index_refresh_magnitudes (or ss_tfidf_build, as the reference re-runs
+ * UpdateTermWeights after every crawl, start_crawl.go:176-177).  Positional postings are dropped (set them again for
+ * phrase search); scorers on this table must be destroyed before and created again after. */
+int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t* del_docs,
+                             uint64_t n_del, const uint32_t* del_term, const uint32_t* del_doc,
+                             uint64_t n_add, const uint32_t* add_term, const uint32_t* add_doc, const float* add_w);
+/* mag[doc] = sqrt(sum float64(float32(w*w))) over the table's CURRENT weights (term_weighting.go:44,72), without the
+ * idf multiplication of ss_tfidf_build.  mag_out [n_docs] nullable. */
+int32_t ss_index_refresh_magnitudes(ss_index* idx, double* mag_out);
+/* The table as it stands (after updates): sizes, then the arrays (each nullable; host or device). */
+int32_t ss_index_get_info(const ss_index* idx, uint64_t* n_docs, uint64_t* n_terms, uint64_t* n_post);
+int32_t ss_index_read(ss_index* idx, uint64_t* term_ptr_out /*[n_terms+1]*/, uint32_t* post_doc_out, float* post_w_out);
+
 /* ---- scoring: retrieval/main_retrieve.go:50-103, get_metadata.go:31-69 -- */
 int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer** out);
 int32_t ss_scorer_destroy(ss_scorer* s);

@@ -263,6 +263,30 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
     }
 }
 
+// magnitudes only (ss_index_refresh_magnitudes): the weights are already final
+__global__ __launch_bounds__(TPB) void k_count_only(const uint32_t* __restrict__ post_doc, uint64_t n_post, int shift, uint32_t nb, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t s_hist[NB_MAX];
+    const uint64_t base = (uint64_t)blockIdx.x * CH;
+    for (uint32_t b = threadIdx.x; b < nb; b += TPB) s_hist[b] = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < PER_THREAD; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        if (i >= n_post) break;
+        atomicAdd(&s_hist[post_doc[i] >> shift], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += TPB)
+        if (s_hist[b]) atomicAdd(&cnt[b], s_hist[b]);
+}
+__global__ void k_sumsq_atomic(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post, double* __restrict__ mag2) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_post; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float w = post_w[i];
+        const float sq = w * w;                                       // term_weighting.go:44 (float32 product)
+        unsafeAtomicAdd(&mag2[post_doc[i]], (double)sq);
+    }
+}
+
 constexpr int TPB_B = 512;
 __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ packed, const uint32_t* __restrict__ off, uint64_t n_docs,
                                                       int shift, double* __restrict__ mag) {
@@ -419,6 +443,70 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     if (w_out && P) SS_HIP(ctx, hipMemcpyAsync(w_out, idx->post_w.p, P * sizeof(float), hipMemcpyDefault, st));
     if (mag_out) SS_HIP(ctx, hipMemcpyAsync(mag_out, idx->mag.p, N * sizeof(double), hipMemcpyDefault, st));
     if (idf_out && T) SS_HIP(ctx, hipMemcpyAsync(idf_out, idf.p, T * sizeof(float), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    return SS_OK;
+}
+
+int32_t ss_index_refresh_magnitudes(ss_index* idx, double* mag_out) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t P = idx->n_post, N = idx->n_docs;
+    int shift = 13;
+    if ((N >> shift) >= (uint64_t)NB_MAX) shift = 14;
+    const uint64_t nb64 = ss::div_up(std::max<uint64_t>(N, 1), (uint64_t)1 << shift);
+    const bool bucketed = P >= ((uint64_t)1 << 22) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
+    SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
+    if (bucketed) {
+        const uint32_t nb = (uint32_t)nb64;
+        ss::DevBuf<uint32_t> b_cnt, b_off, b_cur;
+        ss::DevBuf<uint2> b_packed;
+        SS_HIP(ctx, b_cnt.alloc(nb));
+        SS_HIP(ctx, b_off.alloc(nb + 1));
+        SS_HIP(ctx, b_cur.alloc(nb));
+        SS_HIP(ctx, b_packed.alloc(P));
+        if (ctx->tfidf_bucket_lds < (1 << shift) * 8) {
+            SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
+            ctx->tfidf_bucket_lds = (1 << shift) * 8;
+        }
+        SS_HIP(ctx, hipMemsetAsync(b_cnt.p, 0, nb * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_count_only, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, (const uint32_t*)idx->post_doc.p, P, shift, nb, b_cnt.p);
+        hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, b_cnt.p, nb, b_off.p, b_cur.p);
+        hipLaunchKernelGGL(k_scatter, dim3(ss::div_up(P, SC_CH)), dim3(SC_TPB), 0, st, idx->post_doc.p, idx->post_w.p, P, shift, nb, b_cur.p, b_packed.p);
+        hipLaunchKernelGGL(k_bucket_sum, dim3(nb), dim3(TPB_B), (size_t)(1 << shift) * 8, st, b_packed.p, b_off.p, N, shift, idx->mag.p);
+        SS_HIP(ctx, hipGetLastError());
+        SS_HIP(ctx, hipStreamSynchronize(st));
+    } else {
+        if (P) hipLaunchKernelGGL(k_sumsq_atomic, dim3(std::min<unsigned>(ss::div_up(P, TPB), 16384u)), dim3(TPB), 0, st, (const uint32_t*)idx->post_doc.p,
+                                  (const float*)idx->post_w.p, P, idx->mag.p);
+        hipLaunchKernelGGL(k_sqrt, dim3(ss::div_up(N, TPB)), dim3(TPB), 0, st, idx->mag.p, N);
+        SS_HIP(ctx, hipGetLastError());
+    }
+    idx->weighted = true;
+    if (mag_out) SS_HIP(ctx, hipMemcpyAsync(mag_out, idx->mag.p, N * sizeof(double), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    return SS_OK;
+}
+
+int32_t ss_index_get_info(const ss_index* idx, uint64_t* n_docs, uint64_t* n_terms, uint64_t* n_post) {
+    if (!idx) return SS_ERR_INVALID;
+    if (n_docs) *n_docs = idx->n_docs;
+    if (n_terms) *n_terms = idx->n_terms;
+    if (n_post) *n_post = idx->n_post;
+    return SS_OK;
+}
+
+int32_t ss_index_read(ss_index* idx, uint64_t* term_ptr_out, uint32_t* post_doc_out, float* post_w_out) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (term_ptr_out) SS_HIP(ctx, hipMemcpyAsync(term_ptr_out, idx->term_ptr.p, (idx->n_terms + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
+    if (post_doc_out && idx->n_post) SS_HIP(ctx, hipMemcpyAsync(post_doc_out, idx->post_doc.p, idx->n_post * sizeof(uint32_t), hipMemcpyDefault, st));
+    if (post_w_out && idx->n_post) SS_HIP(ctx, hipMemcpyAsync(post_w_out, idx->post_w.p, idx->n_post * sizeof(float), hipMemcpyDefault, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     return SS_OK;
 }

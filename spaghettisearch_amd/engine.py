@@ -297,6 +297,32 @@ class InvertedIndex:
         check(self.ctx.lib.ss_tfidf_build(self.h, int(total_docs), _ptr(w), _ptr(mag), _ptr(idf)), self.ctx.h)
         return w, mag, idf
 
+    def apply_delta(self, del_docs=None, del_pairs=None, add=None) -> None:
+        """ss_index_apply_delta: del_docs uint32[], del_pairs = (terms uint32[], docs uint32[]), add = (terms, docs, weights f32[])."""
+        dd = _as(del_docs if del_docs is not None else np.zeros(0, np.uint32), "uint32")
+        dt, dp = (_as(del_pairs[0], "uint32"), _as(del_pairs[1], "uint32")) if del_pairs is not None else (np.zeros(0, np.uint32),) * 2
+        at, ad, aw = (_as(add[0], "uint32"), _as(add[1], "uint32"), _as(add[2], "float32")) if add is not None else \
+            (np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32))
+        self.ctx.ready(dd, dt, dp, at, ad, aw)
+        check(self.ctx.lib.ss_index_apply_delta(self.h, int(dd.shape[0]), _ptr(dd), int(dt.shape[0]), _ptr(dt), _ptr(dp),
+                                                int(at.shape[0]), _ptr(at), _ptr(ad), _ptr(aw)), self.ctx.h)
+        n_post = C.c_uint64()
+        check(self.ctx.lib.ss_index_get_info(self.h, None, None, C.byref(n_post)), self.ctx.h)
+        self.n_post = int(n_post.value)
+
+    def refresh_magnitudes(self) -> np.ndarray:
+        mag = np.zeros(self.n_docs, dtype=np.float64)
+        check(self.ctx.lib.ss_index_refresh_magnitudes(self.h, _ptr(mag)), self.ctx.h)
+        return mag
+
+    def read(self):
+        """-> (term_ptr uint64[T+1], post_doc uint32[P], post_w float32[P]) as the table stands."""
+        tp = np.zeros(self.n_terms + 1, dtype=np.uint64)
+        pd = np.zeros(self.n_post, dtype=np.uint32)
+        pw = np.zeros(self.n_post, dtype=np.float32)
+        check(self.ctx.lib.ss_index_read(self.h, _ptr(tp), _ptr(pd), _ptr(pw)), self.ctx.h)
+        return tp, pd, pw
+
     def set_doc_freq(self, df) -> None:
         """ss_index_set_doc_freq: whole-corpus document frequencies when this table is one doc-range shard
         (uint64[n_terms]; None = local list lengths).  Call before tfidf_build."""

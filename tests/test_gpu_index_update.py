@@ -1,0 +1,187 @@
+"""GPU parity: incremental update of a resident inverted table.
+
+Reference: indexer/indexer.go:420-641 (checkAndUpdate) + the re-index that follows it.  The reference rewrites whole
+posting rows in BadgerDB; ss_index_apply_delta merges the delta into the resident CSR on the device.  The checker is
+a dict-of-dicts model of the reference's map[docHash]listPos rows (delete(row, doc) / row[doc] = w), rebuilt into a
+CSR with numpy: the merged table must be BIT-identical to a table built from scratch out of the updated rows, and
+weights / magnitudes / top-k computed on it must equal the oracle's on that from-scratch table.
+"""
+import numpy as np
+import pytest
+
+from spaghettisearch_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rows_of(tp, pd, w):
+    return [dict(zip(pd[int(tp[t]):int(tp[t + 1])].tolist(), w[int(tp[t]):int(tp[t + 1])].tolist())) for t in range(len(tp) - 1)]
+
+
+def csr_of(rows):
+    tp = np.zeros(len(rows) + 1, dtype=np.uint64)
+    docs, ws = [], []
+    for t, row in enumerate(rows):
+        ks = sorted(row)
+        docs.extend(ks)
+        ws.extend(row[k] for k in ks)
+        tp[t + 1] = len(docs)
+    return tp, np.array(docs, dtype=np.uint32), np.array(ws, dtype=np.float32)
+
+
+def random_delta(rng, tp, pd, n_docs, n_terms, n_changed, n_pairs, n_add):
+    """a crawl pass: n_changed pages changed (all their postings go, fresh ones arrive), n_pairs anchor postings go"""
+    changed = rng.choice(n_docs, size=n_changed, replace=False).astype(np.uint32)
+    term_of = np.repeat(np.arange(n_terms, dtype=np.uint32), np.diff(tp.astype(np.int64)))
+    pick = rng.choice(len(pd), size=min(n_pairs, len(pd)), replace=False)
+    del_t, del_d = term_of[pick], pd[pick]
+    # one pair that does not exist (ignored) when there is room for it
+    del_t = np.concatenate([del_t, np.array([n_terms - 1], np.uint32)])
+    del_d = np.concatenate([del_d, np.array([n_docs - 1], np.uint32)])
+    # additions: postings of the changed pages (free: all their old ones go) + postings of brand-new (term, doc) pairs
+    at = rng.integers(0, n_terms, size=n_add).astype(np.uint32)
+    ad = changed[rng.integers(0, len(changed), size=n_add)]
+    key = (at.astype(np.uint64) << np.uint64(32)) | ad.astype(np.uint64)
+    _, first = np.unique(key, return_index=True)
+    first = rng.permutation(first)                                   # unsorted on purpose
+    at, ad = at[first], ad[first]
+    aw = rng.random(len(at), dtype=np.float32) + np.float32(0.01)
+    return changed, (del_t, del_d), (at, ad, aw)
+
+
+def apply_model(rows, changed, del_pairs, add):
+    ch = set(changed.tolist())
+    for row in rows:
+        for d in ch & row.keys():
+            del row[d]
+    for t, d in zip(del_pairs[0].tolist(), del_pairs[1].tolist()):
+        rows[t].pop(d, None)
+    for t, d, w in zip(add[0].tolist(), add[1].tolist(), add[2].tolist()):
+        assert d not in rows[t]
+        rows[t][d] = w
+    return rows
+
+
+@pytest.mark.parametrize("n_docs,n_terms,n_post,n_changed,n_pairs,n_add", [
+    (64, 16, 300, 5, 10, 40), (5000, 800, 60000, 200, 500, 3000), (200000, 40000, 3000000, 5000, 20000, 80000)])
+def test_delta_equals_rebuild(ss_ctx, oracle, n_docs, n_terms, n_post, n_changed, n_pairs, n_add):
+    from spaghettisearch_amd import engine
+    rng = np.random.default_rng(n_terms)
+    tp, pd, tf = synth.zipf_index(n_docs, n_terms, n_post, seed=n_terms + 1)
+    changed, del_pairs, add = random_delta(rng, tp, pd, n_docs, n_terms, n_changed, n_pairs, n_add)
+    tp2, pd2, w2 = csr_of(apply_model(rows_of(tp, pd, tf), changed, del_pairs, add))
+    idx = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
+    try:
+        idx.apply_delta(del_docs=changed, del_pairs=del_pairs, add=add)
+        g_tp, g_pd, g_w = idx.read()
+        assert idx.n_post == len(pd2)
+        assert np.array_equal(g_tp, tp2) and np.array_equal(g_pd, pd2) and np.array_equal(g_w, w2)      # bit-exact
+        # magnitudes of the weights as they stand, vs the oracle's float64 sum of float32 squares
+        mag = idx.refresh_magnitudes()
+        sq = (w2 * w2).astype(np.float32).astype(np.float64)
+        ref = np.sqrt(np.bincount(pd2, weights=sq, minlength=n_docs))
+        np.testing.assert_allclose(mag, ref, rtol=1e-12)
+        # and the reference's own sequence (UpdateTermWeights after the crawl): same as a from-scratch table
+        w, mag, idf = idx.tfidf_build(n_docs)
+        w_ref, mag_ref, idf_ref = oracle.tfidf(tp2, pd2, w2, n_docs, n_docs)
+        assert np.array_equal(w, w_ref)
+        np.testing.assert_allclose(mag, mag_ref, rtol=1e-12)
+    finally:
+        idx.close()
+
+
+def test_two_deltas_and_empty_delta(ss_ctx):
+    from spaghettisearch_amd import engine
+    rng = np.random.default_rng(5)
+    n_docs, n_terms = 3000, 300
+    tp, pd, tf = synth.zipf_index(n_docs, n_terms, 40000, seed=9)
+    rows = rows_of(tp, pd, tf)
+    idx = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
+    try:
+        idx.apply_delta()                                            # nothing to do: table unchanged
+        g = idx.read()
+        assert np.array_equal(g[0], tp) and np.array_equal(g[1], pd) and np.array_equal(g[2], tf)
+        for _ in range(2):
+            cur_tp, cur_pd, _ = csr_of(rows)
+            changed, del_pairs, add = random_delta(rng, cur_tp, cur_pd, n_docs, n_terms, 100, 300, 2000)
+            rows = apply_model(rows, changed, del_pairs, add)
+            idx.apply_delta(del_docs=changed, del_pairs=del_pairs, add=add)
+        tp2, pd2, w2 = csr_of(rows)
+        g = idx.read()
+        assert np.array_equal(g[0], tp2) and np.array_equal(g[1], pd2) and np.array_equal(g[2], w2)
+        # delete everything
+        idx.apply_delta(del_docs=np.arange(n_docs, dtype=np.uint32))
+        assert idx.n_post == 0 and not idx.read()[0].any()
+        # and fill an empty table again
+        idx.apply_delta(add=(np.array([3, 3, 0], np.uint32), np.array([7, 2, 9], np.uint32), np.array([.5, .25, 1], np.float32)))
+        g = idx.read()
+        assert g[1].tolist() == [9, 2, 7] and g[2].tolist() == [1.0, .25, .5] and int(g[0][1]) == 1 and int(g[0][4]) == 3
+    finally:
+        idx.close()
+
+
+def test_rejected_delta_leaves_the_table_unchanged(ss_ctx):
+    from spaghettisearch_amd import engine
+    tp, pd, tf = synth.zipf_index(500, 60, 4000, seed=3)
+    idx = engine.InvertedIndex(ss_ctx, 500, tp, pd, tf)
+    u = lambda *v: np.array(v, dtype=np.uint32)
+    f = lambda *v: np.array(v, dtype=np.float32)
+    t0 = 0
+    d_existing = int(pd[int(tp[t0])])
+    try:
+        cases = [
+            dict(del_docs=u(500)),                                             # doc out of range
+            dict(del_pairs=(u(60), u(1))),                                     # term out of range
+            dict(add=(u(1), u(999), f(1))),                                    # doc out of range
+            dict(add=(u(2, 2), u(5, 5), f(1, 2)), del_docs=u(5)),              # the same posting twice
+            dict(add=(u(t0), u(d_existing), f(1))),                            # exists, not deleted by the delta
+        ]
+        for kw in cases:
+            with pytest.raises(_lib.SpaghettiError) as e:
+                idx.apply_delta(**kw)
+            assert e.value.code == 1                                 # SS_ERR_INVALID
+            g = idx.read()
+            assert np.array_equal(g[0], tp) and np.array_equal(g[1], pd) and np.array_equal(g[2], tf)
+        # the same posting is fine when this delta deletes the old one (a changed page keeps a word)
+        idx.apply_delta(del_pairs=(u(t0), u(d_existing)), add=(u(t0), u(d_existing), f(7)))
+        g = idx.read()
+        assert g[2][int(tp[t0])] == 7.0 and np.array_equal(g[1], pd)
+    finally:
+        idx.close()
+
+
+def test_scorers_must_be_recreated_and_then_score_the_new_table(ss_ctx, oracle):
+    from spaghettisearch_amd import engine
+    from tests.test_gpu_score import assert_same_hits
+    rng = np.random.default_rng(11)
+    n_docs, n_terms = 20000, 3000
+    tp, pd, tf = synth.zipf_index(n_docs, n_terms, 400000, seed=4)
+    btp, bpd, btf = synth.zipf_index(n_docs, n_terms, 900000, seed=6)
+    title = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
+    body = engine.InvertedIndex(ss_ctx, n_docs, btp, bpd, btf)
+    title.tfidf_build(n_docs)
+    body.tfidf_build(n_docs)
+    sc = engine.Scorer(ss_ctx, title, body)
+    try:
+        with pytest.raises(_lib.SpaghettiError) as e:
+            body.apply_delta(del_docs=np.array([1], np.uint32))
+        assert e.value.code == 6                                     # SS_ERR_STATE: a scorer holds the table
+        sc.close()
+        sc = None
+        cur = body.read()
+        changed, del_pairs, add = random_delta(rng, cur[0], cur[1], n_docs, n_terms, 500, 2000, 20000)
+        body.apply_delta(del_docs=changed, del_pairs=del_pairs, add=add)
+        b_mag = body.refresh_magnitudes()
+        b = body.read()
+        t = title.read()
+        t_mag = title.refresh_magnitudes()
+        sc = engine.Scorer(ss_ctx, title, body)
+        q_ptr, q_terms = synth.make_queries(256, 3, n_terms // 2, seed=8)
+        hits, n_hits = sc.score_topk(q_ptr, q_terms, 10)
+        ref, ref_n = oracle.score_topk_batch(n_docs, t, b, t_mag, b_mag, q_ptr, q_terms, 10)
+        assert_same_hits(hits, n_hits, ref, ref_n)
+    finally:
+        if sc is not None:
+            sc.close()
+        title.close()
+        body.close()
