@@ -50,7 +50,13 @@ struct PrCtl {
     uint32_t pad;
 };
 
-enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3, W_ROWS = 4, W_ROWG = 5 };
+enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3, W_ROWS = 4, W_ROWG = 5,
+                  // GW >= 8 (k_pr_sweep): every item belongs to ONE wave
+                  V_SEG = 8,     // a <= SEGW-edge piece of a row with more than T_MULTI in-edges (partials + ticket)
+                  V_ROWW = 9,    // a whole row, T_QUAD < in-edges <= T_MULTI
+                  V_QUAD = 10,   // `count` rows, one per lane group and turn, each `nseg` (= chunks per row) 16-edge chunks long
+                  V_DEG = 11,    // `count` rows of EXACTLY `nseg` (<= 8) in-edges: several rows per lane group and chunk
+                  V_ZERO = 12 }; // `count` non-dangling rows without in-edges
 
 struct WorkItem {
     uint32_t kind;
@@ -83,6 +89,10 @@ struct PrParams {
     const double* tin;        // [MAXK] teleport of a member: (1-d) * N / |set_k|
     const double* nz_in;      // [MAXK] rows without in-edges (this rank) inside topic k's set
     uint32_t ts_mask;         // bit k: topic k has a teleport set (others keep the uniform teleport)
+    uint32_t zrow;            // index of the table's all-zero row (= nd_int): where the unused slots of a chunk gather from
+#ifdef SS_PR_EXP_KINDMASK
+    uint32_t kind_mask;       // experiment builds only: run just these work classes (bit = kind)
+#endif
 };
 
 // ---- reductions --------------------------------------------------------------
@@ -408,6 +418,9 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
 
     for (uint32_t item = blockIdx.x; item < p.n_items; item += gridDim.x) {
         const WorkItem w = p.work[item];
+#ifdef SS_PR_EXP_KINDMASK
+        if (!((p.kind_mask >> w.kind) & 1u)) continue;
+#endif
         if (w.kind == W_SEG) {
             // one block per segment of a long row
             const uint32_t lrow = w.row;
@@ -587,6 +600,284 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     block_reduce_and_publish<GW>(p, dsum, csum, Tw, false);
 }
 
+// ---- the sweep, K >= 5 (GW = 8 / 16): k_pr_sweep -------------------------------------------------------------
+// Every work item belongs to ONE wave (no block barriers on the way), control flow is wave-uniform, and every path
+// is the same software pipeline: a lane group (GW lanes = the GW topic values of one table row) takes 16 in-edges
+// per turn; the index words of turn i+1 are requested before the 16 whole-row gathers of turn i are issued, so a turn
+// costs ONE memory latency.  Slots of a turn that hold no edge gather the table's all-zero row (p.zrow) and add an
+// exact 0.0 — there are no per-edge predicates, flags or LDS traffic anywhere.  Row ends are known from the item:
+//   V_SEG / V_ROWW   the wave's lane groups share one long row (cross-group butterfly at the end)
+//   V_QUAD           one row per lane group, all rows of the item `nch` turns long (rows are in-degree sorted)
+//   V_DEG<R>         R rows of exactly D <= 16/R in-edges per lane group and turn, at fixed slots
+// Measured on the 10M/50M R-MAT, K=16 (MI355X): 1.41 ms per sweep for the block-per-item / flag-driven kernel this
+// replaces; every class alone was latency-bound (0.60 + 0.53 + 0.57 + 0.16 ms, tools/pr_kmask.sh).
+constexpr uint32_t SEGW = 2048;      // edges per V_SEG piece
+
+template <int GW>
+struct SweepCtx {
+    const PrParams& p;
+    const double* __restrict__ T;
+    double* __restrict__ Tw;
+    double S, x0;
+    bool act;
+    int t, gbase, slot;
+    double dsum, csum;
+};
+
+// the 16 index words of a lane group's turn: slot j = r*GW + t holds edge `epos + j` for j < n, the zero row otherwise
+template <int GW>
+__device__ __forceinline__ void idx_turn(const uint32_t* __restrict__ in_src, uint32_t epos, uint32_t n, uint32_t zrow, int t, uint32_t (&src)[CH / GW]) {
+#pragma unroll
+    for (int r = 0; r < CH / GW; r++) {
+        const uint32_t j = (uint32_t)(r * GW + t);
+        const uint32_t raw = NT_LOAD(&in_src[j < n ? epos + j : 0u]);       // unconditional load (edge 0 exists whenever an item has edges)
+        src[r] = j < n ? (raw & SRC_MASK) : zrow;
+    }
+}
+template <int GW>
+__device__ __forceinline__ void gather_turn(const double* __restrict__ T, const uint32_t (&src)[CH / GW], int t, int gbase, double (&v)[CH]) {
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        const uint32_t sj = (uint32_t)__shfl((int)src[j / GW], gbase + (j % GW), 64);
+        v[j] = tab_at<GW>(T, sj, t);
+    }
+}
+
+template <int GW>
+__device__ __forceinline__ void finish_row(SweepCtx<GW>& c, uint32_t lrow, double y, double xo, uint32_t od) {
+    const PrParams& p = c.p;
+    y += c.x0;
+    const size_t xi = (size_t)lrow * GW + c.t;
+    double xn = (y + teleport_of(p, lrow, c.t)) / c.S;      // pagerank.go:117
+    if (c.act) {
+        NT_STORE(xn, &p.x[xi]);
+        c.dsum += fabs(xn - xo);                              // pagerank.go:118
+    } else {
+        xn = xo;                                              // converged topic: frozen
+    }
+    if (lrow < p.sl_nd) {                                     // non-dangling row: next sweep's contribution
+        const double cc = p.d * xn / (double)od;              // pagerank.go:136
+        NT_STORE(cc, &c.Tw[xi]);
+        c.csum += cc;                                         // pagerank.go:137
+    }
+}
+
+// V_SEG / V_ROWW: edges [beg, end) of one row; turn i gives lane group s the edges beg + 64*i + 16*s ...
+template <int GW>
+__device__ __forceinline__ double stream_row(SweepCtx<GW>& c, uint32_t beg, uint32_t end) {
+    constexpr int NS = 64 / GW;
+    const PrParams& p = c.p;
+    const uint32_t turns = (end - beg + NS * CH - 1) / (NS * CH);
+    uint32_t src_n[CH / GW];
+    {
+        const uint32_t e0 = beg + (uint32_t)c.slot * CH;
+        idx_turn<GW>(p.in_src, e0, e0 < end ? min((uint32_t)CH, end - e0) : 0u, p.zrow, c.t, src_n);
+    }
+    double acc = 0.0;
+    for (uint32_t i = 0; i < turns; i++) {
+        uint32_t src[CH / GW];
+#pragma unroll
+        for (int r = 0; r < CH / GW; r++) src[r] = src_n[r];
+        const uint32_t e1 = beg + (i + 1) * (NS * CH) + (uint32_t)c.slot * CH;
+        idx_turn<GW>(p.in_src, e1, e1 < end ? min((uint32_t)CH, end - e1) : 0u, p.zrow, c.t, src_n);
+        double v[CH];
+        gather_turn<GW>(c.T, src, c.t, c.gbase, v);
+#pragma unroll
+        for (int j = 0; j < CH; j++) acc += v[j];
+    }
+    return wave_sum_topic<GW>(acc);
+}
+
+// V_QUAD: rows row0 .. row0+count-1, lane group s takes rows row0 + q*NS + s (q = 0 .. nq-1, nq <= GW), every row is
+// walked in nch turns (its own length decides how many slots of a turn are real)
+template <int GW>
+__device__ __forceinline__ void quad_rows(SweepCtx<GW>& c, uint32_t row0, uint32_t count, uint32_t nch) {
+    constexpr int NS = 64 / GW;
+    const PrParams& p = c.p;
+    const uint32_t nq = (count + NS - 1) / NS;
+    // the bounds and out-degrees of ALL the item's rows in one request: lane t of group s holds row row0 + t*NS + s
+    const uint32_t myq = (uint32_t)c.t * NS + (uint32_t)c.slot;
+    const bool have = myq < count;
+    const uint32_t rq = row0 + (have ? myq : 0u);
+    const uint32_t begv = p.in_ptr[rq], endv = have ? p.in_ptr[rq + 1] : begv;
+    const uint32_t odv = rq < p.sl_nd ? NT_LOAD(&p.outdeg[rq]) : 1u;
+    const uint32_t turns = nq * nch;
+    uint32_t q = 0, ch = 0;                                   // scalar: row group and turn inside it
+    uint32_t src_n[CH / GW];
+    uint32_t b_cur = (uint32_t)__shfl((int)begv, c.gbase, 64), e_cur = (uint32_t)__shfl((int)endv, c.gbase, 64);
+    idx_turn<GW>(p.in_src, b_cur, min((uint32_t)CH, e_cur - b_cur), p.zrow, c.t, src_n);
+    double acc = 0.0;
+    for (uint32_t i = 0; i < turns; i++) {
+        uint32_t src[CH / GW];
+#pragma unroll
+        for (int r = 0; r < CH / GW; r++) src[r] = src_n[r];
+        // next turn: same row group or the next one
+        uint32_t qn = q, cn = ch + 1;
+        if (cn == nch) { cn = 0; qn = q + 1; }
+        uint32_t b_n = b_cur, e_n = e_cur;
+        if (cn == 0 && qn < nq) {
+            b_n = (uint32_t)__shfl((int)begv, c.gbase + (int)qn, 64);
+            e_n = (uint32_t)__shfl((int)endv, c.gbase + (int)qn, 64);
+        }
+        {
+            const uint32_t ep = b_n + cn * CH;
+            idx_turn<GW>(p.in_src, ep, (qn < nq && ep < e_n) ? min((uint32_t)CH, e_n - ep) : 0u, p.zrow, c.t, src_n);
+        }
+        const bool ends = ch + 1 == nch;                      // scalar: this turn completes the rows of group q
+        const uint32_t lrow = row0 + q * NS + (uint32_t)c.slot;
+        const bool valid = q * NS + (uint32_t)c.slot < count;
+        double xo = 0.0;
+        if (ends) xo = NT_LOAD(&p.x[(size_t)(valid ? lrow : row0) * GW + c.t]);
+        double v[CH];
+        gather_turn<GW>(c.T, src, c.t, c.gbase, v);
+#pragma unroll
+        for (int j = 0; j < CH; j++) acc += v[j];
+        if (ends) {
+            const uint32_t od = (uint32_t)__shfl((int)odv, c.gbase + (int)q, 64);
+            if (valid) finish_row<GW>(c, lrow, acc, xo, od);
+            acc = 0.0;
+        }
+        q = qn; ch = cn; b_cur = b_n; e_cur = e_n;
+    }
+}
+
+// V_DEG: `count` rows of exactly D in-edges from row0 (their edges are contiguous from in_ptr[row0]); a lane group
+// takes R rows per turn, row r of the turn at slots r*DM .. r*DM+D-1 (DM = 16/R >= D)
+template <int GW, int R>
+__device__ __forceinline__ void deg_rows(SweepCtx<GW>& c, uint32_t row0, uint32_t count, uint32_t D) {
+    constexpr int NS = 64 / GW;
+    constexpr int DM = CH / R;
+    constexpr int IR = CH / GW;
+    const PrParams& p = c.p;
+    const uint32_t ebase = p.in_ptr[row0];
+    const uint32_t turns = (count + NS * R - 1) / (NS * R);
+    auto idx = [&](uint32_t turn, uint32_t (&src)[IR]) __attribute__((always_inline)) {
+        const uint32_t rb = (turn * NS + (uint32_t)c.slot) * R;           // first row (relative) of this lane group's turn
+#pragma unroll
+        for (int r = 0; r < IR; r++) {
+            const uint32_t j = (uint32_t)(r * GW + c.t);
+            const uint32_t rr = rb + j / DM, u = j % DM;
+            const bool ok = u < D && rr < count;
+            const uint32_t raw = NT_LOAD(&p.in_src[ok ? ebase + rr * D + u : 0u]);
+            src[r] = ok ? (raw & SRC_MASK) : p.zrow;
+        }
+    };
+    uint32_t src_n[IR];
+    idx(0, src_n);
+    for (uint32_t i = 0; i < turns; i++) {
+        uint32_t src[IR];
+#pragma unroll
+        for (int r = 0; r < IR; r++) src[r] = src_n[r];
+        idx(i + 1 < turns ? i + 1 : i, src_n);
+        const uint32_t rb = (i * NS + (uint32_t)c.slot) * R;
+        // old ranks and out-degrees of the R rows travel with the gathers
+        double xo[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) xo[r] = NT_LOAD(&p.x[(size_t)(row0 + (rb + r < count ? rb + r : 0u)) * GW + c.t]);
+        const uint32_t myr = row0 + (rb + (uint32_t)c.t < count ? rb + (uint32_t)c.t : 0u);
+        const uint32_t odv = (c.t < R && myr < p.sl_nd) ? NT_LOAD(&p.outdeg[myr]) : 1u;
+        double v[CH];
+        gather_turn<GW>(c.T, src, c.t, c.gbase, v);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            double y = 0.0;
+#pragma unroll
+            for (int u = 0; u < DM; u++) y += v[r * DM + u];
+            const uint32_t od = (uint32_t)__shfl((int)odv, c.gbase + r, 64);
+            if (rb + r < count) finish_row<GW>(c, row0 + rb + r, y, xo[r], od);
+        }
+    }
+}
+
+template <int GW>
+__global__ __launch_bounds__(TPB) void k_pr_sweep(PrParams p) {
+    constexpr int NS = 64 / GW;
+    PrCtl* ctl = p.ctl;
+    if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
+    const int sweep = ctl->sweep;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SweepCtx<GW> c{p, p.tab_rd[sweep & 1], p.tab_wr[sweep & 1], 0.0, 0.0, false, lane % GW, lane - lane % GW, lane / GW, 0.0, 0.0};
+    c.S = ctl->S[c.t];
+    c.act = ctl->active[c.t] != 0;
+    c.x0 = sweep == 0 ? p.x0[c.t] : 0.0;      // Q4: iteration 1 accumulates onto 1/n
+
+    const uint32_t nw = gridDim.x * WAVES;
+    for (uint32_t item = blockIdx.x * WAVES + wave; item < p.n_items; item += nw) {
+        const WorkItem w = p.work[item];
+#ifdef SS_PR_EXP_KINDMASK
+        if (!((p.kind_mask >> (w.kind & 31)) & 1u)) continue;
+#endif
+        if (w.kind == V_ROWW || w.kind == V_SEG) {
+            const uint32_t lrow = w.row;
+            const uint32_t rbeg = p.in_ptr[lrow], rend = p.in_ptr[lrow + 1];
+            const bool whole = w.kind == V_ROWW;
+            const uint32_t beg = whole ? rbeg : rbeg + w.count * SEGW;
+            const uint32_t end = whole ? rend : min(rend, beg + SEGW);
+            double y = stream_row<GW>(c, beg, end);
+            if (whole) {
+                if (lane < GW) {
+                    const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + c.t]);
+                    const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
+                    finish_row<GW>(c, lrow, y, xo, od);
+                }
+            } else {
+                // several waves (of any blocks) share this row: publish the piece's sum; the last to arrive adds the
+                // pieces in order and finishes the row
+                if (lane < GW) p.segpart[(size_t)(w.sbase + w.count) * GW + c.t] = y;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned prev = 0;
+                if (lane == 0) prev = __hip_atomic_fetch_add(&p.rowticket[w.tix], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+                if (prev == w.nseg - 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) p.rowticket[w.tix] = 0;
+                    if (lane < GW) {
+                        double ys = 0.0;
+                        for (uint32_t q = 0; q < w.nseg; q++) ys += p.segpart[(size_t)(w.sbase + q) * GW + c.t];
+                        const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + c.t]);
+                        const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
+                        finish_row<GW>(c, lrow, ys, xo, od);
+                    }
+                }
+            }
+        } else if (w.kind == V_QUAD) {
+            quad_rows<GW>(c, w.row, w.count, w.nseg);
+        } else if (w.kind == V_DEG) {
+            if (w.nseg <= 2) deg_rows<GW, 8>(c, w.row, w.count, w.nseg);
+            else if (w.nseg <= 4) deg_rows<GW, 4>(c, w.row, w.count, w.nseg);
+            else deg_rows<GW, 2>(c, w.row, w.count, w.nseg);
+        } else {
+            // V_ZERO: non-dangling rows without in-edges: their rank is the shared value xz, only the next contribution
+            // d*xz/outdeg has to be written (dangling ones need nothing at all); 64*16/GW rows per item at most
+            const bool ts = p.memb && ((p.ts_mask >> c.t) & 1u);
+            const double xz_out = c.act ? (ts ? zero_row_rank_ts(p, sweep, c.S, p.x0[c.t], 0.0) : zero_row_rank(p, sweep, c.S, p.x0[c.t])) : ctl->xz[c.t];
+            const double xz_inn = ts ? (c.act ? zero_row_rank_ts(p, sweep, c.S, p.x0[c.t], p.tin[c.t]) : ctl->xz_in[c.t]) : xz_out;
+            uint32_t od[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t rr = (uint32_t)(i * NS + c.slot);
+                od[i] = NT_LOAD(&p.outdeg[w.row + (rr < w.count ? rr : 0u)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t rr = (uint32_t)(i * NS + c.slot);
+                if (rr < w.count) {
+                    const uint32_t lrow = w.row + rr;
+                    const double xz = ts && ((p.memb[lrow] >> c.t) & 1u) ? xz_inn : xz_out;
+                    const double cc = p.d * xz / (double)od[i];                      // pagerank.go:136
+                    NT_STORE(cc, &c.Tw[(size_t)lrow * GW + c.t]);
+                    c.csum += cc;                                                     // pagerank.go:137
+                }
+            }
+        }
+    }
+    block_reduce_and_publish<GW>(p, c.dsum, c.csum, c.Tw, false);
+}
+
 // x0 = 1/n, first contributions and their sum (pagerank.go:103-106 + first :136-137)
 template <int GW>
 __global__ __launch_bounds__(TPB) void k_pr_begin(PrParams p) {
@@ -763,8 +1054,47 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     nsegs = 0;
     nmulti = 0;
     std::vector<WorkItem> seg, rwg, wav, grp, zer;
-    const uint32_t T_ROWG = 24;         // gw >= 8: rows with more in-edges than this (and <= T_SEG) take the row-per-lane-group class
+
+    // gw >= 8: wave-owned items of k_pr_sweep.  deg is sorted descending.
+    std::vector<WorkItem> vseg, vroww, vquad, vdeg, vzero;
+    auto emit_v = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
+        const uint32_t cnt = (uint32_t)deg.size();
+        const uint32_t T_MULTI = 4096, T_QUAD = 512, T_DEG = 8;
+        uint32_t r = 0;
+        for (; r < cnt && deg[r] > T_MULTI; r++) {
+            const uint32_t ns = (deg[r] + SEGW - 1) / SEGW;
+            const uint32_t tix = nmulti++;
+            for (uint32_t s = 0; s < ns; s++) vseg.push_back({V_SEG, row0 + r, s, ns, nsegs, tix});
+            nsegs += ns;
+        }
+        for (; r < cnt && deg[r] > T_QUAD; r++) vroww.push_back({V_ROWW, row0 + r, 0, 0, 0, 0});
+        // one row per lane group and turn; an item's rows all take nch = ceil(longest / 16) turns, at most gw row groups
+        // and about 32 turns per item
+        while (r < cnt && deg[r] > T_DEG) {
+            const uint32_t nch = (deg[r] + CH - 1) / CH;
+            const uint32_t max_groups = std::min<uint32_t>((uint32_t)gw, std::max<uint32_t>(1u, 32u / nch));
+            uint32_t rows = 0;
+            while (r + rows < cnt && deg[r + rows] > T_DEG && rows < max_groups * NSLOT && (deg[r + rows] + CH - 1) / CH == nch) rows++;
+            vquad.push_back({V_QUAD, row0 + r, rows, nch, 0, 0});
+            r += rows;
+        }
+        // exact-degree runs
+        while (r < cnt && deg[r] > 0) {
+            const uint32_t D = deg[r];
+            uint32_t run = 0;
+            while (r + run < cnt && deg[r + run] == D) run++;
+            const uint32_t R = D <= 2 ? 8 : D <= 4 ? 4 : 2;
+            const uint32_t per_item = NSLOT * R * 16;                 // 16 turns
+            for (uint32_t o = 0; o < run; o += per_item) vdeg.push_back({V_DEG, row0 + r + o, std::min(per_item, run - o), D, 0, 0});
+            r += run;
+        }
+        n_pos = r;
+        const uint32_t ZERO_ROWS = 16 * NSLOT;
+        if (non_dangling)
+            for (uint32_t o = r; o < cnt; o += ZERO_ROWS) vzero.push_back({V_ZERO, row0 + o, std::min<uint32_t>(ZERO_ROWS, cnt - o), 0, 0, 0});
+    };
     auto emit = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
+        if (gw >= 8) { emit_v(deg, row0, non_dangling, n_pos); return; }
         const uint32_t cnt = (uint32_t)deg.size();
         // deg is sorted descending: find class boundaries
         uint32_t a = 0;
@@ -777,21 +1107,7 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
             for (uint32_t s = 0; s < ns; s++) seg.push_back({W_SEG, row0 + r, s, ns, nsegs, tix});
             nsegs += ns;
         }
-        if (gw >= 8) {
-            // mid-degree rows: a lane group per row, 2 rows per group and item
-            uint32_t g = a;
-            while (g < c && deg[g] > T_ROWG) g++;
-            for (uint32_t r = a; r < g; r += 2 * WAVES * NSLOT) rwg.push_back({W_ROWG, row0 + r, std::min<uint32_t>(2 * WAVES * NSLOT, g - r), 0, 0, 0});
-            // the rest: items of ~256 in-edges and at most 64 rows per lane group
-            uint32_t r = g;
-            while (r < c) {
-                uint32_t rows = 0;
-                uint64_t edges = 0;
-                while (r + rows < c && rows < 64 * WAVES * NSLOT && edges < 256ull * WAVES * NSLOT) edges += deg[r + rows++];
-                wav.push_back({W_ROWS, row0 + r, rows, 0, 0, 0});
-                r += rows;
-            }
-        } else {
+        {
             uint32_t b = a;
             while (b < c && deg[b] > T_WAVE) b++;
             for (uint32_t r = a; r < b; r += WAVES) wav.push_back({W_WAVE, row0 + r, std::min<uint32_t>(WAVES, b - r), 0, 0, 0});
@@ -815,11 +1131,23 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     items.insert(items.end(), wav.begin(), wav.end());
     items.insert(items.end(), grp.begin(), grp.end());
     items.insert(items.end(), zer.begin(), zer.end());
+    // k_pr_sweep: longest first (pieces of the hubs, whole long rows, then the row groups by falling length)
+    items.insert(items.end(), vseg.begin(), vseg.end());
+    items.insert(items.end(), vroww.begin(), vroww.end());
+    items.insert(items.end(), vquad.begin(), vquad.end());
+    items.insert(items.end(), vdeg.begin(), vdeg.end());
+    items.insert(items.end(), vzero.begin(), vzero.end());
 }
 
 template <int GW>
 void launch_step(ss_pr* pr, hipStream_t st) {
-    hipLaunchKernelGGL(k_pr_step<GW>, dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+    if constexpr (GW >= 8) hipLaunchKernelGGL(k_pr_sweep<GW>, dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+    else hipLaunchKernelGGL(k_pr_step<GW>, dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+}
+template <int GW>
+void sweep_occupancy(int* blocks_per_cu) {
+    if constexpr (GW >= 8) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_pr_sweep<GW>, TPB, 0);
+    else *blocks_per_cu = 8;
 }
 template <int GW>
 void launch_begin(ss_pr* pr, hipStream_t st, unsigned nb) {
@@ -879,17 +1207,24 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     uint32_t nsegs = 0, nmulti = 0, seg_edges = 0, pos_nd = 0, pos_d = 0;
     build_work(g, GW, items, nsegs, nmulti, seg_edges, pos_nd, pos_d);
     if (items.empty()) items.push_back({W_ZERO, 0, 0, 0, 0, 0});
-    // persistent grid: 8 blocks per CU at most, each walks the work table round-robin
-    pr->nblocks = (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
+    // persistent grid, each block (gw < 8) or wave (gw >= 8) walks the work table round-robin: gw < 8: 8 blocks per CU at
+    // most; gw >= 8: exactly the waves the chip holds at once
+    int per_cu = 8;
+    SS_GW_DISPATCH(GW, sweep_occupancy, &per_cu);
+    if (per_cu < 1) per_cu = 1;
+    if (const char* e = getenv("SS_PR_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
+    pr->nblocks = GW >= 8 ? (unsigned)std::min<size_t>(ss::div_up(items.size(), (size_t)WAVES), (size_t)ctx->cu_count * per_cu)
+                          : (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
 
-    if ((uint64_t)g->nd_int * GW * 8 >= (1ull << 32))
+    if (((uint64_t)g->nd_int + 1) * GW * 8 >= (1ull << 32))
         return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_create: contribution table of %llu rows x %d topics exceeds 4 GiB (shard the graph over more ranks)",
                          (unsigned long long)g->nd_int, GW);
     SS_HIP(ctx, pr->x.alloc_streaming(n_local * GW));
-    SS_HIP(ctx, pr->tab0.alloc((size_t)g->nd_int * GW));
+    // + the all-zero row k_pr_sweep's unused slots gather from (never written: the exchange and the sweeps stop at nd_int)
+    SS_HIP(ctx, pr->tab0.alloc(((size_t)g->nd_int + 1) * GW));
     SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, std::max<size_t>(pr->tab0.bytes(), 8), st));
     if (g->world == 1) {
-        SS_HIP(ctx, pr->tab1.alloc((size_t)g->nd_int * GW));
+        SS_HIP(ctx, pr->tab1.alloc(((size_t)g->nd_int + 1) * GW));
         SS_HIP(ctx, hipMemsetAsync(pr->tab1.p, 0, std::max<size_t>(pr->tab1.bytes(), 8), st));
     } else {
         SS_HIP(ctx, pr->send.alloc((size_t)g->sl_nd * GW));
@@ -944,6 +1279,16 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     p.n_items = (uint32_t)items.size();
     p.pos_nd = pos_nd;
     p.pos_d = pos_d;
+    p.zrow = (uint32_t)g->nd_int;
+#ifdef SS_PR_EXP_KINDMASK
+    p.kind_mask = getenv("SS_PR_KIND_MASK") ? (uint32_t)strtoul(getenv("SS_PR_KIND_MASK"), nullptr, 0) : 0xFFFFFFFFu;
+    {
+        size_t cnt[16] = {0};
+        for (auto& it : items) cnt[it.kind & 15]++;
+        fprintf(stderr, "[pr] items: seg %zu wave %zu group %zu zero %zu | vseg %zu vroww %zu vquad %zu vdeg %zu vzero %zu; blocks %u\n", cnt[0], cnt[1], cnt[2], cnt[3],
+                cnt[8], cnt[9], cnt[10], cnt[11], cnt[12], pr->nblocks);
+    }
+#endif
     *out = guard.release();
     return SS_OK;
 }
@@ -1091,7 +1436,7 @@ int32_t ss_pr_exchange_buffers(ss_pr* pr, void** send_dev, uint64_t* send_bytes,
     if (send_dev) *send_dev = pr->send.p;
     if (send_bytes) *send_bytes = pr->send.bytes();
     if (recv_dev) *recv_dev = pr->tab0.p;
-    if (recv_bytes) *recv_bytes = pr->tab0.bytes();
+    if (recv_bytes) *recv_bytes = (uint64_t)pr->g->nd_int * pr->gw * sizeof(double);   // without the table's zero row
     return SS_OK;
 }
 
