@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <queue>
 
 namespace {
 
@@ -65,6 +66,7 @@ struct WorkItem {
     uint32_t nseg;    // SEG: segments of this row
     uint32_t sbase;   // SEG: index of the row's first segment partial
     uint32_t tix;     // SEG: per-row ticket index
+    uint32_t beg, end; // k_pr_sweep items: the item's in-edges are in_src[beg .. end)
 };
 
 struct PrParams {
@@ -90,6 +92,7 @@ struct PrParams {
     const double* nz_in;      // [MAXK] rows without in-edges (this rank) inside topic k's set
     uint32_t ts_mask;         // bit k: topic k has a teleport set (others keep the uniform teleport)
     uint32_t zrow;            // index of the table's all-zero row (= nd_int): where the unused slots of a chunk gather from
+    const uint32_t* woff;     // k_pr_sweep: [waves][8]: wave w's items of class c are work[woff[8w+c] .. woff[8w+c+1])
 #ifdef SS_PR_EXP_KINDMASK
     uint32_t kind_mask;       // experiment builds only: run just these work classes (bit = kind)
 #endif
@@ -182,36 +185,42 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
         red[wave][1][t] = csum;
     }
     __syncthreads();
+    // Hand-off of the block's partial sums to the last block to arrive, without fences (a release would write back the
+    // XCD's whole dirty L2 — this sweep's rank and table stores — once per block; MI355X_MICROARCH.md, hand-off forms):
+    // every partial is stored write-through (sc1), the storing wave drains its stores, one lane takes a ticket with an
+    // agent-scope atomic, and the last block reads the partials with sc1 loads.
     if (threadIdx.x < 2 * GW) {
         const int which = threadIdx.x / GW, tt = threadIdx.x % GW;
         double v = red[0][which][tt];
 #pragma unroll
         for (int w = 1; w < WAVES; w++) v += red[w][which][tt];
-        p.partials[(size_t)blockIdx.x * 2 * GW + threadIdx.x] = v;
+        __hip_atomic_store(&p.partials[(size_t)blockIdx.x * 2 * GW + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // publish: drain stores, barrier, one lane releases and takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned prev = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == gridDim.x - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_last = last;
+        s_last = prev == gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
 
-    // deterministic column sums over all blocks: column = (which, topic)
+    // deterministic column sums over all blocks: column = (which, topic); the loads go out in batches of 16
     constexpr int NCOL = 2 * GW;
     constexpr int NPART = TPB / NCOL;
     const int col = threadIdx.x % NCOL, part = threadIdx.x / NCOL;
     double acc = 0.0;
-    for (unsigned b = part; b < gridDim.x; b += NPART) acc += p.partials[(size_t)b * NCOL + col];
+    for (unsigned b0 = part; b0 < gridDim.x; b0 += 16 * NPART) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const unsigned b = b0 + u * NPART;
+            v[u] = __hip_atomic_load(&p.partials[(size_t)(b < gridDim.x ? b : b0) * NCOL + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (b0 + u * NPART < gridDim.x) acc += v[u];
+    }
     colsum[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < NCOL) {
@@ -624,6 +633,11 @@ struct SweepCtx {
     double dsum, csum;
 };
 
+// edges of [epos, lim) that fall into a 16-slot turn starting at epos: saturating, so that a turn past the end has none
+__device__ __forceinline__ uint32_t turn_fill(uint32_t epos, uint32_t lim) {
+    return min((uint32_t)CH, __builtin_elementwise_sub_sat(lim, epos));
+}
+
 // the 16 index words of a lane group's turn: slot j = r*GW + t holds edge `epos + j` for j < n, the zero row otherwise
 template <int GW>
 __device__ __forceinline__ void idx_turn(const uint32_t* __restrict__ in_src, uint32_t epos, uint32_t n, uint32_t zrow, int t, uint32_t (&src)[CH / GW]) {
@@ -648,149 +662,246 @@ __device__ __forceinline__ void finish_row(SweepCtx<GW>& c, uint32_t lrow, doubl
     const PrParams& p = c.p;
     y += c.x0;
     const size_t xi = (size_t)lrow * GW + c.t;
+#ifdef SS_PR_EXP_NODIVV
+    double xn = (y + teleport_of(p, lrow, c.t)) * (1.0 / c.S);   // 1/S is loop-invariant: hoisted
+#else
     double xn = (y + teleport_of(p, lrow, c.t)) / c.S;      // pagerank.go:117
+#endif
     if (c.act) {
+#ifndef SS_PR_EXP_NOSTOREV
         NT_STORE(xn, &p.x[xi]);
+#endif
         c.dsum += fabs(xn - xo);                              // pagerank.go:118
     } else {
         xn = xo;                                              // converged topic: frozen
     }
     if (lrow < p.sl_nd) {                                     // non-dangling row: next sweep's contribution
+#ifdef SS_PR_EXP_NODIVV
+        const double cc = p.d * xn * (double)__builtin_amdgcn_rcpf((float)od);
+#else
         const double cc = p.d * xn / (double)od;              // pagerank.go:136
+#endif
+#ifndef SS_PR_EXP_NOSTOREV
         NT_STORE(cc, &c.Tw[xi]);
+#endif
         c.csum += cc;                                         // pagerank.go:137
     }
 }
 
-// V_SEG / V_ROWW: edges [beg, end) of one row; turn i gives lane group s the edges beg + 64*i + 16*s ...
+// V_SEG / V_ROWW: the wave's items are long rows (or <= SEGW-edge pieces of the longest ones); turn i of an item
+// gives lane group s the edges beg + 64*i + 16*s ...  The pipeline runs across the items: the last turn of one item
+// requests the first index words of the next.
 template <int GW>
-__device__ __forceinline__ double stream_row(SweepCtx<GW>& c, uint32_t beg, uint32_t end) {
+__device__ __forceinline__ void long_rows(SweepCtx<GW>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1, int lane) {
     constexpr int NS = 64 / GW;
+    constexpr uint32_t TW = NS * CH;                          // edges per wave turn
     const PrParams& p = c.p;
-    const uint32_t turns = (end - beg + NS * CH - 1) / (NS * CH);
+    if (i0 >= i1) return;
+    WorkItem cur = work[i0], nxt = work[i0 + 1];              // the table ends with two unused items: reading ahead is safe
     uint32_t src_n[CH / GW];
     {
-        const uint32_t e0 = beg + (uint32_t)c.slot * CH;
-        idx_turn<GW>(p.in_src, e0, e0 < end ? min((uint32_t)CH, end - e0) : 0u, p.zrow, c.t, src_n);
+        const uint32_t e0 = cur.beg + (uint32_t)c.slot * CH;
+        idx_turn<GW>(p.in_src, e0, turn_fill(e0, cur.end), p.zrow, c.t, src_n);
     }
-    double acc = 0.0;
-    for (uint32_t i = 0; i < turns; i++) {
-        uint32_t src[CH / GW];
+    for (uint32_t it = i0; it < i1; it++) {
+        const WorkItem nn = work[it + 2];
+        const uint32_t lrow = cur.row;
+        // the row's old rank and out-degree: asked for now, used after the last turn
+        const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + c.t]);
+        const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
+        const uint32_t turns = (cur.end - cur.beg + TW - 1) / TW;
+        const bool more = it + 1 < i1;
+        double acc = 0.0;
+        for (uint32_t i = 0; i < turns; i++) {
+            uint32_t src[CH / GW];
 #pragma unroll
-        for (int r = 0; r < CH / GW; r++) src[r] = src_n[r];
-        const uint32_t e1 = beg + (i + 1) * (NS * CH) + (uint32_t)c.slot * CH;
-        idx_turn<GW>(p.in_src, e1, e1 < end ? min((uint32_t)CH, end - e1) : 0u, p.zrow, c.t, src_n);
-        double v[CH];
-        gather_turn<GW>(c.T, src, c.t, c.gbase, v);
+            for (int r = 0; r < CH / GW; r++) src[r] = src_n[r];
+            const bool last = i + 1 == turns;                 // scalar
+            const uint32_t e1 = (last ? nxt.beg : cur.beg + (i + 1) * TW) + (uint32_t)c.slot * CH;
+            const uint32_t lim = last ? (more ? nxt.end : 0u) : cur.end;
+            idx_turn<GW>(p.in_src, e1, turn_fill(e1, lim), p.zrow, c.t, src_n);
+            double v[CH];
+            gather_turn<GW>(c.T, src, c.t, c.gbase, v);
+#ifdef SS_PR_DEBUG
+            {
+                double sv = 0.0;
+                for (int j = 0; j < CH; j++) sv += v[j];
+                if (c.t == 0 && cur.row == 2 && p.ctl->sweep == 0) printf("[turn] i %u slot %d src %u e1 %u lim %u sv %.6e srcn %u zrow %u nn %u\n", i, c.slot, src[0], e1, lim, sv, src_n[0], p.zrow, turn_fill(e1, lim));
+            }
+#endif
 #pragma unroll
-        for (int j = 0; j < CH; j++) acc += v[j];
+            for (int j = 0; j < CH; j++) acc += v[j];
+        }
+        const double y = wave_sum_topic<GW>(acc);
+#ifdef SS_PR_DEBUG
+        if (lane == 0) printf("[long] wave %u it %u/%u-%u kind %u row %u beg %u end %u turns %u y %.6e xo %.6e od %u\n", blockIdx.x * WAVES + (threadIdx.x >> 6), it, i0, i1,
+                              cur.kind, cur.row, cur.beg, cur.end, turns, y, xo, od);
+#endif
+        if (cur.kind == V_ROWW) {
+            if (lane < GW) finish_row<GW>(c, lrow, y, xo, od);
+        } else {
+            // several waves (of any blocks) share this row: publish the piece's sum; the last to arrive adds the
+            // pieces in order and finishes the row
+            // (write-through stores, drained, then the ticket; the last arriver reads with sc1 loads: no fences — see
+            // block_reduce_and_publish)
+            if (lane < GW) __hip_atomic_store(&p.segpart[(size_t)(cur.sbase + cur.count) * GW + c.t], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(&p.rowticket[cur.tix], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+            if (prev == cur.nseg - 1) {
+                if (lane == 0) __hip_atomic_store(&p.rowticket[cur.tix], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < GW) {
+                    double ys = 0.0;
+                    for (uint32_t q = 0; q < cur.nseg; q++)
+                        ys += __hip_atomic_load(&p.segpart[(size_t)(cur.sbase + q) * GW + c.t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    finish_row<GW>(c, lrow, ys, xo, od);
+                }
+            }
+        }
+        cur = nxt;
+        nxt = nn;
     }
-    return wave_sum_topic<GW>(acc);
 }
 
-// V_QUAD: rows row0 .. row0+count-1, lane group s takes rows row0 + q*NS + s (q = 0 .. nq-1, nq <= GW), every row is
-// walked in nch turns (its own length decides how many slots of a turn are real)
+// V_QUAD: an item = rows row .. row+count-1, lane group s takes rows row + q*NS + s (q = 0 .. nq-1, nq <= GW), every row
+// is walked in nch (= item.nseg) turns (its own length decides how many slots of a turn are real).  The bounds and
+// out-degrees of ALL rows of an item come in one request (lane t of group s holds row `row + t*NS + s`), one item ahead;
+// the pipeline runs across row groups and items.
 template <int GW>
-__device__ __forceinline__ void quad_rows(SweepCtx<GW>& c, uint32_t row0, uint32_t count, uint32_t nch) {
+__device__ __forceinline__ void quad_rows(SweepCtx<GW>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1) {
     constexpr int NS = 64 / GW;
     const PrParams& p = c.p;
-    const uint32_t nq = (count + NS - 1) / NS;
-    // the bounds and out-degrees of ALL the item's rows in one request: lane t of group s holds row row0 + t*NS + s
+    if (i0 >= i1) return;
     const uint32_t myq = (uint32_t)c.t * NS + (uint32_t)c.slot;
-    const bool have = myq < count;
-    const uint32_t rq = row0 + (have ? myq : 0u);
-    const uint32_t begv = p.in_ptr[rq], endv = have ? p.in_ptr[rq + 1] : begv;
-    const uint32_t odv = rq < p.sl_nd ? NT_LOAD(&p.outdeg[rq]) : 1u;
-    const uint32_t turns = nq * nch;
-    uint32_t q = 0, ch = 0;                                   // scalar: row group and turn inside it
+    auto bounds = [&](const WorkItem& w, bool live, uint32_t& bv, uint32_t& ev, uint32_t& ov) __attribute__((always_inline)) {
+        const bool have = live && myq < w.count;
+        const uint32_t rq = live ? w.row + (have ? myq : 0u) : 0u;
+        const uint32_t b = p.in_ptr[rq], e = p.in_ptr[rq + 1];
+        bv = b;
+        ev = have ? e : b;
+        ov = rq < p.sl_nd ? NT_LOAD(&p.outdeg[rq]) : 1u;
+    };
+    WorkItem cur = work[i0], nxt = work[i0 + 1];
+    uint32_t cb, ce, co, nb, ne, no;
+    bounds(cur, true, cb, ce, co);
+    bounds(nxt, i0 + 1 < i1, nb, ne, no);
+    uint32_t it = i0, q = 0, ch = 0;                          // scalar: item, row group and turn inside it
+    uint32_t nq = (cur.count + NS - 1) / NS, nch = cur.nseg;
     uint32_t src_n[CH / GW];
-    uint32_t b_cur = (uint32_t)__shfl((int)begv, c.gbase, 64), e_cur = (uint32_t)__shfl((int)endv, c.gbase, 64);
-    idx_turn<GW>(p.in_src, b_cur, min((uint32_t)CH, e_cur - b_cur), p.zrow, c.t, src_n);
+    {
+        const uint32_t b0 = (uint32_t)__shfl((int)cb, c.gbase, 64), e0 = (uint32_t)__shfl((int)ce, c.gbase, 64);
+        idx_turn<GW>(p.in_src, b0, turn_fill(b0, e0), p.zrow, c.t, src_n);
+    }
     double acc = 0.0;
-    for (uint32_t i = 0; i < turns; i++) {
+    while (it < i1) {
         uint32_t src[CH / GW];
 #pragma unroll
         for (int r = 0; r < CH / GW; r++) src[r] = src_n[r];
-        // next turn: same row group or the next one
+        // the turn after this one: same row group, the next one, or the first of the next item
         uint32_t qn = q, cn = ch + 1;
-        if (cn == nch) { cn = 0; qn = q + 1; }
-        uint32_t b_n = b_cur, e_n = e_cur;
-        if (cn == 0 && qn < nq) {
-            b_n = (uint32_t)__shfl((int)begv, c.gbase + (int)qn, 64);
-            e_n = (uint32_t)__shfl((int)endv, c.gbase + (int)qn, 64);
+        bool cross = false;
+        if (cn == nch) {
+            cn = 0;
+            qn = q + 1;
+            if (qn == nq) { qn = 0; cross = true; }
         }
+        const bool live_n = !cross || it + 1 < i1;
         {
+            const uint32_t b_n = (uint32_t)__shfl((int)(cross ? nb : cb), c.gbase + (int)qn, 64);
+            const uint32_t e_n = (uint32_t)__shfl((int)(cross ? ne : ce), c.gbase + (int)qn, 64);
             const uint32_t ep = b_n + cn * CH;
-            idx_turn<GW>(p.in_src, ep, (qn < nq && ep < e_n) ? min((uint32_t)CH, e_n - ep) : 0u, p.zrow, c.t, src_n);
+            idx_turn<GW>(p.in_src, ep, live_n ? turn_fill(ep, e_n) : 0u, p.zrow, c.t, src_n);
         }
         const bool ends = ch + 1 == nch;                      // scalar: this turn completes the rows of group q
-        const uint32_t lrow = row0 + q * NS + (uint32_t)c.slot;
-        const bool valid = q * NS + (uint32_t)c.slot < count;
+        const uint32_t lrow = cur.row + q * NS + (uint32_t)c.slot;
+        const bool valid = q * NS + (uint32_t)c.slot < cur.count;
         double xo = 0.0;
-        if (ends) xo = NT_LOAD(&p.x[(size_t)(valid ? lrow : row0) * GW + c.t]);
+        if (ends) xo = NT_LOAD(&p.x[(size_t)(valid ? lrow : cur.row) * GW + c.t]);
         double v[CH];
         gather_turn<GW>(c.T, src, c.t, c.gbase, v);
 #pragma unroll
         for (int j = 0; j < CH; j++) acc += v[j];
         if (ends) {
-            const uint32_t od = (uint32_t)__shfl((int)odv, c.gbase + (int)q, 64);
+            const uint32_t od = (uint32_t)__shfl((int)co, c.gbase + (int)q, 64);
             if (valid) finish_row<GW>(c, lrow, acc, xo, od);
             acc = 0.0;
         }
-        q = qn; ch = cn; b_cur = b_n; e_cur = e_n;
+        q = qn;
+        ch = cn;
+        if (cross) {
+            it++;
+            cur = nxt;
+            cb = nb; ce = ne; co = no;
+            nq = (cur.count + NS - 1) / NS;
+            nch = cur.nseg;
+            nxt = work[it + 1];
+            bounds(nxt, it + 1 < i1, nb, ne, no);
+        }
     }
 }
 
-// V_DEG: `count` rows of exactly D in-edges from row0 (their edges are contiguous from in_ptr[row0]); a lane group
-// takes R rows per turn, row r of the turn at slots r*DM .. r*DM+D-1 (DM = 16/R >= D)
+// V_DEG: an item = `count` rows of exactly D (= item.nseg) in-edges from `row` (their edges are contiguous from item.beg);
+// a lane group takes R rows per turn, row r of the turn at slots r*DM .. r*DM+D-1 (DM = 16/R >= D)
 template <int GW, int R>
-__device__ __forceinline__ void deg_rows(SweepCtx<GW>& c, uint32_t row0, uint32_t count, uint32_t D) {
+__device__ __forceinline__ void deg_rows(SweepCtx<GW>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1) {
     constexpr int NS = 64 / GW;
     constexpr int DM = CH / R;
     constexpr int IR = CH / GW;
     const PrParams& p = c.p;
-    const uint32_t ebase = p.in_ptr[row0];
-    const uint32_t turns = (count + NS * R - 1) / (NS * R);
-    auto idx = [&](uint32_t turn, uint32_t (&src)[IR]) __attribute__((always_inline)) {
+    if (i0 >= i1) return;
+    auto idx = [&](const WorkItem& w, bool live, uint32_t turn, uint32_t (&src)[IR]) __attribute__((always_inline)) {
         const uint32_t rb = (turn * NS + (uint32_t)c.slot) * R;           // first row (relative) of this lane group's turn
 #pragma unroll
         for (int r = 0; r < IR; r++) {
             const uint32_t j = (uint32_t)(r * GW + c.t);
             const uint32_t rr = rb + j / DM, u = j % DM;
-            const bool ok = u < D && rr < count;
-            const uint32_t raw = NT_LOAD(&p.in_src[ok ? ebase + rr * D + u : 0u]);
+            const bool ok = live && u < w.nseg && rr < w.count;
+            const uint32_t raw = NT_LOAD(&p.in_src[ok ? w.beg + rr * w.nseg + u : 0u]);
             src[r] = ok ? (raw & SRC_MASK) : p.zrow;
         }
     };
+    WorkItem cur = work[i0], nxt = work[i0 + 1];
     uint32_t src_n[IR];
-    idx(0, src_n);
-    for (uint32_t i = 0; i < turns; i++) {
-        uint32_t src[IR];
+    idx(cur, true, 0, src_n);
+    for (uint32_t it = i0; it < i1; it++) {
+        const WorkItem nn = work[it + 2];
+        const uint32_t row0 = cur.row, count = cur.count;
+        const uint32_t turns = (count + NS * R - 1) / (NS * R);
+        for (uint32_t i = 0; i < turns; i++) {
+            uint32_t src[IR];
 #pragma unroll
-        for (int r = 0; r < IR; r++) src[r] = src_n[r];
-        idx(i + 1 < turns ? i + 1 : i, src_n);
-        const uint32_t rb = (i * NS + (uint32_t)c.slot) * R;
-        // old ranks and out-degrees of the R rows travel with the gathers
-        double xo[R];
+            for (int r = 0; r < IR; r++) src[r] = src_n[r];
+            if (i + 1 < turns) idx(cur, true, i + 1, src_n);
+            else idx(nxt, it + 1 < i1, 0, src_n);
+            const uint32_t rb = (i * NS + (uint32_t)c.slot) * R;
+            // old ranks and out-degrees of the R rows travel with the gathers
+            double xo[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) xo[r] = NT_LOAD(&p.x[(size_t)(row0 + (rb + r < count ? rb + r : 0u)) * GW + c.t]);
-        const uint32_t myr = row0 + (rb + (uint32_t)c.t < count ? rb + (uint32_t)c.t : 0u);
-        const uint32_t odv = (c.t < R && myr < p.sl_nd) ? NT_LOAD(&p.outdeg[myr]) : 1u;
-        double v[CH];
-        gather_turn<GW>(c.T, src, c.t, c.gbase, v);
+            for (int r = 0; r < R; r++) xo[r] = NT_LOAD(&p.x[(size_t)(row0 + (rb + r < count ? rb + r : 0u)) * GW + c.t]);
+            const uint32_t myr = row0 + (rb + (uint32_t)c.t < count ? rb + (uint32_t)c.t : 0u);
+            const uint32_t odv = (c.t < R && myr < p.sl_nd) ? NT_LOAD(&p.outdeg[myr]) : 1u;
+            double v[CH];
+            gather_turn<GW>(c.T, src, c.t, c.gbase, v);
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            double y = 0.0;
+            for (int r = 0; r < R; r++) {
+                double y = 0.0;
 #pragma unroll
-            for (int u = 0; u < DM; u++) y += v[r * DM + u];
-            const uint32_t od = (uint32_t)__shfl((int)odv, c.gbase + r, 64);
-            if (rb + r < count) finish_row<GW>(c, row0 + rb + r, y, xo[r], od);
+                for (int u = 0; u < DM; u++) y += v[r * DM + u];
+                const uint32_t od = (uint32_t)__shfl((int)odv, c.gbase + r, 64);
+                if (rb + r < count) finish_row<GW>(c, row0 + rb + r, y, xo[r], od);
+            }
         }
+        cur = nxt;
+        nxt = nn;
     }
 }
 
+#ifndef SS_PR_MINW
+#define SS_PR_MINW 1
+#endif
 template <int GW>
-__global__ __launch_bounds__(TPB) void k_pr_sweep(PrParams p) {
+__global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     constexpr int NS = 64 / GW;
     PrCtl* ctl = p.ctl;
     if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
@@ -802,76 +913,46 @@ __global__ __launch_bounds__(TPB) void k_pr_sweep(PrParams p) {
     c.act = ctl->active[c.t] != 0;
     c.x0 = sweep == 0 ? p.x0[c.t] : 0.0;      // Q4: iteration 1 accumulates onto 1/n
 
-    const uint32_t nw = gridDim.x * WAVES;
-    for (uint32_t item = blockIdx.x * WAVES + wave; item < p.n_items; item += nw) {
-        const WorkItem w = p.work[item];
-#ifdef SS_PR_EXP_KINDMASK
-        if (!((p.kind_mask >> (w.kind & 31)) & 1u)) continue;
+    // This wave's items: work[off[k] .. off[k+1]) for class k.  The host dealt the items to the waves so that every wave
+    // gets the same number of turns (ss_pr_create); one loop per class, so that the register allocator sees each
+    // pipeline on its own instead of the union of all of them.
+    const uint32_t* __restrict__ off = p.woff + (size_t)(blockIdx.x * WAVES + wave) * 8;
+#ifndef SS_PR_ONLY
+#define SS_PR_ONLY 63
 #endif
-        if (w.kind == V_ROWW || w.kind == V_SEG) {
-            const uint32_t lrow = w.row;
-            const uint32_t rbeg = p.in_ptr[lrow], rend = p.in_ptr[lrow + 1];
-            const bool whole = w.kind == V_ROWW;
-            const uint32_t beg = whole ? rbeg : rbeg + w.count * SEGW;
-            const uint32_t end = whole ? rend : min(rend, beg + SEGW);
-            double y = stream_row<GW>(c, beg, end);
-            if (whole) {
-                if (lane < GW) {
-                    const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + c.t]);
-                    const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
-                    finish_row<GW>(c, lrow, y, xo, od);
-                }
-            } else {
-                // several waves (of any blocks) share this row: publish the piece's sum; the last to arrive adds the
-                // pieces in order and finishes the row
-                if (lane < GW) p.segpart[(size_t)(w.sbase + w.count) * GW + c.t] = y;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                unsigned prev = 0;
-                if (lane == 0) prev = __hip_atomic_fetch_add(&p.rowticket[w.tix], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
-                if (prev == w.nseg - 1) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) p.rowticket[w.tix] = 0;
-                    if (lane < GW) {
-                        double ys = 0.0;
-                        for (uint32_t q = 0; q < w.nseg; q++) ys += p.segpart[(size_t)(w.sbase + q) * GW + c.t];
-                        const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + c.t]);
-                        const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
-                        finish_row<GW>(c, lrow, ys, xo, od);
-                    }
-                }
-            }
-        } else if (w.kind == V_QUAD) {
-            quad_rows<GW>(c, w.row, w.count, w.nseg);
-        } else if (w.kind == V_DEG) {
-            if (w.nseg <= 2) deg_rows<GW, 8>(c, w.row, w.count, w.nseg);
-            else if (w.nseg <= 4) deg_rows<GW, 4>(c, w.row, w.count, w.nseg);
-            else deg_rows<GW, 2>(c, w.row, w.count, w.nseg);
-        } else {
-            // V_ZERO: non-dangling rows without in-edges: their rank is the shared value xz, only the next contribution
-            // d*xz/outdeg has to be written (dangling ones need nothing at all); 64*16/GW rows per item at most
-            const bool ts = p.memb && ((p.ts_mask >> c.t) & 1u);
-            const double xz_out = c.act ? (ts ? zero_row_rank_ts(p, sweep, c.S, p.x0[c.t], 0.0) : zero_row_rank(p, sweep, c.S, p.x0[c.t])) : ctl->xz[c.t];
-            const double xz_inn = ts ? (c.act ? zero_row_rank_ts(p, sweep, c.S, p.x0[c.t], p.tin[c.t]) : ctl->xz_in[c.t]) : xz_out;
-            uint32_t od[16];
+#ifdef SS_PR_EXP_KINDMASK
+#define SS_PR_CLASS_ON(c) ((p.kind_mask >> (8 + (c))) & 1u)
+#else
+#define SS_PR_CLASS_ON(c) true
+#endif
+    if ((SS_PR_ONLY & 1) && SS_PR_CLASS_ON(0)) long_rows<GW>(c, p.work, off[0], off[1], lane);
+    if ((SS_PR_ONLY & 2) && SS_PR_CLASS_ON(1)) quad_rows<GW>(c, p.work, off[1], off[2]);
+    if ((SS_PR_ONLY & 4) && SS_PR_CLASS_ON(2)) deg_rows<GW, 2>(c, p.work, off[2], off[3]);
+    if ((SS_PR_ONLY & 8) && SS_PR_CLASS_ON(3)) deg_rows<GW, 4>(c, p.work, off[3], off[4]);
+    if ((SS_PR_ONLY & 16) && SS_PR_CLASS_ON(4)) deg_rows<GW, 8>(c, p.work, off[4], off[5]);
+    if ((SS_PR_ONLY & 32) && SS_PR_CLASS_ON(5))
+    for (uint32_t item = off[5]; item < off[6]; item++) {
+        const WorkItem w = p.work[item];
+        // V_ZERO: non-dangling rows without in-edges: their rank is the shared value xz, only the next contribution
+        // d*xz/outdeg has to be written (dangling ones need nothing at all); 16 rows per lane group and item at most
+        const bool ts = p.memb && ((p.ts_mask >> c.t) & 1u);
+        const double xz_out = c.act ? (ts ? zero_row_rank_ts(p, sweep, c.S, p.x0[c.t], 0.0) : zero_row_rank(p, sweep, c.S, p.x0[c.t])) : ctl->xz[c.t];
+        const double xz_inn = ts ? (c.act ? zero_row_rank_ts(p, sweep, c.S, p.x0[c.t], p.tin[c.t]) : ctl->xz_in[c.t]) : xz_out;
+        uint32_t od[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t rr = (uint32_t)(i * NS + c.slot);
-                od[i] = NT_LOAD(&p.outdeg[w.row + (rr < w.count ? rr : 0u)]);
-            }
+        for (int i = 0; i < 16; i++) {
+            const uint32_t rr = (uint32_t)(i * NS + c.slot);
+            od[i] = NT_LOAD(&p.outdeg[w.row + (rr < w.count ? rr : 0u)]);
+        }
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t rr = (uint32_t)(i * NS + c.slot);
-                if (rr < w.count) {
-                    const uint32_t lrow = w.row + rr;
-                    const double xz = ts && ((p.memb[lrow] >> c.t) & 1u) ? xz_inn : xz_out;
-                    const double cc = p.d * xz / (double)od[i];                      // pagerank.go:136
-                    NT_STORE(cc, &c.Tw[(size_t)lrow * GW + c.t]);
-                    c.csum += cc;                                                     // pagerank.go:137
-                }
+        for (int i = 0; i < 16; i++) {
+            const uint32_t rr = (uint32_t)(i * NS + c.slot);
+            if (rr < w.count) {
+                const uint32_t lrow = w.row + rr;
+                const double xz = ts && ((p.memb[lrow] >> c.t) & 1u) ? xz_inn : xz_out;
+                const double cc = p.d * xz / (double)od[i];                      // pagerank.go:136
+                NT_STORE(cc, &c.Tw[(size_t)lrow * GW + c.t]);
+                c.csum += cc;                                                     // pagerank.go:137
             }
         }
     }
@@ -975,9 +1056,11 @@ __global__ void k_pr_memb_zero_count(const uint32_t* __restrict__ memb, uint32_t
 // write, no contribution write, no reductions.  mode 0 = the real index stream, 1 = indices hashed to uniformly
 // random rows (no hub reuse), 2 = consecutive rows (a streamed table).  Each lane group keeps one running sum and
 // stores it once, so the loads cannot be dropped.
-template <int GW>
+// POL (experiments with the cache policy of the gathers): 0 default, 1 all non-temporal, 2 all sc1 (agent-scope atomic
+// load), 3 rows below `hot` default / others non-temporal, 4 rows below `hot` default / others sc1
+template <int GW, int POL>
 __global__ __launch_bounds__(TPB) void k_pr_probe(const double* __restrict__ T, const uint32_t* __restrict__ in_src, size_t n_edges,
-                                                  uint32_t n_rows, int mode, double* __restrict__ sink) {
+                                                  uint32_t n_rows, int mode, double* __restrict__ sink, uint32_t hot) {
     if constexpr (GW >= 8) {
         constexpr int NSLOT = 64 / GW;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1005,7 +1088,12 @@ __global__ __launch_bounds__(TPB) void k_pr_probe(const double* __restrict__ T, 
 #pragma unroll
             for (int j = 0; j < CH; j++) {
                 const uint32_t sj = (uint32_t)__shfl((int)src[j / GW], gbase + (j % GW), 64);
-                v[j] = T[(size_t)sj * GW + t];
+                const double* a = &T[(size_t)sj * GW + t];
+                if constexpr (POL == 0) v[j] = *a;
+                else if constexpr (POL == 1) v[j] = __builtin_nontemporal_load(a);
+                else if constexpr (POL == 2) v[j] = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if constexpr (POL == 3) v[j] = sj < hot ? *a : __builtin_nontemporal_load(a);
+                else v[j] = sj < hot ? *a : __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
             for (int j = 0; j < CH; j++) acc += v[j];
@@ -1029,6 +1117,7 @@ struct ss_pr {
     ss::DevBuf<uint32_t> memb;          // topic-sensitive teleport (optional)
     ss::DevBuf<double> tin, nz_in;
     ss::DevBuf<WorkItem> work;
+    ss::DevBuf<uint32_t> woff;          // k_pr_sweep: per-wave class offsets into work
     ss::DevBuf<PrCtl> ctl;
     bool begun = false;
     bool need_finalize = false;   // world>1: a begin/step is waiting for its exchange + finalize
@@ -1044,7 +1133,7 @@ int pick_gw(int k) {
 }
 
 void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
-                uint32_t& seg_edges, uint32_t& pos_nd, uint32_t& pos_d) {
+                uint32_t& seg_edges, uint32_t& pos_nd, uint32_t& pos_d, uint32_t (&vbeg)[7]) {
     const uint32_t NSLOT = 64 / gw;
     // gw >= 8: rows above T_SEG in-edges get block(s) of their own, everything else is walked in
     // 16-edge chunks by lane groups (W_ROWS).  gw < 8: wave-per-row / group-per-row classes.
@@ -1056,7 +1145,7 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     std::vector<WorkItem> seg, rwg, wav, grp, zer;
 
     // gw >= 8: wave-owned items of k_pr_sweep.  deg is sorted descending.
-    std::vector<WorkItem> vseg, vroww, vquad, vdeg, vzero;
+    std::vector<WorkItem> vseg, vroww, vquad, vdeg[3], vzero;
     auto emit_v = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
         const uint32_t T_MULTI = 4096, T_QUAD = 512, T_DEG = 8;
@@ -1085,7 +1174,7 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
             while (r + run < cnt && deg[r + run] == D) run++;
             const uint32_t R = D <= 2 ? 8 : D <= 4 ? 4 : 2;
             const uint32_t per_item = NSLOT * R * 16;                 // 16 turns
-            for (uint32_t o = 0; o < run; o += per_item) vdeg.push_back({V_DEG, row0 + r + o, std::min(per_item, run - o), D, 0, 0});
+            for (uint32_t o = 0; o < run; o += per_item) vdeg[R == 2 ? 0 : R == 4 ? 1 : 2].push_back({V_DEG, row0 + r + o, std::min(per_item, run - o), D, 0, 0});
             r += run;
         }
         n_pos = r;
@@ -1132,11 +1221,20 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     items.insert(items.end(), grp.begin(), grp.end());
     items.insert(items.end(), zer.begin(), zer.end());
     // k_pr_sweep: longest first (pieces of the hubs, whole long rows, then the row groups by falling length)
+    vbeg[0] = (uint32_t)items.size();
     items.insert(items.end(), vseg.begin(), vseg.end());
     items.insert(items.end(), vroww.begin(), vroww.end());
+    vbeg[1] = (uint32_t)items.size();
+    // row groups by falling length (the dangling class was appended after the non-dangling one)
+    std::stable_sort(vquad.begin(), vquad.end(), [](const WorkItem& a, const WorkItem& b) { return a.nseg > b.nseg; });
     items.insert(items.end(), vquad.begin(), vquad.end());
-    items.insert(items.end(), vdeg.begin(), vdeg.end());
+    for (int k = 0; k < 3; k++) {
+        vbeg[2 + k] = (uint32_t)items.size();
+        items.insert(items.end(), vdeg[k].begin(), vdeg[k].end());
+    }
+    vbeg[5] = (uint32_t)items.size();
     items.insert(items.end(), vzero.begin(), vzero.end());
+    vbeg[6] = (uint32_t)items.size();
 }
 
 template <int GW>
@@ -1205,7 +1303,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
 
     std::vector<WorkItem> items;
     uint32_t nsegs = 0, nmulti = 0, seg_edges = 0, pos_nd = 0, pos_d = 0;
-    build_work(g, GW, items, nsegs, nmulti, seg_edges, pos_nd, pos_d);
+    uint32_t vbeg[7] = {0};
+    build_work(g, GW, items, nsegs, nmulti, seg_edges, pos_nd, pos_d, vbeg);
     if (items.empty()) items.push_back({W_ZERO, 0, 0, 0, 0, 0});
     // persistent grid, each block (gw < 8) or wave (gw >= 8) walks the work table round-robin: gw < 8: 8 blocks per CU at
     // most; gw >= 8: exactly the waves the chip holds at once
@@ -1215,6 +1314,72 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     if (const char* e = getenv("SS_PR_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
     pr->nblocks = GW >= 8 ? (unsigned)std::min<size_t>(ss::div_up(items.size(), (size_t)WAVES), (size_t)ctx->cu_count * per_cu)
                           : (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
+    std::vector<uint32_t> woff;
+    if (GW >= 8) {
+        // k_pr_sweep: the items' edge ranges, then the items dealt to the grid's waves
+        std::vector<uint32_t> h_in_ptr(n_local + 1, 0);
+        if (n_local) {
+            SS_HIP(ctx, hipMemcpyAsync(h_in_ptr.data(), g->in_ptr.p, (n_local + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            SS_HIP(ctx, hipStreamSynchronize(st));
+        }
+        const uint32_t NS = 64 / GW;
+        std::vector<double> cost(items.size());
+        for (size_t i = 0; i < items.size(); i++) {
+            WorkItem& w = items[i];
+            double turns = 1.0;
+            switch (w.kind) {
+                case V_ROWW: w.beg = h_in_ptr[w.row]; w.end = h_in_ptr[w.row + 1]; turns = ss::div_up(w.end - w.beg, NS * CH); break;
+                case V_SEG:
+                    w.beg = h_in_ptr[w.row] + w.count * SEGW;
+                    w.end = std::min(h_in_ptr[w.row + 1], w.beg + SEGW);
+                    turns = ss::div_up(w.end - w.beg, NS * CH) + 2.0;
+                    break;
+                case V_QUAD: w.beg = h_in_ptr[w.row]; w.end = h_in_ptr[w.row + w.count]; turns = (double)ss::div_up(w.count, NS) * w.nseg; break;
+                case V_DEG: {
+                    w.beg = h_in_ptr[w.row]; w.end = h_in_ptr[w.row + w.count];
+                    const uint32_t R = w.nseg <= 2 ? 8 : w.nseg <= 4 ? 4 : 2;
+                    turns = (double)ss::div_up(w.count, NS * R) * (R == 8 ? 2.5 : R == 4 ? 1.7 : 1.3);   // a turn finishes R rows per lane group
+                    break;
+                }
+                default: turns = 0.5; break;
+            }
+            cost[i] = turns + 1.0;                                   // + the item's own overhead
+        }
+        // Longest-processing-time deal: items in table order (classes by falling item length), each to the wave with the
+        // least work so far — every wave ends up with the same number of turns (+- one item), whatever the degree mix.
+        const uint32_t nw = pr->nblocks * WAVES;
+        std::vector<std::vector<uint32_t>> mine(nw);
+        {
+            using Load = std::pair<double, uint32_t>;
+            std::priority_queue<Load, std::vector<Load>, std::greater<Load>> pq;
+            for (uint32_t w = 0; w < nw; w++) pq.push({0.0, w});
+            for (size_t i = 0; i < items.size(); i++) {
+                Load l = pq.top();
+                pq.pop();
+                mine[l.second].push_back((uint32_t)i);
+                l.first += cost[i];
+                pq.push(l);
+            }
+        }
+        auto cls = [&](size_t i) { int k = 0; while (k < 5 && i >= vbeg[k + 1]) k++; return k; };
+        std::vector<WorkItem> dealt;
+        dealt.reserve(items.size() + 2);
+        woff.assign((size_t)nw * 8, 0);
+        for (uint32_t w = 0; w < nw; w++) {
+            // table order inside a wave's list = class order
+            int k = 0;
+            woff[(size_t)w * 8] = (uint32_t)dealt.size();
+            for (uint32_t i : mine[w]) {
+                const int ki = cls(i);
+                while (k < ki) woff[(size_t)w * 8 + ++k] = (uint32_t)dealt.size();
+                dealt.push_back(items[i]);
+            }
+            while (k < 7) woff[(size_t)w * 8 + ++k] = (uint32_t)dealt.size();
+        }
+        dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});              // the pipelines read two items ahead
+        dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});
+        items.swap(dealt);
+    }
 
     if (((uint64_t)g->nd_int + 1) * GW * 8 >= (1ull << 32))
         return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_create: contribution table of %llu rows x %d topics exceeds 4 GiB (shard the graph over more ranks)",
@@ -1235,6 +1400,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     SS_HIP(ctx, pr->segpart.alloc((size_t)std::max(nsegs, 1u) * GW));
     SS_HIP(ctx, pr->rowticket.alloc(std::max(nmulti, 1u)));
     SS_HIP(ctx, hipMemsetAsync(pr->rowticket.p, 0, pr->rowticket.bytes(), st));
+    SS_HIP(ctx, pr->woff.alloc(std::max<size_t>(woff.size(), 8)));
+    if (!woff.empty()) SS_HIP(ctx, hipMemcpyAsync(pr->woff.p, woff.data(), woff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     SS_HIP(ctx, pr->work.alloc(items.size()));
     SS_HIP(ctx, hipMemcpyAsync(pr->work.p, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
     SS_HIP(ctx, pr->ctl.alloc(1));
@@ -1280,6 +1447,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     p.pos_nd = pos_nd;
     p.pos_d = pos_d;
     p.zrow = (uint32_t)g->nd_int;
+    p.woff = pr->woff.p;
 #ifdef SS_PR_EXP_KINDMASK
     p.kind_mask = getenv("SS_PR_KIND_MASK") ? (uint32_t)strtoul(getenv("SS_PR_KIND_MASK"), nullptr, 0) : 0xFFFFFFFFu;
     {
@@ -1553,7 +1721,10 @@ int32_t ss_pr_probe(ss_pr* pr, int32_t mode, int32_t n_reps, float* ms_out) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SS_HIP(ctx, hipSetDevice(ctx->device));
     if (pr->gw < 8) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_probe: the probe mirrors the chunked gather of the K >= 5 kernels");
-    if (mode < 0 || mode > 2 || n_reps < 1) return ctx->fail(SS_ERR_INVALID, "ss_pr_probe: mode 0..2, n_reps >= 1");
+    if (mode < 0 || (mode & 7) > 2 || (mode >> 3) > 4 || n_reps < 1) return ctx->fail(SS_ERR_INVALID, "ss_pr_probe: mode 0..2 (+ 8 * gather cache policy 0..4), n_reps >= 1");
+    const int pol = mode >> 3;
+    mode &= 7;
+    const uint32_t hot = getenv("SS_PR_PROBE_HOT") ? (uint32_t)strtoul(getenv("SS_PR_PROBE_HOT"), nullptr, 0) : 24576u;
     const ss_graph* g = pr->g;
     const unsigned nb = (unsigned)ctx->cu_count * 8;
     ss::DevBuf<double> sink;
@@ -1565,8 +1736,15 @@ int32_t ss_pr_probe(ss_pr* pr, int32_t mode, int32_t n_reps, float* ms_out) {
     const double* T = pr->tab0.p;
     for (int r = 0; r < n_reps + 1; r++) {
         if (r == 1) SS_HIP(ctx, hipEventRecord(e0, st));          // first launch = warm-up
-        if (pr->gw == 8) hipLaunchKernelGGL(k_pr_probe<8>, dim3(nb), dim3(TPB), 0, st, T, (const uint32_t*)g->in_src.p, (size_t)g->e_local, (uint32_t)g->nd_int, mode, sink.p);
-        else hipLaunchKernelGGL(k_pr_probe<16>, dim3(nb), dim3(TPB), 0, st, T, (const uint32_t*)g->in_src.p, (size_t)g->e_local, (uint32_t)g->nd_int, mode, sink.p);
+#define SS_PROBE_LAUNCH(GWV, POLV) hipLaunchKernelGGL((k_pr_probe<GWV, POLV>), dim3(nb), dim3(TPB), 0, st, T, (const uint32_t*)g->in_src.p, (size_t)g->e_local, (uint32_t)g->nd_int, mode, sink.p, hot)
+        if (pr->gw == 8) SS_PROBE_LAUNCH(8, 0);
+        else switch (pol) {
+            case 0: SS_PROBE_LAUNCH(16, 0); break;
+            case 1: SS_PROBE_LAUNCH(16, 1); break;
+            case 2: SS_PROBE_LAUNCH(16, 2); break;
+            case 3: SS_PROBE_LAUNCH(16, 3); break;
+            default: SS_PROBE_LAUNCH(16, 4); break;
+        }
     }
     SS_HIP(ctx, hipEventRecord(e1, st));
     SS_HIP(ctx, hipEventSynchronize(e1));
