@@ -51,7 +51,7 @@ struct PrCtl {
     uint32_t pad;
 };
 
-enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3, W_ROWS = 4, W_ROWG = 5,
+enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3,   // GW < 8 (k_pr_step): block-owned items
                   // GW >= 8 (k_pr_sweep): every item belongs to ONE wave
                   V_SEG = 8,     // a <= SEGW-edge piece of a row with more than T_MULTI in-edges (partials + ticket)
                   V_ROWW = 9,    // a whole row, T_QUAD < in-edges <= T_MULTI
@@ -304,85 +304,14 @@ __device__ __forceinline__ double gather_sum(const double* __restrict__ T, const
     return (a0 + a1) + (a2 + a3);
 }
 
-// One lane group (GW lanes = GW topics of one node) takes CH=16 consecutive in-edges: the group's lanes
-// load the 16 indices between them (GW=16: ONE coalesced 64-byte load), then 16 independent gathers are
-// in flight per group, each one table row (128 bytes at GW=16).  Used for GW >= 8; narrower groups keep
-// the wave-per-row / group-per-row classes (measured faster there: 0.71 vs 1.42 ms per sweep at K=1).
-// v[j] = T[src_j][t] for j < n, 0 otherwise; returns the group's 16 "last edge of row" flags.
-template <int GW>
-__device__ __forceinline__ uint32_t gather_chunk(const double* __restrict__ T, const uint32_t* __restrict__ in_src,
-                                                 size_t pos, uint32_t n, int lane, double (&v)[CH]) {
-    constexpr int R = CH / GW;                 // indices per lane
-    const int t = lane % GW, gbase = lane - t;
-    uint32_t src[R];
-    uint32_t last = 0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint32_t j = (uint32_t)(r * GW + t);
-        const uint32_t raw = j < n ? NT_LOAD(&in_src[pos + j]) : 0u;
-        const unsigned long long flags = __ballot(raw >> 31);
-        last |= ((uint32_t)(flags >> gbase) & ((1u << GW) - 1u)) << (r * GW);
-        src[r] = raw & SRC_MASK;
-    }
-#pragma unroll
-    for (int j = 0; j < CH; j++) {
-        const uint32_t sj = (uint32_t)__shfl((int)src[j / GW], gbase + (j % GW), 64);
-        v[j] = (uint32_t)j < n ? tab_at<GW>(T, sj, t) : 0.0;
-    }
-    return last & 0xFFFFu;
-}
-
-// gather_chunk in two steps (W_ROWS puts other loads between them): the index words + row-end flags, then the gathers
-template <int GW>
-__device__ __forceinline__ uint32_t chunk_head(const uint32_t* __restrict__ in_src, size_t pos, uint32_t n, int lane, uint32_t (&src)[CH / GW]) {
-    constexpr int R = CH / GW;
-    const int t = lane % GW, gbase = lane - t;
-    uint32_t last = 0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint32_t j = (uint32_t)(r * GW + t);
-        const uint32_t raw = j < n ? NT_LOAD(&in_src[pos + j]) : 0u;
-        const unsigned long long flags = __ballot(raw >> 31);
-        last |= ((uint32_t)(flags >> gbase) & ((1u << GW) - 1u)) << (r * GW);
-        src[r] = raw & SRC_MASK;
-    }
-    return last & 0xFFFFu;
-}
-template <int GW>
-__device__ __forceinline__ void chunk_head_noflags(const uint32_t* __restrict__ in_src, size_t pos, uint32_t n, int lane, uint32_t (&src)[CH / GW]) {
-    constexpr int R = CH / GW;
-    const int t = lane % GW;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint32_t j = (uint32_t)(r * GW + t);
-        src[r] = (j < n ? NT_LOAD(&in_src[pos + j]) : 0u) & SRC_MASK;
-    }
-}
-template <int GW>
-__device__ __forceinline__ void chunk_tail(const double* __restrict__ T, const uint32_t (&src)[CH / GW], uint32_t n, int lane, double (&v)[CH]) {
-    const int t = lane % GW, gbase = lane - t;
-#pragma unroll
-    for (int j = 0; j < CH; j++) {
-        // edges past the chunk's end read row 0 (always there, always cached) and count as zero: sixteen unconditional
-        // loads instead of sixteen exec-mask branches
-        const uint32_t sj = (uint32_t)j < n ? (uint32_t)__shfl((int)src[j / GW], gbase + (j % GW), 64) : 0u;
-        const double x = tab_at<GW>(T, sj, t);
-        v[j] = (uint32_t)j < n ? x : 0.0;
-    }
-}
-
-// ---- the sweep ---------------------------------------------------------------
+// ---- the sweep, K <= 4 (GW = 1 / 2 / 4) ----------------------------------------
 // Persistent grid: a fixed number of blocks walks the work table round-robin, so the
-// per-launch costs (partials, release fence, ticket) are paid ~2k times, not per work item.
+// per-launch costs (partials, ticket) are paid ~2k times, not per work item.  (K >= 5: k_pr_sweep below.)
 template <int GW>
 __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     constexpr int NSLOT = 64 / GW;
     __shared__ double rowred[WAVES][MAXK];
     __shared__ int s_rowlast;
-#ifndef SS_PR_EXP_LDSX
-#define SS_PR_EXP_LDSX 1
-#endif
-    __shared__ double rowsum[GW >= 8 ? WAVES * CH * 64 * SS_PR_EXP_LDSX : 1];   // GW>=8: finished row sums of a chunk, [wave][k-th finished row][lane]
 
     PrCtl* ctl = p.ctl;
     if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
@@ -397,32 +326,23 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
 
     double dsum = 0.0, csum = 0.0;
 
-    // xo / od: the row's old rank and out-degree, already loaded by the caller (W_ROWS requests them together with the
-    // gathers of the chunk in which the row ends, so that the row's epilogue costs no second memory latency)
-    auto finish_with = [&](uint32_t lrow, double y, double xo, uint32_t od) __attribute__((always_inline)) {
+    auto finish = [&](uint32_t lrow, double y) __attribute__((always_inline)) {
+        const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + t]);
+        const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
         y += x0;
         const size_t xi = (size_t)lrow * GW + t;
         double xn = (y + teleport_of(p, lrow, t)) / S;  // pagerank.go:117
         if (act) {
-#ifndef SS_PR_EXP_NOSTORE_X
             NT_STORE(xn, &p.x[xi]);
-#endif
             dsum += fabs(xn - xo);                      // pagerank.go:118
         } else {
             xn = xo;                                    // converged topic: frozen
         }
         if (lrow < p.sl_nd) {                           // non-dangling row: next sweep's contribution
             const double c = p.d * xn / (double)od;     // pagerank.go:136
-#ifndef SS_PR_EXP_NOSTORE_T
             NT_STORE(c, &Tw[xi]);
-#endif
             csum += c;                                  // pagerank.go:137
         }
-    };
-    auto finish = [&](uint32_t lrow, double y) __attribute__((always_inline)) {
-        const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + t]);
-        const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
-        finish_with(lrow, y, xo, od);
     };
 
     for (uint32_t item = blockIdx.x; item < p.n_items; item += gridDim.x) {
@@ -436,20 +356,7 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
             const size_t rbeg = p.in_ptr[lrow], rend = p.in_ptr[lrow + 1];
             const size_t beg = rbeg + (size_t)w.count * p.seg_edges;
             const size_t end = min(rend, beg + (size_t)p.seg_edges);
-            double acc = 0.0;
-            if constexpr (GW >= 8) {
-                // the block's lane groups take 16-edge chunks round-robin
-                for (size_t pos = beg + (size_t)(wave * NSLOT + slot) * CH; pos < end; pos += (size_t)WAVES * NSLOT * CH) {
-                    double v[CH];
-                    gather_chunk<GW>(T, p.in_src, pos, (uint32_t)min((size_t)CH, end - pos), lane, v);
-                    double a = 0.0;
-#pragma unroll
-                    for (int j = 0; j < CH; j++) a += v[j];
-                    acc += a;
-                }
-            } else {
-                acc = gather_sum<GW>(T, p.in_src, beg, end, wave * NSLOT + slot, WAVES * NSLOT, t);
-            }
+            double acc = gather_sum<GW>(T, p.in_src, beg, end, wave * NSLOT + slot, WAVES * NSLOT, t);
             acc = wave_sum_topic<GW>(acc);
             __syncthreads();                            // rowred / s_rowlast reuse across items
             if (lane < GW) rowred[wave][t] = acc;
@@ -485,90 +392,6 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
                     double ys = 0.0;
                     for (uint32_t q = 0; q < w.nseg; q++) ys += p.segpart[(size_t)(w.sbase + q) * GW + t];
                     finish(lrow, ys);
-                }
-            }
-        } else if (w.kind == W_ROWS) {
-            if constexpr (GW >= 8) {
-                // every lane group owns a contiguous run of rows (and so of in-edges) and walks it
-                // in 16-edge chunks; row ends come from the flag bit, finished sums go through LDS
-                const uint32_t gi = wave * NSLOT + slot;
-                const uint32_t rpg = (w.count + WAVES * NSLOT - 1) / (WAVES * NSLOT);
-                uint32_t row = w.row + min(gi * rpg, w.count);
-                const uint32_t row_hi = w.row + min((gi + 1) * rpg, w.count);
-                size_t pos = p.in_ptr[row];
-                const size_t end = p.in_ptr[row_hi];
-                double* my = rowsum + (size_t)wave * CH * 64 + lane;
-                double acc = 0.0;
-                while (pos < end) {
-                    const uint32_t n = (uint32_t)min((size_t)CH, end - pos);
-                    double v[CH];
-                    uint32_t src[CH / GW];
-                    const uint32_t last = chunk_head<GW>(p.in_src, pos, n, lane, src);
-                    // a row ends in this chunk: its old rank and out-degree travel with the gathers
-                    double xo0 = 0.0;
-                    uint32_t od0 = 1u;
-                    if (last) {
-                        xo0 = NT_LOAD(&p.x[(size_t)row * GW + t]);
-                        if (row < p.sl_nd) od0 = NT_LOAD(&p.outdeg[row]);
-                    }
-                    chunk_tail<GW>(T, src, n, lane, v);
-                    // positions at which ANY lane group of the wave ends a row (scalar): everywhere else the edge is a plain add
-                    uint32_t any = 0;
-#pragma unroll
-                    for (int g = 0; g < 64; g += GW) any |= (uint32_t)__builtin_amdgcn_readlane((int)last, g);
-                    uint32_t nfin = 0;
-#pragma unroll
-                    for (int j = 0; j < CH; j++) {
-                        acc += v[j];
-                        if (j == CH - 1) {
-                            // pin: the old rank / out-degree requested BEFORE the gathers are consumed here, after them (they
-                            // have landed by now: loads return in order) — keeps the compiler from sinking the request into
-                            // the row epilogue below, where it would cost a second memory latency per chunk
-                            asm volatile("" : "+v"(xo0), "+v"(od0));
-                        }
-                        if (any & (1u << j)) {
-                            if ((last >> j) & 1u) {
-                                my[nfin * 64] = acc;
-                                nfin++;
-                                acc = 0.0;
-                            }
-                        }
-                    }
-#if defined(SS_PR_EXP_NOFINISH)
-                    for (uint32_t r = 0; r < nfin; r++) dsum += my[r * 64] + xo0;      // experiment: no row epilogue
-#elif defined(SS_PR_EXP_NODIV)
-                    if (nfin) { NT_STORE(my[0] + xo0, &p.x[(size_t)row * GW + t]); if (row < p.sl_nd) NT_STORE(my[0] * (double)od0, &Tw[(size_t)row * GW + t]); }
-                    for (uint32_t r = 1; r < nfin; r++) { NT_STORE(my[r * 64], &p.x[(size_t)(row + r) * GW + t]); if (row + r < p.sl_nd) NT_STORE(my[r * 64], &Tw[(size_t)(row + r) * GW + t]); }
-#else
-                    if (nfin) finish_with(row, my[0], xo0, od0);
-                    for (uint32_t r = 1; r < nfin; r++) finish(row + r, my[r * 64]);
-#endif
-                    row += nfin;
-                    pos += n;
-                }
-            }
-        } else if (w.kind == W_ROWG) {
-            if constexpr (GW >= 8) {
-                // mid-degree rows (T_ROWG < in-edges <= T_SEG, most of the graph's edges): one lane group per ROW, rows dealt
-                // round-robin to the groups (they are degree-sorted, so the groups of a wave run about equally long).  The row's
-                // in-edges go by in 16-edge chunks, row ends come from in_ptr: no flags, no LDS, the running sum stays in a
-                // register; the row's old rank and out-degree are requested before its first gathers.
-                for (uint32_t r = wave * NSLOT + slot; r < w.count; r += WAVES * NSLOT) {
-                    const uint32_t lrow = w.row + r;
-                    const size_t beg = p.in_ptr[lrow], end = p.in_ptr[lrow + 1];
-                    const double xo = NT_LOAD(&p.x[(size_t)lrow * GW + t]);
-                    const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
-                    double acc = 0.0;
-                    for (size_t pos = beg; pos < end; pos += CH) {
-                        const uint32_t n = (uint32_t)min((size_t)CH, end - pos);
-                        uint32_t src[CH / GW];
-                        double v[CH];
-                        chunk_head_noflags<GW>(p.in_src, pos, n, lane, src);
-                        chunk_tail<GW>(T, src, n, lane, v);
-#pragma unroll
-                        for (int j = 0; j < CH; j++) acc += v[j];
-                    }
-                    finish_with(lrow, acc, xo, od);
                 }
             }
         } else if (w.kind == W_WAVE) {
@@ -1067,7 +890,7 @@ __global__ __launch_bounds__(TPB) void k_pr_probe(const double* __restrict__ T, 
         const int t = lane % GW, slot = lane / GW, gbase = lane - t;
         const size_t groups = (size_t)gridDim.x * WAVES * NSLOT;
         const size_t gi = ((size_t)blockIdx.x * WAVES + wave) * NSLOT + slot;
-        // contiguous span of 16-edge chunks per lane group, like a W_ROWS item
+        // contiguous span of 16-edge chunks per lane group
         const size_t n_chunks = n_edges / CH;
         const size_t per = (n_chunks + groups - 1) / groups;
         size_t c = min(gi * per, n_chunks);
@@ -1135,11 +958,11 @@ int pick_gw(int k) {
 void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
                 uint32_t& seg_edges, uint32_t& pos_nd, uint32_t& pos_d, uint32_t (&vbeg)[7]) {
     const uint32_t NSLOT = 64 / gw;
-    // gw >= 8: rows above T_SEG in-edges get block(s) of their own, everything else is walked in
-    // 16-edge chunks by lane groups (W_ROWS).  gw < 8: wave-per-row / group-per-row classes.
-    const uint32_t T_SEG = gw >= 8 ? 512 : 32 * NSLOT;
+    // gw < 8: rows above T_SEG in-edges get block(s) of their own, then wave-per-row / group-per-row classes.
+    // gw >= 8: emit_v below.
+    const uint32_t T_SEG = 32 * NSLOT;
     const uint32_t T_WAVE = 2 * NSLOT;
-    seg_edges = gw >= 8 ? 2048 : 128 * NSLOT;
+    seg_edges = 128 * NSLOT;
     nsegs = 0;
     nmulti = 0;
     std::vector<WorkItem> seg, rwg, wav, grp, zer;
@@ -1148,7 +971,8 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     std::vector<WorkItem> vseg, vroww, vquad, vdeg[3], vzero;
     auto emit_v = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
-        const uint32_t T_MULTI = 4096, T_QUAD = 512, T_DEG = 8;
+        const uint32_t T_MULTI = 4096, T_DEG = 8;
+        const uint32_t T_QUAD = getenv("SS_PR_T_QUAD") ? (uint32_t)atoi(getenv("SS_PR_T_QUAD")) : 256u;
         uint32_t r = 0;
         for (; r < cnt && deg[r] > T_MULTI; r++) {
             const uint32_t ns = (deg[r] + SEGW - 1) / SEGW;
