@@ -258,10 +258,10 @@ def main() -> None:
                                "parallelism": "single GPU"},
                 })
                 ach = algo_bytes / (kern_ms * 1e-3) / 1e9
-                tr = profiled_traffic("k_pr_step") if (n, e, kt) == (10_000_000, 50_000_000, 16) else None
+                tr = profiled_traffic("k_pr_sweep") if (n, e, kt) == (10_000_000, 50_000_000, 16) else None
                 result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": ach / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
-                                      "kernel": f"k_pr_step<{kt if kt in (1, 2, 4, 8, 16) else 16}>",
+                                      "kernel": (f"k_pr_step<{1 if kt == 1 else 2}>" if kt <= 2 else f"k_pr_sweep<{8 if kt <= 8 else 16}>"),
                                       "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes}
                 if tr:
                     result["roofline"]["traffic_detail"] = tr
@@ -679,28 +679,25 @@ def main() -> None:
                 flat = {"value": ns / cdt, "unit": "queries/s", "cores": 1,
                         "sample": f"first {ns} queries of the same batch, flat-array single-thread C restatement of "
                                   f"main_retrieve.go:50-103 + get_metadata.go:31-69 (oracle/oracle.c:orc_score_topk_batch)"}
-                # reference-shaped: string-keyed maps, appended weight slices, insertion-sort appendSort; the
-                # reference fans goroutines out per term and per candidate, so B1 may use every core (one query per thread)
+                # reference-shaped: string-keyed maps, appended weight slices, insertion-sort appendSort
+                # (util.go:48-54 is quadratic in the candidates: ~0.3 s per head query on one core, and memory-bound when
+                # every core runs one, so the sample is single-threaded and small)
                 mm = pyoracle.MagMap(mt, mb)
-                nb1 = 32
+                nb1 = 4
                 t0 = time.perf_counter()
-                pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=True)
+                pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=False)
                 bdt = time.perf_counter() - t0
-                nb1 = int(max(32, min(nq, nb1 * args.cpu_seconds / max(bdt, 1e-3) / 2)))
+                nb1 = int(max(4, min(ns, 64, nb1 * args.cpu_seconds / max(bdt, 1e-3) / 2)))
                 t0 = time.perf_counter()
-                hb1, nb1n, th1 = pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=True)
+                hb1, nb1n, th1 = pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=False)
                 bdt = time.perf_counter() - t0
-                t0 = time.perf_counter()
-                pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:9], q_terms[:24], k, threads=False)
-                b1s = time.perf_counter() - t0
                 mm.close()
                 chk = min(nb1, ns)
                 b1_same = bool(np.array_equal(hb1["final"][:chk], ref["final"][:chk]))
-                topk["cpu_baseline"] = {"value": nb1 / bdt, "unit": "queries/s", "cores": th1, "kind": "port",
+                topk["cpu_baseline"] = {"value": nb1 / bdt, "unit": "queries/s", "cores": 1, "kind": "port",
                                         "sample": f"reference-shaped restatement (B1) of main_retrieve.go:61-97 + get_metadata.go:46-69 + "
-                                                  f"util.go:48-54 on the first {nb1} queries of the same batch, one query per thread "
+                                                  f"util.go:48-54 on the first {nb1} queries of the same batch, single thread "
                                                   f"(oracle/oracle.c:orc_score_topk_batch_hashed); forw[4] map built outside the timing",
-                                        "single_thread": {"value": 8 / b1s, "unit": "queries/s", "cores": 1, "sample": "first 8 queries"},
                                         "final_ranks_match_flat_port": b1_same, "flat_port": flat}
                 t0 = time.perf_counter()
                 _, _, th = pyoracle.score_topk_batch(nd, title, body, mt, mb, q_ptr, q_terms, k, omp=True)

@@ -21,11 +21,11 @@
 //   * k_score_slices builds the slice's window plan in LDS (window = a doc range holding <= CAP records; every
 //     record of a doc lies in one window), then streams the windows, window j+1's records in flight while window
 //     j is processed.  Per window TWO stages:
-//       1. FILTER (every record; one LDS float atomic, one LDS read, one barrier per window, no probing, no keys):
-//          c = impact * coef(list) is added into slot hash(doc) of a small float table ("sketch": collisions only
-//          make the sum larger); after the barrier every record reads its slot back: the value is an upper bound
-//          of its document's FinalRank.  If it is below the running threshold the record is dropped.  Three
-//          tables rotate so that clearing the slots a window touched needs no second barrier.
+//       1. FILTER (every record; one LDS integer atomic, one LDS read, one barrier per window, no probing, no keys):
+//          c = impact * coef(list), in fixed point and rounded up, is added into slot hash(doc) of a small table
+//          ("sketch": collisions only make the sum larger); after the barrier every record reads its slot back: the
+//          value is an upper bound of its document's FinalRank.  If it is below the running threshold the record is
+//          dropped.  Three tables rotate so that clearing the slots a window touched needs no second barrier.
 //       2. EXACT (survivors only, batched): surviving records are appended to a pending list {doc, index in
 //          list, list}; when the list fills (or the slice ends) all threads gather the survivors' float32
 //          weights and float64 magnitudes from the index (one round of HBM latency for the whole batch), aggregate

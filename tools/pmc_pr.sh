@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc_pr.sh "<counters>" tag   -- rocprofv3 --pmc over the PageRank half of bench.py, per-dispatch averages for k_pr_step<16>
+# usage: tools/pmc_pr.sh "<counters>" tag   -- rocprofv3 --pmc over the PageRank half of bench.py, per-dispatch averages for k_pr_sweep<16>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmcpr_$2
 rm -rf $out
@@ -11,7 +11,7 @@ if not f:
     print("no counter file"); sys.exit(0)
 acc = collections.defaultdict(float); n = collections.defaultdict(set)
 for row in csv.DictReader(open(f[0])):
-    if "k_pr_step<16>" not in row["Kernel_Name"]: continue
+    if "k_pr_sweep<16>" not in row["Kernel_Name"]: continue
     acc[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]].add(row["Dispatch_Id"])
 for c, v in acc.items():
     print(c, round(v / max(len(n[c]), 1)))
