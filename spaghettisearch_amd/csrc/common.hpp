@@ -31,6 +31,7 @@ struct ss_ctx {
     bool ev_valid[3] = {false, false, false};
     int cu_count = 256;
     size_t total_mem = 0;
+    int tfidf_scatter_lds = 0;         // k_scatter's dynamic LDS size granted on this device
     int tfidf_bucket_lds = 0;          // dynamic LDS size already granted to k_bucket_sum on this device
     void* comm = nullptr;              // RCCL communicator of this rank (ss_comm_init), ncclComm_t
     int comm_rank = 0, comm_world = 1;

@@ -144,8 +144,9 @@ __global__ __launch_bounds__(TPB) void k_weight(const uint64_t* __restrict__ ter
 // One float64 atomic per posting into a random 8-byte word of mag2 costs a memory-side read-modify-write each
 // (26 G/s on this part: 24.8 ms for the 641M-posting body table).  Instead the postings are partitioned once by
 // doc range ("bucket" = 2^shift consecutive docs) and every bucket is summed in LDS:
-//   k_weight_count   w = tf*idf in place, per-block LDS histogram of the buckets, one global add per touched bucket
-//   k_bucket_offsets exclusive scan of the <= 4096 bucket counts
+//   k_weight_count   w = tf*idf in place; every block owns a contiguous range of postings and leaves its bucket histogram
+//                    as one column of a [bucket][block] count matrix
+//   k_bucket_rowscan + k_bucket_offsets   exclusive scans: inside a bucket over the blocks, then over the buckets
 //   k_scatter        {doc, float32(w*w)} of every posting to its bucket's region (block claims a run per bucket,
 //                    LDS ticket per posting)
 //   k_bucket_sum     one workgroup per bucket: float64 LDS accumulators, sqrt, write mag
@@ -166,33 +167,154 @@ __device__ __forceinline__ void chunk_term_range(const uint64_t* __restrict__ te
     }
 }
 
+// Pass 1.  Block b owns the contiguous postings [b*per, (b+1)*per) (per is a multiple of the chunk sizes of both passes):
+// WEIGHT: w = tf*idf in place; the block's bucket histogram is kept in LDS over its whole range and written ONCE, as column
+// b of the [bucket][block] count matrix — no global atomics (the first version added every block's counts of every touched
+// bucket to global counters and claimed its output runs the same way: ~150M returning atomics on ~1200 words, most of
+// the 9 ms the two passes took).
+constexpr int WIN = CH + 2;                   // term window of a chunk: a chunk of CH postings spans at most CH + 1 non-empty terms
+template <bool WEIGHT>
 __global__ __launch_bounds__(TPB) void k_weight_count(const uint64_t* __restrict__ term_ptr, uint64_t n_terms,
                                                       const uint32_t* __restrict__ post_doc, float* __restrict__ post_w,
-                                                      const float* __restrict__ idf, uint64_t n_post, int shift, uint32_t nb,
-                                                      uint32_t* __restrict__ cnt) {
-    __shared__ uint64_t s_t[2];
+                                                      const float* __restrict__ idf, uint64_t n_post, uint64_t per, int shift, uint32_t nb,
+                                                      uint32_t nblk, uint32_t* __restrict__ mat) {
     __shared__ uint32_t s_hist[NB_MAX];
-    const uint64_t base = (uint64_t)blockIdx.x * CH;
-    const uint64_t last = min(base + CH, n_post) - 1;
+    __shared__ uint32_t s_tp[WEIGHT ? WIN : 1];   // term_ptr[t0 + k] - base, clamped to [0, 2^32-1]: where the chunk's terms start
+    __shared__ uint64_t s_t0;
+    __shared__ uint32_t s_need;
     for (uint32_t b = threadIdx.x; b < nb; b += TPB) s_hist[b] = 0;
-    chunk_term_range(term_ptr, n_terms, base, last, s_t);
-    __syncthreads();
-    const uint64_t t_lo = s_t[0], t_hi = s_t[1];
-#pragma unroll 4
-    for (int j = 0; j < PER_THREAD; j++) {
-        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
-        if (i >= n_post) break;
-        uint64_t lo = t_lo, hi = t_hi + 1;   // term_ptr[lo] <= i < term_ptr[hi]
+    const uint64_t r0 = (uint64_t)blockIdx.x * per, r1 = min(n_post, r0 + per);
+    if (WEIGHT && threadIdx.x == 0) {
+        uint64_t lo = 0, hi = n_terms;                                // largest t with term_ptr[t] <= r0 (once per block)
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
-            if (term_ptr[mid] <= i) lo = mid; else hi = mid;
+            if (term_ptr[mid] <= r0) lo = mid; else hi = mid;
         }
-        post_w[i] = post_w[i] * idf[lo];                              // term_weighting.go:42
-        atomicAdd(&s_hist[post_doc[i] >> shift], 1u);
+        s_t0 = lo;
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += TPB)
-        if (s_hist[b]) atomicAdd(&cnt[b], s_hist[b]);
+    for (uint64_t base = r0; base < r1; base += CH) {
+        const uint32_t n_here = (uint32_t)min((uint64_t)CH, r1 - base);
+        // every thread takes PER_THREAD CONSECUTIVE postings (vector loads), so it finds the term of its first posting
+        // once and walks from there; the chunk's term starts are staged in LDS relative to `base`
+        const uint32_t x0 = threadIdx.x * PER_THREAD;
+        uint32_t k = 0;
+        uint64_t t0 = 0;
+        if (WEIGHT) {
+            t0 = s_t0;                                                // term of posting `base` or an earlier one
+            if (threadIdx.x == 0) s_need = 0;
+            __syncthreads();
+            // coarse probe: how far do the chunk's terms reach?  thread q looks at term t0 + 1 + 16 q
+            {
+                const uint64_t t = t0 + 1 + (uint64_t)threadIdx.x * 16;
+                const uint64_t v = t <= n_terms ? term_ptr[t] : ~0ull;
+                if (v < base + n_here) atomicMax(&s_need, threadIdx.x + 1);
+            }
+            __syncthreads();
+            const uint32_t need = min((uint32_t)WIN, s_need * 16 + 18);   // window entries that can matter
+            for (uint32_t q = threadIdx.x; q < need; q += TPB) {
+                const uint64_t t = t0 + q;
+                const uint64_t v = t <= n_terms ? term_ptr[t] : ~0ull;
+                s_tp[q] = v <= base ? 0u : (v - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(v - base));
+            }
+            __syncthreads();
+            // largest k with s_tp[k] <= x0 (s_tp[0] = 0); a window that ends before the chunk does (runs of empty terms) is
+            // finished from global memory below
+            uint32_t lo = 0, hi = need;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_tp[mid] <= x0) lo = mid; else hi = mid;
+            }
+            k = lo;
+        }
+        if (x0 < n_here) {
+            uint32_t doc[PER_THREAD];
+            float w[PER_THREAD];
+            const uint64_t i0 = base + x0;
+            const bool full = x0 + PER_THREAD <= n_here;
+            if (full) {
+#pragma unroll
+                for (int v4 = 0; v4 < PER_THREAD / 4; v4++) {
+                    const uint4 d = *reinterpret_cast<const uint4*>(&post_doc[i0 + v4 * 4]);
+                    doc[v4 * 4] = d.x; doc[v4 * 4 + 1] = d.y; doc[v4 * 4 + 2] = d.z; doc[v4 * 4 + 3] = d.w;
+                    if (WEIGHT) {
+                        const float4 f = *reinterpret_cast<const float4*>(&post_w[i0 + v4 * 4]);
+                        w[v4 * 4] = f.x; w[v4 * 4 + 1] = f.y; w[v4 * 4 + 2] = f.z; w[v4 * 4 + 3] = f.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PER_THREAD; j++) {
+                    const bool ok = x0 + j < n_here;
+                    doc[j] = ok ? post_doc[i0 + j] : 0u;
+                    if (WEIGHT) w[j] = ok ? post_w[i0 + j] : 0.f;
+                }
+            }
+            if (WEIGHT) {
+                const uint32_t need = min((uint32_t)WIN, s_need * 16 + 18);
+                uint64_t t = t0 + k;
+#pragma unroll
+                for (int j = 0; j < PER_THREAD; j++) {
+                    const uint32_t x = x0 + j;
+                    if (x >= n_here) break;
+                    while (k + 1 < need && s_tp[k + 1] <= x) k++;
+                    t = t0 + k;
+                    if (k + 1 >= need) {                              // past the staged window: rare (long runs of empty terms)
+                        uint64_t lo = t, hi = n_terms;
+                        const uint64_t i = i0 + j;
+                        if (term_ptr[hi] <= i) lo = hi;
+                        while (hi - lo > 1) {
+                            const uint64_t mid = (lo + hi) >> 1;
+                            if (term_ptr[mid] <= i) lo = mid; else hi = mid;
+                        }
+                        t = lo;
+                    }
+                    w[j] = w[j] * idf[t];                             // term_weighting.go:42
+                }
+                if (full) {
+#pragma unroll
+                    for (int v4 = 0; v4 < PER_THREAD / 4; v4++)
+                        *reinterpret_cast<float4*>(&post_w[i0 + v4 * 4]) = make_float4(w[v4 * 4], w[v4 * 4 + 1], w[v4 * 4 + 2], w[v4 * 4 + 3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PER_THREAD; j++)
+                        if (x0 + j < n_here) post_w[i0 + j] = w[j];
+                }
+                // the thread holding the chunk's last posting knows where the next chunk's terms start
+                if (x0 + PER_THREAD >= n_here) s_t0 = t;
+            }
+#pragma unroll
+            for (int j = 0; j < PER_THREAD; j++)
+                if (x0 + j < n_here) atomicAdd(&s_hist[doc[j] >> shift], 1u);
+        }
+        if (WEIGHT) __syncthreads();                                  // s_t0 / s_tp are rewritten by the next chunk
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += TPB) mat[(size_t)b * nblk + blockIdx.x] = s_hist[b];
+}
+
+// Per bucket (one wave each): exclusive scan of the bucket's row of the count matrix over the blocks, in place; the
+// row's total goes to cnt[bucket].
+__global__ __launch_bounds__(64) void k_bucket_rowscan(uint32_t* __restrict__ mat, uint32_t nblk, uint32_t* __restrict__ cnt) {
+    uint32_t* row = mat + (size_t)blockIdx.x * nblk;
+    const uint32_t per = (nblk + 63) / 64, lane = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t i = lane * per + j;
+        if (i < nblk) sum += row[i];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += v;
+    }
+    uint32_t run = incl - sum;
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t i = lane * per + j;
+        if (i < nblk) { const uint32_t c = row[i]; row[i] = run; run += c; }
+    }
+    if (lane == 63) cnt[blockIdx.x] = incl;
 }
 
 // off[b] = sum of cnt[< b] (off[nb] = total); cursor[b] = off[b].  One block, nb <= NB_MAX.
@@ -222,63 +344,108 @@ __global__ __launch_bounds__(1024) void k_bucket_offsets(const uint32_t* __restr
     }
 }
 
-#ifndef SS_SC_TPB
-#define SS_SC_TPB 1024
-#endif
-constexpr int SC_TPB = SS_SC_TPB;             // bigger blocks: longer runs per bucket where short lists spread a block over many buckets
-constexpr int SC_CH = SC_TPB * PER_THREAD;
+// k_scatter: {doc, float32(w*w)} of every posting to its bucket's region.  A wave's 64 postings of a short list
+// belong to 64 different buckets: written directly they are 64 partial-line stores per instruction (5.9 ms for the
+// 641M-posting table, 1.9x write amplification).  The block therefore sorts its SC_CH records by bucket in LDS first
+// (histogram -> exclusive scan -> LDS ticket per record) and then writes them out in LDS order: consecutive lanes write
+// consecutive records of a bucket's run.
+constexpr int SC_TPB = 1024;
+constexpr int SC_PT = 8;                       // records per thread
+constexpr int SC_CH = SC_TPB * SC_PT;         // 8192 records = 64 KB of staging
+struct ScatterLds {
+    uint2 rec[SC_CH];
+    uint16_t bkt[SC_CH];                       // bucket of the record at each staging position
+    uint32_t hist[NB_MAX];                     // records of the chunk per bucket (the returning add is also the record's rank)
+    uint32_t loff[NB_MAX];                     // first staging position of the bucket
+    uint32_t gout[NB_MAX];                     // where this chunk's run of the bucket starts in the output
+    uint32_t cur[NB_MAX];                      // next output position of THIS block in the bucket (from the scanned count matrix)
+    uint32_t part[SC_TPB / 64];
+};
 __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post,
-                                                 int shift, uint32_t nb, uint32_t* __restrict__ cursor, uint2* __restrict__ out) {
-    __shared__ uint32_t s_hist[NB_MAX];
-    __shared__ uint32_t s_base[NB_MAX];
-    const uint64_t base = (uint64_t)blockIdx.x * SC_CH;
-    for (uint32_t b = threadIdx.x; b < nb; b += SC_TPB) s_hist[b] = 0;
-    __syncthreads();
-    uint32_t doc[PER_THREAD];
-#pragma unroll
-    for (int j = 0; j < PER_THREAD; j++) {
-        const uint64_t i = base + (uint64_t)j * SC_TPB + threadIdx.x;
-        doc[j] = 0xFFFFFFFFu;
-        if (i < n_post) {
-            doc[j] = post_doc[i];
-            atomicAdd(&s_hist[doc[j] >> shift], 1u);
-        }
+                                                 uint64_t per, int shift, uint32_t nb, uint32_t nblk, const uint32_t* __restrict__ mat,
+                                                 const uint32_t* __restrict__ off, uint2* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sc_smem[];
+    ScatterLds& L = *reinterpret_cast<ScatterLds*>(sc_smem);
+    for (uint32_t b = threadIdx.x; b < NB_MAX; b += SC_TPB) {
+        L.hist[b] = 0;
+        L.cur[b] = b < nb ? off[b] + mat[(size_t)b * nblk + blockIdx.x] : 0u;
     }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += SC_TPB) {
-        const uint32_t c = s_hist[b];
-        if (c) { s_base[b] = atomicAdd(&cursor[b], c); s_hist[b] = 0; }    // this block's run inside bucket b
-    }
-    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * per, r1 = min(n_post, r0 + per);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int BPT = NB_MAX / SC_TPB;      // consecutive buckets per thread in the scan
+    // the next chunk's postings are requested before the current chunk goes through its LDS phases
+    uint32_t ndoc[SC_PT];
+    float nw[SC_PT];
+    auto fetch = [&](uint64_t base) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < PER_THREAD; j++) {
-        const uint64_t i = base + (uint64_t)j * SC_TPB + threadIdx.x;
-        if (doc[j] != 0xFFFFFFFFu) {
-            const uint32_t b = doc[j] >> shift;
-            const float w = post_w[i];
-            const float sq = w * w;                                    // term_weighting.go:44 (float32 product)
-            const uint32_t r = atomicAdd(&s_hist[b], 1u);
-            out[(uint64_t)s_base[b] + r] = make_uint2(doc[j], __float_as_uint(sq));
+        for (int j = 0; j < SC_PT; j++) {
+            const uint64_t i = base + (uint64_t)j * SC_TPB + threadIdx.x;
+            const bool ok = i < r1;
+            ndoc[j] = ok ? post_doc[i] : 0xFFFFFFFFu;
+            nw[j] = ok ? post_w[i] : 0.f;
         }
+    };
+    fetch(r0);
+    __syncthreads();
+    for (uint64_t base = r0; base < r1; base += SC_CH) {
+        uint32_t doc[SC_PT], rank[SC_PT];
+        float w[SC_PT];
+#pragma unroll
+        for (int j = 0; j < SC_PT; j++) { doc[j] = ndoc[j]; w[j] = nw[j]; }
+        fetch(base + SC_CH);
+        // (1) count; the returned value is the record's rank inside its bucket
+#pragma unroll
+        for (int j = 0; j < SC_PT; j++) rank[j] = doc[j] != 0xFFFFFFFFu ? atomicAdd(&L.hist[doc[j] >> shift], 1u) : 0u;
+        __syncthreads();
+        // (2) exclusive scan of the counts -> staging offsets; claim this chunk's runs from the block's cursors
+        uint32_t c[BPT], run = 0;
+#pragma unroll
+        for (int q = 0; q < BPT; q++) { c[q] = L.hist[threadIdx.x * BPT + q]; run += c[q]; }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) L.part[wv] = incl;
+        __syncthreads();
+        uint32_t o = incl - run;
+        for (int q = 0; q < wv; q++) o += L.part[q];
+#pragma unroll
+        for (int q = 0; q < BPT; q++) {
+            const uint32_t b = threadIdx.x * BPT + q;
+            L.loff[b] = o;
+            o += c[q];
+            const uint32_t g = L.cur[b];
+            L.gout[b] = g;
+            L.cur[b] = g + c[q];
+            L.hist[b] = 0;
+        }
+        __syncthreads();
+        // (3) records to their staging positions
+#pragma unroll
+        for (int j = 0; j < SC_PT; j++) {
+            if (doc[j] != 0xFFFFFFFFu) {
+                const uint32_t b = doc[j] >> shift;
+                const float sq = w[j] * w[j];                          // term_weighting.go:44 (float32 product)
+                const uint32_t pos = L.loff[b] + rank[j];
+                L.rec[pos] = make_uint2(doc[j], __float_as_uint(sq));
+                L.bkt[pos] = (uint16_t)b;
+            }
+        }
+        __syncthreads();
+        // (4) out, in staging order: consecutive lanes write consecutive records of a bucket's run
+        const uint32_t n_here = (uint32_t)min((uint64_t)SC_CH, r1 - base);
+        for (uint32_t pos = threadIdx.x; pos < n_here; pos += SC_TPB) {
+            const uint32_t b = L.bkt[pos];
+            out[(uint64_t)L.gout[b] + (pos - L.loff[b])] = L.rec[pos];
+        }
+        // the next chunk's phase (1) only touches hist; its phase (2) rewrites loff / gout after the barrier that follows (1),
+        // by which time every thread has left (4)
     }
 }
 
-// magnitudes only (ss_index_refresh_magnitudes): the weights are already final
-__global__ __launch_bounds__(TPB) void k_count_only(const uint32_t* __restrict__ post_doc, uint64_t n_post, int shift, uint32_t nb, uint32_t* __restrict__ cnt) {
-    __shared__ uint32_t s_hist[NB_MAX];
-    const uint64_t base = (uint64_t)blockIdx.x * CH;
-    for (uint32_t b = threadIdx.x; b < nb; b += TPB) s_hist[b] = 0;
-    __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < PER_THREAD; j++) {
-        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
-        if (i >= n_post) break;
-        atomicAdd(&s_hist[post_doc[i] >> shift], 1u);
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += TPB)
-        if (s_hist[b]) atomicAdd(&cnt[b], s_hist[b]);
-}
+// magnitudes only (ss_index_refresh_magnitudes): small tables
 __global__ void k_sumsq_atomic(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post, double* __restrict__ mag2) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_post; i += (uint64_t)gridDim.x * blockDim.x) {
         const float w = post_w[i];
@@ -309,6 +476,52 @@ __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ 
 __global__ void k_sqrt(double* __restrict__ v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = sqrt(v[i]);                                     // term_weighting.go:72
+}
+
+
+// ---- bucketed magnitude pass: buffers (allocated before the clock starts) and launches ------------------------
+struct BucketPass {
+    ss::DevBuf<uint32_t> mat, cnt, off, cur;
+    ss::DevBuf<uint2> packed;
+    uint32_t nb = 0, nblk = 0;
+    uint64_t per = 0;
+    int shift = 13;
+};
+int32_t bucket_pass_prepare(ss_ctx* ctx, uint64_t P, uint32_t nb, int shift, BucketPass& bp) {
+    bp.nb = nb;
+    bp.shift = shift;
+    // blocks own contiguous ranges whose length is a multiple of both passes' chunk sizes; ~1024 ranges
+    const uint64_t unit = SC_CH;
+    static_assert(SC_CH % CH == 0, "a range must be whole chunks of both passes");
+    bp.per = std::max<uint64_t>(unit, ss::div_up(ss::div_up(P, (uint64_t)1024), unit) * unit);
+    bp.nblk = (uint32_t)ss::div_up(P, bp.per);
+    SS_HIP(ctx, bp.mat.alloc((size_t)nb * bp.nblk));
+    SS_HIP(ctx, bp.cnt.alloc(nb));
+    SS_HIP(ctx, bp.off.alloc(nb + 1));
+    SS_HIP(ctx, bp.cur.alloc(nb));
+    SS_HIP(ctx, bp.packed.alloc(P));
+    if (!ctx->tfidf_scatter_lds) {
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+        ctx->tfidf_scatter_lds = 1;
+    }
+    if (ctx->tfidf_bucket_lds < (1 << shift) * 8) {
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
+        ctx->tfidf_bucket_lds = (1 << shift) * 8;
+    }
+    return SS_OK;
+}
+// weight: also w = tf*idf in place (ss_tfidf_build); otherwise the magnitudes of the weights as they stand
+void bucket_pass_launch(ss_index* idx, hipStream_t st, BucketPass& bp, bool weight, const float* idf) {
+    const uint64_t P = idx->n_post, N = idx->n_docs, T = idx->n_terms;
+    if (weight) hipLaunchKernelGGL(k_weight_count<true>, dim3(bp.nblk), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
+                                   idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p);
+    else hipLaunchKernelGGL(k_weight_count<false>, dim3(bp.nblk), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
+                            idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p);
+    hipLaunchKernelGGL(k_bucket_rowscan, dim3(bp.nb), dim3(64), 0, st, bp.mat.p, bp.nblk, bp.cnt.p);
+    hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, bp.cnt.p, bp.nb, bp.off.p, bp.cur.p);
+    hipLaunchKernelGGL(k_scatter, dim3(bp.nblk), dim3(SC_TPB), sizeof(ScatterLds), st, idx->post_doc.p, idx->post_w.p, P, bp.per, bp.shift, bp.nb,
+                       bp.nblk, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(bp.nb), dim3(TPB_B), (size_t)(1 << bp.shift) * 8, st, bp.packed.p, bp.off.p, N, bp.shift, idx->mag.p);
 }
 
 }  // namespace
@@ -400,6 +613,7 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     SS_HIP(ctx, idf.alloc(T));
     // large tables: bucketed magnitude pass (no global float64 atomics); small ones: one atomic per posting
     int shift = 13;                                                   // 8192 docs per bucket = 64 KB of float64 LDS accumulators
+    if (const char* e = std::getenv("SS_TFIDF_SHIFT")) shift = std::max(10, std::min(14, atoi(e)));
     if ((N >> shift) >= (uint64_t)NB_MAX) shift = 14;
     const uint64_t nb64 = ss::div_up(std::max<uint64_t>(N, 1), (uint64_t)1 << shift);
     // SS_TFIDF_BUCKET_MIN (tests, A/B): smallest table that takes the bucketed pass; a huge value forces the atomics
@@ -407,30 +621,15 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     if (const char* e = std::getenv("SS_TFIDF_BUCKET_MIN")) min_p = std::strtoull(e, nullptr, 10);
     const bool bucketed = P >= std::max<uint64_t>(min_p, 1) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
     const uint32_t nb = (uint32_t)nb64;
-    ss::DevBuf<uint32_t> b_cnt, b_off, b_cur;
-    ss::DevBuf<uint2> b_packed;
-    if (bucketed) {
-        SS_HIP(ctx, b_cnt.alloc(nb));
-        SS_HIP(ctx, b_off.alloc(nb + 1));
-        SS_HIP(ctx, b_cur.alloc(nb));
-        SS_HIP(ctx, b_packed.alloc(P));
-        if (ctx->tfidf_bucket_lds < (1 << shift) * 8) {
-            SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
-            ctx->tfidf_bucket_lds = (1 << shift) * 8;
-        }
-    }
+    BucketPass bp;
+    if (bucketed) SS_TRY(bucket_pass_prepare(ctx, P, nb, shift, bp));
     SS_HIP(ctx, hipStreamSynchronize(st));       // allocator work (and anything queued before) is over when the clock starts
     SS_HIP(ctx, hipEventRecord(ctx->ev[2][0], st));
     SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
     if (T) hipLaunchKernelGGL(k_idf, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p,
                               idx->has_df_global ? idx->df_global.p : nullptr, T, (double)total_docs, idf.p);
     if (bucketed) {
-        SS_HIP(ctx, hipMemsetAsync(b_cnt.p, 0, nb * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_weight_count, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
-                           idf.p, P, shift, nb, b_cnt.p);
-        hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, b_cnt.p, nb, b_off.p, b_cur.p);
-        hipLaunchKernelGGL(k_scatter, dim3(ss::div_up(P, SC_CH)), dim3(SC_TPB), 0, st, idx->post_doc.p, idx->post_w.p, P, shift, nb, b_cur.p, b_packed.p);
-        hipLaunchKernelGGL(k_bucket_sum, dim3(nb), dim3(TPB_B), (size_t)(1 << shift) * 8, st, b_packed.p, b_off.p, N, shift, idx->mag.p);
+        bucket_pass_launch(idx, st, bp, true, idf.p);
     } else {
         if (P) hipLaunchKernelGGL(k_weight, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p,
                                   idx->post_w.p, idf.p, P, idx->mag.p);
@@ -460,22 +659,9 @@ int32_t ss_index_refresh_magnitudes(ss_index* idx, double* mag_out) {
     const bool bucketed = P >= ((uint64_t)1 << 22) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
     SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
     if (bucketed) {
-        const uint32_t nb = (uint32_t)nb64;
-        ss::DevBuf<uint32_t> b_cnt, b_off, b_cur;
-        ss::DevBuf<uint2> b_packed;
-        SS_HIP(ctx, b_cnt.alloc(nb));
-        SS_HIP(ctx, b_off.alloc(nb + 1));
-        SS_HIP(ctx, b_cur.alloc(nb));
-        SS_HIP(ctx, b_packed.alloc(P));
-        if (ctx->tfidf_bucket_lds < (1 << shift) * 8) {
-            SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
-            ctx->tfidf_bucket_lds = (1 << shift) * 8;
-        }
-        SS_HIP(ctx, hipMemsetAsync(b_cnt.p, 0, nb * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_count_only, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, (const uint32_t*)idx->post_doc.p, P, shift, nb, b_cnt.p);
-        hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, b_cnt.p, nb, b_off.p, b_cur.p);
-        hipLaunchKernelGGL(k_scatter, dim3(ss::div_up(P, SC_CH)), dim3(SC_TPB), 0, st, idx->post_doc.p, idx->post_w.p, P, shift, nb, b_cur.p, b_packed.p);
-        hipLaunchKernelGGL(k_bucket_sum, dim3(nb), dim3(TPB_B), (size_t)(1 << shift) * 8, st, b_packed.p, b_off.p, N, shift, idx->mag.p);
+        BucketPass bp;
+        SS_TRY(bucket_pass_prepare(ctx, P, (uint32_t)nb64, shift, bp));
+        bucket_pass_launch(idx, st, bp, false, nullptr);
         SS_HIP(ctx, hipGetLastError());
         SS_HIP(ctx, hipStreamSynchronize(st));
     } else {
