@@ -949,10 +949,13 @@ struct ss_pr {
 
 namespace {
 
-int pick_gw(int k) {
+int pick_gw(int k, uint64_t table_rows) {
     // K = 3, 4 run the wave-item sweep padded to 8 topics (measured on the 10M/50M R-MAT at K=4: 0.77 ms against 0.94 ms
-    // for the 4-wide block-item kernel; at K=1 the narrow kernel wins, 0.55 against 0.79 ms)
+    // for the 4-wide block-item kernel; at K=1 the narrow kernel wins there, 0.55 against 0.79 ms).  K <= 2 on a graph whose
+    // padded table stays cache-resident (<= 64 MB of 64-byte rows) also takes it: the padding costs no HBM traffic then
+    // and the wave-item pipeline is quicker than the block-item one (2^20 nodes / 5M edges, K=1: 0.134 against 0.19 ms)
     if (k >= 3 && k <= 8) return 8;
+    if (k <= 2 && table_rows * 64 <= (64ull << 20)) return 8;
     int gw = 1;
     while (gw < k) gw <<= 1;
     return gw;
@@ -1124,7 +1127,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     std::unique_ptr<ss_pr> guard(pr);
     pr->g = g;
     pr->k = k_topics;
-    pr->gw = pick_gw(k_topics);
+    pr->gw = pick_gw(k_topics, g->nd_int);
     const int GW = pr->gw;
     const size_t n_local = g->n_local();
 

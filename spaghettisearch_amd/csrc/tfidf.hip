@@ -350,29 +350,33 @@ __global__ __launch_bounds__(1024) void k_bucket_offsets(const uint32_t* __restr
 // (histogram -> exclusive scan -> LDS ticket per record) and then writes them out in LDS order: consecutive lanes write
 // consecutive records of a bucket's run.
 constexpr int SC_TPB = 1024;
-constexpr int SC_PT = 8;                       // records per thread
-constexpr int SC_CH = SC_TPB * SC_PT;         // 8192 records = 64 KB of staging
-struct ScatterLds {
-    uint2 rec[SC_CH];
-    uint16_t bkt[SC_CH];                       // bucket of the record at each staging position
-    uint32_t hist[NB_MAX];                     // records of the chunk per bucket (the returning add is also the record's rank)
-    uint32_t loff[NB_MAX];                     // first staging position of the bucket
-    uint32_t gout[NB_MAX];                     // where this chunk's run of the bucket starts in the output
-    uint32_t cur[NB_MAX];                      // next output position of THIS block in the bucket (from the scanned count matrix)
-    uint32_t part[SC_TPB / 64];
-};
+#ifndef SS_SC_PT
+#define SS_SC_PT 8
+#endif
+constexpr int SC_PT = SS_SC_PT;                // records per thread
+constexpr int SC_CH = SC_TPB * SC_PT;         // records per chunk (staged in LDS)
+constexpr int SC_BPT_MAX = NB_MAX / SC_TPB;
+// LDS: rec[SC_CH] (8 B), then four tables of nbp = bpt * SC_TPB words (hist, loff, gout, cur), part[16], bkt[SC_CH] (2 B).
+// 10M docs (1221 buckets, bpt = 2): 64 + 32 + 16 KB, one workgroup per CU (4096-record chunks and two workgroups per CU measured 5 % slower).
+inline size_t scatter_lds_bytes(uint32_t bpt) { return (size_t)SC_CH * 8 + (size_t)4 * bpt * SC_TPB * 4 + 64 + (size_t)SC_CH * 2; }
 __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post,
-                                                 uint64_t per, int shift, uint32_t nb, uint32_t nblk, const uint32_t* __restrict__ mat,
-                                                 const uint32_t* __restrict__ off, uint2* __restrict__ out) {
+                                                 uint64_t per, int shift, uint32_t nb, uint32_t nblk, uint32_t bpt,
+                                                 const uint32_t* __restrict__ mat, const uint32_t* __restrict__ off, uint2* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_smem[];
-    ScatterLds& L = *reinterpret_cast<ScatterLds*>(sc_smem);
-    for (uint32_t b = threadIdx.x; b < NB_MAX; b += SC_TPB) {
-        L.hist[b] = 0;
-        L.cur[b] = b < nb ? off[b] + mat[(size_t)b * nblk + blockIdx.x] : 0u;
+    const uint32_t nbp = bpt * SC_TPB;
+    uint2* const L_rec = reinterpret_cast<uint2*>(sc_smem);
+    uint32_t* const L_hist = reinterpret_cast<uint32_t*>(L_rec + SC_CH);   // records of the chunk per bucket (the returning add is also the record's rank)
+    uint32_t* const L_loff = L_hist + nbp;                                 // first staging position of the bucket
+    uint32_t* const L_gout = L_loff + nbp;                                 // where this chunk's run of the bucket starts in the output
+    uint32_t* const L_cur = L_gout + nbp;                                  // next output position of THIS block in the bucket
+    uint32_t* const L_part = L_cur + nbp;
+    uint16_t* const L_bkt = reinterpret_cast<uint16_t*>(L_part + 16);      // bucket of the record at each staging position
+    for (uint32_t b = threadIdx.x; b < nbp; b += SC_TPB) {
+        L_hist[b] = 0;
+        L_cur[b] = b < nb ? off[b] + mat[(size_t)b * nblk + blockIdx.x] : 0u;
     }
     const uint64_t r0 = (uint64_t)blockIdx.x * per, r1 = min(n_post, r0 + per);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int BPT = NB_MAX / SC_TPB;      // consecutive buckets per thread in the scan
     // the next chunk's postings are requested before the current chunk goes through its LDS phases
     uint32_t ndoc[SC_PT];
     float nw[SC_PT];
@@ -395,31 +399,36 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
         fetch(base + SC_CH);
         // (1) count; the returned value is the record's rank inside its bucket
 #pragma unroll
-        for (int j = 0; j < SC_PT; j++) rank[j] = doc[j] != 0xFFFFFFFFu ? atomicAdd(&L.hist[doc[j] >> shift], 1u) : 0u;
+        for (int j = 0; j < SC_PT; j++) rank[j] = doc[j] != 0xFFFFFFFFu ? atomicAdd(&L_hist[doc[j] >> shift], 1u) : 0u;
         __syncthreads();
         // (2) exclusive scan of the counts -> staging offsets; claim this chunk's runs from the block's cursors
-        uint32_t c[BPT], run = 0;
+        uint32_t c[SC_BPT_MAX], run = 0;
 #pragma unroll
-        for (int q = 0; q < BPT; q++) { c[q] = L.hist[threadIdx.x * BPT + q]; run += c[q]; }
+        for (int q = 0; q < SC_BPT_MAX; q++) {
+            c[q] = (uint32_t)q < bpt ? L_hist[threadIdx.x * bpt + q] : 0u;
+            run += c[q];
+        }
         uint32_t incl = run;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(incl, o, 64);
             if (lane >= o) incl += v;
         }
-        if (lane == 63) L.part[wv] = incl;
+        if (lane == 63) L_part[wv] = incl;
         __syncthreads();
         uint32_t o = incl - run;
-        for (int q = 0; q < wv; q++) o += L.part[q];
+        for (int q = 0; q < wv; q++) o += L_part[q];
 #pragma unroll
-        for (int q = 0; q < BPT; q++) {
-            const uint32_t b = threadIdx.x * BPT + q;
-            L.loff[b] = o;
-            o += c[q];
-            const uint32_t g = L.cur[b];
-            L.gout[b] = g;
-            L.cur[b] = g + c[q];
-            L.hist[b] = 0;
+        for (int q = 0; q < SC_BPT_MAX; q++) {
+            if ((uint32_t)q < bpt) {
+                const uint32_t b = threadIdx.x * bpt + q;
+                L_loff[b] = o;
+                o += c[q];
+                const uint32_t g = L_cur[b];
+                L_gout[b] = g;
+                L_cur[b] = g + c[q];
+                L_hist[b] = 0;
+            }
         }
         __syncthreads();
         // (3) records to their staging positions
@@ -428,17 +437,17 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
             if (doc[j] != 0xFFFFFFFFu) {
                 const uint32_t b = doc[j] >> shift;
                 const float sq = w[j] * w[j];                          // term_weighting.go:44 (float32 product)
-                const uint32_t pos = L.loff[b] + rank[j];
-                L.rec[pos] = make_uint2(doc[j], __float_as_uint(sq));
-                L.bkt[pos] = (uint16_t)b;
+                const uint32_t pos = L_loff[b] + rank[j];
+                L_rec[pos] = make_uint2(doc[j], __float_as_uint(sq));
+                L_bkt[pos] = (uint16_t)b;
             }
         }
         __syncthreads();
         // (4) out, in staging order: consecutive lanes write consecutive records of a bucket's run
         const uint32_t n_here = (uint32_t)min((uint64_t)SC_CH, r1 - base);
         for (uint32_t pos = threadIdx.x; pos < n_here; pos += SC_TPB) {
-            const uint32_t b = L.bkt[pos];
-            out[(uint64_t)L.gout[b] + (pos - L.loff[b])] = L.rec[pos];
+            const uint32_t b = L_bkt[pos];
+            out[(uint64_t)L_gout[b] + (pos - L_loff[b])] = L_rec[pos];
         }
         // the next chunk's phase (1) only touches hist; its phase (2) rewrites loff / gout after the barrier that follows (1),
         // by which time every thread has left (4)
@@ -462,9 +471,17 @@ __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ 
     for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) acc[i] = 0.0;
     __syncthreads();
     const uint32_t lo = off[b], hi = off[b + 1];
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += TPB_B) {
-        const uint2 r = packed[i];
-        atomicAdd(&acc[r.x & (bd - 1)], (double)__uint_as_float(r.y)); // :44 (float64 accumulate; LDS)
+    // 8 records per thread in flight (two workgroups of 512 per CU: 64 KB)
+    for (uint32_t i0 = lo; i0 < hi; i0 += 8 * TPB_B) {
+        uint2 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t i = i0 + u * TPB_B + threadIdx.x;
+            r[u] = i < hi ? packed[i] : make_uint2(0u, 0u);            // a zero square adds nothing
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u * TPB_B + threadIdx.x < hi) atomicAdd(&acc[r[u].x & (bd - 1)], (double)__uint_as_float(r[u].y));   // :44 (float64 accumulate; LDS)
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) {
@@ -483,7 +500,7 @@ __global__ void k_sqrt(double* __restrict__ v, uint64_t n) {
 struct BucketPass {
     ss::DevBuf<uint32_t> mat, cnt, off, cur;
     ss::DevBuf<uint2> packed;
-    uint32_t nb = 0, nblk = 0;
+    uint32_t nb = 0, nblk = 0, bpt = 1;
     uint64_t per = 0;
     int shift = 13;
 };
@@ -491,18 +508,20 @@ int32_t bucket_pass_prepare(ss_ctx* ctx, uint64_t P, uint32_t nb, int shift, Buc
     bp.nb = nb;
     bp.shift = shift;
     // blocks own contiguous ranges whose length is a multiple of both passes' chunk sizes; ~1024 ranges
-    const uint64_t unit = SC_CH;
-    static_assert(SC_CH % CH == 0, "a range must be whole chunks of both passes");
-    bp.per = std::max<uint64_t>(unit, ss::div_up(ss::div_up(P, (uint64_t)1024), unit) * unit);
+    const uint64_t unit = std::max<uint64_t>(SC_CH, CH);
+    static_assert(SC_CH % CH == 0 || CH % SC_CH == 0, "a range must be whole chunks of both passes");
+    const uint64_t target_blocks = getenv("SS_TFIDF_NBLK") ? (uint64_t)atoi(getenv("SS_TFIDF_NBLK")) : 1024;
+    bp.per = std::max<uint64_t>(unit, ss::div_up(ss::div_up(P, target_blocks), unit) * unit);
     bp.nblk = (uint32_t)ss::div_up(P, bp.per);
     SS_HIP(ctx, bp.mat.alloc((size_t)nb * bp.nblk));
     SS_HIP(ctx, bp.cnt.alloc(nb));
     SS_HIP(ctx, bp.off.alloc(nb + 1));
     SS_HIP(ctx, bp.cur.alloc(nb));
     SS_HIP(ctx, bp.packed.alloc(P));
-    if (!ctx->tfidf_scatter_lds) {
-        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-        ctx->tfidf_scatter_lds = 1;
+    bp.bpt = ss::div_up(nb, (uint32_t)SC_TPB);
+    if (ctx->tfidf_scatter_lds < (int)scatter_lds_bytes(bp.bpt)) {
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(bp.bpt)));
+        ctx->tfidf_scatter_lds = (int)scatter_lds_bytes(bp.bpt);
     }
     if (ctx->tfidf_bucket_lds < (1 << shift) * 8) {
         SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
@@ -519,8 +538,8 @@ void bucket_pass_launch(ss_index* idx, hipStream_t st, BucketPass& bp, bool weig
                             idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p);
     hipLaunchKernelGGL(k_bucket_rowscan, dim3(bp.nb), dim3(64), 0, st, bp.mat.p, bp.nblk, bp.cnt.p);
     hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, bp.cnt.p, bp.nb, bp.off.p, bp.cur.p);
-    hipLaunchKernelGGL(k_scatter, dim3(bp.nblk), dim3(SC_TPB), sizeof(ScatterLds), st, idx->post_doc.p, idx->post_w.p, P, bp.per, bp.shift, bp.nb,
-                       bp.nblk, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p);
+    hipLaunchKernelGGL(k_scatter, dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.bpt), st, idx->post_doc.p, idx->post_w.p, P, bp.per, bp.shift, bp.nb,
+                       bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p);
     hipLaunchKernelGGL(k_bucket_sum, dim3(bp.nb), dim3(TPB_B), (size_t)(1 << bp.shift) * 8, st, bp.packed.p, bp.off.p, N, bp.shift, idx->mag.p);
 }
 
