@@ -55,7 +55,10 @@ namespace {
 #define SS_TPB 512
 #endif
 constexpr int TPB = SS_TPB;        // k_score_slices workgroup
-constexpr int TPB_M = 256;         // k_merge_topk workgroup
+#ifndef SS_TPB_M
+#define SS_TPB_M 256
+#endif
+constexpr int TPB_M = SS_TPB_M;    // k_merge_topk workgroup
 #ifndef SS_CAP
 #define SS_CAP 1024
 #endif
@@ -159,6 +162,7 @@ struct ScoreParams {
     int32_t kth_j;             // smallest j with 2^j >= k
     int32_t exact_all;         // 1: the filter's assumptions do not hold for this call: every record goes to the exact stage
     uint64_t* so_key; uint32_t* so_doc; uint32_t* so_cnt;   // per slice top-k
+    uint32_t* q_ticket;       // per query: slices that have handed in their list (fused merge); null = k_merge_topk runs as its own launch
     ss_hit* hits; int32_t* n_hits;
 };
 
@@ -683,6 +687,95 @@ __device__ __forceinline__ void chunk_filter(const SliceLds& S, const uint32_t (
     }
 }
 
+// NT = threads of the calling workgroup.  FUSED: called by the last slice of the query to finish inside k_score_slices — the
+// slices' lists were stored write-through and are read with sc1 loads (no fence; see the hand-off at the end of
+// k_score_slices).
+template <int NT, bool FUSED>
+__device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t q, unsigned char* smem) {
+    double* accT = reinterpret_cast<double*>(smem);                    // [k]
+    double* accB = accT + p.k;                                         // [k]
+    double* mgT = accB + p.k;                                          // [k]
+    double* mgB = mgT + p.k;                                           // [k]
+    uint64_t* cd_key = reinterpret_cast<uint64_t*>(mgB + p.k);         // [cb]
+    uint64_t* sc64 = cd_key + p.cb;                                    // [1]
+    uint32_t* cd_doc = reinterpret_cast<uint32_t*>(sc64 + 1);          // [cb]
+    uint32_t* sc32 = cd_doc + p.cb;                                    // [4]
+    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), 0ull, -INFINITY, (uint32_t)p.cb};
+    const int tid = threadIdx.x;
+    const int k = p.k;
+    if (tid == 0) { sc32[0] = 0; sc64[0] = 0ull; }
+    __syncthreads();
+    for (uint32_t s = p.slice_base[q]; s < p.slice_base[q + 1]; s++) {
+        const uint32_t n = FUSED ? __hip_atomic_load(&p.so_cnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.so_cnt[s];   // <= k, and cb >= 2k: room after a compaction
+        if (sc32[0] + n > tk.cb) topk_compact(tk, k);
+        __syncthreads();
+        const uint64_t thr = *tk.thr;
+        for (uint32_t i = tid; i < n; i += NT) {
+            const uint64_t key = FUSED ? __hip_atomic_load(&p.so_key[(size_t)s * k + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.so_key[(size_t)s * k + i];
+            if (key >= thr) {
+                const uint32_t j = atomicAdd(tk.count, 1u);
+                tk.key[j] = key;
+                tk.doc[j] = FUSED ? __hip_atomic_load(&p.so_doc[(size_t)s * k + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.so_doc[(size_t)s * k + i];
+            }
+        }
+        __syncthreads();
+    }
+    topk_compact(tk, k);
+    const uint32_t n_out = sc32[0];
+
+    // explain: TitleRank/BodyRank of the winners, re-derived from the posting lists
+    for (uint32_t i = tid; i < n_out; i += NT) { accT[i] = 0.0; accB[i] = 0.0; mgT[i] = 1.0; mgB[i] = 1.0; }
+    __syncthreads();
+    const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
+    const bool has_phrase = p.ph_off && p.ph_off[q + 1] > p.ph_off[q];
+    const uint32_t L = 2 * nd + (has_phrase ? 4u : 0u);
+    for (uint32_t task = tid; task < n_out * L; task += NT) {
+        const uint32_t i = task / L, l = task % L;
+        const int field = l & 1;
+        uint64_t addr, waddr;
+        uint32_t len;
+        double mult;
+        if (l < 2 * nd) {
+            const uint32_t term = p.dterm[t0 + (l >> 1)];
+            const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
+            addr = (uint64_t)((field ? p.t_rec : p.b_rec) + ptr[term]);
+            waddr = (uint64_t)((field ? p.t_w : p.b_w) + ptr[term]);
+            len = (uint32_t)(ptr[term + 1] - ptr[term]);
+            mult = (double)p.dmult[t0 + (l >> 1)];
+        } else {
+            addr = (uint64_t)(x_rec_of(p, (int)(l - 2 * nd)) + p.x_off[q]);
+            waddr = (uint64_t)(x_w_of(p, (int)(l - 2 * nd)) + p.x_off[q]);
+            len = p.x_cnt[(size_t)q * 4 + (l - 2 * nd)];
+            mult = 1.0;
+        }
+        const uint32_t d = cd_doc[i];
+        const uint32_t pos = lower_bound_interp(addr, 0, len, d);
+        if (pos < len && load_doc(addr, pos) == d) {
+            const double v = (double)load_w(waddr, pos) * mult;
+            const double mag = (field ? p.t_mag : p.b_mag)[d];
+            if (field) { atomicAdd(&accT[i], v); mgT[i] = mag; }
+            else { atomicAdd(&accB[i], v); mgB[i] = mag; }
+        }
+    }
+    __syncthreads();
+    const double qmag = p.qmag[q];
+    const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
+    for (uint32_t i = tid; i < (uint32_t)k; i += NT) {
+        ss_hit h;
+        h.doc = 0; h._pad = 0; h.title = 0.0; h.body = 0.0; h.pagerank = 0.0; h.final = 0.0;
+        if (i < n_out) {
+            const uint32_t d = cd_doc[i];
+            const double sqd = probs ? topic_dot(p.prior, probs, p.k_topics, d) : 0.0;
+            double title, body, fin;
+            final_rank(accT[i], accB[i], mgT[i], mgB[i], qmag, sqd, title, body, fin);
+            h.doc = d; h.title = title; h.body = body; h.pagerank = sqd; h.final = fin;
+        }
+        p.hits[(size_t)q * k + i] = h;
+    }
+    if (tid == 0) p.n_hits[q] = (int32_t)n_out;
+}
+
+
 __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slices(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ScoreLds lo_ = score_lds_layout(p.cb);
@@ -1018,11 +1111,36 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
 
     topk_compact(tk, p.k);
     const uint32_t n_out = cand_count;
-    for (uint32_t i = tid; i < n_out; i += TPB) {
-        p.so_key[(size_t)slice_id * p.k + i] = cd_key[i];
-        p.so_doc[(size_t)slice_id * p.k + i] = cd_doc[i];
+    if (!p.q_ticket) {
+        for (uint32_t i = tid; i < n_out; i += TPB) {
+            p.so_key[(size_t)slice_id * p.k + i] = cd_key[i];
+            p.so_doc[(size_t)slice_id * p.k + i] = cd_doc[i];
+        }
+        if (tid == 0) p.so_cnt[slice_id] = n_out;
+    } else {
+        // Fused merge: the slice's list goes out write-through (sc1), every wave drains its stores, one lane takes the
+        // query's ticket; the slice that arrives last merges the query right here while other workgroups are still
+        // scoring — no second launch, no fence (the readers use sc1 loads; MI355X_MICROARCH.md, hand-off forms).
+        for (uint32_t i = tid; i < n_out; i += TPB) {
+            __hip_atomic_store(&p.so_key[(size_t)slice_id * p.k + i], cd_key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&p.so_doc[(size_t)slice_id * p.k + i], cd_doc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) __hip_atomic_store(&p.so_cnt[slice_id], n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint32_t* last_flag = reinterpret_cast<uint32_t*>(smem);   // the slice's LDS is free from here on
+        if (tid == 0) {
+            const uint32_t n_sl = p.slice_base[sd.q + 1] - p.slice_base[sd.q];
+            const uint32_t prev = __hip_atomic_fetch_add(&p.q_ticket[sd.q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = prev == n_sl - 1;
+            if (last) __hip_atomic_store(&p.q_ticket[sd.q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+            *last_flag = last ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool last = *last_flag != 0;
+        __syncthreads();
+        if (last) merge_query<TPB, true>(p, sd.q, smem);
     }
-    if (tid == 0) p.so_cnt[slice_id] = n_out;
     DIAG_NOW(t_k3);
     DIAG_ADD(11, t_k3 - t_k0);
 #ifdef SS_DIAG
@@ -1176,88 +1294,7 @@ size_t score_lds_bytes(int cb) { return score_lds_layout(cb).total; }
 // ---- K5: merge a query's slices, explain the winners ------------------------------
 __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* accT = reinterpret_cast<double*>(smem);                    // [k]
-    double* accB = accT + p.k;                                         // [k]
-    double* mgT = accB + p.k;                                          // [k]
-    double* mgB = mgT + p.k;                                           // [k]
-    uint64_t* cd_key = reinterpret_cast<uint64_t*>(mgB + p.k);         // [cb]
-    uint64_t* sc64 = cd_key + p.cb;                                    // [1]
-    uint32_t* cd_doc = reinterpret_cast<uint32_t*>(sc64 + 1);          // [cb]
-    uint32_t* sc32 = cd_doc + p.cb;                                    // [4]
-    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), 0ull, -INFINITY, (uint32_t)p.cb};
-    const int tid = threadIdx.x;
-    const uint32_t q = blockIdx.x;
-    const int k = p.k;
-    if (tid == 0) { sc32[0] = 0; sc64[0] = 0ull; }
-    __syncthreads();
-    for (uint32_t s = p.slice_base[q]; s < p.slice_base[q + 1]; s++) {
-        const uint32_t n = p.so_cnt[s];                  // <= k, and cb >= 2k: room after a compaction
-        if (sc32[0] + n > tk.cb) topk_compact(tk, k);
-        __syncthreads();
-        const uint64_t thr = *tk.thr;
-        for (uint32_t i = tid; i < n; i += TPB_M) {
-            const uint64_t key = p.so_key[(size_t)s * k + i];
-            if (key >= thr) {
-                const uint32_t j = atomicAdd(tk.count, 1u);
-                tk.key[j] = key;
-                tk.doc[j] = p.so_doc[(size_t)s * k + i];
-            }
-        }
-        __syncthreads();
-    }
-    topk_compact(tk, k);
-    const uint32_t n_out = sc32[0];
-
-    // explain: TitleRank/BodyRank of the winners, re-derived from the posting lists
-    for (uint32_t i = tid; i < n_out; i += TPB_M) { accT[i] = 0.0; accB[i] = 0.0; mgT[i] = 1.0; mgB[i] = 1.0; }
-    __syncthreads();
-    const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
-    const bool has_phrase = p.ph_off && p.ph_off[q + 1] > p.ph_off[q];
-    const uint32_t L = 2 * nd + (has_phrase ? 4u : 0u);
-    for (uint32_t task = tid; task < n_out * L; task += TPB_M) {
-        const uint32_t i = task / L, l = task % L;
-        const int field = l & 1;
-        uint64_t addr, waddr;
-        uint32_t len;
-        double mult;
-        if (l < 2 * nd) {
-            const uint32_t term = p.dterm[t0 + (l >> 1)];
-            const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-            addr = (uint64_t)((field ? p.t_rec : p.b_rec) + ptr[term]);
-            waddr = (uint64_t)((field ? p.t_w : p.b_w) + ptr[term]);
-            len = (uint32_t)(ptr[term + 1] - ptr[term]);
-            mult = (double)p.dmult[t0 + (l >> 1)];
-        } else {
-            addr = (uint64_t)(x_rec_of(p, (int)(l - 2 * nd)) + p.x_off[q]);
-            waddr = (uint64_t)(x_w_of(p, (int)(l - 2 * nd)) + p.x_off[q]);
-            len = p.x_cnt[(size_t)q * 4 + (l - 2 * nd)];
-            mult = 1.0;
-        }
-        const uint32_t d = cd_doc[i];
-        const uint32_t pos = lower_bound_interp(addr, 0, len, d);
-        if (pos < len && load_doc(addr, pos) == d) {
-            const double v = (double)load_w(waddr, pos) * mult;
-            const double mag = (field ? p.t_mag : p.b_mag)[d];
-            if (field) { atomicAdd(&accT[i], v); mgT[i] = mag; }
-            else { atomicAdd(&accB[i], v); mgB[i] = mag; }
-        }
-    }
-    __syncthreads();
-    const double qmag = p.qmag[q];
-    const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
-    for (uint32_t i = tid; i < (uint32_t)k; i += TPB_M) {
-        ss_hit h;
-        h.doc = 0; h._pad = 0; h.title = 0.0; h.body = 0.0; h.pagerank = 0.0; h.final = 0.0;
-        if (i < n_out) {
-            const uint32_t d = cd_doc[i];
-            const double sqd = probs ? topic_dot(p.prior, probs, p.k_topics, d) : 0.0;
-            double title, body, fin;
-            final_rank(accT[i], accB[i], mgT[i], mgB[i], qmag, sqd, title, body, fin);
-            h.doc = d; h.title = title; h.body = body; h.pagerank = sqd; h.final = fin;
-        }
-        p.hits[(size_t)q * k + i] = h;
-    }
-    if (tid == 0) p.n_hits[q] = (int32_t)n_out;
+    merge_query<TPB_M, false>(p, blockIdx.x, smem);
 }
 
 size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 16 + 16; }
@@ -1401,7 +1438,8 @@ struct ss_scorer {
     ss::DevBuf<float> d_xw[4];                  // ... and their float32 weight sums
     ss::DevBuf<uint32_t> d_xcnt;
     ss::DevBuf<uint64_t> d_so_key;
-    ss::DevBuf<uint32_t> d_so_doc, d_so_cnt;
+    ss::DevBuf<uint32_t> d_so_doc, d_so_cnt, d_qticket;
+    size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
     ss::DevBuf<ss_hit> d_hits;
     ss::DevBuf<int32_t> d_nhits;
     ~ss_scorer() {
@@ -1798,6 +1836,12 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     SS_HIP(ctx, ensure(s->d_so_key, n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_doc, n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_cnt, n_slices));
+    const bool fused = std::getenv("SS_SCORE_SEPARATE_MERGE") == nullptr;
+    if (fused && s->qticket_zeroed < (size_t)n_q) {
+        SS_HIP(ctx, ensure(s->d_qticket, (size_t)n_q));
+        SS_HIP(ctx, hipMemsetAsync(s->d_qticket.p, 0, (size_t)n_q * sizeof(uint32_t), st));
+        s->qticket_zeroed = (size_t)n_q;
+    }
     SS_HIP(ctx, ensure(s->d_hits, (size_t)n_q * k));
     SS_HIP(ctx, ensure(s->d_nhits, n_q));
 
@@ -1831,6 +1875,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.kth_j = kth_j;
     p.exact_all = exact_all ? 1 : 0;
     p.so_key = s->d_so_key.p; p.so_doc = s->d_so_doc.p; p.so_cnt = s->d_so_cnt.p;
+    p.q_ticket = fused ? s->d_qticket.p : nullptr;
     // results straight into the caller's buffers when both live in device memory (then the call does not wait either)
     bool dev_out = false;
     {
@@ -1853,7 +1898,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
     if (any_phrase) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
     hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_slices), dim3(TPB), lds_score, st, p);
-    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
+    if (!fused) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
     ctx->ev_valid[1] = true;
     SS_HIP(ctx, hipGetLastError());
