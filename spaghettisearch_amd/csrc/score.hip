@@ -223,9 +223,25 @@ __device__ __forceinline__ uint32_t lower_bound_interp(uint64_t list_addr, uint3
         else if (db < v) { L = b; dl = db; }
         else { L = a; dl = da; H = b; dh = db; }
     }
+    // finish 8-ary: seven independent probes per step (one latency) instead of three dependent ones
     while (H - L > 1) {
-        const uint32_t mid = L + ((H - L) >> 1);
-        if (load_doc(list_addr, mid) < v) L = mid; else H = mid;
+        const uint32_t step = (H - L + 7) >> 3;                             // >= 1
+        uint32_t d[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) d[i] = load_doc(list_addr, min(L + step * (uint32_t)(i + 1), H - 1));
+        uint32_t nl = L, nh = H;
+#pragma unroll
+        for (int i = 6; i >= 0; i--) {
+            const uint32_t pos = min(L + step * (uint32_t)(i + 1), H - 1);
+            if (d[i] >= v) nh = pos;                                        // doc[pos] >= v: the answer is at or before pos
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const uint32_t pos = min(L + step * (uint32_t)(i + 1), H - 1);
+            if (d[i] < v) nl = max(nl, pos);                                // doc[pos] < v: the answer is after pos
+        }
+        L = nl;                                                             // every probe is on one side or the other:
+        H = nh;                                                             // the bracket shrinks to <= step
     }
     return H;
 }
@@ -876,12 +892,16 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
         }
     }
     __syncthreads();
+    DIAG_NOW(t_s1);
+    DIAG_ADD(6, t_s1 - t_k0);
     if (tid < 2 * L) {                      // the two bounds of a list by two threads: independent search chains
         const int l = tid >> 1;
         if (tid & 1) t_hi[l] = sd.dhi == 0xFFFFFFFFu ? S.f_cur[l] : lower_bound_interp(S.l_rec[l], 0, S.f_cur[l], sd.dhi);
         else t_lo[l] = sd.dlo == 0 ? 0u : lower_bound_interp(S.l_rec[l], 0, S.f_cur[l], sd.dlo);
     }
     __syncthreads();
+    DIAG_NOW(t_s2);
+    DIAG_ADD(7, t_s2 - t_s1);
     // fixed-point scale of the filter: the largest coefficient (an impact of 1.0 in that list) = FX_ONE units
     const float coef_max = __uint_as_float(*coef_max_bits);
     const float fx_scale = coef_max > 0.0f ? (float)FX_ONE / coef_max : 1.0f;
@@ -1525,7 +1545,7 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     {
         unsigned long long h[24];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h)) == hipSuccess) {
-            const char* names[12] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "-", "-", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total"};
+            const char* names[12] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "cyc_setup_lists", "cyc_setup_bounds", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total"};
             fprintf(stderr, "[ss diag] k_score_slices (thread 0 of every slice):");
             for (int i = 0; i < 12; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
             fprintf(stderr, "\n");
