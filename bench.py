@@ -403,6 +403,7 @@ def main() -> None:
             # ---- CPU baseline: the oracle on the same graph, bounded sample
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 from oracle import pyoracle
+                log("cpu baseline (PageRank): flat port, reference-shaped, OpenMP ...")
                 h_ptr = out_ptr.cpu().numpy().view(np.uint64)
                 h_dst = out_dst.cpu().numpy().view(np.uint32)
                 t0 = time.perf_counter()
@@ -665,6 +666,7 @@ def main() -> None:
 
             if keep_host:
                 from oracle import pyoracle
+                log("cpu baseline (top-k): flat port, reference-shaped, OpenMP ...")
                 title = (h_tptr, h_tdoc, wt)
                 body = (h_bptr, h_bdoc, wb)
                 ns = 64
@@ -680,23 +682,33 @@ def main() -> None:
                         "sample": f"first {ns} queries of the same batch, flat-array single-thread C restatement of "
                                   f"main_retrieve.go:50-103 + get_metadata.go:31-69 (oracle/oracle.c:orc_score_topk_batch)"}
                 # reference-shaped: string-keyed maps, appended weight slices, insertion-sort appendSort
-                # (util.go:48-54 is quadratic in the candidates: ~0.3 s per head query on one core, and memory-bound when
-                # every core runs one, so the sample is single-threaded and small)
+                # (util.go:48-54 is quadratic in the candidates — every insert shifts half of a ~100k-row slice of 152-byte
+                # Rank_combined structs: 10-80 s per head query on one core — so the sample is one query, more if time allows)
                 mm = pyoracle.MagMap(mt, mb)
-                nb1 = 4
-                t0 = time.perf_counter()
-                pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=False)
-                bdt = time.perf_counter() - t0
-                nb1 = int(max(4, min(ns, 64, nb1 * args.cpu_seconds / max(bdt, 1e-3) / 2)))
+                log(f"cpu baseline (top-k): flat port done ({ns} queries in {cdt:.1f}s); reference-shaped sample ...")
+                # appendSort is quadratic in a query's candidates, so the sample is sized by candidates, not by queries:
+                # time the first query, then take the longest prefix of the batch whose estimated cost (~ postings^2) fits
+                h_bp, h_tp = body[0].astype(np.int64), title[0].astype(np.int64)
+                qt = q_terms.astype(np.int64).reshape(-1, 3)
+                posts = ((h_bp[qt + 1] - h_bp[qt]) + (h_tp[qt + 1] - h_tp[qt])).sum(axis=1).astype(np.float64)
+                nb1 = 1
                 t0 = time.perf_counter()
                 hb1, nb1n, th1 = pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=False)
                 bdt = time.perf_counter() - t0
+                est = bdt * np.maximum((posts / posts[0]) ** 2, posts / posts[0])
+                more = int(min(ns, 64, np.searchsorted(np.cumsum(est), args.cpu_seconds)))
+                if more > 1 and bdt < args.cpu_seconds:
+                    nb1 = more
+                    t0 = time.perf_counter()
+                    hb1, nb1n, th1 = pyoracle.score_topk_batch_hashed(mm, title, body, q_ptr[:nb1 + 1], q_terms[:3 * nb1], k, threads=False)
+                    bdt = time.perf_counter() - t0
                 mm.close()
                 chk = min(nb1, ns)
                 b1_same = bool(np.array_equal(hb1["final"][:chk], ref["final"][:chk]))
                 topk["cpu_baseline"] = {"value": nb1 / bdt, "unit": "queries/s", "cores": 1, "kind": "port",
                                         "sample": f"reference-shaped restatement (B1) of main_retrieve.go:61-97 + get_metadata.go:46-69 + "
-                                                  f"util.go:48-54 on the first {nb1} queries of the same batch, single thread "
+                                                  f"util.go:48-54 on the first {nb1} queries of the same batch ({int(posts[:nb1].sum())} postings; appendSort is quadratic "
+                                                  f"in a query's candidates), single thread "
                                                   f"(oracle/oracle.c:orc_score_topk_batch_hashed); forw[4] map built outside the timing",
                                         "final_ranks_match_flat_port": b1_same, "flat_port": flat}
                 t0 = time.perf_counter()

@@ -113,7 +113,7 @@ constexpr int DEPTH = 3;                             // windows whose records ar
 // clamped to FX_CLAMP; a slot that reaches FX_CLAMP counts as "unbounded" (its records survive).  PC records of
 // FX_CLAMP each stay below 2^32: the sums never wrap.
 constexpr uint32_t FX_ONE = 1u << 18;
-constexpr uint32_t FX_CLAMP = 1u << 21;
+constexpr uint32_t FX_CLAMP = SS_PC > 1024 ? 1u << 20 : 1u << 21;
 static_assert((uint64_t)FX_CLAMP * SS_PC < (1ull << 32), "filter sums must not wrap");
 constexpr int KTH_N = 11;                            // k'-th largest impact per term for k' = 2^0 .. 2^10
 static_assert(DEPTH == 3, "ring slots, filter tables and survivor counters rotate together");
