@@ -47,8 +47,9 @@ struct PrCtl {
     int32_t iters[MAXK];
     int32_t sweep;        // sweeps completed
     int32_t n_active;
-    uint32_t ticket;      // last-block arrival counter
+    uint32_t ticket;      // last-group arrival counter
     uint32_t pad;
+    uint32_t gticket[8];  // last-block-of-a-group arrival counters
 };
 
 enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3,   // GW < 8 (k_pr_step): block-owned items
@@ -198,34 +199,57 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // Two levels, so that nobody sums a thousand rows alone: the blocks form NG groups (block % NG); the last block of a
+    // group to arrive sums the group's rows (one batch of loads per thread) into a group row, the last group to finish
+    // sums the NG group rows.  Fixed grouping, fixed order: deterministic.
+    constexpr unsigned NG = 8;
+    constexpr int NCOL = 2 * GW;
+    constexpr int NPART = TPB / NCOL;
+    const unsigned ng = min(NG, gridDim.x);
+    const unsigned grp = blockIdx.x % ng;
+    const unsigned members = (gridDim.x - grp + ng - 1) / ng;         // blocks b = grp, grp + ng, ...
+    double* const gpart = p.partials + (size_t)gridDim.x * NCOL;      // [NG][NCOL] behind the block rows
     if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == gridDim.x - 1;
+        const unsigned prev = __hip_atomic_fetch_add(&p.ctl->gticket[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == members - 1;
     }
     __syncthreads();
     if (!s_last) return;
-
-    // deterministic column sums over all blocks: column = (which, topic); the loads go out in batches of 16
-    constexpr int NCOL = 2 * GW;
-    constexpr int NPART = TPB / NCOL;
     const int col = threadIdx.x % NCOL, part = threadIdx.x / NCOL;
-    double acc = 0.0;
-    for (unsigned b0 = part; b0 < gridDim.x; b0 += 16 * NPART) {
-        double v[16];
+    {
+        double acc = 0.0;
+        for (unsigned m0 = part; m0 < members; m0 += 16 * NPART) {
+            double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const unsigned b = b0 + u * NPART;
-            v[u] = __hip_atomic_load(&p.partials[(size_t)(b < gridDim.x ? b : b0) * NCOL + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < 16; u++) {
+                const unsigned m = m0 + u * NPART;
+                v[u] = __hip_atomic_load(&p.partials[(size_t)(grp + ng * (m < members ? m : m0)) * NCOL + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (m0 + u * NPART < members) acc += v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 16; u++)
-            if (b0 + u * NPART < gridDim.x) acc += v[u];
+        colsum[threadIdx.x] = acc;
     }
-    colsum[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < NCOL) {
         double v = 0.0;
         for (int q = 0; q < NPART; q++) v += colsum[q * NCOL + threadIdx.x];
+        __hip_atomic_store(&gpart[(size_t)grp * NCOL + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.ctl->gticket[grp] = 0;                                      // ready for the next launch (kernel boundary)
+        const unsigned prev = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == ng - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < NCOL) {
+        double v = 0.0;
+        for (unsigned gq = 0; gq < ng; gq++)
+            v += __hip_atomic_load(&gpart[(size_t)gq * NCOL + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tot[threadIdx.x / GW][threadIdx.x % GW] = v;
     }
     __syncthreads();
@@ -1226,7 +1250,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         SS_HIP(ctx, hipMemsetAsync(pr->send.p, 0, std::max<size_t>(pr->send.bytes(), 8), st));
     }
     const unsigned begin_blocks = std::max(1u, std::min(2048u, ss::div_up(n_local * GW, TPB)));
-    SS_HIP(ctx, pr->partials.alloc((size_t)std::max(pr->nblocks, begin_blocks) * 2 * GW));
+    SS_HIP(ctx, pr->partials.alloc(((size_t)std::max(pr->nblocks, begin_blocks) + 8) * 2 * GW));   // block rows + 8 group rows
     SS_HIP(ctx, pr->segpart.alloc((size_t)std::max(nsegs, 1u) * GW));
     SS_HIP(ctx, pr->rowticket.alloc(std::max(nmulti, 1u)));
     SS_HIP(ctx, hipMemsetAsync(pr->rowticket.p, 0, pr->rowticket.bytes(), st));
