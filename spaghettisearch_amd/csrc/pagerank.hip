@@ -509,28 +509,16 @@ __device__ __forceinline__ void finish_row(SweepCtx<GW>& c, uint32_t lrow, doubl
     const PrParams& p = c.p;
     y += c.x0;
     const size_t xi = (size_t)lrow * GW + c.t;
-#ifdef SS_PR_EXP_NODIVV
-    double xn = (y + teleport_of(p, lrow, c.t)) * (1.0 / c.S);   // 1/S is loop-invariant: hoisted
-#else
     double xn = (y + teleport_of(p, lrow, c.t)) / c.S;      // pagerank.go:117
-#endif
     if (c.act) {
-#ifndef SS_PR_EXP_NOSTOREV
         NT_STORE(xn, &p.x[xi]);
-#endif
         c.dsum += fabs(xn - xo);                              // pagerank.go:118
     } else {
         xn = xo;                                              // converged topic: frozen
     }
     if (lrow < p.sl_nd) {                                     // non-dangling row: next sweep's contribution
-#ifdef SS_PR_EXP_NODIVV
-        const double cc = p.d * xn * (double)__builtin_amdgcn_rcpf((float)od);
-#else
         const double cc = p.d * xn / (double)od;              // pagerank.go:136
-#endif
-#ifndef SS_PR_EXP_NOSTOREV
         NT_STORE(cc, &c.Tw[xi]);
-#endif
         c.csum += cc;                                         // pagerank.go:137
     }
 }
@@ -569,21 +557,10 @@ __device__ __forceinline__ void long_rows(SweepCtx<GW>& c, const WorkItem* __res
             idx_turn<GW>(p.in_src, e1, turn_fill(e1, lim), p.zrow, c.t, src_n);
             double v[CH];
             gather_turn<GW>(c.T, src, c.t, c.gbase, v);
-#ifdef SS_PR_DEBUG
-            {
-                double sv = 0.0;
-                for (int j = 0; j < CH; j++) sv += v[j];
-                if (c.t == 0 && cur.row == 2 && p.ctl->sweep == 0) printf("[turn] i %u slot %d src %u e1 %u lim %u sv %.6e srcn %u zrow %u nn %u\n", i, c.slot, src[0], e1, lim, sv, src_n[0], p.zrow, turn_fill(e1, lim));
-            }
-#endif
 #pragma unroll
             for (int j = 0; j < CH; j++) acc += v[j];
         }
         const double y = wave_sum_topic<GW>(acc);
-#ifdef SS_PR_DEBUG
-        if (lane == 0) printf("[long] wave %u it %u/%u-%u kind %u row %u beg %u end %u turns %u y %.6e xo %.6e od %u\n", blockIdx.x * WAVES + (threadIdx.x >> 6), it, i0, i1,
-                              cur.kind, cur.row, cur.beg, cur.end, turns, y, xo, od);
-#endif
         if (cur.kind == V_ROWW) {
             if (lane < GW) finish_row<GW>(c, lrow, y, xo, od);
         } else {
@@ -764,20 +741,17 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     // gets the same number of turns (ss_pr_create); one loop per class, so that the register allocator sees each
     // pipeline on its own instead of the union of all of them.
     const uint32_t* __restrict__ off = p.woff + (size_t)(blockIdx.x * WAVES + wave) * 8;
-#ifndef SS_PR_ONLY
-#define SS_PR_ONLY 63
-#endif
 #ifdef SS_PR_EXP_KINDMASK
 #define SS_PR_CLASS_ON(c) ((p.kind_mask >> (8 + (c))) & 1u)
 #else
 #define SS_PR_CLASS_ON(c) true
 #endif
-    if ((SS_PR_ONLY & 1) && SS_PR_CLASS_ON(0)) long_rows<GW>(c, p.work, off[0], off[1], lane);
-    if ((SS_PR_ONLY & 2) && SS_PR_CLASS_ON(1)) quad_rows<GW>(c, p.work, off[1], off[2]);
-    if ((SS_PR_ONLY & 4) && SS_PR_CLASS_ON(2)) deg_rows<GW, 2>(c, p.work, off[2], off[3]);
-    if ((SS_PR_ONLY & 8) && SS_PR_CLASS_ON(3)) deg_rows<GW, 4>(c, p.work, off[3], off[4]);
-    if ((SS_PR_ONLY & 16) && SS_PR_CLASS_ON(4)) deg_rows<GW, 8>(c, p.work, off[4], off[5]);
-    if ((SS_PR_ONLY & 32) && SS_PR_CLASS_ON(5))
+    if (SS_PR_CLASS_ON(0)) long_rows<GW>(c, p.work, off[0], off[1], lane);
+    if (SS_PR_CLASS_ON(1)) quad_rows<GW>(c, p.work, off[1], off[2]);
+    if (SS_PR_CLASS_ON(2)) deg_rows<GW, 2>(c, p.work, off[2], off[3]);
+    if (SS_PR_CLASS_ON(3)) deg_rows<GW, 4>(c, p.work, off[3], off[4]);
+    if (SS_PR_CLASS_ON(4)) deg_rows<GW, 8>(c, p.work, off[4], off[5]);
+    if (SS_PR_CLASS_ON(5))
     for (uint32_t item = off[5]; item < off[6]; item++) {
         const WorkItem w = p.work[item];
         // V_ZERO: non-dangling rows without in-edges: their rank is the shared value xz, only the next contribution
