@@ -189,8 +189,10 @@ int32_t ss_pr_read(ss_pr* pr, double* rank_out);
 /* Diagnostic (bench.py roofline.gather_ceiling_ms; no reference counterpart): average milliseconds of a gather-ONLY
  * pass over this state's in-edge stream and contribution table with the sweep's own load shape — what the access
  * pattern of computeRankInherited (pagerank.go:126-145) costs on this chip with every other part of the sweep
- * removed.  mode 0 = the graph's index stream, 1 = uniformly random rows (no hub reuse), 2 = consecutive rows.
- * k_topics >= 5 only. */
+ * removed.  mode 0 = the graph's index stream, 1 = uniformly random rows (no hub reuse), 2 = consecutive rows;
+ * + 8 * p selects the cache policy of the gathers (p = 0 default, 1 non-temporal, 2 sc1, 3 / 4 default for the rows
+ * below SS_PR_PROBE_HOT and non-temporal / sc1 for the others: tools/pr_probe_pol.py).  States that run the 8- or
+ * 16-wide sweep only. */
 int32_t ss_pr_probe(ss_pr* pr, int32_t mode, int32_t n_reps, float* ms_out);
 
 /* ---- inverted index + TF-IDF: ranking/term_weighting.go:10-123 --------- */
