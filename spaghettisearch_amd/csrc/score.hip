@@ -278,6 +278,11 @@ __device__ unsigned long long g_slice[4096][4];      // per launch index: {start
 #define DIAG_ADD(i, v) do { } while (0)
 #define DIAG_NOW(var) do { } while (0)
 #endif
+#ifdef SS_DIAG
+#define DIAG_NOWX(var) DIAG_NOW(var)
+#else
+#define DIAG_NOWX(var) do { } while (0)
+#endif
 
 // ---- running top-k in LDS ------------------------------------------------------
 struct TopK {
@@ -1020,8 +1025,13 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
             uint32_t* sk_prv = S.sk + prv_ * SK;                                                                           \
             uint32_t h[CPW], u[CPW];                                                                                       \
             /* stage 1a: every record adds its share into its doc's slot (waits for THIS window's records only) */        \
+            DIAG_NOWX(t_a0_);                                                                                              \
             chunk_add<S_>(sk_cur, lane, rec, cnt, cf, h);                                                                  \
+            DIAG_NOWX(t_a1_);                                                                                              \
             lds_barrier();                                                                                                 \
+            DIAG_NOWX(t_a2_);                                                                                              \
+            DIAG_ADD(12, t_a1_ - t_a0_);                                                                                   \
+            DIAG_ADD(13, t_a2_ - t_a1_);                                                                                   \
             /* ONE round of LDS latency for everything the rest of the step needs: the survivor count of the previous */  \
             /* window (complete now, stable until its counter is re-used), this window's slots, the plan row of the   */  \
             /* window that is requested next                                                                          */  \
@@ -1545,9 +1555,9 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     {
         unsigned long long h[24];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h)) == hipSuccess) {
-            const char* names[12] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "cyc_setup_lists", "cyc_setup_bounds", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total"};
+            const char* names[14] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "cyc_setup_lists", "cyc_setup_bounds", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total", "cyc_win_add", "cyc_win_barrier"};
             fprintf(stderr, "[ss diag] k_score_slices (thread 0 of every slice):");
-            for (int i = 0; i < 12; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+            for (int i = 0; i < 14; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
             fprintf(stderr, "\n");
         }
         static unsigned long long hs[4096][4];
