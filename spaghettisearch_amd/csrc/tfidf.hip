@@ -256,7 +256,7 @@ __global__ __launch_bounds__(TPB) void k_weight_count(const uint64_t* __restrict
 #pragma unroll
                 for (int j = 0; j < PER_THREAD; j++) {
                     const uint32_t x = x0 + j;
-                    if (x >= n_here) break;
+                    if (x >= n_here) continue;
                     while (k + 1 < need && s_tp[k + 1] <= x) k++;
                     t = t0 + k;
                     if (k + 1 >= need) {                              // past the staged window: rare (long runs of empty terms)
