@@ -239,3 +239,23 @@ def test_reference_stop_threshold(ss_ctx, oracle, n, e, seed):
         g.close()
         assert ref_it.max() < 300 and np.abs(it - ref_it).max() <= 1, (it.tolist(), ref_it.tolist())
         np.testing.assert_allclose(rank, ref, rtol=1e-12)
+
+
+def test_run_to_run_bit_identical(ss_ctx):
+    # static work deal, fixed-order partial sums, no float atomics: two runs (and two states on one graph) agree bit for bit
+    from spaghettisearch_amd import engine
+    n, e = 150000, 900000
+    ptr, dst = synth.rmat_graph(n, e, seed=77)
+    outs = []
+    for k_topics in (16, 5, 1):
+        n_topic = synth.topic_sizes(n, k_topics)
+        g = engine.Graph(ss_ctx, n, ptr, dst)
+        r1, i1 = g.pagerank(0.75, 1e-12, n_topic)
+        r2, i2 = g.pagerank(0.75, 1e-12, n_topic)
+        g.close()
+        g = engine.Graph(ss_ctx, n, ptr, dst)
+        r3, i3 = g.pagerank(0.75, 1e-12, n_topic)
+        g.close()
+        assert i1.tolist() == i2.tolist() == i3.tolist()
+        assert r1.tobytes() == r2.tobytes() == r3.tobytes()
+        outs.append(r1)
