@@ -283,6 +283,13 @@ __device__ unsigned long long g_slice[4096][4];      // per launch index: {start
 #else
 #define DIAG_NOWX(var) do { } while (0)
 #endif
+#if defined(SS_DIAG) && defined(SS_DIAG_LOOP)      // stamps INSIDE the window loop: they cost more than what they measure
+#define DIAG_NOWL(var) DIAG_NOW(var)
+#define DIAG_ADDL(i, v) DIAG_ADD(i, v)
+#else
+#define DIAG_NOWL(var) do { } while (0)
+#define DIAG_ADDL(i, v) do { } while (0)
+#endif
 
 // ---- running top-k in LDS ------------------------------------------------------
 struct TopK {
@@ -745,6 +752,7 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
     const uint32_t n_out = sc32[0];
 
     // explain: TitleRank/BodyRank of the winners, re-derived from the posting lists
+    DIAG_NOWX(t_m0);
     for (uint32_t i = tid; i < n_out; i += NT) { accT[i] = 0.0; accB[i] = 0.0; mgT[i] = 1.0; mgB[i] = 1.0; }
     __syncthreads();
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
@@ -779,6 +787,8 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
         }
     }
     __syncthreads();
+    DIAG_NOWX(t_m1);
+    DIAG_ADD(14, t_m1 - t_m0);
     const double qmag = p.qmag[q];
     const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
     for (uint32_t i = tid; i < (uint32_t)k; i += NT) {
@@ -1025,13 +1035,13 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
             uint32_t* sk_prv = S.sk + prv_ * SK;                                                                           \
             uint32_t h[CPW], u[CPW];                                                                                       \
             /* stage 1a: every record adds its share into its doc's slot (waits for THIS window's records only) */        \
-            DIAG_NOWX(t_a0_);                                                                                              \
+            DIAG_NOWL(t_a0_);                                                                                              \
             chunk_add<S_>(sk_cur, lane, rec, cnt, cf, h);                                                                  \
-            DIAG_NOWX(t_a1_);                                                                                              \
+            DIAG_NOWL(t_a1_);                                                                                              \
             lds_barrier();                                                                                                 \
-            DIAG_NOWX(t_a2_);                                                                                              \
-            DIAG_ADD(12, t_a1_ - t_a0_);                                                                                   \
-            DIAG_ADD(13, t_a2_ - t_a1_);                                                                                   \
+            DIAG_NOWL(t_a2_);                                                                                              \
+            DIAG_ADDL(12, t_a1_ - t_a0_);                                                                                   \
+            DIAG_ADDL(13, t_a2_ - t_a1_);                                                                                   \
             /* ONE round of LDS latency for everything the rest of the step needs: the survivor count of the previous */  \
             /* window (complete now, stable until its counter is re-used), this window's slots, the plan row of the   */  \
             /* window that is requested next                                                                          */  \
@@ -1555,9 +1565,9 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     {
         unsigned long long h[24];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h)) == hipSuccess) {
-            const char* names[14] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "cyc_setup_lists", "cyc_setup_bounds", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total", "cyc_win_add", "cyc_win_barrier"};
+            const char* names[15] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "cyc_setup_lists", "cyc_setup_bounds", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total", "cyc_win_add", "cyc_win_barrier", "cyc_merge_explain"};
             fprintf(stderr, "[ss diag] k_score_slices (thread 0 of every slice):");
-            for (int i = 0; i < 14; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+            for (int i = 0; i < 15; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
             fprintf(stderr, "\n");
         }
         static unsigned long long hs[4096][4];
