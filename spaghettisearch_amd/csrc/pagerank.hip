@@ -13,15 +13,17 @@
 // HBM layout (node-major, the K topic values of a node are contiguous so that ONE
 // index read serves K gathers and a K=16 gather is one 128-byte line):
 //   x     [n_local][GW]   rank of this rank's rows, updated in place
-//   table [nd_int ][GW]   contributions w_p of ALL non-dangling nodes, read by
-//                         random gather; written for the next sweep
+//   table [nd_int+1][GW]  contributions w_p of ALL non-dangling nodes, read by
+//                         random gather; written for the next sweep; the last row is
+//                         all zero (where the unused slots of a turn gather from)
 //                         (world==1: ping-pong pair; world>1: own slice -> `send`,
-//                          host all-gathers it into `table`)
-// One kernel per sweep.  The pull SpMV, the normalise, the L1 delta, the next
-// sweep's contributions and their sum (next `total`) are fused; block partial
-// sums are combined deterministically by the last block to arrive
-// (agent-scope release/acquire, cdna_hip_programming.md Guideline 16), which also
-// applies the stop rule — the loop needs no host round trip per iteration.
+//                          ss_pr_exchange all-gathers it into `table`)
+// One kernel per sweep (k_pr_sweep for K >= 3, k_pr_step for K <= 2 on large graphs).
+// The pull SpMV, the normalise, the L1 delta, the next sweep's contributions and
+// their sum (next `total`) are fused; block partial sums are handed to the last
+// block to arrive (write-through stores + ticket, no fences) and combined in a fixed
+// order; that block also applies the stop rule — the loop needs no host round trip
+// per iteration.
 //
 // Algorithmic bytes per sweep: 4E + 8N + 16*K*N.
 #include "graph.hpp"
