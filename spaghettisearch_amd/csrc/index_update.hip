@@ -34,17 +34,17 @@ __global__ void k_mark_docs(const uint32_t* __restrict__ del_docs, uint64_t n_de
     }
 }
 // keep[i] = 1 unless the posting's doc is deleted
-__global__ void k_keep_from_bitmap(const uint32_t* __restrict__ post_doc, uint64_t n_post, const uint32_t* __restrict__ bitmap, uint32_t* __restrict__ keep) {
+__global__ void k_keep_from_bitmap(const uint32_t* __restrict__ post_doc, uint64_t n_post, const uint32_t* __restrict__ bitmap, uint8_t* __restrict__ keep) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_post; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t d = post_doc[i];
-        keep[i] = (bitmap[d >> 5] >> (d & 31)) & 1u ? 0u : 1u;
+        keep[i] = (bitmap[d >> 5] >> (d & 31)) & 1u ? 0 : 1;
     }
 }
 // single postings to delete: locate (term, doc) by binary search; a pair that does not exist is ignored, like the
 // reference's delete(docP, docHash) on a map without the key
 __global__ void k_unkeep_pairs(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ post_doc, uint64_t n_terms, uint64_t n_docs,
                                const uint32_t* __restrict__ del_term, const uint32_t* __restrict__ del_doc, uint64_t n_del,
-                               uint32_t* __restrict__ keep, uint32_t* __restrict__ err) {
+                               uint8_t* __restrict__ keep, uint32_t* __restrict__ err) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_del; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t t = del_term[i], d = del_doc[i];
         if ((uint64_t)t >= n_terms || (uint64_t)d >= n_docs) { atomicOr(err, 2u); continue; }
@@ -54,7 +54,7 @@ __global__ void k_unkeep_pairs(const uint64_t* __restrict__ term_ptr, const uint
             const uint64_t mid = (lo + hi) >> 1;
             if (post_doc[mid] < d) lo = mid + 1; else hi = mid;
         }
-        if (lo < end && post_doc[lo] == d) keep[lo] = 0u;
+        if (lo < end && post_doc[lo] == d) keep[lo] = 0;
     }
 }
 __global__ void k_add_keys(const uint32_t* __restrict__ add_term, const uint32_t* __restrict__ add_doc, uint64_t n_add, uint64_t n_terms, uint64_t n_docs,
@@ -65,51 +65,77 @@ __global__ void k_add_keys(const uint32_t* __restrict__ add_term, const uint32_t
         keys[i] = ((uint64_t)t << 32) | d;
     }
 }
-// first index in the sorted add keys whose term is >= t
-__device__ __forceinline__ uint64_t add_lower(const uint64_t* __restrict__ keys, uint64_t n, uint64_t key) {
-    uint64_t lo = 0, hi = n;
+// first index in the sorted add keys whose key is >= `key`, inside [lo, hi)
+__device__ __forceinline__ uint32_t add_lower(const uint64_t* __restrict__ keys, uint32_t lo, uint32_t hi, uint64_t key) {
     while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
+        const uint32_t mid = (lo + hi) >> 1;
         if (keys[mid] < key) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
+// add_ptr[t] = first new posting of term t in the sorted delta (a CSR over the terms: the merge looks a term's additions
+// up with two loads instead of two searches per posting)
+__global__ void k_add_ptr(const uint64_t* __restrict__ add_keys, uint32_t n_add, uint64_t n_terms, uint32_t* __restrict__ add_ptr) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_terms) return;
+    add_ptr[t] = t == n_terms ? n_add : add_lower(add_keys, 0, n_add, t << 32);
+}
 // new list lengths: survivors + additions per term
-__global__ void k_new_counts(const uint64_t* __restrict__ term_ptr, const uint64_t* __restrict__ kept_before /*[P+1]*/, uint64_t n_terms,
-                             const uint64_t* __restrict__ add_keys, uint64_t n_add, uint64_t* __restrict__ cnt /*[T+1]*/) {
+__global__ void k_new_counts(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ kept_before /*[P+1]*/, uint64_t n_terms,
+                             const uint32_t* __restrict__ add_ptr, uint64_t* __restrict__ cnt /*[T+1]*/) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_terms) return;
     if (t == n_terms) { cnt[t] = 0; return; }
-    const uint64_t kept = kept_before[term_ptr[t + 1]] - kept_before[term_ptr[t]];
-    const uint64_t a0 = add_lower(add_keys, n_add, t << 32), a1 = add_lower(add_keys, n_add, (t + 1) << 32);
-    cnt[t] = kept + (a1 - a0);
+    cnt[t] = (uint64_t)(kept_before[term_ptr[t + 1]] - kept_before[term_ptr[t]]) + (add_ptr[t + 1] - add_ptr[t]);
 }
-// every surviving posting writes itself to its slot in the merged list.  `term_of`: the posting's term by binary search
-// in term_ptr over the block's span (as k_weight does).
+// every surviving posting writes itself to its slot in the merged list.  One block per CHUNK consecutive postings: the
+// block finds the terms its chunk spans with two binary searches, each posting finds its own term inside that short
+// range (a chunk of a long list is one term); a term without additions needs nothing more.
+constexpr int PK_PT = 8;
+constexpr int PK_CHUNK = TPB * PK_PT;
 __global__ __launch_bounds__(TPB) void k_place_kept(const uint64_t* __restrict__ term_ptr, uint64_t n_terms, const uint32_t* __restrict__ post_doc,
-                                                    const float* __restrict__ post_w, uint64_t n_post, const uint32_t* __restrict__ keep,
-                                                    const uint64_t* __restrict__ kept_before, const uint64_t* __restrict__ add_keys, uint64_t n_add,
-                                                    const uint64_t* __restrict__ new_ptr, uint32_t* __restrict__ out_doc, float* __restrict__ out_w) {
-    const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n_post || !keep[i]) return;
-    uint64_t lo = 0, hi = n_terms;            // largest t with term_ptr[t] <= i
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (term_ptr[mid] <= i) lo = mid; else hi = mid;
+                                                    const float* __restrict__ post_w, uint64_t n_post, const uint8_t* __restrict__ keep,
+                                                    const uint32_t* __restrict__ kept_before, const uint64_t* __restrict__ add_keys,
+                                                    const uint32_t* __restrict__ add_ptr, const uint64_t* __restrict__ new_ptr,
+                                                    uint32_t* __restrict__ out_doc, float* __restrict__ out_w) {
+    __shared__ uint64_t s_t[2];
+    const uint64_t base = (uint64_t)blockIdx.x * PK_CHUNK;
+    const uint64_t last = min(base + PK_CHUNK, n_post) - 1;
+    if (threadIdx.x < 2) {
+        const uint64_t target = threadIdx.x == 0 ? base : last;      // largest t with term_ptr[t] <= target
+        uint64_t lo = 0, hi = n_terms;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (term_ptr[mid] <= target) lo = mid; else hi = mid;
+        }
+        s_t[threadIdx.x] = lo;
     }
-    const uint64_t t = lo;
-    const uint32_t d = post_doc[i];
-    const uint64_t rank_kept = kept_before[i] - kept_before[term_ptr[t]];
-    const uint64_t a0 = add_lower(add_keys, n_add, t << 32);
-    const uint64_t adds_below = add_lower(add_keys, n_add, (t << 32) | d) - a0;
-    const uint64_t o = new_ptr[t] + rank_kept + adds_below;
-    out_doc[o] = d;
-    out_w[o] = post_w[i];
+    __syncthreads();
+    const uint64_t t_lo = s_t[0], t_hi = s_t[1];
+#pragma unroll 4
+    for (int j = 0; j < PK_PT; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        if (i > last) break;
+        if (!keep[i]) continue;
+        uint64_t lo = t_lo, hi = t_hi + 1;                            // term_ptr[lo] <= i < term_ptr[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (term_ptr[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint64_t t = lo;
+        const uint32_t d = post_doc[i];
+        const uint32_t rank_kept = kept_before[i] - kept_before[term_ptr[t]];
+        const uint32_t a0 = add_ptr[t], a1 = add_ptr[t + 1];
+        const uint32_t adds_below = a1 > a0 ? add_lower(add_keys, a0, a1, (t << 32) | d) - a0 : 0u;
+        const uint64_t o = new_ptr[t] + rank_kept + adds_below;
+        out_doc[o] = d;
+        out_w[o] = post_w[i];
+    }
 }
 // every new posting: its rank among the additions of its term + the survivors of the term with a smaller doc id
-__global__ void k_place_adds(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ post_doc, const uint32_t* __restrict__ keep,
-                             const uint64_t* __restrict__ kept_before, const uint64_t* __restrict__ add_keys, const uint32_t* __restrict__ add_order,
-                             const float* __restrict__ add_w, uint64_t n_add, const uint64_t* __restrict__ new_ptr,
+__global__ void k_place_adds(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ post_doc, const uint8_t* __restrict__ keep,
+                             const uint32_t* __restrict__ kept_before, const uint64_t* __restrict__ add_keys, const uint32_t* __restrict__ add_order,
+                             const float* __restrict__ add_w, uint64_t n_add, const uint32_t* __restrict__ add_ptr, const uint64_t* __restrict__ new_ptr,
                              uint32_t* __restrict__ out_doc, float* __restrict__ out_w, uint32_t* __restrict__ err) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_add) return;
@@ -117,7 +143,6 @@ __global__ void k_place_adds(const uint64_t* __restrict__ term_ptr, const uint32
     if (j > 0 && add_keys[j - 1] == key) { atomicOr(err, 8u); return; }             // the same (term, doc) twice in the delta
     const uint64_t t = key >> 32;
     const uint32_t d = (uint32_t)key;
-    const uint64_t a0 = add_lower(add_keys, n_add, t << 32);
     uint64_t lo = term_ptr[t], hi = term_ptr[t + 1];
     const uint64_t end = hi;
     while (lo < hi) {
@@ -125,20 +150,45 @@ __global__ void k_place_adds(const uint64_t* __restrict__ term_ptr, const uint32
         if (post_doc[mid] < d) lo = mid + 1; else hi = mid;
     }
     if (lo < end && post_doc[lo] == d && keep[lo]) { atomicOr(err, 16u); return; }   // the posting already exists and was not deleted
-    const uint64_t kept_below = kept_before[lo] - kept_before[term_ptr[t]];
-    const uint64_t o = new_ptr[t] + (j - a0) + kept_below;
+    const uint32_t kept_below = kept_before[lo] - kept_before[term_ptr[t]];
+    const uint64_t o = new_ptr[t] + ((uint32_t)j - add_ptr[t]) + kept_below;
     out_doc[o] = d;
     out_w[o] = add_w[add_order[j]];
 }
 __global__ void k_iota(uint32_t* __restrict__ v, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
 }
-// strictly ascending inside every list of the merged table
-__global__ void k_check_merged(const uint64_t* __restrict__ new_ptr, uint64_t n_terms, const uint32_t* __restrict__ doc, uint32_t* __restrict__ err) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_terms) return;
-    for (uint64_t i = new_ptr[t] + 1; i < new_ptr[t + 1]; i++)
-        if (doc[i] <= doc[i - 1]) { atomicOr(err, 32u); return; }
+// strictly ascending inside every list of the merged table: every posting looks at its predecessor (a term boundary is
+// found like in k_place_kept)
+__global__ __launch_bounds__(TPB) void k_check_merged(const uint64_t* __restrict__ new_ptr, uint64_t n_terms, const uint32_t* __restrict__ doc, uint64_t n_post,
+                                                      uint32_t* __restrict__ err) {
+    __shared__ uint64_t s_t[2];
+    const uint64_t base = (uint64_t)blockIdx.x * PK_CHUNK;
+    if (base >= n_post) return;
+    const uint64_t last = min(base + PK_CHUNK, n_post) - 1;
+    if (threadIdx.x < 2) {
+        const uint64_t target = threadIdx.x == 0 ? base : last;
+        uint64_t lo = 0, hi = n_terms;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (new_ptr[mid] <= target) lo = mid; else hi = mid;
+        }
+        s_t[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const uint64_t t_lo = s_t[0], t_hi = s_t[1];
+    bool bad = false;
+    for (int j = 0; j < PK_PT; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        if (i > last || i == 0) continue;
+        uint64_t lo = t_lo, hi = t_hi + 1;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (new_ptr[mid] <= i) lo = mid; else hi = mid;
+        }
+        if (i > new_ptr[lo] && doc[i] <= doc[i - 1]) bad = true;      // not the first posting of its list
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(err, 32u);
 }
 
 template <typename In, typename Out>
@@ -151,6 +201,17 @@ int32_t exclusive_scan_u64(ss_ctx* ctx, In in, Out out, size_t n) {
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SS_OK;
 }
+template <typename In, typename Out>
+int32_t exclusive_scan_u32(ss_ctx* ctx, In in, Out out, size_t n) {
+    size_t tmp_bytes = 0;
+    SS_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (uint32_t)0, n, rocprim::plus<uint32_t>(), ctx->stream));
+    ss::DevBuf<char> tmp;
+    SS_HIP(ctx, tmp.alloc(tmp_bytes));
+    SS_HIP(ctx, rocprim::exclusive_scan(tmp.p, tmp_bytes, in, out, (uint32_t)0, n, rocprim::plus<uint32_t>(), ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
 
 }  // namespace
 
@@ -169,16 +230,17 @@ int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t*
     const uint64_t P = idx->n_post, T = idx->n_terms, N = idx->n_docs;
     if (P + n_add >= ((uint64_t)1 << 32)) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_index_apply_delta: more than 2^32 postings");
 
-    ss::DevBuf<uint32_t> bitmap, keep, err, d_del_docs, d_del_term, d_del_doc, d_add_term, d_add_doc, order_in, order;
+    ss::DevBuf<uint32_t> bitmap, err, d_del_docs, d_del_term, d_del_doc, d_add_term, d_add_doc, order_in, order, kept_before, add_ptr;
+    ss::DevBuf<uint8_t> keep;
     ss::DevBuf<float> d_add_w;
-    ss::DevBuf<uint64_t> kept_before, keys_in, keys, cnt, new_ptr;
+    ss::DevBuf<uint64_t> keys_in, keys, cnt, new_ptr;
     SS_HIP(ctx, bitmap.alloc((N + 31) / 32));
     SS_HIP(ctx, keep.alloc(P + 1));
     SS_HIP(ctx, kept_before.alloc(P + 1));
     SS_HIP(ctx, err.alloc(1));
     SS_HIP(ctx, hipMemsetAsync(bitmap.p, 0, std::max<size_t>(bitmap.bytes(), 4), st));
     SS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(uint32_t), st));
-    SS_HIP(ctx, hipMemsetAsync(keep.p + P, 0, sizeof(uint32_t), st));
+    SS_HIP(ctx, hipMemsetAsync(keep.p + P, 0, 1, st));
     if (n_del_docs) {
         SS_HIP(ctx, d_del_docs.alloc(n_del_docs));
         SS_HIP(ctx, hipMemcpyAsync(d_del_docs.p, del_docs, n_del_docs * sizeof(uint32_t), hipMemcpyDefault, st));
@@ -214,15 +276,17 @@ int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t*
         SS_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.p, keys.p, order_in.p, order.p, (size_t)n_add, 0u, 64u, st));
         SS_HIP(ctx, hipStreamSynchronize(st));
     }
-    // survivors before every posting, new list lengths, new term_ptr
+    // survivors before every posting, the delta as a CSR over the terms, new list lengths, new term_ptr
     {
-        auto in_it = rocprim::make_transform_iterator(keep.p, [] __device__(uint32_t x) { return (uint64_t)x; });
-        SS_TRY(exclusive_scan_u64(ctx, in_it, kept_before.p, (size_t)(P + 1)));
+        auto in_it = rocprim::make_transform_iterator(keep.p, [] __device__(uint8_t x) { return (uint32_t)x; });
+        SS_TRY(exclusive_scan_u32(ctx, in_it, kept_before.p, (size_t)(P + 1)));
     }
+    SS_HIP(ctx, add_ptr.alloc(T + 1));
+    hipLaunchKernelGGL(k_add_ptr, dim3(grid_for(T + 1)), dim3(TPB), 0, st, (const uint64_t*)keys.p, (uint32_t)n_add, T, add_ptr.p);
     SS_HIP(ctx, cnt.alloc(T + 1));
     SS_HIP(ctx, new_ptr.alloc(T + 1));
-    hipLaunchKernelGGL(k_new_counts, dim3(grid_for(T + 1)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint64_t*)kept_before.p, T,
-                       (const uint64_t*)keys.p, n_add, cnt.p);
+    hipLaunchKernelGGL(k_new_counts, dim3(grid_for(T + 1)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint32_t*)kept_before.p, T,
+                       (const uint32_t*)add_ptr.p, cnt.p);
     SS_TRY(exclusive_scan_u64(ctx, cnt.p, new_ptr.p, (size_t)(T + 1)));
     std::vector<uint64_t> h_new_ptr(T + 1);
     SS_HIP(ctx, hipMemcpyAsync(h_new_ptr.data(), new_ptr.p, (T + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -232,13 +296,13 @@ int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t*
     ss::DevBuf<float> out_w;
     SS_HIP(ctx, out_doc.alloc(P2));
     SS_HIP(ctx, out_w.alloc(P2));
-    if (P) hipLaunchKernelGGL(k_place_kept, dim3(ss::div_up(P, TPB)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, T, (const uint32_t*)idx->post_doc.p,
-                              (const float*)idx->post_w.p, P, (const uint32_t*)keep.p, (const uint64_t*)kept_before.p, (const uint64_t*)keys.p, n_add,
-                              (const uint64_t*)new_ptr.p, out_doc.p, out_w.p);
+    if (P) hipLaunchKernelGGL(k_place_kept, dim3(ss::div_up(P, PK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, T, (const uint32_t*)idx->post_doc.p,
+                              (const float*)idx->post_w.p, P, (const uint8_t*)keep.p, (const uint32_t*)kept_before.p, (const uint64_t*)keys.p,
+                              (const uint32_t*)add_ptr.p, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p);
     if (n_add) hipLaunchKernelGGL(k_place_adds, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint32_t*)idx->post_doc.p,
-                                  (const uint32_t*)keep.p, (const uint64_t*)kept_before.p, (const uint64_t*)keys.p, (const uint32_t*)order.p,
-                                  (const float*)d_add_w.p, n_add, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p, err.p);
-    if (T) hipLaunchKernelGGL(k_check_merged, dim3(grid_for(T)), dim3(TPB), 0, st, (const uint64_t*)new_ptr.p, T, (const uint32_t*)out_doc.p, err.p);
+                                  (const uint8_t*)keep.p, (const uint32_t*)kept_before.p, (const uint64_t*)keys.p, (const uint32_t*)order.p,
+                                  (const float*)d_add_w.p, n_add, (const uint32_t*)add_ptr.p, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p, err.p);
+    if (P2) hipLaunchKernelGGL(k_check_merged, dim3(ss::div_up(P2, PK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)new_ptr.p, T, (const uint32_t*)out_doc.p, P2, err.p);
     SS_HIP(ctx, hipGetLastError());
     uint32_t h_err = 0;
     SS_HIP(ctx, hipMemcpyAsync(&h_err, err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
