@@ -63,7 +63,8 @@ def apply_model(rows, changed, del_pairs, add):
 
 
 @pytest.mark.parametrize("n_docs,n_terms,n_post,n_changed,n_pairs,n_add", [
-    (64, 16, 300, 5, 10, 40), (5000, 800, 60000, 200, 500, 3000), (200000, 40000, 3000000, 5000, 20000, 80000)])
+    (64, 16, 300, 5, 10, 40), (5000, 800, 60000, 200, 500, 3000), (200000, 40000, 3000000, 5000, 20000, 80000),
+    (3000, 50000, 20000, 300, 400, 6000)])        # most terms empty: chunks span thousands of terms
 def test_delta_equals_rebuild(ss_ctx, oracle, n_docs, n_terms, n_post, n_changed, n_pairs, n_add):
     from spaghettisearch_amd import engine
     rng = np.random.default_rng(n_terms)
