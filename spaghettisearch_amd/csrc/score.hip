@@ -146,6 +146,11 @@ struct ScoreParams {
     Rec* x_rec[4];             // 0: body sums (driver body pass), 1: title sums (driver body pass), 2: body (title pass), 3: title (title pass)
     float* x_w[4];             // the float32 weight sums themselves (phrase.go:59,69,73,83,90)
     uint32_t* x_cnt;           // [n_q][4]
+    // k_phrase_match runs one workgroup per PART (<= PH_PART candidates of the driver's body or title list): parts of a query
+    // write their matches compactly from the part's own offset, k_phrase_close then closes the gaps per query
+    const uint4* ph_parts;     // [n_parts] {query, pass, first candidate (index inside the driver's list), candidates}
+    const uint32_t* ph_pbase;  // [n_q+1] parts of query q: ph_parts[ph_pbase[q] .. ph_pbase[q+1])
+    uint32_t* ph_pcnt;         // [n_parts][2] matches found by the part: body sums, title sums
     const double* prior;       // [n_docs][k_topics] or null
     int32_t k_topics;
     const uint32_t* q_off;     // [n_q+1] into dterm/dmult
@@ -244,6 +249,11 @@ __device__ __forceinline__ uint32_t lower_bound_interp(uint64_t list_addr, uint3
         H = nh;                                                             // the bracket shrinks to <= step
     }
     return H;
+}
+
+// lower_bound over records a[lo .. hi) (one posting list: shorter than 2^32) with the interpolation search
+__device__ __forceinline__ uint64_t lower_bound_rec_interp(const Rec* __restrict__ a, uint64_t lo, uint64_t hi, uint32_t v) {
+    return lo + lower_bound_interp((uint64_t)(a + lo), 0u, (uint32_t)(hi - lo), v);
 }
 
 // get_metadata.go:53-69 for one candidate
@@ -1235,17 +1245,17 @@ __device__ __forceinline__ float impact_of(float w, double mag) {
     return __double2float_ru((double)w / mag);
 }
 
+constexpr uint32_t PH_PART = 8192;   // candidates per k_phrase_match workgroup
 __global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
     __shared__ int32_t s_pb[PH_MAX * PH_TPB];     // body posting index of term i for this thread's doc, -1 = none
     __shared__ int32_t s_pt[PH_MAX * PH_TPB];
     __shared__ uint32_t s_wave[2][PH_TPB / 64];
     __shared__ uint32_t s_base[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t q = blockIdx.x;
+    const uint4 part = p.ph_parts[blockIdx.x];
+    const uint32_t q = part.x;
+    const int pass = (int)part.y;
     const uint32_t f0 = p.ph_off[q], m = p.ph_off[q + 1] - f0;
-    uint32_t* cnt = p.x_cnt + (size_t)q * 4;
-    if (tid < 4) cnt[tid] = 0;
-    if (m == 0 || p.ph_drv[q] == 0xFFFFFFFFu) return;       // no phrase / a phrase word unknown to the index
     const uint32_t drv_term = p.ph_terms[f0 + p.ph_drv[q]];
     const uint64_t* pos_ptr2[2] = {p.b_pos_ptr, p.t_pos_ptr};
     const float* pos2[2] = {p.b_pos, p.t_pos};
@@ -1253,80 +1263,108 @@ __global__ __launch_bounds__(PH_TPB) void k_phrase_match(ScoreParams p) {
     int32_t* my_pt = s_pt + tid;
     if (tid < 2) s_base[tid] = 0;
     __syncthreads();
-
-    for (int pass = 0; pass < 2; pass++) {
-        // pass 0: driver's body postings; pass 1: driver's title postings whose doc has no driver body posting
-        const uint64_t c0 = pass == 0 ? p.b_ptr[drv_term] : p.t_ptr[drv_term];
-        const uint64_t c1 = pass == 0 ? p.b_ptr[drv_term + 1] : p.t_ptr[drv_term + 1];
-        const Rec* crec = pass == 0 ? p.b_rec : p.t_rec;
-        if (tid < 2) s_base[tid] = 0;
-        __syncthreads();
-        for (uint64_t cb = c0; cb < c1; cb += PH_TPB) {
-            const uint64_t ci = cb + tid;
-            bool body_ok = false, title_ok = false;
-            float sum_b = 0.0f, sum_t = 0.0f;
-            uint32_t d = 0;
-            if (ci < c1) {
-                d = crec[ci].doc;
-                bool all = true, body_all = true, title_all = true;
-                if (pass == 1) {
-                    const uint64_t b0 = p.b_ptr[drv_term], b1 = p.b_ptr[drv_term + 1];
-                    const uint64_t pos = lower_bound_rec(p.b_rec, b0, b1, d);
-                    if (pos < b1 && p.b_rec[pos].doc == d) all = false;       // already handled in pass 0
-                }
-                for (uint32_t i = 0; i < m && all; i++) {
-                    const uint32_t term = p.ph_terms[f0 + i];
-                    const uint64_t b0 = p.b_ptr[term], b1 = p.b_ptr[term + 1];
-                    const uint64_t t0 = p.t_ptr[term], t1 = p.t_ptr[term + 1];
-                    const uint64_t pb = lower_bound_rec(p.b_rec, b0, b1, d);
-                    const uint64_t pt = lower_bound_rec(p.t_rec, t0, t1, d);
-                    const bool hb = pb < b1 && p.b_rec[pb].doc == d, ht = pt < t1 && p.t_rec[pt].doc == d;
-                    my_pb[i * PH_TPB] = hb ? (int32_t)pb : -1;
-                    my_pt[i * PH_TPB] = ht ? (int32_t)pt : -1;
-                    if (!hb && !ht) all = false;                      // phrase.go:63
-                    if (hb) sum_b += p.b_w[pb]; else body_all = false;          // phrase.go:69,80-84
-                    if (ht) sum_t += p.t_w[pt]; else title_all = false;         // phrase.go:73,87-91
-                }
-                if (all) {
-                    if (body_all) body_ok = positions_chain(pos_ptr2, pos2, 0, my_pb, (int)m);
-                    if (title_all) title_ok = positions_chain(pos_ptr2, pos2, 1, my_pt, (int)m);
-                }
+    // pass 0: driver's body postings; pass 1: driver's title postings whose doc has no driver body posting
+    const uint64_t l0 = pass == 0 ? p.b_ptr[drv_term] : p.t_ptr[drv_term];
+    const uint64_t c0 = l0 + part.z, c1 = c0 + part.w;
+    const Rec* crec = pass == 0 ? p.b_rec : p.t_rec;
+    const uint32_t out0 = p.x_off[q] + part.z;    // the part's matches go out compactly from its first candidate's slot
+    for (uint64_t cb = c0; cb < c1; cb += PH_TPB) {
+        const uint64_t ci = cb + tid;
+        bool body_ok = false, title_ok = false;
+        float sum_b = 0.0f, sum_t = 0.0f;
+        uint32_t d = 0;
+        if (ci < c1) {
+            d = crec[ci].doc;
+            bool all = true, body_all = true, title_all = true;
+            if (pass == 1) {
+                const uint64_t b0 = p.b_ptr[drv_term], b1 = p.b_ptr[drv_term + 1];
+                const uint64_t pos = lower_bound_rec_interp(p.b_rec, b0, b1, d);
+                if (pos < b1 && p.b_rec[pos].doc == d) all = false;       // already handled in pass 0
             }
-            // ordered compaction of the matches of this chunk (keeps the lists doc-sorted)
-            const unsigned long long mb = __ballot(body_ok), mt = __ballot(title_ok);
-            if (lane == 0) { s_wave[0][wave] = (uint32_t)__popcll(mb); s_wave[1][wave] = (uint32_t)__popcll(mt); }
-            __syncthreads();
-            uint32_t ob = s_base[0], ot = s_base[1];
-            for (int w2 = 0; w2 < wave; w2++) { ob += s_wave[0][w2]; ot += s_wave[1][w2]; }
-            const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-            if (body_ok) {
-                const uint32_t o = p.x_off[q] + ob + (uint32_t)__popcll(mb & below);
-                const int x = pass == 0 ? 0 : 2;
-                Rec r;
-                r.doc = d; r.imp = impact_of(sum_b, p.b_mag[d]);
-                p.x_rec[x][o] = r;
-                p.x_w[x][o] = sum_b;
+            for (uint32_t i = 0; i < m && all; i++) {
+                const uint32_t term = p.ph_terms[f0 + i];
+                const uint64_t b0 = p.b_ptr[term], b1 = p.b_ptr[term + 1];
+                const uint64_t t0 = p.t_ptr[term], t1 = p.t_ptr[term + 1];
+                const uint64_t pb = lower_bound_rec_interp(p.b_rec, b0, b1, d);
+                const uint64_t pt = lower_bound_rec_interp(p.t_rec, t0, t1, d);
+                const bool hb = pb < b1 && p.b_rec[pb].doc == d, ht = pt < t1 && p.t_rec[pt].doc == d;
+                my_pb[i * PH_TPB] = hb ? (int32_t)pb : -1;
+                my_pt[i * PH_TPB] = ht ? (int32_t)pt : -1;
+                if (!hb && !ht) all = false;                      // phrase.go:63
+                if (hb) sum_b += p.b_w[pb]; else body_all = false;          // phrase.go:69,80-84
+                if (ht) sum_t += p.t_w[pt]; else title_all = false;         // phrase.go:73,87-91
             }
-            if (title_ok) {
-                const uint32_t o = p.x_off[q] + ot + (uint32_t)__popcll(mt & below);
-                const int x = pass == 0 ? 1 : 3;
-                Rec r;
-                r.doc = d; r.imp = impact_of(sum_t, p.t_mag[d]);
-                p.x_rec[x][o] = r;
-                p.x_w[x][o] = sum_t;
+            if (all) {
+                if (body_all) body_ok = positions_chain(pos_ptr2, pos2, 0, my_pb, (int)m);
+                if (title_all) title_ok = positions_chain(pos_ptr2, pos2, 1, my_pt, (int)m);
             }
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t tb = 0, tt = 0;
-                for (int w2 = 0; w2 < PH_TPB / 64; w2++) { tb += s_wave[0][w2]; tt += s_wave[1][w2]; }
-                s_base[0] += tb;
-                s_base[1] += tt;
-            }
-            __syncthreads();
         }
-        if (tid == 0) { cnt[pass == 0 ? 0 : 2] = s_base[0]; cnt[pass == 0 ? 1 : 3] = s_base[1]; }
+        // ordered compaction of the matches of this chunk (keeps the lists doc-sorted)
+        const unsigned long long mb = __ballot(body_ok), mt = __ballot(title_ok);
+        if (lane == 0) { s_wave[0][wave] = (uint32_t)__popcll(mb); s_wave[1][wave] = (uint32_t)__popcll(mt); }
+        __syncthreads();
+        uint32_t ob = s_base[0], ot = s_base[1];
+        for (int w2 = 0; w2 < wave; w2++) { ob += s_wave[0][w2]; ot += s_wave[1][w2]; }
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        if (body_ok) {
+            const uint32_t o = out0 + ob + (uint32_t)__popcll(mb & below);
+            const int x = pass == 0 ? 0 : 2;
+            Rec r;
+            r.doc = d; r.imp = impact_of(sum_b, p.b_mag[d]);
+            x_rec_of(p, x)[o] = r;
+            x_w_of(p, x)[o] = sum_b;
+        }
+        if (title_ok) {
+            const uint32_t o = out0 + ot + (uint32_t)__popcll(mt & below);
+            const int x = pass == 0 ? 1 : 3;
+            Rec r;
+            r.doc = d; r.imp = impact_of(sum_t, p.t_mag[d]);
+            x_rec_of(p, x)[o] = r;
+            x_w_of(p, x)[o] = sum_t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tb = 0, tt = 0;
+            for (int w2 = 0; w2 < PH_TPB / 64; w2++) { tb += s_wave[0][w2]; tt += s_wave[1][w2]; }
+            s_base[0] += tb;
+            s_base[1] += tt;
+        }
         __syncthreads();
     }
+    if (tid < 2) p.ph_pcnt[(size_t)blockIdx.x * 2 + tid] = s_base[tid];
+}
+
+// Per query: the parts' match runs, each compact from its own offset, are moved down into one contiguous doc-sorted list
+// per result kind (in part order = doc order), and the four counts are written.  Only matches move.
+__global__ __launch_bounds__(PH_TPB) void k_phrase_close(ScoreParams p) {
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    uint32_t run[4] = {0u, 0u, 0u, 0u};
+    const uint32_t base = p.x_off[q];
+    for (uint32_t pi = p.ph_pbase[q]; pi < p.ph_pbase[q + 1]; pi++) {
+        const uint4 part = p.ph_parts[pi];
+        for (int kind = 0; kind < 2; kind++) {
+            const int x = (int)part.y * 2 + kind;
+            const uint32_t n = p.ph_pcnt[(size_t)pi * 2 + kind];
+            const uint32_t src = base + part.z, dst = base + run[x];
+            if (n && src != dst) {
+                Rec* xr = x_rec_of(p, x);
+                float* xw = x_w_of(p, x);
+                // dst < src and the ranges may overlap: a chunk is read whole before it is written
+                for (uint32_t i0 = 0; i0 < n; i0 += PH_TPB) {
+                    const uint32_t i = i0 + (uint32_t)tid;
+                    Rec r{};
+                    float w = 0.f;
+                    if (i < n) { r = xr[src + i]; w = xw[src + i]; }
+                    __syncthreads();
+                    if (i < n) { xr[dst + i] = r; xw[dst + i] = w; }
+                    __syncthreads();
+                }
+            }
+            run[x] += n;
+        }
+    }
+    if (tid < 4) p.x_cnt[(size_t)q * 4 + tid] = run[tid];
 }
 
 size_t score_lds_bytes(int cb) { return score_lds_layout(cb).total; }
@@ -1476,7 +1514,7 @@ struct ss_scorer {
     int plan_turn = 0;
     ss::DevBuf<Rec> d_x[4];                     // phrase result lists: scoring records
     ss::DevBuf<float> d_xw[4];                  // ... and their float32 weight sums
-    ss::DevBuf<uint32_t> d_xcnt;
+    ss::DevBuf<uint32_t> d_xcnt, d_pcnt;
     ss::DevBuf<uint64_t> d_so_key;
     ss::DevBuf<uint32_t> d_so_doc, d_so_cnt, d_qticket;
     size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
@@ -1686,7 +1724,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     std::vector<uint32_t> h_terms(n_tok);
     if (n_tok) SS_HIP(ctx, hipMemcpy(h_terms.data(), q_terms, n_tok * sizeof(uint32_t), hipMemcpyDefault));
     // phrase part (retrieval/phrase.go): tokens of all quoted phrases of a query, concatenated
-    std::vector<uint32_t> h_pptr(n_q + 1, 0), h_pterms, h_pdrv(n_q, 0xFFFFFFFFu), h_xoff(n_q + 1, 0);
+    std::vector<uint32_t> h_pptr(n_q + 1, 0), h_pterms, h_pdrv(n_q, 0xFFFFFFFFu), h_xoff(n_q + 1, 0), h_pbase(n_q + 1, 0);
+    std::vector<uint4> h_parts;                 // k_phrase_match work: {query, pass, first candidate, candidates}
     if (p_ptr) {
         if (!s->title->pos_ptr.p || !s->body->pos_ptr.p)
             return ctx->fail(SS_ERR_STATE, "ss_score_topk_phrase: positional postings not loaded (ss_index_set_positions on both tables)");
@@ -1725,6 +1764,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     for (int q = 0; q < n_q && p_ptr; q++) {
         const uint32_t m = h_pptr[q + 1] - h_pptr[q];
         h_xoff[q + 1] = h_xoff[q];
+        h_pbase[q + 1] = (uint32_t)h_parts.size();
         if (m == 0) continue;
         any_phrase = true;
         if (m > 16) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_score_topk_phrase: query %d has a phrase of %u terms (max 16)", q, m);
@@ -1736,8 +1776,18 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
             const uint64_t df = (tp[t + 1] - tp[t]) + (bp[t + 1] - bp[t]);
             if (df < best) { best = df; h_pdrv[q] = i; }
         }
+        h_pbase[q + 1] = (uint32_t)h_parts.size();
         if (!known) { h_pdrv[q] = 0xFFFFFFFFu; continue; }
         h_xoff[q + 1] = h_xoff[q] + (uint32_t)std::min<uint64_t>(best, 0x7FFFFFFFull);   // matches <= docs of the rarest term
+        // candidates = the rarest term's body postings (pass 0), then its title postings (pass 1), PH_PART per workgroup
+        const uint32_t dt = h_pterms[h_pptr[q] + h_pdrv[q]];
+        const uint64_t nbody = bp[dt + 1] - bp[dt], ntitle = tp[dt + 1] - tp[dt];
+        for (int pass = 0; pass < 2; pass++) {
+            const uint64_t nc = pass == 0 ? nbody : ntitle;
+            for (uint64_t c = 0; c < nc; c += PH_PART)
+                h_parts.push_back(make_uint4((uint32_t)q, (uint32_t)pass, (uint32_t)c, (uint32_t)std::min<uint64_t>(PH_PART, nc - c)));
+        }
+        h_pbase[q + 1] = (uint32_t)h_parts.size();
     }
     // Slice size: SLICE_TARGET postings when the batch fills the chip several times over; smaller (down to
     // SLICE_MIN) for small batches, so that one query's lists are spread over many CUs instead of being
@@ -1830,6 +1880,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const size_t o_pterms = o; o = align16(o + h_pterms.size() * sizeof(uint32_t));
     const size_t o_pdrv = o;   o = align16(o + n_q * sizeof(uint32_t));
     const size_t o_xoff = o;   o = align16(o + (n_q + 1) * sizeof(uint32_t));
+    const size_t o_pbase = o;  o = align16(o + (n_q + 1) * sizeof(uint32_t));
+    const size_t o_parts = o;  o = align16(o + h_parts.size() * sizeof(uint4));
     const size_t o_probs = o;  o = align16(o + h_probs.size() * sizeof(double));
     const size_t plan_bytes = o;
     const int pb = s->plan_turn;
@@ -1862,6 +1914,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_pterms.empty()) std::memcpy(hp + o_pterms, h_pterms.data(), h_pterms.size() * sizeof(uint32_t));
     std::memcpy(hp + o_pdrv, h_pdrv.data(), n_q * sizeof(uint32_t));
     std::memcpy(hp + o_xoff, h_xoff.data(), (n_q + 1) * sizeof(uint32_t));
+    std::memcpy(hp + o_pbase, h_pbase.data(), (n_q + 1) * sizeof(uint32_t));
+    if (!h_parts.empty()) std::memcpy(hp + o_parts, h_parts.data(), h_parts.size() * sizeof(uint4));
     if (!h_probs.empty()) std::memcpy(hp + o_probs, h_probs.data(), h_probs.size() * sizeof(double));
     SS_HIP(ctx, hipMemcpyAsync(s->d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, st));
     SS_HIP(ctx, hipEventRecord(s->plan_ev[pb], st));
@@ -1872,6 +1926,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
             SS_HIP(ctx, ensure(s->d_xw[x], (size_t)h_xoff[n_q]));
         }
         SS_HIP(ctx, ensure(s->d_xcnt, (size_t)n_q * 4));
+        SS_HIP(ctx, ensure(s->d_pcnt, std::max<size_t>(h_parts.size(), 1) * 2));
     }
     SS_HIP(ctx, ensure(s->d_so_key, n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_doc, n_slices * k));
@@ -1898,6 +1953,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         p.x_off = reinterpret_cast<const uint32_t*>(dp + o_xoff);
         for (int x = 0; x < 4; x++) { p.x_rec[x] = s->d_x[x].p; p.x_w[x] = s->d_xw[x].p; }
         p.x_cnt = s->d_xcnt.p;
+        p.ph_parts = reinterpret_cast<const uint4*>(dp + o_parts);
+        p.ph_pbase = reinterpret_cast<const uint32_t*>(dp + o_pbase);
+        p.ph_pcnt = s->d_pcnt.p;
     }
     p.prior = K ? s->prior.p : nullptr;
     p.k_topics = K;
@@ -1936,7 +1994,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         s->lds_attr = cb;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
-    if (any_phrase) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
+    if (any_phrase) {
+        if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, st, p);
+        hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
+    }
     hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_slices), dim3(TPB), lds_score, st, p);
     if (!fused) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));

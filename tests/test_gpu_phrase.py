@@ -83,3 +83,63 @@ def test_phrase_matches_oracle(ss_ctx, oracle):
     sc.close()
     ti.close()
     bi.close()
+
+
+def positional_table_fast(n_docs, n_terms, n_post, seed, max_pos=12):
+    """vectorised variant for larger tables: c consecutive positions from a random start, sometimes a -100 anchor entry"""
+    tp, pd, _ = synth.zipf_index(n_docs, n_terms, n_post, seed=seed, q=1000.0, clip_frac=0.9)
+    rng = np.random.default_rng(seed + 100)
+    n = len(pd)
+    c = rng.integers(1, 4, size=n)
+    anchor = rng.random(n) < 0.1
+    cnt = c + anchor
+    pos_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+    start = rng.integers(0, max_pos, size=n).astype(np.float32)
+    within = (np.arange(int(pos_ptr[-1])) - np.repeat(pos_ptr[:-1].astype(np.int64), cnt)).astype(np.float32)
+    pos = np.repeat(start, cnt) + within
+    last = np.repeat(c, cnt) == within.astype(np.int64)            # the extra slot of anchored postings
+    pos[last] = np.float32(-100.0)
+    tf = (cnt / 8.0).astype(np.float32)
+    return (tp, pd, tf), (pos_ptr, pos.astype(np.float32))
+
+
+def test_phrase_candidates_over_several_workgroups(ss_ctx, oracle):
+    # the rarest phrase term has more postings than one k_phrase_match workgroup takes (8192): the parts' match runs are
+    # closed up per query by k_phrase_close; bit-exact against the oracle, title pass included
+    from spaghettisearch_amd import engine
+    n_docs, n_terms = 60000, 10
+    (bt, bpos) = positional_table_fast(n_docs, n_terms, 330000, seed=15)
+    (tt, tpos) = positional_table_fast(n_docs, n_terms, 150000, seed=16, max_pos=4)
+    assert np.diff(bt[0].astype(np.int64)).min() > 2 * 8192 and np.diff(tt[0].astype(np.int64)).min() > 8192
+    wb, mb, _ = oracle.tfidf(*bt, n_docs, n_docs)
+    wt, mt, _ = oracle.tfidf(*tt, n_docs, n_docs)
+    title, body = (tt[0], tt[1], wt), (bt[0], bt[1], wb)
+    ti = engine.InvertedIndex(ss_ctx, n_docs, *title)
+    bi = engine.InvertedIndex(ss_ctx, n_docs, *body)
+    ti.set_weighted(mt)
+    bi.set_weighted(mb)
+    ti.set_positions(*tpos)
+    bi.set_positions(*bpos)
+    sc = engine.Scorer(ss_ctx, ti, bi)
+    try:
+        cases = [([], [0, 1]), ([2], [3, 4]), ([], [5, 6, 7]), ([1], [9, 8]), ([], [4])]
+        q_terms = np.array([t for q, _ in cases for t in q], dtype=np.uint32)
+        q_ptr = np.concatenate([[0], np.cumsum([len(q) for q, _ in cases])]).astype(np.uint32)
+        p_terms = np.array([t for _, ph in cases for t in ph], dtype=np.uint32)
+        p_ptr = np.concatenate([[0], np.cumsum([len(ph) for _, ph in cases])]).astype(np.uint32)
+        hits, n_hits = sc.score_topk_phrase(q_ptr, q_terms, p_ptr, p_terms, 300)
+        n_phrase_docs = 0
+        for qi, (q, ph) in enumerate(cases):
+            extra = oracle.phrase(title, body, tpos, bpos, ph)
+            n_phrase_docs += len(extra[0])
+            ref, _ = oracle.score_topk(n_docs, title, body, mt, mb, np.array(q, np.uint32), 300, query_len=len(q) + len(ph), extra=extra)
+            n = int(n_hits[qi])
+            assert n == len(ref), (qi, n, len(ref))
+            assert hits["doc"][qi, :n].tolist() == ref["doc"].tolist(), qi
+            for f in ("title", "body", "final"):
+                assert np.array_equal(hits[f][qi, :n], ref[f]), (qi, f)
+        assert n_phrase_docs > 1000
+    finally:
+        sc.close()
+        ti.close()
+        bi.close()
