@@ -11,6 +11,9 @@ kt = int(os.environ.get("K", "16"))
 out_ptr, out_dst = synth.rmat_graph_torch(n, e, seed=42, device=dev)
 g = engine.Graph(ctx, n, out_ptr, out_dst)
 pr = engine.PageRankState(g, 0.75, -1.0, synth.topic_sizes(n, kt), max_iter=0)
+if os.environ.get("TS"):      # opt-in topic-sensitive teleport: topic k teleports to a random 1/16 of the nodes
+    rng = np.random.default_rng(3)
+    pr.set_teleport([rng.choice(n, size=n // 16, replace=False).astype(np.uint32) for _ in range(kt)])
 pr.begin()
 pr.step(5)
 ms = []
