@@ -675,7 +675,9 @@ int32_t ss_index_refresh_magnitudes(ss_index* idx, double* mag_out) {
     int shift = 13;
     if ((N >> shift) >= (uint64_t)NB_MAX) shift = 14;
     const uint64_t nb64 = ss::div_up(std::max<uint64_t>(N, 1), (uint64_t)1 << shift);
-    const bool bucketed = P >= ((uint64_t)1 << 22) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
+    uint64_t min_p = (uint64_t)1 << 22;
+    if (const char* e = std::getenv("SS_TFIDF_BUCKET_MIN")) min_p = std::strtoull(e, nullptr, 10);     // tests, A/B (as in ss_tfidf_build)
+    const bool bucketed = P >= std::max<uint64_t>(min_p, 1) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
     SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
     if (bucketed) {
         BucketPass bp;

@@ -186,3 +186,18 @@ def test_scorers_must_be_recreated_and_then_score_the_new_table(ss_ctx, oracle):
             sc.close()
         title.close()
         body.close()
+
+
+def test_refresh_magnitudes_bucketed_pass(ss_ctx, monkeypatch):
+    # ss_index_refresh_magnitudes on a table sent down the bucketed (large-table) pass: same bits as the float64 sums
+    from spaghettisearch_amd import engine
+    monkeypatch.setenv("SS_TFIDF_BUCKET_MIN", "1")
+    for n_docs, n_terms, n_post in ((9000, 300, 120000), (70000, 5000, 900000), (1, 1, 1)):
+        tp, pd, tf = synth.zipf_index(n_docs, n_terms, min(n_post, n_docs * n_terms // 2 + 1), seed=n_docs)
+        ix = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
+        try:
+            mag = ix.refresh_magnitudes()
+        finally:
+            ix.close()
+        ref = np.sqrt(np.bincount(pd, weights=(tf * tf).astype(np.float32).astype(np.float64), minlength=n_docs))
+        assert np.array_equal(mag, ref)
