@@ -1778,7 +1778,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
         h_pbase[q + 1] = (uint32_t)h_parts.size();
         if (!known) { h_pdrv[q] = 0xFFFFFFFFu; continue; }
-        h_xoff[q + 1] = h_xoff[q] + (uint32_t)std::min<uint64_t>(best, 0x7FFFFFFFull);   // matches <= docs of the rarest term
+        if ((uint64_t)h_xoff[q] + best >= (1ull << 32))
+            return ctx->fail(SS_ERR_UNSUPPORTED, "ss_score_topk_phrase: the phrases of this batch have more than 2^32 candidate documents (split the batch)");
+        h_xoff[q + 1] = h_xoff[q] + (uint32_t)best;   // matches <= docs of the rarest term
         // candidates = the rarest term's body postings (pass 0), then its title postings (pass 1), PH_PART per workgroup
         const uint32_t dt = h_pterms[h_pptr[q] + h_pdrv[q]];
         const uint64_t nbody = bp[dt + 1] - bp[dt], ntitle = tp[dt + 1] - tp[dt];
