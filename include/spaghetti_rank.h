@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 2
+#define SS_ABI_VERSION 3
 
 enum {
     SS_OK = 0,
@@ -87,6 +87,13 @@ int32_t ss_shutdown(ss_ctx* ctx);
  * stream here, or synchronise the producer first.  Host pointers need nothing. */
 int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream);
 int32_t ss_synchronize(ss_ctx* ctx);
+/* Tuning and diagnostic switches of one context (no reference counterpart; nothing reads the environment).  The
+ * defaults are the measured best; tests use the switches to reach kernel variants that the defaults would not pick
+ * at test sizes ("pr.force_narrow", "tfidf.bucket_min", "score.exact_all", "score.separate_merge"), experiments to
+ * sweep a parameter.  Unknown names are SS_ERR_INVALID; SS_OPTION_DEFAULT restores the default.  An option is read
+ * when the object it concerns is created or the call it concerns is made. */
+#define SS_OPTION_DEFAULT INT64_MIN
+int32_t ss_set_option(ss_ctx* ctx, const char* name, int64_t value);
 const char* ss_last_error(ss_ctx* ctx); /* ctx may be NULL: last global error */
 
 /* ---- multi-GPU: one context (= one GPU) per rank, collectives inside the library (RCCL over xGMI) -----------

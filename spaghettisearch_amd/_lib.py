@@ -50,6 +50,7 @@ PROTOTYPES = {
     "ss_shutdown": (_i32, [_vp]),
     "ss_set_stream": (_i32, [_vp, _vp]),
     "ss_synchronize": (_i32, [_vp]),
+    "ss_set_option": (_i32, [_vp, C.c_char_p, C.c_int64]),
     "ss_last_error": (C.c_char_p, [_vp]),
     "ss_comm_unique_id": (_i32, [_vp]),
     "ss_comm_init": (_i32, [_vp, _vp, _i32, _i32]),

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -35,6 +36,12 @@ struct ss_ctx {
     int tfidf_bucket_lds = 0;          // dynamic LDS size already granted to k_bucket_sum on this device
     void* comm = nullptr;              // RCCL communicator of this rank (ss_comm_init), ncclComm_t
     int comm_rank = 0, comm_world = 1;
+    // tuning / diagnostic options (ss_set_option); the defaults live at the point of use
+    std::map<std::string, int64_t> options;
+    int64_t opt(const char* name, int64_t dflt) const {
+        auto it = options.find(name);
+        return it == options.end() ? dflt : it->second;
+    }
 
     int32_t fail(int32_t code, const char* fmt, ...) {
         char buf[1024];

@@ -92,6 +92,33 @@ int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream) {
     return SS_OK;
 }
 
+// Every option a call site reads; ss_set_option refuses anything else, so a typo cannot silently do nothing.
+static const char* const k_option_names[] = {
+    "pr.force_narrow",      // 1: K <= 2 always runs the block-item kernel k_pr_step (tests reach it on small graphs)
+    "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
+    "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
+    "pr.probe_hot",         // ss_pr_probe policies 3/4: rows below this index use the default cache policy
+    "pr.topic_blocks",      // ss_pagerank_run_sharded: split K into this many topic blocks whose exchanges overlap the next block's sweep
+    "tfidf.blocks",         // workgroups of the bucketed magnitude pass (default 1024)
+    "tfidf.bucket_shift",   // log2 docs per bucket (default 13, 14 beyond 33M docs)
+    "tfidf.bucket_min",     // smallest table (postings) that takes the bucketed pass (default 4M)
+    "score.exact_all",      // 1: switch the upper-bound filter off (every record takes the exact stage)
+    "score.slice_target",   // postings per (query, slice) workgroup (default: from the batch)
+    "score.separate_merge", // 1: the per-query merge runs as its own launch (k_merge_topk)
+};
+
+int32_t ss_set_option(ss_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return SS_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    for (const char* n : k_option_names)
+        if (std::strcmp(n, name) == 0) {
+            if (value == SS_OPTION_DEFAULT) ctx->options.erase(name);
+            else ctx->options[name] = value;
+            return SS_OK;
+        }
+    return ctx->fail(SS_ERR_INVALID, "ss_set_option: unknown option '%s'", name);
+}
+
 int32_t ss_synchronize(ss_ctx* ctx) {
     if (!ctx) return SS_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);

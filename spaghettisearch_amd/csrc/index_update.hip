@@ -276,6 +276,16 @@ int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t*
         SS_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.p, keys.p, order_in.p, order.p, (size_t)n_add, 0u, 64u, st));
         SS_HIP(ctx, hipStreamSynchronize(st));
     }
+    // Range errors stop the update HERE: the placement kernels below index term_ptr / add_ptr / new_ptr by the delta's
+    // term ids, so an out-of-range id must never reach them.
+    {
+        uint32_t h_early = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&h_early, err.p, sizeof(h_early), hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        if (h_early & 1) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: del_docs holds a doc id >= n_docs (table unchanged)");
+        if (h_early & 2) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a (term, doc) to delete is out of range (table unchanged)");
+        if (h_early & 4) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a posting to add is out of range (table unchanged)");
+    }
     // survivors before every posting, the delta as a CSR over the terms, new list lengths, new term_ptr
     {
         auto in_it = rocprim::make_transform_iterator(keep.p, [] __device__(uint8_t x) { return (uint32_t)x; });

@@ -330,9 +330,9 @@ __device__ __forceinline__ double gather_sum(const double* __restrict__ T, const
     return (a0 + a1) + (a2 + a3);
 }
 
-// ---- the sweep, K <= 4 (GW = 1 / 2 / 4) ----------------------------------------
+// ---- the sweep, K <= 2 (GW = 1 / 2) on graphs whose padded table would not stay cache-resident ---------------
 // Persistent grid: a fixed number of blocks walks the work table round-robin, so the
-// per-launch costs (partials, ticket) are paid ~2k times, not per work item.  (K >= 5: k_pr_sweep below.)
+// per-launch costs (partials, ticket) are paid ~2k times, not per work item.  (K >= 3: k_pr_sweep below.)
 template <int GW>
 __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
     constexpr int NSLOT = 64 / GW;
@@ -398,25 +398,21 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
             } else {
                 // several blocks share this row: publish the segment partial; the last
                 // arriver adds the partials in segment order and finishes the row
-                if (threadIdx.x < GW) p.segpart[(size_t)(w.sbase + w.count) * GW + t] = y;
+                // (the fence-free hand-off of block_reduce_and_publish / long_rows: the partial is stored write-through by
+                // wave 0, which drains its stores and then takes the ticket itself; the last arriver reads with sc1 loads)
+                if (threadIdx.x < GW) __hip_atomic_store(&p.segpart[(size_t)(w.sbase + w.count) * GW + t], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
                 if (threadIdx.x == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned prev = __hip_atomic_fetch_add(&p.rowticket[w.tix], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int last = prev == w.nseg - 1;
-                    if (last) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        p.rowticket[w.tix] = 0;
-                    }
+                    if (last) __hip_atomic_store(&p.rowticket[w.tix], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_rowlast = last;
                 }
                 __syncthreads();
                 if (s_rowlast && threadIdx.x < GW) {
                     double ys = 0.0;
-                    for (uint32_t q = 0; q < w.nseg; q++) ys += p.segpart[(size_t)(w.sbase + q) * GW + t];
+                    for (uint32_t q = 0; q < w.nseg; q++)
+                        ys += __hip_atomic_load(&p.segpart[(size_t)(w.sbase + q) * GW + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     finish(lrow, ys);
                 }
             }
@@ -949,16 +945,15 @@ struct ss_pr {
 
 namespace {
 
-int pick_gw(int k, uint64_t table_rows) {
+int pick_gw(int k, uint64_t table_rows, bool force_narrow) {
     // K = 3, 4 run the wave-item sweep padded to 8 topics (measured on the 10M/50M R-MAT at K=4: 0.77 ms against 0.94 ms
     // for the 4-wide block-item kernel; at K=1 the narrow kernel wins there, 0.55 against 0.79 ms).  K <= 2 on a graph whose
     // padded table stays cache-resident (<= 64 MB of 64-byte rows) also takes it: the padding costs no HBM traffic then
     // and the wave-item pipeline is quicker than the block-item one (2^20 nodes / 5M edges, K=1: 0.134 against 0.19 ms)
     if (k >= 3 && k <= 8) return 8;
-    if (k <= 2 && table_rows * 64 <= (64ull << 20)) return 8;
-    int gw = 1;
-    while (gw < k) gw <<= 1;
-    return gw;
+    if (k <= 2 && table_rows * 64 <= (64ull << 20) && !force_narrow) return 8;   // "pr.force_narrow": tests reach k_pr_step on small graphs
+    if (k <= 2) return k;
+    return 16;
 }
 
 void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
@@ -978,7 +973,7 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
     auto emit_v = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
         const uint32_t T_MULTI = 4096, T_DEG = 8;
-        const uint32_t T_QUAD = getenv("SS_PR_T_QUAD") ? (uint32_t)atoi(getenv("SS_PR_T_QUAD")) : 256u;
+        const uint32_t T_QUAD = (uint32_t)g->ctx->opt("pr.t_quad", 256);
         uint32_t r = 0;
         for (; r < cnt && deg[r] > T_MULTI; r++) {
             const uint32_t ns = (deg[r] + SEGW - 1) / SEGW;
@@ -1101,7 +1096,6 @@ void launch_read(ss_pr* pr, hipStream_t st, int by_orig, uint64_t stride, uint32
     switch (gw) {                            \
         case 1: fn<1>(__VA_ARGS__); break;   \
         case 2: fn<2>(__VA_ARGS__); break;   \
-        case 4: fn<4>(__VA_ARGS__); break;   \
         case 8: fn<8>(__VA_ARGS__); break;   \
         default: fn<16>(__VA_ARGS__); break; \
     }
@@ -1127,7 +1121,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     std::unique_ptr<ss_pr> guard(pr);
     pr->g = g;
     pr->k = k_topics;
-    pr->gw = pick_gw(k_topics, g->nd_int);
+    pr->gw = pick_gw(k_topics, g->nd_int, ctx->opt("pr.force_narrow", 0) != 0);
     const int GW = pr->gw;
     const size_t n_local = g->n_local();
 
@@ -1141,7 +1135,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     int per_cu = 8;
     SS_GW_DISPATCH(GW, sweep_occupancy, &per_cu);
     if (per_cu < 1) per_cu = 1;
-    if (const char* e = getenv("SS_PR_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
+    per_cu = (int)std::max<int64_t>(1, ctx->opt("pr.blocks_per_cu", per_cu));
     pr->nblocks = GW >= 8 ? (unsigned)std::min<size_t>(ss::div_up(items.size(), (size_t)WAVES), (size_t)ctx->cu_count * per_cu)
                           : (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
     std::vector<uint32_t> woff;
@@ -1554,7 +1548,7 @@ int32_t ss_pr_probe(ss_pr* pr, int32_t mode, int32_t n_reps, float* ms_out) {
     if (mode < 0 || (mode & 7) > 2 || (mode >> 3) > 4 || n_reps < 1) return ctx->fail(SS_ERR_INVALID, "ss_pr_probe: mode 0..2 (+ 8 * gather cache policy 0..4), n_reps >= 1");
     const int pol = mode >> 3;
     mode &= 7;
-    const uint32_t hot = getenv("SS_PR_PROBE_HOT") ? (uint32_t)strtoul(getenv("SS_PR_PROBE_HOT"), nullptr, 0) : 24576u;
+    const uint32_t hot = (uint32_t)ctx->opt("pr.probe_hot", 24576);
     const ss_graph* g = pr->g;
     const unsigned nb = (unsigned)ctx->cu_count * 8;
     ss::DevBuf<double> sink;

@@ -1586,7 +1586,7 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     SS_HIP(ctx, hipMemcpyAsync(&h_flags, flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->clean = h_flags == 0;
-    if (const char* e = std::getenv("SS_SCORE_EXACT_ALL")) s->clean = s->clean && std::atoi(e) == 0;   // tests: force the filter off
+    if (ctx->opt("score.exact_all", 0) != 0) s->clean = false;   // tests: force the filter off
     title->users++;
     body->users++;
     *out = s.release();
@@ -1807,8 +1807,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         // 1.5x the batch's postings per resident workgroup slot, never below SLICE_MIN (a slice costs ~45 us of
         // threshold warm-up whatever its size) nor above SLICE_TARGET
         slice_target = std::min<uint64_t>(SLICE_TARGET, std::max<uint64_t>(SLICE_MIN, batch_tot * 3 / (2 * slots)));
-        static const char* env = std::getenv("SS_SLICE_TARGET");       // experiments only
-        if (env && *env) slice_target = std::max<uint64_t>(1024, std::strtoull(env, nullptr, 10));
+        slice_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.slice_target", (int64_t)slice_target));   // experiments only
     }
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
     std::vector<double> h_qmag(n_q), h_ub(n_q, 0.0);
@@ -1933,7 +1932,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     SS_HIP(ctx, ensure(s->d_so_key, n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_doc, n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_cnt, n_slices));
-    const bool fused = std::getenv("SS_SCORE_SEPARATE_MERGE") == nullptr;
+    const bool fused = ctx->opt("score.separate_merge", 0) == 0;
     if (fused && s->qticket_zeroed < (size_t)n_q) {
         SS_HIP(ctx, ensure(s->d_qticket, (size_t)n_q));
         SS_HIP(ctx, hipMemsetAsync(s->d_qticket.p, 0, (size_t)n_q * sizeof(uint32_t), st));

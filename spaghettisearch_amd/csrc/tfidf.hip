@@ -510,7 +510,7 @@ int32_t bucket_pass_prepare(ss_ctx* ctx, uint64_t P, uint32_t nb, int shift, Buc
     // blocks own contiguous ranges whose length is a multiple of both passes' chunk sizes; ~1024 ranges
     const uint64_t unit = std::max<uint64_t>(SC_CH, CH);
     static_assert(SC_CH % CH == 0 || CH % SC_CH == 0, "a range must be whole chunks of both passes");
-    const uint64_t target_blocks = getenv("SS_TFIDF_NBLK") ? (uint64_t)atoi(getenv("SS_TFIDF_NBLK")) : 1024;
+    const uint64_t target_blocks = (uint64_t)std::max<int64_t>(1, ctx->opt("tfidf.blocks", 1024));
     bp.per = std::max<uint64_t>(unit, ss::div_up(ss::div_up(P, target_blocks), unit) * unit);
     bp.nblk = (uint32_t)ss::div_up(P, bp.per);
     SS_HIP(ctx, bp.mat.alloc((size_t)nb * bp.nblk));
@@ -632,12 +632,11 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     SS_HIP(ctx, idf.alloc(T));
     // large tables: bucketed magnitude pass (no global float64 atomics); small ones: one atomic per posting
     int shift = 13;                                                   // 8192 docs per bucket = 64 KB of float64 LDS accumulators
-    if (const char* e = std::getenv("SS_TFIDF_SHIFT")) shift = std::max(10, std::min(14, atoi(e)));
+    shift = (int)std::max<int64_t>(10, std::min<int64_t>(14, ctx->opt("tfidf.bucket_shift", shift)));
     if ((N >> shift) >= (uint64_t)NB_MAX) shift = 14;
     const uint64_t nb64 = ss::div_up(std::max<uint64_t>(N, 1), (uint64_t)1 << shift);
-    // SS_TFIDF_BUCKET_MIN (tests, A/B): smallest table that takes the bucketed pass; a huge value forces the atomics
-    uint64_t min_p = (uint64_t)1 << 22;
-    if (const char* e = std::getenv("SS_TFIDF_BUCKET_MIN")) min_p = std::strtoull(e, nullptr, 10);
+    // "tfidf.bucket_min" (tests, A/B): smallest table that takes the bucketed pass; a huge value forces the atomics
+    const uint64_t min_p = (uint64_t)ctx->opt("tfidf.bucket_min", (int64_t)1 << 22);
     const bool bucketed = P >= std::max<uint64_t>(min_p, 1) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
     const uint32_t nb = (uint32_t)nb64;
     BucketPass bp;
@@ -675,8 +674,7 @@ int32_t ss_index_refresh_magnitudes(ss_index* idx, double* mag_out) {
     int shift = 13;
     if ((N >> shift) >= (uint64_t)NB_MAX) shift = 14;
     const uint64_t nb64 = ss::div_up(std::max<uint64_t>(N, 1), (uint64_t)1 << shift);
-    uint64_t min_p = (uint64_t)1 << 22;
-    if (const char* e = std::getenv("SS_TFIDF_BUCKET_MIN")) min_p = std::strtoull(e, nullptr, 10);     // tests, A/B (as in ss_tfidf_build)
+    const uint64_t min_p = (uint64_t)ctx->opt("tfidf.bucket_min", (int64_t)1 << 22);     // tests, A/B (as in ss_tfidf_build)
     const bool bucketed = P >= std::max<uint64_t>(min_p, 1) && P < ((uint64_t)1 << 32) && nb64 <= (uint64_t)NB_MAX;
     SS_HIP(ctx, hipMemsetAsync(idx->mag.p, 0, N * sizeof(double), st));
     if (bucketed) {

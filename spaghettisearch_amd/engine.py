@@ -101,6 +101,25 @@ class Context:
     def synchronize(self) -> None:
         check(self.lib.ss_synchronize(self.h), self.h)
 
+    def set_option(self, name: str, value: Optional[int]) -> None:
+        """ss_set_option: tuning / diagnostic switch of this context; None restores the default."""
+        check(self.lib.ss_set_option(self.h, name.encode(), -(1 << 63) if value is None else int(value)), self.h)
+
+    def options(self, **kv):
+        """Context manager: set options (dots written as double underscores: pr__force_narrow=1), restore the defaults on exit."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                for k, v in kv.items():
+                    ctx.set_option(k.replace("__", "."), v)
+
+            def __exit__(self_inner, *exc):
+                for k in kv:
+                    ctx.set_option(k.replace("__", "."), None)
+                return False
+        return _Scope()
+
     # ---- in-library collectives (RCCL over xGMI): one context per rank
     @staticmethod
     def comm_unique_id() -> bytes:

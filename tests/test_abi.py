@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"not exported: {missing}"
     # the Python binding covers exactly the declared set
     assert sorted(_lib.PROTOTYPES) == declared_symbols()
-    assert _lib.load().ss_abi_version() == 2
+    assert _lib.load().ss_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device():
@@ -72,4 +72,4 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
                     "-lspaghetti_rank", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
-    assert out.startswith("abi=2 init=")
+    assert out.startswith("abi=3 init=")

@@ -45,10 +45,18 @@ def test_pagerank_config4_graph(ss_ctx, oracle):
     # (3) a state that met the stop rule is a fixed point to the stop tolerance: one more sweep moves it by < eps
     assert np.abs(x4 - x3).sum(axis=1).max() < 1e-6
     pr.close()
-    # (4) a topic run on its own (another kernel instantiation) agrees with its column of the 16-wide run
+    # (4) a topic run on its own and a pair of topics (k_pr_step<1> and <2>: 3.2M non-dangling rows x 64 B leave the caches,
+    #     so the narrow block-item kernel is what the default picks here) against the oracle and the 16-wide run
     alone, it1 = g.pagerank(D, 1e-6, [int(n_topic[5])])
     assert int(it1[0]) == int(iters[5])
     np.testing.assert_allclose(alone[0], rank[5], rtol=1e-13)
+    pair, it2 = g.pagerank(D, 1e-6, [int(n_topic[0]), int(n_topic[K - 1])])
+    assert it2.tolist() == [int(iters[0]), int(iters[K - 1])]
+    np.testing.assert_allclose(pair[0], rank[0], rtol=1e-13)
+    np.testing.assert_allclose(pair[1], rank[K - 1], rtol=1e-13)
+    ref1, ref1_it = oracle.pagerank(N, h_ptr, h_dst, D, 1e-6, [int(n_topic[5])])
+    assert int(it1[0]) == int(ref1_it[0])
+    np.testing.assert_allclose(alone[0], ref1[0], rtol=1e-12)
     # (5) two doc-range shards (one process plays the all-gather) reproduce the unsharded ranks
     stream = torch.cuda.Stream()
     ss_ctx.set_stream(stream.cuda_stream)

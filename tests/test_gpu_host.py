@@ -46,7 +46,14 @@ def corpus():
     cats = {"Arts": {"numPages": 900.0, "wordCount": 1e4}, "Science": {"numPages": 412.0, "wordCount": 5e3},
             "Sports": {"numPages": 77.0, "wordCount": 2e3}}
 
-    def inverted(p_doc, seed):
+    uncrawled = sorted({doc.index(c) for v in children.values() for c in v} - set(range(n_crawled)))
+    anchor_only = set()
+
+    def inverted(p_doc, seed, anchors):
+        """anchors: the table also holds anchor/meta words, which parser.getWordInfo (parser/parser.go:195-207) stores
+        as position float32(-100), appended AFTER the real positions and counted in the term frequency; the anchor
+        text of a link lands in the TITLE row of the child (indexer.go:261-300), so uncrawled children own title
+        postings that consist of -100 entries only."""
         r = np.random.default_rng(seed)
         table = {}
         for wi, w in enumerate(word):
@@ -56,13 +63,22 @@ def corpus():
             for d in ds:
                 m = int(r.integers(1, 17))
                 c = int(r.integers(1, m + 1))
-                tf = float(np.float32(c) / np.float32(m))
                 pos = sorted(r.integers(0, 500, size=c).astype(float).tolist())
+                if anchors and r.random() < 0.3:
+                    k = int(r.integers(1, 4))
+                    pos += [-100.0] * k                    # not sorted: the reference sorts inside intersect (util.go:187-188)
+                    c, m = c + k, m + k
+                tf = float(np.float32(c) / np.float32(m))
                 row[doc[int(d)]] = [tf] + pos              # [normTF, positions...] (indexer.go:362)
+            if anchors:
+                for d in r.choice(uncrawled, size=min(len(uncrawled), 1 + wi % 7), replace=False):
+                    k = int(r.integers(1, 4))
+                    row[doc[int(d)]] = [float(np.float32(k) / np.float32(k + int(r.integers(0, 5))))] + [-100.0] * k
+                    anchor_only.add((w, doc[int(d)]))
             table[h(w)] = row
         return table
-    return {"doc": doc, "word": word, "children": children, "cats": cats,
-            "title": inverted(0.05, 1), "body": inverted(0.4, 2), "n_all": n_all}
+    return {"doc": doc, "word": word, "children": children, "cats": cats, "anchor_only": anchor_only,
+            "title": inverted(0.05, 1, True), "body": inverted(0.4, 2, False), "n_all": n_all}
 
 
 def make_tables(host, corpus):
@@ -155,7 +171,8 @@ def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
     # --- server.go:47 ----------------------------------------------------------------------
     di = host.DeviceIndex()
     di.load(forw, inv)
-    queries = ["w3 w17 w40", "W5, w5!  w9", "w149 nosuchword", "zzz", 'w1 "w2 w3" w4', '"w0 w1"', '"w5" w6 "w0"']
+    queries = ["w3 w17 w40", "W5, w5!  w9", "w149 nosuchword", "zzz", 'w1 "w2 w3" w4', '"w0 w1"', '"w5" w6 "w0"',
+               '"w148"', 'w30 "w6"']       # one-term phrases: a doc whose only w148 / w6 posting is anchor text matches through -100
     got = di.RetrieveBatch(queries, 50)
     # oracle on the tables as they are now (weighted), dense ids in sorted key order
     docs_sorted = sorted(set(forw[3].keys()))
@@ -188,6 +205,10 @@ def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
         assert [r.FinalRank for r in res] == hits["final"].tolist()
         assert all(r.PageRank == 0.0 for r in res)                                      # Q9: nil topicProbs
     assert len(got[3]) == 0 and len(got[0]) > 0
+    # the -100 sentinel on the Retrieve path: results of the one-term phrases include docs that hold the word as anchor text only
+    for qi, w in ((7, "w148"), (8, "w6")):
+        only = {d for (ww, d) in corpus["anchor_only"] if ww == w}
+        assert only and only & {r.DocHash for r in got[qi]}, (w, len(only))
     # BASELINE config 1: single query, top-10 = the first 10 of the top-50
     top10 = di.RetrieveBatch([queries[0]], 10)[0]
     assert [r.DocHash for r in top10] == [r.DocHash for r in got[0][:10]]

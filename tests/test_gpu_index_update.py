@@ -134,6 +134,8 @@ def test_rejected_delta_leaves_the_table_unchanged(ss_ctx):
             dict(del_docs=u(500)),                                             # doc out of range
             dict(del_pairs=(u(60), u(1))),                                     # term out of range
             dict(add=(u(1), u(999), f(1))),                                    # doc out of range
+            dict(add=(u(60), u(1), f(1))),                                     # term = n_terms
+            dict(add=(u(0xFFFFFFF0), u(1), f(1))),                             # term far out of range (no placement kernel may run)
             dict(add=(u(2, 2), u(5, 5), f(1, 2)), del_docs=u(5)),              # the same posting twice
             dict(add=(u(t0), u(d_existing), f(1))),                            # exists, not deleted by the delta
         ]
@@ -188,15 +190,15 @@ def test_scorers_must_be_recreated_and_then_score_the_new_table(ss_ctx, oracle):
         body.close()
 
 
-def test_refresh_magnitudes_bucketed_pass(ss_ctx, monkeypatch):
+def test_refresh_magnitudes_bucketed_pass(ss_ctx):
     # ss_index_refresh_magnitudes on a table sent down the bucketed (large-table) pass: same bits as the float64 sums
     from spaghettisearch_amd import engine
-    monkeypatch.setenv("SS_TFIDF_BUCKET_MIN", "1")
     for n_docs, n_terms, n_post in ((9000, 300, 120000), (70000, 5000, 900000), (1, 1, 1)):
         tp, pd, tf = synth.zipf_index(n_docs, n_terms, min(n_post, n_docs * n_terms // 2 + 1), seed=n_docs)
         ix = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
         try:
-            mag = ix.refresh_magnitudes()
+            with ss_ctx.options(tfidf__bucket_min=1):
+                mag = ix.refresh_magnitudes()
         finally:
             ix.close()
         ref = np.sqrt(np.bincount(pd, weights=(tf * tf).astype(np.float32).astype(np.float64), minlength=n_docs))

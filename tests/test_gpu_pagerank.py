@@ -133,6 +133,85 @@ def test_edge_cases(ss_ctx, oracle):
     np.testing.assert_allclose(rank, ref, rtol=1e-13)
 
 
+# ---- the block-item kernel k_pr_step<1/2> (K <= 2 on graphs whose padded table would leave the caches) --------------
+# pick_gw sends K <= 2 on small graphs to k_pr_sweep<8>; option "pr.force_narrow" keeps the narrow kernel so that its
+# classes (W_SEG with the multi-segment ticket path, W_WAVE, W_GROUP, W_ZERO) meet the oracle directly.
+def _skewed_graph():
+    rng = np.random.default_rng(3)
+    n = 70000
+    edges = {(int(s), 0) for s in range(1, 60001)}                      # hub: 60k in-edges = many W_SEG segments
+    edges |= {(int(s), 1) for s in rng.choice(n, 3000, replace=False)}  # several segments at K=1 (128*64 edges each)
+    edges |= {(int(s), 2) for s in rng.choice(n, 300, replace=False)}
+    edges |= {(int(a), int(b)) for a, b in rng.integers(0, n, size=(50000, 2))}
+    return (n,) + csr(n, list(edges))
+
+
+@pytest.mark.parametrize("k_topics", [1, 2])
+def test_narrow_kernel_skewed_rows(ss_ctx, oracle, k_topics):
+    n, ptr, dst = _skewed_graph()
+    n_topic = [n, 7][:k_topics]
+    with ss_ctx.options(pr__force_narrow=1):
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
+        rank2, iters2, _, _ = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-12)
+    assert rank.tobytes() == rank2.tobytes() and iters.tolist() == iters2.tolist()     # run-to-run bit-identical
+    # and the wide kernel the default picks for this size gives the same ranks
+    wide, wide_it, _, _ = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
+    assert wide_it.tolist() == iters.tolist()
+    np.testing.assert_allclose(wide, rank, rtol=1e-13)
+
+
+@pytest.mark.parametrize("k_topics", [1, 2])
+def test_narrow_kernel_rmat_and_edge_cases(ss_ctx, oracle, k_topics):
+    with ss_ctx.options(pr__force_narrow=1):
+        n, e = 20000, 100000
+        ptr, dst = synth.rmat_graph(n, e, seed=100 + k_topics)
+        n_topic = synth.topic_sizes(n, k_topics)
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-9)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-12)
+        nt = [10, 3][:k_topics]
+        # no edges at all: every node dangling (pagerank.go:131-134)
+        ptr = np.zeros(11, dtype=np.uint64)
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 10, ptr, np.zeros(0, np.uint32), nt, 1e-12)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-14)
+        # single node with a self loop
+        ptr, dst = csr(1, [(0, 0)])
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 1, ptr, dst, [1] * k_topics, 1e-12)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-14)
+        # complete graph on 40 nodes
+        ptr, dst = csr(40, [(a, b) for a in range(40) for b in range(40)])
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 40, ptr, dst, [40, 9][:k_topics], 1e-13)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-13)
+        # max_iter cut
+        ptr, dst = synth.rmat_graph(1000, 5000, seed=1)
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 1000, ptr, dst, [1000, 10][:k_topics], 1e-30, max_iter=3)
+        assert iters.tolist() == [3] * k_topics == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-13)
+        # the reference's own stop threshold (start_crawl.go:175): to the floating-point fixed point
+        ptr, dst = synth.rmat_graph(30000, 160000, seed=3)
+        nt = [15000, 7][:k_topics]
+        ref, ref_it = oracle.pagerank(30000, ptr, dst, 0.75, 1e-20, nt, max_iter=300)
+        from spaghettisearch_amd import engine
+        g = engine.Graph(ss_ctx, 30000, ptr, dst)
+        rank, it = g.pagerank(0.75, 1e-20, nt, max_iter=300)
+        g.close()
+        assert ref_it.max() < 300 and np.abs(it - ref_it).max() <= 1
+        np.testing.assert_allclose(rank, ref, rtol=1e-12)
+
+
+def test_option_names_are_checked(ss_ctx):
+    from spaghettisearch_amd import SpaghettiError
+    with pytest.raises(SpaghettiError):
+        ss_ctx.set_option("pr.no_such_switch", 1)
+    ss_ctx.set_option("pr.force_narrow", 1)
+    ss_ctx.set_option("pr.force_narrow", None)
+
+
 def test_bad_input_is_rejected(ss_ctx):
     from spaghettisearch_amd import SpaghettiError, engine
     ptr = np.array([0, 1, 2], dtype=np.uint64)

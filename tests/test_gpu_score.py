@@ -318,8 +318,8 @@ def test_long_queries_many_lists(ss_ctx, oracle):
         close_all(sc, ti, bi)
 
 
-def test_fused_and_separate_merge_agree(ss_ctx, oracle, monkeypatch):
-    # the per-query merge runs inside k_score_slices (last slice of the query to finish); SS_SCORE_SEPARATE_MERGE=1 keeps
+def test_fused_and_separate_merge_agree(ss_ctx, oracle):
+    # the per-query merge runs inside k_score_slices (last slice of the query to finish); option "score.separate_merge" keeps
     # it as its own launch: same hits, bit for bit, for single- and multi-slice queries, twice in a row (tickets reset)
     n_docs, n_terms = 300000, 2000
     title = synth.zipf_index(n_docs, n_terms, 400000, seed=31)
@@ -330,10 +330,7 @@ def test_fused_and_separate_merge_agree(ss_ctx, oracle, monkeypatch):
         q2_ptr, q2_terms = synth.make_queries(96, 2, n_terms, seed=34)
         runs = []
         for mode in ("fused", "fused", "separate", "fused"):
-            if mode == "separate":
-                monkeypatch.setenv("SS_SCORE_SEPARATE_MERGE", "1")
-            else:
-                monkeypatch.delenv("SS_SCORE_SEPARATE_MERGE", raising=False)
+            ss_ctx.set_option("score.separate_merge", 1 if mode == "separate" else None)
             runs.append((sc.score_topk(q_ptr, q_terms, 100), sc.score_topk(q2_ptr, q2_terms, 7)))
         ref = oracle.score_topk_batch(n_docs, title, body, np.ones(n_docs), np.ones(n_docs), q_ptr, q_terms, 100)
         assert_same_hits(*runs[0][0], *ref)

@@ -76,16 +76,16 @@ def test_rejects_unsorted_and_out_of_range(ss_ctx):
 
 @pytest.mark.parametrize("n_docs,n_terms,n_post,total", [(1, 1, 1, 1), (9000, 300, 120000, 9000), (70000, 5000, 900000, 80000),
                                                           (20000, 40, 400000, 20000)])
-def test_bucketed_magnitude_pass(ss_ctx, oracle, monkeypatch, n_docs, n_terms, n_post, total):
+def test_bucketed_magnitude_pass(ss_ctx, oracle, n_docs, n_terms, n_post, total):
     # large tables sum the squares per doc-range bucket in LDS instead of one global float64 atomic per posting;
-    # SS_TFIDF_BUCKET_MIN=1 sends these small tables down that path (several buckets, a partial last bucket, one doc)
+    # option "tfidf.bucket_min" = 1 sends these small tables down that path (several buckets, a partial last bucket, one doc)
     from spaghettisearch_amd import engine
     tp, pd, tf = synth.zipf_index(n_docs, n_terms, min(n_post, n_docs * n_terms // 2 + 1), seed=n_docs)
     w_ref, mag_ref, idf_ref = oracle.tfidf(tp, pd, tf, total, n_docs)
-    for knob in ("1", str(1 << 62)):                                  # bucketed, then the atomic pass: same bits
-        monkeypatch.setenv("SS_TFIDF_BUCKET_MIN", knob)
+    for knob in (1, 1 << 62):                                         # bucketed, then the atomic pass: same bits
         ix = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
-        w, mag, idf = ix.tfidf_build(total)
+        with ss_ctx.options(tfidf__bucket_min=knob):
+            w, mag, idf = ix.tfidf_build(total)
         ix.close()
         assert np.array_equal(w.view(np.uint32), w_ref.view(np.uint32))
         assert np.array_equal(idf.view(np.uint32), idf_ref.view(np.uint32))
