@@ -102,6 +102,8 @@ static const char* const k_option_names[] = {
     "tfidf.blocks",         // workgroups of the bucketed magnitude pass (default 1024)
     "tfidf.bucket_shift",   // log2 docs per bucket (default 13, 14 beyond 33M docs)
     "tfidf.bucket_min",     // smallest table (postings) that takes the bucketed pass (default 4M)
+    "score.wave",           // 0: never use the wave-per-slice kernel k_score_wave
+    "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
     "score.exact_all",      // 1: switch the upper-bound filter off (every record takes the exact stage)
     "score.slice_target",   // postings per (query, slice) workgroup (default: from the batch)
     "score.separate_merge", // 1: the per-query merge runs as its own launch (k_merge_topk)

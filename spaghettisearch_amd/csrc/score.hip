@@ -40,320 +40,9 @@
 //   * k_merge_topk: one workgroup per query merges its slices' top-k lists, re-derives
 //     title/body/pagerank of the k winners by binary search and writes ss_hit rows.
 //   Ties: ascending doc id (Q10); NaN finals last.
-#include "index.hpp"
-#include "order.hpp"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <memory>
-#include <new>
+#include "score_common.hpp"
 
 namespace {
-
-#ifndef SS_TPB
-#define SS_TPB 512
-#endif
-constexpr int TPB = SS_TPB;        // k_score_slices workgroup
-#ifndef SS_TPB_M
-#define SS_TPB_M 256
-#endif
-constexpr int TPB_M = SS_TPB_M;    // k_merge_topk workgroup
-#ifndef SS_CAP
-#define SS_CAP 1024
-#endif
-constexpr int CAP = SS_CAP;        // records per window (capacity)
-#ifndef SS_TARGET_64THS
-#define SS_TARGET_64THS 59
-#endif
-constexpr int TARGET = CAP * SS_TARGET_64THS / 64;   // planned records per window
-constexpr int PPT = CAP / TPB;     // records per thread and window
-#ifndef SS_SK_BITS
-#define SS_SK_BITS 11
-#endif
-constexpr int SK = 1 << SS_SK_BITS;                  // slots of one filter table (three rotate)
-#ifndef SS_PC
-#define SS_PC 1024
-#endif
-constexpr int PC = SS_PC;          // pending survivor records = capacity of the exact stage (>= CAP)
-constexpr int PPX = (PC + TPB - 1) / TPB;            // pending records per thread in a flush
-#ifndef SS_HT
-#define SS_HT 2048
-#endif
-constexpr int HT = SS_HT;          // exact-stage hash slots (load <= PC/HT)
-constexpr int MAXL = 2 * SS_MAX_QUERY_TERMS + 4;     // (term, field) lists per query + 4 phrase result lists
-#ifndef SS_TBL_CAP
-#define SS_TBL_CAP 2048
-#endif
-constexpr int TBL_CAP = SS_TBL_CAP;                  // window-cursor table entries: (n_win+1) * L <= TBL_CAP
-constexpr int OFF_CAP = TBL_CAP + TBL_CAP / 4 - (TBL_CAP + TBL_CAP / 4) % 8;   // window-offset table entries: n_win * OS <= OFF_CAP
-constexpr int MAX_WIN = 1023;
-constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t NOREC = 0xFFFFu;                  // "no first record" in a packed ht_rec half
-#ifndef SS_CB_MIN
-#define SS_CB_MIN 256
-#endif
-#ifndef SS_SLICE_TARGET
-#define SS_SLICE_TARGET 262144
-#endif
-constexpr uint64_t SLICE_TARGET = SS_SLICE_TARGET;
-constexpr uint32_t MAX_SLICES_PER_Q = 256;
-#ifndef SS_SLICE_MIN
-#define SS_SLICE_MIN 16384
-#endif
-constexpr uint64_t SLICE_MIN = SS_SLICE_MIN;         // smallest adaptive slice (postings)
-constexpr int MAXCH = PC / 64;                       // chunked windows: most 64-record chunks per window (their records fit the exact stage)
-constexpr int WAVES = TPB / 64;
-constexpr int CPW = (MAXCH + WAVES - 1) / WAVES;     // chunk slots per wave and window
-constexpr int LCH = 12;                              // queries with at most this many lists take the chunked window loop
-constexpr int OSC = 16;                              // bytes per window row: LCH + 1 cumulative chunk counts, then the window's records / 8
-constexpr int DEPTH = 3;                             // windows whose records are in flight or in registers (= number of filter tables)
-// The filter sums in FIXED POINT: ds_add_u32 costs ~1/30 of ds_add_f32 on gfx950 (tools/micro/lds_ops.hip: 26 vs 880 ticks
-// per wave-instruction).  A record's share is scaled so that the largest coefficient maps to FX_ONE units, rounded up, and
-// clamped to FX_CLAMP; a slot that reaches FX_CLAMP counts as "unbounded" (its records survive).  PC records of
-// FX_CLAMP each stay below 2^32: the sums never wrap.
-constexpr uint32_t FX_ONE = 1u << 18;
-constexpr uint32_t FX_CLAMP = SS_PC > 1024 ? 1u << 20 : 1u << 21;
-static_assert((uint64_t)FX_CLAMP * SS_PC < (1ull << 32), "filter sums must not wrap");
-constexpr int KTH_N = 11;                            // k'-th largest impact per term for k' = 2^0 .. 2^10
-static_assert(DEPTH == 3, "ring slots, filter tables and survivor counters rotate together");
-static_assert(PC >= CAP && PC < 0xFFFF, "the exact stage must hold one whole window; record indices are 16-bit");
-static_assert(CAP % TPB == 0 && HT % 256 == 0, "sizes");
-
-struct __attribute__((aligned(8))) Rec {   // scoring layout: 8 bytes per posting
-    uint32_t doc;
-    float imp;                               // float32 upper bound of w / magnitude(doc, field); 0 where the weight is 0
-};
-
-struct SliceDesc {
-    uint32_t q;
-    uint32_t dlo, dhi;   // doc range [dlo, dhi); dhi = 0xFFFFFFFF: to the end
-    uint32_t pad;
-};
-
-struct ScoreParams {
-    // per table: term_ptr, scoring records, the index's float32 weights and float64 magnitudes, k'-th largest impacts
-    const uint64_t* t_ptr; const Rec* t_rec; const float* t_w; const double* t_mag; const float* t_kth;
-    const uint64_t* b_ptr; const Rec* b_rec; const float* b_w; const double* b_mag; const float* b_kth;
-    // positional postings (phrase search, retrieval/phrase.go): pos_ptr[P+1] into pos[] per table, or null
-    const uint64_t* t_pos_ptr; const float* t_pos;
-    const uint64_t* b_pos_ptr; const float* b_pos;
-    // phrase part of the batch: ph_off[n_q+1] into ph_terms (all quoted phrases of a query concatenated,
-    // main_retrieve.go:26), driver = index of the phrase's rarest term; outputs of k_phrase_match:
-    // four doc-sorted record lists per query (body/title sums found via the driver's body/title postings)
-    const uint32_t* ph_off; const uint32_t* ph_terms; const uint32_t* ph_drv;
-    const uint32_t* x_off;     // [n_q+1] capacity offsets of the phrase result lists
-    Rec* x_rec[4];             // 0: body sums (driver body pass), 1: title sums (driver body pass), 2: body (title pass), 3: title (title pass)
-    float* x_w[4];             // the float32 weight sums themselves (phrase.go:59,69,73,83,90)
-    uint32_t* x_cnt;           // [n_q][4]
-    // k_phrase_match runs one workgroup per PART (<= PH_PART candidates of the driver's body or title list): parts of a query
-    // write their matches compactly from the part's own offset, k_phrase_close then closes the gaps per query
-    const uint4* ph_parts;     // [n_parts] {query, pass, first candidate (index inside the driver's list), candidates}
-    const uint32_t* ph_pbase;  // [n_q+1] parts of query q: ph_parts[ph_pbase[q] .. ph_pbase[q+1])
-    uint32_t* ph_pcnt;         // [n_parts][2] matches found by the part: body sums, title sums
-    const double* prior;       // [n_docs][k_topics] or null
-    int32_t k_topics;
-    const uint32_t* q_off;     // [n_q+1] into dterm/dmult
-    const uint32_t* dterm;     // distinct known terms per query, first-occurrence order
-    const uint32_t* dmult;     // multiplicity of each
-    const double* qmag;        // [n_q] sqrt(queryLength)
-    const double* probs;       // [n_q][k_topics] or null
-    const double* sqd_ub;      // [n_q] upper bound of sqd over all docs (when probs)
-    const uint32_t* slice_base;// [n_q+1] (query order)
-    const SliceDesc* slices;   // query order
-    const uint32_t* order;     // launch order -> slice index (longest first)
-    int32_t k;
-    int32_t cb;                // candidate buffer entries (power of two >= 2k)
-    int32_t kth_j;             // smallest j with 2^j >= k
-    int32_t exact_all;         // 1: the filter's assumptions do not hold for this call: every record goes to the exact stage
-    uint64_t* so_key; uint32_t* so_doc; uint32_t* so_cnt;   // per slice top-k
-    uint32_t* q_ticket;       // per query: slices that have handed in their list (fused merge); null = k_merge_topk runs as its own launch
-    ss_hit* hits; int32_t* n_hits;
-};
-
-using ss::fkey;
-using ss::funkey;
-using ss::better;
-
-// kernel arguments stay in scalar registers only while they are never indexed with a run-time value
-__device__ __forceinline__ Rec* x_rec_of(const ScoreParams& p, int x) { return x == 0 ? p.x_rec[0] : x == 1 ? p.x_rec[1] : x == 2 ? p.x_rec[2] : p.x_rec[3]; }
-__device__ __forceinline__ float* x_w_of(const ScoreParams& p, int x) { return x == 0 ? p.x_w[0] : x == 1 ? p.x_w[1] : x == 2 ? p.x_w[2] : p.x_w[3]; }
-
-// Lists are addressed by the absolute address of their first record (regular posting lists and the
-// per-query phrase result lists alike); explicit global address space keeps the loads global_load_*.
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // native vector: loads as one global_load_dwordx2
-typedef const u32x2 __attribute__((address_space(1)))* gptr_u2;
-typedef const uint32_t __attribute__((address_space(1)))* gptr_u32;
-typedef const float __attribute__((address_space(1)))* gptr_f32;
-__device__ __forceinline__ u32x2 load_rec(uint64_t list_addr, uint64_t idx) { return *(gptr_u2)(list_addr + idx * sizeof(Rec)); }
-__device__ __forceinline__ uint32_t load_doc(uint64_t list_addr, uint64_t idx) { return *(gptr_u32)(list_addr + idx * sizeof(Rec)); }
-__device__ __forceinline__ float load_w(uint64_t w_addr, uint64_t idx) { return *(gptr_f32)(w_addr + idx * sizeof(float)); }
-__device__ __forceinline__ uint64_t lower_bound_rec(const Rec* __restrict__ a, uint64_t lo, uint64_t hi, uint32_t v) {
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (a[mid].doc < v) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-__device__ __forceinline__ uint32_t lower_bound_addr(uint64_t list_addr, uint32_t lo, uint32_t hi, uint32_t v) {
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (load_doc(list_addr, mid) < v) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-// Same result as lower_bound_addr with fewer DEPENDENT loads: every probe of a search in HBM costs a full
-// memory latency (~1 us under load) and the slice set-up is nothing but such chains.  Doc ids of a list are
-// close to uniform, so the position of v is guessed by interpolation and bracketed by two independent probes
-// at guess -/+ sqrt(range) (one latency): the bracket shrinks n -> 2*sqrt(n) per step (262144 -> 1024 -> 64 ->
-// 16), then bisection.  Any distribution stays correct: a probe on the wrong side still halves nothing but
-// keeps the invariant, and after 4 steps plain bisection finishes.
-__device__ __forceinline__ uint32_t lower_bound_interp(uint64_t list_addr, uint32_t lo, uint32_t hi, uint32_t v) {
-    if (lo >= hi) return lo;
-    uint32_t L = lo, H = hi - 1;
-    uint32_t dl = load_doc(list_addr, L), dh = load_doc(list_addr, H);      // independent: one latency
-    if (dl >= v) return lo;
-    if (dh < v) return hi;
-    // invariant: doc[L] = dl < v <= dh = doc[H]; the answer is in (L, H]
-    for (int it = 0; it < 4 && H - L > 32; it++) {
-        const uint32_t n = H - L;
-        const float frac = (float)(v - dl) / (float)(dh - dl);             // dl < dh
-        uint32_t g = L + (uint32_t)(frac * (float)n);
-        const uint32_t dlt = (uint32_t)__fsqrt_rn((float)n) + 2;
-        uint32_t a = g > L + dlt ? g - dlt : L + 1;                        // a in [L+1, H-1]
-        a = min(a, H - 1);
-        uint32_t b = min(a + 2 * dlt, H - 1);                              // b in [a, H-1]
-        const uint32_t da = load_doc(list_addr, a), db = load_doc(list_addr, b);
-        if (da >= v) { H = a; dh = da; }
-        else if (db < v) { L = b; dl = db; }
-        else { L = a; dl = da; H = b; dh = db; }
-    }
-    // finish 8-ary: seven independent probes per step (one latency) instead of three dependent ones
-    while (H - L > 1) {
-        const uint32_t step = (H - L + 7) >> 3;                             // >= 1
-        uint32_t d[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) d[i] = load_doc(list_addr, min(L + step * (uint32_t)(i + 1), H - 1));
-        uint32_t nl = L, nh = H;
-#pragma unroll
-        for (int i = 6; i >= 0; i--) {
-            const uint32_t pos = min(L + step * (uint32_t)(i + 1), H - 1);
-            if (d[i] >= v) nh = pos;                                        // doc[pos] >= v: the answer is at or before pos
-        }
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const uint32_t pos = min(L + step * (uint32_t)(i + 1), H - 1);
-            if (d[i] < v) nl = max(nl, pos);                                // doc[pos] < v: the answer is after pos
-        }
-        L = nl;                                                             // every probe is on one side or the other:
-        H = nh;                                                             // the bracket shrinks to <= step
-    }
-    return H;
-}
-
-// lower_bound over records a[lo .. hi) (one posting list: shorter than 2^32) with the interpolation search
-__device__ __forceinline__ uint64_t lower_bound_rec_interp(const Rec* __restrict__ a, uint64_t lo, uint64_t hi, uint32_t v) {
-    return lo + lower_bound_interp((uint64_t)(a + lo), 0u, (uint32_t)(hi - lo), v);
-}
-
-// get_metadata.go:53-69 for one candidate
-__device__ __forceinline__ void final_rank(double T, double B, double mt, double mb, double qmag, double sqd,
-                                           double& title, double& body, double& fin) {
-    body = B / (mb * qmag);                          // :57
-    title = T / (mt * qmag);                         // :58
-    if (body != body) body = 0.0;                    // :61-63
-    if (title != title) title = 0.0;                 // :64-66
-    fin = (0.33 * sqd + 0.38 * title + 0.29 * body) * 100.0;   // :69
-}
-
-__device__ __forceinline__ double topic_dot(const double* __restrict__ prior, const double* __restrict__ probs, int K, uint32_t doc) {
-    double sqd = 0.0;                                // get_metadata.go:39-42, topic order
-    const double* pr = prior + (size_t)doc * K;
-    for (int t = 0; t < K; t++) sqd += probs[t] * pr[t];
-    return sqd;
-}
-
-// Workgroup barrier that does NOT drain the vector-memory counter: the next window's records stay
-// in flight across it (a __syncthreads() would emit s_waitcnt vmcnt(0), cdna_hip_programming.md §5
-// "Pipelining across barriers").  LDS traffic is complete after lgkmcnt(0).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-#ifdef SS_DIAG
-// Diagnostic build only (make DIAG=1): event counts and s_memtime sums of wave 0 of every slice, printed by ss_scorer_destroy.
-__device__ unsigned long long g_diag[24];
-__device__ unsigned long long g_slice[4096][4];      // per launch index: {start (realtime 100 MHz), end, windows, records}
-#define DIAG_ADD(i, v) do { if ((threadIdx.x) == 0) atomicAdd(&g_diag[i], (unsigned long long)(v)); } while (0)
-#define DIAG_NOW(var) unsigned long long var; do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define DIAG_ADD(i, v) do { } while (0)
-#define DIAG_NOW(var) do { } while (0)
-#endif
-#ifdef SS_DIAG
-#define DIAG_NOWX(var) DIAG_NOW(var)
-#else
-#define DIAG_NOWX(var) do { } while (0)
-#endif
-#if defined(SS_DIAG) && defined(SS_DIAG_LOOP)      // stamps INSIDE the window loop: they cost more than what they measure
-#define DIAG_NOWL(var) DIAG_NOW(var)
-#define DIAG_ADDL(i, v) DIAG_ADD(i, v)
-#else
-#define DIAG_NOWL(var) do { } while (0)
-#define DIAG_ADDL(i, v) do { } while (0)
-#endif
-
-// ---- running top-k in LDS ------------------------------------------------------
-struct TopK {
-    uint64_t* key;    // [cb]
-    uint32_t* doc;    // [cb]
-    uint32_t* count;  // shared scalar (may run past cb while an overflow is pending)
-    uint64_t* thr;    // shared scalar: admit keys >= thr
-    float* thr_f;     // shared scalar: float lower bound of the threshold score (-inf: no threshold)
-    uint64_t thr0;    // floor of the threshold known before any posting was read (0 = none)
-    float thr0_f;
-    uint32_t cb;
-};
-
-// Sort the candidate buffer best-first and keep the k best. All threads call.
-// (An enumeration sort — every entry counts the entries that precede it, 2 barriers instead of 38 — measured
-// 25 % slower end to end: 65k broadcast LDS reads cost more than the bitonic network's barriers.)
-// (by value: a reference would force the struct into scratch memory for the out-of-line call)
-__device__ void topk_compact(const TopK tk, int k) {
-    DIAG_ADD(4, 1);
-    lds_barrier();
-    const uint32_t nthr = blockDim.x;
-    const uint32_t n = min(*tk.count, tk.cb);
-    uint32_t n2 = 64;
-    while (n2 < n) n2 <<= 1;
-    for (uint32_t i = n + threadIdx.x; i < n2; i += nthr) { tk.key[i] = 0ull; tk.doc[i] = EMPTY; }   // worst sentinels
-    lds_barrier();
-    for (uint32_t size = 2; size <= n2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t i = threadIdx.x; i < (n2 >> 1); i += nthr) {
-                const uint32_t lo = 2 * i - (i & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool desc = ((lo & size) == 0);     // this run sorted best-first
-                const uint64_t ka = tk.key[lo], kb = tk.key[hi];
-                const uint32_t da = tk.doc[lo], db = tk.doc[hi];
-                const bool swap = desc ? better(kb, db, ka, da) : better(ka, da, kb, db);
-                if (swap) { tk.key[lo] = kb; tk.key[hi] = ka; tk.doc[lo] = db; tk.doc[hi] = da; }
-            }
-            lds_barrier();
-        }
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t keep = min(n, (uint32_t)k);
-        *tk.count = keep;
-        const bool full = keep == (uint32_t)k;
-        uint64_t t = full ? tk.key[k - 1] : 0ull;
-        float tf = -INFINITY;
-        if (full && t != 0ull) tf = __double2float_rd(funkey(t));
-        if (tk.thr0 > t) { t = tk.thr0; tf = tk.thr0_f; }
-        else if (tk.thr0_f > tf) tf = tk.thr0_f;
-        *tk.thr = t;
-        *tk.thr_f = tf;
-    }
-    lds_barrier();
-}
 
 // ---- K4: score one (query, doc-range slice) --------------------------------------
 #ifndef SS_WGS_PER_CU
@@ -404,11 +93,6 @@ struct SliceLds {
     float* l_coef;       // [MAXL] filter coefficient in fixed-point units: upper bound of (38|29)*mult/sqrt(queryLength) * scale
     uint16_t* off;       // [OFF_CAP] offset of list l inside window j: off[j*OS+l], count at [j*OS+OS-1]
     uint32_t* overflow;  // shared scalar
-};
-struct SliceQuery {      // per-query constants of the exact stage
-    double qmag, sqd_ub;
-    float qmag_f, sqd_ub_f;
-    const double* probs;
 };
 
 // generic window loop (L > LCH lists): records of one window as raw 8-byte vectors (one global_load_dwordx2 per posting)
@@ -670,17 +354,7 @@ __device__ __forceinline__ void chunk_issue(const WinRow& w, const WaveLists& wl
     }
 }
 
-// the running threshold in the filter's units, rounded down: a slot below it cannot hold a doc of the top-k.
-// thr_f = -inf (no threshold yet) -> 0: everything survives; never above FX_CLAMP: clamped shares always survive.
-__device__ __forceinline__ uint32_t fx_threshold(float thr_f, float r_ub, float fx_scale) {
-    const float t = (thr_f - r_ub) * fx_scale * (1.0f - 0x1p-20f);
-    return t > 0.0f ? min((uint32_t)t, FX_CLAMP) : 0u;
-}
 
-// a record's share of FinalRank in fixed-point units, rounded up, clamped (NaN -> 1: only reachable with the filter off)
-__device__ __forceinline__ uint32_t fx_share(float imp, float coef_fx) {
-    return min((uint32_t)(imp * coef_fx), FX_CLAMP - 1u) + 1u;
-}
 // filter slot of a doc: doc ids inside a window are a narrow range, so folding the id's low bits spreads them
 __device__ __forceinline__ uint32_t fx_slot(uint32_t doc) { return (doc ^ (doc >> SS_SK_BITS)) & (uint32_t)(SK - 1); }
 
@@ -728,7 +402,9 @@ __device__ __forceinline__ void chunk_filter(const SliceLds& S, const uint32_t (
 // NT = threads of the calling workgroup.  FUSED: called by the last slice of the query to finish inside k_score_slices — the
 // slices' lists were stored write-through and are read with sc1 loads (no fence; see the hand-off at the end of
 // k_score_slices).
-template <int NT, bool FUSED>
+// FLAT: the query's slices (k_score_wave) appended their candidates to ONE list per query (qc_cnt[q] entries from
+// slice_base[q] * k on); otherwise every slice owns k entries and so_cnt[s] says how many it filled.
+template <int NT, bool FUSED, bool FLAT = false>
 __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t q, unsigned char* smem) {
     double* accT = reinterpret_cast<double*>(smem);                    // [k]
     double* accB = accT + p.k;                                         // [k]
@@ -741,8 +417,37 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
     TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), 0ull, -INFINITY, (uint32_t)p.cb};
     const int tid = threadIdx.x;
     const int k = p.k;
-    if (tid == 0) { sc32[0] = 0; sc64[0] = 0ull; }
+    if (tid == 0) { sc32[0] = 0; sc32[1] = 0; sc64[0] = 0ull; }
     __syncthreads();
+    if (FLAT) {
+        const uint32_t n = p.qc_cnt[q];
+        const size_t base = (size_t)p.slice_base[q] * k;
+        uint32_t* overflow = &sc32[1];
+        for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+            const uint32_t i = i0 + tid;
+            bool have = i < n;
+            uint64_t key = 0;
+            uint32_t doc = 0;
+            if (have) { key = p.so_key[base + i]; doc = p.so_doc[base + i]; }
+            for (;;) {
+                const uint64_t thr = *tk.thr;
+                if (have) {
+                    if (key >= thr) {
+                        const uint32_t j = atomicAdd(tk.count, 1u);
+                        if (j < tk.cb) { tk.key[j] = key; tk.doc[j] = doc; have = false; }
+                        else *overflow = 1;
+                    } else {
+                        have = false;
+                    }
+                }
+                __syncthreads();
+                if (!*overflow) break;
+                topk_compact(tk, k);
+                if (tid == 0) *overflow = 0;
+                __syncthreads();
+            }
+        }
+    } else
     for (uint32_t s = p.slice_base[q]; s < p.slice_base[q + 1]; s++) {
         const uint32_t n = FUSED ? __hip_atomic_load(&p.so_cnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.so_cnt[s];   // <= k, and cb >= 2k: room after a compaction
         if (sc32[0] + n > tk.cb) topk_compact(tk, k);
@@ -1372,27 +1077,42 @@ size_t score_lds_bytes(int cb) { return score_lds_layout(cb).total; }
 // ---- K5: merge a query's slices, explain the winners ------------------------------
 __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (p.q_fast && p.q_fast[blockIdx.x]) return;          // k_merge_flat's
     merge_query<TPB_M, false>(p, blockIdx.x, smem);
+}
+// the queries scored by k_score_wave: one candidate list per query
+__global__ __launch_bounds__(TPB_M) void k_merge_flat(ScoreParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    merge_query<TPB_M, false, true>(p, p.merge_q[blockIdx.x], smem);
 }
 
 size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 16 + 16; }
 
 // scoring layout: {doc, float32 upper bound of w/mag[doc]} per posting; flags: bit 0 = a weight is negative or not finite,
 // bit 1 = a magnitude is not a positive finite number under a non-zero weight (the filter's assumptions, see k_score_slices)
+// The record array is padded to whole 64-record blocks ({doc 0xFFFFFFFF, impact 0}) and skip[g] = doc of record 64*g: the wave
+// kernel reads whole 512-byte blocks and finds them through the skip index.
 __global__ void k_pack_recs(const uint32_t* __restrict__ doc, const float* __restrict__ w, const double* __restrict__ mag,
-                            uint64_t n, Rec* __restrict__ out, uint32_t* __restrict__ flags) {
+                            uint64_t n, Rec* __restrict__ out, uint32_t* __restrict__ skip, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_pad = (n + 63) & ~(uint64_t)63;
     uint32_t f = 0;
-    for (; i < n; i += stride) {
+    for (; i < n_pad; i += stride) {
         Rec r;
-        r.doc = doc[i];
-        const float wi = w[i];
-        const double m = mag[r.doc];
-        if (!(wi >= 0.0f) || isinf(wi)) f |= 1u;
-        if (wi != 0.0f && (!(m > 0.0) || isinf(m))) f |= 2u;
-        r.imp = impact_of(wi, m);
+        if (i < n) {
+            r.doc = doc[i];
+            const float wi = w[i];
+            const double m = mag[r.doc];
+            if (!(wi >= 0.0f) || isinf(wi)) f |= 1u;
+            if (wi != 0.0f && (!(m > 0.0) || isinf(m))) f |= 2u;
+            r.imp = impact_of(wi, m);
+        } else {
+            r.doc = 0xFFFFFFFFu;
+            r.imp = 0.0f;
+        }
         out[i] = r;
+        if ((i & 63) == 0) skip[i >> 6] = r.doc;
     }
     if (__ballot(f != 0)) {
         for (int o = 32; o > 0; o >>= 1) f |= (uint32_t)__shfl_xor((int)f, o, 64);
@@ -1490,12 +1210,22 @@ double unkey(uint64_t k) {
 
 }  // namespace
 
+namespace ss {
+// score_wave.hip
+size_t score_wave_prep_bytes(unsigned n_slices);
+void launch_score_wave(const void* params, unsigned n_slices, void* prep, hipStream_t st);
+int score_wave_max_lists();
+int score_wave_max_k();
+void score_wave_diag_dump();
+}  // namespace ss
+
 struct ss_scorer {
     ss_ctx* ctx = nullptr;
     ss_index* title = nullptr;
     ss_index* body = nullptr;
     uint64_t n_docs = 0, n_terms = 0;
-    ss::DevBuf<Rec> t_rec, b_rec;              // scoring records {doc, impact}
+    ss::DevBuf<Rec> t_rec, b_rec;              // scoring records {doc, impact}, padded to whole 64-record blocks
+    ss::DevBuf<uint32_t> t_skip, b_skip;        // skip[g] = doc of record 64*g
     ss::DevBuf<float> t_kth, b_kth;             // [T][KTH_N] k'-th largest impact per term (threshold floor)
     bool clean = true;                          // weights >= 0 and finite, magnitudes positive and finite where a weight is not 0
     bool prior_clean = true;                    // every prior value >= 0 and finite
@@ -1504,7 +1234,7 @@ struct ss_scorer {
     int k_topics = 0;
     int lds_attr = 0;
     // per-call workspaces, grow-only (no hipMalloc/hipFree on the steady-state query path)
-    ss::DevBuf<unsigned char> d_plan;
+    ss::DevBuf<unsigned char> d_plan, d_wprep;
     // pinned staging for the plan, double-buffered: a call that returns results in device memory does not wait
     // for the GPU, so the next call plans (and fills the other buffer) while this one's copy and kernels run
     unsigned char* h_plan[2] = {nullptr, nullptr};
@@ -1516,7 +1246,7 @@ struct ss_scorer {
     ss::DevBuf<float> d_xw[4];                  // ... and their float32 weight sums
     ss::DevBuf<uint32_t> d_xcnt, d_pcnt;
     ss::DevBuf<uint64_t> d_so_key;
-    ss::DevBuf<uint32_t> d_so_doc, d_so_cnt, d_qticket;
+    ss::DevBuf<uint32_t> d_so_doc, d_so_cnt, d_qticket, d_qcnt;
     size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
     ss::DevBuf<ss_hit> d_hits;
     ss::DevBuf<int32_t> d_nhits;
@@ -1558,8 +1288,10 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     s->body = body;
     s->n_docs = title->n_docs;
     s->n_terms = title->n_terms;
-    SS_HIP(ctx, s->t_rec.alloc(title->n_post));
-    SS_HIP(ctx, s->b_rec.alloc(body->n_post));
+    SS_HIP(ctx, s->t_rec.alloc(((title->n_post + 63) & ~(uint64_t)63) + 64));
+    SS_HIP(ctx, s->b_rec.alloc(((body->n_post + 63) & ~(uint64_t)63) + 64));
+    SS_HIP(ctx, s->t_skip.alloc((title->n_post + 63) / 64 + 1));
+    SS_HIP(ctx, s->b_skip.alloc((body->n_post + 63) / 64 + 1));
     SS_HIP(ctx, s->t_kth.alloc((size_t)s->n_terms * KTH_N));
     SS_HIP(ctx, s->b_kth.alloc((size_t)s->n_terms * KTH_N));
     ss::DevBuf<uint32_t> flags;
@@ -1570,11 +1302,11 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     if (title->n_post)
         hipLaunchKernelGGL(k_pack_recs, dim3(std::min<unsigned>(ss::div_up(title->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
                            (const uint32_t*)title->post_doc.p, (const float*)title->post_w.p, (const double*)title->mag.p,
-                           title->n_post, s->t_rec.p, flags.p);
+                           title->n_post, s->t_rec.p, s->t_skip.p, flags.p);
     if (body->n_post)
         hipLaunchKernelGGL(k_pack_recs, dim3(std::min<unsigned>(ss::div_up(body->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
                            (const uint32_t*)body->post_doc.p, (const float*)body->post_w.p, (const double*)body->mag.p,
-                           body->n_post, s->b_rec.p, flags.p);
+                           body->n_post, s->b_rec.p, s->b_skip.p, flags.p);
     if (s->n_terms) {
         hipLaunchKernelGGL(k_kth_impact, dim3((unsigned)s->n_terms), dim3(KH_TPB), 0, ctx->stream, (const uint64_t*)title->term_ptr.p,
                            (const Rec*)s->t_rec.p, s->t_kth.p);
@@ -1600,6 +1332,7 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
 #ifdef SS_DIAG
+    ss::score_wave_diag_dump();
     {
         unsigned long long h[24];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h)) == hipSuccess) {
@@ -1809,6 +1542,21 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         slice_target = std::min<uint64_t>(SLICE_TARGET, std::max<uint64_t>(SLICE_MIN, batch_tot * 3 / (2 * slots)));
         slice_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.slice_target", (int64_t)slice_target));   // experiments only
     }
+    // k_score_wave (one wave per slice) takes the plain OR queries: few lists, no phrase part, small k, inputs for which the
+    // filter's assumptions hold, and a list long enough for the threshold floor (k'-th largest impact, k' >= k) to exist;
+    // everything else runs k_score_slices.  Option "score.wave" = 0 switches the wave kernel off (tests, A/B).
+    const bool wave_ok = ctx->opt("score.wave", 1) != 0 && !exact_all && k <= ss::score_wave_max_k();
+    uint64_t wave_target = 0;
+    if (wave_ok) {
+        // about four slices per resident wave slot, 8k .. 48k postings each
+        const uint64_t slots = (uint64_t)std::max(ctx->cu_count, 1) * 9;
+        uint64_t batch_tot = 0;
+        for (uint32_t i = 0; i < n_tok; i++)
+            if ((uint64_t)h_terms[i] < s->n_terms) batch_tot += (tp[h_terms[i] + 1] - tp[h_terms[i]]) + (bp[h_terms[i] + 1] - bp[h_terms[i]]);
+        wave_target = std::min<uint64_t>(49152, std::max<uint64_t>(8192, batch_tot / (4 * slots)));
+        wave_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.wave_slice_target", (int64_t)wave_target));
+    }
+    std::vector<uint8_t> h_fast(n_q, 0);
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
     std::vector<double> h_qmag(n_q), h_ub(n_q, 0.0);
     std::vector<SliceDesc> h_slices;
@@ -1844,9 +1592,22 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         // the window plan holds (n_win + 1) * L cursors: keep a slice within what the plan can cut into regular windows
         const uint64_t n_lists = 2 * (h_dterm.size() - d0) + 4;
         const uint64_t plan_cap = std::max<uint64_t>(TARGET, (uint64_t)(TBL_CAP / n_lists > 2 ? TBL_CAP / n_lists - 2 : 1) * TARGET * 7 / 8);
-        const uint64_t q_target = std::min<uint64_t>(slice_target, plan_cap);
+        uint64_t q_target = std::min<uint64_t>(slice_target, plan_cap);
+        uint64_t max_slices = MAX_SLICES_PER_Q;
+        {
+            uint64_t longest = 0;
+            for (size_t j = d0; j < h_dterm.size(); j++)
+                longest = std::max<uint64_t>(longest, std::max(tp[h_dterm[j] + 1] - tp[h_dterm[j]], bp[h_dterm[j] + 1] - bp[h_dterm[j]]));
+            const bool phrase_q = p_ptr && h_pptr[q + 1] > h_pptr[q];
+            if (wave_ok && !phrase_q && h_dterm.size() > d0 && 2 * (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists() &&
+                longest >= (uint64_t)4 * (uint64_t)k && longest >= 1024) {
+                h_fast[q] = 1;
+                q_target = wave_target;
+                max_slices = 4096;
+            }
+        }
         uint64_t ns = std::max<uint64_t>(1, (tot + q_target - 1) / q_target);
-        ns = std::min<uint64_t>(ns, std::min<uint64_t>(MAX_SLICES_PER_Q, s->n_docs));
+        ns = std::min<uint64_t>(ns, std::min<uint64_t>(max_slices, s->n_docs));
         for (uint64_t j = 0; j < ns; j++) {
             SliceDesc sd;
             sd.q = (uint32_t)q;
@@ -1860,9 +1621,17 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     }
     const size_t n_slices = h_slices.size();
     const size_t n_d = h_dterm.size();
-    std::vector<uint32_t> h_order(n_slices);
+    // launch order: the wave kernel's slices first, then k_score_slices' (each group longest first); merge list = the wave queries
+    std::vector<uint32_t> h_order(n_slices), h_mergeq;
     for (size_t i = 0; i < n_slices; i++) h_order[i] = (uint32_t)i;
-    std::stable_sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b) { return h_slice_cost[a] > h_slice_cost[b]; });
+    std::stable_sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b) {
+        const int fa = h_fast[h_slices[a].q], fb = h_fast[h_slices[b].q];
+        return fa != fb ? fa > fb : h_slice_cost[a] > h_slice_cost[b];
+    });
+    size_t n_fast_slices = 0;
+    for (size_t i = 0; i < n_slices; i++) n_fast_slices += h_fast[h_slices[i].q];
+    for (int q = 0; q < n_q; q++)
+        if (h_fast[q]) h_mergeq.push_back((uint32_t)q);
 
     int cb = SS_CB_MIN;
     while (cb < 2 * k) cb <<= 1;
@@ -1884,6 +1653,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const size_t o_pbase = o;  o = align16(o + (n_q + 1) * sizeof(uint32_t));
     const size_t o_parts = o;  o = align16(o + h_parts.size() * sizeof(uint4));
     const size_t o_probs = o;  o = align16(o + h_probs.size() * sizeof(double));
+    const size_t o_mergeq = o; o = align16(o + h_mergeq.size() * sizeof(uint32_t));
+    const size_t o_qfast = o;  o = align16(o + (size_t)n_q);
     const size_t plan_bytes = o;
     const int pb = s->plan_turn;
     s->plan_turn ^= 1;
@@ -1918,6 +1689,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     std::memcpy(hp + o_pbase, h_pbase.data(), (n_q + 1) * sizeof(uint32_t));
     if (!h_parts.empty()) std::memcpy(hp + o_parts, h_parts.data(), h_parts.size() * sizeof(uint4));
     if (!h_probs.empty()) std::memcpy(hp + o_probs, h_probs.data(), h_probs.size() * sizeof(double));
+    if (!h_mergeq.empty()) std::memcpy(hp + o_mergeq, h_mergeq.data(), h_mergeq.size() * sizeof(uint32_t));
+    std::memcpy(hp + o_qfast, h_fast.data(), (size_t)n_q);
     SS_HIP(ctx, hipMemcpyAsync(s->d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, st));
     SS_HIP(ctx, hipEventRecord(s->plan_ev[pb], st));
     s->plan_ev_pending[pb] = true;
@@ -1938,6 +1711,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipMemsetAsync(s->d_qticket.p, 0, (size_t)n_q * sizeof(uint32_t), st));
         s->qticket_zeroed = (size_t)n_q;
     }
+    if (!h_mergeq.empty()) {
+        SS_HIP(ctx, ensure(s->d_qcnt, (size_t)n_q));
+        SS_HIP(ctx, hipMemsetAsync(s->d_qcnt.p, 0, (size_t)n_q * sizeof(uint32_t), st));
+    }
     SS_HIP(ctx, ensure(s->d_hits, (size_t)n_q * k));
     SS_HIP(ctx, ensure(s->d_nhits, n_q));
 
@@ -1945,6 +1722,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     ScoreParams p{};
     p.t_ptr = s->title->term_ptr.p; p.t_rec = s->t_rec.p; p.t_w = s->title->post_w.p; p.t_mag = s->title->mag.p; p.t_kth = s->t_kth.p;
     p.b_ptr = s->body->term_ptr.p; p.b_rec = s->b_rec.p; p.b_w = s->body->post_w.p; p.b_mag = s->body->mag.p; p.b_kth = s->b_kth.p;
+    p.t_skip = s->t_skip.p; p.b_skip = s->b_skip.p;
     p.t_pos_ptr = s->title->pos_ptr.p; p.t_pos = s->title->pos.p;
     p.b_pos_ptr = s->body->pos_ptr.p; p.b_pos = s->body->pos.p;
     if (any_phrase) {
@@ -1975,6 +1753,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.exact_all = exact_all ? 1 : 0;
     p.so_key = s->d_so_key.p; p.so_doc = s->d_so_doc.p; p.so_cnt = s->d_so_cnt.p;
     p.q_ticket = fused ? s->d_qticket.p : nullptr;
+    p.qc_cnt = s->d_qcnt.p;
+    p.merge_q = reinterpret_cast<const uint32_t*>(dp + o_mergeq);
+    p.q_fast = reinterpret_cast<const uint8_t*>(dp + o_qfast);
     // results straight into the caller's buffers when both live in device memory (then the call does not wait either)
     bool dev_out = false;
     {
@@ -1999,8 +1780,17 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, st, p);
         hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
     }
-    hipLaunchKernelGGL(k_score_slices, dim3((unsigned)n_slices), dim3(TPB), lds_score, st, p);
-    if (!fused) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
+    if (n_fast_slices) {
+        SS_HIP(ctx, ensure(s->d_wprep, ss::score_wave_prep_bytes((unsigned)n_fast_slices)));
+        ss::launch_score_wave(&p, (unsigned)n_fast_slices, s->d_wprep.p, st);
+    }
+    if (n_slices > n_fast_slices) {
+        ScoreParams ps = p;
+        ps.order = p.order + n_fast_slices;
+        hipLaunchKernelGGL(k_score_slices, dim3((unsigned)(n_slices - n_fast_slices)), dim3(TPB), lds_score, st, ps);
+    }
+    if (!fused && n_slices > n_fast_slices) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
+    if (!h_mergeq.empty()) hipLaunchKernelGGL(k_merge_flat, dim3((unsigned)h_mergeq.size()), dim3(TPB_M), lds_merge, st, p);
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
     ctx->ev_valid[1] = true;
     SS_HIP(ctx, hipGetLastError());
