@@ -1090,34 +1090,82 @@ size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 
 
 // scoring layout: {doc, float32 upper bound of w/mag[doc]} per posting; flags: bit 0 = a weight is negative or not finite,
 // bit 1 = a magnitude is not a positive finite number under a non-zero weight (the filter's assumptions, see k_score_slices)
-// The record array is padded to whole 64-record blocks ({doc 0xFFFFFFFF, impact 0}) and skip[g] = doc of record 64*g: the wave
-// kernel reads whole 512-byte blocks and finds them through the skip index.
 __global__ void k_pack_recs(const uint32_t* __restrict__ doc, const float* __restrict__ w, const double* __restrict__ mag,
-                            uint64_t n, Rec* __restrict__ out, uint32_t* __restrict__ skip, uint32_t* __restrict__ flags) {
+                            uint64_t n, Rec* __restrict__ out, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t n_pad = (n + 63) & ~(uint64_t)63;
     uint32_t f = 0;
-    for (; i < n_pad; i += stride) {
+    for (; i < n; i += stride) {
         Rec r;
-        if (i < n) {
-            r.doc = doc[i];
-            const float wi = w[i];
-            const double m = mag[r.doc];
-            if (!(wi >= 0.0f) || isinf(wi)) f |= 1u;
-            if (wi != 0.0f && (!(m > 0.0) || isinf(m))) f |= 2u;
-            r.imp = impact_of(wi, m);
-        } else {
-            r.doc = 0xFFFFFFFFu;
-            r.imp = 0.0f;
-        }
+        r.doc = doc[i];
+        const float wi = w[i];
+        const double m = mag[r.doc];
+        if (!(wi >= 0.0f) || isinf(wi)) f |= 1u;
+        if (wi != 0.0f && (!(m > 0.0) || isinf(m))) f |= 2u;
+        r.imp = impact_of(wi, m);
         out[i] = r;
-        if ((i & 63) == 0) skip[i >> 6] = r.doc;
     }
     if (__ballot(f != 0)) {
         for (int o = 32; o > 0; o >>= 1) f |= (uint32_t)__shfl_xor((int)f, o, 64);
         if ((threadIdx.x & 63) == 0) atomicOr(flags, f);
     }
+}
+
+// Combined lists for k_score_wave: the title and body postings of a term merged into ONE doc-sorted list (body before title
+// on the same doc), field in bit 31 of the doc word.  c_ptr[t] = t_ptr[t] + b_ptr[t]; c_org[i] = the posting's index in its own
+// table's list (the exact stage reads the float32 weight there).  One thread per posting of one table: its place is its own
+// index plus the number of the OTHER field's postings of the term that come before it.  A block finds the terms its
+// postings span with two binary searches; each posting then finds its term inside that short range.
+constexpr int CM_TPB = 256, CM_PT = 8, CM_CHUNK = CM_TPB * CM_PT;
+__global__ __launch_bounds__(CM_TPB) void k_merge_lists(const uint64_t* __restrict__ my_ptr, const Rec* __restrict__ my_rec, uint64_t n_my,
+                                                        const uint64_t* __restrict__ ot_ptr, const Rec* __restrict__ ot_rec, uint64_t n_terms,
+                                                        int my_field, Rec* __restrict__ c_rec, uint32_t* __restrict__ c_org) {
+    __shared__ uint64_t s_t[2];
+    const uint64_t base = (uint64_t)blockIdx.x * CM_CHUNK;
+    if (base >= n_my) return;
+    const uint64_t last = min(base + CM_CHUNK, n_my) - 1;
+    if (threadIdx.x < 2) {
+        const uint64_t target = threadIdx.x == 0 ? base : last;      // largest t with my_ptr[t] <= target
+        uint64_t lo = 0, hi = n_terms;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (my_ptr[mid] <= target) lo = mid; else hi = mid;
+        }
+        s_t[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const uint64_t t_lo = s_t[0], t_hi = s_t[1];
+    for (int j = 0; j < CM_PT; j++) {
+        const uint64_t i = base + (uint64_t)j * CM_TPB + threadIdx.x;
+        if (i > last) break;
+        uint64_t lo = t_lo, hi = t_hi + 1;                            // my_ptr[lo] <= i < my_ptr[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (my_ptr[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint64_t t = lo;
+        const Rec r = my_rec[i];
+        // postings of the other field before this one: body (field 0) goes first on the same doc
+        const uint64_t o0 = ot_ptr[t], o1 = ot_ptr[t + 1];
+        const uint64_t before = lower_bound_rec(ot_rec, o0, o1, my_field == 0 ? r.doc : r.doc + 1u) - o0;
+        const uint64_t pos = my_ptr[t] + o0 + (i - my_ptr[t]) + before;       // c_ptr[t] = my_ptr[t] + ot_ptr[t]
+        Rec c = r;
+        c.doc = r.doc | ((uint32_t)my_field << 31);
+        c_rec[pos] = c;
+        c_org[pos] = (uint32_t)(i - my_ptr[t]);
+    }
+}
+// pad behind the combined records ({doc 0x7FFFFFFF body, impact 0}: in no window) and the skip index: c_skip[g] = doc of record 64*g
+__global__ void k_combined_finish(Rec* __restrict__ c_rec, uint64_t n, uint32_t* __restrict__ c_skip) {
+    const uint64_t n_pad = ((n + 63) & ~(uint64_t)63) + 64;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i >= n) { Rec r; r.doc = 0x7FFFFFFFu; r.imp = 0.0f; c_rec[i] = r; }
+        if ((i & 63) == 0) c_skip[i >> 6] = c_rec[i].doc & 0x7FFFFFFFu;
+    }
+}
+__global__ void k_add_ptr_u64(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
 }
 
 // k'-th largest impact of every term's list for k' = 2^0 .. 2^10 (0 where the list is shorter), as LOWER bounds:
@@ -1224,8 +1272,13 @@ struct ss_scorer {
     ss_index* title = nullptr;
     ss_index* body = nullptr;
     uint64_t n_docs = 0, n_terms = 0;
-    ss::DevBuf<Rec> t_rec, b_rec;              // scoring records {doc, impact}, padded to whole 64-record blocks
-    ss::DevBuf<uint32_t> t_skip, b_skip;        // skip[g] = doc of record 64*g
+    ss::DevBuf<Rec> t_rec, b_rec;              // scoring records {doc, impact}
+    // combined lists (k_score_wave): title + body postings of a term merged by doc, field in bit 31 of the doc word
+    ss::DevBuf<Rec> c_rec;
+    ss::DevBuf<uint32_t> c_org, c_skip;
+    ss::DevBuf<uint64_t> c_ptr;
+    bool has_combined = false;
+    uint64_t c_pad_block = 0;
     ss::DevBuf<float> t_kth, b_kth;             // [T][KTH_N] k'-th largest impact per term (threshold floor)
     bool clean = true;                          // weights >= 0 and finite, magnitudes positive and finite where a weight is not 0
     bool prior_clean = true;                    // every prior value >= 0 and finite
@@ -1288,10 +1341,8 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     s->body = body;
     s->n_docs = title->n_docs;
     s->n_terms = title->n_terms;
-    SS_HIP(ctx, s->t_rec.alloc(((title->n_post + 63) & ~(uint64_t)63) + 64));
-    SS_HIP(ctx, s->b_rec.alloc(((body->n_post + 63) & ~(uint64_t)63) + 64));
-    SS_HIP(ctx, s->t_skip.alloc((title->n_post + 63) / 64 + 1));
-    SS_HIP(ctx, s->b_skip.alloc((body->n_post + 63) / 64 + 1));
+    SS_HIP(ctx, s->t_rec.alloc(title->n_post));
+    SS_HIP(ctx, s->b_rec.alloc(body->n_post));
     SS_HIP(ctx, s->t_kth.alloc((size_t)s->n_terms * KTH_N));
     SS_HIP(ctx, s->b_kth.alloc((size_t)s->n_terms * KTH_N));
     ss::DevBuf<uint32_t> flags;
@@ -1302,11 +1353,35 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     if (title->n_post)
         hipLaunchKernelGGL(k_pack_recs, dim3(std::min<unsigned>(ss::div_up(title->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
                            (const uint32_t*)title->post_doc.p, (const float*)title->post_w.p, (const double*)title->mag.p,
-                           title->n_post, s->t_rec.p, s->t_skip.p, flags.p);
+                           title->n_post, s->t_rec.p, flags.p);
     if (body->n_post)
         hipLaunchKernelGGL(k_pack_recs, dim3(std::min<unsigned>(ss::div_up(body->n_post, 256), 16384u)), dim3(256), 0, ctx->stream,
                            (const uint32_t*)body->post_doc.p, (const float*)body->post_w.p, (const double*)body->mag.p,
-                           body->n_post, s->b_rec.p, s->b_skip.p, flags.p);
+                           body->n_post, s->b_rec.p, flags.p);
+    {
+        // combined lists: only while doc ids leave bit 31 free and the table stays below 2^32 postings (the wave kernel's limits)
+        const uint64_t pc = title->n_post + body->n_post;
+        if (s->n_docs < (1ull << 31) && pc < (1ull << 32) - 128 && s->n_terms && ctx->opt("score.wave", 1) != 0) {
+            const uint64_t pc_pad = ((pc + 63) & ~(uint64_t)63) + 64;
+            SS_HIP(ctx, s->c_rec.alloc(pc_pad));
+            SS_HIP(ctx, s->c_org.alloc(pc_pad));
+            SS_HIP(ctx, s->c_skip.alloc(pc_pad / 64 + 1));
+            SS_HIP(ctx, s->c_ptr.alloc(s->n_terms + 1));
+            hipLaunchKernelGGL(k_add_ptr_u64, dim3(ss::div_up(s->n_terms + 1, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)title->term_ptr.p,
+                               (const uint64_t*)body->term_ptr.p, s->n_terms + 1, s->c_ptr.p);
+            if (body->n_post)
+                hipLaunchKernelGGL(k_merge_lists, dim3(ss::div_up(body->n_post, CM_CHUNK)), dim3(CM_TPB), 0, ctx->stream, (const uint64_t*)body->term_ptr.p,
+                                   (const Rec*)s->b_rec.p, body->n_post, (const uint64_t*)title->term_ptr.p, (const Rec*)s->t_rec.p, s->n_terms, 0,
+                                   s->c_rec.p, s->c_org.p);
+            if (title->n_post)
+                hipLaunchKernelGGL(k_merge_lists, dim3(ss::div_up(title->n_post, CM_CHUNK)), dim3(CM_TPB), 0, ctx->stream, (const uint64_t*)title->term_ptr.p,
+                                   (const Rec*)s->t_rec.p, title->n_post, (const uint64_t*)body->term_ptr.p, (const Rec*)s->b_rec.p, s->n_terms, 1,
+                                   s->c_rec.p, s->c_org.p);
+            hipLaunchKernelGGL(k_combined_finish, dim3(std::min<unsigned>(ss::div_up(pc_pad, 256), 16384u)), dim3(256), 0, ctx->stream, s->c_rec.p, pc, s->c_skip.p);
+            s->has_combined = true;
+            s->c_pad_block = ((pc + 63) & ~(uint64_t)63) / 64;
+        }
+    }
     if (s->n_terms) {
         hipLaunchKernelGGL(k_kth_impact, dim3((unsigned)s->n_terms), dim3(KH_TPB), 0, ctx->stream, (const uint64_t*)title->term_ptr.p,
                            (const Rec*)s->t_rec.p, s->t_kth.p);
@@ -1545,7 +1620,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // k_score_wave (one wave per slice) takes the plain OR queries: few lists, no phrase part, small k, inputs for which the
     // filter's assumptions hold, and a list long enough for the threshold floor (k'-th largest impact, k' >= k) to exist;
     // everything else runs k_score_slices.  Option "score.wave" = 0 switches the wave kernel off (tests, A/B).
-    const bool wave_ok = ctx->opt("score.wave", 1) != 0 && !exact_all && k <= ss::score_wave_max_k();
+    const bool wave_ok = ctx->opt("score.wave", 1) != 0 && s->has_combined && !exact_all && k <= ss::score_wave_max_k();
     uint64_t wave_target = 0;
     if (wave_ok) {
         // about four slices per resident wave slot, 8k .. 48k postings each
@@ -1599,7 +1674,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
             for (size_t j = d0; j < h_dterm.size(); j++)
                 longest = std::max<uint64_t>(longest, std::max(tp[h_dterm[j] + 1] - tp[h_dterm[j]], bp[h_dterm[j] + 1] - bp[h_dterm[j]]));
             const bool phrase_q = p_ptr && h_pptr[q + 1] > h_pptr[q];
-            if (wave_ok && !phrase_q && h_dterm.size() > d0 && 2 * (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists() &&
+            if (wave_ok && !phrase_q && h_dterm.size() > d0 && (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists() &&
                 longest >= (uint64_t)4 * (uint64_t)k && longest >= 1024) {
                 h_fast[q] = 1;
                 q_target = wave_target;
@@ -1722,7 +1797,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     ScoreParams p{};
     p.t_ptr = s->title->term_ptr.p; p.t_rec = s->t_rec.p; p.t_w = s->title->post_w.p; p.t_mag = s->title->mag.p; p.t_kth = s->t_kth.p;
     p.b_ptr = s->body->term_ptr.p; p.b_rec = s->b_rec.p; p.b_w = s->body->post_w.p; p.b_mag = s->body->mag.p; p.b_kth = s->b_kth.p;
-    p.t_skip = s->t_skip.p; p.b_skip = s->b_skip.p;
+    p.c_ptr = s->c_ptr.p; p.c_rec = s->c_rec.p; p.c_org = s->c_org.p; p.c_skip = s->c_skip.p;
+    p.c_pad_block = (uint32_t)s->c_pad_block;
     p.t_pos_ptr = s->title->pos_ptr.p; p.t_pos = s->title->pos.p;
     p.b_pos_ptr = s->body->pos_ptr.p; p.b_pos = s->body->pos.p;
     if (any_phrase) {

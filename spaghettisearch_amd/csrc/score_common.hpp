@@ -97,8 +97,10 @@ struct ScoreParams {
     // per table: term_ptr, scoring records, the index's float32 weights and float64 magnitudes, k'-th largest impacts
     const uint64_t* t_ptr; const Rec* t_rec; const float* t_w; const double* t_mag; const float* t_kth;
     const uint64_t* b_ptr; const Rec* b_rec; const float* b_w; const double* b_mag; const float* b_kth;
-    // skip index of the record arrays (k_score_wave): skip[g] = doc of record 64*g, one entry per 512-byte block of records
-    const uint32_t* t_skip; const uint32_t* b_skip;
+    // combined lists of k_score_wave: per term the title and body postings merged by doc (field in bit 31 of the doc word),
+    // c_org = index of the posting in its own table's list, c_skip[g] = doc of record 64*g (one entry per 512-byte block)
+    const uint64_t* c_ptr; const Rec* c_rec; const uint32_t* c_org; const uint32_t* c_skip;
+    uint32_t c_pad_block;     // blocks of real records (the block behind them is all padding)
     // positional postings (phrase search, retrieval/phrase.go): pos_ptr[P+1] into pos[] per table, or null
     const uint64_t* t_pos_ptr; const float* t_pos;
     const uint64_t* b_pos_ptr; const float* b_pos;

@@ -9,6 +9,8 @@
 //     exact stage's table and the running top-k are all private to the wave, so the main loop has no workgroup barrier
 //     and no cross-wave traffic at all: LDS operations of one wave execute in order, which is the only ordering the
 //     filter needs (add -> read back -> clear).
+//   * the lists are the COMBINED lists of the scorer (title and body postings of a term merged by doc, field in bit 31 of
+//     the doc word): a query of n terms is n lists, not 2n, and the sparse title lists cost no blocks of their own.
 //   * records are read as whole 512-byte BLOCKS (64 records, aligned in the record array) found through a skip index
 //     (skip[g] = doc of record 64*g, 1/128 of the record bytes).  A window is a doc range [b_lo, b_hi); a block belongs
 //     to every window it overlaps and each record decides by ONE compare whether it is in the current window — so
@@ -33,28 +35,43 @@ namespace {
 
 constexpr int WCW = 16;                 // block slots per group (= one regular window)
 #ifndef SSW_MINW
-#define SSW_MINW 2
+#define SSW_MINW 3
 #endif
 #ifndef SSW_DEPTH
 #define SSW_DEPTH 2
 #endif
 constexpr int WDEPTH = SSW_DEPTH;       // groups whose loads are in flight or in registers (2 or 3)
 constexpr int WSK = 1024;               // sketch slots; slot WSK is a dummy that always holds 0
-constexpr int WSE = 480;                // skip entries staged per round
-constexpr int WGMAX = 64;               // group rows per round; 2 * ceil((WSE + WL) / WCW) <= WGMAX
-constexpr int WPW = 128;                // pending survivors = capacity of the wave's exact stage
-constexpr int WHT = 256;                // exact-stage hash slots
+// LDS per wave decides the occupancy: 13.6 KB is three waves per SIMD (12 per CU), and the loop is latency-bound below that
+#ifndef SSW_SE
+#define SSW_SE 224
+#endif
+#ifndef SSW_SLACK
+#define SSW_SLACK 3
+#endif
+constexpr int WSE = SSW_SE;             // skip entries staged per round
+constexpr int WGMAX = 2 * ((WSE + 12 + 15) / 16) + 2;   // group rows per round
+constexpr int WPW = 96;                 // pending survivors = capacity of the wave's exact stage
+constexpr int WHT = 128;                // exact-stage hash slots (they share their LDS with the skip entries: plan_round refills them)
+constexpr int WHT_SHIFT = 25;           // 32 - log2(WHT)
+static_assert((1 << (32 - WHT_SHIFT)) == WHT, "hash shift");
 constexpr int WL = 12;                  // lists per query
 constexpr int WCB = 256;                // candidate buffer (>= 2k)
 constexpr uint32_t WINF = 0xFFFFFFFFu;
-constexpr uint32_t D_EMPTY = 0xFFFFu;   // group slot without a block
+// block descriptor: list (4 bits) | D_FIRST | D_LAST | block index in the table's record array << 6.  A slot without a block
+// names a block the wave reads anyway, as a "list" whose lane bounds are empty: the loop has no "empty" case.
 constexpr uint32_t D_FIRST = 0x10u, D_LAST = 0x20u;    // the block is the first / last one of its list: part of it belongs to a neighbouring list
 constexpr uint32_t FX_CLAMP_SLOW = 1u << 17;           // oversize windows: (WSE + WL) * 64 records of this much stay below 2^32
 static_assert((uint64_t)(WSE + WL) * 64 * FX_CLAMP_SLOW < (1ull << 32), "slow-path sums must not wrap");
 static_assert((uint64_t)WCW * 64 * FX_CLAMP < (1ull << 32), "fast-path sums must not wrap");
 static_assert(2 * ((WSE + WL + WCW - 1) / WCW) <= WGMAX, "a round's plan must fit its rows");
+static_assert(WPW <= 128, "wave_flush takes two pending entries per lane");
 enum : uint32_t { M_NORMAL = 1, M_SLOW = 2, M_SKIP = 0 };
 
+#ifdef SSW_CHECK
+// checked build (tools/build_diag.sh with EXTRA=-DSSW_CHECK): a block index outside its table is recorded and replaced by block 0
+__device__ uint32_t g_wcheck[8];
+#endif
 #ifdef SS_DIAG
 __device__ unsigned long long g_wdiag[32];
 #define WDIAG_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_wdiag[i], (unsigned long long)(v)); } while (0)
@@ -65,6 +82,10 @@ __device__ unsigned long long g_wdiag[32];
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// number of set bits of the wave mask m below this lane (v_mbcnt: no 64-bit per-lane mask to keep in registers)
+__device__ __forceinline__ uint32_t bits_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -150,28 +171,31 @@ __device__ __forceinline__ uint32_t w_slot(uint32_t doc) { return (doc ^ (doc >>
 // What a slice needs to know about one of its lists, resolved by k_wave_prep for all slices of the batch at once (the
 // chains of dependent loads and the searches in the skip index then run side by side instead of at the head of every slice).
 struct __attribute__((aligned(16))) WPrep {
-    uint32_t g0, g1;          // first / last block of the list
+    uint32_t g0, g1;          // first / last block of the (combined) list
     uint32_t cg, ge;          // blocks that hold the slice's doc range
-    uint32_t p0_lo;           // first posting of the list (low 32 bits)
     uint32_t lanes;           // lo_lane | hi_lane << 8 | active << 16
-    float kth;                // k'-th largest impact of the list (threshold floor)
+    float kth_b, kth_t;       // k'-th largest impact of the term's body / title list (threshold floor)
     uint32_t mult;
 };
 
+typedef const ScoreParams __attribute__((address_space(4)))* kparams_chk_t;
+struct RareArgs { const double* t_mag; const double* b_mag; const double* prior; const uint32_t* c_org; int32_t k_topics, k; };
+
 struct WaveLds {
     double2* s_rec;      // [WPW] exact stage: {addend, magnitude}
-    uint4* pend;         // [WPW] the same bytes while pending: {doc, index in list, list, -}
-    uint64_t* l_w;       // [WL] address of the list's first float32 weight
+    uint4* pend;         // [WPW] the same bytes while pending: {doc, index in the combined arrays, term, field}
+    uint64_t* l_wb;      // [WL] address of the first float32 weight of the term's body list
+    uint64_t* l_wt;      // [WL] ... of its title list
     uint32_t* l_mult;    // [WL]
-    uint32_t* l_field;   // [WL]
     uint32_t* ht_key;    // [WHT]
     uint32_t* ht_rec;    // [WHT]
     uint32_t* overflow;
 };
 
 // ---- exact stage of one wave (flush_pending / score_owned of score.hip for 64 threads) ------------------------------
-__device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& tk, const SliceQuery& Q, const ScoreParams& p, int lane,
+__device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& tk, const SliceQuery& Q, const RareArgs& ra, int lane,
                                                  uint32_t doc, uint32_t slot) {
+    const RareArgs* kp = &ra;
     uint32_t e_doc = EMPTY;
     uint64_t e_key = 0;
     if (slot != EMPTY) {
@@ -189,7 +213,7 @@ __device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& t
         if (Q.probs) {
             // the prior row is only fetched if the doc can still make the top-k (every operation of final_rank is monotone in sqd)
             final_rank(T, B, mt, mb, Q.qmag, Q.sqd_ub, title, body, fin);
-            if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, Q.qmag, topic_dot(p.prior, Q.probs, p.k_topics, e_doc), title, body, fin);
+            if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, Q.qmag, topic_dot(kp->prior, Q.probs, kp->k_topics, e_doc), title, body, fin);
             else e_doc = EMPTY;
         } else {
             final_rank(T, B, mt, mb, Q.qmag, 0.0, title, body, fin);
@@ -209,30 +233,39 @@ __device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& t
         }
         lds_wait();
         if (!*S.overflow) break;
-        topk_compact(tk, p.k);
+        topk_compact(tk, kp->k);
         if (lane == 0) *S.overflow = 0;
         lds_wait();
     }
 }
 
-__device__ __noinline__ void wave_flush(const WaveLds S, const TopK tk, const SliceQuery Q, const ScoreParams& p, int lane, uint32_t n) {
-    uint32_t pdoc[2], pl[2], own[2];
+__device__ __noinline__ void wave_flush(const WaveLds S, const TopK tk, const SliceQuery Q, const RareArgs ra, int lane, uint32_t n) {
+    const RareArgs* kp = &ra;
+    uint32_t pdoc[2], pl[2], pf[2], own[2];
     float pw[2];
     double pm[2];
+    uint32_t porg[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const uint32_t i = lane + r * 64;
         pl[r] = EMPTY;
+        pf[r] = 0;
         pdoc[r] = 0;
-        pw[r] = 0.f;
+        porg[r] = 0;
         pm[r] = 1.0;
         if (i < n) {
             const uint4 e = S.pend[i];
             pdoc[r] = e.x;
             pl[r] = e.z;
-            pw[r] = load_w(S.l_w[e.z], e.y);
-            pm[r] = (S.l_field[e.z] ? p.t_mag : p.b_mag)[e.x];
+            pf[r] = e.w;
+            porg[r] = kp->c_org[e.y];                   // the posting's index in its own table's list
+            pm[r] = (e.w ? kp->t_mag : kp->b_mag)[e.x];
         }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        pw[r] = 0.f;
+        if (pl[r] != EMPTY) pw[r] = load_w(pf[r] ? S.l_wt[pl[r]] : S.l_wb[pl[r]], porg[r]);
     }
     lds_wait();                                     // every pending entry has been read: the bytes may be rewritten
 #pragma unroll
@@ -241,14 +274,14 @@ __device__ __noinline__ void wave_flush(const WaveLds S, const TopK tk, const Sl
         own[r] = EMPTY;
         if (l != EMPTY) {
             const uint32_t i = lane + r * 64;
-            uint32_t h = (pdoc[r] * 2654435761u) >> 24;             // 8 hash bits -> [0, WHT)
+            uint32_t h = (pdoc[r] * 2654435761u) >> WHT_SHIFT;      // -> [0, WHT)
             for (;;) {
                 const uint32_t prev = atomicCAS(&S.ht_key[h], EMPTY, pdoc[r]);
                 if (prev == EMPTY) own[r] = h;
                 if (prev == EMPTY || prev == pdoc[r]) break;
                 h = (h + 1) & (uint32_t)(WHT - 1);
             }
-            const uint32_t field = S.l_field[l];
+            const uint32_t field = pf[r];
             const double v = (double)pw[r] * (double)S.l_mult[l];    // main_retrieve.go:61-69: a duplicate token counts again
             S.s_rec[i] = make_double2(v, pm[r]);
             asm volatile("" ::: "memory");
@@ -266,29 +299,19 @@ __device__ __noinline__ void wave_flush(const WaveLds S, const TopK tk, const Sl
     }
     lds_wait();
 #pragma unroll
-    for (int r = 0; r < 2; r++) wave_score_owned(S, tk, Q, p, lane, pdoc[r], own[r]);
+    for (int r = 0; r < 2; r++) wave_score_owned(S, tk, Q, ra, lane, pdoc[r], own[r]);
 }
 
-// per-list constants, lane l < L holds list l
+// per-list constants, lane l < L holds list l (= distinct query term l)
 struct WList {
-    uint32_t tb_lo, tb_hi;      // address of the table's record array (t_rec or b_rec)
     uint32_t g0, g1;            // first / last 64-record block of the list
     uint32_t lo_lane, hi_lane;  // lanes of block g0 below lo_lane and lanes of block g1 from hi_lane on belong to other lists
     uint32_t ge;                // last block that can hold a doc of the slice
     uint32_t cg;                // block that holds the frontier
     uint32_t q, soff;           // this round: skip entries staged, where in `se`
-    uint32_t pos0;              // 64 * cg - (first posting of the list): index in the list of lane 0 of block cg (may wrap for block g0)
-    uint32_t rb_lo, rb_hi;      // address of block cg
-    float coef;                 // filter coefficient in fixed-point units
+    float coef_b, coef_t;       // filter coefficients of a body / title posting, in fixed-point units
     bool active;
 };
-
-__device__ __forceinline__ void set_round_base(WList& w, uint32_t p0_lo) {
-    const uint64_t a = (((uint64_t)w.tb_hi << 32) | w.tb_lo) + (uint64_t)w.cg * 512u;
-    w.rb_lo = (uint32_t)a;
-    w.rb_hi = (uint32_t)(a >> 32);
-    w.pos0 = w.cg * 64u - p0_lo;
-}
 
 // membership of a block's 64 records in the doc range [b_lo, b_lo + span) of list `l`
 __device__ __forceinline__ bool block_active(uint32_t d, uint32_t doc, uint32_t b_lo, uint32_t span, const WList& w, int lane) {
@@ -302,15 +325,15 @@ __device__ __forceinline__ bool block_active(uint32_t d, uint32_t doc, uint32_t 
     return act;
 }
 
-__device__ __forceinline__ uint64_t block_addr(uint32_t d, const WList& w) {
-    const int l = (int)(d & 15u);
-    return (((uint64_t)rl(w.rb_hi, l) << 32) | rl(w.rb_lo, l)) + (uint64_t)(d >> 6) * 512u;
-}
+// address of the 512-byte block a descriptor names: table base (scalar, by the list's field) + 512 * block index
+// address of the 512-byte block a descriptor names
+__device__ __forceinline__ uint64_t block_addr(uint32_t d, uint64_t tb) { return tb + ((uint64_t)(d >> 6) << 9); }
 
 struct WaveCtx {
     uint32_t* sk;
     uint32_t (*ghdr)[4];
-    uint16_t (*gdesc)[WCW];
+    uint32_t (*gdesc)[WCW];
+    uint64_t tb;             // the combined record array
     WaveLds S;
     TopK tk;
     SliceQuery Q;
@@ -323,16 +346,17 @@ __device__ __forceinline__ uint32_t wave_thr_fx(const WaveCtx& C) { return max(1
 // window; they are added with the smaller clamp, and the whole sketch is cleared at the end).  Otherwise the caller has
 // added them (and its slots are cleared here).  The pending list must be empty.  Survivors go to the exact stage by doc
 // sub-range, bisected until a piece fits.
-__device__ __noinline__ void slow_window(const WaveCtx C, const ScoreParams& p, const WList w, int lane, uint32_t row, uint32_t n_blocks,
+__device__ __noinline__ void slow_window(const WaveCtx C, const RareArgs ra, const WList w, int lane, uint32_t row, uint32_t n_blocks,
                                          uint32_t b_lo, uint32_t span, bool need_add) {
     const uint32_t clamp = need_add ? FX_CLAMP_SLOW : FX_CLAMP;
     if (need_add) {
         for (uint32_t i = 0; i < n_blocks; i++) {
             const uint32_t d = rfl(C.gdesc[row + i / WCW][i % WCW]);
-            const u32x2 rec = *(gptr_u2)(block_addr(d, w) + (uint32_t)lane * 8u);
-            const float coef = __uint_as_float(rl(__float_as_uint(w.coef), (int)(d & 15u)));
-            if (block_active(d, rec.x, b_lo, span, w, lane))
-                atomicAdd(&C.sk[w_slot(rec.x)], min(fx_share(__uint_as_float(rec.y), coef), clamp));
+            const u32x2 rec = *(gptr_u2)(block_addr(d, C.tb) + (uint32_t)lane * 8u);
+            const uint32_t doc = rec.x & 0x7FFFFFFFu;
+            const float cb = __uint_as_float(rl(__float_as_uint(w.coef_b), (int)(d & 15u))), ct = __uint_as_float(rl(__float_as_uint(w.coef_t), (int)(d & 15u)));
+            if (block_active(d, doc, b_lo, span, w, lane))
+                atomicAdd(&C.sk[w_slot(doc)], min(fx_share(__uint_as_float(rec.y), (rec.x >> 31) ? ct : cb), clamp));
         }
         lds_wait();
     }
@@ -344,9 +368,10 @@ __device__ __noinline__ void slow_window(const WaveCtx C, const ScoreParams& p, 
             uint32_t cnt = 0;
             for (uint32_t i = 0; i < n_blocks; i++) {
                 const uint32_t d = rfl(C.gdesc[row + i / WCW][i % WCW]);
-                const u32x2 rec = *(gptr_u2)(block_addr(d, w) + (uint32_t)lane * 8u);
-                const bool act = block_active(d, rec.x, b_lo, span, w, lane) && (rec.x - (b_lo + cur)) < sub;
-                const uint32_t u = act ? C.sk[w_slot(rec.x)] : 0u;
+                const u32x2 rec = *(gptr_u2)(block_addr(d, C.tb) + (uint32_t)lane * 8u);
+                const uint32_t doc = rec.x & 0x7FFFFFFFu;
+                const bool act = block_active(d, doc, b_lo, span, w, lane) && (doc - (b_lo + cur)) < sub;
+                const uint32_t u = act ? C.sk[w_slot(doc)] : 0u;
                 cnt += (uint32_t)__popcll(__ballot(act && u >= thr));
             }
             if (cnt <= (uint32_t)WPW || sub == 1) break;
@@ -355,22 +380,21 @@ __device__ __noinline__ void slow_window(const WaveCtx C, const ScoreParams& p, 
         uint32_t n = 0;
         for (uint32_t i = 0; i < n_blocks; i++) {
             const uint32_t d = rfl(C.gdesc[row + i / WCW][i % WCW]);
-            const u32x2 rec = *(gptr_u2)(block_addr(d, w) + (uint32_t)lane * 8u);
-            const bool act = block_active(d, rec.x, b_lo, span, w, lane) && (rec.x - (b_lo + cur)) < sub;
-            const uint32_t u = act ? C.sk[w_slot(rec.x)] : 0u;
+            const u32x2 rec = *(gptr_u2)(block_addr(d, C.tb) + (uint32_t)lane * 8u);
+            const uint32_t doc = rec.x & 0x7FFFFFFFu;
+            const bool act = block_active(d, doc, b_lo, span, w, lane) && (doc - (b_lo + cur)) < sub;
+            const uint32_t u = act ? C.sk[w_slot(doc)] : 0u;
             const bool surv = act && u >= thr;
             const unsigned long long m = __ballot(surv);
             if (m) {
                 const int l = (int)(d & 15u);
-                const uint32_t idx0 = rl(w.pos0, l) + (d >> 6) * 64u;
-                const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-                const uint32_t pos = n + (uint32_t)__popcll(m & below);
-                if (surv && pos < (uint32_t)WPW) C.S.pend[pos] = make_uint4(rec.x, idx0 + (uint32_t)lane, (uint32_t)l, 0u);
+                const uint32_t pos = n + bits_below(m);
+                if (surv && pos < (uint32_t)WPW) C.S.pend[pos] = make_uint4(doc, (d >> 6) * 64u + (uint32_t)lane, (uint32_t)l, rec.x >> 31);
                 n += (uint32_t)__popcll(m);
             }
         }
         lds_wait();
-        if (n) wave_flush(C.S, C.tk, C.Q, p, lane, min(n, (uint32_t)WPW));
+        if (n) wave_flush(C.S, C.tk, C.Q, ra, lane, min(n, (uint32_t)WPW));
         cur += sub;
     }
     if (need_add) {
@@ -379,8 +403,8 @@ __device__ __noinline__ void slow_window(const WaveCtx C, const ScoreParams& p, 
         // the caller's adds: clear exactly the slots of the window's records
         for (uint32_t i = 0; i < n_blocks; i++) {
             const uint32_t d = rfl(C.gdesc[row + i / WCW][i % WCW]);
-            const u32x2 rec = *(gptr_u2)(block_addr(d, w) + (uint32_t)lane * 8u);
-            if (block_active(d, rec.x, b_lo, span, w, lane)) C.sk[w_slot(rec.x)] = 0u;
+            const u32x2 rec = *(gptr_u2)(block_addr(d, C.tb) + (uint32_t)lane * 8u);
+            if (block_active(d, rec.x & 0x7FFFFFFFu, b_lo, span, w, lane)) C.sk[w_slot(rec.x & 0x7FFFFFFFu)] = 0u;
         }
     }
     lds_wait();
@@ -391,63 +415,84 @@ __device__ __noinline__ void slow_window(const WaveCtx C, const ScoreParams& p, 
 // are counted by hand: a group is ALWAYS WCW loads, nothing else issues vector-memory operations inside the hot loop,
 // and block c of the group being processed has exactly (WCW - 1 - c) + (WDEPTH - 1) * WCW younger loads in flight.
 // ring_wait<N> names the destination "+v" so that no consumer is scheduled above it (cdna_hip_programming.md §5.7 (ii)).
+#ifndef SSW_PLAIN_RING
+#define SSW_ASM_RING 1      // -DSSW_PLAIN_RING: compiler-counted loads (A/B builds; about 1.6x slower)
+#endif
 #ifdef SSW_ASM_RING
 template <int N>
 __device__ __forceinline__ void ring_wait(u32x2& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
 __device__ __forceinline__ void ring_keep(u32x2& r) { asm volatile("" : "+v"(r)); }
+template <int N>
+__device__ __forceinline__ void ring_drain_slot() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }   // the slot's data is not used: no operand, no copy
 #else
+template <int N>
+__device__ __forceinline__ void ring_drain_slot() {}
 template <int N>
 __device__ __forceinline__ void ring_wait(u32x2&) {}
 __device__ __forceinline__ void ring_keep(u32x2&) {}
 #endif
 
 template <int S_, int C_>
-__device__ __forceinline__ void block_issue(const WList& w, uint32_t dv, int lane, uint64_t dummy, u32x2 (&rec)[WDEPTH][WCW]) {
-    const uint32_t d = rl(dv, C_);
-    uint64_t base = dummy;
-    uint32_t voff = 0;
-    if (d != D_EMPTY) {
-        base = block_addr(d, w);
-        voff = (uint32_t)lane * 8u;
+__device__ __forceinline__ void block_issue(uint64_t tb, uint32_t dv, uint32_t lane8, u32x2 (&rec)[WDEPTH][WCW]) {
+#ifdef SSW_CHECK
+    uint32_t dchk = rl(dv, C_);
+    {
+        const kparams_chk_t kp = (kparams_chk_t)__builtin_amdgcn_kernarg_segment_ptr();
+        const uint32_t lim = kp->c_pad_block;
+        if ((dchk >> 6) > lim) {
+            if (lane8 == 0) { atomicAdd(&g_wcheck[0], 1u); g_wcheck[1] = dchk; g_wcheck[2] = lim; g_wcheck[3] = blockIdx.x; }
+            dchk &= 63u;
+        }
     }
+    const uint64_t base = block_addr(dchk, tb);
+#else
+    const uint64_t base = block_addr(rl(dv, C_), tb);               // scalar
+#endif
 #ifdef SSW_ASM_RING
-    const uint64_t addr = base + voff;
+    const uint64_t addr = base + lane8;
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rec[S_][C_]) : "v"(addr));
 #else
-    rec[S_][C_] = *(gptr_u2)(base + voff);
+    rec[S_][C_] = *(gptr_u2)(base + lane8);
 #endif
 }
 template <int S_>
-__device__ __forceinline__ void group_issue(const WaveCtx& C, const WList& w, uint32_t row, int lane, uint64_t dummy,
-                                            u32x2 (&rec)[WDEPTH][WCW], uint32_t (&dvr)[WDEPTH]) {
-    const uint32_t dv = C.gdesc[row][lane & (WCW - 1)];
+__device__ __forceinline__ void group_issue(const ScoreParams& p, uint32_t (*gdesc)[WCW], uint32_t row, int lane, u32x2 (&rec)[WDEPTH][WCW],
+                                            uint32_t (&dvr)[WDEPTH]) {
+    // the table base straight from the kernel arguments (a scalar register by construction; as a member of a struct that is
+    // also handed to the non-inlined rare paths it ends up in vector registers)
+    const uint64_t tb = (uint64_t)p.c_rec;
+    const uint32_t dv = gdesc[row][lane & (WCW - 1)];
+    const uint32_t lane8 = (uint32_t)lane * 8u;
     dvr[S_] = dv;
-    block_issue<S_, 0>(w, dv, lane, dummy, rec);  block_issue<S_, 1>(w, dv, lane, dummy, rec);
-    block_issue<S_, 2>(w, dv, lane, dummy, rec);  block_issue<S_, 3>(w, dv, lane, dummy, rec);
-    block_issue<S_, 4>(w, dv, lane, dummy, rec);  block_issue<S_, 5>(w, dv, lane, dummy, rec);
-    block_issue<S_, 6>(w, dv, lane, dummy, rec);  block_issue<S_, 7>(w, dv, lane, dummy, rec);
-    block_issue<S_, 8>(w, dv, lane, dummy, rec);  block_issue<S_, 9>(w, dv, lane, dummy, rec);
-    block_issue<S_, 10>(w, dv, lane, dummy, rec); block_issue<S_, 11>(w, dv, lane, dummy, rec);
-    block_issue<S_, 12>(w, dv, lane, dummy, rec); block_issue<S_, 13>(w, dv, lane, dummy, rec);
-    block_issue<S_, 14>(w, dv, lane, dummy, rec); block_issue<S_, 15>(w, dv, lane, dummy, rec);
+    block_issue<S_, 0>(tb, dv, lane8, rec);  block_issue<S_, 1>(tb, dv, lane8, rec);
+    block_issue<S_, 2>(tb, dv, lane8, rec);  block_issue<S_, 3>(tb, dv, lane8, rec);
+    block_issue<S_, 4>(tb, dv, lane8, rec);  block_issue<S_, 5>(tb, dv, lane8, rec);
+    block_issue<S_, 6>(tb, dv, lane8, rec);  block_issue<S_, 7>(tb, dv, lane8, rec);
+    block_issue<S_, 8>(tb, dv, lane8, rec);  block_issue<S_, 9>(tb, dv, lane8, rec);
+    block_issue<S_, 10>(tb, dv, lane8, rec); block_issue<S_, 11>(tb, dv, lane8, rec);
+    block_issue<S_, 12>(tb, dv, lane8, rec); block_issue<S_, 13>(tb, dv, lane8, rec);
+    block_issue<S_, 14>(tb, dv, lane8, rec); block_issue<S_, 15>(tb, dv, lane8, rec);
     static_assert(WCW == 16, "group_issue is written out for 16 block slots");
 }
 
-// block C_ of ring slot S_: wait for its records, add every record of the window into the sketch; returns the slot (WSK: none)
+// block C_ of ring slot S_: every record of the window adds its share into the sketch; returns the slot's BYTE offset
+// (4 * WSK: the lane holds no record of the window)
 template <int S_, int C_>
 __device__ __forceinline__ uint32_t block_add(uint32_t* sk, const WList& w, uint32_t dv, uint32_t b_lo, uint32_t span, int lane,
                                               u32x2 (&rec)[WDEPTH][WCW]) {
     ring_wait<(WCW - 1 - C_) + (WDEPTH - 1) * WCW>(rec[S_][C_]);
+#ifdef SSW_EXP_SKIPADD      // timing experiment only (wrong results): loads and waits, no filter work
+    return (rec[S_][C_].x == 0x12345678u) ? 0u : 4u * (uint32_t)WSK;
+#endif
     const uint32_t d = rl(dv, C_);
-    uint32_t h = (uint32_t)WSK;
-    if (d != D_EMPTY) {
-        const float coef = __uint_as_float(rl(__float_as_uint(w.coef), (int)(d & 15u)));
-        if (block_active(d, rec[S_][C_].x, b_lo, span, w, lane)) {
-            h = w_slot(rec[S_][C_].x);
-            atomicAdd(&sk[h], fx_share(__uint_as_float(rec[S_][C_].y), coef));
-        }
+    const float cb = __uint_as_float(rl(__float_as_uint(w.coef_b), (int)(d & 15u))), ct = __uint_as_float(rl(__float_as_uint(w.coef_t), (int)(d & 15u)));
+    const uint32_t doc = rec[S_][C_].x & 0x7FFFFFFFu;
+    uint32_t h4 = 4u * (uint32_t)WSK;
+    if (block_active(d, doc, b_lo, span, w, lane)) {
+        h4 = w_slot(doc) * 4u;
+        atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sk) + h4), fx_share(__uint_as_float(rec[S_][C_].y), (int32_t)rec[S_][C_].x < 0 ? ct : cb));
     }
-    return h;
+    return h4;
 }
 
 // ---- planning of one round (not hot: once per ~WSE blocks) ---------------------------------------------------------
@@ -455,8 +500,12 @@ __device__ __forceinline__ uint32_t block_add(uint32_t* sk, const WList& w, uint
 // writes the rows (ghdr / gdesc) the streaming loop reads.  Returns {n_rows, e}; adv_out[l] = how many blocks list l's
 // cursor advances when the next round starts at e.
 struct RoundPlan { uint32_t n_rows, e; };
-__device__ __noinline__ RoundPlan plan_round(WList w, const ScoreParams& p, uint32_t* se, uint32_t (*ghdr)[4], uint16_t (*gdesc)[WCW],
+__device__ __noinline__ RoundPlan plan_round(WList w, const uint32_t* c_skip, uint32_t* se, uint32_t (*ghdr)[4], uint32_t (*gdesc)[WCW],
                                              uint32_t* adv_out, int L, unsigned long long act_mask, uint32_t F, uint32_t dhi, int lane) {
+    // a slot without a block re-reads the cursor block of the first active list as "list" 15, whose lane bounds are
+    // empty: no record of it is ever in a window
+    const int l_first = __ffsll((long long)act_mask) - 1;
+    const uint32_t d_empty = 15u | D_FIRST | D_LAST | (rl(w.cg, l_first) << 6);
     const uint32_t rem = w.active && lane < L ? w.ge - w.cg + 1u : 0u;
     const uint32_t tot_rem = wave_sum(rem);
     uint32_t ql = 0;
@@ -465,8 +514,7 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const ScoreParams& p, uint
     w.soff = wave_excl_scan(ql, lane);
     for (int l = 0; l < L; l++) {
         const uint32_t n = rl(w.q, l), so = rl(w.soff, l), cgl = rl(w.cg, l);
-        const uint32_t* sp = (l & 1) ? p.t_skip : p.b_skip;
-        for (uint32_t i = lane; i < n; i += 64) se[so + i] = sp[cgl + 1u + i];
+        for (uint32_t i = lane; i < n; i += 64) se[so + i] = c_skip[cgl + 1u + i];
     }
     lds_wait();
     // the round ends where the first list runs out of staged entries
@@ -479,8 +527,12 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const ScoreParams& p, uint
     const uint32_t q_drv = dkey >> 6, tot_q = wave_sum(w.q);
     const uint32_t so_drv = rl(w.soff, drv);
     const int l_act = __popcll(act_mask);
+    // A window = s driver blocks: expected blocks of a window = s * tot_q / q_drv + one boundary block per other list;
+    // aim SSW_SLACK below WCW: the other lists' counts fluctuate, and a window with more than WCW blocks takes the slow
+    // path, which costs far more than the block slots left empty (measured at config 3: slack 0 / 1 / 2 / 3 blocks ->
+    // 0.81 / 0.67 / 0.67 / 0.66 ms per batch; a fractional s with the same slack is no better).
     uint32_t s = 1;
-    if (q_drv) s = max(1u, (uint32_t)(((uint64_t)(WCW > l_act ? WCW - l_act : 1) * q_drv) / max(tot_q, 1u)));
+    if (q_drv) s = max(1u, (uint32_t)(((uint64_t)(WCW - SSW_SLACK > l_act ? WCW - SSW_SLACK - l_act : 1) * q_drv) / max(tot_q, 1u)));
     const uint32_t nd_e = q_drv ? lds_lower_bound(se + so_drv, q_drv, e) : 0u;      // driver blocks that start inside (F, e)
     uint32_t nw = nd_e / s + 1u;
     if (nw > 63u) { nw = 63u; e = se[so_drv + 63u * s - 1u]; }
@@ -495,11 +547,13 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const ScoreParams& p, uint
         fst[l] = 0; num[l] = 0;
         if (l < L && ((act_mask >> l) & 1ull)) {
             const uint32_t n = rl(w.q, l), so = rl(w.soff, l);
+            // Block i of the list (0 = the cursor block) holds docs from its first doc (the entry before E[i]) up to E[i]
+            // INCLUSIVE: in a combined list the body and the title posting of one doc may sit on either side of a block
+            // boundary.  So the blocks of [B_j, B_j+1) are i = (entries < B_j) .. (entries < B_j+1).
             const uint32_t lb = (uint32_t)lane <= nw ? lds_lower_bound(se + so, n, Bj) : 0u;     // entries < B_j
-            const uint32_t ub = lb + ((lb < n && se[so + lb] == Bj) ? 1u : 0u);                   // entries <= B_j
             const uint32_t lb_next = (uint32_t)__shfl_down((int)lb, 1, 64);
-            fst[l] = ub;                                                                       // also: cursor advance if the round ends at B_j
-            num[l] = (uint32_t)lane < nw ? lb_next - ub + 1u : 0u;
+            fst[l] = lb;                                                                       // also: cursor advance if the round ends at B_j
+            num[l] = (uint32_t)lane < nw ? lb_next - lb + 1u : 0u;
             cnt += num[l];
         }
     }
@@ -521,16 +575,16 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const ScoreParams& p, uint
             if (l < L && ((act_mask >> l) & 1ull)) {
                 const uint32_t cgl = rl(w.cg, l), g0l = rl(w.g0, l), g1l = rl(w.g1, l);
                 for (uint32_t b = 0; b < num[l]; b++) {
-                    const uint32_t rel = fst[l] + b;
-                    uint32_t d = (uint32_t)l | (rel << 6);
-                    if (cgl + rel == g0l) d |= D_FIRST;
-                    if (cgl + rel == g1l) d |= D_LAST;
-                    gdesc[row0 + n / WCW][n % WCW] = (uint16_t)d;
+                    const uint32_t g = cgl + fst[l] + b;
+                    uint32_t d = (uint32_t)l | (g << 6);
+                    if (g == g0l) d |= D_FIRST;
+                    if (g == g1l) d |= D_LAST;
+                    gdesc[row0 + n / WCW][n % WCW] = d;
                     n++;
                 }
             }
         }
-        for (uint32_t i = n; i < rows * WCW; i++) gdesc[row0 + i / WCW][i % WCW] = (uint16_t)D_EMPTY;
+        for (uint32_t i = n; i < rows * WCW; i++) gdesc[row0 + i / WCW][i % WCW] = d_empty;
         for (uint32_t r = 0; r < rows; r++) {
             ghdr[row0 + r][0] = Bj;
             ghdr[row0 + r][1] = b_hi - Bj;
@@ -543,8 +597,11 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const ScoreParams& p, uint
         for (int l = 0; l < WL; l++) adv_out[l] = fst[l];
     }
     // pad rows: the ring reads WDEPTH rows ahead of the row it processes
-    for (int i = lane; i < 2 * WDEPTH * WCW; i += 64) gdesc[n_rows + i / WCW][i % WCW] = (uint16_t)D_EMPTY;
+    for (int i = lane; i < 2 * WDEPTH * WCW; i += 64) gdesc[n_rows + i / WCW][i % WCW] = d_empty;
     if (lane < 2 * WDEPTH) { ghdr[n_rows + lane][0] = 0; ghdr[n_rows + lane][1] = 0; ghdr[n_rows + lane][2] = M_SKIP; ghdr[n_rows + lane][3] = 0; }
+    lds_wait();
+    // the exact stage's table lives where the skip entries were: all empty again
+    for (int i = lane; i < 2 * WHT; i += 64) se[i] = EMPTY;
     lds_wait();
     return RoundPlan{n_rows, e};
 }
@@ -553,7 +610,7 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const ScoreParams& p, uint
 
 namespace ssw {
 
-// one thread per (wave slice, list): list bounds, the slice's block range in the list (two searches in the skip index)
+// one thread per (wave slice, term): list bounds, the slice's block range in the list (two searches in the skip index)
 __global__ __launch_bounds__(256) void k_wave_prep(ScoreParams p, uint32_t n_slices, WPrep* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slices * (uint32_t)WL) return;
@@ -562,24 +619,21 @@ __global__ __launch_bounds__(256) void k_wave_prep(ScoreParams p, uint32_t n_sli
     const SliceDesc sd = p.slices[slice_id];
     const uint32_t t0 = p.q_off[sd.q], nd = p.q_off[sd.q + 1] - t0;
     WPrep r{};
-    if (l < 2 * nd) {
-        const int field = l & 1;
-        const uint32_t term = p.dterm[t0 + (l >> 1)];
-        const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-        const uint64_t p0 = ptr[term], p1 = ptr[term + 1];
-        const uint32_t* sp = field ? p.t_skip : p.b_skip;
+    if (l < nd) {
+        const uint32_t term = p.dterm[t0 + l];
+        const uint64_t p0 = p.c_ptr[term], p1 = p.c_ptr[term + 1];
         const bool active = p1 > p0;
         r.g0 = (uint32_t)(p0 >> 6);
         r.g1 = active ? (uint32_t)((p1 - 1) >> 6) : r.g0;
-        r.p0_lo = (uint32_t)p0;
         r.lanes = (uint32_t)(p0 & 63) | ((active ? (uint32_t)((p1 - 1) & 63) + 1u : 0u) << 8) | ((active ? 1u : 0u) << 16);
-        r.kth = (field ? p.t_kth : p.b_kth)[(size_t)term * KTH_N + p.kth_j];
-        r.mult = p.dmult[t0 + (l >> 1)];
+        r.kth_b = p.b_kth[(size_t)term * KTH_N + p.kth_j];
+        r.kth_t = p.t_kth[(size_t)term * KTH_N + p.kth_j];
+        r.mult = p.dmult[t0 + l];
         uint32_t lo = 0, hi = 0;
         if (r.g1 > r.g0) {
-            // entries skip[g0+1 .. g1] are first docs of the list's own blocks
-            lo = sd.dlo == 0 ? 0u : skip_lower_bound(sp, r.g0 + 1, r.g1 + 1, sd.dlo + 1u);     // entries <= dlo
-            hi = sd.dhi == WINF ? r.g1 - r.g0 : skip_lower_bound(sp, r.g0 + 1, r.g1 + 1, sd.dhi);   // entries < dhi
+            // entries c_skip[g0+1 .. g1] are first docs of the list's own blocks
+            lo = sd.dlo == 0 ? 0u : skip_lower_bound(p.c_skip, r.g0 + 1, r.g1 + 1, sd.dlo);          // entries < dlo (a block that starts AT dlo may follow one that ends with dlo)
+            hi = sd.dhi == WINF ? r.g1 - r.g0 : skip_lower_bound(p.c_skip, r.g0 + 1, r.g1 + 1, sd.dhi);   // entries < dhi
         }
         r.cg = r.g0 + lo;
         r.ge = r.g0 + hi;
@@ -589,16 +643,17 @@ __global__ __launch_bounds__(256) void k_wave_prep(ScoreParams p, uint32_t n_sli
 }
 
 __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, const WPrep* __restrict__ prep) {
-    __shared__ uint32_t sk[WSK + 64];
-    __shared__ uint32_t se[WSE + 32];
+    __shared__ uint32_t sk[WSK + 4];
+    __shared__ uint32_t se[(WSE + 32) > 2 * WHT ? (WSE + 32) : 2 * WHT];   // skip entries while a round is planned, then ht_key | ht_rec
     __shared__ __attribute__((aligned(16))) uint32_t ghdr[WGMAX + 2 * WDEPTH][4];
-    __shared__ uint16_t gdesc[WGMAX + 2 * WDEPTH][WCW];
+    __shared__ uint32_t gdesc[WGMAX + 2 * WDEPTH][WCW];
     __shared__ __attribute__((aligned(16))) unsigned char pend_raw[WPW * 16];
-    __shared__ uint32_t ht_key[WHT], ht_rec[WHT];
+    uint32_t* const ht_key = se;
+    uint32_t* const ht_rec = se + WHT;
     __shared__ uint64_t cd_key[WCB];
     __shared__ uint32_t cd_doc[WCB];
-    __shared__ uint64_t l_w[WL];
-    __shared__ uint32_t l_mult[WL], l_field[WL], l_adv[WL];
+    __shared__ uint64_t l_wb[WL], l_wt[WL];
+    __shared__ uint32_t l_mult[WL], l_adv[WL];
     __shared__ uint64_t sc64[2];
     __shared__ uint32_t sc32[8];
 
@@ -608,17 +663,18 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     const SliceDesc sd = p.slices[slice_id];
     const uint32_t q = sd.q;
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
-    const int L = (int)(2 * nd);                       // <= WL (host)
+    const int L = (int)nd;                             // <= WL (host): one combined list per distinct term
 
     WaveCtx C;
     C.sk = sk;
     C.ghdr = ghdr;
     C.gdesc = gdesc;
+    C.tb = (uint64_t)p.c_rec;
     C.S.s_rec = reinterpret_cast<double2*>(pend_raw);
     C.S.pend = reinterpret_cast<uint4*>(pend_raw);
-    C.S.l_w = l_w;
+    C.S.l_wb = l_wb;
+    C.S.l_wt = l_wt;
     C.S.l_mult = l_mult;
-    C.S.l_field = l_field;
     C.S.ht_key = ht_key;
     C.S.ht_rec = ht_rec;
     C.S.overflow = &sc32[1];
@@ -629,20 +685,15 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     C.Q.qmag_f = (float)C.Q.qmag;
     C.r_ub = C.Q.probs ? __double2float_ru(33.0 * C.Q.sqd_ub * (1.0 + 0x1p-12)) : 0.0f;
 
-    for (int i = lane; i < WSK + 64; i += 64) sk[i] = 0u;
-    for (int i = lane; i < WHT; i += 64) { ht_key[i] = EMPTY; ht_rec[i] = EMPTY; }
+    for (int i = lane; i < WSK + 4; i += 64) sk[i] = 0u;
     if (lane == 0) { sc32[0] = 0; sc32[1] = 0; sc64[0] = 0ull; *reinterpret_cast<float*>(&sc32[2]) = -INFINITY; }
 
-    // ---- the lists (lane l: list l = field l&1 of distinct term l>>1), resolved by k_wave_prep ----
+    // ---- the lists (lane l: the combined list of distinct term l), resolved by k_wave_prep ----
     WList w{};
-    uint32_t p0_lo = 0;
-    float coef_raw = 0.f, floor_l = 0.f;
+    w.lo_lane = 64;                                    // lanes that hold no list: no lane of a block is theirs (see plan_round: d_empty)
+    float coef_raw_b = 0.f, coef_raw_t = 0.f, floor_l = 0.f;
     if (lane < L) {
         const WPrep r = prep[(size_t)blockIdx.x * WL + lane];
-        const int field = lane & 1;                    // 0 = body, 1 = title
-        const uint64_t tb = (uint64_t)(field ? p.t_rec : p.b_rec);
-        w.tb_lo = (uint32_t)tb;
-        w.tb_hi = (uint32_t)(tb >> 32);
         w.active = (r.lanes >> 16) != 0;
         w.g0 = r.g0;
         w.g1 = r.g1;
@@ -650,34 +701,35 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
         w.hi_lane = (r.lanes >> 8) & 0xFFu;
         w.cg = r.cg;
         w.ge = r.ge;
-        p0_lo = r.p0_lo;
-        // first float32 weight of the list: the table's weights + the list's first posting (64-bit; the prep record keeps the low word)
         {
-            const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-            const uint32_t term = p.dterm[t0 + (lane >> 1)];
-            l_w[lane] = (uint64_t)((field ? p.t_w : p.b_w) + ptr[term]);
+            const uint32_t term = p.dterm[t0 + lane];
+            l_wb[lane] = (uint64_t)(p.b_w + p.b_ptr[term]);
+            l_wt[lane] = (uint64_t)(p.t_w + p.t_ptr[term]);
         }
         l_mult[lane] = r.mult;
-        l_field[lane] = (uint32_t)field;
-        // filter coefficient and threshold floor exactly as in k_score_slices (get_metadata.go:57-58,69)
-        const double share = (field ? 38.0 : 29.0) * (double)r.mult / C.Q.qmag;
-        coef_raw = __double2float_ru(share * (1.0 + 0x1p-12));
-        if (r.kth > 0.0f) floor_l = fmaxf(0.0f, __double2float_rd(share * (1.0 - 0x1p-12) * (double)r.kth));
+        // filter coefficients and threshold floor exactly as in k_score_slices (get_metadata.go:57-58,69)
+        const double share_b = 29.0 * (double)r.mult / C.Q.qmag, share_t = 38.0 * (double)r.mult / C.Q.qmag;
+        coef_raw_b = __double2float_ru(share_b * (1.0 + 0x1p-12));
+        coef_raw_t = __double2float_ru(share_t * (1.0 + 0x1p-12));
+        if (r.kth_b > 0.0f) floor_l = fmaxf(floor_l, __double2float_rd(share_b * (1.0 - 0x1p-12) * (double)r.kth_b));
+        if (r.kth_t > 0.0f) floor_l = fmaxf(floor_l, __double2float_rd(share_t * (1.0 - 0x1p-12) * (double)r.kth_t));
     }
+    const float coef_raw = fmaxf(coef_raw_b, coef_raw_t);
     const float coef_max = __uint_as_float(wave_max((coef_raw > 0.0f && coef_raw < INFINITY) ? __float_as_uint(coef_raw) : 0u));
     C.fx_scale = coef_max > 0.0f ? (float)FX_ONE / coef_max : 1.0f;
-    w.coef = coef_raw * C.fx_scale * (1.0f + 0x1p-20f);
+    w.coef_b = coef_raw_b * C.fx_scale * (1.0f + 0x1p-20f);
+    w.coef_t = coef_raw_t * C.fx_scale * (1.0f + 0x1p-20f);
     const float thr0_f = __uint_as_float(wave_max(__float_as_uint(floor_l)));
     const uint64_t thr0_key = thr0_f > 0.0f ? fkey((double)thr0_f) : 0ull;
     C.tk = TopK{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), thr0_key, thr0_f > 0.0f ? thr0_f : -INFINITY, (uint32_t)WCB};
     if (lane == 0 && thr0_f > 0.0f) { sc64[0] = thr0_key; *reinterpret_cast<float*>(&sc32[2]) = thr0_f; }
     const unsigned long long act_mask = __ballot(lane < L && w.active);
     lds_wait();
-    const uint64_t dummy = (uint64_t)p.q_off;          // 8 readable bytes for block slots without a block
 
     DIAG_NOW(t_w1);
     WDIAG_ADD(0, 1);
     WDIAG_ADD(10, t_w1 - t_w0);
+    const RareArgs ra{p.t_mag, p.b_mag, p.prior, p.c_org, p.k_topics, p.k};
     uint32_t F = sd.dlo;                               // frontier: docs below it are done
     uint32_t pend_n = 0;                               // pending survivors (wave-uniform)
     uint32_t thr_fx = wave_thr_fx(C);
@@ -689,8 +741,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
 #endif
     while (act_mask && F < sd.dhi) {
         DIAG_NOW(t_p0);
-        const RoundPlan rp = plan_round(w, p, se, ghdr, gdesc, l_adv, L, act_mask, F, sd.dhi, lane);
-        set_round_base(w, p0_lo);
+        const RoundPlan rp = plan_round(w, p.c_skip, se, ghdr, gdesc, l_adv, L, act_mask, F, sd.dhi, lane);
         const uint32_t n_rows = rp.n_rows;
         DIAG_NOW(t_p1);
         WDIAG_ADD(1, 1);
@@ -705,10 +756,10 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
 #ifdef SSW_ASM_RING
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring counts from zero
 #endif
-            group_issue<0>(C, w, r0, lane, dummy, rec, dvr);
-            group_issue<1>(C, w, r0 + 1, lane, dummy, rec, dvr);
+            group_issue<0>(p, gdesc, r0, lane, rec, dvr);
+            group_issue<1>(p, gdesc, r0 + 1, lane, rec, dvr);
 #if SSW_DEPTH == 3
-            group_issue<2>(C, w, r0 + 2, lane, dummy, rec, dvr);
+            group_issue<2>(p, gdesc, r0 + 2, lane, rec, dvr);
 #endif
 #ifdef SS_DIAG
 #define WSTAMP(var) DIAG_NOW(var)
@@ -730,7 +781,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                     SSW_ADD(S_, 0) SSW_ADD(S_, 1) SSW_ADD(S_, 2) SSW_ADD(S_, 3) SSW_ADD(S_, 4) SSW_ADD(S_, 5) SSW_ADD(S_, 6) SSW_ADD(S_, 7) \
                     SSW_ADD(S_, 8) SSW_ADD(S_, 9) SSW_ADD(S_, 10) SSW_ADD(S_, 11) SSW_ADD(S_, 12) SSW_ADD(S_, 13) SSW_ADD(S_, 14) SSW_ADD(S_, 15) \
                     WSTAMP(ts1);                                                                                           \
-                    _Pragma("unroll") for (int c = 0; c < WCW; c++) u[c] = sk[h[c]];                                       \
+                    _Pragma("unroll") for (int c = 0; c < WCW; c++) u[c] = *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sk) + h[c]); \
                     uint32_t tot = 0;                                                                                      \
                     _Pragma("unroll") for (int c = 0; c < WCW; c++) tot += (uint32_t)__popcll(__ballot(u[c] >= thr_fx));   \
                     WSTAMP(ts2);                                                                                           \
@@ -743,23 +794,21 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                             if (m) {                                                                                       \
                                 const uint32_t d = rl(dvr[S_], c);                                                         \
                                 const int l = (int)(d & 15u);                                                              \
-                                const uint32_t idx0 = rl(w.pos0, l) + (d >> 6) * 64u;                                      \
-                                const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));                \
-                                if (surv) C.S.pend[pend_n + (uint32_t)__popcll(m & below)] = make_uint4(rec[S_][c].x, idx0 + (uint32_t)lane, (uint32_t)l, 0u); \
+                                if (surv) C.S.pend[pend_n + bits_below(m)] = make_uint4(rec[S_][c].x & 0x7FFFFFFFu, (d >> 6) * 64u + (uint32_t)lane, (uint32_t)l, rec[S_][c].x >> 31); \
                                 pend_n += (uint32_t)__popcll(m);                                                           \
                             }                                                                                              \
                         }                                                                                                  \
                     }                                                                                                      \
-                    _Pragma("unroll") for (int c = 0; c < WCW; c++) if (h[c] != (uint32_t)WSK) sk[h[c]] = 0u;              \
+                    _Pragma("unroll") for (int c = 0; c < WCW; c++) if (h[c] != 4u * (uint32_t)WSK) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sk) + h[c]) = 0u; \
                     WSTAMP(ts3);                                                                                           \
                     WACC(2, ts2, ts3);                                                                                     \
                 } else {                                                                                                   \
                     if (mode == M_SLOW) { ev = EV_SLOW; ev_row = r_; goto ssw_event; }                                     \
                     /* a row without work (pad row, tail of an oversize window): its dummy loads still count */           \
-                    ring_wait<(WDEPTH - 1) * WCW>(rec[S_][WCW - 1]);                                                       \
+                    ring_drain_slot<(WDEPTH - 1) * WCW>();                                                                 \
                 }                                                                                                          \
                 WSTAMP(ts4);                                                                                               \
-                group_issue<S_>(C, w, r_ + WDEPTH, lane, dummy, rec, dvr);                                                 \
+                group_issue<S_>(p, gdesc, r_ + WDEPTH, lane, rec, dvr);                                                 \
                 WSTAMP(ts5);                                                                                               \
                 WACC(3, ts4, ts5);                                                                                         \
             }
@@ -791,11 +840,11 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                 DIAG_NOW(t_e0);
                 const uint4 hv = *reinterpret_cast<const uint4*>(ghdr[ev_row]);
                 const uint32_t b_lo = rfl(hv.x), span = rfl(hv.y), n_blk = rfl(hv.w);
-                if (pend_n) wave_flush(C.S, C.tk, C.Q, p, lane, pend_n);
+                if (pend_n) wave_flush(C.S, C.tk, C.Q, ra, lane, pend_n);
                 pend_n = 0;
                 r0 = ev_row;                            // EV_FLUSH: the row has not been touched: it runs again
-                if (ev == EV_OVERFLOW) { slow_window(C, p, w, lane, ev_row, n_blk, b_lo, span, false); r0 = ev_row + 1; }
-                if (ev == EV_SLOW) { slow_window(C, p, w, lane, ev_row, n_blk, b_lo, span, true); r0 = ev_row + 1; }
+                if (ev == EV_OVERFLOW) { slow_window(C, ra, w, lane, ev_row, n_blk, b_lo, span, false); r0 = ev_row + 1; }
+                if (ev == EV_SLOW) { slow_window(C, ra, w, lane, ev_row, n_blk, b_lo, span, true); r0 = ev_row + 1; }
                 thr_fx = wave_thr_fx(C);
                 DIAG_NOW(t_e1);
                 WDIAG_ADD(12, t_e1 - t_e0);
@@ -809,7 +858,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
         lds_wait();
     }
     WDIAG_ADD(7, pend_n);
-    if (pend_n) wave_flush(C.S, C.tk, C.Q, p, lane, pend_n);
+    if (pend_n) wave_flush(C.S, C.tk, C.Q, ra, lane, pend_n);
     DIAG_NOW(t_w2);
 
     // hand the candidates in: appended to the query's list (k_merge_flat sorts; a slice sorts only if it holds more than k)
@@ -846,6 +895,13 @@ void launch_score_wave(const void* params, unsigned n_slices, void* prep, hipStr
 int score_wave_max_lists() { return WL; }
 int score_wave_max_k() { return WCB / 2; }
 void score_wave_diag_dump() {
+#ifdef SSW_CHECK
+    {
+        uint32_t c[8];
+        if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_wcheck), sizeof(c)) == hipSuccess)
+            fprintf(stderr, "[ss check] k_score_wave: bad block indices=%u (last desc 0x%x limit %u slice %u)\n", c[0], c[1], c[2], c[3]);
+    }
+#endif
 #ifdef SS_DIAG
     unsigned long long h[32];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wdiag), sizeof(h)) == hipSuccess) {
