@@ -73,6 +73,15 @@ struct ss_ctx {
 
 namespace ss {
 
+// Device memory pool (ctx.hip): freed blocks are kept and handed out again, by size class.  One call of the offline entry
+// points allocates and frees some thirty temporaries; hipMalloc + hipFree cost ~0.1 ms a pair and hipFree waits for the
+// device, which is most of what a caller of ss_graph_create + ss_pagerank_run waited for on a small graph.  The pool holds at
+// most 8 GiB (of 288; option "mem.pool_mb" on any context changes it for the process, 0 switches it off).
+hipError_t pool_alloc(void** p, size_t bytes);
+void pool_free(void* p);
+void pool_set_limit(size_t bytes);
+void pool_trim();      // really free everything the pool holds
+
 // Device allocation that frees itself; raw pointers are handed to kernels.
 template <typename T>
 struct DevBuf {
@@ -88,7 +97,7 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p);
         p = nullptr;
         n = 0;
     }
@@ -96,7 +105,7 @@ struct DevBuf {
         release();
         n = count;
         if (count == 0) count = 1;
-        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        return pool_alloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     }
     // streamed-once data: uncached memory type, so it does not occupy L2 lines
     hipError_t alloc_streaming(size_t count) {

@@ -1,7 +1,107 @@
 // ctx.hip — context, stream and error plumbing of the C ABI (include/spaghetti_rank.h).
 #include "common.hpp"
 
+#include <unordered_map>
+
 namespace ss {
+
+// ---- device memory pool ------------------------------------------------------------------------------------------
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void*> free_blocks;        // (device, size class) -> block
+    std::unordered_map<void*, std::pair<int, size_t>> live;           // block -> (device, size class) of the blocks handed out
+    size_t held = 0, limit = (size_t)8 << 30;
+};
+Pool& pool() { static Pool* p = new Pool(); return *p; }   // never destroyed: DevBufs of static objects may outlive main
+// size classes: powers of two below 1 MiB, then eighths of the power of two (at most 12.5 % over)
+size_t size_class(size_t b) {
+    if (b <= 4096) return 4096;
+    size_t p2 = 4096;
+    while (p2 < b) p2 <<= 1;
+    if (p2 <= ((size_t)1 << 20)) return p2;
+    const size_t step = p2 >> 4;                         // p2/2 < b <= p2
+    return (b + step - 1) / step * step;
+}
+}  // namespace
+
+hipError_t pool_alloc(void** out, size_t bytes) {
+    Pool& P = pool();
+    const size_t cls = size_class(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free_blocks.find({dev, cls});
+        if (it != P.free_blocks.end()) {
+            *out = it->second;
+            P.free_blocks.erase(it);
+            P.held -= cls;
+            P.live[*out] = {dev, cls};
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, cls);
+    if (e != hipSuccess) {                               // give the pool's memory back and try once more
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(out, cls);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.live[*out] = {dev, cls};
+    }
+    return e;
+}
+
+void pool_free(void* p) {
+    if (!p) return;
+    Pool& P = pool();
+    size_t cls = 0;
+    int dev = 0;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.live.find(p);
+        if (it != P.live.end()) { dev = it->second.first; cls = it->second.second; P.live.erase(it); }
+        // a block larger than half the limit is not worth holding
+    }
+    // hipFree waits for the device before the memory goes; the pool keeps that guarantee (work of ANY stream that still uses
+    // the block is over before somebody else can get it) and saves the unmap / map that follows.
+    if (cls && cls <= P.limit / 2) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        if (cur != dev) (void)hipSetDevice(cur);
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.held + cls <= P.limit) {
+            P.free_blocks.emplace(std::make_pair(dev, cls), p);
+            P.held += cls;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void pool_trim() {
+    Pool& P = pool();
+    std::multimap<std::pair<int, size_t>, void*> take;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        take.swap(P.free_blocks);
+        P.held = 0;
+    }
+    for (auto& kv : take) (void)hipFree(kv.second);
+}
+
+void pool_set_limit(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(pool().mu);
+        pool().limit = bytes;
+    }
+    pool_trim();
+}
+
 static std::mutex g_err_mu;
 static std::string g_err;
 void set_global_error(const std::string& msg) {
@@ -97,6 +197,8 @@ static const char* const k_option_names[] = {
     "pr.force_narrow",      // 1: K <= 2 always runs the block-item kernel k_pr_step (tests reach it on small graphs)
     "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
+    "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 8192, 0 = off)
+    "pr.trace",             // 1: ss_graph_create / ss_pr_create print their phase times to stderr
     "pr.probe_hot",         // ss_pr_probe policies 3/4: rows below this index use the default cache policy
     "pr.topic_blocks",      // ss_pagerank_run_sharded: split K into this many topic blocks whose exchanges overlap the next block's sweep
     "tfidf.blocks",         // workgroups of the bucketed magnitude pass (default 1024)
@@ -116,6 +218,7 @@ int32_t ss_set_option(ss_ctx* ctx, const char* name, int64_t value) {
         if (std::strcmp(n, name) == 0) {
             if (value == SS_OPTION_DEFAULT) ctx->options.erase(name);
             else ctx->options[name] = value;
+            if (std::strcmp(name, "mem.pool_mb") == 0) ss::pool_set_limit(value == SS_OPTION_DEFAULT ? (size_t)8 << 30 : (size_t)std::max<int64_t>(0, value) << 20);
             return SS_OK;
         }
     return ctx->fail(SS_ERR_INVALID, "ss_set_option: unknown option '%s'", name);

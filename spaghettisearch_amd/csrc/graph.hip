@@ -6,14 +6,16 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
 
 namespace {
 
 constexpr int TPB = 256;
 
-// out-degree per node, count of non-dangling nodes
-__global__ void k_outdeg(const uint64_t* __restrict__ out_ptr, uint64_t n, uint32_t* __restrict__ outdeg,
-                         unsigned long long* __restrict__ n_nd, uint32_t* __restrict__ err) {
+// out-degree per node, count of non-dangling nodes (one atomic per block: one per wave on a single word took 1.9 ms at 10M nodes)
+__global__ __launch_bounds__(TPB) void k_outdeg(const uint64_t* __restrict__ out_ptr, uint64_t n, uint32_t* __restrict__ outdeg,
+                                                unsigned long long* __restrict__ n_nd, uint32_t* __restrict__ err) {
+    __shared__ unsigned s_cnt[TPB / 64];
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned nd = 0;
     if (v < n) {
@@ -22,8 +24,14 @@ __global__ void k_outdeg(const uint64_t* __restrict__ out_ptr, uint64_t n, uint3
         outdeg[v] = (uint32_t)(b - a);
         nd = b > a;
     }
-    unsigned long long m = __ballot(nd);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_nd, (unsigned long long)__popcll(m));
+    const unsigned long long m = __ballot(nd);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned c = 0;
+        for (int w = 0; w < TPB / 64; w++) c += s_cnt[w];
+        if (c) atomicAdd(n_nd, (unsigned long long)c);
+    }
 }
 
 // in-degree histogram + range check of out_dst
@@ -38,23 +46,25 @@ __global__ void k_indeg(const uint32_t* __restrict__ out_dst, uint64_t e, uint64
     }
 }
 
-// sort key per node: class (dangling last), in-degree descending, original id ascending
+// sort key per node: class (dangling last), in-degree descending; the sort is stable and the values start as the ids in
+// ascending order, so equal keys keep ascending original id
 __global__ void k_row_keys(const uint32_t* __restrict__ outdeg, const uint32_t* __restrict__ indeg, uint64_t n,
-                           uint64_t* __restrict__ keys) {
+                           uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    uint64_t cls = outdeg[v] == 0 ? 1ull : 0ull;
-    keys[v] = (cls << 63) | ((uint64_t)(0x7FFFFFFFu - min(indeg[v], 0x7FFFFFFFu)) << 32) | v;
+    const uint32_t cls = outdeg[v] == 0 ? 1u : 0u;
+    keys[v] = (cls << 31) | (0x7FFFFFFFu - min(indeg[v], 0x7FFFFFFFu));
+    ids[v] = (uint32_t)v;
 }
 
 // sorted position -> internal id (round-robin deal over ranks inside each class)
-__global__ void k_assign_ids(const uint64_t* __restrict__ sorted_keys, uint64_t n, uint64_t n_nd, uint32_t world,
+__global__ void k_assign_ids(const uint32_t* __restrict__ sorted_ids, uint64_t n, uint64_t n_nd, uint32_t world,
                              uint32_t sl_nd, uint32_t sl_d, const uint32_t* __restrict__ indeg,
                              uint32_t* __restrict__ new_id, uint32_t* __restrict__ old_id,
                              uint32_t* __restrict__ indeg_int) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t v = (uint32_t)(sorted_keys[i] & 0xFFFFFFFFull);
+    const uint32_t v = sorted_ids[i];
     uint64_t id;
     if (i < n_nd) {
         uint64_t g = i % world, pos = i / world;
@@ -69,20 +79,38 @@ __global__ void k_assign_ids(const uint64_t* __restrict__ sorted_keys, uint64_t 
     indeg_int[id] = indeg[v];
 }
 
-// one thread per edge: find its source row (upper_bound on out_ptr), emit (dst_int<<32 | src_int)
-__global__ void k_edge_keys(const uint64_t* __restrict__ out_ptr, const uint32_t* __restrict__ out_dst,
-                            uint64_t n, uint64_t e, const uint32_t* __restrict__ new_id,
-                            uint64_t* __restrict__ keys) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < e; i += stride) {
-        // largest p with out_ptr[p] <= i
-        uint64_t lo = 0, hi = n;  // invariant: out_ptr[lo] <= i < out_ptr[hi]
+// Edge i of the out-edge CSR -> (key = internal id of its child, value = internal id of its parent).  A block takes EK_CHUNK
+// consecutive edges, finds the rows they span with two binary searches, and every edge finds its row inside that short range.
+constexpr int EK_PT = 8, EK_CHUNK = TPB * EK_PT;
+__global__ __launch_bounds__(TPB) void k_edge_keys(const uint64_t* __restrict__ out_ptr, const uint32_t* __restrict__ out_dst,
+                                                   uint64_t n, uint64_t e, const uint32_t* __restrict__ new_id,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    __shared__ uint64_t s_r[2];
+    const uint64_t base = (uint64_t)blockIdx.x * EK_CHUNK;
+    if (base >= e) return;
+    const uint64_t last = min(base + EK_CHUNK, e) - 1;
+    if (threadIdx.x < 2) {
+        const uint64_t target = threadIdx.x == 0 ? base : last;      // largest p with out_ptr[p] <= target
+        uint64_t lo = 0, hi = n;
         while (hi - lo > 1) {
-            uint64_t mid = (lo + hi) >> 1;
+            const uint64_t mid = (lo + hi) >> 1;
+            if (out_ptr[mid] <= target) lo = mid; else hi = mid;
+        }
+        s_r[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const uint64_t r_lo = s_r[0], r_hi = s_r[1];
+#pragma unroll 4
+    for (int j = 0; j < EK_PT; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        if (i > last) break;
+        uint64_t lo = r_lo, hi = r_hi + 1;                            // out_ptr[lo] <= i < out_ptr[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
             if (out_ptr[mid] <= i) lo = mid; else hi = mid;
         }
-        keys[i] = ((uint64_t)new_id[out_dst[i]] << 32) | new_id[lo];
+        keys[i] = new_id[out_dst[i]];
+        vals[i] = new_id[lo];
     }
 }
 
@@ -105,14 +133,11 @@ __global__ void k_local_ptr(const uint64_t* __restrict__ in_ptr_int, uint32_t sl
     in_ptr_local[l] = (uint32_t)v;
 }
 
-__global__ void k_extract_src(const uint64_t* __restrict__ keys, uint64_t off_nd, uint64_t e_nd, uint64_t off_d,
+__global__ void k_extract_src(const uint32_t* __restrict__ srcs, uint64_t off_nd, uint64_t e_nd, uint64_t off_d,
                               uint64_t e_loc, uint32_t* __restrict__ in_src) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < e_loc; i += stride) {
-        uint64_t k = i < e_nd ? keys[off_nd + i] : keys[off_d + (i - e_nd)];
-        in_src[i] = (uint32_t)(k & 0xFFFFFFFFull);
-    }
+    for (; i < e_loc; i += stride) in_src[i] = i < e_nd ? srcs[off_nd + i] : srcs[off_d + (i - e_nd)];
 }
 
 // bit 31 of the last in-edge entry of every row marks the row end (pagerank.hip walks rows by it)
@@ -137,46 +162,66 @@ inline unsigned grid_for(uint64_t n, unsigned cap = 65535u * 16u) {
     return (unsigned)std::min<uint64_t>(b, cap);
 }
 
-int32_t sort_u64(ss_ctx* ctx, uint64_t* in, uint64_t* out, uint64_t n, unsigned end_bit) {
+// stable LSD radix sort of (key, value) pairs on the low `end_bit` bits of the key; enqueues only (tmp must outlive the sort)
+int32_t sort_pairs_u32(ss_ctx* ctx, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, uint64_t n, unsigned end_bit,
+                       ss::DevBuf<char>& tmp) {
     if (n == 0) return SS_OK;
     size_t tmp_bytes = 0;
-    SS_HIP(ctx, rocprim::radix_sort_keys(nullptr, tmp_bytes, in, out, (size_t)n, 0u, end_bit, ctx->stream));
-    ss::DevBuf<char> tmp;
+    SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, ctx->stream));
     SS_HIP(ctx, tmp.alloc(tmp_bytes));
-    SS_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tmp_bytes, in, out, (size_t)n, 0u, end_bit, ctx->stream));
-    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SS_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, ctx->stream));
     return SS_OK;
 }
+inline unsigned bits_for(uint64_t n) { unsigned b = 1; while (b < 32 && ((uint64_t)1 << b) < n) b++; return b; }
 
 int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_in) {
     ss_ctx* ctx = g->ctx;
     hipStream_t st = ctx->stream;
+    const bool trace = ctx->opt("pr.trace", 0) != 0;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto tg0 = t_now();
     const uint64_t n = g->n, e = g->e;
     const uint32_t W = (uint32_t)g->world;
 
-    ss::DevBuf<uint64_t> d_out_ptr;
-    ss::DevBuf<uint32_t> d_out_dst, d_outdeg, d_indeg;
+    // inputs already in device memory are used where they are (no 8N + 4E byte copy)
+    auto on_device = [](const void* p) {
+        hipPointerAttribute_t a{};
+        const bool d = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        return d;
+    };
+    ss::DevBuf<uint64_t> b_out_ptr;
+    ss::DevBuf<uint32_t> b_out_dst, d_outdeg, d_indeg;
     ss::DevBuf<unsigned long long> d_cnt;
     ss::DevBuf<uint32_t> d_err;
-    SS_HIP(ctx, d_out_ptr.alloc(n + 1));
-    SS_HIP(ctx, d_out_dst.alloc(e));
+    const uint64_t* d_out_ptr = out_ptr_in;
+    const uint32_t* d_out_dst = out_dst_in;
+    if (!on_device(out_ptr_in)) {
+        SS_HIP(ctx, b_out_ptr.alloc(n + 1));
+        SS_HIP(ctx, hipMemcpyAsync(b_out_ptr.p, out_ptr_in, (n + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
+        d_out_ptr = b_out_ptr.p;
+    }
+    if (e && !on_device(out_dst_in)) {
+        SS_HIP(ctx, b_out_dst.alloc(e));
+        SS_HIP(ctx, hipMemcpyAsync(b_out_dst.p, out_dst_in, e * sizeof(uint32_t), hipMemcpyDefault, st));
+        d_out_dst = b_out_dst.p;
+    }
     SS_HIP(ctx, d_outdeg.alloc(n));
     SS_HIP(ctx, d_indeg.alloc(n));
     SS_HIP(ctx, d_cnt.alloc(1));
     SS_HIP(ctx, d_err.alloc(1));
-    SS_HIP(ctx, hipMemcpyAsync(d_out_ptr.p, out_ptr_in, (n + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
-    if (e) SS_HIP(ctx, hipMemcpyAsync(d_out_dst.p, out_dst_in, e * sizeof(uint32_t), hipMemcpyDefault, st));
     SS_HIP(ctx, hipMemsetAsync(d_indeg.p, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), st));
     SS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned long long), st));
     SS_HIP(ctx, hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), st));
 
     // the first/last offsets must frame out_dst exactly
     uint64_t h_first = 0, h_last = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&h_first, d_out_ptr.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_last, d_out_ptr.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&h_first, d_out_ptr, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&h_last, d_out_ptr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 
-    if (n) hipLaunchKernelGGL(k_outdeg, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_out_ptr.p, n, d_outdeg.p, d_cnt.p, d_err.p);
-    if (e) hipLaunchKernelGGL(k_indeg, dim3(grid_for(e, 8192)), dim3(TPB), 0, st, d_out_dst.p, e, n, d_indeg.p, d_err.p);
+    if (n) hipLaunchKernelGGL(k_outdeg, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_out_ptr, n, d_outdeg.p, d_cnt.p, d_err.p);
+    if (e) hipLaunchKernelGGL(k_indeg, dim3(grid_for(e, 8192)), dim3(TPB), 0, st, d_out_dst, e, n, d_indeg.p, d_err.p);
     unsigned long long h_nd = 0;
     uint32_t h_err = 0;
     SS_HIP(ctx, hipMemcpyAsync(&h_nd, d_cnt.p, sizeof(h_nd), hipMemcpyDeviceToHost, st));
@@ -201,12 +246,18 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     g->cnt_nd = (uint32_t)((h_nd + W - 1 - g->rank) / W);
     g->cnt_d = (uint32_t)((n_d + W - 1 - g->rank) / W);
 
+    const auto tg1 = t_now();
     // ---- node order ---------------------------------------------------------
-    ss::DevBuf<uint64_t> keys_a, keys_b;
+    // The in-edge lists are sorted by destination only (stable: inside a row the parents keep the order of the input CSR, i.e.
+    // ascending original parent id): 32-bit keys over the bits the ids need instead of 64-bit (destination, source) keys.
+    ss::DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b;
+    ss::DevBuf<char> sort_tmp1, sort_tmp2;
     SS_HIP(ctx, keys_a.alloc(std::max<uint64_t>(n, e)));
     SS_HIP(ctx, keys_b.alloc(std::max<uint64_t>(n, e)));
-    if (n) hipLaunchKernelGGL(k_row_keys, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_outdeg.p, d_indeg.p, n, keys_a.p);
-    SS_TRY(sort_u64(ctx, keys_a.p, keys_b.p, n, 64));
+    SS_HIP(ctx, vals_a.alloc(std::max<uint64_t>(n, e)));
+    SS_HIP(ctx, vals_b.alloc(std::max<uint64_t>(n, e)));
+    if (n) hipLaunchKernelGGL(k_row_keys, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_outdeg.p, d_indeg.p, n, keys_a.p, vals_a.p);
+    SS_TRY(sort_pairs_u32(ctx, keys_a.p, keys_b.p, vals_a.p, vals_b.p, n, 32, sort_tmp1));
 
     ss::DevBuf<uint32_t> indeg_int;
     SS_HIP(ctx, g->new_id.alloc(n));
@@ -214,7 +265,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     SS_HIP(ctx, indeg_int.alloc(g->n_int + 1));
     hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(g->n_int + 1, 4096)), dim3(TPB), 0, st, g->old_id.p, g->n_int, 0xFFFFFFFFu);
     SS_HIP(ctx, hipMemsetAsync(indeg_int.p, 0, (g->n_int + 1) * sizeof(uint32_t), st));
-    if (n) hipLaunchKernelGGL(k_assign_ids, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, keys_b.p, n, (uint64_t)h_nd, W,
+    if (n) hipLaunchKernelGGL(k_assign_ids, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, (const uint32_t*)vals_b.p, n, (uint64_t)h_nd, W,
                               g->sl_nd, g->sl_d, d_indeg.p, g->new_id.p, g->old_id.p, indeg_int.p);
 
     // in_ptr over internal ids (exclusive scan of in-degrees, n_int+1 entries)
@@ -232,13 +283,16 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
         SS_HIP(ctx, hipStreamSynchronize(st));
     }
 
+    const auto tg2 = t_now();
     // ---- edges: (dst_int, src_int) sorted ------------------------------------
     if (e) {
-        hipLaunchKernelGGL(k_edge_keys, dim3(grid_for(e, 16384)), dim3(TPB), 0, st, d_out_ptr.p, d_out_dst.p, n, e,
-                           g->new_id.p, keys_a.p);
-        SS_TRY(sort_u64(ctx, keys_a.p, keys_b.p, e, 64));
+        hipLaunchKernelGGL(k_edge_keys, dim3(ss::div_up(e, EK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)d_out_ptr, (const uint32_t*)d_out_dst, n, e,
+                           (const uint32_t*)g->new_id.p, keys_a.p, vals_a.p);
+        SS_TRY(sort_pairs_u32(ctx, keys_a.p, keys_b.p, vals_a.p, vals_b.p, e, bits_for(g->n_int), sort_tmp2));
     }
 
+    if (trace) SS_HIP(ctx, hipStreamSynchronize(st));
+    const auto tg3 = t_now();
     // ---- this rank's rows -----------------------------------------------------
     const uint64_t id0_nd = (uint64_t)g->rank * g->sl_nd;
     const uint64_t id0_d = g->nd_int + (uint64_t)g->rank * g->sl_d;
@@ -260,7 +314,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     hipLaunchKernelGGL(k_local_ptr, dim3(ss::div_up((uint64_t)n_local + 1, TPB)), dim3(TPB), 0, st, in_ptr_int.p, g->sl_nd,
                        g->sl_d, id0_nd, id0_d, h_ptr[0], h_ptr[2], e_nd, g->in_ptr.p);
     if (g->e_local)
-        hipLaunchKernelGGL(k_extract_src, dim3(grid_for(g->e_local, 16384)), dim3(TPB), 0, st, keys_b.p, h_ptr[0], e_nd,
+        hipLaunchKernelGGL(k_extract_src, dim3(grid_for(g->e_local, 16384)), dim3(TPB), 0, st, (const uint32_t*)vals_b.p, h_ptr[0], e_nd,
                            h_ptr[2], g->e_local, g->in_src.p);
     if (g->e_local)
         hipLaunchKernelGGL(k_flag_row_ends, dim3(ss::div_up((uint64_t)n_local, TPB)), dim3(TPB), 0, st, (const uint32_t*)g->in_ptr.p,
@@ -279,6 +333,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     if (g->cnt_nd) g->max_indeg = std::max(g->max_indeg, g->h_indeg_nd[0]);
     if (g->cnt_d) g->max_indeg = std::max(g->max_indeg, g->h_indeg_d[0]);
     SS_HIP(ctx, hipGetLastError());
+    if (trace) fprintf(stderr, "[pr trace] ss_graph_create: upload + degrees %.2f ms, node order %.2f ms, edge sort %.2f ms, local rows %.2f ms\n", t_ms(tg0, tg1), t_ms(tg1, tg2), t_ms(tg2, tg3), t_ms(tg3, t_now()));
     return SS_OK;
 }
 

@@ -29,6 +29,7 @@
 #include "graph.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <memory>
 #include <queue>
@@ -778,6 +779,25 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     block_reduce_and_publish<GW>(p, c.dsum, c.csum, c.Tw, false);
 }
 
+// k_pr_sweep's items: their in-edge ranges from the device's in_ptr (the host deals the items by their turn counts, which it
+// knows from the sorted in-degrees; copying in_ptr itself to the host cost 14 of the 17 ms of ss_pr_create at 10M nodes)
+__global__ void k_pr_item_ranges(WorkItem* __restrict__ work, uint32_t n_items, const uint32_t* __restrict__ in_ptr) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    WorkItem w = work[i];
+    switch (w.kind) {
+        case V_ROWW: w.beg = in_ptr[w.row]; w.end = in_ptr[w.row + 1]; break;
+        case V_SEG:
+            w.beg = in_ptr[w.row] + w.count * SEGW;
+            w.end = min(in_ptr[w.row + 1], w.beg + SEGW);
+            break;
+        case V_QUAD:
+        case V_DEG: w.beg = in_ptr[w.row]; w.end = in_ptr[w.row + w.count]; break;
+        default: return;
+    }
+    work[i] = w;
+}
+
 // x0 = 1/n, first contributions and their sum (pagerank.go:103-106 + first :136-137)
 template <int GW>
 __global__ __launch_bounds__(TPB) void k_pr_begin(PrParams p) {
@@ -987,16 +1007,18 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
         while (r < cnt && deg[r] > T_DEG) {
             const uint32_t nch = (deg[r] + CH - 1) / CH;
             const uint32_t max_groups = std::min<uint32_t>((uint32_t)gw, std::max<uint32_t>(1u, 32u / nch));
-            uint32_t rows = 0;
-            while (r + rows < cnt && deg[r + rows] > T_DEG && rows < max_groups * NSLOT && (deg[r + rows] + CH - 1) / CH == nch) rows++;
+            // rows of the same turn count nch: in-degree > (nch - 1) * CH (and > T_DEG), found by bisection in the sorted degrees
+            const uint32_t lim = std::max<uint32_t>(T_DEG, (nch - 1) * CH);
+            const uint32_t same = (uint32_t)(std::upper_bound(deg.begin() + r, deg.end(), lim + 1, std::greater<uint32_t>()) - (deg.begin() + r));
+            const uint32_t rows = std::min<uint32_t>(same, max_groups * NSLOT);
             vquad.push_back({V_QUAD, row0 + r, rows, nch, 0, 0});
             r += rows;
         }
         // exact-degree runs
         while (r < cnt && deg[r] > 0) {
             const uint32_t D = deg[r];
-            uint32_t run = 0;
-            while (r + run < cnt && deg[r + run] == D) run++;
+            // deg is sorted descending: the run of rows with exactly D in-edges ends at the first smaller degree
+            const uint32_t run = (uint32_t)(std::upper_bound(deg.begin() + r, deg.end(), D, std::greater<uint32_t>()) - (deg.begin() + r));
             const uint32_t R = D <= 2 ? 8 : D <= 4 ? 4 : 2;
             const uint32_t per_item = NSLOT * R * 16;                 // 16 turns
             for (uint32_t o = 0; o < run; o += per_item) vdeg[R == 2 ? 0 : R == 4 ? 1 : 2].push_back({V_DEG, row0 + r + o, std::min(per_item, run - o), D, 0, 0});
@@ -1125,10 +1147,15 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     const int GW = pr->gw;
     const size_t n_local = g->n_local();
 
+    const bool trace = ctx->opt("pr.trace", 0) != 0;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto tc0 = t_now();
     std::vector<WorkItem> items;
     uint32_t nsegs = 0, nmulti = 0, seg_edges = 0, pos_nd = 0, pos_d = 0;
     uint32_t vbeg[7] = {0};
     build_work(g, GW, items, nsegs, nmulti, seg_edges, pos_nd, pos_d, vbeg);
+    const auto tc1 = t_now();
     if (items.empty()) items.push_back({W_ZERO, 0, 0, 0, 0, 0});
     // persistent grid, each block (gw < 8) or wave (gw >= 8) walks the work table round-robin: gw < 8: 8 blocks per CU at
     // most; gw >= 8: exactly the waves the chip holds at once
@@ -1140,27 +1167,22 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                           : (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
     std::vector<uint32_t> woff;
     if (GW >= 8) {
-        // k_pr_sweep: the items' edge ranges, then the items dealt to the grid's waves
-        std::vector<uint32_t> h_in_ptr(n_local + 1, 0);
-        if (n_local) {
-            SS_HIP(ctx, hipMemcpyAsync(h_in_ptr.data(), g->in_ptr.p, (n_local + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            SS_HIP(ctx, hipStreamSynchronize(st));
-        }
+        // k_pr_sweep: the items' turn counts (from the sorted in-degrees the graph keeps on the host), then the items dealt to the
+        // grid's waves; the edge ranges are filled in on the device (k_pr_item_ranges)
         const uint32_t NS = 64 / GW;
+        auto deg_of = [&](uint32_t lrow) -> uint32_t {
+            return lrow < g->sl_nd ? (lrow < g->h_indeg_nd.size() ? g->h_indeg_nd[lrow] : 0u)
+                                   : (lrow - g->sl_nd < g->h_indeg_d.size() ? g->h_indeg_d[lrow - g->sl_nd] : 0u);
+        };
         std::vector<double> cost(items.size());
         for (size_t i = 0; i < items.size(); i++) {
-            WorkItem& w = items[i];
+            const WorkItem& w = items[i];
             double turns = 1.0;
             switch (w.kind) {
-                case V_ROWW: w.beg = h_in_ptr[w.row]; w.end = h_in_ptr[w.row + 1]; turns = ss::div_up(w.end - w.beg, NS * CH); break;
-                case V_SEG:
-                    w.beg = h_in_ptr[w.row] + w.count * SEGW;
-                    w.end = std::min(h_in_ptr[w.row + 1], w.beg + SEGW);
-                    turns = ss::div_up(w.end - w.beg, NS * CH) + 2.0;
-                    break;
-                case V_QUAD: w.beg = h_in_ptr[w.row]; w.end = h_in_ptr[w.row + w.count]; turns = (double)ss::div_up(w.count, NS) * w.nseg; break;
+                case V_ROWW: turns = ss::div_up(deg_of(w.row), NS * CH); break;
+                case V_SEG: turns = ss::div_up(std::min<uint32_t>(SEGW, deg_of(w.row) - w.count * SEGW), NS * CH) + 2.0; break;
+                case V_QUAD: turns = (double)ss::div_up(w.count, NS) * w.nseg; break;
                 case V_DEG: {
-                    w.beg = h_in_ptr[w.row]; w.end = h_in_ptr[w.row + w.count];
                     const uint32_t R = w.nseg <= 2 ? 8 : w.nseg <= 4 ? 4 : 2;
                     turns = (double)ss::div_up(w.count, NS * R) * (R == 8 ? 2.5 : R == 4 ? 1.7 : 1.3);   // a turn finishes R rows per lane group
                     break;
@@ -1172,39 +1194,50 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         // Longest-processing-time deal: items in table order (classes by falling item length), each to the wave with the
         // least work so far — every wave ends up with the same number of turns (+- one item), whatever the degree mix.
         const uint32_t nw = pr->nblocks * WAVES;
-        std::vector<std::vector<uint32_t>> mine(nw);
+        // The items come in falling cost inside each class.  Deal them nw at a time: the waves ordered by their load so far, the
+        // chunk's items in table order (costliest first inside a class) to the least loaded waves first — the longest-processing-
+        // time rule applied per chunk, one sort of nw loads per chunk instead of a heap operation per item (3 ms -> 0.4 ms at
+        // 60k items / 3072 waves, same balance: every wave ends within one item of the mean).
+        std::vector<uint32_t> owner(items.size());
         {
-            using Load = std::pair<double, uint32_t>;
-            std::priority_queue<Load, std::vector<Load>, std::greater<Load>> pq;
-            for (uint32_t w = 0; w < nw; w++) pq.push({0.0, w});
-            for (size_t i = 0; i < items.size(); i++) {
-                Load l = pq.top();
-                pq.pop();
-                mine[l.second].push_back((uint32_t)i);
-                l.first += cost[i];
-                pq.push(l);
+            std::vector<double> load(nw, 0.0);
+            std::vector<uint32_t> by_load(nw);
+            for (uint32_t w = 0; w < nw; w++) by_load[w] = w;
+            for (size_t i0 = 0; i0 < items.size(); i0 += nw) {
+                const size_t n_chunk = std::min<size_t>(nw, items.size() - i0);
+                if (i0) std::stable_sort(by_load.begin(), by_load.end(), [&](uint32_t a, uint32_t b) { return load[a] < load[b]; });
+                // the chunk's costliest item to the least loaded wave: order the chunk by falling cost (it already is, except
+                // where it crosses a class boundary)
+                std::vector<uint32_t> idx(n_chunk);
+                for (size_t j = 0; j < n_chunk; j++) idx[j] = (uint32_t)(i0 + j);
+                std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+                for (size_t j = 0; j < n_chunk; j++) {
+                    owner[idx[j]] = by_load[j];
+                    load[by_load[j]] += cost[idx[j]];
+                }
             }
         }
+        // table order inside a wave's list = item order = class order: count per (wave, class), offsets, place
         auto cls = [&](size_t i) { int k = 0; while (k < 5 && i >= vbeg[k + 1]) k++; return k; };
-        std::vector<WorkItem> dealt;
-        dealt.reserve(items.size() + 2);
         woff.assign((size_t)nw * 8, 0);
+        std::vector<uint32_t> cnt((size_t)nw * 8, 0);
+        for (size_t i = 0; i < items.size(); i++) cnt[(size_t)owner[i] * 8 + cls(i)]++;
+        uint32_t run_off = 0;
         for (uint32_t w = 0; w < nw; w++) {
-            // table order inside a wave's list = class order
-            int k = 0;
-            woff[(size_t)w * 8] = (uint32_t)dealt.size();
-            for (uint32_t i : mine[w]) {
-                const int ki = cls(i);
-                while (k < ki) woff[(size_t)w * 8 + ++k] = (uint32_t)dealt.size();
-                dealt.push_back(items[i]);
+            for (int k = 0; k < 8; k++) {
+                woff[(size_t)w * 8 + k] = run_off;
+                run_off += cnt[(size_t)w * 8 + k];
+                cnt[(size_t)w * 8 + k] = woff[(size_t)w * 8 + k];       // becomes the write cursor of (wave, class)
             }
-            while (k < 7) woff[(size_t)w * 8 + ++k] = (uint32_t)dealt.size();
         }
+        std::vector<WorkItem> dealt(items.size());
+        for (size_t i = 0; i < items.size(); i++) dealt[cnt[(size_t)owner[i] * 8 + cls(i)]++] = items[i];
         dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});              // the pipelines read two items ahead
         dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});
         items.swap(dealt);
     }
 
+    const auto tc2 = t_now();
     if (((uint64_t)g->nd_int + 1) * GW * 8 >= (1ull << 32))
         return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_create: contribution table of %llu rows x %d topics exceeds 4 GiB (shard the graph over more ranks)",
                          (unsigned long long)g->nd_int, GW);
@@ -1228,6 +1261,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     if (!woff.empty()) SS_HIP(ctx, hipMemcpyAsync(pr->woff.p, woff.data(), woff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     SS_HIP(ctx, pr->work.alloc(items.size()));
     SS_HIP(ctx, hipMemcpyAsync(pr->work.p, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
+    if (GW >= 8)
+        hipLaunchKernelGGL(k_pr_item_ranges, dim3(ss::div_up(items.size(), TPB)), dim3(TPB), 0, st, pr->work.p, (uint32_t)items.size(), (const uint32_t*)g->in_ptr.p);
     SS_HIP(ctx, pr->ctl.alloc(1));
     SS_HIP(ctx, hipMemsetAsync(pr->ctl.p, 0, sizeof(PrCtl), st));
     double h_x0[MAXK];
@@ -1235,6 +1270,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     SS_HIP(ctx, pr->x0.alloc(MAXK));
     SS_HIP(ctx, hipMemcpyAsync(pr->x0.p, h_x0, sizeof(h_x0), hipMemcpyHostToDevice, st));
     SS_HIP(ctx, hipStreamSynchronize(st));   // items / h_x0 are stack/host temporaries
+    if (trace) fprintf(stderr, "[pr trace] ss_pr_create: build_work %.2f ms (%zu items), edge ranges + deal %.2f ms, alloc + upload %.2f ms\n", t_ms(tc0, tc1), items.size(), t_ms(tc1, tc2), t_ms(tc2, t_now()));
 
     PrParams& p = pr->prm;
     p.in_ptr = g->in_ptr.p;
@@ -1530,11 +1566,15 @@ int32_t ss_pr_read(ss_pr* pr, double* rank_out) {
     SS_HIP(ctx, hipSetDevice(ctx->device));
     const ss_graph* g = pr->g;
     if (g->world != 1) return ctx->fail(SS_ERR_STATE, "ss_pr_read: world>1, use ss_pr_read_local");
+    // ranks wanted in device memory: written there directly (no K*N*8-byte staging buffer and copy)
+    hipPointerAttribute_t pa{};
+    const bool dev_out = hipPointerGetAttributes(&pa, rank_out) == hipSuccess && pa.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
     ss::DevBuf<double> d_out;
-    SS_HIP(ctx, d_out.alloc((size_t)g->n * pr->k));
-    SS_GW_DISPATCH(pr->gw, launch_read, pr, ctx->stream, 1, (uint64_t)g->n, (uint32_t*)nullptr, d_out.p);
+    if (!dev_out) SS_HIP(ctx, d_out.alloc((size_t)g->n * pr->k));
+    SS_GW_DISPATCH(pr->gw, launch_read, pr, ctx->stream, 1, (uint64_t)g->n, (uint32_t*)nullptr, dev_out ? rank_out : d_out.p);
     SS_HIP(ctx, hipGetLastError());
-    SS_HIP(ctx, hipMemcpyAsync(rank_out, d_out.p, (size_t)g->n * pr->k * sizeof(double), hipMemcpyDefault, ctx->stream));
+    if (!dev_out) SS_HIP(ctx, hipMemcpyAsync(rank_out, d_out.p, (size_t)g->n * pr->k * sizeof(double), hipMemcpyDefault, ctx->stream));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SS_OK;
 }

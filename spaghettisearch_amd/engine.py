@@ -207,6 +207,18 @@ class Graph:
               self.ctx.h)
         return rank, iters
 
+    def pagerank_dev(self, damping: float, eps: float, n_topic: Sequence[int], rank_out, max_iter: int = 0):
+        """ss_pagerank_run with the ranks left in device memory (`rank_out`: torch float64 [K][N] on the GPU) -> iters [K]."""
+        n_topic = np.ascontiguousarray(np.atleast_1d(n_topic), dtype=np.int32)
+        K = len(n_topic)
+        rank_out = _as(rank_out, "float64")
+        if rank_out.numel() < K * self.n:
+            raise ValueError("rank_out too small")
+        iters = np.zeros(K, dtype=np.int32)
+        check(self.ctx.lib.ss_pagerank_run(self.h, damping, eps, max_iter, K, _ptr(n_topic), _ptr(rank_out), _ptr(iters)),
+              self.ctx.h)
+        return iters
+
     def close(self) -> None:
         if self.h:
             self.ctx.lib.ss_graph_destroy(self.h)
