@@ -179,10 +179,19 @@ int32_t ss_pr_exchange_buffers(ss_pr* pr, void** send_dev, uint64_t* send_bytes,
 int32_t ss_pr_exchange(ss_pr* pr, int32_t allreduce);
 /* The whole sharded power iteration of one rank: begin, {sweep, exchange, finalize} until the device-side stop rule
  * (pagerank.go:93) has fired for every topic on every rank (the ranks agree: they finalize the same gathered sums).
+ * The K topic vectors run as topic blocks (option "pr.topic_blocks", default 2 from 8 topics on) whose exchanges are
+ * enqueued on a second stream of the context: block b's collective overlaps block b+1's sweep.
+ * Topics are independent, so the results are those of running every block's topics on their own.
  * ids_out [n_rows_local] original node ids of this rank's rows, rank_out [k_topics][n_rows_local], iters_out [k_topics].
  * Every rank writes its own rows of forw[3]; no gather of the result is needed.  k_topics <= 16 per call. */
 int32_t ss_pagerank_run_sharded(ss_graph* g, double damping, double eps, int32_t max_iter, int32_t k_topics,
                                 const int32_t* n_topic, int32_t allreduce, uint32_t* ids_out, double* rank_out, int32_t* iters_out);
+/* The same pipeline for the shards of ONE process: shards[s] = shard s of `world` of the same graph, all on one context
+ * (one device); the all-gather is played by device-to-device copies on the context's second stream.  Tests run the
+ * topic-blocked, overlapped schedule through this on one GPU (RCCL refuses two ranks on one device), and a host that wants
+ * several shards on one device can use it as it is.  rank_out [k_topics][n_nodes] in original ids (host memory). */
+int32_t ss_pagerank_run_group(ss_graph* const* shards, int32_t world, double damping, double eps, int32_t max_iter, int32_t k_topics,
+                              const int32_t* n_topic, double* rank_out, int32_t* iters_out);
 /* Waits for the stream; iters_out[k_topics] = iterations executed per topic,
  * *n_active = topics still iterating, *sweeps = K-wide sweeps executed. */
 int32_t ss_pr_status(ss_pr* pr, int32_t* iters_out, int32_t* n_active, int32_t* sweeps,

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "ss_pr_exchange_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_vp), C.POINTER(_u64)]),
     "ss_pr_exchange": (_i32, [_vp, _i32]),
     "ss_pagerank_run_sharded": (_i32, [_vp, _f64, _f64, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "ss_pagerank_run_group": (_i32, [_vp, _i32, _f64, _f64, _i32, _i32, _vp, _vp, _vp]),
     "ss_pr_status": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]),
     "ss_pr_read_local": (_i32, [_vp, _vp, _vp]),
     "ss_pr_read": (_i32, [_vp, _vp]),

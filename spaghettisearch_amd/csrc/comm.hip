@@ -28,16 +28,18 @@ int32_t comm_fail(ss_ctx* ctx, const char* what, ncclResult_t r) {
     } while (0)
 
 // all-gather of `bytes` per rank, device buffers, on the context's stream (enqueue only)
-int32_t comm_allgather(ss_ctx* ctx, const void* send, void* recv, size_t bytes) {
+int32_t comm_allgather_on(ss_ctx* ctx, const void* send, void* recv, size_t bytes, hipStream_t st) {
     if (!ctx->comm) return ctx->fail(SS_ERR_STATE, "no communicator: call ss_comm_init first");
-    SS_NCCL(ctx, ncclAllGather(send, recv, bytes, ncclChar, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    SS_NCCL(ctx, ncclAllGather(send, recv, bytes, ncclChar, static_cast<ncclComm_t>(ctx->comm), st));
     return SS_OK;
 }
-int32_t comm_allreduce_f64(ss_ctx* ctx, const double* send, double* recv, size_t count) {
+int32_t comm_allreduce_f64_on(ss_ctx* ctx, const double* send, double* recv, size_t count, hipStream_t st) {
     if (!ctx->comm) return ctx->fail(SS_ERR_STATE, "no communicator: call ss_comm_init first");
-    SS_NCCL(ctx, ncclAllReduce(send, recv, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    SS_NCCL(ctx, ncclAllReduce(send, recv, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(ctx->comm), st));
     return SS_OK;
 }
+int32_t comm_allgather(ss_ctx* ctx, const void* send, void* recv, size_t bytes) { return comm_allgather_on(ctx, send, recv, bytes, ctx->stream); }
+int32_t comm_allreduce_f64(ss_ctx* ctx, const double* send, double* recv, size_t count) { return comm_allreduce_f64_on(ctx, send, recv, count, ctx->stream); }
 
 }  // namespace ss
 

@@ -25,6 +25,7 @@ struct ss_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // stream all work is enqueued on
     hipStream_t own_stream = nullptr;  // created by ss_init
+    hipStream_t comm_stream = nullptr; // the exchange steps of the sharded sweep run here, beside the sweeps on `stream`
     std::recursive_mutex mu;           // serialises calls on this ctx
     std::string last_error;
     // timing hook (ss_last_kernel_ms): [kind][0]=start, [1]=stop
@@ -126,5 +127,8 @@ inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) /
 // comm.hip: collectives on the context's stream (enqueue only); SS_ERR_STATE without a communicator
 int32_t comm_allgather(ss_ctx* ctx, const void* send, void* recv, size_t bytes);
 int32_t comm_allreduce_f64(ss_ctx* ctx, const double* send, double* recv, size_t count);
+// the same on a given stream (the pipelined sharded sweep puts its exchanges on ctx->comm_stream)
+int32_t comm_allgather_on(ss_ctx* ctx, const void* send, void* recv, size_t bytes, hipStream_t st);
+int32_t comm_allreduce_f64_on(ss_ctx* ctx, const double* send, double* recv, size_t count, hipStream_t st);
 
 }  // namespace ss

@@ -160,6 +160,12 @@ int32_t ss_init(int32_t device_id, ss_ctx** out) {
         return SS_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if ((e = hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking)) != hipSuccess) {
+        ss::set_global_error(std::string("ss_init: hipStreamCreate (comm): ") + hipGetErrorString(e));
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return SS_ERR_HIP;
+    }
     for (int k = 0; k < 3; k++)
         for (int j = 0; j < 2; j++)
             if ((e = hipEventCreate(&ctx->ev[k][j])) != hipSuccess) {
@@ -179,6 +185,7 @@ int32_t ss_shutdown(ss_ctx* ctx) {
     for (int k = 0; k < 3; k++)
         for (int j = 0; j < 2; j++)
             if (ctx->ev[k][j]) (void)hipEventDestroy(ctx->ev[k][j]);
+    if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SS_OK;

@@ -1487,6 +1487,117 @@ int32_t ss_pr_exchange(ss_pr* pr, int32_t allreduce) {
     return ss::comm_allreduce_f64(ctx, pr->tab0.p, pr->tab0.p, slice * (size_t)g->world);
 }
 
+}  // extern "C"
+
+namespace {
+
+// ---- the sharded power iteration as ONE pipeline inside the library ---------------------------------
+// The K topic vectors are split into B topic blocks (separate states over the same shard); block b's exchange runs on the
+// context's second stream while block b+1 is finalised and swept on the first:
+//     compute:  [fin 0][sweep 0]      [fin 1][sweep 1]      [fin 0][sweep 0] ...
+//     comm:                 [exchange 0 ..........][exchange 1 ..........]
+// HIP events order the two streams; the host enqueues and looks at the device-side stop rule every BATCH sweeps.  Topics are
+// independent power iterations (pagerank.go:54-63), so a block's results are bit for bit those of running its topics alone.
+// The exchange is a functor: RCCL for one shard per process (ss_pagerank_run_sharded), device-to-device copies for the
+// shards of a single-process group (ss_pagerank_run_group: tests, and one process driving several shards on one device).
+struct ShardBlocks { std::vector<ss_pr*> blk; };
+
+template <typename Exchange>
+int32_t run_pipelined(ss_ctx* ctx, std::vector<ShardBlocks>& sh, int32_t max_iter, Exchange&& exchange, int32_t* iters_out,
+                      const std::vector<int>& blk_k0) {
+    const int B = (int)sh[0].blk.size(), S = (int)sh.size();
+    hipStream_t cs = ctx->stream, xs = ctx->comm_stream;
+    std::vector<hipEvent_t> ev_step(B), ev_xchg(B);
+    for (int b = 0; b < B; b++) {
+        SS_HIP(ctx, hipEventCreateWithFlags(&ev_step[b], hipEventDisableTiming));
+        SS_HIP(ctx, hipEventCreateWithFlags(&ev_xchg[b], hipEventDisableTiming));
+    }
+    auto cleanup = [&] {
+        (void)hipStreamSynchronize(xs);
+        (void)hipStreamSynchronize(cs);
+        for (int b = 0; b < B; b++) { (void)hipEventDestroy(ev_step[b]); (void)hipEventDestroy(ev_xchg[b]); }
+    };
+    int32_t rc = SS_OK;
+    auto start_exchange = [&](int b) -> int32_t {
+        SS_HIP(ctx, hipEventRecord(ev_step[b], cs));
+        SS_HIP(ctx, hipStreamWaitEvent(xs, ev_step[b], 0));
+        SS_TRY(exchange(b, xs));
+        SS_HIP(ctx, hipEventRecord(ev_xchg[b], xs));
+        return SS_OK;
+    };
+    // prime: every block begun, its first exchange in flight
+    for (int b = 0; b < B && rc == SS_OK; b++) {
+        for (int s = 0; s < S; s++) {
+            ss_pr* pr = sh[s].blk[b];
+            const size_t n_el = (size_t)pr->g->n_local() * pr->gw;
+            const unsigned nb = std::max(1u, std::min(2048u, ss::div_up(n_el, TPB)));
+            SS_HIP(ctx, hipMemsetAsync(&pr->ctl.p->ticket, 0, sizeof(uint32_t), cs));
+            SS_GW_DISPATCH(pr->gw, launch_begin, pr, cs, nb);
+            pr->begun = true;
+        }
+        rc = start_exchange(b);
+    }
+    bool first = true;
+    const int BATCH = 8;
+    int32_t sweeps_done = 0;
+    for (;;) {
+        if (rc != SS_OK) break;
+        int todo = BATCH;
+        if (max_iter > 0) todo = std::min(BATCH, std::max(1, max_iter - sweeps_done));
+        for (int i = 0; i < todo && rc == SS_OK; i++) {
+            for (int b = 0; b < B && rc == SS_OK; b++) {
+                if (hipStreamWaitEvent(cs, ev_xchg[b], 0) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "hipStreamWaitEvent"); break; }
+                for (int s = 0; s < S; s++) SS_GW_DISPATCH(sh[s].blk[b]->gw, launch_finalize, sh[s].blk[b], cs, first ? 1 : 0);
+                for (int s = 0; s < S; s++) SS_GW_DISPATCH(sh[s].blk[b]->gw, launch_step, sh[s].blk[b], cs);
+                rc = start_exchange(b);
+            }
+            first = false;
+            sweeps_done++;
+        }
+        if (rc != SS_OK) break;
+        if (hipGetLastError() != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: launch failed"); break; }
+        // the stop rule lives on the device and is evaluated identically on every rank (same gathered sums, same order);
+        // what the host reads lags the in-flight sweep by one, and launches after convergence are no-ops on all ranks alike
+        int32_t n_active = 0;
+        for (int b = 0; b < B && rc == SS_OK; b++) {
+            PrCtl h;
+            if (hipMemcpyAsync(&h, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+                hipStreamSynchronize(cs) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: status read failed"); break; }
+            n_active += h.n_active;
+        }
+        if (n_active == 0) break;
+    }
+    // drain: apply the exchanges still in flight (no-ops after convergence)
+    for (int b = 0; b < B && rc == SS_OK; b++) {
+        if (hipStreamWaitEvent(cs, ev_xchg[b], 0) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "hipStreamWaitEvent"); break; }
+        for (int s = 0; s < S; s++) {
+            SS_GW_DISPATCH(sh[s].blk[b]->gw, launch_finalize, sh[s].blk[b], cs, first ? 1 : 0);
+            sh[s].blk[b]->need_finalize = false;
+        }
+    }
+    if (rc == SS_OK && iters_out) {
+        for (int b = 0; b < B && rc == SS_OK; b++) {
+            PrCtl h;
+            if (hipMemcpyAsync(&h, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+                hipStreamSynchronize(cs) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: status read failed"); break; }
+            for (int k = 0; k < sh[0].blk[b]->k; k++) iters_out[blk_k0[b] + k] = h.iters[k];
+        }
+    }
+    cleanup();
+    return rc;
+}
+
+// topic blocks of a K-topic run: option "pr.topic_blocks" (default 2 from 8 topics on: one block's exchange then hides behind
+// the other block's sweep), never more blocks than topics
+int topic_blocks_for(ss_ctx* ctx, int k_topics) {
+    int B = (int)ctx->opt("pr.topic_blocks", k_topics >= 8 ? 2 : 1);
+    return std::max(1, std::min(B, k_topics));
+}
+
+}  // namespace
+
+extern "C" {
+
 int32_t ss_pagerank_run_sharded(ss_graph* g, double damping, double eps, int32_t max_iter, int32_t k_topics,
                                 const int32_t* n_topic, int32_t allreduce, uint32_t* ids_out, double* rank_out, int32_t* iters_out) {
     if (!g) return SS_ERR_INVALID;
@@ -1497,27 +1608,94 @@ int32_t ss_pagerank_run_sharded(ss_graph* g, double damping, double eps, int32_t
         return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_sharded: k_topics must be 1..%d, n_topic/rank_out not NULL", MAXK);
     if (!(eps >= 0.0) && max_iter <= 0 && !(eps != eps))
         return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_sharded: eps < 0 (never converges) needs max_iter > 0");
-    ss_pr* pr = nullptr;
-    SS_TRY(ss_pr_create(g, damping, eps, max_iter, k_topics, n_topic, &pr));
-    int32_t rc = ss_pr_begin(pr);
-    if (rc == SS_OK) rc = ss_pr_exchange(pr, allreduce);
-    if (rc == SS_OK) rc = ss_pr_finalize(pr);
-    int32_t n_active = k_topics, sweeps = 0;
-    // the stop rule lives on the device and is evaluated identically on every rank (same gathered sums, same order):
-    // the host looks every BATCH sweeps, launches after convergence are no-ops on all ranks alike
-    const int BATCH = 8;
-    while (rc == SS_OK && n_active > 0) {
-        int todo = BATCH;
-        if (max_iter > 0) todo = std::min(BATCH, std::max(1, max_iter - sweeps));
-        for (int i = 0; i < todo && rc == SS_OK; i++) {
-            rc = ss_pr_step(pr, 1);
-            if (rc == SS_OK) rc = ss_pr_exchange(pr, allreduce);
-            if (rc == SS_OK) rc = ss_pr_finalize(pr);
-        }
-        if (rc == SS_OK) rc = ss_pr_status(pr, iters_out, &n_active, &sweeps, nullptr, nullptr);
+    if (!ctx->comm || ctx->comm_world != g->world || ctx->comm_rank != g->rank)
+        return ctx->fail(SS_ERR_STATE, "ss_pagerank_run_sharded: the context's communicator (rank %d of %d) does not match the graph's shard (rank %d of %d)",
+                         ctx->comm ? ctx->comm_rank : -1, ctx->comm ? ctx->comm_world : 0, g->rank, g->world);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    const int B = topic_blocks_for(ctx, k_topics);
+    std::vector<ShardBlocks> sh(1);
+    std::vector<int> k0(B + 1);
+    for (int b = 0; b <= B; b++) k0[b] = (int)((int64_t)k_topics * b / B);
+    int32_t rc = SS_OK;
+    for (int b = 0; b < B && rc == SS_OK; b++) {
+        ss_pr* pr = nullptr;
+        rc = ss_pr_create(g, damping, eps, max_iter, k0[b + 1] - k0[b], n_topic + k0[b], &pr);
+        if (rc == SS_OK) sh[0].blk.push_back(pr);
     }
-    if (rc == SS_OK) rc = ss_pr_read_local(pr, ids_out, rank_out);
-    ss_pr_destroy(pr);
+    if (rc == SS_OK) {
+        auto exchange = [&](int b, hipStream_t xs) -> int32_t {
+            ss_pr* pr = sh[0].blk[b];
+            const size_t slice = (size_t)g->sl_nd * pr->gw;            // doubles per rank
+            if (!allreduce) return ss::comm_allgather_on(ctx, pr->send.p, pr->tab0.p, slice * sizeof(double), xs);
+            // north-star form: own slice inside a zeroed full-size table, tables summed
+            SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, pr->tab0.bytes(), xs));
+            SS_HIP(ctx, hipMemcpyAsync(pr->tab0.p + (size_t)g->rank * slice, pr->send.p, slice * sizeof(double), hipMemcpyDeviceToDevice, xs));
+            return ss::comm_allreduce_f64_on(ctx, pr->tab0.p, pr->tab0.p, slice * (size_t)g->world, xs);
+        };
+        rc = run_pipelined(ctx, sh, max_iter, exchange, iters_out, k0);
+    }
+    // this rank's rows: ids once, ranks block by block (topic-major: rank_out[k][rows])
+    const size_t n_rows = (size_t)g->cnt_nd + g->cnt_d;
+    for (int b = 0; b < (int)sh[0].blk.size() && rc == SS_OK; b++)
+        rc = ss_pr_read_local(sh[0].blk[b], b == 0 ? ids_out : nullptr, rank_out + (size_t)k0[b] * n_rows);
+    for (ss_pr* pr : sh[0].blk) ss_pr_destroy(pr);
+    return rc;
+}
+
+int32_t ss_pagerank_run_group(ss_graph* const* shards, int32_t world, double damping, double eps, int32_t max_iter, int32_t k_topics,
+                              const int32_t* n_topic, double* rank_out, int32_t* iters_out) {
+    if (!shards || world < 2 || !shards[0]) return SS_ERR_INVALID;
+    ss_ctx* ctx = shards[0]->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (k_topics < 1 || k_topics > MAXK || !n_topic || !rank_out)
+        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_group: k_topics must be 1..%d, n_topic/rank_out not NULL", MAXK);
+    if (!(eps >= 0.0) && max_iter <= 0 && !(eps != eps))
+        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_group: eps < 0 (never converges) needs max_iter > 0");
+    for (int s = 0; s < world; s++)
+        if (!shards[s] || shards[s]->ctx != ctx || shards[s]->world != world || shards[s]->rank != s || shards[s]->n != shards[0]->n)
+            return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_group: shards[%d] is not shard %d of %d of the same graph on this context", s, s, world);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    const int B = topic_blocks_for(ctx, k_topics);
+    std::vector<ShardBlocks> sh(world);
+    std::vector<int> k0(B + 1);
+    for (int b = 0; b <= B; b++) k0[b] = (int)((int64_t)k_topics * b / B);
+    int32_t rc = SS_OK;
+    for (int s = 0; s < world && rc == SS_OK; s++)
+        for (int b = 0; b < B && rc == SS_OK; b++) {
+            ss_pr* pr = nullptr;
+            rc = ss_pr_create(shards[s], damping, eps, max_iter, k0[b + 1] - k0[b], n_topic + k0[b], &pr);
+            if (rc == SS_OK) sh[s].blk.push_back(pr);
+        }
+    if (rc == SS_OK) {
+        // the all-gather, by hand: every shard's slice into every shard's table, rank order
+        auto exchange = [&](int b, hipStream_t xs) -> int32_t {
+            for (int dst = 0; dst < world; dst++)
+                for (int src = 0; src < world; src++) {
+                    ss_pr* from = sh[src].blk[b];
+                    ss_pr* to = sh[dst].blk[b];
+                    const size_t slice = (size_t)shards[src]->sl_nd * from->gw;
+                    SS_HIP(ctx, hipMemcpyAsync(to->tab0.p + (size_t)src * slice, from->send.p, slice * sizeof(double), hipMemcpyDeviceToDevice, xs));
+                }
+            return SS_OK;
+        };
+        rc = run_pipelined(ctx, sh, max_iter, exchange, iters_out, k0);
+    }
+    // assemble [K][N] by original id
+    const uint64_t n = shards[0]->n;
+    for (int s = 0; s < world && rc == SS_OK; s++) {
+        const size_t n_rows = (size_t)shards[s]->cnt_nd + shards[s]->cnt_d;
+        std::vector<uint32_t> ids(n_rows);
+        for (int b = 0; b < B && rc == SS_OK; b++) {
+            const int kb = k0[b + 1] - k0[b];
+            std::vector<double> part((size_t)kb * n_rows);
+            rc = ss_pr_read_local(sh[s].blk[b], ids.data(), part.data());
+            if (rc != SS_OK) break;
+            for (int k = 0; k < kb; k++)
+                for (size_t i = 0; i < n_rows; i++) rank_out[(size_t)(k0[b] + k) * n + ids[i]] = part[(size_t)k * n_rows + i];
+        }
+    }
+    for (auto& s : sh)
+        for (ss_pr* pr : s.blk) ss_pr_destroy(pr);
     return rc;
 }
 

@@ -207,6 +207,19 @@ class Graph:
               self.ctx.h)
         return rank, iters
 
+    @staticmethod
+    def pagerank_group(shards, damping: float, eps: float, n_topic: Sequence[int], max_iter: int = 0):
+        """ss_pagerank_run_group: all `world` shards of one graph on one context, the library's pipelined (topic-blocked,
+        two-stream) sharded loop with in-process copies as the exchange -> (rank [K][N], iters [K])."""
+        n_topic = np.ascontiguousarray(np.atleast_1d(n_topic), dtype=np.int32)
+        K = len(n_topic)
+        ctx = shards[0].ctx
+        hs = (C.c_void_p * len(shards))(*[g.h for g in shards])
+        rank = np.zeros((K, shards[0].n), dtype=np.float64)
+        iters = np.zeros(K, dtype=np.int32)
+        check(ctx.lib.ss_pagerank_run_group(hs, len(shards), damping, eps, max_iter, K, _ptr(n_topic), _ptr(rank), _ptr(iters)), ctx.h)
+        return rank, iters
+
     def pagerank_dev(self, damping: float, eps: float, n_topic: Sequence[int], rank_out, max_iter: int = 0):
         """ss_pagerank_run with the ranks left in device memory (`rank_out`: torch float64 [K][N] on the GPU) -> iters [K]."""
         n_topic = np.ascontiguousarray(np.atleast_1d(n_topic), dtype=np.int32)

@@ -254,6 +254,43 @@ def test_sharded_layout_single_process(ss_ctx, oracle):
         ss_ctx.set_stream(None)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_in_library_pipelined_sharded_run(ss_ctx, oracle, world):
+    """ss_pagerank_run_group: the library's own sharded loop (topic blocks, exchanges on the context's second stream, events
+    between the streams) with all shards in this process and device copies standing in for the RCCL all-gather."""
+    from spaghettisearch_amd import engine
+    n, e = 30000, 160000
+    ptr, dst = synth.rmat_graph(n, e, seed=77)
+    graphs = [engine.Graph(ss_ctx, n, ptr, dst, rank=r, world=world) for r in range(world)]
+    try:
+        for k_topics, blocks in ((16, None), (16, 4), (5, None), (9, 3), (2, 2), (1, None)):
+            n_topic = synth.topic_sizes(n, k_topics)
+            ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-9, n_topic)
+            with ss_ctx.options(pr__topic_blocks=blocks):
+                rank, iters = engine.Graph.pagerank_group(graphs, D, 1e-9, n_topic)
+                rank2, iters2 = engine.Graph.pagerank_group(graphs, D, 1e-9, n_topic)
+            assert iters.tolist() == ref_iters.tolist(), (k_topics, blocks)
+            np.testing.assert_allclose(rank, ref, rtol=1e-12)
+            assert rank.tobytes() == rank2.tobytes() and iters.tolist() == iters2.tolist()     # run to run
+            # a block's results are bit for bit those of its topics run on their own (topics are independent: pagerank.go:54-63)
+            b = blocks if blocks else (2 if k_topics >= 8 else 1)
+            b = min(b, k_topics)
+            bounds = [k_topics * i // b for i in range(b + 1)]
+            with ss_ctx.options(pr__topic_blocks=1):
+                for lo, hi in zip(bounds[:-1], bounds[1:]):
+                    alone, it_alone = engine.Graph.pagerank_group(graphs, D, 1e-9, n_topic[lo:hi])
+                    assert alone.tobytes() == rank[lo:hi].tobytes() and it_alone.tolist() == iters[lo:hi].tolist()
+        # fixed iteration count (max_iter) and the reference's eps = 1e-20
+        n_topic = synth.topic_sizes(n, 6)
+        ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-30, n_topic, max_iter=5)
+        rank, iters = engine.Graph.pagerank_group(graphs, D, 1e-30, n_topic, max_iter=5)
+        assert iters.tolist() == [5] * 6 == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-13)
+    finally:
+        for g in graphs:
+            g.close()
+
+
 def _mp_worker(rank, world, port, n, e, n_topic, out_path):
     """One process per shard, all on cuda:0: the production driver (sharding.iterate + DistExchange +
     gather_ranks) with the real HIP states; gloo + host-staged exchange stand in for RCCL."""

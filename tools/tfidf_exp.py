@@ -1,5 +1,5 @@
-"""TF-IDF build timing (config-3 body table): device ms between HIP events, 3 builds on fresh copies of the table.
-    [SS_TFIDF_SHIFT=14] python tools/tfidf_exp.py"""
+"""TF-IDF build timing (config-3 body table): device ms between HIP events, 3 builds on fresh copies of the table, for a list of
+(tfidf.blocks, tfidf.bucket_shift) settings.   CFG="1024:13 2048:13" python tools/tfidf_exp.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -8,12 +8,16 @@ dev = torch.device('cuda', 0)
 ctx = engine.Context(0)
 nd, nt, P = 10_000_000, 1_000_000, int(os.environ.get("P", 640_000_000))
 b_ptr, b_doc, b_tf = synth.zipf_index_torch(nd, nt, P, seed=44, device=dev)
-ms = []
-for r in range(3):
-    bi = engine.InvertedIndex(ctx, nd, b_ptr, b_doc, b_tf.clone())
-    bi.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
-    ctx.synchronize()
-    ms.append(ctx.last_kernel_ms(2))
-    bi.close()
-print(f"shift={os.environ.get('SS_TFIDF_SHIFT', 'default')} P={b_doc.numel()}: tfidf build ms {['%.2f' % m for m in ms]}", flush=True)
+for cfg in os.environ.get("CFG", "1024:13").split():
+    blocks, shift = (int(x) for x in cfg.split(":"))
+    ctx.set_option("tfidf.blocks", blocks)
+    ctx.set_option("tfidf.bucket_shift", shift)
+    ms = []
+    for r in range(3):
+        bi = engine.InvertedIndex(ctx, nd, b_ptr, b_doc, b_tf.clone())
+        bi.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
+        ctx.synchronize()
+        ms.append(ctx.last_kernel_ms(2))
+        bi.close()
+    print(f"blocks={blocks} shift={shift} P={b_doc.numel()}: tfidf build ms {['%.2f' % m for m in ms]}", flush=True)
 ctx.close()
