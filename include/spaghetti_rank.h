@@ -105,6 +105,11 @@ const char* ss_last_error(ss_ctx* ctx); /* ctx may be NULL: last global error */
 #define SS_COMM_ID_BYTES 128
 int32_t ss_comm_unique_id(void* id_out /*[SS_COMM_ID_BYTES]*/);
 int32_t ss_comm_init(ss_ctx* ctx, const void* id /*[SS_COMM_ID_BYTES]*/, int32_t rank, int32_t world);
+/* 2-D decomposition (topic groups x doc shards): split the ranks into groups by color, renumbered by key inside a group; the
+ * context's communicator becomes the group's.  A host with 8 GPUs and 16 topics can then run two groups of four doc shards,
+ * each on 8 topics: a rank receives 3/4 of HALF the contribution table per sweep instead of 7/8 of all of it.
+ *   ss_comm_split(ctx, rank / 4, rank % 4); ss_graph_create(..., rank % 4, 4); ss_pagerank_run_sharded(g, ..., 8, n_topic + 8 * (rank / 4), ...) */
+int32_t ss_comm_split(ss_ctx* ctx, int32_t color, int32_t key);
 int32_t ss_comm_destroy(ss_ctx* ctx);
 int32_t ss_comm_info(ss_ctx* ctx, int32_t* rank_out /* -1: no communicator */, int32_t* world_out);
 /* The exchange steps of the index side: whole-corpus document frequencies = all-reduce(sum) of the
@@ -125,6 +130,15 @@ int32_t ss_comm_allgather(ss_ctx* ctx, const void* send, void* recv, uint64_t by
 int32_t ss_graph_create(ss_ctx* ctx, uint64_t n_nodes, uint64_t n_edges,
                         const uint64_t* out_ptr /*[n_nodes+1]*/, const uint32_t* out_dst /*[n_edges]*/,
                         int32_t rank, int32_t world, ss_graph** out);
+/* Incremental update of the resident link graph (indexer/indexer.go:302: re-indexing a changed page rewrites
+ * its forw[2] row, and setInverted :350-408 may add child pages never seen before).  The child lists of the `changed`
+ * parents (distinct node ids) are replaced by new_children[new_ptr[i] .. new_ptr[i+1]); n_nodes_new >= n_nodes admits new
+ * nodes (ids n_nodes .. n_nodes_new-1: new children, or new parents when they are in `changed`).  The library keeps the
+ * adjacency resident, patches it on the device and rebuilds its layout from it: no upload of the unchanged rows.  The result
+ * is the graph ss_graph_create would build from the updated rows (same layout, bit-identical PageRank).  No PageRank state
+ * may exist on the graph; on an error the graph is unchanged. */
+int32_t ss_graph_apply_delta(ss_graph* g, uint64_t n_nodes_new, uint64_t n_changed, const uint32_t* changed /*[n_changed]*/,
+                             const uint64_t* new_ptr /*[n_changed+1]*/, const uint32_t* new_children);
 int32_t ss_graph_get_info(const ss_graph* g, ss_graph_info* info);
 int32_t ss_graph_destroy(ss_graph* g);
 

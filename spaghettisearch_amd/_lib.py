@@ -54,11 +54,13 @@ PROTOTYPES = {
     "ss_last_error": (C.c_char_p, [_vp]),
     "ss_comm_unique_id": (_i32, [_vp]),
     "ss_comm_init": (_i32, [_vp, _vp, _i32, _i32]),
+    "ss_comm_split": (_i32, [_vp, _i32, _i32]),
     "ss_comm_destroy": (_i32, [_vp]),
     "ss_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "ss_comm_allreduce_u64": (_i32, [_vp, _vp, _u64]),
     "ss_comm_allgather": (_i32, [_vp, _vp, _vp, _u64]),
     "ss_graph_create": (_i32, [_vp, _u64, _u64, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "ss_graph_apply_delta": (_i32, [_vp, _u64, _u64, _vp, _vp, _vp]),
     "ss_graph_get_info": (_i32, [_vp, C.POINTER(SsGraphInfo)]),
     "ss_graph_destroy": (_i32, [_vp]),
     "ss_pagerank_run": (_i32, [_vp, _f64, _f64, _i32, _i32, _vp, _vp, _vp]),

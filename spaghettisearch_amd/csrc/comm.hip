@@ -73,13 +73,41 @@ int32_t ss_comm_init(ss_ctx* ctx, const void* id, int32_t rank, int32_t world) {
     return SS_OK;
 }
 
+// 2-D decomposition of the sharded sweep (topic groups x doc shards): the `world` ranks split into groups by `color`; inside
+// a group the ranks are renumbered by `key`.  The context's communicator becomes the group's (ss_comm_info then reports the
+// rank and size inside the group); the parent is kept and released by ss_comm_destroy.  Collective over the parent.
+int32_t ss_comm_split(ss_ctx* ctx, int32_t color, int32_t key) {
+    if (!ctx) return SS_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!ctx->comm) return ctx->fail(SS_ERR_STATE, "ss_comm_split: no communicator");
+    if (ctx->comm_parent) return ctx->fail(SS_ERR_STATE, "ss_comm_split: already split");
+    if (color < 0 || key < 0) return ctx->fail(SS_ERR_INVALID, "ss_comm_split: color and key must be >= 0");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    ncclComm_t sub = nullptr;
+    SS_NCCL(ctx, ncclCommSplit(static_cast<ncclComm_t>(ctx->comm), color, key, &sub, nullptr));
+    int r = 0, w = 1;
+    SS_NCCL(ctx, ncclCommUserRank(sub, &r));
+    SS_NCCL(ctx, ncclCommCount(sub, &w));
+    ctx->comm_parent = ctx->comm;
+    ctx->comm = sub;
+    ctx->comm_rank = r;
+    ctx->comm_world = w;
+    return SS_OK;
+}
+
 int32_t ss_comm_destroy(ss_ctx* ctx) {
     if (!ctx) return SS_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ctx->comm) return SS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    const ncclResult_t r = ncclCommDestroy(static_cast<ncclComm_t>(ctx->comm));
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    ncclResult_t r = ncclCommDestroy(static_cast<ncclComm_t>(ctx->comm));
+    if (ctx->comm_parent) {
+        const ncclResult_t r2 = ncclCommDestroy(static_cast<ncclComm_t>(ctx->comm_parent));
+        if (r == ncclSuccess) r = r2;
+        ctx->comm_parent = nullptr;
+    }
     ctx->comm = nullptr;
     ctx->comm_rank = 0;
     ctx->comm_world = 1;

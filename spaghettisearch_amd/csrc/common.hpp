@@ -36,6 +36,7 @@ struct ss_ctx {
     int tfidf_scatter_lds = 0;         // k_scatter's dynamic LDS size granted on this device
     int tfidf_bucket_lds = 0;          // dynamic LDS size already granted to k_bucket_sum on this device
     void* comm = nullptr;              // RCCL communicator of this rank (ss_comm_init), ncclComm_t
+    void* comm_parent = nullptr;       // the communicator `comm` was split from (ss_comm_split)
     int comm_rank = 0, comm_world = 1;
     // tuning / diagnostic options (ss_set_option); the defaults live at the point of use
     std::map<std::string, int64_t> options;

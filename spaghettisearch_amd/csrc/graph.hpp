@@ -29,6 +29,11 @@ struct ss_graph {
     uint64_t e_local = 0, e_local_nd = 0;
     uint32_t max_indeg = 0;
 
+    // the adjacency as the host handed it over (out-edge CSR over original ids): kept resident so that a re-crawled page's
+    // child list can be replaced on the device (ss_graph_apply_delta) without a new upload
+    ss::DevBuf<uint64_t> out_ptr;  // [n+1]
+    ss::DevBuf<uint32_t> out_dst;  // [e]
+    int users = 0;                 // ss_pr states on this graph
     ss::DevBuf<uint32_t> new_id;  // [n]     original id -> internal id
     ss::DevBuf<uint32_t> old_id;  // [n_int] internal id -> original id (0xFFFFFFFF = padding row)
     // local rows: lrow in [0, sl_nd) = non-dangling slice, [sl_nd, sl_nd+sl_d) = dangling slice

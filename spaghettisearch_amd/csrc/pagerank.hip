@@ -1317,6 +1317,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                 cnt[8], cnt[9], cnt[10], cnt[11], cnt[12], pr->nblocks);
     }
 #endif
+    g->users++;
     *out = guard.release();
     return SS_OK;
 }
@@ -1400,6 +1401,8 @@ int32_t ss_pr_destroy(ss_pr* pr) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    pr->g->users--;
     delete pr;
     return SS_OK;
 }

@@ -133,6 +133,10 @@ class Context:
             raise ValueError("communicator id must be SS_COMM_ID_BYTES long")
         check(self.lib.ss_comm_init(self.h, C.c_char_p(uid), rank, world), self.h)
 
+    def comm_split(self, color: int, key: int) -> None:
+        """ss_comm_split: topic groups x doc shards; the context's communicator becomes its group's."""
+        check(self.lib.ss_comm_split(self.h, color, key), self.h)
+
     def comm_destroy(self) -> None:
         check(self.lib.ss_comm_destroy(self.h), self.h)
 
@@ -178,6 +182,16 @@ class Graph:
         check(ctx.lib.ss_graph_create(ctx.h, self.n, self.e, _ptr(out_ptr), _ptr(out_dst), rank, world, C.byref(h)), ctx.h)
         self.h = h
         self.rank, self.world = rank, world
+
+    def apply_delta(self, n_nodes_new: int, changed, new_ptr, new_children) -> None:
+        """ss_graph_apply_delta: replace the child lists of the `changed` parents (and admit nodes up to n_nodes_new)."""
+        changed = _as(changed, "uint32")
+        new_ptr = _as(new_ptr, "uint64")
+        new_children = _as(new_children, "uint32")
+        self.ctx.ready(changed, new_ptr, new_children)
+        check(self.ctx.lib.ss_graph_apply_delta(self.h, int(n_nodes_new), int(changed.shape[0]), _ptr(changed), _ptr(new_ptr), _ptr(new_children)),
+              self.ctx.h)
+        self.n = int(n_nodes_new)
 
     def info(self) -> SsGraphInfo:
         gi = SsGraphInfo()

@@ -48,6 +48,17 @@ def test_world1_communicator_round_trip(ctx1):
     ctx1.comm_allgather(ds, dr, send.nbytes)
     ctx1.synchronize()
     assert torch.equal(ds, dr)
+    # 2-D decomposition: a world of one splits into one group of one; collectives keep working on the group's communicator
+    with pytest.raises(SpaghettiError):
+        ctx1.comm_split(-1, 0)
+    ctx1.comm_split(0, 0)
+    assert ctx1.comm_info() == (0, 1)
+    with pytest.raises(SpaghettiError) as ei:            # one split per context
+        ctx1.comm_split(0, 0)
+    assert ei.value.code == 6
+    h2 = np.arange(5, dtype=np.uint64)
+    ctx1.comm_allreduce_u64(h2)
+    assert np.array_equal(h2, np.arange(5, dtype=np.uint64))
     ctx1.comm_destroy()
     assert ctx1.comm_info() == (-1, 0)
     ctx1.comm_destroy()                                   # idempotent
