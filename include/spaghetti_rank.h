@@ -259,19 +259,35 @@ int32_t ss_index_set_positions(ss_index* idx, const uint64_t* pos_ptr, const flo
  * there is ignored like Go's delete on a missing key), the postings (add_term[i], add_doc[i], add_w[i]) arrive (the
  * re-indexed page; a pair must not exist unless this delta deletes it).  The delta is merged into the resident CSR on
  * the device — no re-flatten, no re-upload — and every list is re-validated to be strictly ascending by doc; on any
- * error the table is unchanged.  Weights are taken as given (the reference stores whatever listPos[0] holds);
- * magnitudes are NOT touched: call ss_index_refresh_magnitudes (or ss_tfidf_build, as the reference re-runs
- * UpdateTermWeights after every crawl, start_crawl.go:176-177).  Positional postings are dropped (set them again for
- * phrase search); scorers on this table must be destroyed before and created again after. */
+ * error the table is unchanged.  Weights are taken as given (the reference stores whatever listPos[0] holds).
+ * Magnitudes: when the table's squared magnitudes are resident (after ss_tfidf_build or ss_index_refresh_magnitudes), the
+ * delta updates the magnitudes of the docs it touches itself, in O(delta): what left is subtracted, what came is added
+ * (float64 sums of float32 squares are exact, so the result is the one a full pass gives; ss_index_read_magnitudes reads
+ * them back for the forw[4] rows).  After ss_index_set_weighted (magnitudes given from outside) they are NOT touched: call
+ * ss_index_refresh_magnitudes.  Positional postings: kept postings keep theirs; ss_index_apply_delta gives the new postings
+ * empty position lists, ss_index_apply_delta_pos takes theirs (add_pos_ptr[n_add+1] into add_pos, in the order of the add
+ * arrays; parser.go:195-207).  Doc and term ids must exist: grow the table first (ss_index_resize) when a re-indexed page
+ * brings new words or new child pages (indexer.go:350-408).  Scorers on this table must be destroyed before and created
+ * again after. */
 int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t* del_docs,
                              uint64_t n_del, const uint32_t* del_term, const uint32_t* del_doc,
                              uint64_t n_add, const uint32_t* add_term, const uint32_t* add_doc, const float* add_w);
+int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint32_t* del_docs,
+                                 uint64_t n_del, const uint32_t* del_term, const uint32_t* del_doc,
+                                 uint64_t n_add, const uint32_t* add_term, const uint32_t* add_doc, const float* add_w,
+                                 const uint64_t* add_pos_ptr /*[n_add+1] nullable*/, const float* add_pos);
+/* Grow the doc and / or term space of a resident table (new docs have no postings and magnitude 0, new terms empty lists). */
+int32_t ss_index_resize(ss_index* idx, uint64_t n_docs_new, uint64_t n_terms_new);
+/* mag_out[i] = magnitude of docs[i] as it stands (host or device arrays). */
+int32_t ss_index_read_magnitudes(ss_index* idx, uint64_t n, const uint32_t* docs, double* mag_out);
 /* mag[doc] = sqrt(sum float64(float32(w*w))) over the table's CURRENT weights (term_weighting.go:44,72), without the
  * idf multiplication of ss_tfidf_build.  mag_out [n_docs] nullable. */
 int32_t ss_index_refresh_magnitudes(ss_index* idx, double* mag_out);
 /* The table as it stands (after updates): sizes, then the arrays (each nullable; host or device). */
 int32_t ss_index_get_info(const ss_index* idx, uint64_t* n_docs, uint64_t* n_terms, uint64_t* n_post);
 int32_t ss_index_read(ss_index* idx, uint64_t* term_ptr_out /*[n_terms+1]*/, uint32_t* post_doc_out, float* post_w_out);
+/* the positional postings as they stand (each nullable): pos_ptr_out [n_post+1], pos_out [pos_ptr[n_post]] */
+int32_t ss_index_read_positions(ss_index* idx, uint64_t* pos_ptr_out, float* pos_out);
 
 /* ---- scoring: retrieval/main_retrieve.go:50-103, get_metadata.go:31-69 -- */
 int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer** out);

@@ -82,9 +82,13 @@ PROTOTYPES = {
     "ss_index_destroy": (_i32, [_vp]),
     "ss_tfidf_build": (_i32, [_vp, _u64, _vp, _vp, _vp]),
     "ss_index_apply_delta": (_i32, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp]),
+    "ss_index_apply_delta_pos": (_i32, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "ss_index_resize": (_i32, [_vp, _u64, _u64]),
+    "ss_index_read_magnitudes": (_i32, [_vp, _u64, _vp, _vp]),
     "ss_index_refresh_magnitudes": (_i32, [_vp, _vp]),
     "ss_index_get_info": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "ss_index_read": (_i32, [_vp, _vp, _vp, _vp]),
+    "ss_index_read_positions": (_i32, [_vp, _vp, _vp]),
     "ss_index_set_doc_freq": (_i32, [_vp, _vp]),
     "ss_index_set_weighted": (_i32, [_vp, _vp]),
     "ss_index_set_positions": (_i32, [_vp, _vp, _vp]),

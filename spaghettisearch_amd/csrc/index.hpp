@@ -14,6 +14,8 @@ struct ss_index {
     ss::DevBuf<uint32_t> post_doc;
     ss::DevBuf<float> post_w;
     ss::DevBuf<double> mag;        // sqrt(sum w^2) per doc, valid once `weighted`
+    ss::DevBuf<double> mag2;       // sum w^2 per doc (before the square root): what an incremental update adds to / subtracts from
+    bool mag2_valid = false;       // mag2 matches the table (set by ss_tfidf_build / ss_index_refresh_magnitudes, not by ss_index_set_weighted)
     ss::DevBuf<uint64_t> pos_ptr;  // [P+1] positional postings (phrase search), optional
     ss::DevBuf<float> pos;         // positions as stored by the reference: float32, -100 = anchor/meta text
     ss::DevBuf<uint64_t> df_global; // [T] whole-corpus document frequencies when this table is one doc-range shard (optional)

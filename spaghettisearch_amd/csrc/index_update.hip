@@ -42,11 +42,15 @@ __global__ void k_keep_from_bitmap(const uint32_t* __restrict__ post_doc, uint64
 }
 // single postings to delete: locate (term, doc) by binary search; a pair that does not exist is ignored, like the
 // reference's delete(docP, docHash) on a map without the key
-__global__ void k_unkeep_pairs(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ post_doc, uint64_t n_terms, uint64_t n_docs,
+// (pair_sq[i] = float32(w*w) of the posting pair i removed, or -1: nothing live was there — the magnitude update subtracts it;
+//  the keep flag is cleared with an atomic on its word so that a pair listed twice, or a pair of a deleted doc, counts once)
+__global__ void k_unkeep_pairs(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w,
+                               uint64_t n_terms, uint64_t n_docs,
                                const uint32_t* __restrict__ del_term, const uint32_t* __restrict__ del_doc, uint64_t n_del,
-                               uint8_t* __restrict__ keep, uint32_t* __restrict__ err) {
+                               uint8_t* __restrict__ keep, float* __restrict__ pair_sq, uint32_t* __restrict__ err) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_del; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t t = del_term[i], d = del_doc[i];
+        pair_sq[i] = -1.0f;
         if ((uint64_t)t >= n_terms || (uint64_t)d >= n_docs) { atomicOr(err, 2u); continue; }
         uint64_t lo = term_ptr[t], hi = term_ptr[t + 1];
         const uint64_t end = hi;
@@ -54,7 +58,45 @@ __global__ void k_unkeep_pairs(const uint64_t* __restrict__ term_ptr, const uint
             const uint64_t mid = (lo + hi) >> 1;
             if (post_doc[mid] < d) lo = mid + 1; else hi = mid;
         }
-        if (lo < end && post_doc[lo] == d) keep[lo] = 0;
+        if (lo < end && post_doc[lo] == d) {
+            uint32_t* word = reinterpret_cast<uint32_t*>(keep + (lo & ~(uint64_t)3));
+            const uint32_t sh = (uint32_t)(lo & 3) * 8u;
+            const uint32_t old = atomicAnd(word, ~(0xFFu << sh));
+            if ((old >> sh) & 0xFFu) {
+                const float w = post_w[lo];
+                pair_sq[i] = w * w;                                   // term_weighting.go:44 (float32 product)
+            }
+        }
+    }
+}
+// magnitudes of the touched docs (term_weighting.go:44,72), O(delta): the squared magnitudes are resident (float64 sums of
+// float32 squares: exact, so subtracting what left and adding what came gives the sum a full pass would give)
+__global__ void k_mag_zero_docs(const uint32_t* __restrict__ docs, uint64_t n, double* __restrict__ mag2) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mag2[docs[i]] = 0.0;
+}
+__global__ void k_mag_sub_pairs(const uint32_t* __restrict__ del_doc, const float* __restrict__ pair_sq, uint64_t n, double* __restrict__ mag2) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (pair_sq[i] >= 0.0f) unsafeAtomicAdd(&mag2[del_doc[i]], -(double)pair_sq[i]);
+}
+__global__ void k_mag_add(const uint32_t* __restrict__ add_doc, const float* __restrict__ add_w, uint64_t n, double* __restrict__ mag2) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float sq = add_w[i] * add_w[i];
+        unsafeAtomicAdd(&mag2[add_doc[i]], (double)sq);
+    }
+}
+__global__ void k_mag_sqrt_docs(const uint32_t* __restrict__ docs, uint64_t n, const double* __restrict__ mag2, double* __restrict__ mag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mag[docs[i]] = sqrt(mag2[docs[i]]);
+}
+__global__ void k_gather_f64(const double* __restrict__ v, const uint32_t* __restrict__ idx, uint64_t n, uint64_t limit, double* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint64_t)idx[i] < limit ? v[idx[i]] : 0.0;
+}
+// positional postings of the merged table: every output posting copies its positions from the old array or from the delta's
+__global__ void k_copy_positions(const uint64_t* __restrict__ new_pos_ptr, const uint64_t* __restrict__ src_start /* bit 63: from the delta */,
+                                 uint64_t n_post, const float* __restrict__ old_pos, const float* __restrict__ add_pos, float* __restrict__ out) {
+    for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_post; o += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = new_pos_ptr[o], n = new_pos_ptr[o + 1] - b, s = src_start[o];
+        const float* from = (s >> 63) ? add_pos + (s & ~(1ull << 63)) : old_pos + s;
+        for (uint64_t q = 0; q < n; q++) out[b + q] = from[q];
     }
 }
 __global__ void k_add_keys(const uint32_t* __restrict__ add_term, const uint32_t* __restrict__ add_doc, uint64_t n_add, uint64_t n_terms, uint64_t n_docs,
@@ -97,7 +139,8 @@ __global__ __launch_bounds__(TPB) void k_place_kept(const uint64_t* __restrict__
                                                     const float* __restrict__ post_w, uint64_t n_post, const uint8_t* __restrict__ keep,
                                                     const uint32_t* __restrict__ kept_before, const uint64_t* __restrict__ add_keys,
                                                     const uint32_t* __restrict__ add_ptr, const uint64_t* __restrict__ new_ptr,
-                                                    uint32_t* __restrict__ out_doc, float* __restrict__ out_w) {
+                                                    uint32_t* __restrict__ out_doc, float* __restrict__ out_w,
+                                                    const uint64_t* __restrict__ pos_ptr /*nullable*/, uint64_t* __restrict__ len_out, uint64_t* __restrict__ src_start) {
     __shared__ uint64_t s_t[2];
     const uint64_t base = (uint64_t)blockIdx.x * PK_CHUNK;
     const uint64_t last = min(base + PK_CHUNK, n_post) - 1;
@@ -130,13 +173,15 @@ __global__ __launch_bounds__(TPB) void k_place_kept(const uint64_t* __restrict__
         const uint64_t o = new_ptr[t] + rank_kept + adds_below;
         out_doc[o] = d;
         out_w[o] = post_w[i];
+        if (pos_ptr) { len_out[o] = pos_ptr[i + 1] - pos_ptr[i]; src_start[o] = pos_ptr[i]; }
     }
 }
 // every new posting: its rank among the additions of its term + the survivors of the term with a smaller doc id
 __global__ void k_place_adds(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ post_doc, const uint8_t* __restrict__ keep,
                              const uint32_t* __restrict__ kept_before, const uint64_t* __restrict__ add_keys, const uint32_t* __restrict__ add_order,
                              const float* __restrict__ add_w, uint64_t n_add, const uint32_t* __restrict__ add_ptr, const uint64_t* __restrict__ new_ptr,
-                             uint32_t* __restrict__ out_doc, float* __restrict__ out_w, uint32_t* __restrict__ err) {
+                             uint32_t* __restrict__ out_doc, float* __restrict__ out_w, uint32_t* __restrict__ err,
+                             const uint64_t* __restrict__ add_pos_ptr /*nullable*/, uint64_t* __restrict__ len_out /*nullable*/, uint64_t* __restrict__ src_start) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_add) return;
     const uint64_t key = add_keys[j];
@@ -154,6 +199,19 @@ __global__ void k_place_adds(const uint64_t* __restrict__ term_ptr, const uint32
     const uint64_t o = new_ptr[t] + ((uint32_t)j - add_ptr[t]) + kept_below;
     out_doc[o] = d;
     out_w[o] = add_w[add_order[j]];
+    if (len_out) {
+        const uint32_t a = add_order[j];
+        len_out[o] = add_pos_ptr ? add_pos_ptr[a + 1] - add_pos_ptr[a] : 0ull;
+        src_start[o] = (1ull << 63) | (add_pos_ptr ? add_pos_ptr[a] : 0ull);
+    }
+}
+__global__ void k_check_mono_u64(const uint64_t* __restrict__ p, uint64_t n, uint32_t* __restrict__ err) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) bad = bad || p[i + 1] < p[i];
+    if (bad) atomicOr(err, 1u);
+}
+__global__ void k_fill_u64(uint64_t* __restrict__ v, uint64_t lo, uint64_t hi, uint64_t x) {
+    for (uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * blockDim.x) v[i] = x;
 }
 __global__ void k_iota(uint32_t* __restrict__ v, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
@@ -219,6 +277,12 @@ extern "C" {
 
 int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t* del_docs, uint64_t n_del, const uint32_t* del_term,
                              const uint32_t* del_doc, uint64_t n_add, const uint32_t* add_term, const uint32_t* add_doc, const float* add_w) {
+    return ss_index_apply_delta_pos(idx, n_del_docs, del_docs, n_del, del_term, del_doc, n_add, add_term, add_doc, add_w, nullptr, nullptr);
+}
+
+int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint32_t* del_docs, uint64_t n_del, const uint32_t* del_term,
+                                 const uint32_t* del_doc, uint64_t n_add, const uint32_t* add_term, const uint32_t* add_doc, const float* add_w,
+                                 const uint64_t* add_pos_ptr, const float* add_pos) {
     if (!idx) return SS_ERR_INVALID;
     ss_ctx* ctx = idx->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -232,10 +296,32 @@ int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t*
 
     ss::DevBuf<uint32_t> bitmap, err, d_del_docs, d_del_term, d_del_doc, d_add_term, d_add_doc, order_in, order, kept_before, add_ptr;
     ss::DevBuf<uint8_t> keep;
-    ss::DevBuf<float> d_add_w;
-    ss::DevBuf<uint64_t> keys_in, keys, cnt, new_ptr;
+    ss::DevBuf<float> d_add_w, pair_sq, d_add_pos;
+    ss::DevBuf<uint64_t> keys_in, keys, cnt, new_ptr, d_add_pos_ptr, len_out, src_start, new_pos_ptr;
+    const bool has_pos = idx->pos_ptr.p != nullptr;
+    uint64_t n_add_pos = 0;
+    if (has_pos && add_pos_ptr && n_add) {
+        std::vector<uint64_t> ends(2);
+        SS_HIP(ctx, hipMemcpy(&ends[0], add_pos_ptr, sizeof(uint64_t), hipMemcpyDefault));
+        SS_HIP(ctx, hipMemcpy(&ends[1], add_pos_ptr + n_add, sizeof(uint64_t), hipMemcpyDefault));
+        if (ends[0] != 0 || (ends[1] && !add_pos)) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: add_pos_ptr[0] != 0 or add_pos NULL");
+        n_add_pos = ends[1];
+        SS_HIP(ctx, d_add_pos_ptr.alloc(n_add + 1));
+        SS_HIP(ctx, d_add_pos.alloc(n_add_pos));
+        SS_HIP(ctx, hipMemcpyAsync(d_add_pos_ptr.p, add_pos_ptr, (n_add + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
+        if (n_add_pos) SS_HIP(ctx, hipMemcpyAsync(d_add_pos.p, add_pos, n_add_pos * sizeof(float), hipMemcpyDefault, st));
+        ss::DevBuf<uint32_t> perr;
+        SS_HIP(ctx, perr.alloc(1));
+        SS_HIP(ctx, hipMemsetAsync(perr.p, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_check_mono_u64, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint64_t*)d_add_pos_ptr.p, n_add, perr.p);
+        uint32_t h_perr = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&h_perr, perr.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        if (h_perr) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: add_pos_ptr is not non-decreasing");
+    }
+    SS_HIP(ctx, pair_sq.alloc(n_del));
     SS_HIP(ctx, bitmap.alloc((N + 31) / 32));
-    SS_HIP(ctx, keep.alloc(P + 1));
+    SS_HIP(ctx, keep.alloc(((P + 1) + 3) & ~(uint64_t)3));
     SS_HIP(ctx, kept_before.alloc(P + 1));
     SS_HIP(ctx, err.alloc(1));
     SS_HIP(ctx, hipMemsetAsync(bitmap.p, 0, std::max<size_t>(bitmap.bytes(), 4), st));
@@ -252,8 +338,8 @@ int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t*
         SS_HIP(ctx, d_del_doc.alloc(n_del));
         SS_HIP(ctx, hipMemcpyAsync(d_del_term.p, del_term, n_del * sizeof(uint32_t), hipMemcpyDefault, st));
         SS_HIP(ctx, hipMemcpyAsync(d_del_doc.p, del_doc, n_del * sizeof(uint32_t), hipMemcpyDefault, st));
-        hipLaunchKernelGGL(k_unkeep_pairs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint32_t*)idx->post_doc.p, T, N,
-                           (const uint32_t*)d_del_term.p, (const uint32_t*)d_del_doc.p, n_del, keep.p, err.p);
+        hipLaunchKernelGGL(k_unkeep_pairs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint32_t*)idx->post_doc.p,
+                           (const float*)idx->post_w.p, T, N, (const uint32_t*)d_del_term.p, (const uint32_t*)d_del_doc.p, n_del, keep.p, pair_sq.p, err.p);
     }
     // additions sorted by (term, doc); the order array carries the weights along
     SS_HIP(ctx, keys_in.alloc(n_add));
@@ -306,12 +392,20 @@ int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t*
     ss::DevBuf<float> out_w;
     SS_HIP(ctx, out_doc.alloc(P2));
     SS_HIP(ctx, out_w.alloc(P2));
+    if (has_pos) {
+        SS_HIP(ctx, len_out.alloc(P2 + 1));
+        SS_HIP(ctx, src_start.alloc(P2 + 1));
+        SS_HIP(ctx, new_pos_ptr.alloc(P2 + 1));
+        SS_HIP(ctx, hipMemsetAsync(len_out.p, 0, (P2 + 1) * sizeof(uint64_t), st));
+    }
     if (P) hipLaunchKernelGGL(k_place_kept, dim3(ss::div_up(P, PK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, T, (const uint32_t*)idx->post_doc.p,
                               (const float*)idx->post_w.p, P, (const uint8_t*)keep.p, (const uint32_t*)kept_before.p, (const uint64_t*)keys.p,
-                              (const uint32_t*)add_ptr.p, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p);
+                              (const uint32_t*)add_ptr.p, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p,
+                              has_pos ? (const uint64_t*)idx->pos_ptr.p : nullptr, len_out.p, src_start.p);
     if (n_add) hipLaunchKernelGGL(k_place_adds, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint32_t*)idx->post_doc.p,
                                   (const uint8_t*)keep.p, (const uint32_t*)kept_before.p, (const uint64_t*)keys.p, (const uint32_t*)order.p,
-                                  (const float*)d_add_w.p, n_add, (const uint32_t*)add_ptr.p, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p, err.p);
+                                  (const float*)d_add_w.p, n_add, (const uint32_t*)add_ptr.p, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p, err.p,
+                                  (const uint64_t*)d_add_pos_ptr.p, has_pos ? len_out.p : nullptr, src_start.p);
     if (P2) hipLaunchKernelGGL(k_check_merged, dim3(ss::div_up(P2, PK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)new_ptr.p, T, (const uint32_t*)out_doc.p, P2, err.p);
     SS_HIP(ctx, hipGetLastError());
     uint32_t h_err = 0;
@@ -323,14 +417,95 @@ int32_t ss_index_apply_delta(ss_index* idx, uint64_t n_del_docs, const uint32_t*
     if (h_err & 8) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: the same (term, doc) is added twice (table unchanged)");
     if (h_err & 16) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a posting to add already exists and is not deleted by this delta (table unchanged)");
     if (h_err & 32) return ctx->fail(SS_ERR_UNSORTED, "ss_index_apply_delta: merged list not strictly ascending (table unchanged)");
+    // positional postings follow their postings (listPos[1:] of every kept row entry; the re-indexed page brings its own)
+    ss::DevBuf<float> new_pos;
+    if (has_pos) {
+        SS_TRY(exclusive_scan_u64(ctx, len_out.p, new_pos_ptr.p, (size_t)(P2 + 1)));
+        uint64_t total = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&total, new_pos_ptr.p + P2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        SS_HIP(ctx, new_pos.alloc(total));
+        if (P2) hipLaunchKernelGGL(k_copy_positions, dim3(grid_for(P2)), dim3(TPB), 0, st, (const uint64_t*)new_pos_ptr.p, (const uint64_t*)src_start.p, P2,
+                                   (const float*)idx->pos.p, (const float*)d_add_pos.p, new_pos.p);
+        SS_HIP(ctx, hipGetLastError());
+    }
+    // magnitudes of the touched docs: what left is subtracted from, what came is added to the resident squared magnitudes
+    if (idx->mag2_valid) {
+        if (n_del_docs) hipLaunchKernelGGL(k_mag_zero_docs, dim3(grid_for(n_del_docs)), dim3(TPB), 0, st, (const uint32_t*)d_del_docs.p, n_del_docs, idx->mag2.p);
+        if (n_del) hipLaunchKernelGGL(k_mag_sub_pairs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint32_t*)d_del_doc.p, (const float*)pair_sq.p, n_del, idx->mag2.p);
+        if (n_add) hipLaunchKernelGGL(k_mag_add, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint32_t*)d_add_doc.p, (const float*)d_add_w.p, n_add, idx->mag2.p);
+        if (n_del_docs) hipLaunchKernelGGL(k_mag_sqrt_docs, dim3(grid_for(n_del_docs)), dim3(TPB), 0, st, (const uint32_t*)d_del_docs.p, n_del_docs, (const double*)idx->mag2.p, idx->mag.p);
+        if (n_del) hipLaunchKernelGGL(k_mag_sqrt_docs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint32_t*)d_del_doc.p, n_del, (const double*)idx->mag2.p, idx->mag.p);
+        if (n_add) hipLaunchKernelGGL(k_mag_sqrt_docs, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint32_t*)d_add_doc.p, n_add, (const double*)idx->mag2.p, idx->mag.p);
+        SS_HIP(ctx, hipGetLastError());
+    }
+    SS_HIP(ctx, hipStreamSynchronize(st));
     // commit
     idx->post_doc = std::move(out_doc);
     idx->post_w = std::move(out_w);
     idx->term_ptr = std::move(new_ptr);
     idx->h_term_ptr = std::move(h_new_ptr);
     idx->n_post = P2;
-    idx->pos_ptr.release();            // positional postings no longer line up: set them again for phrase search
-    idx->pos.release();
+    if (has_pos) {
+        idx->pos_ptr = std::move(new_pos_ptr);
+        idx->pos = std::move(new_pos);
+    }
+    return SS_OK;
+}
+
+int32_t ss_index_resize(ss_index* idx, uint64_t n_docs_new, uint64_t n_terms_new) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (idx->users > 0) return ctx->fail(SS_ERR_STATE, "ss_index_resize: %d scorer(s) still hold this table", idx->users);
+    if (n_docs_new < idx->n_docs || n_terms_new < idx->n_terms) return ctx->fail(SS_ERR_INVALID, "ss_index_resize: a table only grows");
+    if (n_docs_new >= 0xFFFFFFF0ull || n_terms_new >= 0xFFFFFFF0ull) return ctx->fail(SS_ERR_INVALID, "ss_index_resize: n_docs/n_terms out of range");
+    if (idx->has_df_global && n_terms_new != idx->n_terms) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_index_resize: a doc-range shard with whole-corpus document frequencies cannot grow its term space");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t T = idx->n_terms, N = idx->n_docs, P = idx->n_post;
+    if (n_terms_new > T) {                                   // new terms: empty lists behind the last posting
+        ss::DevBuf<uint64_t> tp;
+        SS_HIP(ctx, tp.alloc(n_terms_new + 1));
+        SS_HIP(ctx, hipMemcpyAsync(tp.p, idx->term_ptr.p, (T + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(n_terms_new - T)), dim3(TPB), 0, st, tp.p, T + 1, n_terms_new + 1, P);
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        idx->term_ptr = std::move(tp);
+        idx->h_term_ptr.resize(n_terms_new + 1, P);
+        idx->n_terms = n_terms_new;
+    }
+    if (n_docs_new > N) {                                    // new docs: no postings yet, magnitude 0
+        ss::DevBuf<double> m, m2;
+        SS_HIP(ctx, m.alloc(n_docs_new));
+        SS_HIP(ctx, m2.alloc(n_docs_new));
+        SS_HIP(ctx, hipMemsetAsync(m.p, 0, n_docs_new * sizeof(double), st));
+        SS_HIP(ctx, hipMemsetAsync(m2.p, 0, n_docs_new * sizeof(double), st));
+        SS_HIP(ctx, hipMemcpyAsync(m.p, idx->mag.p, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (idx->mag2.p) SS_HIP(ctx, hipMemcpyAsync(m2.p, idx->mag2.p, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        idx->mag = std::move(m);
+        idx->mag2 = std::move(m2);
+        idx->n_docs = n_docs_new;
+    }
+    return SS_OK;
+}
+
+int32_t ss_index_read_magnitudes(ss_index* idx, uint64_t n, const uint32_t* docs, double* mag_out) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (n && (!docs || !mag_out)) return ctx->fail(SS_ERR_INVALID, "ss_index_read_magnitudes: NULL argument");
+    if (n == 0) return SS_OK;
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ss::DevBuf<uint32_t> d_docs;
+    ss::DevBuf<double> d_out;
+    SS_HIP(ctx, d_docs.alloc(n));
+    SS_HIP(ctx, d_out.alloc(n));
+    SS_HIP(ctx, hipMemcpyAsync(d_docs.p, docs, n * sizeof(uint32_t), hipMemcpyDefault, st));
+    hipLaunchKernelGGL(k_gather_f64, dim3(grid_for(n)), dim3(TPB), 0, st, (const double*)idx->mag.p, (const uint32_t*)d_docs.p, n, idx->n_docs, d_out.p);
+    SS_HIP(ctx, hipMemcpyAsync(mag_out, d_out.p, n * sizeof(double), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
     return SS_OK;
 }
 

@@ -465,7 +465,7 @@ __global__ void k_sumsq_atomic(const uint32_t* __restrict__ post_doc, const floa
 
 constexpr int TPB_B = 512;
 __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ packed, const uint32_t* __restrict__ off, uint64_t n_docs,
-                                                      int shift, double* __restrict__ mag) {
+                                                      int shift, double* __restrict__ mag, double* __restrict__ mag2) {
     extern __shared__ double acc[];                                    // [1 << shift]
     const uint32_t bd = 1u << shift, b = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) acc[i] = 0.0;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ 
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) {
         const uint64_t d = (uint64_t)b * bd + i;
-        if (d < n_docs) mag[d] = sqrt(acc[i]);                         // term_weighting.go:72
+        if (d < n_docs) { mag[d] = sqrt(acc[i]); mag2[d] = acc[i]; }   // term_weighting.go:72
     }
 }
 
@@ -540,7 +540,7 @@ void bucket_pass_launch(ss_index* idx, hipStream_t st, BucketPass& bp, bool weig
     hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, bp.cnt.p, bp.nb, bp.off.p, bp.cur.p);
     hipLaunchKernelGGL(k_scatter, dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.bpt), st, idx->post_doc.p, idx->post_w.p, P, bp.per, bp.shift, bp.nb,
                        bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p);
-    hipLaunchKernelGGL(k_bucket_sum, dim3(bp.nb), dim3(TPB_B), (size_t)(1 << bp.shift) * 8, st, bp.packed.p, bp.off.p, N, bp.shift, idx->mag.p);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(bp.nb), dim3(TPB_B), (size_t)(1 << bp.shift) * 8, st, bp.packed.p, bp.off.p, N, bp.shift, idx->mag.p, idx->mag2.p);
 }
 
 }  // namespace
@@ -576,6 +576,7 @@ int32_t ss_index_create(ss_ctx* ctx, uint64_t n_docs, uint64_t n_terms, const ui
     SS_HIP(ctx, idx->post_doc.alloc(P));
     SS_HIP(ctx, idx->post_w.alloc(P));
     SS_HIP(ctx, idx->mag.alloc(n_docs));
+    SS_HIP(ctx, idx->mag2.alloc(n_docs));
     if (P) {
         SS_HIP(ctx, hipMemcpyAsync(idx->post_doc.p, post_doc, P * sizeof(uint32_t), hipMemcpyDefault, st));
         SS_HIP(ctx, hipMemcpyAsync(idx->post_w.p, post_tf, P * sizeof(float), hipMemcpyDefault, st));
@@ -651,8 +652,10 @@ int32_t ss_tfidf_build(ss_index* idx, uint64_t total_docs, float* w_out, double*
     } else {
         if (P) hipLaunchKernelGGL(k_weight, dim3(ss::div_up(P, CH)), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p,
                                   idx->post_w.p, idf.p, P, idx->mag.p);
+        SS_HIP(ctx, hipMemcpyAsync(idx->mag2.p, idx->mag.p, N * sizeof(double), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_sqrt, dim3(ss::div_up(N, TPB)), dim3(TPB), 0, st, idx->mag.p, N);
     }
+    idx->mag2_valid = true;
     SS_HIP(ctx, hipEventRecord(ctx->ev[2][1], st));
     ctx->ev_valid[2] = true;
     SS_HIP(ctx, hipGetLastError());
@@ -686,9 +689,11 @@ int32_t ss_index_refresh_magnitudes(ss_index* idx, double* mag_out) {
     } else {
         if (P) hipLaunchKernelGGL(k_sumsq_atomic, dim3(std::min<unsigned>(ss::div_up(P, TPB), 16384u)), dim3(TPB), 0, st, (const uint32_t*)idx->post_doc.p,
                                   (const float*)idx->post_w.p, P, idx->mag.p);
+        SS_HIP(ctx, hipMemcpyAsync(idx->mag2.p, idx->mag.p, N * sizeof(double), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_sqrt, dim3(ss::div_up(N, TPB)), dim3(TPB), 0, st, idx->mag.p, N);
         SS_HIP(ctx, hipGetLastError());
     }
+    idx->mag2_valid = true;
     idx->weighted = true;
     if (mag_out) SS_HIP(ctx, hipMemcpyAsync(mag_out, idx->mag.p, N * sizeof(double), hipMemcpyDefault, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
@@ -712,6 +717,19 @@ int32_t ss_index_read(ss_index* idx, uint64_t* term_ptr_out, uint32_t* post_doc_
     if (term_ptr_out) SS_HIP(ctx, hipMemcpyAsync(term_ptr_out, idx->term_ptr.p, (idx->n_terms + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
     if (post_doc_out && idx->n_post) SS_HIP(ctx, hipMemcpyAsync(post_doc_out, idx->post_doc.p, idx->n_post * sizeof(uint32_t), hipMemcpyDefault, st));
     if (post_w_out && idx->n_post) SS_HIP(ctx, hipMemcpyAsync(post_w_out, idx->post_w.p, idx->n_post * sizeof(float), hipMemcpyDefault, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    return SS_OK;
+}
+
+int32_t ss_index_read_positions(ss_index* idx, uint64_t* pos_ptr_out, float* pos_out) {
+    if (!idx) return SS_ERR_INVALID;
+    ss_ctx* ctx = idx->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!idx->pos_ptr.p) return ctx->fail(SS_ERR_STATE, "ss_index_read_positions: the table holds no positional postings");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (pos_ptr_out) SS_HIP(ctx, hipMemcpyAsync(pos_ptr_out, idx->pos_ptr.p, (idx->n_post + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
+    if (pos_out && idx->pos.n) SS_HIP(ctx, hipMemcpyAsync(pos_out, idx->pos.p, idx->pos.n * sizeof(float), hipMemcpyDefault, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     return SS_OK;
 }
@@ -787,6 +805,7 @@ int32_t ss_index_set_weighted(ss_index* idx, const double* mag) {
     SS_HIP(ctx, hipMemcpyAsync(idx->mag.p, mag, idx->n_docs * sizeof(double), hipMemcpyDefault, ctx->stream));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     idx->weighted = true;
+    idx->mag2_valid = false;       // given magnitudes: their squares are not the exact sums an incremental update needs
     return SS_OK;
 }
 

@@ -355,18 +355,39 @@ class InvertedIndex:
         check(self.ctx.lib.ss_tfidf_build(self.h, int(total_docs), _ptr(w), _ptr(mag), _ptr(idf)), self.ctx.h)
         return w, mag, idf
 
-    def apply_delta(self, del_docs=None, del_pairs=None, add=None) -> None:
-        """ss_index_apply_delta: del_docs uint32[], del_pairs = (terms uint32[], docs uint32[]), add = (terms, docs, weights f32[])."""
+    def apply_delta(self, del_docs=None, del_pairs=None, add=None, add_pos=None) -> None:
+        """ss_index_apply_delta(_pos): del_docs uint32[], del_pairs = (terms uint32[], docs uint32[]), add = (terms, docs, weights f32[]),
+        add_pos = (pos_ptr uint64[n_add+1], pos float32[]) positional postings of the new postings (tables with positions)."""
         dd = _as(del_docs if del_docs is not None else np.zeros(0, np.uint32), "uint32")
         dt, dp = (_as(del_pairs[0], "uint32"), _as(del_pairs[1], "uint32")) if del_pairs is not None else (np.zeros(0, np.uint32),) * 2
         at, ad, aw = (_as(add[0], "uint32"), _as(add[1], "uint32"), _as(add[2], "float32")) if add is not None else \
             (np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32))
-        self.ctx.ready(dd, dt, dp, at, ad, aw)
-        check(self.ctx.lib.ss_index_apply_delta(self.h, int(dd.shape[0]), _ptr(dd), int(dt.shape[0]), _ptr(dt), _ptr(dp),
-                                                int(at.shape[0]), _ptr(at), _ptr(ad), _ptr(aw)), self.ctx.h)
+        pp, pv = (_as(add_pos[0], "uint64"), _as(add_pos[1], "float32")) if add_pos is not None else (None, None)
+        self.ctx.ready(dd, dt, dp, at, ad, aw, pp, pv)
+        check(self.ctx.lib.ss_index_apply_delta_pos(self.h, int(dd.shape[0]), _ptr(dd), int(dt.shape[0]), _ptr(dt), _ptr(dp),
+                                                    int(at.shape[0]), _ptr(at), _ptr(ad), _ptr(aw), _ptr(pp), _ptr(pv)), self.ctx.h)
         n_post = C.c_uint64()
         check(self.ctx.lib.ss_index_get_info(self.h, None, None, C.byref(n_post)), self.ctx.h)
         self.n_post = int(n_post.value)
+
+    def resize(self, n_docs: int, n_terms: int) -> None:
+        """ss_index_resize: grow the doc and / or term space (new words, new child pages of a re-indexed page)."""
+        check(self.ctx.lib.ss_index_resize(self.h, int(n_docs), int(n_terms)), self.ctx.h)
+        self.n_docs, self.n_terms = int(n_docs), int(n_terms)
+
+    def read_magnitudes(self, docs) -> np.ndarray:
+        docs = _as(docs, "uint32")
+        out = np.zeros(int(docs.shape[0]), dtype=np.float64)
+        check(self.ctx.lib.ss_index_read_magnitudes(self.h, int(docs.shape[0]), _ptr(docs), _ptr(out)), self.ctx.h)
+        return out
+
+    def read_positions(self):
+        """-> (pos_ptr uint64[P+1], pos float32[]) as they stand (tables with positional postings)."""
+        pp = np.zeros(self.n_post + 1, dtype=np.uint64)
+        check(self.ctx.lib.ss_index_read_positions(self.h, _ptr(pp), None), self.ctx.h)
+        pv = np.zeros(int(pp[-1]), dtype=np.float32)
+        check(self.ctx.lib.ss_index_read_positions(self.h, None, _ptr(pv)), self.ctx.h)
+        return pp, pv
 
     def refresh_magnitudes(self) -> np.ndarray:
         mag = np.zeros(self.n_docs, dtype=np.float64)

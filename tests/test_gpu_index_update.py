@@ -134,7 +134,7 @@ def test_rejected_delta_leaves_the_table_unchanged(ss_ctx):
             dict(del_docs=u(500)),                                             # doc out of range
             dict(del_pairs=(u(60), u(1))),                                     # term out of range
             dict(add=(u(1), u(999), f(1))),                                    # doc out of range
-            dict(add=(u(60), u(1), f(1))),                                     # term = n_terms
+            dict(add=(u(60), u(1), f(1))),                                     # term = n_terms: grow the table first (ss_index_resize)
             dict(add=(u(0xFFFFFFF0), u(1), f(1))),                             # term far out of range (no placement kernel may run)
             dict(add=(u(2, 2), u(5, 5), f(1, 2)), del_docs=u(5)),              # the same posting twice
             dict(add=(u(t0), u(d_existing), f(1))),                            # exists, not deleted by the delta
@@ -149,6 +149,91 @@ def test_rejected_delta_leaves_the_table_unchanged(ss_ctx):
         idx.apply_delta(del_pairs=(u(t0), u(d_existing)), add=(u(t0), u(d_existing), f(7)))
         g = idx.read()
         assert g[2][int(tp[t0])] == 7.0 and np.array_equal(g[1], pd)
+    finally:
+        idx.close()
+
+
+def test_growth_positions_and_touched_magnitudes(ss_ctx, oracle):
+    """A re-indexed page brings NEW words and NEW child pages (indexer.go:350-408): the table grows first; positional postings
+    follow their postings through the merge (kept ones keep theirs, the page's new ones arrive with the delta); the magnitudes
+    of the touched docs are updated by the delta itself, in O(delta), and equal a full pass bit for bit."""
+    from spaghettisearch_amd import engine
+    rng = np.random.default_rng(77)
+    n_docs, n_terms = 6000, 900
+    tp, pd, tf = synth.zipf_index(n_docs, n_terms, 90000, seed=21)
+    # positions: 1..4 per posting, some of them the -100 anchor sentinel (parser.go:195-207)
+    lens = rng.integers(1, 5, size=len(pd))
+    pos_ptr = np.zeros(len(pd) + 1, dtype=np.uint64)
+    pos_ptr[1:] = np.cumsum(lens)
+    pos = rng.integers(0, 400, size=int(pos_ptr[-1])).astype(np.float32)
+    pos[rng.random(len(pos)) < 0.1] = -100.0
+    idx = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
+    try:
+        idx.set_positions(pos_ptr, pos)
+        w0, mag0, _ = idx.tfidf_build(n_docs)                          # weighted table, squared magnitudes resident
+        # model: rows[t][doc] = (w, positions)
+        rows = [dict() for _ in range(n_terms)]
+        for t in range(n_terms):
+            for i in range(int(tp[t]), int(tp[t + 1])):
+                rows[t][int(pd[i])] = (w0[i], pos[int(pos_ptr[i]):int(pos_ptr[i + 1])].tolist())
+        n_docs2, n_terms2 = n_docs + 40, n_terms + 25                  # new child pages, new words
+        idx.resize(n_docs2, n_terms2)
+        rows += [dict() for _ in range(n_terms2 - n_terms)]
+        changed = rng.choice(n_docs, size=150, replace=False).astype(np.uint32)
+        term_of = np.repeat(np.arange(n_terms, dtype=np.uint32), np.diff(tp.astype(np.int64)))
+        pick = rng.choice(len(pd), size=400, replace=False)
+        del_t, del_d = term_of[pick], pd[pick]
+        del_t = np.concatenate([del_t, del_t[:5]])                      # the same pair twice: counted once
+        del_d = np.concatenate([del_d, del_d[:5]])
+        docs_for_add = np.concatenate([changed, np.arange(n_docs, n_docs2, dtype=np.uint32)])
+        at = rng.integers(0, n_terms2, size=3000).astype(np.uint32)
+        ad = docs_for_add[rng.integers(0, len(docs_for_add), size=3000)]
+        key = (at.astype(np.uint64) << np.uint64(32)) | ad.astype(np.uint64)
+        _, first = np.unique(key, return_index=True)
+        first = rng.permutation(first)
+        at, ad = at[first], ad[first]
+        aw = (rng.random(len(at), dtype=np.float32) + np.float32(0.01)).astype(np.float32)
+        alens = rng.integers(0, 4, size=len(at))
+        app = np.zeros(len(at) + 1, dtype=np.uint64)
+        app[1:] = np.cumsum(alens)
+        apos = rng.integers(0, 400, size=int(app[-1])).astype(np.float32)
+        # model update
+        ch = set(changed.tolist())
+        for row in rows:
+            for d in ch & row.keys():
+                del row[d]
+        for t, d in zip(del_t.tolist(), del_d.tolist()):
+            rows[t].pop(d, None)
+        for j, (t, d, w) in enumerate(zip(at.tolist(), ad.tolist(), aw.tolist())):
+            assert d not in rows[t]
+            rows[t][d] = (np.float32(w), apos[int(app[j]):int(app[j + 1])].tolist())
+        idx.apply_delta(del_docs=changed, del_pairs=(del_t, del_d), add=(at, ad, aw), add_pos=(app, apos))
+        # expected arrays
+        e_tp = np.zeros(n_terms2 + 1, dtype=np.uint64)
+        e_pd, e_w, e_pp, e_pos = [], [], [0], []
+        for t, row in enumerate(rows):
+            for d in sorted(row):
+                e_pd.append(d)
+                e_w.append(row[d][0])
+                e_pos += row[d][1]
+                e_pp.append(len(e_pos))
+            e_tp[t + 1] = len(e_pd)
+        e_pd, e_w = np.array(e_pd, np.uint32), np.array(e_w, np.float32)
+        g_tp, g_pd, g_w = idx.read()
+        assert np.array_equal(g_tp, e_tp) and np.array_equal(g_pd, e_pd) and np.array_equal(g_w, e_w)
+        g_pp, g_pos = idx.read_positions()
+        assert np.array_equal(g_pp, np.array(e_pp, np.uint64)) and np.array_equal(g_pos, np.array(e_pos, np.float32))
+        # magnitudes: the delta's own update of the touched docs == a full pass == float64 sums of float32 squares
+        touched = np.unique(np.concatenate([changed, del_d, ad])).astype(np.uint32)
+        inc = idx.read_magnitudes(touched)
+        sq = (e_w * e_w).astype(np.float32).astype(np.float64)
+        ref = np.sqrt(np.bincount(e_pd, weights=sq, minlength=n_docs2))
+        assert np.array_equal(inc, ref[touched])
+        untouched = np.setdiff1d(np.arange(n_docs, dtype=np.uint32), touched)[:500]
+        assert np.array_equal(idx.read_magnitudes(untouched), mag0[untouched])
+        full = idx.refresh_magnitudes()
+        assert np.array_equal(full, ref)
+        assert np.array_equal(idx.read_magnitudes(touched), ref[touched])
     finally:
         idx.close()
 
