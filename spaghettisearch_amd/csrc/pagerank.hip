@@ -862,13 +862,16 @@ __global__ void k_pr_read(const double* __restrict__ x, const PrCtl* __restrict_
 // ---- topic-sensitive teleport (opt-in): sets -> per-row membership bits of this rank's rows ------------------------
 __global__ void k_pr_memb(const uint64_t* __restrict__ set_ptr, const uint32_t* __restrict__ set_nodes, int k_topics, uint64_t n_nodes,
                           const uint32_t* __restrict__ new_id, uint64_t nd_int, uint32_t sl_nd, uint32_t sl_d, int rank,
-                          uint32_t* __restrict__ memb, uint32_t* __restrict__ err) {
+                          uint32_t* __restrict__ memb, uint32_t* __restrict__ seen, uint32_t* __restrict__ err) {
     const uint64_t total = set_ptr[k_topics];
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         int k = 0;
         while (k + 1 < k_topics && set_ptr[k + 1] <= i) k++;
         const uint32_t v = set_nodes[i];
         if ((uint64_t)v >= n_nodes) { atomicOr(err, 1u); continue; }
+        // |set_k| comes from set_ptr, membership is one bit per node: a node listed twice would get less than its share.
+        // Checked over ALL nodes (not only this rank's rows) so that every rank of a sharded graph takes the same decision.
+        if (atomicOr(&seen[v], 1u << k) & (1u << k)) { atomicOr(err, 2u); continue; }
         const uint64_t iid = new_id[v];
         uint32_t lrow;
         int owner;
@@ -1354,9 +1357,11 @@ int32_t ss_pr_set_teleport(ss_pr* pr, const uint64_t* set_ptr, const uint32_t* s
     }
     const size_t n_local = g->n_local();
     ss::DevBuf<uint64_t> d_ptr;
-    ss::DevBuf<uint32_t> d_nodes, d_err;
+    ss::DevBuf<uint32_t> d_nodes, d_err, d_seen;
     ss::DevBuf<unsigned long long> d_cnt;
     SS_HIP(ctx, d_ptr.alloc(K + 1));
+    SS_HIP(ctx, d_seen.alloc(g->n));
+    SS_HIP(ctx, hipMemsetAsync(d_seen.p, 0, std::max<size_t>(d_seen.bytes(), 4), st));
     SS_HIP(ctx, d_nodes.alloc(total));
     SS_HIP(ctx, d_err.alloc(1));
     SS_HIP(ctx, d_cnt.alloc(MAXK));
@@ -1371,7 +1376,7 @@ int32_t ss_pr_set_teleport(ss_pr* pr, const uint64_t* set_ptr, const uint32_t* s
     if (total)
         hipLaunchKernelGGL(k_pr_memb, dim3(std::min<unsigned>(ss::div_up(total, TPB), 4096u)), dim3(TPB), 0, st, (const uint64_t*)d_ptr.p,
                            (const uint32_t*)d_nodes.p, K, g->n, (const uint32_t*)g->new_id.p, g->nd_int, std::max(g->sl_nd, 1u), std::max(g->sl_d, 1u),
-                           g->rank, pr->memb.p, d_err.p);
+                           g->rank, pr->memb.p, d_seen.p, d_err.p);
     const uint32_t n_zero = (g->cnt_nd - p.pos_nd) + (g->cnt_d - p.pos_d);
     if (n_zero)
         hipLaunchKernelGGL(k_pr_memb_zero_count, dim3(std::min<unsigned>(ss::div_up(n_zero, TPB), 4096u)), dim3(TPB), 0, st,
@@ -1382,9 +1387,10 @@ int32_t ss_pr_set_teleport(ss_pr* pr, const uint64_t* set_ptr, const uint32_t* s
     SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
-    if (h_err) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: a teleport set holds a node id >= n_nodes");
+    if (h_err & 1u) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: a teleport set holds a node id >= n_nodes");
+    if (h_err & 2u) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: a teleport set lists a node twice (the ids of a set must be distinct)");
     double h_nz[MAXK];
-    for (int k = 0; k < MAXK; k++) h_nz[k] = (double)h_cnt[k];      // a node listed twice counts once (one bit per row)
+    for (int k = 0; k < MAXK; k++) h_nz[k] = (double)h_cnt[k];
     SS_HIP(ctx, hipMemcpyAsync(pr->tin.p, h_tin, sizeof(h_tin), hipMemcpyHostToDevice, st));
     SS_HIP(ctx, hipMemcpyAsync(pr->nz_in.p, h_nz, sizeof(h_nz), hipMemcpyHostToDevice, st));
     SS_HIP(ctx, hipStreamSynchronize(st));

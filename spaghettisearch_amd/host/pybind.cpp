@@ -40,11 +40,48 @@ PYBIND11_MODULE(_host, m) {
         for (auto* p : v) out.push_back(p);
         return out;
     };
-    m.def("UpdateTopicSensitivePagerank", [as_dbs](double d, double eps, std::vector<db::MemDB*> forward) {
+    m.def("UpdateTopicSensitivePagerank", [as_dbs](double d, double eps, std::vector<db::MemDB*> forward, bool teleport_sets,
+                                                   std::vector<db::MemDB*> inv) {
         db::Context ctx;
-        auto f = as_dbs(forward);
-        ranking::UpdateTopicSensitivePagerank(ctx, d, eps, f);
-    }, py::arg("dampingFactor"), py::arg("convergenceCriterion"), py::arg("forward"));
+        auto f = as_dbs(forward), i = as_dbs(inv);
+        ranking::TopicSensitive ts;
+        ts.teleport_sets = teleport_sets;
+        ts.inv = &i;
+        ranking::UpdateTopicSensitivePagerank(ctx, d, eps, f, ts);
+    }, py::arg("dampingFactor"), py::arg("convergenceCriterion"), py::arg("forward"), py::arg("teleport_sets") = false,
+       py::arg("inv") = std::vector<db::MemDB*>());
+    m.def("TopicTeleportSets", [as_dbs](std::vector<db::MemDB*> forward, std::vector<db::MemDB*> inv) {
+        db::Context ctx;
+        auto f = as_dbs(forward), i = as_dbs(inv);
+        return ranking::TopicTeleportSets(ctx, f, i);
+    });
+    py::class_<ranking::ResidentPagerank>(m, "ResidentPagerank")
+        .def(py::init<>())
+        .def("Build", [as_dbs](ranking::ResidentPagerank& r, std::vector<db::MemDB*> forward) {
+            db::Context ctx;
+            auto f = as_dbs(forward);
+            r.Build(ctx, f);
+        })
+        .def("ApplyDelta", [as_dbs](ranking::ResidentPagerank& r, std::vector<db::MemDB*> forward, const std::vector<std::string>& parents) {
+            db::Context ctx;
+            auto f = as_dbs(forward);
+            r.ApplyDelta(ctx, f, parents);
+        })
+        .def("Run", [as_dbs](ranking::ResidentPagerank& r, double d, double eps, std::vector<db::MemDB*> forward) {
+            db::Context ctx;
+            auto f = as_dbs(forward);
+            r.Run(ctx, d, eps, f);
+        })
+        .def_readonly("name", &ranking::ResidentPagerank::name);
+    auto page_info = [](const py::dict& d) {
+        retrieval::PageIndexInfo p;
+        p.docHash = d["docHash"].cast<std::string>();
+        if (d.contains("title")) p.title = d["title"].cast<std::map<std::string, std::vector<float>>>();
+        if (d.contains("body")) p.body = d["body"].cast<std::map<std::string, std::vector<float>>>();
+        if (d.contains("anchors")) p.anchors = d["anchors"].cast<std::map<std::string, std::map<std::string, std::vector<float>>>>();
+        if (d.contains("children")) p.children = d["children"].cast<std::vector<std::string>>();
+        return p;
+    };
     m.def("UpdateTermWeights", [as_dbs](db::MemDB* inv, std::vector<db::MemDB*> forw, const std::string& info) {
         db::Context ctx;
         auto f = as_dbs(forw);
@@ -70,11 +107,28 @@ PYBIND11_MODULE(_host, m) {
             di.load(ctx, f, i);
         })
         .def("RetrieveBatch", [](retrieval::DeviceIndex& di, const std::vector<std::string>& queries, int k,
-                                 py::object topic_probs) {
-            if (topic_probs.is_none()) return di.RetrieveBatch(queries, k, nullptr);
+                                 py::object topic_probs, bool live_topic_probs) {
+            if (topic_probs.is_none()) return di.RetrieveBatch(queries, k, nullptr, live_topic_probs);
             auto tp = topic_probs.cast<std::vector<std::map<std::string, double>>>();
-            return di.RetrieveBatch(queries, k, &tp);
-        }, py::arg("queries"), py::arg("k") = 50, py::arg("topic_probs") = py::none())
+            return di.RetrieveBatch(queries, k, &tp, live_topic_probs);
+        }, py::arg("queries"), py::arg("k") = 50, py::arg("topic_probs") = py::none(), py::arg("live_topic_probs") = false)
+        .def("LoadTopics", [as_dbs](retrieval::DeviceIndex& di, std::vector<db::MemDB*> forw, std::vector<db::MemDB*> inv) {
+            db::Context ctx;
+            auto f = as_dbs(forw), i = as_dbs(inv);
+            di.LoadTopics(ctx, f, i);
+        })
+        .def("liveTopicProbs", &retrieval::DeviceIndex::liveTopicProbs)
+        .def("ApplyDelta", [as_dbs, page_info](retrieval::DeviceIndex& di, std::vector<db::MemDB*> forw, std::vector<db::MemDB*> inv,
+                                               const py::dict& before, const py::dict& after, bool update_magnitudes) {
+            db::Context ctx;
+            auto f = as_dbs(forw), i = as_dbs(inv);
+            di.ApplyDelta(ctx, f, i, page_info(before), page_info(after), update_magnitudes);
+        }, py::arg("forw"), py::arg("inv"), py::arg("before"), py::arg("after"), py::arg("update_magnitudes") = true)
+        .def("ReloadPrior", [as_dbs](retrieval::DeviceIndex& di, std::vector<db::MemDB*> forw) {
+            db::Context ctx;
+            auto f = as_dbs(forw);
+            di.ReloadPrior(ctx, f);
+        })
         .def("save_snapshot", &retrieval::DeviceIndex::save_snapshot)
         .def("load_snapshot", &retrieval::DeviceIndex::load_snapshot)
         .def_readonly("categories", &retrieval::DeviceIndex::categories);

@@ -56,59 +56,197 @@ struct DenseIds {
 
 namespace ranking {
 
-inline void UpdateTopicSensitivePagerank(db::Context& ctx, double dampingFactor, double convergenceCriterion,
-                                         std::vector<db::DB*>& forward) {
-    using namespace spaghetti;
-    std::fprintf(stderr, "Ranking with damping factor='%f', convergence_criteria='%f'\n", dampingFactor, convergenceCriterion);
+// OPT-IN, beyond what the reference executes.  The reference advertises topic-sensitive PageRank
+// (README.md:9) but its topics differ only by the start value 1/numPages (pagerank.go:54-63,104); the topic data it does
+// store are the ODP keyword vectors: forw[5][category] = {numPages, wordCount}, inv[2][wordHash] = map[category]frequency
+// (crawler/ODP-scraper.go:97-139).  With `teleport_sets` a crawled page joins the teleport set of the category whose
+// keywords it holds most of, by the estimate computeTopicProbs uses for a query (tf / wordCount, main_retrieve.go:143-145):
+//     mass(page, c) = sum over the words w of the page (inv[0] or inv[1] row of w holds the page) of inv[2][w][c] / wordCount(c)
+// topic(page) = argmax_c mass (ties: the first category in key order); a page without keyword hits joins no set, and a
+// category without pages keeps the reference's uniform teleport (ss_pr_set_teleport).  Default: off = reference behaviour.
+struct TopicSensitive {
+    bool teleport_sets = false;
+    std::vector<db::DB*>* inv = nullptr;      // needed with teleport_sets: inv[0], inv[1], inv[2]
+};
+
+// category -> the doc hashes of its teleport set (sorted), by the rule above
+inline std::map<std::string, std::vector<std::string>> TopicTeleportSets(db::Context& ctx, std::vector<db::DB*>& forward,
+                                                                         std::vector<db::DB*>& inv) {
+    std::vector<std::string> cat;
+    std::vector<double> word_count;
+    for (auto& kv : forward[5]->Iterate(ctx)) {
+        auto md = jsonmini::parse_map_f64(kv.second);
+        cat.push_back(kv.first);
+        word_count.push_back(md.count("wordCount") ? md["wordCount"] : 0.0);
+    }
+    const size_t K = cat.size();
+    std::map<std::string, std::vector<double>> mass;                      // doc -> [K]
+    for (auto& kw : inv[2]->Iterate(ctx)) {
+        const std::map<std::string, double> freq = jsonmini::parse_map_f64(kw.second);
+        std::vector<double> share(K, 0.0);
+        bool any = false;
+        for (size_t c = 0; c < K; c++) {
+            auto it = freq.find(cat[c]);
+            if (it != freq.end() && word_count[c] > 0.0) { share[c] = it->second / word_count[c]; any = true; }
+        }
+        if (!any) continue;
+        for (int table = 0; table < 2; table++) {
+            if (!inv[table]->Has(ctx, kw.first)) continue;
+            for (auto& post : jsonmini::parse_map_f32list(inv[table]->Get(ctx, kw.first))) {
+                auto& m = mass[post.first];
+                if (m.empty()) m.assign(K, 0.0);
+                for (size_t c = 0; c < K; c++) m[c] += share[c];
+            }
+        }
+    }
+    std::map<std::string, std::vector<std::string>> sets;
+    for (auto& c : cat) sets[c];
+    for (auto& dm : mass) {
+        size_t best = 0;
+        for (size_t c = 1; c < K; c++)
+            if (dm.second[c] > dm.second[best]) best = c;
+        if (dm.second[best] > 0.0) sets[cat[best]].push_back(dm.first);   // std::map iteration: doc hashes arrive sorted
+    }
+    return sets;
+}
+
+// The link graph kept on the device between crawls: Build flattens forw[2] once, ApplyDelta patches the
+// resident adjacency with the re-crawled parents' new rows (ss_graph_apply_delta: no re-flatten, no re-upload), Run is the
+// compute + write-back half of UpdateTopicSensitivePagerank.  New pages get ids at the end, so ids are stable across deltas.
+class ResidentPagerank {
+public:
+    std::vector<std::string> name;
+    std::unordered_map<std::string, uint32_t> id;
+    ss_graph* g = nullptr;
+
+    ResidentPagerank() = default;
+    ResidentPagerank(const ResidentPagerank&) = delete;
+    ResidentPagerank& operator=(const ResidentPagerank&) = delete;
+    ~ResidentPagerank() { if (g) ss_graph_destroy(g); }
+
     // pagerank.go:17-44 — node set = parents U children (frontier pages are nodes without children)
-    const std::vector<db::KV> nodes = forward[2]->Iterate(ctx);
-    std::vector<std::vector<std::string>> children(nodes.size());
-    std::vector<std::string> all;
-    for (size_t i = 0; i < nodes.size(); i++) {
-        children[i] = jsonmini::parse_string_list(nodes[i].second);
-        all.push_back(nodes[i].first);
-        for (auto& c : children[i]) all.push_back(c);
-    }
-    DenseIds ids;
-    ids.build(all.begin(), all.end());
-    const size_t n = ids.name.size();
-    if (n == 0) return;
-    std::vector<uint64_t> out_ptr(n + 1, 0);
-    for (size_t i = 0; i < nodes.size(); i++) out_ptr[ids.id[nodes[i].first] + 1] = children[i].size();
-    for (size_t v = 0; v < n; v++) out_ptr[v + 1] += out_ptr[v];
-    std::vector<uint32_t> out_dst(out_ptr[n]);
-    for (size_t i = 0; i < nodes.size(); i++) {
-        uint64_t base = out_ptr[ids.id[nodes[i].first]];
-        for (auto& c : children[i]) out_dst[base++] = ids.id[c];
-    }
-    // pagerank.go:46-63 — one power iteration per category, differing by numPages only
-    const std::vector<db::KV> cats = forward[5]->Iterate(ctx);
-    std::vector<std::string> cat_name;
-    std::vector<int32_t> n_topic;
-    for (auto& kv : cats) {
-        auto val = jsonmini::parse_map_f64(kv.second);
-        std::fprintf(stderr, "number of webnodes in %s is %d\n", kv.first.c_str(), (int)val["numPages"]);
-        cat_name.push_back(kv.first);
-        n_topic.push_back((int32_t)(int)val["numPages"]);
-    }
-    const int K = (int)cat_name.size();
-    std::vector<double> rank((size_t)K * n);
-    if (K > 0) {
-        ss_graph* g = nullptr;
+    void Build(db::Context& ctx, std::vector<db::DB*>& forward) {
+        using namespace spaghetti;
+        if (g) { ss_graph_destroy(g); g = nullptr; }
+        const std::vector<db::KV> nodes = forward[2]->Iterate(ctx);
+        std::vector<std::vector<std::string>> children(nodes.size());
+        std::vector<std::string> all;
+        for (size_t i = 0; i < nodes.size(); i++) {
+            children[i] = jsonmini::parse_string_list(nodes[i].second);
+            all.push_back(nodes[i].first);
+            for (auto& c : children[i]) all.push_back(c);
+        }
+        DenseIds ids;
+        ids.build(all.begin(), all.end());
+        name = std::move(ids.name);
+        id = std::move(ids.id);
+        const size_t n = name.size();
+        if (n == 0) return;
+        std::vector<uint64_t> out_ptr(n + 1, 0);
+        for (size_t i = 0; i < nodes.size(); i++) out_ptr[id[nodes[i].first] + 1] = children[i].size();
+        for (size_t v = 0; v < n; v++) out_ptr[v + 1] += out_ptr[v];
+        std::vector<uint32_t> out_dst(out_ptr[n]);
+        for (size_t i = 0; i < nodes.size(); i++) {
+            uint64_t base = out_ptr[id[nodes[i].first]];
+            for (auto& c : children[i]) out_dst[base++] = id[c];
+        }
         check(ss_graph_create(default_ctx(), n, out_dst.size(), out_ptr.data(), out_dst.data(), 0, 1, &g), "ss_graph_create");
-        std::vector<int32_t> iters(K);
-        const int32_t rc = ss_pagerank_run(g, dampingFactor, convergenceCriterion, 0, K, n_topic.data(), rank.data(), iters.data());
-        ss_graph_destroy(g);
-        check(rc, "ss_pagerank_run");
     }
-    // pagerank.go:65-82 — forw[3][doc] = map[category]rank
-    auto bw = forward[3]->BatchWrite_init(ctx);
-    for (size_t v = 0; v < n; v++) {
-        std::map<std::string, double> PR;
-        for (int k = 0; k < K; k++) PR[cat_name[k]] = rank[(size_t)k * n + v];
-        bw->BatchSet(ctx, ids.name[v], jsonmini::dump(PR));
+
+    // The forw[2] rows of `parents` were rewritten (indexer.go:301-304 after a re-crawl): patch the resident graph.
+    void ApplyDelta(db::Context& ctx, std::vector<db::DB*>& forward, const std::vector<std::string>& parents) {
+        using namespace spaghetti;
+        if (!g) { Build(ctx, forward); return; }
+        auto node = [&](const std::string& h) {
+            auto it = id.find(h);
+            if (it != id.end()) return it->second;
+            const uint32_t v = (uint32_t)name.size();
+            name.push_back(h);
+            id[h] = v;
+            return v;
+        };
+        std::vector<std::string> uniq(parents);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        const size_t n_before = name.size();
+        std::vector<uint32_t> changed, kids;
+        std::vector<uint64_t> ptr{0};
+        for (auto& p : uniq) {
+            changed.push_back(node(p));
+            if (forward[2]->Has(ctx, p))
+                for (auto& c : jsonmini::parse_string_list(forward[2]->Get(ctx, p))) kids.push_back(node(c));
+            ptr.push_back(kids.size());
+        }
+        const int32_t rc = ss_graph_apply_delta(g, name.size(), changed.size(), changed.data(), ptr.data(), kids.data());
+        if (rc != SS_OK) {                         // the graph is unchanged: so are the ids
+            for (size_t v = n_before; v < name.size(); v++) id.erase(name[v]);
+            name.resize(n_before);
+        }
+        check(rc, "ss_graph_apply_delta");
     }
-    bw->Flush(ctx);
+
+    // pagerank.go:46-82 — one power iteration per category (all of them in one K-wide run), forw[3][doc] = map[category]rank
+    void Run(db::Context& ctx, double dampingFactor, double convergenceCriterion, std::vector<db::DB*>& forward,
+             const TopicSensitive& ts = TopicSensitive()) {
+        using namespace spaghetti;
+        const size_t n = name.size();
+        if (n == 0) return;
+        const std::vector<db::KV> cats = forward[5]->Iterate(ctx);
+        std::vector<std::string> cat_name;
+        std::vector<int32_t> n_topic;
+        for (auto& kv : cats) {
+            auto val = jsonmini::parse_map_f64(kv.second);
+            std::fprintf(stderr, "number of webnodes in %s is %d\n", kv.first.c_str(), (int)val["numPages"]);
+            cat_name.push_back(kv.first);
+            n_topic.push_back((int32_t)(int)val["numPages"]);
+        }
+        const int K = (int)cat_name.size();
+        std::vector<double> rank((size_t)K * n);
+        if (K > 0 && !ts.teleport_sets) {
+            std::vector<int32_t> iters(K);
+            check(ss_pagerank_run(g, dampingFactor, convergenceCriterion, 0, K, n_topic.data(), rank.data(), iters.data()), "ss_pagerank_run");
+        } else if (K > 0) {
+            if (!ts.inv) throw std::runtime_error("UpdateTopicSensitivePagerank: teleport_sets needs the inverted tables");
+            const auto sets = TopicTeleportSets(ctx, forward, *ts.inv);
+            std::vector<uint64_t> set_ptr{0};
+            std::vector<uint32_t> set_nodes;
+            for (auto& c : cat_name) {
+                for (auto& d : sets.at(c)) {
+                    auto it = id.find(d);
+                    if (it != id.end()) set_nodes.push_back(it->second);   // a page outside the link graph has no rank to receive
+                }
+                set_ptr.push_back(set_nodes.size());
+            }
+            ss_pr* pr = nullptr;
+            check(ss_pr_create(g, dampingFactor, convergenceCriterion, 0, K, n_topic.data(), &pr), "ss_pr_create");
+            int32_t rc = ss_pr_set_teleport(pr, set_ptr.data(), set_nodes.data());
+            if (rc == SS_OK) rc = ss_pr_begin(pr);
+            int32_t n_active = K, sweeps = 0;
+            std::vector<int32_t> iters(K);
+            while (rc == SS_OK && n_active > 0) {
+                rc = ss_pr_step(pr, 8);                          // the stop rule runs on the device: finished topics stand still
+                if (rc == SS_OK) rc = ss_pr_status(pr, iters.data(), &n_active, &sweeps, nullptr, nullptr);
+            }
+            if (rc == SS_OK) rc = ss_pr_read(pr, rank.data());
+            ss_pr_destroy(pr);
+            check(rc, "topic-sensitive PageRank");
+        }
+        auto bw = forward[3]->BatchWrite_init(ctx);
+        for (size_t v = 0; v < n; v++) {
+            std::map<std::string, double> PR;
+            for (int k = 0; k < K; k++) PR[cat_name[k]] = rank[(size_t)k * n + v];
+            bw->BatchSet(ctx, name[v], jsonmini::dump(PR));
+        }
+        bw->Flush(ctx);
+    }
+};
+
+inline void UpdateTopicSensitivePagerank(db::Context& ctx, double dampingFactor, double convergenceCriterion,
+                                         std::vector<db::DB*>& forward, const TopicSensitive& ts = TopicSensitive()) {
+    std::fprintf(stderr, "Ranking with damping factor='%f', convergence_criteria='%f'\n", dampingFactor, convergenceCriterion);
+    ResidentPagerank pr;
+    pr.Build(ctx, forward);
+    pr.Run(ctx, dampingFactor, convergenceCriterion, forward, ts);
 }
 
 // term_weighting.go:59-123

@@ -169,6 +169,16 @@ struct FlatCorpus {
     }
 };
 
+// What the indexer writes for one page (indexer/indexer.go:23-348): its own postings in inv[0] / inv[1] (setInverted
+// :350-408, listPos = [normTF, positions...]), the anchor words it puts into the TITLE rows of its children (:236-290,
+// positions -100) and its forw[2] row.  `before` = what checkAndUpdate (:420-641) removes, `after` = what the re-index adds.
+struct PageIndexInfo {
+    std::string docHash;
+    std::map<std::string, std::vector<float>> title, body;                           // wordHash -> listPos
+    std::map<std::string, std::map<std::string, std::vector<float>>> anchors;        // childHash -> wordHash -> listPos
+    std::vector<std::string> children;                                               // forw[2][docHash]
+};
+
 class DeviceIndex {
 public:
     spaghetti::DenseIds docs, terms;
@@ -178,6 +188,8 @@ public:
     ss_scorer* scorer = nullptr;
     std::vector<std::string> categories;
     std::function<std::vector<std::string>(const std::string&)> laundry = defaultLaundry;
+    bool mags_resident = false;      // squared magnitudes resident on the device: deltas keep them up to date
+    bool flat_stale = false;         // deltas were applied since `flat` was filled
 
     ~DeviceIndex() {
         if (scorer) ss_scorer_destroy(scorer);
@@ -257,6 +269,10 @@ public:
     // flat arrays -> device state (ss_index x2, positions, magnitudes, scorer, prior)
     void upload() {
         using namespace spaghetti;
+        if (scorer) { ss_scorer_destroy(scorer); scorer = nullptr; }
+        if (title) { ss_index_destroy(title); title = nullptr; }
+        if (body) { ss_index_destroy(body); body = nullptr; }
+        mags_resident = flat_stale = false;
         const size_t n = flat.doc_names.size(), T = flat.term_names.size();
         check(ss_index_create(default_ctx(), n, T, flat.title.term_ptr.data(), flat.title.post_doc.data(), flat.title.post_w.data(), &title), "ss_index_create(title)");
         check(ss_index_create(default_ctx(), n, T, flat.body.term_ptr.data(), flat.body.post_doc.data(), flat.body.post_w.data(), &body), "ss_index_create(body)");
@@ -272,7 +288,7 @@ public:
 
     // On-disk snapshot of the flattened tables with the md5-hex <-> dense-id maps: written once after
     // the offline rank update, read at every server start instead of decoding the JSON tables.
-    void save_snapshot(const std::string& path) const { flat.save(path); }
+    void save_snapshot(const std::string& path) { sync_flat(); flat.save(path); }
     void load_snapshot(const std::string& path) {
         flat.load(path);
         docs.name = flat.doc_names;
@@ -284,13 +300,245 @@ public:
         upload();
     }
 
+    // ---- incremental re-index of one page on the resident tables --------------------------------------
+    // The table side repeats the reference's writes: checkAndUpdate removes the page's old title words from inv[0]
+    // (indexer.go:455-492), its old body words from inv[1] (:494-531) and the postings its anchor words made in its old
+    // children's title rows (:533-616; the child's WHOLE posting of that word goes, also what other parents put there);
+    // the re-index upserts the new postings (`value[docHash] = ...`, :395-403 and :277-285) and rewrites forw[2] (:301-304).
+    // [The reference collects these writes in batch writers fed from reads of the pre-state, so of two removals that hit
+    // the same row only the last (in goroutine order) survives the flush; here every removal is applied.]
+    // The device side is ONE delta per table: pairs to delete, postings to add (an upsert deletes its pair first), merged
+    // into the resident CSR by ss_index_apply_delta_pos after growing the doc / term space for new children and new words.
+    // Weights are stored as given (listPos[0]).  update_magnitudes: the touched docs' magnitudes follow the delta on the
+    // device (O(delta) once the squared magnitudes are resident) and their forw[4] rows are rewritten; false leaves
+    // forw[4] and the device magnitudes as they were, which is what the reference serves until the next UpdateTermWeights.
+    void ApplyDelta(db::Context& ctx, std::vector<db::DB*>& forw, std::vector<db::DB*>& inv, const PageIndexInfo& before,
+                    const PageIndexInfo& after, bool update_magnitudes = true) {
+        using namespace spaghetti;
+        if (!title || !body) throw std::runtime_error("ApplyDelta: the index is not loaded");
+        if (before.docHash != after.docHash) throw std::runtime_error("ApplyDelta: before and after describe different pages");
+        struct Post { std::string term, doc; std::vector<float> listPos; };
+        std::vector<std::pair<std::string, std::string>> del[2];          // (wordHash, docHash) per table
+        std::vector<Post> add[2];
+        for (auto& kv : before.title) del[0].emplace_back(kv.first, before.docHash);
+        for (auto& kv : before.body) del[1].emplace_back(kv.first, before.docHash);
+        for (auto& ch : before.anchors)
+            for (auto& kv : ch.second) del[0].emplace_back(kv.first, ch.first);
+        for (auto& kv : after.title) add[0].push_back({kv.first, after.docHash, kv.second});
+        for (auto& kv : after.body) add[1].push_back({kv.first, after.docHash, kv.second});
+        for (auto& ch : after.anchors)
+            for (auto& kv : ch.second) add[0].push_back({kv.first, ch.first, kv.second});
+        for (int t = 0; t < 2; t++)
+            for (auto& a : add[t])
+                if (a.listPos.empty()) throw std::runtime_error("ApplyDelta: posting without a weight entry");
+        // --- tables -----------------------------------------------------------------------------------------------------
+        for (int t = 0; t < 2; t++) {
+            std::map<std::string, std::map<std::string, std::vector<float>>> rows;   // the rows this delta touches
+            auto row_of = [&](const std::string& w) -> std::map<std::string, std::vector<float>>& {
+                auto it = rows.find(w);
+                if (it != rows.end()) return it->second;
+                auto& r = rows[w];
+                if (inv[t]->Has(ctx, w)) r = jsonmini::parse_map_f32list(inv[t]->Get(ctx, w));
+                return r;
+            };
+            for (auto& d : del[t]) row_of(d.first).erase(d.second);
+            for (auto& a : add[t]) row_of(a.term)[a.doc] = a.listPos;
+            auto bw = inv[t]->BatchWrite_init(ctx);
+            for (auto& r : rows) {
+                if (r.second.empty()) { if (inv[t]->Has(ctx, r.first)) inv[t]->Delete(ctx, r.first); }   // "delete this row" (:484-489)
+                else bw->BatchSet(ctx, r.first, jsonmini::dump(r.second));
+            }
+            bw->Flush(ctx);
+        }
+        forw[2]->Set(ctx, after.docHash, jsonmini::dump(after.children));
+        // --- device -----------------------------------------------------------------------------------------------------
+        auto grow = [](DenseIds& ids, const std::string& h) {
+            auto it = ids.id.find(h);
+            if (it != ids.id.end()) return it->second;
+            const uint32_t v = (uint32_t)ids.name.size();
+            ids.name.push_back(h);
+            ids.id[h] = v;
+            return v;
+        };
+        const size_t n_before = docs.name.size(), t_before = terms.name.size();
+        for (int t = 0; t < 2; t++)
+            for (auto& a : add[t]) { grow(docs, a.doc); grow(terms, a.term); }
+        for (auto& c : after.children) grow(docs, c);
+        const size_t n = docs.name.size(), T = terms.name.size();
+        if (scorer) { ss_scorer_destroy(scorer); scorer = nullptr; }      // scorers on a table go before its delta
+        if (n != n_before || T != t_before) {
+            check(ss_index_resize(title, n, T), "ss_index_resize(title)");
+            check(ss_index_resize(body, n, T), "ss_index_resize(body)");
+        }
+        if (update_magnitudes && !mags_resident) {                        // once: squared magnitudes of the stored weights
+            check(ss_index_refresh_magnitudes(title, nullptr), "ss_index_refresh_magnitudes(title)");
+            check(ss_index_refresh_magnitudes(body, nullptr), "ss_index_refresh_magnitudes(body)");
+            mags_resident = true;
+        }
+        std::vector<uint32_t> touched;
+        ss_index* table[2] = {title, body};
+        for (int t = 0; t < 2; t++) {
+            std::vector<uint32_t> del_term, del_doc, add_term, add_doc;
+            std::vector<float> add_w, add_pos;
+            std::vector<uint64_t> add_pos_ptr{0};
+            std::map<std::pair<uint32_t, uint32_t>, bool> seen;
+            auto del_pair = [&](const std::string& w, const std::string& d) {
+                auto ti = terms.id.find(w);
+                auto di = docs.id.find(d);
+                if (ti == terms.id.end() || di == docs.id.end()) return;  // never indexed: nothing to delete
+                if (seen.emplace(std::make_pair(ti->second, di->second), true).second) {
+                    del_term.push_back(ti->second);
+                    del_doc.push_back(di->second);
+                    touched.push_back(di->second);
+                }
+            };
+            for (auto& d : del[t]) del_pair(d.first, d.second);
+            for (auto& a : add[t]) del_pair(a.term, a.doc);               // upsert
+            std::map<std::pair<uint32_t, uint32_t>, const Post*> last;    // the last write of a (word, doc) wins, as in a map
+            for (auto& a : add[t]) last[{terms.id[a.term], docs.id[a.doc]}] = &a;
+            for (auto& kv : last) {
+                add_term.push_back(kv.first.first);
+                add_doc.push_back(kv.first.second);
+                add_w.push_back(kv.second->listPos[0]);
+                add_pos.insert(add_pos.end(), kv.second->listPos.begin() + 1, kv.second->listPos.end());
+                add_pos_ptr.push_back(add_pos.size());
+                touched.push_back(kv.first.second);
+            }
+            check(ss_index_apply_delta_pos(table[t], 0, nullptr, del_term.size(), del_term.data(), del_doc.data(), add_term.size(),
+                                           add_term.data(), add_doc.data(), add_w.data(), add_pos_ptr.data(), add_pos.data()),
+                  t == 0 ? "ss_index_apply_delta_pos(title)" : "ss_index_apply_delta_pos(body)");
+        }
+        std::sort(touched.begin(), touched.end());
+        touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+        if (update_magnitudes && !touched.empty()) {
+            std::vector<double> mt(touched.size()), mb(touched.size());
+            check(ss_index_read_magnitudes(title, touched.size(), touched.data(), mt.data()), "ss_index_read_magnitudes(title)");
+            check(ss_index_read_magnitudes(body, touched.size(), touched.data(), mb.data()), "ss_index_read_magnitudes(body)");
+            auto bw = forw[4]->BatchWrite_init(ctx);
+            for (size_t i = 0; i < touched.size(); i++) {
+                const std::string& d = docs.name[touched[i]];
+                std::map<std::string, double> row;
+                if (forw[4]->Has(ctx, d)) row = jsonmini::parse_map_f64(forw[4]->Get(ctx, d));
+                row["title"] = mt[i];
+                row["body"] = mb[i];
+                bw->BatchSet(ctx, d, jsonmini::dump(row));
+            }
+            bw->Flush(ctx);
+        }
+        // the PageRank table follows the doc space: new docs hold 0 until the next PageRank run (ReloadPrior)
+        const size_t K = categories.size();
+        if (n != n_before && K) {
+            std::vector<double> grown(K * n, 0.0);
+            for (size_t k = 0; k < K; k++) std::copy(flat.prior.begin() + k * n_before, flat.prior.begin() + (k + 1) * n_before, grown.begin() + k * n);
+            flat.prior.swap(grown);
+        }
+        flat_stale = true;
+        check(ss_scorer_create(default_ctx(), title, body, &scorer), "ss_scorer_create");
+        if (K > 0 && K <= SS_MAX_TOPICS) check(ss_scorer_set_prior(scorer, (int32_t)K, flat.prior.data()), "ss_scorer_set_prior");
+    }
+
+    // forw[3] was rewritten (UpdateTopicSensitivePagerank / ResidentPagerank::Run): refresh the scorer's PageRank table.
+    void ReloadPrior(db::Context& ctx, std::vector<db::DB*>& forw) {
+        using namespace spaghetti;
+        const std::vector<db::KV> ranks = forw[3]->Iterate(ctx);
+        std::vector<std::string> cat;
+        for (auto& kv : ranks) for (auto& c : jsonmini::parse_map_f64(kv.second)) cat.push_back(c.first);
+        std::sort(cat.begin(), cat.end());
+        cat.erase(std::unique(cat.begin(), cat.end()), cat.end());
+        const size_t K = cat.size(), n = docs.name.size();
+        flat.categories = categories = cat;
+        flat.prior.assign(K * n, 0.0);
+        for (auto& kv : ranks) {
+            auto it = docs.id.find(kv.first);
+            if (it == docs.id.end()) continue;                 // a node that is in no table yet: cannot be retrieved either
+            for (auto& c : jsonmini::parse_map_f64(kv.second))
+                flat.prior[(std::lower_bound(cat.begin(), cat.end(), c.first) - cat.begin()) * n + it->second] = c.second;
+        }
+        if (scorer) check(ss_scorer_set_prior(scorer, K <= SS_MAX_TOPICS ? (int32_t)K : 0, flat.prior.data()), "ss_scorer_set_prior");
+    }
+
+    // after deltas the flattened host copy is read back from the device (only save_snapshot needs it)
+    void sync_flat() {
+        using namespace spaghetti;
+        if (!flat_stale) return;
+        const size_t n = docs.name.size();
+        flat.doc_names = docs.name;
+        flat.term_names = terms.name;
+        ss_index* table[2] = {title, body};
+        FlatTable* ft[2] = {&flat.title, &flat.body};
+        for (int t = 0; t < 2; t++) {
+            uint64_t nd = 0, nt = 0, np = 0;
+            check(ss_index_get_info(table[t], &nd, &nt, &np), "ss_index_get_info");
+            ft[t]->term_ptr.resize(nt + 1);
+            ft[t]->post_doc.resize(np);
+            ft[t]->post_w.resize(np);
+            check(ss_index_read(table[t], ft[t]->term_ptr.data(), ft[t]->post_doc.data(), ft[t]->post_w.data()), "ss_index_read");
+            ft[t]->pos_ptr.resize(np + 1);
+            check(ss_index_read_positions(table[t], ft[t]->pos_ptr.data(), nullptr), "ss_index_read_positions");
+            ft[t]->pos.resize(ft[t]->pos_ptr[np]);
+            check(ss_index_read_positions(table[t], nullptr, ft[t]->pos.data()), "ss_index_read_positions");
+            std::vector<uint32_t> all(n);
+            for (size_t i = 0; i < n; i++) all[i] = (uint32_t)i;
+            ft[t]->mag.resize(n);
+            check(ss_index_read_magnitudes(table[t], n, all.data(), ft[t]->mag.data()), "ss_index_read_magnitudes");
+        }
+        flat_stale = false;
+    }
+
+    // OPT-IN: the ODP keyword vectors for computeTopicProbs at query time — the call the reference has
+    // commented out (main_retrieve.go:41-43,87-88).  Kept as hash maps in host memory: a query has a handful of words.
+    std::unordered_map<std::string, std::vector<std::pair<uint32_t, double>>> keyword_topics;   // wordHash -> (index into topic_names, frequency)
+    std::vector<std::string> topic_names;                                                       // forw[5] keys
+    std::vector<double> topic_word_count;
+    void LoadTopics(db::Context& ctx, std::vector<db::DB*>& forw, std::vector<db::DB*>& inv) {
+        topic_names.clear();
+        topic_word_count.clear();
+        keyword_topics.clear();
+        for (auto& kv : forw[5]->Iterate(ctx)) {
+            auto md = jsonmini::parse_map_f64(kv.second);
+            topic_names.push_back(kv.first);
+            topic_word_count.push_back(md.count("wordCount") ? md["wordCount"] : 0.0);
+        }
+        for (auto& kv : inv[2]->Iterate(ctx)) {
+            auto& v = keyword_topics[kv.first];
+            for (auto& tf : jsonmini::parse_map_f64(kv.second)) {
+                auto it = std::lower_bound(topic_names.begin(), topic_names.end(), tf.first);
+                if (it != topic_names.end() && *it == tf.first) v.emplace_back((uint32_t)(it - topic_names.begin()), tf.second);
+            }
+        }
+    }
+    // computeTopicProbs (main_retrieve.go:106-159) with the product started at 1 (as_written = false above), on the
+    // resident keyword vectors.  A query word outside inv[2] carries no topic information and is skipped — the reference
+    // would panic on it (:120-121), which no serving path can afford.
+    std::map<std::string, double> liveTopicProbs(const std::vector<std::string>& queryTokenised) const {
+        const size_t K = topic_names.size();
+        std::vector<double> probs(K, 1.0);
+        std::vector<char> seen(K, 0);
+        for (auto& tok : queryTokenised) {
+            auto it = keyword_topics.find(tok);
+            if (it == keyword_topics.end()) continue;
+            for (auto& cf : it->second) { probs[cf.first] *= cf.second / topic_word_count[cf.first]; seen[cf.first] = 1; }   // :143-145
+        }
+        std::map<std::string, double> out;
+        for (size_t c = 0; c < K; c++) out[topic_names[c]] = seen[c] ? probs[c] / (double)K : 0.0;                            // :148,:150
+        return out;
+    }
+
     // A batch of queries in one library call (additive API).  topicProbs: per query
     // category -> probability, or empty (nil map in the shipped reference, main_retrieve.go:88: sqd = 0).
+    // live_topic_probs (opt-in, default off = the reference's nil map): every query's probabilities come from
+    // liveTopicProbs over its non-phrase words (the argument of the commented-out call, main_retrieve.go:43).
     std::vector<std::vector<Rank_combined>> RetrieveBatch(const std::vector<std::string>& queries, int k = 50,
-                                                          const std::vector<std::map<std::string, double>>* topicProbs = nullptr) {
+                                                          const std::vector<std::map<std::string, double>>* topicProbs = nullptr,
+                                                          bool live_topic_probs = false) {
         using namespace spaghetti;
         std::vector<uint32_t> q_ptr{0}, q_terms, p_ptr{0}, p_terms;
         std::vector<int32_t> q_len;
+        std::vector<std::map<std::string, double>> live;
+        if (live_topic_probs) {
+            if (topicProbs) throw std::runtime_error("RetrieveBatch: explicit and live topic probabilities are exclusive");
+            if (topic_names.empty()) throw std::runtime_error("RetrieveBatch: live topic probabilities need LoadTopics");
+        }
         for (std::string query : queries) {
             // main_retrieve.go:17-36
             const std::vector<std::string> phrases = getPhrase(query);
@@ -301,10 +549,13 @@ public:
             std::string joined;
             for (auto& ph : phrases) joined += ph + " ";
             const std::vector<std::string> queryTokenised = laundry(query), phraseTokenised = laundry(joined);
+            std::vector<std::string> hashed;
             for (auto& tok : queryTokenised) {
-                auto it = terms.id.find(md5::hex(tok));
+                hashed.push_back(md5::hex(tok));
+                auto it = terms.id.find(hashed.back());
                 q_terms.push_back(it == terms.id.end() ? SS_UNKNOWN_TERM : it->second);   // ErrKeyNotFound tolerated (:193,:218)
             }
+            if (live_topic_probs) live.push_back(liveTopicProbs(hashed));
             q_ptr.push_back((uint32_t)q_terms.size());
             // all quoted phrases form ONE phrase (main_retrieve.go:26), matched on the device (retrieval/phrase.go)
             for (auto& tok : phraseTokenised) {
@@ -317,6 +568,7 @@ public:
         const int nq = (int)queries.size();
         std::vector<double> probs;
         const size_t K = categories.size();
+        if (live_topic_probs) topicProbs = &live;
         if (topicProbs && K) {
             probs.assign((size_t)nq * K, 0.0);
             for (int q = 0; q < nq; q++)

@@ -290,3 +290,199 @@ def test_concurrent_requests_are_batched(host, corpus):
     assert batcher.batches < len(queries) and batcher.largest_batch > 1
     one = batcher.Retrieve(queries[0])                       # a lone caller is served after the window
     assert [(r.DocHash, r.FinalRank) for r in one] == [(r.DocHash, r.FinalRank) for r in want[0]]
+
+
+def _retrieve_key(res):
+    """sort.Slice on FinalRank is unstable in the reference (main_retrieve.go:96) and dense ids differ between a patched
+    and a freshly loaded index: compare up to the order of equal FinalRanks."""
+    return sorted((-r.FinalRank, r.DocHash, r.TitleRank, r.BodyRank, r.PageRank) for r in res)
+
+
+def test_recrawl_one_page_apply_delta(host, oracle, corpus):
+    """SURVEY.md §8f-4 end to end: a page changed since the last crawl (indexer.go:420-641 checkAndUpdate, then the re-index
+    :23-348).  The tables get the reference's writes, the resident device tables ONE delta each, the resident link graph
+    its changed row — and Retrieve answers like an index loaded from the updated tables, and like the oracle on them."""
+    forw, inv = _weighted_tables(host, corpus)
+    doc, word = corpus["doc"], corpus["word"]
+    di = host.DeviceIndex()
+    di.load(forw, inv)
+    pr = host.ResidentPagerank()
+    pr.Build(forw)
+    page = doc[17]
+    # what the indexer holds of the page as crawled before: its title / body words and the anchor words of its links
+    before = {"docHash": page,
+              "title": {t: row[page] for t, row in corpus["title"].items() if page in row},
+              "body": {t: row[page] for t, row in corpus["body"].items() if page in row},
+              "children": corpus["children"][page], "anchors": {}}
+    kids_old = corpus["children"][page]
+    assert kids_old and before["body"]
+    # anchor words this page put into an old child's title row: pick postings that exist (the reference panics on a missing row)
+    for c in kids_old[:2]:
+        ws = [t for t, row in corpus["title"].items() if c in row][:2]
+        if ws:
+            before["anchors"][c] = {t: json.loads(inv[0].get(t))[c] for t in ws}
+    # the page as crawled now: other words (one brand new), other links (one to a page never seen), new anchor texts
+    new_word, new_child = h("brandnewword"), h("http://site/never-seen-before")
+    kept_child = kids_old[0]
+    after = {"docHash": page,
+             "title": {h(word[3]): [1.0, 0.0], h(word[17]): [0.5, 1.0, -100.0]},
+             "body": {h(word[3]): [0.25, 4.0, 9.0], h(word[40]): [1.0, 0.0, 1.0, 2.0, 7.0], new_word: [0.5, 3.0, 5.0]},
+             "children": [kept_child, doc[5], new_child],
+             "anchors": {kept_child: {h(word[9]): [1.0, -100.0]},
+                         new_child: {new_word: [1.0, -100.0, -100.0], h(word[3]): [0.5, -100.0]}}}
+    di.ApplyDelta(forw, inv, before, after)
+    # --- the tables hold what the reference's writes leave -----------------------------------------------------------------
+    for t, lp in before["title"].items():
+        row = json.loads(inv[0].get(t)) if t in inv[0].keys() else {}
+        assert (page in row) == (t in after["title"])
+    for t in before["body"]:
+        row = json.loads(inv[1].get(t)) if t in inv[1].keys() else {}
+        assert (page in row) == (t in after["body"])
+    for c, ws in before["anchors"].items():
+        for t in ws:
+            row = json.loads(inv[0].get(t)) if t in inv[0].keys() else {}
+            assert (c in row) == (t in after["anchors"].get(c, {}))
+    assert json.loads(inv[1].get(new_word)) == {page: [0.5, 3.0, 5.0]}
+    assert json.loads(inv[0].get(new_word)) == {new_child: [1.0, -100.0, -100.0]}
+    assert json.loads(forw[2].get(page)) == after["children"]
+    # --- magnitudes of the touched docs: forw[4] rows rewritten from the device's O(delta) update ---------------------------
+    for d in [page, new_child, kept_child] + list(before["anchors"]):
+        row = json.loads(forw[4].get(d))
+        for field, t in (("title", inv[0]), ("body", inv[1])):
+            sq = 0.0
+            for term in t.keys():
+                lp = json.loads(t.get(term)).get(d)
+                if lp is not None:
+                    sq += float(np.float32(lp[0]) * np.float32(lp[0]))
+            assert row[field] == pytest.approx(np.sqrt(sq), rel=1e-12), (d, field)
+    # --- Retrieve: patched index == index loaded from the updated tables == oracle ------------------------------------------
+    queries = ["w3 w17 w40", "brandnewword w9", '"w3"', 'w40 "w0 w1"', "w5 w6 w7", '"brandnewword"']
+    got = di.RetrieveBatch(queries, 1000)
+    fresh = host.DeviceIndex()
+    fresh.load(forw, inv)
+    want = fresh.RetrieveBatch(queries, 1000)
+    for q, a, b in zip(queries, got, want):
+        assert len(a) == len(b) and len(a) > 0, q
+        assert _retrieve_key(a) == _retrieve_key(b), q
+    assert page in {r.DocHash for r in got[1]} and new_child in {r.DocHash for r in got[5]}
+    # oracle on the updated tables (dense ids in sorted key order)
+    docs_sorted = sorted(set(forw[3].keys()) | {d for t in (inv[0], inv[1]) for term in t.keys() for d in json.loads(t.get(term))})
+    terms = sorted(set(inv[0].keys()) | set(inv[1].keys()))
+    didx = {k: i for i, k in enumerate(docs_sorted)}
+    tidx = {t: i for i, t in enumerate(terms)}
+
+    def tab(t):
+        rows = {term: json.loads(t.get(term)) for term in t.keys()}
+        return oracle_index(rows, docs_sorted, terms)
+    title, body = tab(inv[0]), tab(inv[1])
+    mt, mb = np.zeros(len(docs_sorted)), np.zeros(len(docs_sorted))
+    for d in forw[4].keys():
+        row = json.loads(forw[4].get(d))
+        mt[didx[d]], mb[didx[d]] = row.get("title", 0.0), row.get("body", 0.0)
+    for q, res in ((queries[0], got[0]), (queries[1], got[1]), (queries[4], got[4])):
+        toks = q.split()
+        qt = np.array([tidx.get(h(t), 0xFFFFFFFF) for t in toks], dtype=np.uint32)
+        hits, _ = oracle.score_topk(len(docs_sorted), title, body, mt, mb, qt, 1000, query_len=len(toks))
+        assert sorted((-float(x["final"]), docs_sorted[int(x["doc"])]) for x in hits) == [(a, b) for a, b, *_ in _retrieve_key(res)], q
+    # a snapshot written after the delta carries the patched tables
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "after.ssnap")
+        di.save_snapshot(path)
+        snap = host.DeviceIndex()
+        snap.load_snapshot(path)
+        for a, b in zip(got, snap.RetrieveBatch(queries, 1000)):
+            assert _retrieve_key(a) == _retrieve_key(b)
+    # --- the link graph: one changed row patched on the device, PageRank re-run, forw[3] rewritten -------------------------
+    pr.ApplyDelta(forw, [page])
+    pr.Run(0.75, 1e-9, forw)
+    children = dict(corpus["children"])
+    children[page] = after["children"]
+    names, idx, ptr, dst = oracle_graph({"children": children})
+    cats = sorted(corpus["cats"])
+    ref, _ = oracle.pagerank(len(names), ptr, dst, 0.75, 1e-9, [int(corpus["cats"][c]["numPages"]) for c in cats])
+    assert sorted(forw[3].keys()) == names and new_child in names
+    for v, name in enumerate(names):
+        row = json.loads(forw[3].get(name))
+        for k, c in enumerate(cats):
+            assert row[c] == pytest.approx(ref[k, v], rel=1e-11)
+    # the scorer's PageRank table follows
+    di.ReloadPrior(forw)
+    probs = [{"Arts": 0.5, "Science": 0.25, "Sports": 0.25}]
+    r = [x for x in di.RetrieveBatch(['"brandnewword"'], 50, probs)[0] if x.DocHash == new_child][0]
+    row = json.loads(forw[3].get(new_child))
+    assert r.PageRank == 0.5 * row["Arts"] + 0.25 * row["Science"] + 0.25 * row["Sports"]
+
+
+def test_opt_in_topic_sensitive_wiring(host, oracle, corpus):
+    """SURVEY.md §8f-3 above the C ABI: OFF by default (reference-identical tables and answers), ON = teleport sets from the
+    stored ODP keyword vectors (forw[5], inv[2]) for UpdateTopicSensitivePagerank and live computeTopicProbs for Retrieve."""
+    forw, inv = make_tables(host, corpus)
+    cats = sorted(corpus["cats"])
+    rng = np.random.default_rng(8)
+    # ODP keyword vectors (crawler/ODP-scraper.go:97-139): word -> {category: frequency}
+    kw = {}
+    for wi in rng.choice(len(corpus["word"]), size=60, replace=False):
+        cs = rng.choice(cats, size=int(rng.integers(1, 3)), replace=False)
+        kw[h(corpus["word"][int(wi)])] = {str(c): int(rng.integers(1, 40)) for c in cs}
+    for k, v in kw.items():
+        inv[2].set(k, json.dumps(v))
+    # default: the reference's uniform teleport, whatever inv[2] holds
+    host.UpdateTopicSensitivePagerank(0.75, 1e-9, forw)
+    names, idx, ptr, dst = oracle_graph(corpus)
+    n_topic = [int(corpus["cats"][c]["numPages"]) for c in cats]
+    ref, _ = oracle.pagerank(len(names), ptr, dst, 0.75, 1e-9, n_topic)
+    for v in (0, 7, len(names) - 1):
+        row = json.loads(forw[3].get(names[v]))
+        assert [row[c] for c in cats] == pytest.approx(ref[:, v].tolist(), rel=1e-12)
+    default_rows = {k: forw[3].get(k) for k in forw[3].keys()}
+    host.UpdateTopicSensitivePagerank(0.75, 1e-9, forw, False, inv)
+    assert {k: forw[3].get(k) for k in forw[3].keys()} == default_rows                    # explicit off == default, bit for bit
+    # opt-in: sets by the stated rule, restated here in Python
+    wc = {c: corpus["cats"][c]["wordCount"] for c in cats}
+    mass = {}
+    for w in sorted(kw):
+        share = [kw[w].get(c, 0) / wc[c] for c in cats]
+        for table in (corpus["title"], corpus["body"]):
+            for d in table.get(w, {}):
+                m = mass.setdefault(d, [0.0] * len(cats))
+                for i in range(len(cats)):
+                    m[i] += share[i]
+    want_sets = {c: [] for c in cats}
+    for d in sorted(mass):
+        best = int(np.argmax(mass[d]))                                                     # first maximum, like the mirror
+        if mass[d][best] > 0:
+            want_sets[cats[best]].append(d)
+    got_sets = host.TopicTeleportSets(forw, inv)
+    assert got_sets == want_sets and all(len(v) > 0 for v in want_sets.values())
+    host.UpdateTopicSensitivePagerank(0.75, 1e-9, forw, True, inv)
+    for k, c in enumerate(cats):
+        members = [idx[d] for d in want_sets[c] if d in idx]
+        ref_ts, _ = oracle.pagerank_topic_ts(len(names), ptr, dst, 0.75, 1e-9, n_topic[k], np.array(members, dtype=np.uint32))
+        got = np.array([json.loads(forw[3].get(nm))[c] for nm in names])
+        np.testing.assert_allclose(got, ref_ts, rtol=1e-11, atol=1e-300)
+        assert got[members].mean() > 1.5 * ref[k][members].mean()                         # the set's pages gained rank
+    # Retrieve: off by default; live probabilities = fixed computeTopicProbs over the query's non-phrase words
+    host.UpdateTermWeights(inv[0], forw, "title")
+    host.UpdateTermWeights(inv[1], forw, "body")
+    di = host.DeviceIndex()
+    di.load(forw, inv)
+    di.LoadTopics(forw, inv)
+    kws = [w for w in corpus["word"] if h(w) in kw]
+    plain = [w for w in corpus["word"] if h(w) not in kw]
+    queries = [f"{kws[0]} {kws[1]}", f"{kws[2]} {plain[0]}", f"{plain[1]} {plain[2]}", f'{kws[3]} "{kws[4]}"']
+    off = di.RetrieveBatch(queries, 50)
+    assert all(r.PageRank == 0.0 for res in off for r in res)                             # Q9: nil topicProbs
+    on = di.RetrieveBatch(queries, 50, None, True)
+    wcl = [wc[c] for c in cats]
+    for q, res_on, res_off in zip(queries, on, off):
+        toks = [t for t in q.replace('"' + kws[4] + '"', "").split()]
+        maps = [{cats.index(c): f for c, f in kw[h(t)].items()} for t in toks if h(t) in kw]
+        probs = oracle.topic_probs(wcl, maps, mode=1) if maps else np.zeros(len(cats))
+        assert list(di.liveTopicProbs([h(t) for t in toks]).values()) == probs.tolist()
+        explicit = di.RetrieveBatch([q], 50, [dict(zip(cats, probs.tolist()))])[0]
+        assert [(r.DocHash, r.FinalRank, r.PageRank) for r in res_on] == [(r.DocHash, r.FinalRank, r.PageRank) for r in explicit]
+        for r in res_on[:5]:
+            row = json.loads(forw[3].get(r.DocHash))
+            assert r.PageRank == pytest.approx(sum(p * row[c] for p, c in zip(probs.tolist(), cats)), rel=1e-12)
+    assert any(r.PageRank > 0 for r in on[0]) and all(r.PageRank == 0.0 for r in on[2])

@@ -73,6 +73,9 @@ def test_default_path_is_untouched_and_clearable(ss_ctx, oracle):
     st = engine.PageRankState(g, D, 1e-10, n_topic)
     with pytest.raises(Exception):                                         # node id out of range
         st.set_teleport([np.array([n], dtype=np.uint32)] * 4)
+    with pytest.raises(Exception, match="twice"):                          # |set| is taken from set_ptr: ids must be distinct
+        st.set_teleport([np.array([3, 9, 3], dtype=np.uint32)] + [np.arange(4, dtype=np.uint32)] * 3)
+    st.set_teleport([np.array([3, 9], dtype=np.uint32)] * 4)               # the same node in different topics is fine
     st.close()
     g.close()
 
