@@ -39,7 +39,99 @@ func newDenseIDs(keys map[string]struct{}) *denseIDs {
 	return d
 }
 
+// UpdateTopicSensitivePagerank keeps the reference's signature and behaviour (every topic teleports uniformly).
 func UpdateTopicSensitivePagerank(ctx context.Context, dampingFactor float64, convergenceCriterion float64, forward []db.DB) {
+	updatePagerank(ctx, dampingFactor, convergenceCriterion, forward, nil)
+}
+
+// UpdateTopicSensitivePagerankTeleport is the OPT-IN form (SURVEY.md §8f-3; no counterpart in the reference, which
+// advertises topic-sensitive PageRank, README.md:9, but differs per topic by the start value only): every category
+// teleports into the pages TopicTeleportSets assigns to it.  inverted = inv (inv[0], inv[1], inv[2] are read).
+func UpdateTopicSensitivePagerankTeleport(ctx context.Context, dampingFactor float64, convergenceCriterion float64, forward []db.DB, inverted []db.DB) {
+	updatePagerank(ctx, dampingFactor, convergenceCriterion, forward, TopicTeleportSets(ctx, forward, inverted))
+}
+
+// TopicTeleportSets: category -> doc hashes.  A page joins the set of the category whose ODP keywords
+// (inv[2][wordHash] = map[category]frequency, forw[5][category]["wordCount"]; crawler/ODP-scraper.go:97-139) it holds
+// most of, by the estimate computeTopicProbs uses for a query (tf / wordCount, main_retrieve.go:143-145):
+//     mass(page, c) = sum over the words w of the page (inv[0] or inv[1] row of w holds the page) of inv[2][w][c] / wordCount(c)
+// ties go to the first category in key order; a page without keyword hits joins no set.
+func TopicTeleportSets(ctx context.Context, forward []db.DB, inverted []db.DB) map[string][]string {
+	catComp, err := forward[5].Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	cats := make([]string, 0, len(catComp.KV))
+	wordCount := make(map[string]float64, len(catComp.KV))
+	for _, kv := range catComp.KV {
+		val := make(map[string]float64, 2)
+		if err = json.Unmarshal(kv.Value, &val); err != nil {
+			panic(err)
+		}
+		cats = append(cats, string(kv.Key))
+		wordCount[string(kv.Key)] = val["wordCount"]
+	}
+	sort.Strings(cats)
+	kwComp, err := inverted[2].Iterate(ctx)
+	if err != nil {
+		panic(err)
+	}
+	mass := make(map[string][]float64)
+	for _, kv := range kwComp.KV {
+		var freq map[string]float64
+		if err = json.Unmarshal(kv.Value, &freq); err != nil {
+			panic(err)
+		}
+		share := make([]float64, len(cats))
+		hit := false
+		for i, c := range cats {
+			if f, ok := freq[c]; ok && wordCount[c] > 0 {
+				share[i] = f / wordCount[c]
+				hit = true
+			}
+		}
+		if !hit {
+			continue
+		}
+		for t := 0; t < 2; t++ {
+			v, err := inverted[t].Get(ctx, string(kv.Key))
+			if err != nil {
+				continue // the keyword is in no page of this table
+			}
+			for docHash := range v.(map[string][]float32) {
+				m, ok := mass[docHash]
+				if !ok {
+					m = make([]float64, len(cats))
+					mass[docHash] = m
+				}
+				for i := range cats {
+					m[i] += share[i]
+				}
+			}
+		}
+	}
+	sets := make(map[string][]string, len(cats))
+	for _, c := range cats {
+		sets[c] = nil
+	}
+	for docHash, m := range mass {
+		best := 0
+		for i := 1; i < len(cats); i++ {
+			if m[i] > m[best] {
+				best = i
+			}
+		}
+		if m[best] > 0 {
+			sets[cats[best]] = append(sets[cats[best]], docHash)
+		}
+	}
+	for _, c := range cats {
+		sort.Strings(sets[c])
+	}
+	return sets
+}
+
+func updatePagerank(ctx context.Context, dampingFactor float64, convergenceCriterion float64, forward []db.DB, teleport map[string][]string) {
 	log.Printf("Ranking with damping factor='%f', convergence_criteria='%f'", dampingFactor, convergenceCriterion)
 
 	// pagerank.go:17-44 — node set = parents U children (frontier pages are nodes without children)
@@ -99,6 +191,9 @@ func UpdateTopicSensitivePagerank(ctx context.Context, dampingFactor float64, co
 	bw := forward[3].BatchWrite_init(ctx)
 	defer bw.Cancel(ctx)
 	if job := spaghetti.Job(); job.World > 1 {
+		if teleport != nil {
+			panic("teleport sets with several GPUs: use the step-wise calls (ss_pr_set_teleport takes the full sets on every rank)")
+		}
 		// Several GPUs (one crawl process per GPU, SS_RANK/SS_WORLD): every process flattens the same tables to the same
 		// ids (sorted hashes), keeps the destination rows of ITS doc-range shard, runs its part of the sweep with one
 		// RCCL all-gather per iteration inside the library, and writes its own rows of forw[3].  K > 16 in groups of 16.
@@ -128,7 +223,20 @@ func UpdateTopicSensitivePagerank(ctx context.Context, dampingFactor float64, co
 	} else {
 		g := spaghetti.Default().NewGraph(outPtr, outDst)
 		defer g.Close()
-		rank, _ := g.PageRank(dampingFactor, convergenceCriterion, nTopic) // all categories, device-resident loop
+		var rank []float64
+		if teleport == nil {
+			rank, _ = g.PageRank(dampingFactor, convergenceCriterion, nTopic) // all categories, device-resident loop
+		} else {
+			sets := make([][]uint32, len(cats))
+			for k, c := range cats {
+				for _, h := range teleport[c] {
+					if v, ok := ids.id[h]; ok { // a page outside the link graph has no rank to receive
+						sets[k] = append(sets[k], v)
+					}
+				}
+			}
+			rank, _ = g.PageRankTeleport(dampingFactor, convergenceCriterion, nTopic, sets)
+		}
 
 		// pagerank.go:65-82 — forw[3][doc] = map[category]rank
 		for v, name := range ids.name {

@@ -13,6 +13,7 @@ import (
 	"crypto/md5"
 	"encoding/hex"
 	"encoding/json"
+	"fmt"
 	"sort"
 	"strings"
 	"sync"
@@ -26,13 +27,28 @@ import (
 
 const topK = 50 // main_retrieve.go:99-100
 
+// deviceIndex is ONE immutable snapshot of the tables on the device.  Requests are tokenised against a snapshot, carry it
+// through the batcher and map the winners back through the same snapshot; Refresh swaps in nothing (the next Retrieve
+// loads a new snapshot) and the old one is destroyed when its last user lets go.
 type deviceIndex struct {
-	scorer  *spaghetti.Scorer
-	termID  map[string]uint32 // md5-hex(word) -> dense term id
-	docName []string          // dense doc id -> md5-hex(url)
+	scorer      *spaghetti.Scorer
+	title, body *spaghetti.Index
+	termID      map[string]uint32 // md5-hex(word) -> dense term id
+	docName     []string          // dense doc id -> md5-hex(url)
+	users       sync.WaitGroup    // requests in flight on this snapshot
 }
 
-var dev *deviceIndex
+func (d *deviceIndex) close() {
+	d.users.Wait() // drain: no batch may still hold the scorer
+	d.scorer.Close()
+	d.title.Close()
+	d.body.Close()
+}
+
+var (
+	devMu sync.RWMutex // guards dev; held for reading only while a request registers itself on the snapshot
+	dev   *deviceIndex
+)
 
 func flatten(ctx context.Context, inv db.DB, termID map[string]uint32, docID map[string]uint32) (ptr []uint64, doc []uint32, w []float32, posPtr []uint64, pos []float32) {
 	comp, err := inv.Iterate(ctx)
@@ -122,6 +138,7 @@ func load(ctx context.Context, forw []db.DB, inv []db.DB) *deviceIndex {
 	}
 	title.SetWeighted(magT)
 	body.SetWeighted(magB)
+	d.title, d.body = title, body
 	d.scorer = c.NewScorer(title, body)
 	return d
 }
@@ -136,16 +153,70 @@ const (
 	maxBatch    = 1024
 )
 
+type reply struct {
+	hits []spaghetti.Hit
+	err  error
+}
+
 type request struct {
+	snap           *deviceIndex
 	qTerms, pTerms []uint32
 	qLen           int32
-	reply          chan []spaghetti.Hit
+	reply          chan reply // buffered: the batcher never blocks on a caller
 }
 
 var (
 	reqs     = make(chan *request, 4*maxBatch)
 	batchers sync.Once
 )
+
+// score answers `batch` (all on one snapshot) with one library call.
+func score(snap *deviceIndex, batch []*request) ([][]spaghetti.Hit, error) {
+	qPtr, pPtr := []uint32{0}, []uint32{0}
+	var qTerms, pTerms []uint32
+	qLen := make([]int32, 0, len(batch))
+	for _, r := range batch {
+		qTerms = append(qTerms, r.qTerms...)
+		pTerms = append(pTerms, r.pTerms...)
+		qPtr = append(qPtr, uint32(len(qTerms)))
+		pPtr = append(pPtr, uint32(len(pTerms)))
+		qLen = append(qLen, r.qLen)
+	}
+	// topicProbs stays nil as in the shipped reference (main_retrieve.go:40,87-88): sqd = 0.
+	return snap.scorer.ScoreTopKPhrase(qPtr, qTerms, pPtr, pTerms, qLen, nil, topK)
+}
+
+// serve answers one batch; every waiter gets a reply or an error, whatever happens (a panic below the library
+// boundary included), and the batcher goroutine survives.
+func serve(snap *deviceIndex, batch []*request) {
+	answered := 0
+	defer func() {
+		if p := recover(); p != nil {
+			for _, r := range batch[answered:] {
+				r.reply <- reply{nil, fmt.Errorf("retrieval batch failed: %v", p)}
+			}
+		}
+	}()
+	hits, err := score(snap, batch)
+	if err == nil {
+		for i, r := range batch {
+			r.reply <- reply{hits[i], nil}
+			answered = i + 1
+		}
+		return
+	}
+	// The library refuses a batch as a whole (limits are validated per request before enqueueing, so this is the
+	// unexpected case): run the requests one by one, so that only the offending request sees the error.
+	for i, r := range batch {
+		one, e := score(snap, batch[i:i+1])
+		if e != nil {
+			r.reply <- reply{nil, e}
+		} else {
+			r.reply <- reply{one[0], nil}
+		}
+		answered = i + 1
+	}
+}
 
 func batchLoop() {
 	for first := range reqs {
@@ -161,43 +232,58 @@ func batchLoop() {
 			}
 		}
 		timer.Stop()
-		qPtr, pPtr := []uint32{0}, []uint32{0}
-		var qTerms, pTerms []uint32
-		qLen := make([]int32, 0, len(batch))
-		for _, r := range batch {
-			qTerms = append(qTerms, r.qTerms...)
-			pTerms = append(pTerms, r.pTerms...)
-			qPtr = append(qPtr, uint32(len(qTerms)))
-			pPtr = append(pPtr, uint32(len(pTerms)))
-			qLen = append(qLen, r.qLen)
-		}
-		// topicProbs stays nil as in the shipped reference (main_retrieve.go:40,87-88): sqd = 0.
-		hits, _ := dev.scorer.ScoreTopKPhrase(qPtr, qTerms, pPtr, pTerms, qLen, nil, topK)
-		for i, r := range batch {
-			r.reply <- hits[i]
+		// requests tokenised against different snapshots (a Refresh fell into the window) are served per snapshot
+		for len(batch) > 0 {
+			snap := batch[0].snap
+			var same, rest []*request
+			for _, r := range batch {
+				if r.snap == snap {
+					same = append(same, r)
+				} else {
+					rest = append(rest, r)
+				}
+			}
+			serve(snap, same)
+			batch = rest
 		}
 	}
 }
 
-// Refresh drops the device copy of the tables; the next Retrieve flattens and uploads them again (call after a
+// Refresh retires the device copy of the tables; the next Retrieve flattens and uploads them again (call after a
 // re-crawl has rewritten inv[*]/forw[3..4]: the reference re-reads BadgerDB on every request and needs no such call).
+// Requests already running finish on the snapshot they started with; it is destroyed — scorer, then both tables — when
+// the last of them is done.
 func Refresh() {
-	warmMu.Lock()
-	defer warmMu.Unlock()
-	if dev != nil {
-		dev.scorer.Close()
-		dev = nil
+	devMu.Lock()
+	old := dev
+	dev = nil
+	devMu.Unlock()
+	if old != nil {
+		go old.close()
 	}
 }
 
-var warmMu sync.Mutex
-
-func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Rank_combined {
-	warmMu.Lock()
+// acquire returns the current snapshot with this request registered on it (release with snap.users.Done()).
+func acquire(ctx context.Context, forw []db.DB, inv []db.DB) *deviceIndex {
+	devMu.RLock()
+	if d := dev; d != nil {
+		d.users.Add(1)
+		devMu.RUnlock()
+		return d
+	}
+	devMu.RUnlock()
+	devMu.Lock()
+	defer devMu.Unlock()
 	if dev == nil {
 		dev = load(ctx, forw, inv)
 	}
-	warmMu.Unlock()
+	dev.users.Add(1)
+	return dev
+}
+
+func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Rank_combined {
+	snap := acquire(ctx, forw, inv)
+	defer snap.users.Done()
 	batchers.Do(func() { go batchLoop() })
 
 	// main_retrieve.go:17-36 — query parsing, unchanged
@@ -212,7 +298,7 @@ func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Ra
 		ids := make([]uint32, len(tokens))
 		for i, tok := range tokens {
 			sum := md5.Sum([]byte(tok))
-			if id, ok := dev.termID[hex.EncodeToString(sum[:])]; ok {
+			if id, ok := snap.termID[hex.EncodeToString(sum[:])]; ok {
 				ids[i] = id
 			} else {
 				ids[i] = 0xFFFFFFFF // badger.ErrKeyNotFound: no postings (main_retrieve.go:193,218)
@@ -222,15 +308,31 @@ func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Ra
 	}
 	// all quoted phrases form ONE phrase (main_retrieve.go:26); it is matched on the device from the
 	// positional part of the postings (retrieval/phrase.go -> ss_score_topk_phrase)
-	r := &request{qTerms: toIDs(queryTokenised), pTerms: toIDs(phraseTokenised),
+	r := &request{snap: snap, qTerms: toIDs(queryTokenised), pTerms: toIDs(phraseTokenised),
 		qLen:  int32(len(queryTokenised) + len(phraseTokenised)), // main_retrieve.go:90
-		reply: make(chan []spaghetti.Hit, 1)}
+		reply: make(chan reply, 1)}
+	// The library's per-request limits are checked HERE, in the request's own goroutine (net/http recovers a panic of a
+	// handler goroutine and the other requests of the batch never see it); the reference has no such limits.
+	if len(r.pTerms) > spaghetti.MaxPhraseTerms {
+		panic(fmt.Errorf("quoted phrase of %d words: at most %d are supported", len(r.pTerms), spaghetti.MaxPhraseTerms))
+	}
+	distinct := make(map[uint32]struct{}, len(r.qTerms))
+	for _, t := range r.qTerms {
+		distinct[t] = struct{}{}
+	}
+	if len(distinct) > spaghetti.MaxQueryTerms {
+		panic(fmt.Errorf("query of %d distinct words: at most %d are supported", len(distinct), spaghetti.MaxQueryTerms))
+	}
 	reqs <- r
-	hits := <-r.reply
+	ans := <-r.reply
+	if ans.err != nil {
+		panic(ans.err) // error policy of the reference: panic in the request goroutine
+	}
+	hits := ans.hits
 
 	out := make([]Rank_combined, 0, len(hits))
 	for _, h := range hits {
-		docHash := dev.docName[h.Doc]
+		docHash := snap.docName[h.Doc]
 		meta := <-getDocInfo(ctx, docHash, forw) // get_metadata.go:211-235, for the winners only
 		meta.PageRank = h.PageRank               // get_metadata.go:68
 		meta.FinalRank = h.Final                 // get_metadata.go:69

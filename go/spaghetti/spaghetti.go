@@ -29,6 +29,12 @@ import (
 	"unsafe"
 )
 
+// Per-request limits of the scorer (a batch that breaks one is refused as a whole: callers validate first).
+const (
+	MaxQueryTerms  = int(C.SS_MAX_QUERY_TERMS)
+	MaxPhraseTerms = int(C.SS_MAX_PHRASE_TERMS)
+)
+
 // Hit mirrors ss_hit.
 type Hit struct {
 	Doc      uint32
@@ -61,13 +67,21 @@ var (
 	global *Ctx
 )
 
+// statusErr turns a library status into an error (nil for SS_OK).
+func statusErr(c *Ctx, rc C.int32_t, what string) error {
+	if rc == C.SS_OK {
+		return nil
+	}
+	var h *C.ss_ctx
+	if c != nil {
+		h = c.h
+	}
+	return fmt.Errorf("%s: status %d: %s", what, int(rc), C.GoString(C.ss_last_error(h)))
+}
+
 func check(c *Ctx, rc C.int32_t, what string) {
-	if rc != C.SS_OK {
-		var h *C.ss_ctx
-		if c != nil {
-			h = c.h
-		}
-		panic(fmt.Errorf("%s: status %d: %s", what, int(rc), C.GoString(C.ss_last_error(h))))
+	if err := statusErr(c, rc, what); err != nil {
+		panic(err)
 	}
 }
 
@@ -84,8 +98,14 @@ func Job() JobInfo {
 }
 
 // Default returns the process-wide context (one process per GPU; the launcher pins the GPU with HIP_VISIBLE_DEVICES, so the
-// device index is 0).  In a multi-GPU job it also joins the job's RCCL communicator: rank 0 writes the 128-byte id to
-// SS_COMM_ID_FILE (atomically: temp file + rename), the other ranks wait for the file.
+// device index is 0).  In a multi-GPU job it also joins the job's RCCL communicator through SS_COMM_ID_FILE:
+//   - the file holds the 128-byte id followed by the job's nonce SS_JOB_ID (the launcher gives every start of the job a
+//     fresh value, e.g. its pid + start time); a reader accepts the file only when the nonce is its own, so a file left
+//     behind by an earlier or crashed job is never used;
+//   - rank 0 removes whatever is at the path first, writes temp file + rename, and removes the file again once
+//     CommInit has returned (ncclCommInitRank is collective: every rank holds the id by then);
+//   - the other ranks wait SS_COMM_TIMEOUT_S seconds at most (default 120) and then panic, so that a job whose rank 0
+//     never came up exits non-zero instead of hanging.
 func Default() *Ctx {
 	once.Do(func() {
 		var h *C.ss_ctx
@@ -96,29 +116,58 @@ func Default() *Ctx {
 			if path == "" {
 				panic(fmt.Errorf("SS_WORLD=%d needs SS_COMM_ID_FILE", job.World))
 			}
+			nonce := []byte(os.Getenv("SS_JOB_ID"))
+			if len(nonce) == 0 {
+				panic(fmt.Errorf("SS_WORLD=%d needs SS_JOB_ID (a value unique to this start of the job)", job.World))
+			}
 			var id []byte
 			if job.Rank == 0 {
+				_ = os.Remove(path)
 				id = CommUniqueID()
-				if err := os.WriteFile(path+".tmp", id, 0o600); err != nil {
+				if err := os.WriteFile(path+".tmp", append(append([]byte{}, id...), nonce...), 0o600); err != nil {
 					panic(err)
 				}
 				if err := os.Rename(path+".tmp", path); err != nil {
 					panic(err)
 				}
 			} else {
-				for {
+				limit := 120
+				if v, err := strconv.Atoi(os.Getenv("SS_COMM_TIMEOUT_S")); err == nil && v > 0 {
+					limit = v
+				}
+				deadline := time.Now().Add(time.Duration(limit) * time.Second)
+				for id == nil {
 					b, err := os.ReadFile(path)
-					if err == nil && len(b) == C.SS_COMM_ID_BYTES {
-						id = b
+					if err == nil && len(b) == C.SS_COMM_ID_BYTES+len(nonce) && string(b[C.SS_COMM_ID_BYTES:]) == string(nonce) {
+						id = b[:C.SS_COMM_ID_BYTES]
 						break
+					}
+					if time.Now().After(deadline) {
+						panic(fmt.Errorf("rank %d: no communicator id for job %q in %s after %d s", job.Rank, string(nonce), path, limit))
 					}
 					time.Sleep(50 * time.Millisecond)
 				}
 			}
 			global.CommInit(id, job.Rank, job.World)
+			if job.Rank == 0 {
+				_ = os.Remove(path)
+			}
 		}
 	})
 	return global
+}
+
+// SetOption sets a named tuning option of the context (ss_set_option; the names are listed in the header).
+func (c *Ctx) SetOption(name string, value int64) {
+	cs := C.CString(name)
+	defer C.free(unsafe.Pointer(cs))
+	check(c, C.ss_set_option(c.h, cs, C.int64_t(value)), "ss_set_option")
+}
+
+// CommSplit replaces the context's communicator by the sub-communicator of the ranks that pass the same color (2-D
+// decomposition: topic groups x doc shards).
+func (c *Ctx) CommSplit(color, key int) {
+	check(c, C.ss_comm_split(c.h, C.int32_t(color), C.int32_t(key)), "ss_comm_split")
 }
 
 func u64p(s []uint64) *C.uint64_t {
@@ -161,6 +210,40 @@ func (c *Ctx) NewGraph(outPtr []uint64, outDst []uint32) *Graph {
 	return &Graph{h, c, n}
 }
 func (g *Graph) Close() { C.ss_graph_destroy(g.h) }
+
+// ApplyDelta patches the resident link graph: the out-edges of changed[i] become newChildren[newPtr[i]:newPtr[i+1]],
+// nNodesNew >= N admits new pages (ss_graph_apply_delta; indexer.go:301-304 rewrites forw[2] of a re-crawled page).
+func (g *Graph) ApplyDelta(nNodesNew uint64, changed []uint32, newPtr []uint64, newChildren []uint32) {
+	check(g.ctx, C.ss_graph_apply_delta(g.h, C.uint64_t(nNodesNew), C.uint64_t(len(changed)), u32p(changed), u64p(newPtr), u32p(newChildren)),
+		"ss_graph_apply_delta")
+	g.N = nNodesNew
+}
+
+// PageRankTeleport is the opt-in topic-sensitive run (SURVEY.md §8f-3): sets[k] = DISTINCT node ids of topic k's
+// teleport set (empty = the reference's uniform teleport for that topic).  rank[k*N+v], iters[k].
+func (g *Graph) PageRankTeleport(d, eps float64, nTopic []int32, sets [][]uint32) ([]float64, []int32) {
+	k := len(nTopic)
+	var pr *C.ss_pr
+	check(g.ctx, C.ss_pr_create(g.h, C.double(d), C.double(eps), 0, C.int32_t(k), i32p(nTopic), &pr), "ss_pr_create")
+	defer C.ss_pr_destroy(pr)
+	setPtr := make([]uint64, k+1)
+	var nodes []uint32
+	for i, s := range sets {
+		nodes = append(nodes, s...)
+		setPtr[i+1] = uint64(len(nodes))
+	}
+	check(g.ctx, C.ss_pr_set_teleport(pr, u64p(setPtr), u32p(nodes)), "ss_pr_set_teleport")
+	check(g.ctx, C.ss_pr_begin(pr), "ss_pr_begin")
+	iters := make([]int32, k)
+	var nActive, sweeps C.int32_t = C.int32_t(k), 0
+	for nActive > 0 {
+		check(g.ctx, C.ss_pr_step(pr, 8), "ss_pr_step")
+		check(g.ctx, C.ss_pr_status(pr, i32p(iters), &nActive, &sweeps, nil, nil), "ss_pr_status")
+	}
+	rank := make([]float64, uint64(k)*g.N)
+	check(g.ctx, C.ss_pr_read(pr, f64p(rank)), "ss_pr_read")
+	return rank, iters
+}
 
 // ---- several GPUs: one process (= one context) per GPU, collectives inside the library (RCCL over xGMI) ----
 //
@@ -250,22 +333,41 @@ func (ix *Index) SetDocFreq(df []uint64) {
 // table: DelDocs lose every posting (the changed page's old words, :455-531), the (DelTerm[i], DelDoc[i]) postings go
 // (anchor words of its children, :533-616), the (AddTerm[i], AddDoc[i], AddW[i]) postings arrive.
 type Delta struct {
-	DelDocs          []uint32
-	DelTerm, DelDoc  []uint32
-	AddTerm, AddDoc  []uint32
-	AddW             []float32
+	DelDocs         []uint32
+	DelTerm, DelDoc []uint32
+	AddTerm, AddDoc []uint32
+	AddW            []float32
+	AddPosPtr       []uint64  // optional: positions of the new postings, AddPosPtr[len(AddTerm)+1] into AddPos
+	AddPos          []float32 // listPos[1:] (parser.go:195-207)
 }
 
 // ApplyDelta merges d into the resident table on the device (no BadgerDB row rewrite, no re-upload).  Scorers on this
 // table must be closed before and created again after; call RefreshMagnitudes or TfIdfBuild next, as
 // start_crawl.go:176-177 re-runs UpdateTermWeights after every crawl.
+//
+// When the table's squared magnitudes are resident (after TfIdfBuild or RefreshMagnitudes) the delta keeps the magnitudes
+// of the docs it touches up to date itself; ReadMagnitudes returns them for the forw[4] rows.  New words / new child
+// pages: Resize first.
 func (ix *Index) ApplyDelta(d Delta) {
-	check(ix.ctx, C.ss_index_apply_delta(ix.h, C.uint64_t(len(d.DelDocs)), u32p(d.DelDocs),
+	check(ix.ctx, C.ss_index_apply_delta_pos(ix.h, C.uint64_t(len(d.DelDocs)), u32p(d.DelDocs),
 		C.uint64_t(len(d.DelTerm)), u32p(d.DelTerm), u32p(d.DelDoc),
-		C.uint64_t(len(d.AddTerm)), u32p(d.AddTerm), u32p(d.AddDoc), f32p(d.AddW)), "ss_index_apply_delta")
+		C.uint64_t(len(d.AddTerm)), u32p(d.AddTerm), u32p(d.AddDoc), f32p(d.AddW), u64p(d.AddPosPtr), f32p(d.AddPos)), "ss_index_apply_delta_pos")
 	var nPost C.uint64_t
 	check(ix.ctx, C.ss_index_get_info(ix.h, nil, nil, &nPost), "ss_index_get_info")
 	ix.NPost = uint64(nPost)
+}
+
+// Resize grows the doc and / or term space of the resident table (ss_index_resize).
+func (ix *Index) Resize(nDocs, nTerms uint64) {
+	check(ix.ctx, C.ss_index_resize(ix.h, C.uint64_t(nDocs), C.uint64_t(nTerms)), "ss_index_resize")
+	ix.NDocs, ix.NTerms = nDocs, nTerms
+}
+
+// ReadMagnitudes returns the magnitudes of docs as they stand on the device.
+func (ix *Index) ReadMagnitudes(docs []uint32) []float64 {
+	mag := make([]float64, len(docs))
+	check(ix.ctx, C.ss_index_read_magnitudes(ix.h, C.uint64_t(len(docs)), u32p(docs), f64p(mag)), "ss_index_read_magnitudes")
+	return mag
 }
 func (ix *Index) RefreshMagnitudes() []float64 {
 	mag := make([]float64, ix.NDocs)
@@ -289,11 +391,16 @@ func (s *Scorer) SetPrior(kTopics int, rank []float64) {
 // ScoreTopKPhrase = ScoreTopK plus one (concatenated) quoted phrase per query (retrieval/phrase.go).
 func (s *Scorer) ScoreTopKPhrase(qPtr, qTerms, pPtr, pTerms []uint32, queryLen []int32, topicProbs []float64, k int) ([][]Hit, error) {
 	nq := len(qPtr) - 1
+	if nq == 0 {
+		return nil, nil
+	}
 	raw := make([]C.ss_hit, nq*k)
 	nHits := make([]int32, nq)
 	rc := C.ss_score_topk_phrase(s.h, C.int32_t(nq), u32p(qPtr), u32p(qTerms), u32p(pPtr), u32p(pTerms), i32p(queryLen),
 		f64p(topicProbs), C.int32_t(k), (*C.ss_hit)(unsafe.Pointer(&raw[0])), i32p(nHits))
-	check(s.ctx, rc, "ss_score_topk_phrase")
+	if err := statusErr(s.ctx, rc, "ss_score_topk_phrase"); err != nil {
+		return nil, err // the caller decides: a serving path must not die of one bad request
+	}
 	out := make([][]Hit, nq)
 	for q := 0; q < nq; q++ {
 		out[q] = make([]Hit, nHits[q])
@@ -313,7 +420,9 @@ func (s *Scorer) ScoreTopK(qPtr, qTerms []uint32, queryLen []int32, topicProbs [
 	nHits := make([]int32, nq)
 	rc := C.ss_score_topk(s.h, C.int32_t(nq), u32p(qPtr), u32p(qTerms), i32p(queryLen), f64p(topicProbs), C.int32_t(k),
 		(*C.ss_hit)(unsafe.Pointer(&raw[0])), i32p(nHits))
-	check(s.ctx, rc, "ss_score_topk")
+	if err := statusErr(s.ctx, rc, "ss_score_topk"); err != nil {
+		return nil, err
+	}
 	out := make([][]Hit, nq)
 	for q := 0; q < nq; q++ {
 		out[q] = make([]Hit, nHits[q])

@@ -638,12 +638,23 @@ private:
             }
             std::vector<std::string> queries;
             for (auto& p : batch) queries.push_back(p.first);
+            bool whole = true;
             try {
                 auto res = di_.RetrieveBatch(queries, k_);
                 for (size_t i = 0; i < batch.size(); i++) batch[i].second.set_value(std::move(res[i]));
             } catch (...) {
-                for (auto& p : batch) p.second.set_exception(std::current_exception());
+                whole = false;
             }
+            // The library refuses a batch as a whole (e.g. one quoted phrase beyond SS_MAX_PHRASE_TERMS): answer the
+            // callers one by one, so that only the caller of the offending query gets the error.
+            if (!whole)
+                for (auto& p : batch) {
+                    try {
+                        p.second.set_value(std::move(di_.RetrieveBatch({p.first}, k_)[0]));
+                    } catch (...) {
+                        p.second.set_exception(std::current_exception());
+                    }
+                }
             n_batches_++;
             largest_ = std::max(largest_, batch.size());
         }

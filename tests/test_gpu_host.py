@@ -486,3 +486,35 @@ def test_opt_in_topic_sensitive_wiring(host, oracle, corpus):
             row = json.loads(forw[3].get(r.DocHash))
             assert r.PageRank == pytest.approx(sum(p * row[c] for p, c in zip(probs.tolist(), cats)), rel=1e-12)
     assert any(r.PageRank > 0 for r in on[0]) and all(r.PageRank == 0.0 for r in on[2])
+
+
+def test_one_bad_request_does_not_fail_its_batch(host, corpus):
+    """A quoted phrase beyond SS_MAX_PHRASE_TERMS makes the library refuse the whole batch: the batching front-end then answers
+    the callers one by one, and only the offending caller sees the error."""
+    import threading
+    forw, inv = _weighted_tables(host, corpus)
+    di = host.DeviceIndex()
+    di.load(forw, inv)
+    good = [f"w{i} w{i + 1}" for i in range(8)]
+    bad = '"' + " ".join(f"w{i}" for i in range(20)) + '"'
+    want = di.RetrieveBatch(good, 50)
+    with pytest.raises(RuntimeError):
+        di.RetrieveBatch(good + [bad], 50)
+    batcher = host.RetrieveBatcher(di, 50, 50000, 1024)
+    queries = good + [bad]
+    got, errs = [None] * len(queries), [None] * len(queries)
+
+    def worker(i):
+        try:
+            got[i] = batcher.Retrieve(queries[i])
+        except Exception as e:          # noqa: BLE001 - the error of the offending request
+            errs[i] = e
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(queries))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errs[-1] is not None and all(e is None for e in errs[:-1])
+    for a, b in zip(want, got[:-1]):
+        assert [(r.DocHash, r.FinalRank) for r in a] == [(r.DocHash, r.FinalRank) for r in b]
