@@ -193,7 +193,7 @@ int32_t ss_pr_exchange_buffers(ss_pr* pr, void** send_dev, uint64_t* send_bytes,
 int32_t ss_pr_exchange(ss_pr* pr, int32_t allreduce);
 /* The whole sharded power iteration of one rank: begin, {sweep, exchange, finalize} until the device-side stop rule
  * (pagerank.go:93) has fired for every topic on every rank (the ranks agree: they finalize the same gathered sums).
- * The K topic vectors run as topic blocks (option "pr.topic_blocks", default 2 from 8 topics on) whose exchanges are
+ * The K topic vectors run as topic blocks (option "pr.topic_blocks", default 2 above 8 topics) whose exchanges are
  * enqueued on a second stream of the context: block b's collective overlaps block b+1's sweep.
  * Topics are independent, so the results are those of running every block's topics on their own.
  * ids_out [n_rows_local] original node ids of this rank's rows, rank_out [k_topics][n_rows_local], iters_out [k_topics].
@@ -301,7 +301,11 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank);
  * count); topic_probs [n_q][k_topics] or NULL (nil map => sqd = 0,
  * main_retrieve.go:88).  hits_out [n_q][k], n_hits_out [n_q] (host or device).
  * Order: FinalRank descending (util.go:48-54), ties ascending doc id, NaN last;
- * reference k = 50 (main_retrieve.go:99-100). 
+ * reference k = 50 (main_retrieve.go:99-100).
+ * The QUERY arrays (q_ptr, q_terms, query_len, topic_probs, and p_ptr / p_terms below) are consumed on the HOST: the
+ * slice plan of a batch (which lists, which doc ranges, which kernel) is made on the CPU from the host copy of the
+ * tables' term_ptr, as the query words themselves arrive from a host-side tokenizer (main_retrieve.go:17-36).  Pass host
+ * arrays; device pointers are accepted and cost one blocking copy back each (~16 KB for 1024 queries).
  * Results in HOST memory: the call returns when they are there.  Results in DEVICE memory (both
  * pointers): the kernels write them directly and the call returns once the work is enqueued on the
  * ctx stream — later work on that stream sees them; ss_synchronize waits for them. */

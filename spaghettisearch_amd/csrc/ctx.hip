@@ -206,6 +206,7 @@ static const char* const k_option_names[] = {
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
     "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 8192, 0 = off)
     "pr.trace",             // 1: ss_graph_create / ss_pr_create print their phase times to stderr
+    "score.trace",          // 1: ss_score_topk prints the host phases of a call (copies in, plan, staging, launches) to stderr
     "pr.probe_hot",         // ss_pr_probe policies 3/4: rows below this index use the default cache policy
     "pr.topic_blocks",      // ss_pagerank_run_sharded: split K into this many topic blocks whose exchanges overlap the next block's sweep
     "tfidf.blocks",         // workgroups of the bucketed magnitude pass (default 1024)

@@ -1596,10 +1596,11 @@ int32_t run_pipelined(ss_ctx* ctx, std::vector<ShardBlocks>& sh, int32_t max_ite
     return rc;
 }
 
-// topic blocks of a K-topic run: option "pr.topic_blocks" (default 2 from 8 topics on: one block's exchange then hides behind
-// the other block's sweep), never more blocks than topics
+// topic blocks of a K-topic run: option "pr.topic_blocks" (default 2 above 8 topics: one block's exchange then hides behind
+// the other block's sweep — and both blocks still fill an 8-wide table; splitting 8 topics or fewer would pad every block to
+// the 8-wide kernel and double the bytes on the wire), never more blocks than topics
 int topic_blocks_for(ss_ctx* ctx, int k_topics) {
-    int B = (int)ctx->opt("pr.topic_blocks", k_topics >= 8 ? 2 : 1);
+    int B = (int)ctx->opt("pr.topic_blocks", k_topics > 8 ? 2 : 1);
     return std::max(1, std::min(B, k_topics));
 }
 

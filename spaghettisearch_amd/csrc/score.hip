@@ -40,6 +40,7 @@
 //   * k_merge_topk: one workgroup per query merges its slices' top-k lists, re-derives
 //     title/body/pagerank of the k winners by binary search and writes ss_hit rows.
 //   Ties: ascending doc id (Q10); NaN finals last.
+#include <chrono>
 #include "score_common.hpp"
 
 namespace {
@@ -1526,6 +1527,12 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (topic_probs && s->k_topics == 0) return ctx->fail(SS_ERR_STATE, "ss_score_topk: topic_probs given but no prior set (ss_scorer_set_prior)");
     if (n_q == 0) return SS_OK;
 
+    const bool trace = ctx->opt("score.trace", 0) != 0;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    const auto th0 = t_now();
     // ---- host-side plan (the host keeps df per term; queries are tiny) -------------
     std::vector<uint32_t> h_qptr(n_q + 1);
     SS_HIP(ctx, hipMemcpy(h_qptr.data(), q_ptr, (n_q + 1) * sizeof(uint32_t), hipMemcpyDefault));
@@ -1569,6 +1576,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     for (size_t i = 0; i < h_probs.size() && !exact_all; i++) exact_all = !(h_probs[i] >= 0.0) || !std::isfinite(h_probs[i]);
     int kth_j = 0;
     while ((1 << kth_j) < k) kth_j++;
+    const auto th1 = t_now();
 
     const std::vector<uint64_t>& tp = s->title->h_term_ptr;
     const std::vector<uint64_t>& bp = s->body->h_term_ptr;
@@ -1714,6 +1722,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
 
     int cb = SS_CB_MIN;
     while (cb < 2 * k) cb <<= 1;
+    const auto th2 = t_now();
 
     // ---- one pinned staging buffer, one H2D copy -------------------------------------
     size_t o = 0;
@@ -1770,6 +1779,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_probs.empty()) std::memcpy(hp + o_probs, h_probs.data(), h_probs.size() * sizeof(double));
     if (!h_mergeq.empty()) std::memcpy(hp + o_mergeq, h_mergeq.data(), h_mergeq.size() * sizeof(uint32_t));
     std::memcpy(hp + o_qfast, h_fast.data(), (size_t)n_q);
+    const auto th3 = t_now();
     SS_HIP(ctx, hipMemcpyAsync(s->d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, st));
     SS_HIP(ctx, hipEventRecord(s->plan_ev[pb], st));
     s->plan_ev_pending[pb] = true;
@@ -1848,6 +1858,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.hits = dev_out ? hits_out : s->d_hits.p;
     p.n_hits = dev_out ? n_hits_out : s->d_nhits.p;
 
+    const auto th4 = t_now();
     const size_t lds_score = score_lds_bytes(cb), lds_merge = merge_lds_bytes(k, cb);
     if (s->lds_attr < cb) {
         SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_slices), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_score));
@@ -1874,6 +1885,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
     ctx->ev_valid[1] = true;
     SS_HIP(ctx, hipGetLastError());
+    if (trace)
+        fprintf(stderr, "[score trace] copies in + checks %.0f us, plan (%zu slices) %.0f us, staging %.0f us, H2D + allocs + params %.0f us, launches %.0f us\n",
+                t_us(th0, th1), n_slices, t_us(th1, th2), t_us(th2, th3), t_us(th3, th4), t_us(th4, t_now()));
     if (dev_out) return SS_OK;                   // ordered on the ctx stream; ss_synchronize (or the stream's owner) waits
     SS_HIP(ctx, hipMemcpyAsync(hits_out, s->d_hits.p, (size_t)n_q * k * sizeof(ss_hit), hipMemcpyDefault, st));
     SS_HIP(ctx, hipMemcpyAsync(n_hits_out, s->d_nhits.p, n_q * sizeof(int32_t), hipMemcpyDefault, st));

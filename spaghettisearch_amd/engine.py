@@ -198,14 +198,21 @@ class Graph:
         check(self.ctx.lib.ss_graph_get_info(self.h, C.byref(gi)), self.ctx.h)
         return gi
 
-    def pagerank_sharded(self, damping: float, eps: float, n_topic: Sequence[int], max_iter: int = 0, allreduce: bool = False):
+    def pagerank_sharded(self, damping: float, eps: float, n_topic: Sequence[int], max_iter: int = 0, allreduce: bool = False, out=None):
         """ss_pagerank_run_sharded (this rank's part of the doc-range-sharded loop, collectives inside the library):
-        -> (ids uint32[rows], rank [K][rows] float64, iters [K] int32)."""
+        -> (ids uint32[rows], rank [K][rows] float64, iters [K] int32).  out = (ids, rank) device tensors keeps the result
+        in HBM (torch int32 [rows], float64 [K][rows])."""
         n_topic = np.ascontiguousarray(np.atleast_1d(n_topic), dtype=np.int32)
         K = len(n_topic)
         rows = int(self.info().n_rows_local)
-        ids = np.zeros(rows, dtype=np.uint32)
-        rank = np.zeros((K, rows), dtype=np.float64)
+        if out is not None:
+            ids, rank = _as(out[0], "uint32"), _as(out[1], "float64")
+            count = lambda a: a.numel() if _is_torch(a) else a.size
+            if count(ids) < rows or count(rank) < K * rows:
+                raise ValueError("out arrays too small")
+        else:
+            ids = np.zeros(rows, dtype=np.uint32)
+            rank = np.zeros((K, rows), dtype=np.float64)
         iters = np.zeros(K, dtype=np.int32)
         check(self.ctx.lib.ss_pagerank_run_sharded(self.h, damping, eps, max_iter, K, _ptr(n_topic), 1 if allreduce else 0,
                                                    _ptr(ids), _ptr(rank), _ptr(iters)), self.ctx.h)
