@@ -167,6 +167,106 @@ __device__ __forceinline__ void chunk_term_range(const uint64_t* __restrict__ te
     }
 }
 
+// ---- head lists: long posting lists are summed bucket-major straight from the table -------------------------------
+// Every posting list is strictly ascending by doc (checked at ss_index_create, kept by the deltas), so the postings of a
+// LONG list that fall into one bucket are one contiguous run of the list.  Lists whose average run is at least `min_run`
+// postings ("head" lists: under Zipf a few hundred terms that hold about half of all postings) skip the partition
+// altogether: k_weight_count and k_scatter pass over them, and k_bucket_sum reads bucket b's run of every head list straight
+// from post_doc / post_w, weighting it on the way (w = tf*idf written once) — 12 bytes per head posting, the algorithmic
+// minimum, instead of the 36 a partitioned posting costs.  Which lists are head only moves work between two exact paths.
+constexpr int HEAD_CAP = 1024;               // most head lists (their run table sits in LDS beside the accumulators: 12 B each)
+struct HeadArgs {
+    const uint32_t* n;                       // number of head lists (device word; 0 = no head path)
+    const uint32_t* term;                    // [HEAD_CAP] their term ids, ascending
+    const uint64_t* hs;                      // [HEAD_CAP] term_ptr[term]      first posting
+    const uint64_t* he;                      // [HEAD_CAP] term_ptr[term + 1]  one past the last
+    const uint32_t* bounds;                  // [nb + 1][HEAD_CAP]: postings of list i with doc < b << shift
+};
+// Threshold: the smallest power-of-two multiple of `thr` that leaves at most HEAD_CAP lists (so that the LONGEST lists are the
+// head lists when many qualify).  hist[j] counts the lists with length >= thr << j.
+constexpr int HEAD_LEVELS = 24;
+__global__ void k_head_hist(const uint64_t* __restrict__ term_ptr, uint64_t n_terms, uint64_t thr, uint32_t* __restrict__ hist) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_terms) return;
+    const uint64_t len = term_ptr[t + 1] - term_ptr[t];
+    for (int j = 0; j < HEAD_LEVELS && len >= (thr << j); j++) atomicAdd(&hist[j], 1u);    // a few thousand lists get here at all
+}
+__global__ void k_head_select(const uint64_t* __restrict__ term_ptr, uint64_t n_terms, uint64_t thr, const uint32_t* __restrict__ hist,
+                              uint32_t* __restrict__ n_head, uint32_t* __restrict__ head_term) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_terms) return;
+    int j = 0;
+    while (j + 1 < HEAD_LEVELS && hist[j] > (uint32_t)HEAD_CAP) j++;
+    if (term_ptr[t + 1] - term_ptr[t] >= (thr << j)) {
+        const uint32_t slot = atomicAdd(n_head, 1u);
+        if (slot < (uint32_t)HEAD_CAP) head_term[slot] = (uint32_t)t;     // (beyond the cap only if 2^23 * thr still leaves too many)
+    }
+}
+// one workgroup: clamp the count, sort the term ids ascending (bitonic, LDS), derive the posting ranges
+__global__ __launch_bounds__(1024) void k_head_sort(const uint64_t* __restrict__ term_ptr, uint32_t* __restrict__ n_head,
+                                                    uint32_t* __restrict__ head_term, uint64_t* __restrict__ hs, uint64_t* __restrict__ he) {
+    __shared__ uint32_t s[HEAD_CAP];
+    const uint32_t n = min(*n_head, (uint32_t)HEAD_CAP);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)HEAD_CAP; i += 1024) s[i] = i < n ? head_term[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= (uint32_t)HEAD_CAP; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < (uint32_t)HEAD_CAP; i += 1024) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const uint32_t a = s[i], b = s[x];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)HEAD_CAP; i += 1024) {
+        const uint32_t t = s[i];
+        head_term[i] = t;
+        hs[i] = i < n ? term_ptr[t] : ~0ull;
+        he[i] = i < n ? term_ptr[t + 1] : ~0ull;
+    }
+    if (threadIdx.x == 0) *n_head = n;
+}
+// bounds[b][i] = lower bound of doc (b << shift) inside head list i, relative to the list's start; b = 0 .. nb
+__global__ void k_head_bounds(const uint32_t* __restrict__ post_doc, const uint32_t* __restrict__ n_head, const uint64_t* __restrict__ hs,
+                              const uint64_t* __restrict__ he, int shift, uint32_t nb, uint32_t* __restrict__ bounds) {
+    const uint32_t i = threadIdx.x + (blockIdx.x % (HEAD_CAP / 256)) * 256, b = blockIdx.x / (HEAD_CAP / 256);
+    if (i >= *n_head) return;
+    uint64_t lo = hs[i], hi = he[i];
+    const uint64_t target = (uint64_t)b << shift;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)post_doc[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    bounds[(size_t)b * HEAD_CAP + i] = (uint32_t)(lo - hs[i]);
+}
+// The head ranges that can overlap a chunk [base, base + n): a head list is longer than two chunks, so at most the one that
+// is running at `base` and the one that starts inside the chunk.  `cur` is the caller's cursor (first head range that
+// ends after `base`; only ever moves forward).  Everything here is uniform over the workgroup.
+struct HeadSkip {
+    uint64_t a_lo, a_hi, b_lo, b_hi;
+    __device__ __forceinline__ bool hit(uint64_t i) const { return (i >= a_lo && i < a_hi) || (i >= b_lo && i < b_hi); }
+};
+__device__ __forceinline__ HeadSkip head_skip(const HeadArgs& h, uint32_t nh, uint32_t& cur, uint64_t base) {
+    while (cur < nh && h.he[cur] <= base) cur++;
+    HeadSkip k;
+    k.a_lo = cur < nh ? h.hs[cur] : ~0ull;
+    k.a_hi = cur < nh ? h.he[cur] : ~0ull;
+    k.b_lo = cur + 1 < nh ? h.hs[cur + 1] : ~0ull;
+    k.b_hi = cur + 1 < nh ? h.he[cur + 1] : ~0ull;
+    return k;
+}
+__device__ __forceinline__ uint32_t head_first(const HeadArgs& h, uint32_t nh, uint64_t r0) {
+    uint32_t lo = 0, hi = nh;                                             // first range with he > r0
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (h.he[mid] <= r0) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 // Pass 1.  Block b owns the contiguous postings [b*per, (b+1)*per) (per is a multiple of the chunk sizes of both passes):
 // WEIGHT: w = tf*idf in place; the block's bucket histogram is kept in LDS over its whole range and written ONCE, as column
 // b of the [bucket][block] count matrix — no global atomics (the first version added every block's counts of every touched
@@ -177,7 +277,7 @@ template <bool WEIGHT>
 __global__ __launch_bounds__(TPB) void k_weight_count(const uint64_t* __restrict__ term_ptr, uint64_t n_terms,
                                                       const uint32_t* __restrict__ post_doc, float* __restrict__ post_w,
                                                       const float* __restrict__ idf, uint64_t n_post, uint64_t per, int shift, uint32_t nb,
-                                                      uint32_t nblk, uint32_t* __restrict__ mat) {
+                                                      uint32_t nblk, uint32_t* __restrict__ mat, HeadArgs head) {
     __shared__ uint32_t s_hist[NB_MAX];
     __shared__ uint32_t s_tp[WEIGHT ? WIN : 1];   // term_ptr[t0 + k] - base, clamped to [0, 2^32-1]: where the chunk's terms start
     __shared__ uint64_t s_t0;
@@ -192,9 +292,23 @@ __global__ __launch_bounds__(TPB) void k_weight_count(const uint64_t* __restrict
         }
         s_t0 = lo;
     }
+    const uint32_t nh = head.n ? *head.n : 0u;
+    uint32_t hcur = nh ? head_first(head, nh, r0) : 0u;
     __syncthreads();
     for (uint64_t base = r0; base < r1; base += CH) {
         const uint32_t n_here = (uint32_t)min((uint64_t)CH, r1 - base);
+        HeadSkip hk{~0ull, ~0ull, ~0ull, ~0ull};
+        if (nh) {
+            hk = head_skip(head, nh, hcur, base);
+            if (hk.a_lo <= base && hk.a_hi >= base + n_here) {            // the whole chunk belongs to a head list: nothing to do here
+                if (WEIGHT) {
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_t0 = head.term[hcur];         // where the next chunk's terms start
+                    __syncthreads();
+                }
+                continue;
+            }
+        }
         // every thread takes PER_THREAD CONSECUTIVE postings (vector loads), so it finds the term of its first posting
         // once and walks from there; the chunk's term starts are staged in LDS relative to `base`
         const uint32_t x0 = threadIdx.x * PER_THREAD;
@@ -257,6 +371,7 @@ __global__ __launch_bounds__(TPB) void k_weight_count(const uint64_t* __restrict
                 for (int j = 0; j < PER_THREAD; j++) {
                     const uint32_t x = x0 + j;
                     if (x >= n_here) continue;
+                    if (nh && hk.hit(i0 + j)) continue;                  // head posting: weighted by k_bucket_sum (w[j] goes back as it came)
                     while (k + 1 < need && s_tp[k + 1] <= x) k++;
                     t = t0 + k;
                     if (k + 1 >= need) {                              // past the staged window: rare (long runs of empty terms)
@@ -285,7 +400,7 @@ __global__ __launch_bounds__(TPB) void k_weight_count(const uint64_t* __restrict
             }
 #pragma unroll
             for (int j = 0; j < PER_THREAD; j++)
-                if (x0 + j < n_here) atomicAdd(&s_hist[doc[j] >> shift], 1u);
+                if (x0 + j < n_here && !(nh && hk.hit(i0 + j))) atomicAdd(&s_hist[doc[j] >> shift], 1u);
         }
         if (WEIGHT) __syncthreads();                                  // s_t0 / s_tp are rewritten by the next chunk
     }
@@ -361,7 +476,8 @@ constexpr int SC_BPT_MAX = NB_MAX / SC_TPB;
 inline size_t scatter_lds_bytes(uint32_t bpt) { return (size_t)SC_CH * 8 + (size_t)4 * bpt * SC_TPB * 4 + 64 + (size_t)SC_CH * 2; }
 __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post,
                                                  uint64_t per, int shift, uint32_t nb, uint32_t nblk, uint32_t bpt,
-                                                 const uint32_t* __restrict__ mat, const uint32_t* __restrict__ off, uint2* __restrict__ out) {
+                                                 const uint32_t* __restrict__ mat, const uint32_t* __restrict__ off, uint2* __restrict__ out,
+                                                 HeadArgs head) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_smem[];
     const uint32_t nbp = bpt * SC_TPB;
     uint2* const L_rec = reinterpret_cast<uint2*>(sc_smem);
@@ -380,11 +496,21 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
     // the next chunk's postings are requested before the current chunk goes through its LDS phases
     uint32_t ndoc[SC_PT];
     float nw[SC_PT];
+    // head lists are not partitioned (k_bucket_sum reads them in place): their postings count as absent here
+    const uint32_t nh = head.n ? *head.n : 0u;
+    uint32_t hcur = nh ? head_first(head, nh, r0) : 0u;
+    bool n_empty = false;                                                  // the fetched chunk holds head postings only (uniform)
     auto fetch = [&](uint64_t base) __attribute__((always_inline)) {
+        HeadSkip hk{~0ull, ~0ull, ~0ull, ~0ull};
+        n_empty = base >= r1;
+        if (nh && base < r1) {
+            hk = head_skip(head, nh, hcur, base);
+            n_empty = hk.a_lo <= base && hk.a_hi >= min(r1, base + SC_CH);
+        }
 #pragma unroll
         for (int j = 0; j < SC_PT; j++) {
             const uint64_t i = base + (uint64_t)j * SC_TPB + threadIdx.x;
-            const bool ok = i < r1;
+            const bool ok = !n_empty && i < r1 && !(nh && hk.hit(i));
             ndoc[j] = ok ? post_doc[i] : 0xFFFFFFFFu;
             nw[j] = ok ? post_w[i] : 0.f;
         }
@@ -396,7 +522,9 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
         float w[SC_PT];
 #pragma unroll
         for (int j = 0; j < SC_PT; j++) { doc[j] = ndoc[j]; w[j] = nw[j]; }
+        const bool empty = n_empty;
         fetch(base + SC_CH);
+        if (empty) continue;
         // (1) count; the returned value is the record's rank inside its bucket
 #pragma unroll
         for (int j = 0; j < SC_PT; j++) rank[j] = doc[j] != 0xFFFFFFFFu ? atomicAdd(&L_hist[doc[j] >> shift], 1u) : 0u;
@@ -444,7 +572,8 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
         }
         __syncthreads();
         // (4) out, in staging order: consecutive lanes write consecutive records of a bucket's run
-        const uint32_t n_here = (uint32_t)min((uint64_t)SC_CH, r1 - base);
+        // (the staged records end where the last bucket's run ends; head postings were never staged)
+        const uint32_t n_here = nh ? L_loff[nbp - 1] + (L_cur[nbp - 1] - L_gout[nbp - 1]) : (uint32_t)min((uint64_t)SC_CH, r1 - base);
         for (uint32_t pos = threadIdx.x; pos < n_here; pos += SC_TPB) {
             const uint32_t b = L_bkt[pos];
             out[(uint64_t)L_gout[b] + (pos - L_loff[b])] = L_rec[pos];
@@ -464,14 +593,25 @@ __global__ void k_sumsq_atomic(const uint32_t* __restrict__ post_doc, const floa
 }
 
 constexpr int TPB_B = 512;
+constexpr int HEAD_PIECE = 512;              // head postings a wave takes at a time
+inline size_t bucket_lds_bytes(int shift) { return ((size_t)1 << shift) * 8 + (size_t)(3 * HEAD_CAP + 4) * 4; }
+// One workgroup per bucket: float64 accumulators in LDS take (A) the bucket's partitioned records and (B) the bucket's run of
+// every head list, read in place — WEIGHT: tf in, w = tf*idf out (term_weighting.go:42), otherwise the weights as they stand.
+template <bool WEIGHT>
 __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ packed, const uint32_t* __restrict__ off, uint64_t n_docs,
-                                                      int shift, double* __restrict__ mag, double* __restrict__ mag2) {
-    extern __shared__ double acc[];                                    // [1 << shift]
+                                                      int shift, double* __restrict__ mag, double* __restrict__ mag2,
+                                                      const uint32_t* __restrict__ post_doc, float* __restrict__ post_w,
+                                                      const float* __restrict__ idf, HeadArgs head) {
+    extern __shared__ double acc[];                                    // [1 << shift], then the head run table
+    __shared__ uint32_t s_wsum[TPB_B / 64];
     const uint32_t bd = 1u << shift, b = blockIdx.x;
+    uint32_t* const pre = reinterpret_cast<uint32_t*>(acc + bd);       // [HEAD_CAP + 1] exclusive prefix of the run lengths
+    uint32_t* const r_pos = pre + HEAD_CAP + 4;                        // [HEAD_CAP] first posting of the run (the bucketed pass has P < 2^32)
+    float* const r_idf = reinterpret_cast<float*>(r_pos + HEAD_CAP);   // [HEAD_CAP] the list's idf
     for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) acc[i] = 0.0;
     __syncthreads();
     const uint32_t lo = off[b], hi = off[b + 1];
-    // 8 records per thread in flight (two workgroups of 512 per CU: 64 KB)
+    // (A) 8 records per thread in flight (two workgroups of 512 per CU)
     for (uint32_t i0 = lo; i0 < hi; i0 += 8 * TPB_B) {
         uint2 r[8];
 #pragma unroll
@@ -482,6 +622,86 @@ __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 8; u++)
             if (i0 + u * TPB_B + threadIdx.x < hi) atomicAdd(&acc[r[u].x & (bd - 1)], (double)__uint_as_float(r[u].y));   // :44 (float64 accumulate; LDS)
+    }
+    // (B) head lists
+    const uint32_t nh = head.n ? *head.n : 0u;
+    if (nh) {
+        const uint32_t* const b0 = head.bounds + (size_t)b * HEAD_CAP;
+        const uint32_t* const b1 = b0 + HEAD_CAP;
+        // exclusive prefix of the run lengths: HEAD_CAP / TPB_B consecutive lists per thread
+        constexpr int PT = HEAD_CAP / TPB_B;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        uint32_t len[PT], run = 0;
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+            const uint32_t i = threadIdx.x * PT + q;
+            const uint32_t lo_i = i < nh ? b0[i] : 0u;
+            len[q] = i < nh ? b1[i] - lo_i : 0u;
+            run += len[q];
+            if (i < nh) {
+                r_pos[i] = (uint32_t)(head.hs[i] + lo_i);
+                if (WEIGHT) r_idf[i] = idf[head.term[i]];
+            }
+        }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t o = incl - run;
+        for (int q = 0; q < wv; q++) o += s_wsum[q];
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+            pre[threadIdx.x * PT + q] = o;
+            o += len[q];
+        }
+        if (threadIdx.x == TPB_B - 1) pre[HEAD_CAP] = o;
+        __syncthreads();
+        const uint32_t total = pre[HEAD_CAP];
+        // the runs laid end to end are cut into pieces of HEAD_PIECE postings; wave w takes pieces w, w + 8, ...
+        for (uint32_t v0 = (uint32_t)wv * HEAD_PIECE; v0 < total; v0 += (TPB_B / 64) * HEAD_PIECE) {
+            const uint32_t v1 = min(total, v0 + (uint32_t)HEAD_PIECE);
+            uint32_t rl = 0, rh = nh;                                  // largest r with pre[r] <= v0
+            while (rh - rl > 1) {
+                const uint32_t mid = (rl + rh) >> 1;
+                if (pre[mid] <= v0) rl = mid; else rh = mid;
+            }
+            uint32_t v = v0;
+            for (uint32_t r = rl; r < nh && v < v1; r++) {
+                const uint32_t r_end = pre[r + 1];
+                if (r_end <= v) continue;                              // empty run
+                const uint32_t n = min(r_end, v1) - v;
+                const uint64_t s0 = (uint64_t)r_pos[r] + (v - pre[r]);
+                const float f = WEIGHT ? r_idf[r] : 1.f;
+                for (uint32_t j0 = 0; j0 < n; j0 += 256) {
+                    uint32_t d[4];
+                    float x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t j = j0 + u * 64 + lane;
+                        d[u] = j < n ? post_doc[s0 + j] : 0u;
+                        x[u] = j < n ? post_w[s0 + j] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t j = j0 + u * 64 + lane;
+                        if (j < n) {
+                            float w = x[u];
+                            if (WEIGHT) {
+                                w = w * f;                             // term_weighting.go:42
+                                post_w[s0 + j] = w;
+                            }
+                            const float sq = w * w;                    // :44 (float32 product)
+                            atomicAdd(&acc[d[u] & (bd - 1)], (double)sq);
+                        }
+                    }
+                }
+                v += n;
+            }
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) {
@@ -500,6 +720,9 @@ __global__ void k_sqrt(double* __restrict__ v, uint64_t n) {
 struct BucketPass {
     ss::DevBuf<uint32_t> mat, cnt, off, cur;
     ss::DevBuf<uint2> packed;
+    ss::DevBuf<uint32_t> h_n, h_term, h_bounds, h_hist;  // head lists (see HeadArgs)
+    ss::DevBuf<uint64_t> h_hs, h_he;
+    uint64_t head_thr = 0;                       // shortest list that takes the head path; 0 = no head path
     uint32_t nb = 0, nblk = 0, bpt = 1;
     uint64_t per = 0;
     int shift = 13;
@@ -510,7 +733,7 @@ int32_t bucket_pass_prepare(ss_ctx* ctx, uint64_t P, uint32_t nb, int shift, Buc
     // blocks own contiguous ranges whose length is a multiple of both passes' chunk sizes; ~1024 ranges
     const uint64_t unit = std::max<uint64_t>(SC_CH, CH);
     static_assert(SC_CH % CH == 0 || CH % SC_CH == 0, "a range must be whole chunks of both passes");
-    const uint64_t target_blocks = (uint64_t)std::max<int64_t>(1, ctx->opt("tfidf.blocks", 1024));
+    const uint64_t target_blocks = (uint64_t)std::max<int64_t>(1, ctx->opt("tfidf.blocks", 4096));
     bp.per = std::max<uint64_t>(unit, ss::div_up(ss::div_up(P, target_blocks), unit) * unit);
     bp.nblk = (uint32_t)ss::div_up(P, bp.per);
     SS_HIP(ctx, bp.mat.alloc((size_t)nb * bp.nblk));
@@ -518,29 +741,57 @@ int32_t bucket_pass_prepare(ss_ctx* ctx, uint64_t P, uint32_t nb, int shift, Buc
     SS_HIP(ctx, bp.off.alloc(nb + 1));
     SS_HIP(ctx, bp.cur.alloc(nb));
     SS_HIP(ctx, bp.packed.alloc(P));
+    // head lists: average run of at least "tfidf.head_min_run" postings per bucket (0 switches the head path off), and longer
+    // than two chunks of either pass (head_skip relies on it)
+    const int64_t min_run = ctx->opt("tfidf.head_min_run", 64);
+    bp.head_thr = min_run > 0 ? std::max<uint64_t>((uint64_t)min_run * nb, 2 * unit + 1) : 0;
+    if (bp.head_thr) {
+        SS_HIP(ctx, bp.h_n.alloc(1));
+        SS_HIP(ctx, bp.h_hist.alloc(HEAD_LEVELS));
+        SS_HIP(ctx, bp.h_term.alloc(HEAD_CAP));
+        SS_HIP(ctx, bp.h_hs.alloc(HEAD_CAP));
+        SS_HIP(ctx, bp.h_he.alloc(HEAD_CAP));
+        SS_HIP(ctx, bp.h_bounds.alloc((size_t)(nb + 1) * HEAD_CAP));
+    }
     bp.bpt = ss::div_up(nb, (uint32_t)SC_TPB);
     if (ctx->tfidf_scatter_lds < (int)scatter_lds_bytes(bp.bpt)) {
         SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(bp.bpt)));
         ctx->tfidf_scatter_lds = (int)scatter_lds_bytes(bp.bpt);
     }
-    if (ctx->tfidf_bucket_lds < (1 << shift) * 8) {
-        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << shift) * 8));
-        ctx->tfidf_bucket_lds = (1 << shift) * 8;
+    if (ctx->tfidf_bucket_lds < (int)bucket_lds_bytes(shift)) {
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_bytes(shift)));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_bytes(shift)));
+        ctx->tfidf_bucket_lds = (int)bucket_lds_bytes(shift);
     }
     return SS_OK;
 }
 // weight: also w = tf*idf in place (ss_tfidf_build); otherwise the magnitudes of the weights as they stand
 void bucket_pass_launch(ss_index* idx, hipStream_t st, BucketPass& bp, bool weight, const float* idf) {
     const uint64_t P = idx->n_post, N = idx->n_docs, T = idx->n_terms;
+    HeadArgs head{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (bp.head_thr && T) {
+        (void)hipMemsetAsync(bp.h_n.p, 0, sizeof(uint32_t), st);
+        (void)hipMemsetAsync(bp.h_hist.p, 0, HEAD_LEVELS * sizeof(uint32_t), st);
+        hipLaunchKernelGGL(k_head_hist, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p, T, bp.head_thr, bp.h_hist.p);
+        hipLaunchKernelGGL(k_head_select, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p, T, bp.head_thr, (const uint32_t*)bp.h_hist.p,
+                           bp.h_n.p, bp.h_term.p);
+        hipLaunchKernelGGL(k_head_sort, dim3(1), dim3(1024), 0, st, idx->term_ptr.p, bp.h_n.p, bp.h_term.p, bp.h_hs.p, bp.h_he.p);
+        hipLaunchKernelGGL(k_head_bounds, dim3((bp.nb + 1) * (HEAD_CAP / 256)), dim3(256), 0, st, (const uint32_t*)idx->post_doc.p, (const uint32_t*)bp.h_n.p,
+                           (const uint64_t*)bp.h_hs.p, (const uint64_t*)bp.h_he.p, bp.shift, bp.nb, bp.h_bounds.p);
+        head = HeadArgs{bp.h_n.p, bp.h_term.p, bp.h_hs.p, bp.h_he.p, bp.h_bounds.p};
+    }
     if (weight) hipLaunchKernelGGL(k_weight_count<true>, dim3(bp.nblk), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
-                                   idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p);
+                                   idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p, head);
     else hipLaunchKernelGGL(k_weight_count<false>, dim3(bp.nblk), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
-                            idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p);
+                            idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p, head);
     hipLaunchKernelGGL(k_bucket_rowscan, dim3(bp.nb), dim3(64), 0, st, bp.mat.p, bp.nblk, bp.cnt.p);
     hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, bp.cnt.p, bp.nb, bp.off.p, bp.cur.p);
     hipLaunchKernelGGL(k_scatter, dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.bpt), st, idx->post_doc.p, idx->post_w.p, P, bp.per, bp.shift, bp.nb,
-                       bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p);
-    hipLaunchKernelGGL(k_bucket_sum, dim3(bp.nb), dim3(TPB_B), (size_t)(1 << bp.shift) * 8, st, bp.packed.p, bp.off.p, N, bp.shift, idx->mag.p, idx->mag2.p);
+                       bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p, head);
+    if (weight) hipLaunchKernelGGL(k_bucket_sum<true>, dim3(bp.nb), dim3(TPB_B), bucket_lds_bytes(bp.shift), st, bp.packed.p, bp.off.p, N, bp.shift,
+                                   idx->mag.p, idx->mag2.p, (const uint32_t*)idx->post_doc.p, idx->post_w.p, idf, head);
+    else hipLaunchKernelGGL(k_bucket_sum<false>, dim3(bp.nb), dim3(TPB_B), bucket_lds_bytes(bp.shift), st, bp.packed.p, bp.off.p, N, bp.shift,
+                            idx->mag.p, idx->mag2.p, (const uint32_t*)idx->post_doc.p, idx->post_w.p, idf, head);
 }
 
 }  // namespace

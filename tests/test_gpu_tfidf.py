@@ -90,3 +90,25 @@ def test_bucketed_magnitude_pass(ss_ctx, oracle, n_docs, n_terms, n_post, total)
         assert np.array_equal(w.view(np.uint32), w_ref.view(np.uint32))
         assert np.array_equal(idf.view(np.uint32), idf_ref.view(np.uint32))
         assert np.array_equal(mag, mag_ref)
+
+
+@pytest.mark.parametrize("n_docs,n_terms,n_post", [(200_000, 60, 3_000_000), (100_000, 2000, 2_500_000), (80_000, 3, 240_000)])
+def test_head_lists_are_summed_in_place(ss_ctx, oracle, n_docs, n_terms, n_post):
+    """Long posting lists skip the partition: the bucket kernel reads bucket b's run of every head list straight from the table
+    and weights it on the way.  Which lists are head (option "tfidf.head_min_run": 0 = none, 1 = every list longer than two
+    chunks) only moves postings between two exact paths: weights, idf and magnitudes keep their bits — also for the
+    magnitudes-only pass (ss_index_refresh_magnitudes)."""
+    from spaghettisearch_amd import engine
+    tp, pd, tf = synth.zipf_index(n_docs, n_terms, n_post, seed=n_terms)
+    assert int(np.diff(tp.astype(np.int64)).max()) > 16385            # at least one list takes the head path
+    w_ref, mag_ref, idf_ref = oracle.tfidf(tp, pd, tf, n_docs, n_docs)
+    for min_run in (0, 1, 32):
+        ix = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
+        with ss_ctx.options(tfidf__bucket_min=1, tfidf__head_min_run=min_run):
+            w, mag, idf = ix.tfidf_build(n_docs)
+            mag2 = ix.refresh_magnitudes()
+        ix.close()
+        assert np.array_equal(w.view(np.uint32), w_ref.view(np.uint32)), min_run
+        assert np.array_equal(idf.view(np.uint32), idf_ref.view(np.uint32))
+        assert np.array_equal(mag, mag_ref), min_run
+        assert np.array_equal(mag2, mag_ref), min_run
