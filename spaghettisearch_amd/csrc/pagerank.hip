@@ -468,7 +468,9 @@ __global__ __launch_bounds__(TPB) void k_pr_step(PrParams p) {
 // replaces; every class alone was latency-bound (0.60 + 0.53 + 0.57 + 0.16 ms, tools/pr_kmask.sh).
 constexpr uint32_t SEGW = 2048;      // edges per V_SEG piece
 
-template <int GW>
+// TS: the state holds teleport sets (ss_pr_set_teleport).  A kernel of its own, so that the reference's path carries no
+// membership loads (a load under a branch in finish_row makes the compiler drain the loads in flight: s_waitcnt vmcnt(0)).
+template <int GW, bool TS>
 struct SweepCtx {
     const PrParams& p;
     const double* __restrict__ T;
@@ -503,12 +505,14 @@ __device__ __forceinline__ void gather_turn(const double* __restrict__ T, const 
     }
 }
 
-template <int GW>
-__device__ __forceinline__ void finish_row(SweepCtx<GW>& c, uint32_t lrow, double y, double xo, uint32_t od) {
+template <int GW, bool TS>
+__device__ __forceinline__ void finish_row(SweepCtx<GW, TS>& c, uint32_t lrow, double y, double xo, uint32_t od) {
     const PrParams& p = c.p;
     y += c.x0;
     const size_t xi = (size_t)lrow * GW + c.t;
-    double xn = (y + teleport_of(p, lrow, c.t)) / c.S;      // pagerank.go:117
+    double tele = p.teleport;
+    if constexpr (TS) tele = teleport_of(p, lrow, c.t);
+    double xn = (y + tele) / c.S;                             // pagerank.go:117
     if (c.act) {
         NT_STORE(xn, &p.x[xi]);
         c.dsum += fabs(xn - xo);                              // pagerank.go:118
@@ -525,8 +529,8 @@ __device__ __forceinline__ void finish_row(SweepCtx<GW>& c, uint32_t lrow, doubl
 // V_SEG / V_ROWW: the wave's items are long rows (or <= SEGW-edge pieces of the longest ones); turn i of an item
 // gives lane group s the edges beg + 64*i + 16*s ...  The pipeline runs across the items: the last turn of one item
 // requests the first index words of the next.
-template <int GW>
-__device__ __forceinline__ void long_rows(SweepCtx<GW>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1, int lane) {
+template <int GW, bool TS>
+__device__ __forceinline__ void long_rows(SweepCtx<GW, TS>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1, int lane) {
     constexpr int NS = 64 / GW;
     constexpr uint32_t TW = NS * CH;                          // edges per wave turn
     const PrParams& p = c.p;
@@ -591,8 +595,8 @@ __device__ __forceinline__ void long_rows(SweepCtx<GW>& c, const WorkItem* __res
 // is walked in nch (= item.nseg) turns (its own length decides how many slots of a turn are real).  The bounds and
 // out-degrees of ALL rows of an item come in one request (lane t of group s holds row `row + t*NS + s`), one item ahead;
 // the pipeline runs across row groups and items.
-template <int GW>
-__device__ __forceinline__ void quad_rows(SweepCtx<GW>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1) {
+template <int GW, bool TS>
+__device__ __forceinline__ void quad_rows(SweepCtx<GW, TS>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1) {
     constexpr int NS = 64 / GW;
     const PrParams& p = c.p;
     if (i0 >= i1) return;
@@ -666,8 +670,8 @@ __device__ __forceinline__ void quad_rows(SweepCtx<GW>& c, const WorkItem* __res
 
 // V_DEG: an item = `count` rows of exactly D (= item.nseg) in-edges from `row` (their edges are contiguous from item.beg);
 // a lane group takes R rows per turn, row r of the turn at slots r*DM .. r*DM+D-1 (DM = 16/R >= D)
-template <int GW, int R>
-__device__ __forceinline__ void deg_rows(SweepCtx<GW>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1) {
+template <int GW, int R, bool TS>
+__device__ __forceinline__ void deg_rows(SweepCtx<GW, TS>& c, const WorkItem* __restrict__ work, uint32_t i0, uint32_t i1) {
     constexpr int NS = 64 / GW;
     constexpr int DM = CH / R;
     constexpr int IR = CH / GW;
@@ -723,7 +727,7 @@ __device__ __forceinline__ void deg_rows(SweepCtx<GW>& c, const WorkItem* __rest
 #ifndef SS_PR_MINW
 #define SS_PR_MINW 1
 #endif
-template <int GW>
+template <int GW, bool TS>
 __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     constexpr int NS = 64 / GW;
     PrCtl* ctl = p.ctl;
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     const int sweep = ctl->sweep;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    SweepCtx<GW> c{p, p.tab_rd[sweep & 1], p.tab_wr[sweep & 1], 0.0, 0.0, false, lane % GW, lane - lane % GW, lane / GW, 0.0, 0.0};
+    SweepCtx<GW, TS> c{p, p.tab_rd[sweep & 1], p.tab_wr[sweep & 1], 0.0, 0.0, false, lane % GW, lane - lane % GW, lane / GW, 0.0, 0.0};
     c.S = ctl->S[c.t];
     c.act = ctl->active[c.t] != 0;
     c.x0 = sweep == 0 ? p.x0[c.t] : 0.0;      // Q4: iteration 1 accumulates onto 1/n
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
         const WorkItem w = p.work[item];
         // V_ZERO: non-dangling rows without in-edges: their rank is the shared value xz, only the next contribution
         // d*xz/outdeg has to be written (dangling ones need nothing at all); 16 rows per lane group and item at most
-        const bool ts = p.memb && ((p.ts_mask >> c.t) & 1u);
+        const bool ts = TS && p.memb && ((p.ts_mask >> c.t) & 1u);
         const double xz_out = c.act ? (ts ? zero_row_rank_ts(p, sweep, c.S, p.x0[c.t], 0.0) : zero_row_rank(p, sweep, c.S, p.x0[c.t])) : ctl->xz[c.t];
         const double xz_inn = ts ? (c.act ? zero_row_rank_ts(p, sweep, c.S, p.x0[c.t], p.tin[c.t]) : ctl->xz_in[c.t]) : xz_out;
         uint32_t od[16];
@@ -1089,12 +1093,15 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
 
 template <int GW>
 void launch_step(ss_pr* pr, hipStream_t st) {
-    if constexpr (GW >= 8) hipLaunchKernelGGL(k_pr_sweep<GW>, dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+    if constexpr (GW >= 8) {
+        if (pr->prm.memb) hipLaunchKernelGGL((k_pr_sweep<GW, true>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+        else hipLaunchKernelGGL((k_pr_sweep<GW, false>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+    }
     else hipLaunchKernelGGL(k_pr_step<GW>, dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
 }
 template <int GW>
 void sweep_occupancy(int* blocks_per_cu) {
-    if constexpr (GW >= 8) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_pr_sweep<GW>, TPB, 0);
+    if constexpr (GW >= 8) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_pr_sweep<GW, false>, TPB, 0);
     else *blocks_per_cu = 8;
 }
 template <int GW>
