@@ -259,10 +259,10 @@ def main() -> None:
                                "parallelism": "single GPU"},
                 })
                 ach = algo_bytes / (kern_ms * 1e-3) / 1e9
-                tr = profiled_traffic("k_pr_sweep") if (n, e, kt) == (10_000_000, 50_000_000, 16) else None
+                tr = profiled_traffic("k_pr_sweep<16") if (n, e, kt) == (10_000_000, 50_000_000, 16) else None
                 result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": ach / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
-                                      "kernel": (f"k_pr_step<{1 if kt == 1 else 2}>" if kt <= 2 else f"k_pr_sweep<{8 if kt <= 8 else 16}>"),
+                                      "kernel": (f"k_pr_step<{1 if kt == 1 else 2}>" if kt <= 2 else f"k_pr_sweep<{8 if kt <= 8 else 16}, false>"),
                                       "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes}
                 if tr:
                     result["roofline"]["traffic_detail"] = tr
@@ -618,10 +618,14 @@ def main() -> None:
             algo_tw = 12 * Pb + 8 * nt + 8 * nd         # SURVEY.md §8d B_tw = 12P + 8T + 8N (body table)
             ach_tw = algo_tw / (tfidf_ms * 1e-3) / 1e9
             tw_traffic = None
+            sc_traffic = None
             if full:
                 parts = [profiled_traffic(kn) for kn in ("k_weight_count", "k_scatter", "k_bucket_sum")]
                 if all(parts):
                     tw_traffic = sum(p["bytes"] for p in parts)
+                parts = [profiled_traffic(kn) for kn in ("k_wave_prep", "k_score_wave", "k_merge_flat")]
+                if all(parts):
+                    sc_traffic = sum(p["bytes"] for p in parts)
             topk = {"metric": "topk_queries_per_sec", "value": world * nq * K / dt, "unit": "queries/s",
                     "ms_per_step": dt * 1e3 / K, "ms_per_step_blocks": summarize(blocks), "scaling": "weak",
                     "config": {"workload": f"{nd} docs / {nt} terms, body P={Pb}, title P={Pt}, {nq} x 3-term OR queries "
@@ -630,13 +634,13 @@ def main() -> None:
                                "parallelism": "single GPU" if world == 1 else f"query-split replicas x{world}"},
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": (profiled_traffic("k_score") or {}).get("bytes") if full else None,
-                                 "kernel": "scoring kernels of one batch (slices + merge)",
+                                 "traffic": sc_traffic,
+                                 "kernel": "scoring kernels of one batch (k_wave_prep + k_score_wave + k_merge_flat)",
                                  "kernel_ms": kern_ms, "kernel_ms_min": min(kms), "algorithmic_bytes": algo_q},
                     "tfidf": {"ms": tfidf_ms, "title_ms": tfidf_title_ms,
                               "what": "ss_tfidf_build of the body table: device time between HIP events (allocations outside)",
                               "roofline": {"bound": "hbm", "achieved": ach_tw, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_tw / HBM_PEAK_GBS,
-                                           "traffic": tw_traffic, "kernel": "k_idf+k_weight_count+k_scatter+k_bucket_sum",
+                                           "traffic": tw_traffic, "kernel": "k_idf + head-list set-up + k_weight_count + k_scatter + k_bucket_sum",
                                            "kernel_ms": tfidf_ms, "algorithmic_bytes": algo_tw}},
                     "tfidf_build_ms": tfidf_ms, "scorer_create_ms": scorer_create_ms,
                     "queries_per_sec_host_in_host_out": nq * K / dt_pcie}

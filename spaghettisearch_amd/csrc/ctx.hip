@@ -73,12 +73,26 @@ void pool_free(void* p) {
         if (cur != dev) (void)hipSetDevice(dev);
         (void)hipDeviceSynchronize();
         if (cur != dev) (void)hipSetDevice(cur);
-        std::lock_guard<std::mutex> lk(P.mu);
-        if (P.held + cls <= P.limit) {
-            P.free_blocks.emplace(std::make_pair(dev, cls), p);
-            P.held += cls;
-            return;
+        // over the limit: the LARGEST held blocks make room (a few big tables of an earlier, larger job must not keep every
+        // small block of the current one out of the pool: that cost config 2's create + run 2 ms after config 4 had run)
+        std::vector<void*> evict;
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            while (P.held + cls > P.limit && !P.free_blocks.empty()) {
+                auto last = std::prev(P.free_blocks.end());
+                if (last->first.second <= cls) break;                   // nothing larger than the newcomer is held
+                evict.push_back(last->second);
+                P.held -= last->first.second;
+                P.free_blocks.erase(last);
+            }
+            if (P.held + cls <= P.limit) {
+                P.free_blocks.emplace(std::make_pair(dev, cls), p);
+                P.held += cls;
+                p = nullptr;
+            }
         }
+        for (void* q : evict) (void)hipFree(q);
+        if (!p) return;
     }
     (void)hipFree(p);
 }
@@ -214,6 +228,7 @@ static const char* const k_option_names[] = {
     "tfidf.head_min_run",   // head lists (summed bucket-major in place): average postings per bucket run, 0 = off (default 64)
     "tfidf.bucket_min",     // smallest table (postings) that takes the bucketed pass (default 4M)
     "score.wave",           // 0: never use the wave-per-slice kernel k_score_wave
+    "score.wave_min_list",  // a query suits k_score_wave if EVERY list of it has this many x k' postings (k' = k rounded up to 2^j; default 16)
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
     "score.exact_all",      // 1: switch the upper-bound filter off (every record takes the exact stage)
     "score.slice_target",   // postings per (query, slice) workgroup (default: from the batch)

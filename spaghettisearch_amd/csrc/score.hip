@@ -1643,6 +1643,40 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         wave_target = std::min<uint64_t>(49152, std::max<uint64_t>(8192, batch_tot / (4 * slots)));
         wave_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.wave_slice_target", (int64_t)wave_target));
     }
+    // Which queries suit k_score_wave: no phrase part, few lists, a list long enough for the threshold floor (k'-th largest
+    // impact, k' = k rounded up to 2^j) to exist — and EVERY list long enough for that floor to be selective: the k'-th largest of
+    // n impacts lets k'/n of a list's records through until the real threshold has risen (measured: batches of term ranks
+    // U[1,100k] — long and short lists mixed — ran 3.5x slower here than in k_score_slices, with 100x the overflow events per
+    // slice).  Option "score.wave_min_list" x k' postings (default 16; 0 = no such demand: tests reach the kernel with small tables).
+    // The kernel is taken per BATCH: two scoring kernels one after the other each pay their ramp-up and tail (a batch split
+    // between them measured slower than either alone), so it runs only when the queries it suits carry 90 % of the batch.
+    const int64_t wml = std::max<int64_t>(0, ctx->opt("score.wave_min_list", 16));
+    const uint64_t wave_min_list = (uint64_t)wml << kth_j;
+    std::vector<uint8_t> h_suits(n_q, 0);
+    bool batch_wave = false;
+    if (wave_ok) {
+        uint64_t fit = 0, all = 0;
+        for (int q = 0; q < n_q; q++) {
+            uint64_t tot = 0, shortest = ~0ull, longest = 0;
+            uint32_t n_known = 0;
+            for (uint32_t i = h_qptr[q]; i < h_qptr[q + 1]; i++) {
+                const uint32_t t = h_terms[i];
+                if ((uint64_t)t >= s->n_terms) continue;
+                n_known++;
+                tot += (tp[t + 1] - tp[t]) + (bp[t + 1] - bp[t]);
+                const uint64_t len = std::max(tp[t + 1] - tp[t], bp[t + 1] - bp[t]);
+                shortest = std::min(shortest, len);
+                longest = std::max(longest, len);
+            }
+            all += tot;
+            const bool phrase_q = p_ptr && h_pptr[q + 1] > h_pptr[q];
+            if (n_known && !phrase_q && longest >= (uint64_t)4 * (uint64_t)k && longest >= 1024 && shortest >= wave_min_list) {
+                h_suits[q] = 1;
+                fit += tot;
+            }
+        }
+        batch_wave = wml == 0 ? fit > 0 : (fit * 10 >= all * 9 && all > 0);
+    }
     std::vector<uint8_t> h_fast(n_q, 0);
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
     std::vector<double> h_qmag(n_q), h_ub(n_q, 0.0);
@@ -1682,12 +1716,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         uint64_t q_target = std::min<uint64_t>(slice_target, plan_cap);
         uint64_t max_slices = MAX_SLICES_PER_Q;
         {
-            uint64_t longest = 0;
-            for (size_t j = d0; j < h_dterm.size(); j++)
-                longest = std::max<uint64_t>(longest, std::max(tp[h_dterm[j] + 1] - tp[h_dterm[j]], bp[h_dterm[j] + 1] - bp[h_dterm[j]]));
-            const bool phrase_q = p_ptr && h_pptr[q + 1] > h_pptr[q];
-            if (wave_ok && !phrase_q && h_dterm.size() > d0 && (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists() &&
-                longest >= (uint64_t)4 * (uint64_t)k && longest >= 1024) {
+            if (batch_wave && h_suits[q] && h_dterm.size() > d0 && (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists()) {
                 h_fast[q] = 1;
                 q_target = wave_target;
                 max_slices = 4096;

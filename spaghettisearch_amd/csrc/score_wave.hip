@@ -509,7 +509,11 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const uint32_t* c_skip, ui
     const uint32_t rem = w.active && lane < L ? w.ge - w.cg + 1u : 0u;
     const uint32_t tot_rem = wave_sum(rem);
     uint32_t ql = 0;
-    if (rem > 1) ql = min(rem - 1u, max(1u, (uint32_t)(((uint64_t)(WSE - WL) * rem) / tot_rem)));
+    // At least TWO entries of every list that has them: a round that ended at a block boundary of this list starts the next
+    // one with its first staged entry EQUAL to F; with that entry alone the list's "last staged entry" is F again, the round
+    // ends where it began and the wave never returns (seen with slices above 32k postings: a list a hundred times sparser
+    // than its neighbours was given one entry per round).  Entries of a list are strictly increasing, so the second is > F.
+    if (rem > 1) ql = min(rem - 1u, max(2u, (uint32_t)(((uint64_t)(WSE - WL) * rem) / tot_rem)));
     w.q = ql;
     w.soff = wave_excl_scan(ql, lane);
     for (int l = 0; l < L; l++) {
@@ -521,6 +525,7 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const uint32_t* c_skip, ui
     uint32_t last = WINF;
     if (rem && w.cg + w.q < w.ge) last = se[w.soff + w.q - 1u];
     uint32_t e = min(wave_min(last), dhi);
+    e = max(e, F + 1u);                                // whatever happens above, a round makes progress (F < dhi: the caller's loop condition)
     // driver = the list with the most staged entries; a window = s of its blocks
     const uint32_t dkey = wave_max((w.q << 6) | (uint32_t)(63 - lane));
     const int drv = 63 - (int)(dkey & 63u);

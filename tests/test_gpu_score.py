@@ -339,3 +339,65 @@ def test_fused_and_separate_merge_agree(ss_ctx, oracle):
                 assert np.array_equal(n, n0) and h.tobytes() == h0.tobytes()
     finally:
         close_all(sc, ti, bi)
+
+
+def _lists_table(lists, seed):
+    ptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+    doc = np.concatenate(lists).astype(np.uint32)
+    return ptr, doc, synth.make_tf(len(doc), np.random.default_rng(seed))
+
+
+@pytest.mark.parametrize("wave_target", [None, 1024, 40000])
+def test_wave_kernel_forced_on_small_tables(ss_ctx, oracle, wave_target):
+    """k_score_wave (one wave per slice) takes a batch only when its queries suit it, which at test sizes they do not; option
+    "score.wave_min_list" = 0 drops the demand on list lengths so that the kernel runs here — whatever the slice size — and must
+    agree with the oracle and with k_score_slices ("score.wave" = 0) bit for bit, with and without the PageRank blend."""
+    n_docs, n_terms = 300000, 20000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 6000000, 400000, seed=44)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        q_ptr, q_terms = synth.make_queries(192, 3, 300, seed=46)              # every list > 1024 postings
+        rng = np.random.default_rng(3)
+        prior = rng.random((4, n_docs)) * 1e-3
+        probs = rng.dirichlet(np.ones(4), size=192)
+        for blend in (False, True):
+            sc.set_prior(prior if blend else None)
+            kw = {"topic_probs": probs} if blend else {}
+            ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, 100,
+                                                 **({"prior": np.ascontiguousarray(prior.T), "topic_probs": probs} if blend else {}))
+            with ss_ctx.options(score__wave_min_list=0, score__wave_slice_target=wave_target):
+                hits, n_hits = sc.score_topk(q_ptr, q_terms, 100, **kw)
+            with ss_ctx.options(score__wave=0):
+                hits0, n0 = sc.score_topk(q_ptr, q_terms, 100, **kw)
+            assert_same_hits(hits, n_hits, ref, ref_n)
+            assert hits.tobytes() == hits0.tobytes() and n_hits.tolist() == n0.tolist()
+    finally:
+        close_all(sc, ti, bi)
+
+
+def test_wave_round_makes_progress_beside_much_denser_lists(ss_ctx, oracle):
+    """Regression: a list a hundred times sparser than its neighbours got ONE skip entry per planning round; after a round that
+    ended at one of its block boundaries that entry equalled the round's start, the round ended where it began and the wave
+    never returned (config-3 index, term ranks U[1,3000], slices above 32k postings).  Dense + sparse lists, large slices."""
+    n_docs = 2_000_000
+    rng = np.random.default_rng(21)
+    dense1 = np.sort(rng.choice(n_docs, 500_000, replace=False)).astype(np.uint32)
+    dense2 = np.sort(rng.choice(n_docs, 450_000, replace=False)).astype(np.uint32)
+    sparse = np.sort(rng.choice(n_docs, 6_000, replace=False)).astype(np.uint32)
+    mid = np.sort(rng.choice(n_docs, 40_000, replace=False)).astype(np.uint32)
+    bt = _lists_table([dense1, dense2, sparse, mid], 1)
+    tt = _lists_table([dense1[::9], dense2[::11], sparse[::2], mid[::5]], 2)
+    wb, mb, _ = oracle.tfidf(*bt, n_docs, n_docs)
+    wt, mt, _ = oracle.tfidf(*tt, n_docs, n_docs)
+    title, body = (tt[0], tt[1], wt), (bt[0], bt[1], wb)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        q_terms = np.array([0, 1, 2, 0, 2, 3, 1, 2, 0, 1, 3], dtype=np.uint32)
+        q_ptr = np.array([0, 3, 6, 8, 11], dtype=np.uint32)
+        ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, 100)
+        for target in (40000, 49152, 12000):
+            with ss_ctx.options(score__wave_min_list=0, score__wave_slice_target=target):
+                hits, n_hits = sc.score_topk(q_ptr, q_terms, 100)
+            assert_same_hits(hits, n_hits, ref, ref_n)
+    finally:
+        close_all(sc, ti, bi)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc_pr2.sh "<counters>" tag   -- rocprofv3 --pmc over tools/pr_exp.py (R=3), per-dispatch medians for k_pr_sweep<16> and k_pr_probe<16>
+# usage: tools/pmc_pr2.sh "<counters>" tag   -- rocprofv3 --pmc over tools/pr_exp.py (R=3), per-dispatch medians for k_pr_sweep<16, false> and k_pr_probe<16, .>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmcpr_$2
 rm -rf $out
@@ -12,8 +12,8 @@ if not f:
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 for row in csv.DictReader(open(f[0])):
     k = row["Kernel_Name"]
-    if "k_pr_sweep<16>" in k: k = "step"
-    elif "k_pr_probe<16>" in k: k = "probe"
+    if "k_pr_sweep<16" in k: k = "step"
+    elif "k_pr_probe<16" in k: k = "probe"
     else: continue
     per[(k, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
 for (k, c), d in sorted(per.items()):

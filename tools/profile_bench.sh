@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{out}/{tag}_{c}/**/*counter_collection.csv", recursive=True)
     per = collections.defaultdict(lambda: collections.defaultdict(float))       # kernel -> dispatch -> sum over instances
     for r in csv.DictReader(open(f[0])):
-        m = re.search(r"(k_\w+(?:<\d+>)?)", r["Kernel_Name"])
+        m = re.search(r"(k_\w+(?:<[\w, ]+>)?)", r["Kernel_Name"])
         if not m or r["Counter_Name"] != c:
             continue
         per[m.group(1)][r["Dispatch_Id"]] += float(r["Counter_Value"])
