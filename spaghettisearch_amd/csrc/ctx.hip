@@ -228,6 +228,7 @@ static const char* const k_option_names[] = {
     "tfidf.head_min_run",   // head lists (summed bucket-major in place): average postings per bucket run, 0 = off (default 64)
     "tfidf.bucket_min",     // smallest table (postings) that takes the bucketed pass (default 4M)
     "score.wave",           // 0: never use the wave-per-slice kernel k_score_wave
+    "score.wave_max_terms", // a query suits k_score_wave if it has at most this many terms (default 6, at most 12)
     "score.wave_min_list",  // a query suits k_score_wave if EVERY list of it has this many x k' postings (k' = k rounded up to 2^j; default 16)
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
     "score.exact_all",      // 1: switch the upper-bound filter off (every record takes the exact stage)

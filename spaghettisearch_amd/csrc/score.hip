@@ -1650,6 +1650,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // slice).  Option "score.wave_min_list" x k' postings (default 16; 0 = no such demand: tests reach the kernel with small tables).
     // The kernel is taken per BATCH: two scoring kernels one after the other each pay their ramp-up and tail (a batch split
     // between them measured slower than either alone), so it runs only when the queries it suits carry 90 % of the batch.
+    // ... and few lists: a window is cut so that its blocks number 16 - 3 - (lists), every list adding a boundary block; with
+    // 12 dense lists a window is one driver block and most windows overflow into the slow path (soak on the config-3 index,
+    // wave / slices time: 0.4-0.9 at <= 5 terms, 1.0-1.1 at 9, 2-3 at 12).  Option "score.wave_max_terms", default 6.
+    const uint32_t wave_max_terms = (uint32_t)std::min<int64_t>(ss::score_wave_max_lists(), std::max<int64_t>(1, ctx->opt("score.wave_max_terms", 6)));
     const int64_t wml = std::max<int64_t>(0, ctx->opt("score.wave_min_list", 16));
     const uint64_t wave_min_list = (uint64_t)wml << kth_j;
     std::vector<uint8_t> h_suits(n_q, 0);
@@ -1670,7 +1674,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
             }
             all += tot;
             const bool phrase_q = p_ptr && h_pptr[q + 1] > h_pptr[q];
-            if (n_known && !phrase_q && longest >= (uint64_t)4 * (uint64_t)k && longest >= 1024 && shortest >= wave_min_list) {
+            // (n_known counts duplicate tokens too: an upper bound of the distinct terms, good enough for the choice)
+            if (n_known && n_known <= wave_max_terms && !phrase_q && longest >= (uint64_t)4 * (uint64_t)k && longest >= 1024 &&
+                shortest >= wave_min_list) {
                 h_suits[q] = 1;
                 fit += tot;
             }

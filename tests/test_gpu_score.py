@@ -401,3 +401,22 @@ def test_wave_round_makes_progress_beside_much_denser_lists(ss_ctx, oracle):
             assert_same_hits(hits, n_hits, ref, ref_n)
     finally:
         close_all(sc, ti, bi)
+
+
+def test_wave_kernel_forced_many_terms(ss_ctx, oracle):
+    """Queries of up to 12 distinct terms in k_score_wave (by default it takes queries of at most 6: more lists leave a window
+    one driver block and most windows go through the slow path — slower, but it must still be exact), duplicates included."""
+    n_docs, n_terms = 300000, 20000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 6000000, 400000, seed=44)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        rng = np.random.default_rng(17)
+        lens = rng.integers(7, 15, size=48)
+        q_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        q_terms = rng.integers(0, 200, size=int(lens.sum())).astype(np.uint32)        # head terms, some drawn twice
+        ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, 50)
+        with ss_ctx.options(score__wave_min_list=0, score__wave_max_terms=12):
+            hits, n_hits = sc.score_topk(q_ptr, q_terms, 50)
+        assert_same_hits(hits, n_hits, ref, ref_n)
+    finally:
+        close_all(sc, ti, bi)
