@@ -532,47 +532,89 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const uint32_t* c_skip, ui
     const uint32_t q_drv = dkey >> 6, tot_q = wave_sum(w.q);
     const uint32_t so_drv = rl(w.soff, drv);
     const int l_act = __popcll(act_mask);
-    // A window = s driver blocks: expected blocks of a window = s * tot_q / q_drv + one boundary block per other list;
-    // aim SSW_SLACK below WCW: the other lists' counts fluctuate, and a window with more than WCW blocks takes the slow
-    // path, which costs far more than the block slots left empty (measured at config 3: slack 0 / 1 / 2 / 3 blocks ->
-    // 0.81 / 0.67 / 0.67 / 0.66 ms per batch; a fractional s with the same slack is no better).
+    // BASE windows of s driver blocks each (lane j: [B_j, B_j+1)), about half a row's worth; then consecutive base windows are
+    // packed into ONE window as long as the EXACT block count — known here from the staged skip entries — fits a row of WCW
+    // blocks.  (The first version cut windows of a fixed stride aimed SSW_SLACK blocks below WCW, because a window above WCW
+    // takes the slow path: rows were 64 % full at config 3, and every slot of a row costs its load, its wait and its filter code
+    // whether it holds a block or not.)
     uint32_t s = 1;
-    if (q_drv) s = max(1u, (uint32_t)(((uint64_t)(WCW - SSW_SLACK > l_act ? WCW - SSW_SLACK - l_act : 1) * q_drv) / max(tot_q, 1u)));
+    if (q_drv) s = max(1u, (uint32_t)(((uint64_t)(WCW > l_act ? WCW - l_act : 1) * q_drv) / max(tot_q, 1u)) / 2u);
     const uint32_t nd_e = q_drv ? lds_lower_bound(se + so_drv, q_drv, e) : 0u;      // driver blocks that start inside (F, e)
     uint32_t nw = nd_e / s + 1u;
     if (nw > 63u) { nw = 63u; e = se[so_drv + 63u * s - 1u]; }
     // lane j <= nw: boundary B_j (B_0 = F, B_nw = e)
     uint32_t Bj = WINF;
     if ((uint32_t)lane <= nw) Bj = lane == 0 ? F : ((uint32_t)lane == nw ? e : se[so_drv + (uint32_t)lane * s - 1u]);
-    // per list: blocks [first, first + num) of window j, relative to the list's cursor block
-    uint32_t fst[WL], num[WL];
+    // per list: entries < B_j (= first block of base window j, relative to the list's cursor block; also the cursor advance if the
+    // round ends at B_j), and the blocks of base window j
+    uint32_t fst[WL];
     uint32_t cnt = 0;
 #pragma unroll
     for (int l = 0; l < WL; l++) {
-        fst[l] = 0; num[l] = 0;
+        fst[l] = 0;
         if (l < L && ((act_mask >> l) & 1ull)) {
             const uint32_t n = rl(w.q, l), so = rl(w.soff, l);
             // Block i of the list (0 = the cursor block) holds docs from its first doc (the entry before E[i]) up to E[i]
             // INCLUSIVE: in a combined list the body and the title posting of one doc may sit on either side of a block
-            // boundary.  So the blocks of [B_j, B_j+1) are i = (entries < B_j) .. (entries < B_j+1).
+            // boundary.  So the blocks of [B_a, B_b) are i = (entries < B_a) .. (entries < B_b).
             const uint32_t lb = (uint32_t)lane <= nw ? lds_lower_bound(se + so, n, Bj) : 0u;     // entries < B_j
             const uint32_t lb_next = (uint32_t)__shfl_down((int)lb, 1, 64);
-            fst[l] = lb;                                                                       // also: cursor advance if the round ends at B_j
-            num[l] = (uint32_t)lane < nw ? lb_next - lb + 1u : 0u;
+            fst[l] = lb;
+            cnt += (uint32_t)lane < nw ? lb_next - lb + 1u : 0u;
+        }
+    }
+    // packing: a run of base windows a..b holds sum(cnt) - (b - a) * l_act blocks (the boundary block of every list is
+    // counted by both neighbours).  Greedy from the left; a base window that is oversize on its own stays alone.
+    const uint32_t la = (uint32_t)l_act;
+    const uint32_t pre = wave_excl_scan((uint32_t)lane < nw ? cnt - la : 0u, lane);                // lane nw: the total
+    // run_end (every lane a: where the run that STARTS at a ends): the largest t in [a + 1, nw] with pre[t] <= pre[a] + WCW - l_act,
+    // by a lane-parallel binary search over the other lanes' prefix values (six shuffles); the leaders are then reached by
+    // following a -> run_end(a) + 1 from window 0 (one readlane per run; a scalar scan over all base windows cost 14k cycles a round)
+    uint32_t run_end;
+    {
+        const uint32_t limit = pre + (uint32_t)WCW - min(la, (uint32_t)WCW);
+        uint32_t lo = (uint32_t)lane + 1u, hi = max(nw, (uint32_t)lane + 1u);
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            const uint32_t v = (uint32_t)__shfl((int)pre, (int)min(mid, 63u), 64);
+            if (lo < hi) { if (v <= limit) lo = mid; else hi = mid - 1u; }
+        }
+        run_end = lo - 1u;
+    }
+    unsigned long long leaders = 0ull;
+    for (uint32_t a = 0; a < nw; a = rl(run_end, (int)a) + 1u) leaders |= 1ull << a;
+    bool leader = ((leaders >> lane) & 1ull) != 0ull;
+    // a leader's window: [B_a, B_{end+1})
+    uint32_t num[WL];
+    cnt = 0;
+    const int nxt_lane = (int)(leader ? run_end + 1u : (uint32_t)lane);
+#pragma unroll
+    for (int l = 0; l < WL; l++) {
+        num[l] = 0;
+        if (l < L && ((act_mask >> l) & 1ull)) {
+            const uint32_t lb_end = (uint32_t)__shfl((int)fst[l], nxt_lane, 64);
+            num[l] = leader ? lb_end - fst[l] + 1u : 0u;
             cnt += num[l];
         }
     }
+    const uint32_t b_hi = (uint32_t)__shfl((int)Bj, nxt_lane, 64);
     // rows: one per regular window; an oversize window takes ceil(cnt / WCW) rows (its block list, walked by the slow path)
-    const uint32_t rows = (uint32_t)lane < nw ? (cnt + WCW - 1) / WCW : 0u;
+    uint32_t rows = leader ? (cnt + WCW - 1) / WCW : 0u;
     const uint32_t roff = wave_excl_scan(rows, lane);
     {
-        // windows 0 .. nw2-1 fit (roff is monotone, so the fitting windows are a prefix; one window alone always fits)
-        const uint32_t nw2 = (uint32_t)__popcll(__ballot((uint32_t)lane < nw && roff + rows <= (uint32_t)WGMAX));
-        if (nw2 < nw) { nw = max(nw2, 1u); e = rl(Bj, (int)nw); }
+        // the windows that fit the row table are a prefix (roff is monotone; one window alone always fits)
+        const unsigned long long bad = __ballot(leader && roff + rows > (uint32_t)WGMAX);
+        if (bad) {
+            uint32_t cut = (uint32_t)__ffsll((long long)bad) - 1u;                 // base window at which the first run that does not fit starts
+            if (cut == 0u) cut = rl(run_end, 0) + 1u;
+            nw = cut;
+            e = rl(Bj, (int)nw);
+            if ((uint32_t)lane >= nw) { leader = false; rows = 0; }
+        }
     }
-    const uint32_t n_rows = rl(roff + rows, (int)nw - 1);
-    const uint32_t b_hi = (uint32_t)__shfl_down((int)Bj, 1, 64);
-    if ((uint32_t)lane < nw) {
+    const uint32_t n_rows = wave_sum(rows);
+    if (leader) {
         uint32_t n = 0;
         const uint32_t row0 = roff;
 #pragma unroll
