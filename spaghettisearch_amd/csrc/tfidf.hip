@@ -593,7 +593,18 @@ __global__ void k_sumsq_atomic(const uint32_t* __restrict__ post_doc, const floa
 }
 
 constexpr int TPB_B = 512;
-constexpr int HEAD_PIECE = 512;              // head postings a wave takes at a time
+#ifndef SS_HEAD_PIECE
+#define SS_HEAD_PIECE 2048
+#endif
+#ifndef SS_HEAD_U
+#define SS_HEAD_U 16
+#endif
+#ifndef SS_BS_U
+#define SS_BS_U 8
+#endif
+constexpr int BS_U = SS_BS_U;                // partitioned records of a thread in flight
+constexpr int HEAD_PIECE = SS_HEAD_PIECE;    // head postings a wave takes at a time
+constexpr int HEAD_U = SS_HEAD_U;            // loads of a lane in flight per array (4: 1.19 ms for the head part of the 641M table, 8: see DESIGN)
 inline size_t bucket_lds_bytes(int shift) { return ((size_t)1 << shift) * 8 + (size_t)(3 * HEAD_CAP + 4) * 4; }
 // One workgroup per bucket: float64 accumulators in LDS take (A) the bucket's partitioned records and (B) the bucket's run of
 // every head list, read in place — WEIGHT: tf in, w = tf*idf out (term_weighting.go:42), otherwise the weights as they stand.
@@ -611,16 +622,16 @@ __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ 
     for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) acc[i] = 0.0;
     __syncthreads();
     const uint32_t lo = off[b], hi = off[b + 1];
-    // (A) 8 records per thread in flight (two workgroups of 512 per CU)
-    for (uint32_t i0 = lo; i0 < hi; i0 += 8 * TPB_B) {
-        uint2 r[8];
+    // (A) BS_U records per thread in flight (two workgroups of 512 per CU)
+    for (uint32_t i0 = lo; i0 < hi; i0 += BS_U * TPB_B) {
+        uint2 r[BS_U];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < BS_U; u++) {
             const uint32_t i = i0 + u * TPB_B + threadIdx.x;
             r[u] = i < hi ? packed[i] : make_uint2(0u, 0u);            // a zero square adds nothing
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < BS_U; u++)
             if (i0 + u * TPB_B + threadIdx.x < hi) atomicAdd(&acc[r[u].x & (bd - 1)], (double)__uint_as_float(r[u].y));   // :44 (float64 accumulate; LDS)
     }
     // (B) head lists
@@ -676,17 +687,17 @@ __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ 
                 const uint32_t n = min(r_end, v1) - v;
                 const uint64_t s0 = (uint64_t)r_pos[r] + (v - pre[r]);
                 const float f = WEIGHT ? r_idf[r] : 1.f;
-                for (uint32_t j0 = 0; j0 < n; j0 += 256) {
-                    uint32_t d[4];
-                    float x[4];
+                for (uint32_t j0 = 0; j0 < n; j0 += HEAD_U * 64) {
+                    uint32_t d[HEAD_U];
+                    float x[HEAD_U];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < HEAD_U; u++) {
                         const uint32_t j = j0 + u * 64 + lane;
                         d[u] = j < n ? post_doc[s0 + j] : 0u;
                         x[u] = j < n ? post_w[s0 + j] : 0.f;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < HEAD_U; u++) {
                         const uint32_t j = j0 + u * 64 + lane;
                         if (j < n) {
                             float w = x[u];
