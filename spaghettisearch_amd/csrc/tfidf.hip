@@ -592,7 +592,10 @@ __global__ void k_sumsq_atomic(const uint32_t* __restrict__ post_doc, const floa
     }
 }
 
-constexpr int TPB_B = 512;
+#ifndef SS_TPB_B
+#define SS_TPB_B 1024
+#endif
+constexpr int TPB_B = SS_TPB_B;
 #ifndef SS_HEAD_PIECE
 #define SS_HEAD_PIECE 2048
 #endif
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(TPB_B) void k_bucket_sum(const uint2* __restrict__ 
     for (uint32_t i = threadIdx.x; i < bd; i += TPB_B) acc[i] = 0.0;
     __syncthreads();
     const uint32_t lo = off[b], hi = off[b + 1];
-    // (A) BS_U records per thread in flight (two workgroups of 512 per CU)
+    // (A) BS_U records per thread in flight (two workgroups of 1024 per CU: 512 threads each measured 6.8 ms for the build, 1024 6.3)
     for (uint32_t i0 = lo; i0 < hi; i0 += BS_U * TPB_B) {
         uint2 r[BS_U];
 #pragma unroll
