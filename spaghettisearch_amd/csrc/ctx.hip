@@ -11,7 +11,10 @@ struct Pool {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, void*> free_blocks;        // (device, size class) -> block
     std::unordered_map<void*, std::pair<int, size_t>> live;           // block -> (device, size class) of the blocks handed out
-    size_t held = 0, limit = (size_t)8 << 30;
+    // default limit: 64 GiB of the 288 GB — the library's own working set at the benchmark sizes is ~20 GB, and a limit that the
+    // working set exceeds turns every release into an eviction and every large allocation into a fresh hipMalloc (the scorer's
+    // 8 GB of combined lists took 0.96 s to create that way, 40 ms from the pool); hipMalloc failures trim the pool and retry
+    size_t held = 0, limit = (size_t)64 << 30;
 };
 Pool& pool() { static Pool* p = new Pool(); return *p; }   // never destroyed: DevBufs of static objects may outlive main
 // size classes: powers of two below 1 MiB, then eighths of the power of two (at most 12.5 % over)
@@ -218,7 +221,7 @@ static const char* const k_option_names[] = {
     "pr.force_narrow",      // 1: K <= 2 always runs the block-item kernel k_pr_step (tests reach it on small graphs)
     "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
-    "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 8192, 0 = off)
+    "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 65536, 0 = off)
     "pr.trace",             // 1: ss_graph_create / ss_pr_create print their phase times to stderr
     "score.trace",          // 1: ss_score_topk prints the host phases of a call (copies in, plan, staging, launches) to stderr
     "pr.probe_hot",         // ss_pr_probe policies 3/4: rows below this index use the default cache policy
@@ -243,7 +246,7 @@ int32_t ss_set_option(ss_ctx* ctx, const char* name, int64_t value) {
         if (std::strcmp(n, name) == 0) {
             if (value == SS_OPTION_DEFAULT) ctx->options.erase(name);
             else ctx->options[name] = value;
-            if (std::strcmp(name, "mem.pool_mb") == 0) ss::pool_set_limit(value == SS_OPTION_DEFAULT ? (size_t)8 << 30 : (size_t)std::max<int64_t>(0, value) << 20);
+            if (std::strcmp(name, "mem.pool_mb") == 0) ss::pool_set_limit(value == SS_OPTION_DEFAULT ? (size_t)64 << 30 : (size_t)std::max<int64_t>(0, value) << 20);
             return SS_OK;
         }
     return ctx->fail(SS_ERR_INVALID, "ss_set_option: unknown option '%s'", name);

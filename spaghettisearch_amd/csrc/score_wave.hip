@@ -34,6 +34,9 @@
 namespace {
 
 constexpr int WCW = 16;                 // block slots per group (= one regular window)
+#ifndef SSW_PACK
+#define SSW_PACK 16      // blocks a packed window may hold (<= WCW)
+#endif
 #ifndef SSW_MINW
 #define SSW_MINW 3
 #endif
@@ -572,7 +575,7 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const uint32_t* c_skip, ui
     // following a -> run_end(a) + 1 from window 0 (one readlane per run; a scalar scan over all base windows cost 14k cycles a round)
     uint32_t run_end;
     {
-        const uint32_t limit = pre + (uint32_t)WCW - min(la, (uint32_t)WCW);
+        const uint32_t limit = pre + (uint32_t)SSW_PACK - min(la, (uint32_t)SSW_PACK);
         uint32_t lo = (uint32_t)lane + 1u, hi = max(nw, (uint32_t)lane + 1u);
 #pragma unroll
         for (int it = 0; it < 6; it++) {
