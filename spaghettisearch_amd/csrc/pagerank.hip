@@ -983,7 +983,7 @@ int pick_gw(int k, uint64_t table_rows, bool force_narrow) {
     return 16;
 }
 
-void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
+void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
                 uint32_t& seg_edges, uint32_t& pos_nd, uint32_t& pos_d, uint32_t (&vbeg)[7]) {
     const uint32_t NSLOT = 64 / gw;
     // gw < 8: rows above T_SEG in-edges get block(s) of their own, then wave-per-row / group-per-row classes.
@@ -1014,6 +1014,9 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
         const uint32_t cnt = (uint32_t)deg.size();
         const uint32_t T_MULTI = 4096, T_DEG = 8;
         const uint32_t T_QUAD = (uint32_t)g->ctx->opt("pr.t_quad", 256);
+        // turns per V_DEG item (a V_QUAD item: twice that): small graphs want finer items — with ~20 turns per wave in all, an
+        // item of 16 leaves the deal nothing to balance ("pr.item_turns"; default from the graph's size, see ss_pr_create)
+        const uint32_t item_turns = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(64, g->ctx->opt("pr.item_turns", item_turns_default)));
         uint32_t r = 0;
         for (; r < cnt && deg[r] > T_MULTI; r++) {
             const uint32_t ns = (deg[r] + SEGW - 1) / SEGW;
@@ -1026,7 +1029,7 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
         // and about 32 turns per item
         while (r < cnt && deg[r] > T_DEG) {
             const uint32_t nch = (deg[r] + CH - 1) / CH;
-            const uint32_t max_groups = std::min<uint32_t>((uint32_t)gw, std::max<uint32_t>(1u, 32u / nch));
+            const uint32_t max_groups = std::min<uint32_t>((uint32_t)gw, std::max<uint32_t>(1u, 2u * item_turns / nch));
             // rows of the same turn count nch: in-degree > (nch - 1) * CH (and > T_DEG), found by bisection in the sorted degrees
             const uint32_t lim = std::max<uint32_t>(T_DEG, (nch - 1) * CH);
             const uint32_t same = run_above(deg, r, lim);
@@ -1040,7 +1043,7 @@ void build_work(const ss_graph* g, int gw, std::vector<WorkItem>& items, uint32_
             // deg is sorted descending: the run of rows with exactly D in-edges ends at the first smaller degree
             const uint32_t run = run_above(deg, r, D - 1);
             const uint32_t R = D <= 2 ? 8 : D <= 4 ? 4 : 2;
-            const uint32_t per_item = NSLOT * R * 16;                 // 16 turns
+            const uint32_t per_item = NSLOT * R * item_turns;
             for (uint32_t o = 0; o < run; o += per_item) vdeg[R == 2 ? 0 : R == 4 ? 1 : 2].push_back({V_DEG, row0 + r + o, std::min(per_item, run - o), D, 0, 0});
             r += run;
         }
@@ -1177,7 +1180,10 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     std::vector<WorkItem> items;
     uint32_t nsegs = 0, nmulti = 0, seg_edges = 0, pos_nd = 0, pos_d = 0;
     uint32_t vbeg[7] = {0};
-    build_work(g, GW, items, nsegs, nmulti, seg_edges, pos_nd, pos_d, vbeg);
+    // item granularity (measured, sweep ms at 2 / 4 / 8 / 16 / 32 turns per V_DEG item): 2^20 nodes, 5M edges, K=1: 0.078 / 0.077 / 0.096 /
+    // 0.102 / 0.158; 10M nodes, 50M edges, K=16: 0.973 / 0.968 / 0.968 / 0.988 / 1.013 — a small graph gives every wave ~20 turns in all,
+    // and the deal can only balance what the items let it; the large one pays for more items in the deal itself (host time)
+    build_work(g, GW, n_local <= ((size_t)4 << 20) ? 4 : 8, items, nsegs, nmulti, seg_edges, pos_nd, pos_d, vbeg);
     const auto tc1 = t_now();
     if (items.empty()) items.push_back({W_ZERO, 0, 0, 0, 0, 0});
     // persistent grid, each block (gw < 8) or wave (gw >= 8) walks the work table round-robin: gw < 8: 8 blocks per CU at
