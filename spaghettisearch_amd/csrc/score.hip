@@ -1635,12 +1635,12 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const bool wave_ok = ctx->opt("score.wave", 1) != 0 && s->has_combined && !exact_all && k <= ss::score_wave_max_k();
     uint64_t wave_target = 0;
     if (wave_ok) {
-        // about four slices per resident wave slot, 8k .. 48k postings each
+        // about 5.5 slices per nine-wave-per-CU slot (four rounds of the 12 waves a CU holds), 8k .. 48k postings each
         const uint64_t slots = (uint64_t)std::max(ctx->cu_count, 1) * 9;
         uint64_t batch_tot = 0;
         for (uint32_t i = 0; i < n_tok; i++)
             if ((uint64_t)h_terms[i] < s->n_terms) batch_tot += (tp[h_terms[i] + 1] - tp[h_terms[i]]) + (bp[h_terms[i] + 1] - bp[h_terms[i]]);
-        wave_target = std::min<uint64_t>(49152, std::max<uint64_t>(8192, batch_tot / (4 * slots)));
+        wave_target = std::min<uint64_t>(49152, std::max<uint64_t>(8192, batch_tot * 2 / (11 * slots)));          // (config 3, ms per batch at 6k / 8k / 10k / 12k / 14k / 17k / 21k postings: 0.661 / 0.635 / 0.616 / 0.623 / 0.655 / 0.649 / 0.639)
         wave_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.wave_slice_target", (int64_t)wave_target));
     }
     // Which queries suit k_score_wave: no phrase part, few lists, a list long enough for the threshold floor (k'-th largest
