@@ -424,6 +424,8 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
         const uint32_t n = p.qc_cnt[q];
         const size_t base = (size_t)p.slice_base[q] * k;
         uint32_t* overflow = &sc32[1];
+        __syncthreads();
+        if (tid == 0) p.qc_cnt[q] = 0u;                                  // every thread has its copy: zero again for the next batch (no memset between batches)
         for (uint32_t i0 = 0; i0 < n; i0 += NT) {
             const uint32_t i = i0 + tid;
             bool have = i < n;
@@ -1292,12 +1294,15 @@ struct ss_scorer {
     int k_topics = 0;
     int lds_attr = 0;
     // per-call workspaces, grow-only (no hipMalloc/hipFree on the steady-state query path)
-    ss::DevBuf<unsigned char> d_plan, d_wprep;
+    ss::DevBuf<unsigned char> d_plan2[2], d_wprep;   // the plan on the device, one buffer per turn: batch i+1's upload runs beside batch i's kernels
     // pinned staging for the plan, double-buffered: a call that returns results in device memory does not wait
     // for the GPU, so the next call plans (and fills the other buffer) while this one's copy and kernels run
     unsigned char* h_plan[2] = {nullptr, nullptr};
     size_t h_plan_cap[2] = {0, 0};
-    hipEvent_t plan_ev[2] = {nullptr, nullptr}; // recorded after the H2D copy of the buffer
+    hipEvent_t plan_ev[2] = {nullptr, nullptr}; // recorded after the H2D copy of the buffer (on the context's second stream)
+    hipEvent_t batch_ev[2] = {nullptr, nullptr};// recorded behind the kernels of the batch that read device buffer [turn]
+    bool batch_ev_pending[2] = {false, false};
+    size_t qcnt_zeroed = 0;                     // counters known to be zero (k_merge_flat leaves its query's counter at zero)
     bool plan_ev_pending[2] = {false, false};
     int plan_turn = 0;
     ss::DevBuf<Rec> d_x[4];                     // phrase result lists: scoring records
@@ -1312,6 +1317,7 @@ struct ss_scorer {
         for (int i = 0; i < 2; i++) {
             if (h_plan[i]) (void)hipHostFree(h_plan[i]);
             if (plan_ev[i]) (void)hipEventDestroy(plan_ev[i]);
+            if (batch_ev[i]) (void)hipEventDestroy(batch_ev[i]);
         }
     }
 };
@@ -1793,7 +1799,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_plan[pb]), plan_bytes * 2, hipHostMallocDefault));
         s->h_plan_cap[pb] = plan_bytes * 2;
     }
-    SS_HIP(ctx, ensure(s->d_plan, plan_bytes));
+    if (!s->batch_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->batch_ev[pb], hipEventDisableTiming));
+    SS_HIP(ctx, ensure(s->d_plan2[pb], plan_bytes));
     unsigned char* hp = s->h_plan[pb];
     std::memcpy(hp + o_qoff, h_qoff.data(), (n_q + 1) * sizeof(uint32_t));
     if (n_d) {
@@ -1815,9 +1822,15 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_mergeq.empty()) std::memcpy(hp + o_mergeq, h_mergeq.data(), h_mergeq.size() * sizeof(uint32_t));
     std::memcpy(hp + o_qfast, h_fast.data(), (size_t)n_q);
     const auto th3 = t_now();
-    SS_HIP(ctx, hipMemcpyAsync(s->d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, st));
-    SS_HIP(ctx, hipEventRecord(s->plan_ev[pb], st));
-    s->plan_ev_pending[pb] = true;
+    // The upload goes out on the context's SECOND stream as soon as the plan is staged — beside the kernels of the previous
+    // batch, which read the other device buffer.  (On the one stream the copy sat
+    // between two batches: 39 us per batch in the kernel trace with the counter memset, 6 % of the wall time at config 3.)
+    if (s->batch_ev_pending[pb]) SS_HIP(ctx, hipEventSynchronize(s->batch_ev[pb]));   // the batch two calls ago read this device buffer: the host runs at most two batches ahead
+    SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, ctx->comm_stream));
+    // ... and the HOST waits for it (~15 us; it has 0.4 ms to spare per batch): the kernels then go out on the caller's stream
+    // with no cross-stream dependency in front of them (a hipStreamWaitEvent there left 21 us between two batches, and two of
+    // them per batch ran the runtime out of signals every ~80 batches: an 8 ms stall)
+    SS_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
     if (any_phrase) {
         for (int x = 0; x < 4; x++) {
             SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
@@ -1835,14 +1848,15 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipMemsetAsync(s->d_qticket.p, 0, (size_t)n_q * sizeof(uint32_t), st));
         s->qticket_zeroed = (size_t)n_q;
     }
-    if (!h_mergeq.empty()) {
+    if (!h_mergeq.empty() && s->qcnt_zeroed < (size_t)n_q) {    // k_merge_flat hands every counter back at zero
         SS_HIP(ctx, ensure(s->d_qcnt, (size_t)n_q));
-        SS_HIP(ctx, hipMemsetAsync(s->d_qcnt.p, 0, (size_t)n_q * sizeof(uint32_t), st));
+        SS_HIP(ctx, hipMemsetAsync(s->d_qcnt.p, 0, s->d_qcnt.bytes(), st));
+        s->qcnt_zeroed = s->d_qcnt.n;
     }
     SS_HIP(ctx, ensure(s->d_hits, (size_t)n_q * k));
     SS_HIP(ctx, ensure(s->d_nhits, n_q));
 
-    const unsigned char* dp = s->d_plan.p;
+    const unsigned char* dp = s->d_plan2[pb].p;
     ScoreParams p{};
     p.t_ptr = s->title->term_ptr.p; p.t_rec = s->t_rec.p; p.t_w = s->title->post_w.p; p.t_mag = s->title->mag.p; p.t_kth = s->t_kth.p;
     p.b_ptr = s->body->term_ptr.p; p.b_rec = s->b_rec.p; p.b_w = s->body->post_w.p; p.b_mag = s->body->mag.p; p.b_kth = s->b_kth.p;
@@ -1901,7 +1915,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
                                         (int)merge_lds_bytes(SS_MAX_TOPK, cb)));
         s->lds_attr = cb;
     }
-    SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
+    const bool timed = ctx->opt("score.timing", 1) != 0;       // the two timing events of ss_last_kernel_ms(1) (each costs the stream a few us)
+    if (timed) SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
     if (any_phrase) {
         if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, st, p);
         hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
@@ -1917,8 +1932,12 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     }
     if (!fused && n_slices > n_fast_slices) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     if (!h_mergeq.empty()) hipLaunchKernelGGL(k_merge_flat, dim3((unsigned)h_mergeq.size()), dim3(TPB_MF), lds_merge, st, p);
-    SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
-    ctx->ev_valid[1] = true;
+    if (timed) {
+        SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
+        ctx->ev_valid[1] = true;
+    }
+    SS_HIP(ctx, hipEventRecord(s->batch_ev[pb], st));
+    s->batch_ev_pending[pb] = true;
     SS_HIP(ctx, hipGetLastError());
     if (trace)
         fprintf(stderr, "[score trace] copies in + checks %.0f us, plan (%zu slices) %.0f us, staging %.0f us, H2D + allocs + params %.0f us, launches %.0f us\n",
