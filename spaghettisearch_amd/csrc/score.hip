@@ -1687,7 +1687,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
                 fit += tot;
             }
         }
-        batch_wave = wml == 0 ? fit > 0 : (fit * 10 >= all * 9 && all > 0);
+        // (a lone query or two — under ~400k postings — finish sooner in k_score_slices: 0.143 against 0.166 ms for two head queries,
+        //  host in / host out; from four queries on the wave kernel leads, 0.21 against 0.31 ms)
+        batch_wave = wml == 0 ? fit > 0 : (fit * 10 >= all * 9 && all >= 400000);
     }
     std::vector<uint8_t> h_fast(n_q, 0);
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
@@ -1822,15 +1824,30 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_mergeq.empty()) std::memcpy(hp + o_mergeq, h_mergeq.data(), h_mergeq.size() * sizeof(uint32_t));
     std::memcpy(hp + o_qfast, h_fast.data(), (size_t)n_q);
     const auto th3 = t_now();
+    // results straight into the caller's buffers when both live in device memory (then the call does not wait either)
+    bool dev_out = false;
+    {
+        hipPointerAttribute_t a1{}, a2{};
+        const bool d1 = hipPointerGetAttributes(&a1, hits_out) == hipSuccess && a1.type == hipMemoryTypeDevice;
+        const bool d2 = hipPointerGetAttributes(&a2, n_hits_out) == hipSuccess && a2.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();                 // plain host memory is reported as an error: not one
+        dev_out = d1 && d2;
+    }
     // The upload goes out on the context's SECOND stream as soon as the plan is staged — beside the kernels of the previous
     // batch, which read the other device buffer.  (On the one stream the copy sat
     // between two batches: 39 us per batch in the kernel trace with the counter memset, 6 % of the wall time at config 3.)
     if (s->batch_ev_pending[pb]) SS_HIP(ctx, hipEventSynchronize(s->batch_ev[pb]));   // the batch two calls ago read this device buffer: the host runs at most two batches ahead
+    if (!dev_out) {
+        // results go back to the host: the call waits for them anyway, and a second wait in the middle would only add to a lone
+        // query's latency (0.15 ms, of which 0.08 are kernels): copy, kernels and read-back follow each other on the one stream
+        SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, st));
+    } else {
     SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, ctx->comm_stream));
     // ... and the HOST waits for it (~15 us; it has 0.4 ms to spare per batch): the kernels then go out on the caller's stream
     // with no cross-stream dependency in front of them (a hipStreamWaitEvent there left 21 us between two batches, and two of
     // them per batch ran the runtime out of signals every ~80 batches: an 8 ms stall)
     SS_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+    }
     if (any_phrase) {
         for (int x = 0; x < 4; x++) {
             SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
@@ -1895,15 +1912,6 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.qc_cnt = s->d_qcnt.p;
     p.merge_q = reinterpret_cast<const uint32_t*>(dp + o_mergeq);
     p.q_fast = reinterpret_cast<const uint8_t*>(dp + o_qfast);
-    // results straight into the caller's buffers when both live in device memory (then the call does not wait either)
-    bool dev_out = false;
-    {
-        hipPointerAttribute_t a1{}, a2{};
-        const bool d1 = hipPointerGetAttributes(&a1, hits_out) == hipSuccess && a1.type == hipMemoryTypeDevice;
-        const bool d2 = hipPointerGetAttributes(&a2, n_hits_out) == hipSuccess && a2.type == hipMemoryTypeDevice;
-        (void)hipGetLastError();                 // plain host memory is reported as an error: not one
-        dev_out = d1 && d2;
-    }
     p.hits = dev_out ? hits_out : s->d_hits.p;
     p.n_hits = dev_out ? n_hits_out : s->d_nhits.p;
 
