@@ -225,6 +225,49 @@ __device__ __forceinline__ uint64_t lower_bound_rec_interp(const Rec* __restrict
     return lo + lower_bound_interp((uint64_t)(a + lo), 0u, (uint32_t)(hi - lo), v);
 }
 
+// number of entries of the global u32 array a[lo, hi) (ascending) that are < v, as an offset from lo: interpolation
+// steps with two independent probes each, then an 8-ary finish (lower_bound_interp of score_common.hpp for 4-byte entries)
+__device__ __forceinline__ uint32_t skip_lower_bound(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t v) {
+    if (lo >= hi) return 0;
+    uint32_t L = lo, H = hi - 1;
+    uint32_t dl = a[L], dh = a[H];
+    if (dl >= v) return 0;
+    if (dh < v) return hi - lo;
+    for (int it = 0; it < 4 && H - L > 32; it++) {
+        const uint32_t n = H - L;
+        const float frac = (float)(v - dl) / (float)(dh - dl);
+        uint32_t g = L + (uint32_t)(frac * (float)n);
+        const uint32_t dlt = (uint32_t)__fsqrt_rn((float)n) + 2;
+        uint32_t x = g > L + dlt ? g - dlt : L + 1;
+        x = min(x, H - 1);
+        const uint32_t y = min(x + 2 * dlt, H - 1);
+        const uint32_t dx = a[x], dy = a[y];
+        if (dx >= v) { H = x; dh = dx; }
+        else if (dy < v) { L = y; dl = dy; }
+        else { L = x; dl = dx; H = y; dh = dy; }
+    }
+    while (H - L > 1) {
+        const uint32_t step = (H - L + 7) >> 3;
+        uint32_t d[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) d[i] = a[min(L + step * (uint32_t)(i + 1), H - 1)];
+        uint32_t nl = L, nh = H;
+#pragma unroll
+        for (int i = 6; i >= 0; i--) {
+            const uint32_t pos = min(L + step * (uint32_t)(i + 1), H - 1);
+            if (d[i] >= v) nh = pos;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const uint32_t pos = min(L + step * (uint32_t)(i + 1), H - 1);
+            if (d[i] < v) nl = max(nl, pos);
+        }
+        L = nl;
+        H = nh;
+    }
+    return H - lo;
+}
+
 // get_metadata.go:53-69 for one candidate
 __device__ __forceinline__ void final_rank(double T, double B, double mt, double mb, double qmag, double sqd,
                                            double& title, double& body, double& fin) {

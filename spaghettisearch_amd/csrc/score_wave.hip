@@ -126,49 +126,6 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t* a, uint32_t 
     return lo;
 }
 
-// number of entries of the global u32 array a[lo, hi) (ascending) that are < v, as an offset from lo: interpolation
-// steps with two independent probes each, then an 8-ary finish (lower_bound_interp of score_common.hpp for 4-byte entries)
-__device__ __forceinline__ uint32_t skip_lower_bound(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t v) {
-    if (lo >= hi) return 0;
-    uint32_t L = lo, H = hi - 1;
-    uint32_t dl = a[L], dh = a[H];
-    if (dl >= v) return 0;
-    if (dh < v) return hi - lo;
-    for (int it = 0; it < 4 && H - L > 32; it++) {
-        const uint32_t n = H - L;
-        const float frac = (float)(v - dl) / (float)(dh - dl);
-        uint32_t g = L + (uint32_t)(frac * (float)n);
-        const uint32_t dlt = (uint32_t)__fsqrt_rn((float)n) + 2;
-        uint32_t x = g > L + dlt ? g - dlt : L + 1;
-        x = min(x, H - 1);
-        const uint32_t y = min(x + 2 * dlt, H - 1);
-        const uint32_t dx = a[x], dy = a[y];
-        if (dx >= v) { H = x; dh = dx; }
-        else if (dy < v) { L = y; dl = dy; }
-        else { L = x; dl = dx; H = y; dh = dy; }
-    }
-    while (H - L > 1) {
-        const uint32_t step = (H - L + 7) >> 3;
-        uint32_t d[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) d[i] = a[min(L + step * (uint32_t)(i + 1), H - 1)];
-        uint32_t nl = L, nh = H;
-#pragma unroll
-        for (int i = 6; i >= 0; i--) {
-            const uint32_t pos = min(L + step * (uint32_t)(i + 1), H - 1);
-            if (d[i] >= v) nh = pos;
-        }
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const uint32_t pos = min(L + step * (uint32_t)(i + 1), H - 1);
-            if (d[i] < v) nl = max(nl, pos);
-        }
-        L = nl;
-        H = nh;
-    }
-    return H - lo;
-}
-
 __device__ __forceinline__ uint32_t w_slot(uint32_t doc) { return (doc ^ (doc >> 10)) & (uint32_t)(WSK - 1); }
 
 // What a slice needs to know about one of its lists, resolved by k_wave_prep for all slices of the batch at once (the
