@@ -82,7 +82,8 @@ namespace ss {
 hipError_t pool_alloc(void** p, size_t bytes);
 void pool_free(void* p);
 void pool_set_limit(size_t bytes);
-void pool_trim();      // really free everything the pool holds
+void pool_trim();
+void pool_stats(uint64_t* misses, double* miss_ms);      // really free everything the pool holds
 
 // Device allocation that frees itself; raw pointers are handed to kernels.
 template <typename T>

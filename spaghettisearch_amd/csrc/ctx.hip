@@ -1,5 +1,6 @@
 // ctx.hip — context, stream and error plumbing of the C ABI (include/spaghetti_rank.h).
 #include "common.hpp"
+#include <chrono>
 
 #include <unordered_map>
 
@@ -15,6 +16,8 @@ struct Pool {
     // working set exceeds turns every release into an eviction and every large allocation into a fresh hipMalloc (the scorer's
     // 8 GB of combined lists took 0.96 s to create that way, 40 ms from the pool); hipMalloc failures trim the pool and retry
     size_t held = 0, limit = (size_t)64 << 30;
+    double miss_ms = 0.0;            // time spent in hipMalloc on pool misses (pr.trace prints it)
+    uint64_t misses = 0;
 };
 Pool& pool() { static Pool* p = new Pool(); return *p; }   // never destroyed: DevBufs of static objects may outlive main
 // size classes: powers of two below 1 MiB, then eighths of the power of two (at most 12.5 % over)
@@ -44,7 +47,10 @@ hipError_t pool_alloc(void** out, size_t bytes) {
             return hipSuccess;
         }
     }
+    const auto tm0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, cls);
+    P.miss_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count();
+    P.misses++;
     if (e != hipSuccess) {                               // give the pool's memory back and try once more
         (void)hipGetLastError();
         pool_trim();
@@ -99,6 +105,8 @@ void pool_free(void* p) {
     }
     (void)hipFree(p);
 }
+
+void pool_stats(uint64_t* misses, double* miss_ms) { *misses = pool().misses; *miss_ms = pool().miss_ms; }
 
 void pool_trim() {
     Pool& P = pool();

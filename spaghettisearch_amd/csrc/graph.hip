@@ -382,6 +382,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     if (g->cnt_nd) g->max_indeg = std::max(g->max_indeg, g->h_indeg_nd[0]);
     if (g->cnt_d) g->max_indeg = std::max(g->max_indeg, g->h_indeg_d[0]);
     SS_HIP(ctx, hipGetLastError());
+    if (trace) { uint64_t pm = 0; double pms = 0; ss::pool_stats(&pm, &pms); fprintf(stderr, "[pr trace] pool: %llu hipMalloc so far, %.2f ms in them\n", (unsigned long long)pm, pms); }
     if (trace) fprintf(stderr, "[pr trace] ss_graph_create: upload + degrees %.2f ms, node order %.2f ms, edge sort %.2f ms, local rows %.2f ms\n", t_ms(tg0, tg1), t_ms(tg1, tg2), t_ms(tg2, tg3), t_ms(tg3, t_now()));
     return SS_OK;
 }
