@@ -39,6 +39,44 @@ struct ss_ctx {
     void* comm_parent = nullptr;       // the communicator `comm` was split from (ss_comm_split)
     int comm_rank = 0, comm_world = 1;
     // tuning / diagnostic options (ss_set_option); the defaults live at the point of use
+    // Pinned host memory for what comes back from the device.  hipMemcpyAsync into PAGEABLE host memory pins the caller's page on
+    // the fly — an mm-lock round trip that took 5-10 ms PER COPY on a loaded 256-core host (ss_graph_create: 7 ms on a quiet box,
+    // 20-40 ms there; the time sat in the enqueue of four 8-byte read-backs).  h_pin: a bump-allocated scratch for small results
+    // (reset at the entry of the call that uses it); pin_cache: free blocks for larger host copies (the graph's in-degrees).
+    unsigned char* h_pin = nullptr;
+    size_t pin_used = 0;
+    static constexpr size_t PIN_SCRATCH = 8192;
+    struct PinBlock { void* p; size_t cap; };
+    std::vector<PinBlock> pin_cache;
+    template <typename T>
+    T* pin(size_t count = 1) {                       // scratch for `count` T (never fails over: 8 KB, callers ask for bytes)
+        const size_t bytes = (count * sizeof(T) + 15) & ~(size_t)15;
+        if (!h_pin || pin_used + bytes > PIN_SCRATCH) pin_used = 0;      // (wraps: nothing is held across calls)
+        T* r = reinterpret_cast<T*>(h_pin + pin_used);
+        pin_used += bytes;
+        return r;
+    }
+    void* pin_alloc(size_t bytes, size_t* cap_out) {
+        size_t best = pin_cache.size();
+        for (size_t i = 0; i < pin_cache.size(); i++)
+            if (pin_cache[i].cap >= bytes && (best == pin_cache.size() || pin_cache[i].cap < pin_cache[best].cap)) best = i;
+        if (best < pin_cache.size()) {
+            PinBlock b = pin_cache[best];
+            pin_cache.erase(pin_cache.begin() + best);
+            *cap_out = b.cap;
+            return b.p;
+        }
+        void* q = nullptr;
+        const size_t cap = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *cap_out = cap;
+        return q;
+    }
+    void pin_free(void* q, size_t cap) {
+        if (!q) return;
+        if (pin_cache.size() < 4) pin_cache.push_back({q, cap});
+        else (void)hipHostFree(q);
+    }
     std::map<std::string, int64_t> options;
     int64_t opt(const char* name, int64_t dflt) const {
         auto it = options.find(name);

@@ -198,6 +198,11 @@ int32_t ss_init(int32_t device_id, ss_ctx** out) {
                 delete ctx;
                 return SS_ERR_HIP;
             }
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), ss_ctx::PIN_SCRATCH, hipHostMallocDefault)) != hipSuccess) {
+        ss::set_global_error(std::string("ss_init: hipHostMalloc: ") + hipGetErrorString(e));
+        delete ctx;
+        return SS_ERR_HIP;
+    }
     *out = ctx;
     return SS_OK;
 }
@@ -212,6 +217,8 @@ int32_t ss_shutdown(ss_ctx* ctx) {
             if (ctx->ev[k][j]) (void)hipEventDestroy(ctx->ev[k][j]);
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    for (auto& b : ctx->pin_cache) (void)hipHostFree(b.p);
     delete ctx;
     return SS_OK;
 }

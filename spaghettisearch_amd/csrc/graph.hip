@@ -254,6 +254,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
         SS_HIP(ctx, hipMemcpyAsync(g->out_ptr.p, out_ptr_in, (n + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
         if (e) SS_HIP(ctx, hipMemcpyAsync(g->out_dst.p, out_dst_in, e * sizeof(uint32_t), hipMemcpyDefault, st));
     }
+    const auto tga = t_now();
     const uint64_t* d_out_ptr = g->out_ptr.p;
     const uint32_t* d_out_dst = g->out_dst.p;
     SS_HIP(ctx, d_outdeg.alloc(n));
@@ -265,17 +266,24 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     SS_HIP(ctx, hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), st));
 
     // the first/last offsets must frame out_dst exactly
-    uint64_t h_first = 0, h_last = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&h_first, d_out_ptr, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_last, d_out_ptr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    // (every read-back lands in the context's pinned scratch: see ss_ctx::h_pin)
+    ctx->pin_used = 0;
+    uint64_t* const hp_first = ctx->pin<uint64_t>(), * const hp_last = ctx->pin<uint64_t>();
+    unsigned long long* const hp_nd = ctx->pin<unsigned long long>();
+    uint32_t* const hp_err = ctx->pin<uint32_t>();
+    SS_HIP(ctx, hipMemcpyAsync(hp_first, d_out_ptr, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(hp_last, d_out_ptr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 
     if (n) hipLaunchKernelGGL(k_outdeg, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_out_ptr, n, d_outdeg.p, d_cnt.p, d_err.p);
     if (e) hipLaunchKernelGGL(k_indeg, dim3(grid_for(e, 8192)), dim3(TPB), 0, st, d_out_dst, e, n, d_indeg.p, d_err.p);
-    unsigned long long h_nd = 0;
-    uint32_t h_err = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&h_nd, d_cnt.p, sizeof(h_nd), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(hp_nd, d_cnt.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(hp_err, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    const auto tgb = t_now();
     SS_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t h_first = *hp_first, h_last = *hp_last;
+    const unsigned long long h_nd = *hp_nd;
+    const uint32_t h_err = *hp_err;
+    if (trace) fprintf(stderr, "[pr trace]   upload: allocs + copies enqueued %.2f ms, rest enqueued %.2f ms, wait %.2f ms\n", t_ms(tg0, tga), t_ms(tga, tgb), t_ms(tgb, t_now()));
     if (h_first != 0 || h_last != e) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: out_ptr[0]=%llu, out_ptr[n]=%llu, expected 0 and n_edges=%llu",
                                                       (unsigned long long)h_first, (unsigned long long)h_last, (unsigned long long)e);
     if (h_err & 1) return ctx->fail(SS_ERR_INVALID, "ss_graph_create: out_ptr is not non-decreasing");
@@ -345,7 +353,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     // ---- this rank's rows -----------------------------------------------------
     const uint64_t id0_nd = (uint64_t)g->rank * g->sl_nd;
     const uint64_t id0_d = g->nd_int + (uint64_t)g->rank * g->sl_d;
-    uint64_t h_ptr[4] = {0, 0, 0, 0};
+    uint64_t* const h_ptr = ctx->pin<uint64_t>(4);
     SS_HIP(ctx, hipMemcpyAsync(&h_ptr[0], in_ptr_int.p + id0_nd, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&h_ptr[1], in_ptr_int.p + id0_nd + g->sl_nd, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&h_ptr[2], in_ptr_int.p + id0_d, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -373,10 +381,19 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
                            (uint64_t)g->sl_nd, g->outdeg.p);
 
     // host copies of local in-degrees (already sorted descending inside each class slice)
-    g->h_indeg_nd.assign(g->cnt_nd, 0);
-    g->h_indeg_d.assign(g->cnt_d, 0);
-    if (g->cnt_nd) SS_HIP(ctx, hipMemcpyAsync(g->h_indeg_nd.data(), indeg_int.p + id0_nd, g->cnt_nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    if (g->cnt_d) SS_HIP(ctx, hipMemcpyAsync(g->h_indeg_d.data(), indeg_int.p + id0_d, g->cnt_d * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    {
+        const size_t need = ((size_t)g->cnt_nd + g->cnt_d + 1) * sizeof(uint32_t);
+        if (g->h_indeg_cap < need) {
+            if (g->h_indeg_block) ctx->pin_free(g->h_indeg_block, g->h_indeg_cap);
+            g->h_indeg_block = ctx->pin_alloc(need, &g->h_indeg_cap);
+            if (!g->h_indeg_block) { g->h_indeg_cap = 0; return ctx->fail(SS_ERR_OOM, "ss_graph_create: no pinned host memory for %zu bytes of in-degrees", need); }
+        }
+        uint32_t* const hb = static_cast<uint32_t*>(g->h_indeg_block);
+        g->h_indeg_nd = ss_graph::HostU32{hb, g->cnt_nd};
+        g->h_indeg_d = ss_graph::HostU32{hb + g->cnt_nd, g->cnt_d};
+        if (g->cnt_nd) SS_HIP(ctx, hipMemcpyAsync(hb, indeg_int.p + id0_nd, g->cnt_nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (g->cnt_d) SS_HIP(ctx, hipMemcpyAsync(hb + g->cnt_nd, indeg_int.p + id0_d, g->cnt_d * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
     SS_HIP(ctx, hipStreamSynchronize(st));
     g->max_indeg = 0;
     if (g->cnt_nd) g->max_indeg = std::max(g->max_indeg, g->h_indeg_nd[0]);
@@ -463,11 +480,14 @@ int32_t ss_graph_apply_delta(ss_graph* g, uint64_t n_nodes_new, uint64_t n_chang
         SS_HIP(ctx, rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, ptr2.p, (uint64_t)0, (size_t)(n_new + 1), rocprim::plus<uint64_t>(), st));
         SS_HIP(ctx, hipStreamSynchronize(st));
     }
-    uint64_t e_new = 0;
-    uint32_t h_err = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&e_new, ptr2.p + n_new, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    ctx->pin_used = 0;
+    uint64_t* const hp_enew = ctx->pin<uint64_t>();
+    uint32_t* const hp_err = ctx->pin<uint32_t>();
+    SS_HIP(ctx, hipMemcpyAsync(hp_enew, ptr2.p + n_new, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(hp_err, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t e_new = *hp_enew;
+    const uint32_t h_err = *hp_err;
     if (h_err & 1) return ctx->fail(SS_ERR_INVALID, "ss_graph_apply_delta: a changed node id is >= n_nodes_new (graph unchanged)");
     if (h_err & 2) return ctx->fail(SS_ERR_INVALID, "ss_graph_apply_delta: the same node is listed twice in `changed` (graph unchanged)");
     if (h_err & 4) return ctx->fail(SS_ERR_INVALID, "ss_graph_apply_delta: a new child id is >= n_nodes_new (graph unchanged)");

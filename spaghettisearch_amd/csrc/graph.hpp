@@ -40,8 +40,20 @@ struct ss_graph {
     ss::DevBuf<uint32_t> in_ptr;  // [sl_nd + sl_d + 1]
     ss::DevBuf<uint32_t> in_src;  // [e_local] internal ids, all < nd_int
     ss::DevBuf<uint32_t> outdeg;  // [sl_nd] out-degree of the local non-dangling rows
-    // host copies of the local in-degrees (sorted descending per class) for work-table building
-    std::vector<uint32_t> h_indeg_nd, h_indeg_d;
+    // host copies of the local in-degrees (sorted descending per class) for work-table building: two spans of ONE pinned block
+    // (from the context's cache; a std::vector cost a 40 MB zero fill + page faults + a copy into pageable memory per create)
+    struct HostU32 {
+        const uint32_t* p = nullptr;
+        size_t n = 0;
+        size_t size() const { return n; }
+        uint32_t operator[](size_t i) const { return p[i]; }
+        const uint32_t* begin() const { return p; }
+        const uint32_t* end() const { return p + n; }
+    };
+    HostU32 h_indeg_nd, h_indeg_d;
+    void* h_indeg_block = nullptr;
+    size_t h_indeg_cap = 0;
+    ~ss_graph() { if (ctx && h_indeg_block) ctx->pin_free(h_indeg_block, h_indeg_cap); }
 
     uint32_t n_local() const { return sl_nd + sl_d; }
     // internal id of local row

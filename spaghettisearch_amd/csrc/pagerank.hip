@@ -999,7 +999,7 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
     std::vector<WorkItem> vseg, vroww, vquad, vdeg[3], vzero;
     // deg is sorted descending: rows from r on with deg > lim (i.e. deg >= lim + 1), by galloping — the runs are short against the
     // array (a plain upper_bound over millions of rows per item was most of this function's 2.5 ms at 10M nodes)
-    auto run_above = [](const std::vector<uint32_t>& deg, uint32_t r, uint32_t lim) -> uint32_t {
+    auto run_above = [](const ss_graph::HostU32& deg, uint32_t r, uint32_t lim) -> uint32_t {
         const uint32_t cnt = (uint32_t)deg.size();
         uint32_t step = 1, lo = r;                     // deg[lo] > lim (the caller's row)
         while (lo + step < cnt && deg[lo + step] > lim) { lo += step; step <<= 1; }
@@ -1010,7 +1010,7 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
         }
         return hi - r;
     };
-    auto emit_v = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
+    auto emit_v = [&](const ss_graph::HostU32& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
         const uint32_t T_MULTI = 4096, T_DEG = 8;
         const uint32_t T_QUAD = (uint32_t)g->ctx->opt("pr.t_quad", 256);
@@ -1052,7 +1052,7 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
         if (non_dangling)
             for (uint32_t o = r; o < cnt; o += ZERO_ROWS) vzero.push_back({V_ZERO, row0 + o, std::min<uint32_t>(ZERO_ROWS, cnt - o), 0, 0, 0});
     };
-    auto emit = [&](const std::vector<uint32_t>& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
+    auto emit = [&](const ss_graph::HostU32& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         if (gw >= 8) { emit_v(deg, row0, non_dangling, n_pos); return; }
         const uint32_t cnt = (uint32_t)deg.size();
         // deg is sorted descending: find class boundaries
@@ -1602,10 +1602,11 @@ int32_t run_pipelined(ss_ctx* ctx, std::vector<ShardBlocks>& sh, int32_t max_ite
         // what the host reads lags the in-flight sweep by one, and launches after convergence are no-ops on all ranks alike
         int32_t n_active = 0;
         for (int b = 0; b < B && rc == SS_OK; b++) {
-            PrCtl h;
-            if (hipMemcpyAsync(&h, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            ctx->pin_used = 0;
+            PrCtl* const hp = ctx->pin<PrCtl>();
+            if (hipMemcpyAsync(hp, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess ||
                 hipStreamSynchronize(cs) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: status read failed"); break; }
-            n_active += h.n_active;
+            n_active += hp->n_active;
         }
         if (n_active == 0) break;
     }
@@ -1619,10 +1620,11 @@ int32_t run_pipelined(ss_ctx* ctx, std::vector<ShardBlocks>& sh, int32_t max_ite
     }
     if (rc == SS_OK && iters_out) {
         for (int b = 0; b < B && rc == SS_OK; b++) {
-            PrCtl h;
-            if (hipMemcpyAsync(&h, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            ctx->pin_used = 0;
+            PrCtl* const hp = ctx->pin<PrCtl>();
+            if (hipMemcpyAsync(hp, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess ||
                 hipStreamSynchronize(cs) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: status read failed"); break; }
-            for (int k = 0; k < sh[0].blk[b]->k; k++) iters_out[blk_k0[b] + k] = h.iters[k];
+            for (int k = 0; k < sh[0].blk[b]->k; k++) iters_out[blk_k0[b] + k] = hp->iters[k];
         }
     }
     cleanup();
@@ -1748,9 +1750,11 @@ int32_t ss_pr_status(ss_pr* pr, int32_t* iters_out, int32_t* n_active, int32_t* 
     ss_ctx* ctx = pr->g->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SS_HIP(ctx, hipSetDevice(ctx->device));
-    PrCtl h;
-    SS_HIP(ctx, hipMemcpyAsync(&h, pr->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pin_used = 0;
+    PrCtl* const hp = ctx->pin<PrCtl>();               // pinned: a read-back into pageable memory pins the page per call (ss_ctx::h_pin)
+    SS_HIP(ctx, hipMemcpyAsync(hp, pr->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, ctx->stream));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const PrCtl h = *hp;
     for (int k = 0; k < pr->k; k++) {
         if (iters_out) iters_out[k] = h.iters[k];
         if (last_delta_out) last_delta_out[k] = h.delta[k];
