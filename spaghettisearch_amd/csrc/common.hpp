@@ -95,6 +95,24 @@ struct ss_ctx {
     }
 };
 
+namespace ss {
+// Small results back from the device: into the context's pinned scratch, wait, copy out (see ss_ctx::h_pin for why never straight
+// into the caller's pageable variables).  Up to two values per call; waits for `st`.
+inline hipError_t fetch(ss_ctx* ctx, hipStream_t st, void* d1, const void* s1, size_t n1, void* d2 = nullptr, const void* s2 = nullptr, size_t n2 = 0) {
+    ctx->pin_used = 0;
+    unsigned char* const p1 = ctx->pin<unsigned char>(n1);
+    unsigned char* const p2 = n2 ? ctx->pin<unsigned char>(n2) : nullptr;
+    hipError_t e = hipMemcpyAsync(p1, s1, n1, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && n2) e = hipMemcpyAsync(p2, s2, n2, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) {
+        std::memcpy(d1, p1, n1);
+        if (n2) std::memcpy(d2, p2, n2);
+    }
+    return e;
+}
+}  // namespace ss
+
 #define SS_HIP(ctx, expr)                                                                  \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \

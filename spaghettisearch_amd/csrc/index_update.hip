@@ -315,8 +315,7 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
         SS_HIP(ctx, hipMemsetAsync(perr.p, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_check_mono_u64, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint64_t*)d_add_pos_ptr.p, n_add, perr.p);
         uint32_t h_perr = 0;
-        SS_HIP(ctx, hipMemcpyAsync(&h_perr, perr.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
+        SS_HIP(ctx, ss::fetch(ctx, st, &h_perr, perr.p, sizeof(uint32_t)));
         if (h_perr) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: add_pos_ptr is not non-decreasing");
     }
     SS_HIP(ctx, pair_sq.alloc(n_del));
@@ -366,8 +365,7 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
     // term ids, so an out-of-range id must never reach them.
     {
         uint32_t h_early = 0;
-        SS_HIP(ctx, hipMemcpyAsync(&h_early, err.p, sizeof(h_early), hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
+        SS_HIP(ctx, ss::fetch(ctx, st, &h_early, err.p, sizeof(h_early)));
         if (h_early & 1) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: del_docs holds a doc id >= n_docs (table unchanged)");
         if (h_early & 2) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a (term, doc) to delete is out of range (table unchanged)");
         if (h_early & 4) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a posting to add is out of range (table unchanged)");
@@ -409,8 +407,7 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
     if (P2) hipLaunchKernelGGL(k_check_merged, dim3(ss::div_up(P2, PK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)new_ptr.p, T, (const uint32_t*)out_doc.p, P2, err.p);
     SS_HIP(ctx, hipGetLastError());
     uint32_t h_err = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&h_err, err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    SS_HIP(ctx, ss::fetch(ctx, st, &h_err, err.p, sizeof(h_err)));
     if (h_err & 1) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: del_docs holds a doc id >= n_docs (table unchanged)");
     if (h_err & 2) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a (term, doc) to delete is out of range (table unchanged)");
     if (h_err & 4) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a posting to add is out of range (table unchanged)");
@@ -422,8 +419,7 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
     if (has_pos) {
         SS_TRY(exclusive_scan_u64(ctx, len_out.p, new_pos_ptr.p, (size_t)(P2 + 1)));
         uint64_t total = 0;
-        SS_HIP(ctx, hipMemcpyAsync(&total, new_pos_ptr.p + P2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
+        SS_HIP(ctx, ss::fetch(ctx, st, &total, new_pos_ptr.p + P2, sizeof(uint64_t)));
         SS_HIP(ctx, new_pos.alloc(total));
         if (P2) hipLaunchKernelGGL(k_copy_positions, dim3(grid_for(P2)), dim3(TPB), 0, st, (const uint64_t*)new_pos_ptr.p, (const uint64_t*)src_start.p, P2,
                                    (const float*)idx->pos.p, (const float*)d_add_pos.p, new_pos.p);

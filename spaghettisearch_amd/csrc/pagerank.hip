@@ -1417,9 +1417,7 @@ int32_t ss_pr_set_teleport(ss_pr* pr, const uint64_t* set_ptr, const uint32_t* s
     SS_HIP(ctx, hipGetLastError());
     uint32_t h_err = 0;
     unsigned long long h_cnt[MAXK];
-    SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    SS_HIP(ctx, ss::fetch(ctx, st, &h_err, d_err.p, sizeof(h_err), h_cnt, d_cnt.p, sizeof(h_cnt)));
     if (h_err & 1u) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: a teleport set holds a node id >= n_nodes");
     if (h_err & 2u) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: a teleport set lists a node twice (the ids of a set must be distinct)");
     double h_nz[MAXK];

@@ -1434,8 +1434,7 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
     }
     SS_HIP(ctx, hipGetLastError());
     uint32_t h_flags = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&h_flags, flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SS_HIP(ctx, ss::fetch(ctx, ctx->stream, &h_flags, flags.p, sizeof(uint32_t)));
     s->clean = h_flags == 0;
     if (ctx->opt("score.exact_all", 0) != 0) s->clean = false;   // tests: force the filter off
     title->users++;

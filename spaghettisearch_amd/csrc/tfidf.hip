@@ -861,9 +861,7 @@ int32_t ss_index_create(ss_ctx* ctx, uint64_t n_docs, uint64_t n_terms, const ui
                               idx->post_doc.p, P, n_docs, d_cnt.p + 1, d_err.p);
     unsigned long long h_cnt[2] = {0, 0};
     uint32_t h_err = 0;
-    SS_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err.p, sizeof(h_err), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    SS_HIP(ctx, ss::fetch(ctx, st, h_cnt, d_cnt.p, sizeof(h_cnt), &h_err, d_err.p, sizeof(h_err)));
     SS_HIP(ctx, hipGetLastError());
     if (h_err & 1) return ctx->fail(SS_ERR_INVALID, "ss_index_create: term_ptr is not non-decreasing");
     if (h_err & 2) return ctx->fail(SS_ERR_INVALID, "ss_index_create: posting holds a doc id >= n_docs");
@@ -1017,8 +1015,7 @@ int32_t ss_index_set_doc_freq(ss_index* idx, const uint64_t* df) {
         hipLaunchKernelGGL(k_check_df, dim3(ss::div_up(T, TPB)), dim3(TPB), 0, st, idx->term_ptr.p, idx->df_global.p, T, err.p);
     }
     uint32_t h_err = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&h_err, err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    SS_HIP(ctx, ss::fetch(ctx, st, &h_err, err.p, sizeof(uint32_t)));
     if (h_err) {
         idx->df_global.release();
         idx->has_df_global = false;
@@ -1039,9 +1036,7 @@ int32_t ss_index_set_positions(ss_index* idx, const uint64_t* pos_ptr, const flo
     SS_HIP(ctx, idx->pos_ptr.alloc(P + 1));
     SS_HIP(ctx, hipMemcpyAsync(idx->pos_ptr.p, pos_ptr, (P + 1) * sizeof(uint64_t), hipMemcpyDefault, st));
     uint64_t ends[2] = {0, 0};
-    SS_HIP(ctx, hipMemcpyAsync(&ends[0], idx->pos_ptr.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&ends[1], idx->pos_ptr.p + P, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    SS_HIP(ctx, ss::fetch(ctx, st, &ends[0], idx->pos_ptr.p, sizeof(uint64_t), &ends[1], idx->pos_ptr.p + P, sizeof(uint64_t)));
     if (ends[0] != 0) { idx->pos_ptr.release(); return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos_ptr[0] != 0"); }
     if (P) {
         // monotone + first 0 + last = total  =>  every range lies inside pos[0, total)
@@ -1050,8 +1045,7 @@ int32_t ss_index_set_positions(ss_index* idx, const uint64_t* pos_ptr, const flo
         SS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_check_pos, dim3(std::min<unsigned>(ss::div_up(P, TPB), 16384u)), dim3(TPB), 0, st, idx->pos_ptr.p, P, err.p);
         uint32_t h_err = 0;
-        SS_HIP(ctx, hipMemcpyAsync(&h_err, err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
+        SS_HIP(ctx, ss::fetch(ctx, st, &h_err, err.p, sizeof(uint32_t)));
         if (h_err) { idx->pos_ptr.release(); return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos_ptr is not non-decreasing"); }
     }
     if (ends[1] && !pos) { idx->pos_ptr.release(); return ctx->fail(SS_ERR_INVALID, "ss_index_set_positions: pos is NULL"); }
