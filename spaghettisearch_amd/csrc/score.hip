@@ -1191,6 +1191,12 @@ __global__ __launch_bounds__(CM_TPB) void k_merge_lists(const uint64_t* __restri
         const uint64_t pos = my_ptr[t] + o0 + (i - my_ptr[t]) + before;       // c_ptr[t] = my_ptr[t] + ot_ptr[t]
         Rec c = r;
         c.doc = r.doc | ((uint32_t)my_field << 31);
+        // a title posting's impact is stored times 38/29 (rounded up twice): ONE filter coefficient per list then serves both
+        // fields in k_score_wave's inner loop (get_metadata.go:69 weighs title 0.38, body 0.29) — still an upper bound
+        if (my_field) {
+            const float v = r.imp * 1.3103449f;                          // 1.3103449f > 38/29; then two ulps up: above the real product
+            c.imp = v > 0.0f ? __uint_as_float(__float_as_uint(v) + 2u) : v;
+        }
         c_rec[pos] = c;
         c_org[pos] = (uint32_t)(i - my_ptr[t]);
     }

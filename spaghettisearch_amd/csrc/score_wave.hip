@@ -314,9 +314,9 @@ __device__ __noinline__ void slow_window(const WaveCtx C, const RareArgs ra, con
             const uint32_t d = rfl(C.gdesc[row + i / WCW][i % WCW]);
             const u32x2 rec = *(gptr_u2)(block_addr(d, C.tb) + (uint32_t)lane * 8u);
             const uint32_t doc = rec.x & 0x7FFFFFFFu;
-            const float cb = __uint_as_float(rl(__float_as_uint(w.coef_b), (int)(d & 15u))), ct = __uint_as_float(rl(__float_as_uint(w.coef_t), (int)(d & 15u)));
+            const float cf = __uint_as_float(rl(__float_as_uint(w.coef_b), (int)(d & 15u)));
             if (block_active(d, doc, b_lo, span, w, lane))
-                atomicAdd(&C.sk[w_slot(doc)], min(fx_share(__uint_as_float(rec.y), (rec.x >> 31) ? ct : cb), clamp));
+                atomicAdd(&C.sk[w_slot(doc)], min(fx_share(__uint_as_float(rec.y), cf), clamp));
         }
         lds_wait();
     }
@@ -445,12 +445,12 @@ __device__ __forceinline__ uint32_t block_add(uint32_t* sk, const WList& w, uint
     return (rec[S_][C_].x == 0x12345678u) ? 0u : 4u * (uint32_t)WSK;
 #endif
     const uint32_t d = rl(dv, C_);
-    const float cb = __uint_as_float(rl(__float_as_uint(w.coef_b), (int)(d & 15u))), ct = __uint_as_float(rl(__float_as_uint(w.coef_t), (int)(d & 15u)));
+    const float cf = __uint_as_float(rl(__float_as_uint(w.coef_b), (int)(d & 15u)));      // one coefficient per list: title impacts are stored pre-scaled (k_merge_lists)
     const uint32_t doc = rec[S_][C_].x & 0x7FFFFFFFu;
     uint32_t h4 = 4u * (uint32_t)WSK;
     if (block_active(d, doc, b_lo, span, w, lane)) {
         h4 = w_slot(doc) * 4u;
-        atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sk) + h4), fx_share(__uint_as_float(rec[S_][C_].y), (int32_t)rec[S_][C_].x < 0 ? ct : cb));
+        atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sk) + h4), fx_share(__uint_as_float(rec[S_][C_].y), cf));
     }
     return h4;
 }
