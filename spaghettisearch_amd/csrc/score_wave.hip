@@ -650,7 +650,8 @@ __global__ __launch_bounds__(256) void k_wave_prep(ScoreParams p, uint32_t n_sli
 }
 
 __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, const WPrep* __restrict__ prep) {
-    __shared__ uint32_t sk[WSK + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t sk[WSK + 4];
+    static_assert(WSK == 1024, "the row's sketch is cleared by four 16-byte stores per lane");
     __shared__ uint32_t se[(WSE + 32) > 2 * WHT ? (WSE + 32) : 2 * WHT];   // skip entries while a round is planned, then ht_key | ht_rec
     __shared__ __attribute__((aligned(16))) uint32_t ghdr[WGMAX + 2 * WDEPTH][4];
     __shared__ uint32_t gdesc[WGMAX + 2 * WDEPTH][WCW];
@@ -806,7 +807,9 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                             }                                                                                              \
                         }                                                                                                  \
                     }                                                                                                      \
-                    _Pragma("unroll") for (int c = 0; c < WCW; c++) if (h[c] != 4u * (uint32_t)WSK) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sk) + h[c]) = 0u; \
+                    /* the whole sketch back to zero: four 16-byte stores per lane (the same 4 KB as one 4-byte store per slot and lane, in 4 instructions instead of 48) */ \
+                    { uint4* const s4_ = reinterpret_cast<uint4*>(sk); const uint4 z_ = make_uint4(0u, 0u, 0u, 0u);       \
+                      s4_[lane] = z_; s4_[lane + 64] = z_; s4_[lane + 128] = z_; s4_[lane + 192] = z_; }                    \
                     WSTAMP(ts3);                                                                                           \
                     WACC(2, ts2, ts3);                                                                                     \
                 } else {                                                                                                   \
