@@ -406,22 +406,25 @@ __device__ __forceinline__ void chunk_filter(const SliceLds& S, const uint32_t (
 // FLAT: the query's slices (k_score_wave) appended their candidates to ONE list per query (qc_cnt[q] entries from
 // slice_base[q] * k on); otherwise every slice owns k entries and so_cnt[s] says how many it filled.
 template <int NT, bool FUSED, bool FLAT = false>
-__device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t q, unsigned char* smem) {
+__device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t q, unsigned char* smem, const int cbm) {
     double* accT = reinterpret_cast<double*>(smem);                    // [k]
     double* accB = accT + p.k;                                         // [k]
     double* mgT = accB + p.k;                                          // [k]
     double* mgB = mgT + p.k;                                           // [k]
     uint64_t* cd_key = reinterpret_cast<uint64_t*>(mgB + p.k);         // [cb]
-    uint64_t* sc64 = cd_key + p.cb;                                    // [1]
+    uint64_t* sc64 = cd_key + cbm;                                     // [1]
     uint32_t* cd_doc = reinterpret_cast<uint32_t*>(sc64 + 1);          // [cb]
-    uint32_t* sc32 = cd_doc + p.cb;                                    // [4]
-    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), 0ull, -INFINITY, (uint32_t)p.cb};
+    uint32_t* sc32 = cd_doc + cbm;                                     // [4]
+    TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), 0ull, -INFINITY, (uint32_t)cbm};
     const int tid = threadIdx.x;
     const int k = p.k;
     if (tid == 0) { sc32[0] = 0; sc32[1] = 0; sc64[0] = 0ull; }
+    DIAG_NOWX(t_g0);
     __syncthreads();
     if (FLAT) {
         const uint32_t n = p.qc_cnt[q];
+        DIAG_ADD(18, n);
+        DIAG_ADD(17, 1);
         const size_t base = (size_t)p.slice_base[q] * k;
         uint32_t* overflow = &sc32[1];
         __syncthreads();
@@ -471,6 +474,7 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
 
     // explain: TitleRank/BodyRank of the winners, re-derived from the posting lists
     DIAG_NOWX(t_m0);
+    DIAG_ADD(15, t_m0 - t_g0);
     for (uint32_t i = tid; i < n_out; i += NT) { accT[i] = 0.0; accB[i] = 0.0; mgT[i] = 1.0; mgB[i] = 1.0; }
     __syncthreads();
     const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
@@ -489,9 +493,11 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
             const uint32_t g0 = (uint32_t)(p0 >> 6), g1 = (uint32_t)((p1 - 1) >> 6);
             // blocks g0+1 .. g1 start inside the list: the doc's first posting lies in the block before the first entry >= d,
             // or — if that entry IS d — at the very start of the next one: search [block start, next block start + 2)
-            const uint32_t gb = g0 + (g1 > g0 ? skip_lower_bound(p.c_skip, g0 + 1, g1 + 1, d) : 0u);
+            const uint32_t gb = g0 + (g1 > g0 ? skip_lower_bound<false>(p.c_skip, g0 + 1, g1 + 1, d) : 0u);
             uint64_t lo = max(p0, (uint64_t)gb << 6), hi = min(p1, ((uint64_t)(gb + 1) << 6) + 2);
             const uint64_t list_addr = (uint64_t)p.c_rec;
+            // a plain binary search (seven dependent probes): the merge is bound by the NUMBER of scattered loads its 300 searches
+            // per query issue, not by their latency — an 8-ary search in two steps (15 probes) made the explain 37 % slower
             while (lo < hi) {                                        // first position with doc >= d
                 const uint64_t mid = (lo + hi) >> 1;
                 if ((load_doc(list_addr, mid) & 0x7FFFFFFFu) < d) lo = mid + 1; else hi = mid;
@@ -501,8 +507,7 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
                 const uint32_t rd = load_doc(list_addr, pos);
                 if ((rd & 0x7FFFFFFFu) != d) break;
                 const int field = (int)(rd >> 31);
-                const uint64_t wbase = (uint64_t)((field ? p.t_w : p.b_w) + (field ? p.t_ptr : p.b_ptr)[term]);
-                const double v = (double)load_w(wbase, p.c_org[pos]) * mult;
+                const double v = (double)p.c_w[pos] * mult;
                 const double mag = (field ? p.t_mag : p.b_mag)[d];
                 if (field) { atomicAdd(&accT[i], v); mgT[i] = mag; }
                 else { atomicAdd(&accB[i], v); mgB[i] = mag; }
@@ -555,6 +560,8 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
         p.hits[(size_t)q * k + i] = h;
     }
     if (tid == 0) p.n_hits[q] = (int32_t)n_out;
+    DIAG_NOWX(t_m2);
+    DIAG_ADD(16, t_m2 - t_m1);
 }
 
 
@@ -930,7 +937,7 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
         __syncthreads();
         const bool last = *last_flag != 0;
         __syncthreads();
-        if (last) merge_query<TPB, true>(p, sd.q, smem);
+        if (last) merge_query<TPB, true>(p, sd.q, smem, p.cb);
     }
     DIAG_NOW(t_k3);
     DIAG_ADD(11, t_k3 - t_k0);
@@ -1114,7 +1121,7 @@ size_t score_lds_bytes(int cb) { return score_lds_layout(cb).total; }
 __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (p.q_fast && p.q_fast[blockIdx.x]) return;          // k_merge_flat's
-    merge_query<TPB_M, false>(p, blockIdx.x, smem);
+    merge_query<TPB_M, false>(p, blockIdx.x, smem, p.cb);
 }
 // the queries scored by k_score_wave: one candidate list per query
 #ifndef SS_TPB_MF
@@ -1123,7 +1130,7 @@ __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
 constexpr int TPB_MF = SS_TPB_MF;   // measured at config 3: 256 threads 0.646 ms per batch, 512: 0.683, 1024: 0.715 (the compactions' barriers)
 __global__ __launch_bounds__(TPB_MF) void k_merge_flat(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    merge_query<TPB_MF, false, true>(p, p.merge_q[blockIdx.x], smem);
+    merge_query<TPB_MF, false, true>(p, p.merge_q[blockIdx.x], smem, p.cb_flat);
 }
 
 size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 16 + 16; }
@@ -1152,14 +1159,15 @@ __global__ void k_pack_recs(const uint32_t* __restrict__ doc, const float* __res
 }
 
 // Combined lists for k_score_wave: the title and body postings of a term merged into ONE doc-sorted list (body before title
-// on the same doc), field in bit 31 of the doc word.  c_ptr[t] = t_ptr[t] + b_ptr[t]; c_org[i] = the posting's index in its own
-// table's list (the exact stage reads the float32 weight there).  One thread per posting of one table: its place is its own
+// on the same doc), field in bit 31 of the doc word.  c_ptr[t] = t_ptr[t] + b_ptr[t]; c_w[i] = the posting's float32 weight, copied
+// from its table (the exact stage reads it by the record's position: one load, where an index into the table's own list cost a
+// second, dependent one per survivor).  One thread per posting of one table: its place is its own
 // index plus the number of the OTHER field's postings of the term that come before it.  A block finds the terms its
 // postings span with two binary searches; each posting then finds its term inside that short range.
 constexpr int CM_TPB = 256, CM_PT = 8, CM_CHUNK = CM_TPB * CM_PT;
 __global__ __launch_bounds__(CM_TPB) void k_merge_lists(const uint64_t* __restrict__ my_ptr, const Rec* __restrict__ my_rec, uint64_t n_my,
                                                         const uint64_t* __restrict__ ot_ptr, const Rec* __restrict__ ot_rec, uint64_t n_terms,
-                                                        int my_field, Rec* __restrict__ c_rec, uint32_t* __restrict__ c_org) {
+                                                        int my_field, const float* __restrict__ my_w, Rec* __restrict__ c_rec, float* __restrict__ c_w) {
     __shared__ uint64_t s_t[2];
     const uint64_t base = (uint64_t)blockIdx.x * CM_CHUNK;
     if (base >= n_my) return;
@@ -1198,7 +1206,7 @@ __global__ __launch_bounds__(CM_TPB) void k_merge_lists(const uint64_t* __restri
             c.imp = v > 0.0f ? __uint_as_float(__float_as_uint(v) + 2u) : v;
         }
         c_rec[pos] = c;
-        c_org[pos] = (uint32_t)(i - my_ptr[t]);
+        c_w[pos] = my_w[i];
     }
 }
 // pad behind the combined records ({doc 0x7FFFFFFF body, impact 0}: in no window) and the skip index: c_skip[g] = doc of record 64*g
@@ -1321,7 +1329,8 @@ struct ss_scorer {
     ss::DevBuf<Rec> t_rec, b_rec;              // scoring records {doc, impact}
     // combined lists (k_score_wave): title + body postings of a term merged by doc, field in bit 31 of the doc word
     ss::DevBuf<Rec> c_rec;
-    ss::DevBuf<uint32_t> c_org, c_skip;
+    ss::DevBuf<uint32_t> c_skip;
+    ss::DevBuf<float> c_w;
     ss::DevBuf<uint64_t> c_ptr;
     bool has_combined = false;
     uint64_t c_pad_block = 0;
@@ -1414,7 +1423,7 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
         if (s->n_docs < (1ull << 31) && pc < (1ull << 32) - 128 && s->n_terms && ctx->opt("score.wave", 1) != 0) {
             const uint64_t pc_pad = ((pc + 63) & ~(uint64_t)63) + 64;
             SS_HIP(ctx, s->c_rec.alloc(pc_pad));
-            SS_HIP(ctx, s->c_org.alloc(pc_pad));
+            SS_HIP(ctx, s->c_w.alloc(pc_pad));
             SS_HIP(ctx, s->c_skip.alloc(pc_pad / 64 + 1));
             SS_HIP(ctx, s->c_ptr.alloc(s->n_terms + 1));
             hipLaunchKernelGGL(k_add_ptr_u64, dim3(ss::div_up(s->n_terms + 1, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)title->term_ptr.p,
@@ -1422,11 +1431,11 @@ int32_t ss_scorer_create(ss_ctx* ctx, ss_index* title, ss_index* body, ss_scorer
             if (body->n_post)
                 hipLaunchKernelGGL(k_merge_lists, dim3(ss::div_up(body->n_post, CM_CHUNK)), dim3(CM_TPB), 0, ctx->stream, (const uint64_t*)body->term_ptr.p,
                                    (const Rec*)s->b_rec.p, body->n_post, (const uint64_t*)title->term_ptr.p, (const Rec*)s->t_rec.p, s->n_terms, 0,
-                                   s->c_rec.p, s->c_org.p);
+                                   (const float*)body->post_w.p, s->c_rec.p, s->c_w.p);
             if (title->n_post)
                 hipLaunchKernelGGL(k_merge_lists, dim3(ss::div_up(title->n_post, CM_CHUNK)), dim3(CM_TPB), 0, ctx->stream, (const uint64_t*)title->term_ptr.p,
                                    (const Rec*)s->t_rec.p, title->n_post, (const uint64_t*)body->term_ptr.p, (const Rec*)s->b_rec.p, s->n_terms, 1,
-                                   s->c_rec.p, s->c_org.p);
+                                   (const float*)title->post_w.p, s->c_rec.p, s->c_w.p);
             hipLaunchKernelGGL(k_combined_finish, dim3(std::min<unsigned>(ss::div_up(pc_pad, 256), 16384u)), dim3(256), 0, ctx->stream, s->c_rec.p, pc, s->c_skip.p);
             s->has_combined = true;
             s->c_pad_block = ((pc + 63) & ~(uint64_t)63) / 64;
@@ -1460,9 +1469,9 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     {
         unsigned long long h[24];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h)) == hipSuccess) {
-            const char* names[15] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "cyc_setup_lists", "cyc_setup_bounds", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total", "cyc_win_add", "cyc_win_barrier", "cyc_merge_explain"};
+            const char* names[19] = {"slices", "windows", "flushes", "flushed_records", "compactions", "records", "cyc_setup_lists", "cyc_setup_bounds", "cyc_flush", "cyc_setup", "cyc_windows", "cyc_total", "cyc_win_add", "cyc_win_barrier", "cyc_merge_explain", "cyc_merge_gather", "cyc_merge_final", "merges", "merge_candidates"};
             fprintf(stderr, "[ss diag] k_score_slices (thread 0 of every slice):");
-            for (int i = 0; i < 15; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+            for (int i = 0; i < 19; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
             fprintf(stderr, "\n");
         }
         static unsigned long long hs[4096][4];
@@ -1803,6 +1812,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
 
     int cb = SS_CB_MIN;
     while (cb < 2 * k) cb <<= 1;
+    // k_merge_flat gathers ALL of a query's candidates before it sorts once (config 3: ~300 per query at k = 100; with room for
+    // 2k only it sorted 2.6 times per query, and the sorts' barriers were half of the merge)
+    const int cb_flat = std::max(cb, 512);
     const auto th2 = t_now();
 
     // ---- one pinned staging buffer, one H2D copy -------------------------------------
@@ -1915,7 +1927,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     ScoreParams p{};
     p.t_ptr = s->title->term_ptr.p; p.t_rec = s->t_rec.p; p.t_w = s->title->post_w.p; p.t_mag = s->title->mag.p; p.t_kth = s->t_kth.p;
     p.b_ptr = s->body->term_ptr.p; p.b_rec = s->b_rec.p; p.b_w = s->body->post_w.p; p.b_mag = s->body->mag.p; p.b_kth = s->b_kth.p;
-    p.c_ptr = s->c_ptr.p; p.c_rec = s->c_rec.p; p.c_org = s->c_org.p; p.c_skip = s->c_skip.p;
+    p.c_ptr = s->c_ptr.p; p.c_rec = s->c_rec.p; p.c_w = s->c_w.p; p.c_skip = s->c_skip.p;
     p.c_pad_block = (uint32_t)s->c_pad_block;
     p.t_pos_ptr = s->title->pos_ptr.p; p.t_pos = s->title->pos.p;
     p.b_pos_ptr = s->body->pos_ptr.p; p.b_pos = s->body->pos.p;
@@ -1943,6 +1955,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.order = reinterpret_cast<const uint32_t*>(dp + o_order);
     p.k = k;
     p.cb = cb;
+    p.cb_flat = cb_flat;
     p.kth_j = kth_j;
     p.exact_all = exact_all ? 1 : 0;
     p.so_key = s->d_so_key.p; p.so_doc = s->d_so_doc.p; p.so_cnt = s->d_so_cnt.p;
@@ -1977,7 +1990,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         hipLaunchKernelGGL(k_score_slices, dim3((unsigned)(n_slices - n_fast_slices)), dim3(TPB), lds_score, st, ps);
     }
     if (!fused && n_slices > n_fast_slices) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
-    if (!h_mergeq.empty()) hipLaunchKernelGGL(k_merge_flat, dim3((unsigned)h_mergeq.size()), dim3(TPB_MF), lds_merge, st, p);
+    if (!h_mergeq.empty()) hipLaunchKernelGGL(k_merge_flat, dim3((unsigned)h_mergeq.size()), dim3(TPB_MF), merge_lds_bytes(k, cb_flat), st, p);
     if (timed) {
         SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
         ctx->ev_valid[1] = true;

@@ -98,8 +98,8 @@ struct ScoreParams {
     const uint64_t* t_ptr; const Rec* t_rec; const float* t_w; const double* t_mag; const float* t_kth;
     const uint64_t* b_ptr; const Rec* b_rec; const float* b_w; const double* b_mag; const float* b_kth;
     // combined lists of k_score_wave: per term the title and body postings merged by doc (field in bit 31 of the doc word),
-    // c_org = index of the posting in its own table's list, c_skip[g] = doc of record 64*g (one entry per 512-byte block)
-    const uint64_t* c_ptr; const Rec* c_rec; const uint32_t* c_org; const uint32_t* c_skip;
+    // c_w = the posting's float32 weight (a copy, in the combined order), c_skip[g] = doc of record 64*g (one entry per 512-byte block)
+    const uint64_t* c_ptr; const Rec* c_rec; const float* c_w; const uint32_t* c_skip;
     uint32_t c_pad_block;     // blocks of real records (the block behind them is all padding)
     // positional postings (phrase search, retrieval/phrase.go): pos_ptr[P+1] into pos[] per table, or null
     const uint64_t* t_pos_ptr; const float* t_pos;
@@ -130,6 +130,7 @@ struct ScoreParams {
     const uint32_t* order;     // launch order -> slice index (longest first)
     int32_t k;
     int32_t cb;                // candidate buffer entries (power of two >= 2k)
+    int32_t cb_flat;           // k_merge_flat's own (>= cb)
     int32_t kth_j;             // smallest j with 2^j >= k
     int32_t exact_all;         // 1: the filter's assumptions do not hold for this call: every record goes to the exact stage
     uint64_t* so_key; uint32_t* so_doc; uint32_t* so_cnt;   // per slice top-k
@@ -154,6 +155,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // native vector: 
 typedef const u32x2 __attribute__((address_space(1)))* gptr_u2;
 typedef const uint32_t __attribute__((address_space(1)))* gptr_u32;
 typedef const float __attribute__((address_space(1)))* gptr_f32;
+typedef const double __attribute__((address_space(1)))* gptr_f64;
 __device__ __forceinline__ u32x2 load_rec(uint64_t list_addr, uint64_t idx) { return *(gptr_u2)(list_addr + idx * sizeof(Rec)); }
 __device__ __forceinline__ uint32_t load_doc(uint64_t list_addr, uint64_t idx) { return *(gptr_u32)(list_addr + idx * sizeof(Rec)); }
 __device__ __forceinline__ float load_w(uint64_t w_addr, uint64_t idx) { return *(gptr_f32)(w_addr + idx * sizeof(float)); }
@@ -227,6 +229,9 @@ __device__ __forceinline__ uint64_t lower_bound_rec_interp(const Rec* __restrict
 
 // number of entries of the global u32 array a[lo, hi) (ascending) that are < v, as an offset from lo: interpolation
 // steps with two independent probes each, then an 8-ary finish (lower_bound_interp of score_common.hpp for 4-byte entries)
+// WIDE = false finishes with a plain binary search: fewer loads in all (k_merge_flat, which is bound by the number of scattered
+// loads it issues); WIDE = true with fewer DEPENDENT ones (the set-up of a slice, which waits for every step)
+template <bool WIDE = true>
 __device__ __forceinline__ uint32_t skip_lower_bound(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t v) {
     if (lo >= hi) return 0;
     uint32_t L = lo, H = hi - 1;
@@ -245,6 +250,13 @@ __device__ __forceinline__ uint32_t skip_lower_bound(const uint32_t* __restrict_
         if (dx >= v) { H = x; dh = dx; }
         else if (dy < v) { L = y; dl = dy; }
         else { L = x; dl = dx; H = y; dh = dy; }
+    }
+    if (!WIDE) {
+        while (H - L > 1) {
+            const uint32_t mid = (L + H) >> 1;
+            if (a[mid] < v) L = mid; else H = mid;
+        }
+        return H - lo;
     }
     while (H - L > 1) {
         const uint32_t step = (H - L + 7) >> 3;
@@ -329,7 +341,7 @@ struct TopK {
 // (An enumeration sort — every entry counts the entries that precede it, 2 barriers instead of 38 — measured
 // 25 % slower end to end: 65k broadcast LDS reads cost more than the bitonic network's barriers.)
 // (by value: a reference would force the struct into scratch memory for the out-of-line call)
-__device__ void topk_compact(const TopK tk, int k) {
+__device__ __forceinline__ void topk_compact_inl(const TopK& tk, int k) {
     DIAG_ADD(4, 1);
     lds_barrier();
     const uint32_t nthr = blockDim.x;
@@ -366,6 +378,7 @@ __device__ void topk_compact(const TopK tk, int k) {
     }
     lds_barrier();
 }
+__device__ void topk_compact(const TopK tk, int k) { topk_compact_inl(tk, k); }
 
 struct SliceQuery {      // per-query constants of the exact stage
     double qmag, sqd_ub;

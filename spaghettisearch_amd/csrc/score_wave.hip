@@ -139,18 +139,51 @@ struct __attribute__((aligned(16))) WPrep {
 };
 
 typedef const ScoreParams __attribute__((address_space(4)))* kparams_chk_t;
-struct RareArgs { const double* t_mag; const double* b_mag; const double* prior; const uint32_t* c_org; int32_t k_topics, k; };
+struct RareArgs { const double* t_mag; const double* b_mag; const double* prior; const float* c_w; int32_t k_topics, k; };
+
+// The wave's LDS, at namespace scope: k_score_wave's rare paths (the exact stage, an oversize window) are functions the kernel
+// CALLS (inlined they cost the hot loop its registers), and a called function that gets LDS pointers as arguments sees generic
+// pointers: every access became a flat_load with vmcnt(0) lgkmcnt(0) behind it, and the argument structs travelled through
+// scratch memory.  Named directly, the same accesses are ds_ instructions and the calls pass two scalars.
+__shared__ __attribute__((aligned(16))) uint32_t sk[WSK + 4];
+static_assert(WSK == 1024, "the row's sketch is cleared by four 16-byte stores per lane");
+__shared__ uint32_t se[(WSE + 32) > 2 * WHT ? (WSE + 32) : 2 * WHT];   // skip entries while a round is planned, then ht_key | ht_rec
+__shared__ __attribute__((aligned(16))) uint32_t ghdr[WGMAX + 2 * WDEPTH][4];
+__shared__ uint32_t gdesc[WGMAX + 2 * WDEPTH][WCW];
+__shared__ __attribute__((aligned(16))) unsigned char pend_raw[WPW * 16];
+__shared__ uint64_t cd_key[WCB];
+__shared__ uint32_t cd_doc[WCB];
+__shared__ uint32_t l_mult[WL], l_adv[WL];
+__shared__ uint64_t sc64[2];
+__shared__ uint32_t sc32[8];
+struct RareState {          // what the called paths need of the slice and the batch, written once by the slice's set-up
+    SliceQuery Q;
+    RareArgs ra;
+    uint64_t thr0_key, tb;
+    float thr0_f, r_ub, fx_scale;
+};
+__shared__ RareState rs;
 
 struct WaveLds {
     double2* s_rec;      // [WPW] exact stage: {addend, magnitude}
     uint4* pend;         // [WPW] the same bytes while pending: {doc, index in the combined arrays, term, field}
-    uint64_t* l_wb;      // [WL] address of the first float32 weight of the term's body list
-    uint64_t* l_wt;      // [WL] ... of its title list
     uint32_t* l_mult;    // [WL]
     uint32_t* ht_key;    // [WHT]
     uint32_t* ht_rec;    // [WHT]
     uint32_t* overflow;
 };
+
+__device__ __forceinline__ WaveLds wave_lds() {
+    return WaveLds{reinterpret_cast<double2*>(pend_raw), reinterpret_cast<uint4*>(pend_raw), l_mult, se, se + WHT, &sc32[1]};
+}
+__device__ __forceinline__ TopK wave_topk(uint64_t thr0_key, float thr0_f) {
+    return TopK{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), thr0_key, thr0_f, (uint32_t)WCB};
+}
+// the candidate buffer sorted and cut to k (topk_compact for one wave), as a call
+__device__ __noinline__ void wave_compact(int k) {
+    const TopK tk = wave_topk(rs.thr0_key, rs.thr0_f);
+    topk_compact_inl(tk, k);
+}
 
 // ---- exact stage of one wave (flush_pending / score_owned of score.hip for 64 threads) ------------------------------
 __device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& tk, const SliceQuery& Q, const RareArgs& ra, int lane,
@@ -173,7 +206,12 @@ __device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& t
         if (Q.probs) {
             // the prior row is only fetched if the doc can still make the top-k (every operation of final_rank is monotone in sqd)
             final_rank(T, B, mt, mb, Q.qmag, Q.sqd_ub, title, body, fin);
-            if (fkey(fin) >= thr0 || fin != fin) final_rank(T, B, mt, mb, Q.qmag, topic_dot(kp->prior, Q.probs, kp->k_topics, e_doc), title, body, fin);
+            if (fkey(fin) >= thr0 || fin != fin) {
+                double sqd = 0.0;                        // topic_dot (get_metadata.go:39-42, topic order) through global pointers
+                const gptr_f64 pr = (gptr_f64)kp->prior + (size_t)e_doc * kp->k_topics, pb = (gptr_f64)Q.probs;
+                for (int t = 0; t < kp->k_topics; t++) sqd += pb[t] * pr[t];
+                final_rank(T, B, mt, mb, Q.qmag, sqd, title, body, fin);
+            }
             else e_doc = EMPTY;
         } else {
             final_rank(T, B, mt, mb, Q.qmag, 0.0, title, body, fin);
@@ -193,41 +231,41 @@ __device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& t
         }
         lds_wait();
         if (!*S.overflow) break;
-        topk_compact(tk, kp->k);
+        wave_compact(kp->k);
         if (lane == 0) *S.overflow = 0;
         lds_wait();
     }
 }
 
-__device__ __noinline__ void wave_flush(const WaveLds S, const TopK tk, const SliceQuery Q, const RareArgs ra, int lane, uint32_t n) {
+__device__ __noinline__ void wave_flush(int lane, uint32_t n) {
+    const WaveLds S = wave_lds();
+    const SliceQuery Q = rs.Q;
+    const RareArgs ra = rs.ra;
+    const TopK tk = wave_topk(rs.thr0_key, rs.thr0_f);
     const RareArgs* kp = &ra;
+    DIAG_NOW(t_f0);
     uint32_t pdoc[2], pl[2], pf[2], own[2];
     float pw[2];
     double pm[2];
-    uint32_t porg[2];
+    // no branch around the loads (a load under a branch makes the compiler drain every load in flight where the branch joins:
+    // the second half's loads would wait for the first's): lanes without an entry read entry 0 (n >= 1) and drop it
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const uint32_t i = lane + r * 64;
-        pl[r] = EMPTY;
-        pf[r] = 0;
-        pdoc[r] = 0;
-        porg[r] = 0;
-        pm[r] = 1.0;
-        if (i < n) {
-            const uint4 e = S.pend[i];
-            pdoc[r] = e.x;
-            pl[r] = e.z;
-            pf[r] = e.w;
-            porg[r] = kp->c_org[e.y];                   // the posting's index in its own table's list
-            pm[r] = (e.w ? kp->t_mag : kp->b_mag)[e.x];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        pw[r] = 0.f;
-        if (pl[r] != EMPTY) pw[r] = load_w(pf[r] ? S.l_wt[pl[r]] : S.l_wb[pl[r]], porg[r]);
+        const bool in = i < n;
+        const uint4 e = S.pend[in ? i : 0u];
+        pdoc[r] = e.x;
+        pl[r] = in ? e.z : EMPTY;
+        pf[r] = e.w;
+        // (the pointers come out of LDS as generic ones: named global, the loads are global_load and count on vmcnt alone)
+        pw[r] = ((gptr_f32)kp->c_w)[e.y];               // the posting's float32 weight, by its position in the combined list
+        pm[r] = ((gptr_f64)(e.w ? kp->t_mag : kp->b_mag))[e.x];
     }
     lds_wait();                                     // every pending entry has been read: the bytes may be rewritten
+#ifdef SS_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    DIAG_NOW(t_f1);
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const uint32_t l = pl[r];
@@ -258,8 +296,13 @@ __device__ __noinline__ void wave_flush(const WaveLds S, const TopK tk, const Sl
         }
     }
     lds_wait();
+    DIAG_NOW(t_f2);
 #pragma unroll
     for (int r = 0; r < 2; r++) wave_score_owned(S, tk, Q, ra, lane, pdoc[r], own[r]);
+    DIAG_NOW(t_f3);
+    WDIAG_ADD(21, t_f1 - t_f0);
+    WDIAG_ADD(22, t_f2 - t_f1);
+    WDIAG_ADD(23, t_f3 - t_f2);
 }
 
 // per-list constants, lane l < L holds list l (= distinct query term l)
@@ -306,8 +349,13 @@ __device__ __forceinline__ uint32_t wave_thr_fx(const WaveCtx& C) { return max(1
 // window; they are added with the smaller clamp, and the whole sketch is cleared at the end).  Otherwise the caller has
 // added them (and its slots are cleared here).  The pending list must be empty.  Survivors go to the exact stage by doc
 // sub-range, bisected until a piece fits.
-__device__ __noinline__ void slow_window(const WaveCtx C, const RareArgs ra, const WList w, int lane, uint32_t row, uint32_t n_blocks,
+__device__ __noinline__ void slow_window(const WList w, int lane, uint32_t row, uint32_t n_blocks,
                                          uint32_t b_lo, uint32_t span, bool need_add) {
+    WaveCtx C;
+    C.sk = sk; C.ghdr = ghdr; C.gdesc = gdesc; C.tb = rs.tb;
+    C.S = wave_lds();
+    C.tk = wave_topk(rs.thr0_key, rs.thr0_f);
+    C.r_ub = rs.r_ub; C.fx_scale = rs.fx_scale;
     const uint32_t clamp = need_add ? FX_CLAMP_SLOW : FX_CLAMP;
     if (need_add) {
         for (uint32_t i = 0; i < n_blocks; i++) {
@@ -354,7 +402,7 @@ __device__ __noinline__ void slow_window(const WaveCtx C, const RareArgs ra, con
             }
         }
         lds_wait();
-        if (n) wave_flush(C.S, C.tk, C.Q, ra, lane, min(n, (uint32_t)WPW));
+        if (n) wave_flush(lane, min(n, (uint32_t)WPW));
         cur += sub;
     }
     if (need_add) {
@@ -476,9 +524,26 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const uint32_t* c_skip, ui
     if (rem > 1) ql = min(rem - 1u, max(2u, (uint32_t)(((uint64_t)(WSE - WL) * rem) / tot_rem)));
     w.q = ql;
     w.soff = wave_excl_scan(ql, lane);
-    for (int l = 0; l < L; l++) {
-        const uint32_t n = rl(w.q, l), so = rl(w.soff, l), cgl = rl(w.cg, l);
-        for (uint32_t i = lane; i < n; i += 64) se[so + i] = c_skip[cgl + 1u + i];
+    // the lists' entries lie back to back in `se` (soff is a running sum): entry j belongs to the last list with entries whose
+    // soff <= j.  All of a lane's loads are issued before the first is stored — list by list, every list cost the round one
+    // memory latency.  No branch around a load: lanes past the end repeat the last entry.
+    const uint32_t tot_q = wave_sum(ql);
+    if (tot_q) {
+        constexpr int NIT = (WSE + 63) / 64;
+        uint32_t sv[NIT], sj[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t j = min((uint32_t)lane + 64u * (uint32_t)it, tot_q - 1u);
+            uint32_t so = 0, cgl = 0;
+            for (int l = 0; l < L; l++) {
+                const uint32_t s_l = rl(w.soff, l);
+                if (rl(w.q, l) && j >= s_l) { so = s_l; cgl = rl(w.cg, l); }
+            }
+            sj[it] = j;
+            sv[it] = ((gptr_u32)c_skip)[cgl + 1u + (j - so)];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) se[sj[it]] = sv[it];
     }
     lds_wait();
     // the round ends where the first list runs out of staged entries
@@ -489,7 +554,7 @@ __device__ __noinline__ RoundPlan plan_round(WList w, const uint32_t* c_skip, ui
     // driver = the list with the most staged entries; a window = s of its blocks
     const uint32_t dkey = wave_max((w.q << 6) | (uint32_t)(63 - lane));
     const int drv = 63 - (int)(dkey & 63u);
-    const uint32_t q_drv = dkey >> 6, tot_q = wave_sum(w.q);
+    const uint32_t q_drv = dkey >> 6;
     const uint32_t so_drv = rl(w.soff, drv);
     const int l_act = __popcll(act_mask);
     // BASE windows of s driver blocks each (lane j: [B_j, B_j+1)), about half a row's worth; then consecutive base windows are
@@ -650,20 +715,8 @@ __global__ __launch_bounds__(256) void k_wave_prep(ScoreParams p, uint32_t n_sli
 }
 
 __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, const WPrep* __restrict__ prep) {
-    __shared__ __attribute__((aligned(16))) uint32_t sk[WSK + 4];
-    static_assert(WSK == 1024, "the row's sketch is cleared by four 16-byte stores per lane");
-    __shared__ uint32_t se[(WSE + 32) > 2 * WHT ? (WSE + 32) : 2 * WHT];   // skip entries while a round is planned, then ht_key | ht_rec
-    __shared__ __attribute__((aligned(16))) uint32_t ghdr[WGMAX + 2 * WDEPTH][4];
-    __shared__ uint32_t gdesc[WGMAX + 2 * WDEPTH][WCW];
-    __shared__ __attribute__((aligned(16))) unsigned char pend_raw[WPW * 16];
     uint32_t* const ht_key = se;
     uint32_t* const ht_rec = se + WHT;
-    __shared__ uint64_t cd_key[WCB];
-    __shared__ uint32_t cd_doc[WCB];
-    __shared__ uint64_t l_wb[WL], l_wt[WL];
-    __shared__ uint32_t l_mult[WL], l_adv[WL];
-    __shared__ uint64_t sc64[2];
-    __shared__ uint32_t sc32[8];
 
     const int lane = threadIdx.x;
     DIAG_NOW(t_w0);
@@ -680,8 +733,6 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     C.tb = (uint64_t)p.c_rec;
     C.S.s_rec = reinterpret_cast<double2*>(pend_raw);
     C.S.pend = reinterpret_cast<uint4*>(pend_raw);
-    C.S.l_wb = l_wb;
-    C.S.l_wt = l_wt;
     C.S.l_mult = l_mult;
     C.S.ht_key = ht_key;
     C.S.ht_rec = ht_rec;
@@ -709,11 +760,6 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
         w.hi_lane = (r.lanes >> 8) & 0xFFu;
         w.cg = r.cg;
         w.ge = r.ge;
-        {
-            const uint32_t term = p.dterm[t0 + lane];
-            l_wb[lane] = (uint64_t)(p.b_w + p.b_ptr[term]);
-            l_wt[lane] = (uint64_t)(p.t_w + p.t_ptr[term]);
-        }
         l_mult[lane] = r.mult;
         // filter coefficients and threshold floor exactly as in k_score_slices (get_metadata.go:57-58,69)
         const double share_b = 29.0 * (double)r.mult / C.Q.qmag, share_t = 38.0 * (double)r.mult / C.Q.qmag;
@@ -731,13 +777,21 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     const uint64_t thr0_key = thr0_f > 0.0f ? fkey((double)thr0_f) : 0ull;
     C.tk = TopK{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), thr0_key, thr0_f > 0.0f ? thr0_f : -INFINITY, (uint32_t)WCB};
     if (lane == 0 && thr0_f > 0.0f) { sc64[0] = thr0_key; *reinterpret_cast<float*>(&sc32[2]) = thr0_f; }
+    if (lane == 0) {
+        rs.Q = C.Q;
+        rs.ra = RareArgs{p.t_mag, p.b_mag, p.prior, p.c_w, p.k_topics, p.k};
+        rs.thr0_key = thr0_key;
+        rs.thr0_f = thr0_f > 0.0f ? thr0_f : -INFINITY;
+        rs.tb = C.tb;
+        rs.r_ub = C.r_ub;
+        rs.fx_scale = C.fx_scale;
+    }
     const unsigned long long act_mask = __ballot(lane < L && w.active);
     lds_wait();
 
     DIAG_NOW(t_w1);
     WDIAG_ADD(0, 1);
     WDIAG_ADD(10, t_w1 - t_w0);
-    const RareArgs ra{p.t_mag, p.b_mag, p.prior, p.c_org, p.k_topics, p.k};
     uint32_t F = sd.dlo;                               // frontier: docs below it are done
     uint32_t pend_n = 0;                               // pending survivors (wave-uniform)
     uint32_t thr_fx = wave_thr_fx(C);
@@ -769,7 +823,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
 #if SSW_DEPTH == 3
             group_issue<2>(p, gdesc, r0 + 2, lane, rec, dvr);
 #endif
-#ifdef SS_DIAG
+#if defined(SS_DIAG) && defined(SS_DIAG_LOOP)      // stamps inside the row loop cost more than the rows (2.4 ms per batch instead of 0.44)
 #define WSTAMP(var) DIAG_NOW(var)
 #define WACC(i, a, b) dg[i] += (b) - (a)
 #else
@@ -850,11 +904,13 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                 DIAG_NOW(t_e0);
                 const uint4 hv = *reinterpret_cast<const uint4*>(ghdr[ev_row]);
                 const uint32_t b_lo = rfl(hv.x), span = rfl(hv.y), n_blk = rfl(hv.w);
-                if (pend_n) wave_flush(C.S, C.tk, C.Q, ra, lane, pend_n);
+#ifndef SSW_EXP_NOFLUSH
+                if (pend_n) wave_flush(lane, pend_n);
+#endif
                 pend_n = 0;
                 r0 = ev_row;                            // EV_FLUSH: the row has not been touched: it runs again
-                if (ev == EV_OVERFLOW) { slow_window(C, ra, w, lane, ev_row, n_blk, b_lo, span, false); r0 = ev_row + 1; }
-                if (ev == EV_SLOW) { slow_window(C, ra, w, lane, ev_row, n_blk, b_lo, span, true); r0 = ev_row + 1; }
+                if (ev == EV_OVERFLOW) { slow_window(w, lane, ev_row, n_blk, b_lo, span, false); r0 = ev_row + 1; }
+                if (ev == EV_SLOW) { slow_window(w, lane, ev_row, n_blk, b_lo, span, true); r0 = ev_row + 1; }
                 thr_fx = wave_thr_fx(C);
                 DIAG_NOW(t_e1);
                 WDIAG_ADD(12, t_e1 - t_e0);
@@ -868,11 +924,16 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
         lds_wait();
     }
     WDIAG_ADD(7, pend_n);
-    if (pend_n) wave_flush(C.S, C.tk, C.Q, ra, lane, pend_n);
+    DIAG_NOW(t_ff0);
+#if !defined(SSW_EXP_NOFINAL) && !defined(SSW_EXP_NOFLUSH)      // (timing experiments only: wrong results)
+    if (pend_n) wave_flush(lane, pend_n);
+#endif
     DIAG_NOW(t_w2);
+    WDIAG_ADD(20, t_w2 - t_ff0);
+    WDIAG_ADD(24, pend_n ? 1 : 0);
 
     // hand the candidates in: appended to the query's list (k_merge_flat sorts; a slice sorts only if it holds more than k)
-    if (sc32[0] > (uint32_t)p.k) topk_compact(C.tk, p.k);
+    if (sc32[0] > (uint32_t)p.k) wave_compact(p.k);
     lds_wait();
     const uint32_t n_out = min(sc32[0], (uint32_t)p.k);
     uint32_t pos = 0;
@@ -915,11 +976,11 @@ void score_wave_diag_dump() {
 #ifdef SS_DIAG
     unsigned long long h[32];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wdiag), sizeof(h)) == hipSuccess) {
-        const char* names[20] = {"slices", "rounds", "rows", "-", "ev_flush", "ev_overflow", "ev_slow", "flushed_records", "handed_in", "blocks",
+        const char* names[25] = {"slices", "rounds", "rows", "-", "ev_flush", "ev_overflow", "ev_slow", "flushed_records", "handed_in", "blocks",
                                  "cyc_setup", "cyc_plan", "cyc_events", "cyc_stream", "cyc_epilogue", "cyc_total", "cyc_row_add", "cyc_row_read",
-                                 "cyc_row_append_clear", "cyc_row_issue"};
+                                 "cyc_row_append_clear", "cyc_row_issue", "cyc_final_flush", "cyc_flush_loads", "cyc_flush_hash", "cyc_flush_score", "final_flushes"};
         fprintf(stderr, "[ss diag] k_score_wave (lane 0 of every slice):");
-        for (int i = 0; i < 20; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+        for (int i = 0; i < 25; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
         fprintf(stderr, "\n");
     }
 #endif

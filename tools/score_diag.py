@@ -22,7 +22,8 @@ print(f"scorer created in {time.time() - t0:.3f}s", file=sys.stderr)
 nq = int(sys.argv[sys.argv.index("--queries") + 1]) if "--queries" in sys.argv else 1024
 import os
 q_ptr, q_terms = synth.make_queries(nq, 3, int(os.environ.get("RANKS", "10000")), seed=45)
-hits, n = sc.score_topk(q_ptr, q_terms, 100)
+for _ in range(int(os.environ.get('BATCHES', '1'))):
+    hits, n = sc.score_topk(q_ptr, q_terms, 100)
 print("kernel ms", ctx.last_kernel_ms(1), file=sys.stderr)
 sc.close()
 ti.close(); bi.close(); ctx.close()
