@@ -378,7 +378,18 @@ __device__ __forceinline__ void topk_compact_inl(const TopK& tk, int k) {
     }
     lds_barrier();
 }
-__device__ void topk_compact(const TopK tk, int k) { topk_compact_inl(tk, k); }
+// the called form: the buffer is in LDS in every caller, and the function is told so (pointer arguments are generic otherwise:
+// flat_load / flat_store with vmcnt(0) lgkmcnt(0) behind every step of the sort)
+__device__ void topk_compact(const TopK tk, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.key));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.doc));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.count));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.thr));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.thr_f));
+#endif
+    topk_compact_inl(tk, k);
+}
 
 struct SliceQuery {      // per-query constants of the exact stage
     double qmag, sqd_ub;

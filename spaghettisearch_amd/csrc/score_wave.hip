@@ -237,20 +237,23 @@ __device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& t
     }
 }
 
-__device__ __noinline__ void wave_flush(int lane, uint32_t n) {
+// NR = pending entries per lane: most flushes (the one at the end of every slice above all) hold fewer than 64 entries, and the
+// second entry's share of the code would run for nothing
+template <int NR>
+__device__ __forceinline__ void flush_body(int lane, uint32_t n) {
     const WaveLds S = wave_lds();
     const SliceQuery Q = rs.Q;
     const RareArgs ra = rs.ra;
     const TopK tk = wave_topk(rs.thr0_key, rs.thr0_f);
     const RareArgs* kp = &ra;
     DIAG_NOW(t_f0);
-    uint32_t pdoc[2], pl[2], pf[2], own[2];
-    float pw[2];
-    double pm[2];
+    uint32_t pdoc[NR], pl[NR], pf[NR], own[NR];
+    float pw[NR];
+    double pm[NR];
     // no branch around the loads (a load under a branch makes the compiler drain every load in flight where the branch joins:
     // the second half's loads would wait for the first's): lanes without an entry read entry 0 (n >= 1) and drop it
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < NR; r++) {
         const uint32_t i = lane + r * 64;
         const bool in = i < n;
         const uint4 e = S.pend[in ? i : 0u];
@@ -267,7 +270,7 @@ __device__ __noinline__ void wave_flush(int lane, uint32_t n) {
 #endif
     DIAG_NOW(t_f1);
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < NR; r++) {
         const uint32_t l = pl[r];
         own[r] = EMPTY;
         if (l != EMPTY) {
@@ -298,11 +301,16 @@ __device__ __noinline__ void wave_flush(int lane, uint32_t n) {
     lds_wait();
     DIAG_NOW(t_f2);
 #pragma unroll
-    for (int r = 0; r < 2; r++) wave_score_owned(S, tk, Q, ra, lane, pdoc[r], own[r]);
+    for (int r = 0; r < NR; r++) wave_score_owned(S, tk, Q, ra, lane, pdoc[r], own[r]);
     DIAG_NOW(t_f3);
     WDIAG_ADD(21, t_f1 - t_f0);
     WDIAG_ADD(22, t_f2 - t_f1);
     WDIAG_ADD(23, t_f3 - t_f2);
+}
+
+__device__ __noinline__ void wave_flush(int lane, uint32_t n) {
+    if (n > 64u) flush_body<2>(lane, n);
+    else flush_body<1>(lane, n);
 }
 
 // per-list constants, lane l < L holds list l (= distinct query term l)
