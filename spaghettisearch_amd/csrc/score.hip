@@ -1315,7 +1315,8 @@ double unkey(uint64_t k) {
 namespace ss {
 // score_wave.hip
 size_t score_wave_prep_bytes(unsigned n_slices);
-void launch_score_wave(const void* params, unsigned n_slices, void* prep, hipStream_t st);
+void launch_wave_prep(const void* params, unsigned n_slices, void* prep, hipStream_t st);
+void launch_score_wave(const void* params, unsigned n_slices, const void* prep, hipStream_t st);
 int score_wave_max_lists();
 int score_wave_max_k();
 void score_wave_diag_dump();
@@ -1342,7 +1343,7 @@ struct ss_scorer {
     int k_topics = 0;
     int lds_attr = 0;
     // per-call workspaces, grow-only (no hipMalloc/hipFree on the steady-state query path)
-    ss::DevBuf<unsigned char> d_plan2[2], d_wprep;   // the plan on the device, one buffer per turn: batch i+1's upload runs beside batch i's kernels
+    ss::DevBuf<unsigned char> d_plan2[2], d_wprep2[2];   // the plan on the device, one buffer per turn: batch i+1's upload runs beside batch i's kernels
     // pinned staging for the plan, double-buffered: a call that returns results in device memory does not wait
     // for the GPU, so the next call plans (and fills the other buffer) while this one's copy and kernels run
     unsigned char* h_plan[2] = {nullptr, nullptr};
@@ -1464,6 +1465,9 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+#if defined(SSW_PHASES) && !defined(SS_DIAG)
+    ss::score_wave_diag_dump();
+#endif
 #ifdef SS_DIAG
     ss::score_wave_diag_dump();
     {
@@ -1883,21 +1887,6 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         (void)hipGetLastError();                 // plain host memory is reported as an error: not one
         dev_out = d1 && d2;
     }
-    // The upload goes out on the context's SECOND stream as soon as the plan is staged — beside the kernels of the previous
-    // batch, which read the other device buffer.  (On the one stream the copy sat
-    // between two batches: 39 us per batch in the kernel trace with the counter memset, 6 % of the wall time at config 3.)
-    if (s->batch_ev_pending[pb]) SS_HIP(ctx, hipEventSynchronize(s->batch_ev[pb]));   // the batch two calls ago read this device buffer: the host runs at most two batches ahead
-    if (!dev_out) {
-        // results go back to the host: the call waits for them anyway, and a second wait in the middle would only add to a lone
-        // query's latency (0.15 ms, of which 0.08 are kernels): copy, kernels and read-back follow each other on the one stream
-        SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, st));
-    } else {
-    SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, ctx->comm_stream));
-    // ... and the HOST waits for it (~15 us; it has 0.4 ms to spare per batch): the kernels then go out on the caller's stream
-    // with no cross-stream dependency in front of them (a hipStreamWaitEvent there left 21 us between two batches, and two of
-    // them per batch ran the runtime out of signals every ~80 batches: an 8 ms stall)
-    SS_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
-    }
     if (any_phrase) {
         for (int x = 0; x < 4; x++) {
             SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
@@ -1966,6 +1955,29 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.hits = dev_out ? hits_out : s->d_hits.p;
     p.n_hits = dev_out ? n_hits_out : s->d_nhits.p;
 
+    // The upload goes out on the context's SECOND stream as soon as the plan is staged — beside the kernels of the previous
+    // batch, which read the other device buffer.  (On the one stream the copy sat
+    // between two batches: 39 us per batch in the kernel trace with the counter memset, 6 % of the wall time at config 3.)
+    if (s->batch_ev_pending[pb]) SS_HIP(ctx, hipEventSynchronize(s->batch_ev[pb]));   // the batch two calls ago read this device buffer: the host runs at most two batches ahead
+    if (n_fast_slices) SS_HIP(ctx, ensure(s->d_wprep2[pb], ss::score_wave_prep_bytes((unsigned)n_fast_slices)));
+    bool prep_done = false;
+    if (!dev_out) {
+        // results go back to the host: the call waits for them anyway, and a second wait in the middle would only add to a lone
+        // query's latency (0.15 ms, of which 0.08 are kernels): copy, kernels and read-back follow each other on the one stream
+        SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, st));
+    } else {
+        SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, ctx->comm_stream));
+        // k_wave_prep reads the plan and the index, nothing of an earlier batch: it follows the copy on the second stream and so
+        // runs beside the previous batch's kernels too (12 us of kernel and one launch gap per batch off the caller's stream)
+        if (n_fast_slices) {
+            ss::launch_wave_prep(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, ctx->comm_stream);
+            prep_done = true;
+        }
+        // ... and the HOST waits for both (~30 us; it has 0.4 ms to spare per batch): the kernels then go out on the caller's stream
+        // with no cross-stream dependency in front of them (a hipStreamWaitEvent there left 21 us between two batches, and two of
+        // them per batch ran the runtime out of signals every ~80 batches: an 8 ms stall)
+        SS_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+    }
     const auto th4 = t_now();
     const size_t lds_score = score_lds_bytes(cb), lds_merge = merge_lds_bytes(k, cb);
     if (s->lds_attr < cb) {
@@ -1981,8 +1993,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
     }
     if (n_fast_slices) {
-        SS_HIP(ctx, ensure(s->d_wprep, ss::score_wave_prep_bytes((unsigned)n_fast_slices)));
-        ss::launch_score_wave(&p, (unsigned)n_fast_slices, s->d_wprep.p, st);
+        if (!prep_done) ss::launch_wave_prep(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, st);
+        ss::launch_score_wave(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, st);
     }
     if (n_slices > n_fast_slices) {
         ScoreParams ps = p;

@@ -75,6 +75,14 @@ enum : uint32_t { M_NORMAL = 1, M_SLOW = 2, M_SKIP = 0 };
 // checked build (tools/build_diag.sh with EXTRA=-DSSW_CHECK): a block index outside its table is recorded and replaced by block 0
 __device__ uint32_t g_wcheck[8];
 #endif
+#ifdef SSW_PHASES
+// -DSSW_PHASES (tools/build_variant.sh): seven s_memtime stamps per slice, summed at its end — light enough to leave the kernel's
+// time alone (the SS_DIAG build's stamps and counters do not: 2.4 ms per batch).  Printed by ss_scorer_destroy.
+__device__ unsigned long long g_wphase[8];
+#define PH_NOW(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define PH_NOW(var) do { } while (0)
+#endif
 #ifdef SS_DIAG
 __device__ unsigned long long g_wdiag[32];
 #define WDIAG_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_wdiag[i], (unsigned long long)(v)); } while (0)
@@ -728,6 +736,10 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
 
     const int lane = threadIdx.x;
     DIAG_NOW(t_w0);
+    PH_NOW(ph0);
+#ifdef SSW_PHASES
+    unsigned long long ph_plan = 0, ph_ev = 0;
+#endif
     const uint32_t slice_id = p.order[blockIdx.x];
     const SliceDesc sd = p.slices[slice_id];
     const uint32_t q = sd.q;
@@ -798,6 +810,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     lds_wait();
 
     DIAG_NOW(t_w1);
+    PH_NOW(ph1);
     WDIAG_ADD(0, 1);
     WDIAG_ADD(10, t_w1 - t_w0);
     uint32_t F = sd.dlo;                               // frontier: docs below it are done
@@ -811,9 +824,14 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
 #endif
     while (act_mask && F < sd.dhi) {
         DIAG_NOW(t_p0);
+        PH_NOW(php0);
         const RoundPlan rp = plan_round(w, p.c_skip, se, ghdr, gdesc, l_adv, L, act_mask, F, sd.dhi, lane);
         const uint32_t n_rows = rp.n_rows;
         DIAG_NOW(t_p1);
+        PH_NOW(php1);
+#ifdef SSW_PHASES
+        ph_plan += php1 - php0;
+#endif
         WDIAG_ADD(1, 1);
         WDIAG_ADD(2, n_rows);
         WDIAG_ADD(11, t_p1 - t_p0);
@@ -910,6 +928,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                 WDIAG_ADD(3 + ev, 1);
                 WDIAG_ADD(7, pend_n);
                 DIAG_NOW(t_e0);
+                PH_NOW(phe0);
                 const uint4 hv = *reinterpret_cast<const uint4*>(ghdr[ev_row]);
                 const uint32_t b_lo = rfl(hv.x), span = rfl(hv.y), n_blk = rfl(hv.w);
 #ifndef SSW_EXP_NOFLUSH
@@ -921,6 +940,10 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                 if (ev == EV_SLOW) { slow_window(w, lane, ev_row, n_blk, b_lo, span, true); r0 = ev_row + 1; }
                 thr_fx = wave_thr_fx(C);
                 DIAG_NOW(t_e1);
+                PH_NOW(phe1);
+#ifdef SSW_PHASES
+                ph_ev += phe1 - phe0;
+#endif
                 WDIAG_ADD(12, t_e1 - t_e0);
             }
         }
@@ -933,10 +956,12 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     }
     WDIAG_ADD(7, pend_n);
     DIAG_NOW(t_ff0);
+    PH_NOW(ph2);
 #if !defined(SSW_EXP_NOFINAL) && !defined(SSW_EXP_NOFLUSH)      // (timing experiments only: wrong results)
     if (pend_n) wave_flush(lane, pend_n);
 #endif
     DIAG_NOW(t_w2);
+    PH_NOW(ph3);
     WDIAG_ADD(20, t_w2 - t_ff0);
     WDIAG_ADD(24, pend_n ? 1 : 0);
 
@@ -953,6 +978,20 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
         p.so_doc[base + i] = cd_doc[i];
     }
     DIAG_NOW(t_w3);
+#ifdef SSW_PHASES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PH_NOW(ph4);
+    if (lane == 0) {
+        atomicAdd(&g_wphase[0], ph1 - ph0);          // set-up
+        atomicAdd(&g_wphase[1], ph_plan);            // planning
+        atomicAdd(&g_wphase[2], ph2 - ph1 - ph_plan - ph_ev);   // streaming
+        atomicAdd(&g_wphase[3], ph_ev);              // events inside the loop
+        atomicAdd(&g_wphase[4], ph3 - ph2);          // the flush at the end
+        atomicAdd(&g_wphase[5], ph4 - ph3);          // hand-in
+        atomicAdd(&g_wphase[6], ph4 - ph0);          // whole slice
+        atomicAdd(&g_wphase[7], 1ull);
+    }
+#endif
     WDIAG_ADD(8, n_out);
 #ifdef SS_DIAG
     WDIAG_ADD(16, dg[0]); WDIAG_ADD(17, dg[1]); WDIAG_ADD(18, dg[2]); WDIAG_ADD(19, dg[3]);
@@ -966,14 +1005,28 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
 namespace ss {
 // prep: device workspace of score_wave_prep_bytes(n_slices) bytes
 size_t score_wave_prep_bytes(unsigned n_slices) { return (size_t)n_slices * WL * sizeof(WPrep); }
-void launch_score_wave(const void* params, unsigned n_slices, void* prep, hipStream_t st) {
+void launch_wave_prep(const void* params, unsigned n_slices, void* prep, hipStream_t st) {
     const ScoreParams& p = *reinterpret_cast<const ScoreParams*>(params);
     hipLaunchKernelGGL(ssw::k_wave_prep, dim3((n_slices * WL + 255) / 256), dim3(256), 0, st, p, n_slices, reinterpret_cast<WPrep*>(prep));
+}
+void launch_score_wave(const void* params, unsigned n_slices, const void* prep, hipStream_t st) {
+    const ScoreParams& p = *reinterpret_cast<const ScoreParams*>(params);
     hipLaunchKernelGGL(ssw::k_score_wave, dim3(n_slices), dim3(64), 0, st, p, reinterpret_cast<const WPrep*>(prep));
 }
 int score_wave_max_lists() { return WL; }
 int score_wave_max_k() { return WCB / 2; }
 void score_wave_diag_dump() {
+#ifdef SSW_PHASES
+    {
+        unsigned long long h[8];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wphase), sizeof(h)) == hipSuccess) {
+            const char* names[8] = {"setup", "plan", "stream", "events", "final_flush", "hand_in", "slice", "slices"};
+            fprintf(stderr, "[ss phases] k_score_wave, s_memtime ticks summed over slices:");
+            for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 #ifdef SSW_CHECK
     {
         uint32_t c[8];
