@@ -251,6 +251,9 @@ static const char* const k_option_names[] = {
     "score.wave_max_terms", // a query suits k_score_wave if it has at most this many terms (default 6, at most 12)
     "score.wave_min_list",  // a query suits k_score_wave if EVERY list of it has this many x k' postings (k' = k rounded up to 2^j; default 16)
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
+    "score.wave_big_pct",   // graded slices: this share of a batch's postings goes into slices of wave_big_x100 % of the target, the rest into wave_small_x100 % (defaults 85 / 115 / 40; 0 = one size)
+    "score.wave_big_x100",
+    "score.wave_small_x100",
     "score.exact_all",      // 1: switch the upper-bound filter off (every record takes the exact stage)
     "score.slice_target",   // postings per (query, slice) workgroup (default: from the batch)
     "score.separate_merge", // 1: the per-query merge runs as its own launch (k_merge_topk)

@@ -1690,7 +1690,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // filter's assumptions hold, and a list long enough for the threshold floor (k'-th largest impact, k' >= k) to exist;
     // everything else runs k_score_slices.  Option "score.wave" = 0 switches the wave kernel off (tests, A/B).
     const bool wave_ok = ctx->opt("score.wave", 1) != 0 && s->has_combined && !exact_all && k <= ss::score_wave_max_k();
-    uint64_t wave_target = 0;
+    uint64_t wave_target = 0, wave_batch_tot = 0, wave_seen = 0;
+    const int64_t grade_pct = ctx->opt("score.wave_big_pct", 85), grade_big = ctx->opt("score.wave_big_x100", 115),
+                  grade_small = ctx->opt("score.wave_small_x100", 40);
     if (wave_ok) {
         // about 5.5 slices per nine-wave-per-CU slot (four rounds of the 12 waves a CU holds), 8k .. 48k postings each
         const uint64_t slots = (uint64_t)std::max(ctx->cu_count, 1) * 9;
@@ -1699,6 +1701,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
             if ((uint64_t)h_terms[i] < s->n_terms) batch_tot += (tp[h_terms[i] + 1] - tp[h_terms[i]]) + (bp[h_terms[i] + 1] - bp[h_terms[i]]);
         wave_target = std::min<uint64_t>(49152, std::max<uint64_t>(8192, batch_tot * 2 / (11 * slots)));          // (config 3, ms per batch at 6k / 8k / 10k / 12k / 14k / 17k / 21k postings: 0.661 / 0.635 / 0.616 / 0.623 / 0.655 / 0.649 / 0.639)
         wave_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.wave_slice_target", (int64_t)wave_target));
+        wave_batch_tot = batch_tot;
     }
     // Which queries suit k_score_wave: no phrase part, few lists, a list long enough for the threshold floor (k'-th largest
     // impact, k' = k rounded up to 2^j) to exist — and EVERY list long enough for that floor to be selective: the k'-th largest of
@@ -1784,6 +1787,13 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
             if (batch_wave && h_suits[q] && h_dterm.size() > d0 && (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists()) {
                 h_fast[q] = 1;
                 q_target = wave_target;
+                // graded slices: the first part of the batch's postings in larger slices, the rest in smaller ones — launched
+                // longest first, the small ones fill the kernel's tail
+                if (grade_pct > 0) {
+                    q_target = wave_seen * 100 < wave_batch_tot * (uint64_t)grade_pct ? wave_target * (uint64_t)grade_big / 100 : wave_target * (uint64_t)grade_small / 100;
+                    q_target = std::max<uint64_t>(q_target, 1024);
+                    wave_seen += tot;
+                }
                 max_slices = 4096;
             }
         }
