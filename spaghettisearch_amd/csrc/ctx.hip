@@ -253,6 +253,7 @@ static const char* const k_option_names[] = {
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
     "score.wave_big_pct",   // graded slices: this share of a batch's postings goes into slices of wave_big_x100 % of the target, the rest into wave_small_x100 % (defaults 85 / 115 / 40; 0 = one size)
     "score.wave_big_x100",
+    "score.grade_slices",   // 1: k_score_slices' slices are graded the same way (default 0)
     "score.wave_small_x100",
     "score.exact_all",      // 1: switch the upper-bound filter off (every record takes the exact stage)
     "score.slice_target",   // postings per (query, slice) workgroup (default: from the batch)

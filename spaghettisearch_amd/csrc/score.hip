@@ -1672,6 +1672,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // SLICE_MIN) for small batches, so that one query's lists are spread over many CUs instead of being
     // walked by a single workgroup (latency of a lone query: 0.72 ms -> see DESIGN.md K4).
     uint64_t slice_target = SLICE_TARGET;
+    uint64_t grade_tot = 0, grade_seen = 0;
+    const bool grade_slices = ctx->opt("score.grade_slices", 0) != 0;
     {
         uint64_t batch_tot = 0;
         for (int q = 0; q < n_q; q++)
@@ -1685,12 +1687,13 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         // threshold warm-up whatever its size) nor above SLICE_TARGET
         slice_target = std::min<uint64_t>(SLICE_TARGET, std::max<uint64_t>(SLICE_MIN, batch_tot * 3 / (2 * slots)));
         slice_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.slice_target", (int64_t)slice_target));   // experiments only
+        grade_tot = batch_tot;
     }
     // k_score_wave (one wave per slice) takes the plain OR queries: few lists, no phrase part, small k, inputs for which the
     // filter's assumptions hold, and a list long enough for the threshold floor (k'-th largest impact, k' >= k) to exist;
     // everything else runs k_score_slices.  Option "score.wave" = 0 switches the wave kernel off (tests, A/B).
     const bool wave_ok = ctx->opt("score.wave", 1) != 0 && s->has_combined && !exact_all && k <= ss::score_wave_max_k();
-    uint64_t wave_target = 0, wave_batch_tot = 0, wave_seen = 0;
+    uint64_t wave_target = 0;
     const int64_t grade_pct = ctx->opt("score.wave_big_pct", 85), grade_big = ctx->opt("score.wave_big_x100", 115),
                   grade_small = ctx->opt("score.wave_small_x100", 40);
     if (wave_ok) {
@@ -1701,7 +1704,6 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
             if ((uint64_t)h_terms[i] < s->n_terms) batch_tot += (tp[h_terms[i] + 1] - tp[h_terms[i]]) + (bp[h_terms[i] + 1] - bp[h_terms[i]]);
         wave_target = std::min<uint64_t>(49152, std::max<uint64_t>(8192, batch_tot * 2 / (11 * slots)));          // (config 3, ms per batch at 6k / 8k / 10k / 12k / 14k / 17k / 21k postings: 0.661 / 0.635 / 0.616 / 0.623 / 0.655 / 0.649 / 0.639)
         wave_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.wave_slice_target", (int64_t)wave_target));
-        wave_batch_tot = batch_tot;
     }
     // Which queries suit k_score_wave: no phrase part, few lists, a list long enough for the threshold floor (k'-th largest
     // impact, k' = k rounded up to 2^j) to exist — and EVERY list long enough for that floor to be selective: the k'-th largest of
@@ -1781,22 +1783,22 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         // the window plan holds (n_win + 1) * L cursors: keep a slice within what the plan can cut into regular windows
         const uint64_t n_lists = 2 * (h_dterm.size() - d0) + 4;
         const uint64_t plan_cap = std::max<uint64_t>(TARGET, (uint64_t)(TBL_CAP / n_lists > 2 ? TBL_CAP / n_lists - 2 : 1) * TARGET * 7 / 8);
-        uint64_t q_target = std::min<uint64_t>(slice_target, plan_cap);
+        uint64_t q_target = slice_target;
         uint64_t max_slices = MAX_SLICES_PER_Q;
-        {
-            if (batch_wave && h_suits[q] && h_dterm.size() > d0 && (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists()) {
-                h_fast[q] = 1;
-                q_target = wave_target;
-                // graded slices: the first part of the batch's postings in larger slices, the rest in smaller ones — launched
-                // longest first, the small ones fill the kernel's tail
-                if (grade_pct > 0) {
-                    q_target = wave_seen * 100 < wave_batch_tot * (uint64_t)grade_pct ? wave_target * (uint64_t)grade_big / 100 : wave_target * (uint64_t)grade_small / 100;
-                    q_target = std::max<uint64_t>(q_target, 1024);
-                    wave_seen += tot;
-                }
-                max_slices = 4096;
-            }
+        const bool fast = batch_wave && h_suits[q] && h_dterm.size() > d0 && (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists();
+        if (fast) {
+            h_fast[q] = 1;
+            q_target = wave_target;
+            max_slices = 4096;
         }
+        // graded slices: the first part of the batch's postings in larger slices, the rest in smaller ones — launched
+        // longest first, the small ones fill the kernel's tail (both kernels; see DESIGN K4b)
+        if (grade_pct > 0 && (fast || grade_slices)) {
+            q_target = grade_seen * 100 < grade_tot * (uint64_t)grade_pct ? q_target * (uint64_t)grade_big / 100 : q_target * (uint64_t)grade_small / 100;
+            q_target = std::max<uint64_t>(q_target, 1024);
+            grade_seen += tot;
+        }
+        if (!fast) q_target = std::min<uint64_t>(q_target, plan_cap);
         uint64_t ns = std::max<uint64_t>(1, (tot + q_target - 1) / q_target);
         ns = std::min<uint64_t>(ns, std::min<uint64_t>(max_slices, s->n_docs));
         for (uint64_t j = 0; j < ns; j++) {

@@ -23,7 +23,7 @@ outs = {}
 for mode in os.environ.get("MODES", "wave,slices").split(","):
     ctx.set_option("score.wave", 1 if mode == "wave" else 0)
     if os.environ.get("WT"): ctx.set_option("score.wave_slice_target", int(os.environ["WT"]))
-    for env, opt in (("GP", "score.wave_big_pct"), ("GB", "score.wave_big_x100"), ("GS", "score.wave_small_x100")):
+    for env, opt in (("GP", "score.wave_big_pct"), ("GB", "score.wave_big_x100"), ("GS", "score.wave_small_x100"), ("GSL", "score.grade_slices")):
         if os.environ.get(env): ctx.set_option(opt, int(os.environ[env]))
     if os.environ.get("ST"): ctx.set_option("score.slice_target", int(os.environ["ST"]))
     if os.environ.get("WML"): ctx.set_option("score.wave_min_list", int(os.environ["WML"]))
