@@ -405,6 +405,8 @@ __device__ __forceinline__ void chunk_filter(const SliceLds& S, const uint32_t (
 // k_score_slices).
 // FLAT: the query's slices (k_score_wave) appended their candidates to ONE list per query (qc_cnt[q] entries from
 // slice_base[q] * k on); otherwise every slice owns k entries and so_cnt[s] says how many it filled.
+constexpr int MERGE_T = 16;     // >= the wave kernel's lists per query (score_wave_max_lists)
+size_t merge_lds_bytes(int k, int cb);
 template <int NT, bool FUSED, bool FLAT = false>
 __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t q, unsigned char* smem, const int cbm) {
     double* accT = reinterpret_cast<double*>(smem);                    // [k]
@@ -415,6 +417,9 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
     uint64_t* sc64 = cd_key + cbm;                                     // [1]
     uint32_t* cd_doc = reinterpret_cast<uint32_t*>(sc64 + 1);          // [cb]
     uint32_t* sc32 = cd_doc + cbm;                                     // [4]
+    uint64_t* tm_p0 = reinterpret_cast<uint64_t*>(sc32 + 4);           // [MERGE_T] FLAT: the terms' combined lists and multiplicities,
+    uint64_t* tm_p1 = tm_p0 + MERGE_T;                                 //           fetched while the candidates are on their way
+    uint32_t* tm_mult = reinterpret_cast<uint32_t*>(tm_p1 + MERGE_T);
     TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), 0ull, -INFINITY, (uint32_t)cbm};
     const int tid = threadIdx.x;
     const int k = p.k;
@@ -422,28 +427,57 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
     DIAG_NOWX(t_g0);
     __syncthreads();
     if (FLAT) {
+#ifdef SSM_EXP_NOGATHER        // (timing experiments only: wrong results)
+        const uint32_t n = min(p.qc_cnt[q], 1u);
+#else
         const uint32_t n = p.qc_cnt[q];
+#endif
         DIAG_ADD(18, n);
         DIAG_ADD(17, 1);
         const size_t base = (size_t)p.slice_base[q] * k;
         uint32_t* overflow = &sc32[1];
+        // two candidates per thread and pass, both loads issued before either is used (no branch around them: a lane without a
+        // candidate re-reads entry 0): ~300 candidates per query at config 3 are ONE round of memory latency, not two
+        uint64_t key[2];
+        uint32_t doc[2];
+        bool have[2];
+        auto load_pass = [&](uint32_t i0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const uint32_t i = i0 + (uint32_t)r * NT + tid;
+                have[r] = i < n;
+                const size_t ii = base + (have[r] ? i : 0u);
+                key[r] = p.so_key[ii];
+                doc[r] = p.so_doc[ii];
+            }
+        };
+        load_pass(0);
+        // what the explain stage needs of the query's terms is requested now, behind the first candidates: these loads (two
+        // dependent levels) run beside them instead of after the sort
+        {
+            const uint32_t tq0 = p.q_off[q], tnd = p.q_off[q + 1] - tq0;
+            if ((uint32_t)tid < min(tnd, (uint32_t)MERGE_T)) {
+                const uint32_t term = p.dterm[tq0 + tid];
+                tm_p0[tid] = p.c_ptr[term];
+                tm_p1[tid] = p.c_ptr[term + 1];
+                tm_mult[tid] = p.dmult[tq0 + tid];
+            }
+        }
         __syncthreads();
         if (tid == 0) p.qc_cnt[q] = 0u;                                  // every thread has its copy: zero again for the next batch (no memset between batches)
-        for (uint32_t i0 = 0; i0 < n; i0 += NT) {
-            const uint32_t i = i0 + tid;
-            bool have = i < n;
-            uint64_t key = 0;
-            uint32_t doc = 0;
-            if (have) { key = p.so_key[base + i]; doc = p.so_doc[base + i]; }
+        for (uint32_t i0 = 0; i0 < n;) {
             for (;;) {
                 const uint64_t thr = *tk.thr;
-                if (have) {
-                    if (key >= thr) {
-                        const uint32_t j = atomicAdd(tk.count, 1u);
-                        if (j < tk.cb) { tk.key[j] = key; tk.doc[j] = doc; have = false; }
-                        else *overflow = 1;
-                    } else {
-                        have = false;
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    if (have[r]) {
+                        if (key[r] >= thr) {
+                            const uint32_t j = atomicAdd(tk.count, 1u);
+                            if (j < tk.cb) { tk.key[j] = key[r]; tk.doc[j] = doc[r]; have[r] = false; }
+                            else *overflow = 1;
+                        } else {
+                            have[r] = false;
+                        }
                     }
                 }
                 __syncthreads();
@@ -452,6 +486,8 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
                 if (tid == 0) *overflow = 0;
                 __syncthreads();
             }
+            i0 += 2 * NT;
+            if (i0 < n) load_pass(i0);
         }
     } else
     for (uint32_t s = p.slice_base[q]; s < p.slice_base[q + 1]; s++) {
@@ -469,7 +505,13 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
         }
         __syncthreads();
     }
+#ifdef SSM_EXP_NOSORT           // (timing experiments only: wrong results)
+    __syncthreads();
+    if (tid == 0) sc32[0] = min(sc32[0], (uint32_t)k);
+    __syncthreads();
+#else
     topk_compact(tk, k);
+#endif
     const uint32_t n_out = sc32[0];
 
     // explain: TitleRank/BodyRank of the winners, re-derived from the posting lists
@@ -484,10 +526,13 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
         // k_score_wave's queries have their combined lists: ONE search per (winner, term) finds the doc's body and title posting
         // side by side, and it runs through the skip index (4 bytes per 64 postings: cache-resident) and then inside one 512-byte
         // block, instead of two interpolation searches over the whole lists (the merge's searches were 58 of its 98 us)
+#ifdef SSM_EXP_NOEXPLAIN
+        for (uint32_t task = tid; task < 0 * nd; task += NT) {
+#else
         for (uint32_t task = tid; task < n_out * nd; task += NT) {
+#endif
             const uint32_t i = task / nd, l = task % nd;
-            const uint32_t term = p.dterm[t0 + l];
-            const uint64_t p0 = p.c_ptr[term], p1 = p.c_ptr[term + 1];
+            const uint64_t p0 = tm_p0[l], p1 = tm_p1[l];
             if (p1 == p0) continue;
             const uint32_t d = cd_doc[i];
             const uint32_t g0 = (uint32_t)(p0 >> 6), g1 = (uint32_t)((p1 - 1) >> 6);
@@ -502,7 +547,7 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
                 const uint64_t mid = (lo + hi) >> 1;
                 if ((load_doc(list_addr, mid) & 0x7FFFFFFFu) < d) lo = mid + 1; else hi = mid;
             }
-            const double mult = (double)p.dmult[t0 + l];
+            const double mult = (double)tm_mult[l];
             for (uint64_t pos = lo; pos < min(p1, lo + 2); pos++) {  // body first, then title, of the same doc
                 const uint32_t rd = load_doc(list_addr, pos);
                 if ((rd & 0x7FFFFFFFu) != d) break;
@@ -1125,15 +1170,15 @@ __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
 }
 // the queries scored by k_score_wave: one candidate list per query
 #ifndef SS_TPB_MF
-#define SS_TPB_MF 256
+#define SS_TPB_MF 320
 #endif
-constexpr int TPB_MF = SS_TPB_MF;   // measured at config 3: 256 threads 0.646 ms per batch, 512: 0.683, 1024: 0.715 (the compactions' barriers)
+constexpr int TPB_MF = SS_TPB_MF;   // 320: the 300 explain searches of a 3-term query at k = 100 are one pass (ms per batch at 256 / 320 / 384 / 512 threads: 0.405 / 0.399 / 0.410 / 0.420)
 __global__ __launch_bounds__(TPB_MF) void k_merge_flat(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     merge_query<TPB_MF, false, true>(p, p.merge_q[blockIdx.x], smem, p.cb_flat);
 }
 
-size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 16 + 16; }
+size_t merge_lds_bytes(int k, int cb) { return (size_t)k * 32 + (size_t)cb * 12 + 8 + 16 + 16 + (size_t)MERGE_T * 20; }
 
 // scoring layout: {doc, float32 upper bound of w/mag[doc]} per posting; flags: bit 0 = a weight is negative or not finite,
 // bit 1 = a magnitude is not a positive finite number under a non-zero weight (the filter's assumptions, see k_score_slices)
