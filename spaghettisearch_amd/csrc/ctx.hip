@@ -185,7 +185,12 @@ int32_t ss_init(int32_t device_id, ss_ctx** out) {
         return SS_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    if ((e = hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking)) != hipSuccess) {
+    // highest priority: what runs there is short and somebody waits for it (the next batch's plan upload and k_wave_prep beside the
+    // current batch's kernels, a topic block's exchange beside the next block's sweep) — at equal priority its workgroups queue
+    // behind every workgroup of the long kernel that was launched first
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if ((e = hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
         ss::set_global_error(std::string("ss_init: hipStreamCreate (comm): ") + hipGetErrorString(e));
         (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;

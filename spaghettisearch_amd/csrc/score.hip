@@ -1912,7 +1912,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_plan[pb]), plan_bytes * 2, hipHostMallocDefault));
         s->h_plan_cap[pb] = plan_bytes * 2;
     }
-    if (!s->batch_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->batch_ev[pb], hipEventDisableTiming));
+    if (!s->batch_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->batch_ev[pb], hipEventDisableTiming | hipEventReleaseToDevice));
     SS_HIP(ctx, ensure(s->d_plan2[pb], plan_bytes));
     unsigned char* hp = s->h_plan[pb];
     std::memcpy(hp + o_qoff, h_qoff.data(), (n_q + 1) * sizeof(uint32_t));
@@ -2064,8 +2064,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
         ctx->ev_valid[1] = true;
     }
+#ifndef SS_EXP_NOBATCHEV
     SS_HIP(ctx, hipEventRecord(s->batch_ev[pb], st));
     s->batch_ev_pending[pb] = true;
+#endif
     SS_HIP(ctx, hipGetLastError());
     if (trace)
         fprintf(stderr, "[score trace] copies in + checks %.0f us, plan (%zu slices) %.0f us, staging %.0f us, H2D + allocs + params %.0f us, launches %.0f us\n",
