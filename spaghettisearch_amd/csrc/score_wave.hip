@@ -76,12 +76,15 @@ enum : uint32_t { M_NORMAL = 1, M_SLOW = 2, M_SKIP = 0 };
 __device__ uint32_t g_wcheck[8];
 #endif
 #ifdef SSW_PHASES
-// -DSSW_PHASES (tools/build_variant.sh): seven s_memtime stamps per slice, summed at its end — light enough to leave the kernel's
-// time alone (the SS_DIAG build's stamps and counters do not: 2.4 ms per batch).  Printed by ss_scorer_destroy.
-__device__ unsigned long long g_wphase[8];
-#define PH_NOW(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+// -DSSW_PHASES (tools/build_variant.sh phases -DSSW_PHASES): s_memtime intervals of a slice's phases, kept in LDS and added to 256
+// rows of global counters at the slice's end — the kernel keeps its time (0.401 against 0.396 ms per batch).  Printed by
+// ss_scorer_destroy.  At config 3: set-up 5.8 %, planning 17.1 %, streaming 65.7 %, events 3.7 %, final flush 4.0 %, hand-in 2.9 %.
+__device__ unsigned long long g_wphase[256][8];     // spread over 256 rows: 105k atomics per batch on eight words took 0.8 ms (the SS_DIAG build's counters still do that)
+__shared__ unsigned long long ph_acc[8];
+// interval i opens (SGN = -) and closes (SGN = +): the stamp goes straight into LDS
+#define PH_MARK(i, SGN) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); if (threadIdx.x == 0) ph_acc[i] SGN##= t_; } while (0)
 #else
-#define PH_NOW(var) do { } while (0)
+#define PH_MARK(i, SGN) do { } while (0)
 #endif
 #ifdef SS_DIAG
 __device__ unsigned long long g_wdiag[32];
@@ -736,10 +739,11 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
 
     const int lane = threadIdx.x;
     DIAG_NOW(t_w0);
-    PH_NOW(ph0);
 #ifdef SSW_PHASES
-    unsigned long long ph_plan = 0, ph_ev = 0;
+    if (threadIdx.x < 8) ph_acc[threadIdx.x] = 0ull;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+    PH_MARK(0, -); PH_MARK(6, -);
     const uint32_t slice_id = p.order[blockIdx.x];
     const SliceDesc sd = p.slices[slice_id];
     const uint32_t q = sd.q;
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     lds_wait();
 
     DIAG_NOW(t_w1);
-    PH_NOW(ph1);
+    PH_MARK(0, +);
     WDIAG_ADD(0, 1);
     WDIAG_ADD(10, t_w1 - t_w0);
     uint32_t F = sd.dlo;                               // frontier: docs below it are done
@@ -824,14 +828,11 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
 #endif
     while (act_mask && F < sd.dhi) {
         DIAG_NOW(t_p0);
-        PH_NOW(php0);
+        PH_MARK(1, -);
         const RoundPlan rp = plan_round(w, p.c_skip, se, ghdr, gdesc, l_adv, L, act_mask, F, sd.dhi, lane);
         const uint32_t n_rows = rp.n_rows;
         DIAG_NOW(t_p1);
-        PH_NOW(php1);
-#ifdef SSW_PHASES
-        ph_plan += php1 - php0;
-#endif
+        PH_MARK(1, +); PH_MARK(2, -);
         WDIAG_ADD(1, 1);
         WDIAG_ADD(2, n_rows);
         WDIAG_ADD(11, t_p1 - t_p0);
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                 WDIAG_ADD(3 + ev, 1);
                 WDIAG_ADD(7, pend_n);
                 DIAG_NOW(t_e0);
-                PH_NOW(phe0);
+                PH_MARK(3, -);
                 const uint4 hv = *reinterpret_cast<const uint4*>(ghdr[ev_row]);
                 const uint32_t b_lo = rfl(hv.x), span = rfl(hv.y), n_blk = rfl(hv.w);
 #ifndef SSW_EXP_NOFLUSH
@@ -940,14 +941,12 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                 if (ev == EV_SLOW) { slow_window(w, lane, ev_row, n_blk, b_lo, span, true); r0 = ev_row + 1; }
                 thr_fx = wave_thr_fx(C);
                 DIAG_NOW(t_e1);
-                PH_NOW(phe1);
-#ifdef SSW_PHASES
-                ph_ev += phe1 - phe0;
-#endif
+                PH_MARK(3, +);
                 WDIAG_ADD(12, t_e1 - t_e0);
             }
         }
         DIAG_NOW(t_p2);
+        PH_MARK(2, +);
         WDIAG_ADD(13, t_p2 - t_p1);
         // ---- next round starts at e ----
         if (lane < L && w.active) w.cg += l_adv[lane];
@@ -956,12 +955,12 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     }
     WDIAG_ADD(7, pend_n);
     DIAG_NOW(t_ff0);
-    PH_NOW(ph2);
+    PH_MARK(4, -);
 #if !defined(SSW_EXP_NOFINAL) && !defined(SSW_EXP_NOFLUSH)      // (timing experiments only: wrong results)
     if (pend_n) wave_flush(lane, pend_n);
 #endif
     DIAG_NOW(t_w2);
-    PH_NOW(ph3);
+    PH_MARK(4, +); PH_MARK(5, -);
     WDIAG_ADD(20, t_w2 - t_ff0);
     WDIAG_ADD(24, pend_n ? 1 : 0);
 
@@ -980,16 +979,11 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     DIAG_NOW(t_w3);
 #ifdef SSW_PHASES
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PH_NOW(ph4);
+    PH_MARK(5, +); PH_MARK(6, +);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) {
-        atomicAdd(&g_wphase[0], ph1 - ph0);          // set-up
-        atomicAdd(&g_wphase[1], ph_plan);            // planning
-        atomicAdd(&g_wphase[2], ph2 - ph1 - ph_plan - ph_ev);   // streaming
-        atomicAdd(&g_wphase[3], ph_ev);              // events inside the loop
-        atomicAdd(&g_wphase[4], ph3 - ph2);          // the flush at the end
-        atomicAdd(&g_wphase[5], ph4 - ph3);          // hand-in
-        atomicAdd(&g_wphase[6], ph4 - ph0);          // whole slice
-        atomicAdd(&g_wphase[7], 1ull);
+        for (int i = 0; i < 7; i++) atomicAdd(&g_wphase[blockIdx.x & 255][i], ph_acc[i]);
+        atomicAdd(&g_wphase[blockIdx.x & 255][7], 1ull);
     }
 #endif
     WDIAG_ADD(8, n_out);
@@ -1018,9 +1012,12 @@ int score_wave_max_k() { return WCB / 2; }
 void score_wave_diag_dump() {
 #ifdef SSW_PHASES
     {
-        unsigned long long h[8];
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wphase), sizeof(h)) == hipSuccess) {
-            const char* names[8] = {"setup", "plan", "stream", "events", "final_flush", "hand_in", "slice", "slices"};
+        static unsigned long long hh[256][8];
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_wphase), sizeof(hh)) == hipSuccess) {
+            for (int r = 0; r < 256; r++)
+                for (int i = 0; i < 8; i++) h[i] += hh[r][i];
+            const char* names[8] = {"setup", "plan", "stream_incl_events", "events", "final_flush", "hand_in", "slice", "slices"};
             fprintf(stderr, "[ss phases] k_score_wave, s_memtime ticks summed over slices:");
             for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
             fprintf(stderr, "\n");
