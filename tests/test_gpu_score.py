@@ -375,6 +375,24 @@ def test_wave_kernel_forced_on_small_tables(ss_ctx, oracle, wave_target):
         close_all(sc, ti, bi)
 
 
+@pytest.mark.parametrize("grade", [(0, 115, 40), (50, 200, 25), (99, 300, 10)])
+def test_wave_graded_slices_agree(ss_ctx, oracle, grade):
+    """The wave kernel's slices are graded (the first part of a batch's postings in larger slices, the rest in smaller ones,
+    options "score.wave_big_pct" / "_big_x100" / "_small_x100"): how a query's doc range is cut must not show in the hits."""
+    n_docs, n_terms = 300000, 20000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 6000000, 400000, seed=47)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        q_ptr, q_terms = synth.make_queries(160, 3, 300, seed=48)
+        ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, 50)
+        with ss_ctx.options(score__wave_min_list=0, score__wave_slice_target=6000, score__wave_big_pct=grade[0],
+                            score__wave_big_x100=grade[1], score__wave_small_x100=grade[2]):
+            hits, n_hits = sc.score_topk(q_ptr, q_terms, 50)
+        assert_same_hits(hits, n_hits, ref, ref_n)
+    finally:
+        close_all(sc, ti, bi)
+
+
 def test_wave_round_makes_progress_beside_much_denser_lists(ss_ctx, oracle):
     """Regression: a list a hundred times sparser than its neighbours got ONE skip entry per planning round; after a round that
     ended at one of its block boundaries that entry equalled the round's start, the round ended where it began and the wave
