@@ -44,7 +44,10 @@ constexpr int WCW = 16;                 // block slots per group (= one regular 
 #define SSW_DEPTH 2
 #endif
 constexpr int WDEPTH = SSW_DEPTH;       // groups whose loads are in flight or in registers (2 or 3)
-constexpr int WSK = 1024;               // sketch slots; slot WSK is a dummy that always holds 0
+#ifndef SSW_WSK
+#define SSW_WSK 1024
+#endif
+constexpr int WSK = SSW_WSK;            // sketch slots (1024: 2048 measured, see DESIGN K4b); slot WSK is a dummy that always holds 0
 // LDS per wave decides the occupancy: 13.6 KB is three waves per SIMD (12 per CU), and the loop is latency-bound below that
 #ifndef SSW_SE
 #define SSW_SE 224
@@ -79,12 +82,19 @@ __device__ uint32_t g_wcheck[8];
 // -DSSW_PHASES (tools/build_variant.sh phases -DSSW_PHASES): s_memtime intervals of a slice's phases, kept in LDS and added to 256
 // rows of global counters at the slice's end — the kernel keeps its time (0.401 against 0.396 ms per batch).  Printed by
 // ss_scorer_destroy.  At config 3: set-up 5.8 %, planning 17.1 %, streaming 65.7 %, events 3.7 %, final flush 4.0 %, hand-in 2.9 %.
+__device__ unsigned long long g_wrows[256][4];
 __device__ unsigned long long g_wphase[256][8];     // spread over 256 rows: 105k atomics per batch on eight words took 0.8 ms (the SS_DIAG build's counters still do that)
 __shared__ unsigned long long ph_acc[8];
 // interval i opens (SGN = -) and closes (SGN = +): the stamp goes straight into LDS
 #define PH_MARK(i, SGN) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); if (threadIdx.x == 0) ph_acc[i] SGN##= t_; } while (0)
 #else
 #define PH_MARK(i, SGN) do { } while (0)
+#endif
+#ifdef SSW_PHASES
+__shared__ unsigned int ph_rows[4];     // rows, rows with a survivor, survivors, rows with > 4 survivors
+#define PH_COUNT(tot) do { if (threadIdx.x == 0) { ph_rows[0]++; ph_rows[1] += (tot) ? 1u : 0u; ph_rows[2] += (tot); ph_rows[3] += (tot) > 4u ? 1u : 0u; } } while (0)
+#else
+#define PH_COUNT(tot) do { } while (0)
 #endif
 #ifdef SS_DIAG
 __device__ unsigned long long g_wdiag[32];
@@ -138,6 +148,7 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t* a, uint32_t 
 }
 
 __device__ __forceinline__ uint32_t w_slot(uint32_t doc) { return (doc ^ (doc >> 10)) & (uint32_t)(WSK - 1); }
+static_assert((WSK & (WSK - 1)) == 0 && WSK % 256 == 0, "sketch size");
 
 // What a slice needs to know about one of its lists, resolved by k_wave_prep for all slices of the batch at once (the
 // chains of dependent loads and the searches in the skip index then run side by side instead of at the head of every slice).
@@ -157,7 +168,7 @@ struct RareArgs { const double* t_mag; const double* b_mag; const double* prior;
 // pointers: every access became a flat_load with vmcnt(0) lgkmcnt(0) behind it, and the argument structs travelled through
 // scratch memory.  Named directly, the same accesses are ds_ instructions and the calls pass two scalars.
 __shared__ __attribute__((aligned(16))) uint32_t sk[WSK + 4];
-static_assert(WSK == 1024, "the row's sketch is cleared by four 16-byte stores per lane");
+
 __shared__ uint32_t se[(WSE + 32) > 2 * WHT ? (WSE + 32) : 2 * WHT];   // skip entries while a round is planned, then ht_key | ht_rec
 __shared__ __attribute__((aligned(16))) uint32_t ghdr[WGMAX + 2 * WDEPTH][4];
 __shared__ uint32_t gdesc[WGMAX + 2 * WDEPTH][WCW];
@@ -741,6 +752,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     DIAG_NOW(t_w0);
 #ifdef SSW_PHASES
     if (threadIdx.x < 8) ph_acc[threadIdx.x] = 0ull;
+    if (threadIdx.x < 4) ph_rows[threadIdx.x] = 0u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     PH_MARK(0, -); PH_MARK(6, -);
@@ -875,6 +887,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                     _Pragma("unroll") for (int c = 0; c < WCW; c++) tot += (uint32_t)__popcll(__ballot(u[c] >= thr_fx));   \
                     WSTAMP(ts2);                                                                                           \
                     WACC(0, ts0, ts1); WACC(1, ts1, ts2);                                                                  \
+                    PH_COUNT(tot);                                                                                         \
                     if (tot) {                                                                                             \
                         if (pend_n + tot > (uint32_t)WPW) { ev = EV_OVERFLOW; ev_row = r_; goto ssw_event; }               \
                         _Pragma("unroll") for (int c = 0; c < WCW; c++) {                                                  \
@@ -890,7 +903,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
                     }                                                                                                      \
                     /* the whole sketch back to zero: four 16-byte stores per lane (the same 4 KB as one 4-byte store per slot and lane, in 4 instructions instead of 48) */ \
                     { uint4* const s4_ = reinterpret_cast<uint4*>(sk); const uint4 z_ = make_uint4(0u, 0u, 0u, 0u);       \
-                      s4_[lane] = z_; s4_[lane + 64] = z_; s4_[lane + 128] = z_; s4_[lane + 192] = z_; }                    \
+                      _Pragma("unroll") for (int j_ = 0; j_ < WSK / 256; j_++) s4_[lane + 64 * j_] = z_; }                  \
                     WSTAMP(ts3);                                                                                           \
                     WACC(2, ts2, ts3);                                                                                     \
                 } else {                                                                                                   \
@@ -984,6 +997,7 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     if (lane == 0) {
         for (int i = 0; i < 7; i++) atomicAdd(&g_wphase[blockIdx.x & 255][i], ph_acc[i]);
         atomicAdd(&g_wphase[blockIdx.x & 255][7], 1ull);
+        for (int i = 0; i < 4; i++) atomicAdd(&g_wrows[blockIdx.x & 255][i], (unsigned long long)ph_rows[i]);
     }
 #endif
     WDIAG_ADD(8, n_out);
@@ -1018,6 +1032,11 @@ void score_wave_diag_dump() {
             for (int r = 0; r < 256; r++)
                 for (int i = 0; i < 8; i++) h[i] += hh[r][i];
             const char* names[8] = {"setup", "plan", "stream_incl_events", "events", "final_flush", "hand_in", "slice", "slices"};
+            static unsigned long long rr[256][4];
+            unsigned long long r4[4] = {0, 0, 0, 0};
+            if (hipMemcpyFromSymbol(rr, HIP_SYMBOL(g_wrows), sizeof(rr)) == hipSuccess)
+                for (int r = 0; r < 256; r++) for (int i = 0; i < 4; i++) r4[i] += rr[r][i];
+            fprintf(stderr, "[ss phases] rows=%llu rows_with_survivors=%llu survivors=%llu rows_with_more_than_4=%llu\n", r4[0], r4[1], r4[2], r4[3]);
             fprintf(stderr, "[ss phases] k_score_wave, s_memtime ticks summed over slices:");
             for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
             fprintf(stderr, "\n");
