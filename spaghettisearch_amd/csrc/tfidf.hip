@@ -249,14 +249,17 @@ struct HeadSkip {
     uint64_t a_lo, a_hi, b_lo, b_hi;
     __device__ __forceinline__ bool hit(uint64_t i) const { return (i >= a_lo && i < a_hi) || (i >= b_lo && i < b_hi); }
 };
-__device__ __forceinline__ HeadSkip head_skip(const HeadArgs& h, uint32_t nh, uint32_t& cur, uint64_t base) {
+// `k` is the caller's copy of the two ranges, kept across chunks: they only change when `base` passes the end of the running
+// head list (a few times per block).  Read afresh for every chunk they were two rounds of dependent global loads in front
+// of every chunk — and k_scatter, one workgroup per CU with barriers between its phases, has nothing to run beside them.
+// Start with k = {0, 0, 0, 0} (stale: the first call loads).
+__device__ __forceinline__ void head_skip(const HeadArgs& h, uint32_t nh, uint32_t& cur, uint64_t base, HeadSkip& k) {
+    if (base < k.a_hi) return;                                            // still inside (or in front of) range `cur`
     while (cur < nh && h.he[cur] <= base) cur++;
-    HeadSkip k;
     k.a_lo = cur < nh ? h.hs[cur] : ~0ull;
     k.a_hi = cur < nh ? h.he[cur] : ~0ull;
     k.b_lo = cur + 1 < nh ? h.hs[cur + 1] : ~0ull;
     k.b_hi = cur + 1 < nh ? h.he[cur + 1] : ~0ull;
-    return k;
 }
 __device__ __forceinline__ uint32_t head_first(const HeadArgs& h, uint32_t nh, uint64_t r0) {
     uint32_t lo = 0, hi = nh;                                             // first range with he > r0
@@ -295,11 +298,11 @@ __global__ __launch_bounds__(TPB) void k_weight_count(const uint64_t* __restrict
     const uint32_t nh = head.n ? *head.n : 0u;
     uint32_t hcur = nh ? head_first(head, nh, r0) : 0u;
     __syncthreads();
+    HeadSkip hk = nh ? HeadSkip{0ull, 0ull, 0ull, 0ull} : HeadSkip{~0ull, ~0ull, ~0ull, ~0ull};
     for (uint64_t base = r0; base < r1; base += CH) {
         const uint32_t n_here = (uint32_t)min((uint64_t)CH, r1 - base);
-        HeadSkip hk{~0ull, ~0ull, ~0ull, ~0ull};
         if (nh) {
-            hk = head_skip(head, nh, hcur, base);
+            head_skip(head, nh, hcur, base, hk);
             if (hk.a_lo <= base && hk.a_hi >= base + n_here) {            // the whole chunk belongs to a head list: nothing to do here
                 if (WEIGHT) {
                     __syncthreads();
@@ -500,11 +503,11 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
     const uint32_t nh = head.n ? *head.n : 0u;
     uint32_t hcur = nh ? head_first(head, nh, r0) : 0u;
     bool n_empty = false;                                                  // the fetched chunk holds head postings only (uniform)
+    HeadSkip hk = nh ? HeadSkip{0ull, 0ull, 0ull, 0ull} : HeadSkip{~0ull, ~0ull, ~0ull, ~0ull};
     auto fetch = [&](uint64_t base) __attribute__((always_inline)) {
-        HeadSkip hk{~0ull, ~0ull, ~0ull, ~0ull};
         n_empty = base >= r1;
         if (nh && base < r1) {
-            hk = head_skip(head, nh, hcur, base);
+            head_skip(head, nh, hcur, base, hk);
             n_empty = hk.a_lo <= base && hk.a_hi >= min(r1, base + SC_CH);
         }
 #pragma unroll
@@ -525,6 +528,10 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
         const bool empty = n_empty;
         fetch(base + SC_CH);
         if (empty) continue;
+#if defined(SS_EXP_SC) && SS_EXP_SC == 3      // timing experiments only (wrong results): loads alone
+        if (doc[0] == 0x12345678u) out[0] = make_uint2(0u, __float_as_uint(w[0]));
+        continue;
+#endif
         // (1) count; the returned value is the record's rank inside its bucket
 #pragma unroll
         for (int j = 0; j < SC_PT; j++) rank[j] = doc[j] != 0xFFFFFFFFu ? atomicAdd(&L_hist[doc[j] >> shift], 1u) : 0u;
@@ -559,6 +566,9 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
             }
         }
         __syncthreads();
+#if defined(SS_EXP_SC) && SS_EXP_SC == 2      // ... loads, count and scan
+        continue;
+#endif
         // (3) records to their staging positions
 #pragma unroll
         for (int j = 0; j < SC_PT; j++) {
@@ -574,6 +584,10 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
         // (4) out, in staging order: consecutive lanes write consecutive records of a bucket's run
         // (the staged records end where the last bucket's run ends; head postings were never staged)
         const uint32_t n_here = nh ? L_loff[nbp - 1] + (L_cur[nbp - 1] - L_gout[nbp - 1]) : (uint32_t)min((uint64_t)SC_CH, r1 - base);
+#if defined(SS_EXP_SC) && SS_EXP_SC == 1      // ... everything but the stores
+        if (n_here == 0x12345678u) out[0] = L_rec[0];
+        continue;
+#endif
         for (uint32_t pos = threadIdx.x; pos < n_here; pos += SC_TPB) {
             const uint32_t b = L_bkt[pos];
             out[(uint64_t)L_gout[b] + (pos - L_loff[b])] = L_rec[pos];
