@@ -97,8 +97,8 @@ __shared__ unsigned int ph_rows[4];     // rows, rows with a survivor, survivors
 #define PH_COUNT(tot) do { } while (0)
 #endif
 #ifdef SS_DIAG
-__device__ unsigned long long g_wdiag[32];
-#define WDIAG_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_wdiag[i], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long g_wdiag[256][32];     // 256 rows (by block index): atomics of 13k slices on 32 words serialise and cost the kernel more than it takes
+#define WDIAG_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_wdiag[blockIdx.x & 255][i], (unsigned long long)(v)); } while (0)
 #else
 #define WDIAG_ADD(i, v) do { } while (0)
 #endif
@@ -1051,8 +1051,11 @@ void score_wave_diag_dump() {
     }
 #endif
 #ifdef SS_DIAG
-    unsigned long long h[32];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wdiag), sizeof(h)) == hipSuccess) {
+    static unsigned long long hw[256][32];
+    unsigned long long h[32] = {};
+    if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wdiag), sizeof(hw)) == hipSuccess) {
+        for (int r = 0; r < 256; r++)
+            for (int i = 0; i < 32; i++) h[i] += hw[r][i];
         const char* names[25] = {"slices", "rounds", "rows", "-", "ev_flush", "ev_overflow", "ev_slow", "flushed_records", "handed_in", "blocks",
                                  "cyc_setup", "cyc_plan", "cyc_events", "cyc_stream", "cyc_epilogue", "cyc_total", "cyc_row_add", "cyc_row_read",
                                  "cyc_row_append_clear", "cyc_row_issue", "cyc_final_flush", "cyc_flush_loads", "cyc_flush_hash", "cyc_flush_score", "final_flushes"};
