@@ -610,6 +610,24 @@ def main() -> None:
                 sc.score_topk(d_qptr, d_qterms, k, out=(d_hits, d_nhits))
                 kms.append(ctx.last_kernel_ms(1))
             kern_ms = sum(kms) / len(kms)
+            # option "score.pipeline" (off by default, NOT the headline): a batch's merge runs on a third stream under the next
+            # batch's k_score_wave; the hits are complete after ss_synchronize instead of in stream order.  Same batches, same check.
+            pipelined = None
+            if world == 1:
+                ctx.synchronize(); torch.cuda.synchronize()
+                ref_h, ref_n = d_hits.clone(), d_nhits.clone()
+                ctx.set_option("score.timing", 0)
+                ctx.set_option("score.pipeline", 1)
+                dtp, blocks_p = timed_blocks(batches)
+                ctx.synchronize(); torch.cuda.synchronize()
+                same_p = bool(torch.equal(ref_h, d_hits) and torch.equal(ref_n, d_nhits))
+                ctx.set_option("score.pipeline", None)
+                ctx.set_option("score.timing", None)
+                pipelined = {"value": nq * K / dtp, "unit": "queries/s", "ms_per_step": dtp * 1e3 / K, "ms_per_step_blocks": summarize(blocks_p),
+                             "hits_equal_unpipelined": same_p,
+                             "what": "option score.pipeline=1: k_merge_flat of batch i on the context's merge stream under k_score_wave of "
+                                     "batch i+1; hits complete after ss_synchronize (not in stream order) — opt-in, not the headline"}
+                del ref_h, ref_n
             t0 = time.perf_counter()
             for _ in range(K):
                 hits, n_hits = sc.score_topk(q_ptr, q_terms, k)      # host in, host out: PCIe-inclusive
@@ -646,6 +664,8 @@ def main() -> None:
                                            "kernel_ms": tfidf_ms, "algorithmic_bytes": algo_tw}},
                     "tfidf_build_ms": tfidf_ms, "scorer_create_ms": scorer_create_ms,
                     "queries_per_sec_host_in_host_out": nq * K / dt_pcie}
+            if pipelined is not None:
+                topk["pipelined_option"] = pipelined
 
             # ---- one query through the ABI, host in / host out (the reference's call shape: one Retrieve per request,
             #      k = 50, main_retrieve.go:99-100)

@@ -26,6 +26,7 @@ struct ss_ctx {
     hipStream_t stream = nullptr;      // stream all work is enqueued on
     hipStream_t own_stream = nullptr;  // created by ss_init
     hipStream_t comm_stream = nullptr; // the exchange steps of the sharded sweep run here, beside the sweeps on `stream`
+    hipStream_t merge_stream = nullptr; // option "score.pipeline": k_merge_flat of a batch runs here, under the next batch's k_score_wave
     std::recursive_mutex mu;           // serialises calls on this ctx
     std::string last_error;
     // timing hook (ss_last_kernel_ms): [kind][0]=start, [1]=stop

@@ -1388,30 +1388,37 @@ struct ss_scorer {
     int k_topics = 0;
     int lds_attr = 0;
     // per-call workspaces, grow-only (no hipMalloc/hipFree on the steady-state query path)
-    ss::DevBuf<unsigned char> d_plan2[2], d_wprep2[2];   // the plan on the device, one buffer per turn: batch i+1's upload runs beside batch i's kernels
+    // Turns of per-batch buffers: the host runs at most TURNS batches ahead.  (Three were measured for the pipelined mode, so that a
+    // batch's plan upload and k_wave_prep — which do not fit beside k_score_wave's three waves of 168 VGPRs per SIMD — are enqueued
+    // one batch earlier: 0.395 against 0.399 ms per batch, not worth a third set of buffers.)
+    static constexpr int TURNS = 2;
+    ss::DevBuf<unsigned char> d_plan2[TURNS], d_wprep2[TURNS];   // the plan on the device, one buffer per turn: batch i+1's upload runs beside batch i's kernels
     // pinned staging for the plan, double-buffered: a call that returns results in device memory does not wait
     // for the GPU, so the next call plans (and fills the other buffer) while this one's copy and kernels run
-    unsigned char* h_plan[2] = {nullptr, nullptr};
-    size_t h_plan_cap[2] = {0, 0};
-    hipEvent_t plan_ev[2] = {nullptr, nullptr}; // recorded after the H2D copy of the buffer (on the context's second stream)
-    hipEvent_t batch_ev[2] = {nullptr, nullptr};// recorded behind the kernels of the batch that read device buffer [turn]
-    bool batch_ev_pending[2] = {false, false};
-    size_t qcnt_zeroed = 0;                     // counters known to be zero (k_merge_flat leaves its query's counter at zero)
-    bool plan_ev_pending[2] = {false, false};
+    unsigned char* h_plan[TURNS] = {};
+    size_t h_plan_cap[TURNS] = {};
+    hipEvent_t plan_ev[TURNS] = {}; // recorded after the H2D copy of the buffer (on the context's second stream)
+    hipEvent_t batch_ev[TURNS] = {};// recorded behind the kernels of the batch that read device buffer [turn]
+    bool batch_ev_pending[TURNS] = {};
+    size_t qcnt_zeroed2[TURNS] = {};           // counters known to be zero (k_merge_flat leaves its query's counter at zero)
+    bool plan_ev_pending[TURNS] = {};
     int plan_turn = 0;
     ss::DevBuf<Rec> d_x[4];                     // phrase result lists: scoring records
     ss::DevBuf<float> d_xw[4];                  // ... and their float32 weight sums
     ss::DevBuf<uint32_t> d_xcnt, d_pcnt;
-    ss::DevBuf<uint64_t> d_so_key;
-    ss::DevBuf<uint32_t> d_so_doc, d_so_cnt, d_qticket, d_qcnt;
+    ss::DevBuf<uint64_t> d_so_key2[TURNS];           // the slices' candidates, one set per turn ("score.pipeline": batch i's merge reads its set while batch i+1 fills the other)
+    ss::DevBuf<uint32_t> d_so_doc2[TURNS], d_so_cnt, d_qticket, d_qcnt2[TURNS];
+    hipEvent_t wave_ev[TURNS] = {};  // "score.pipeline": behind k_score_wave on the caller's stream; the merge stream waits for it
+    bool merge_pending = false;                 // a merge may still be running on the context's merge stream
     size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
     ss::DevBuf<ss_hit> d_hits;
     ss::DevBuf<int32_t> d_nhits;
     ~ss_scorer() {
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < TURNS; i++) {
             if (h_plan[i]) (void)hipHostFree(h_plan[i]);
             if (plan_ev[i]) (void)hipEventDestroy(plan_ev[i]);
             if (batch_ev[i]) (void)hipEventDestroy(batch_ev[i]);
+            if (wave_ev[i]) (void)hipEventDestroy(wave_ev[i]);
         }
     }
 };
@@ -1510,6 +1517,7 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->merge_stream) (void)hipStreamSynchronize(ctx->merge_stream);
 #if defined(SSW_PHASES) && !defined(SS_DIAG)
     ss::score_wave_diag_dump();
 #endif
@@ -1546,6 +1554,7 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank) 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SS_HIP(ctx, hipSetDevice(ctx->device));
     if (k_topics < 0 || k_topics > SS_MAX_TOPICS) return ctx->fail(SS_ERR_INVALID, "ss_scorer_set_prior: bad k_topics");
+    if (ctx->merge_stream) SS_HIP(ctx, hipStreamSynchronize(ctx->merge_stream));   // a pipelined merge may still read the prior
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (k_topics == 0 || !rank) {
         s->prior.release();
@@ -1907,7 +1916,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const size_t o_qfast = o;  o = align16(o + (size_t)n_q);
     const size_t plan_bytes = o;
     const int pb = s->plan_turn;
-    s->plan_turn ^= 1;
+    s->plan_turn = (s->plan_turn + 1) % ss_scorer::TURNS;
     if (!s->plan_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->plan_ev[pb], hipEventDisableTiming));
     if (s->plan_ev_pending[pb]) {                // the copy that last read this buffer (two calls ago) must be over
         SS_HIP(ctx, hipEventSynchronize(s->plan_ev[pb]));
@@ -1960,8 +1969,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, ensure(s->d_xcnt, (size_t)n_q * 4));
         SS_HIP(ctx, ensure(s->d_pcnt, std::max<size_t>(h_parts.size(), 1) * 2));
     }
-    SS_HIP(ctx, ensure(s->d_so_key, n_slices * k));
-    SS_HIP(ctx, ensure(s->d_so_doc, n_slices * k));
+    SS_HIP(ctx, ensure(s->d_so_key2[pb], n_slices * k));
+    SS_HIP(ctx, ensure(s->d_so_doc2[pb], n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_cnt, n_slices));
     const bool fused = ctx->opt("score.separate_merge", 0) == 0;
     if (fused && s->qticket_zeroed < (size_t)n_q) {
@@ -1969,10 +1978,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipMemsetAsync(s->d_qticket.p, 0, (size_t)n_q * sizeof(uint32_t), st));
         s->qticket_zeroed = (size_t)n_q;
     }
-    if (!h_mergeq.empty() && s->qcnt_zeroed < (size_t)n_q) {    // k_merge_flat hands every counter back at zero
-        SS_HIP(ctx, ensure(s->d_qcnt, (size_t)n_q));
-        SS_HIP(ctx, hipMemsetAsync(s->d_qcnt.p, 0, s->d_qcnt.bytes(), st));
-        s->qcnt_zeroed = s->d_qcnt.n;
+    if (!h_mergeq.empty() && s->qcnt_zeroed2[pb] < (size_t)n_q) {    // k_merge_flat hands every counter back at zero
+        SS_HIP(ctx, ensure(s->d_qcnt2[pb], (size_t)n_q));
+        SS_HIP(ctx, hipMemsetAsync(s->d_qcnt2[pb].p, 0, s->d_qcnt2[pb].bytes(), st));
+        s->qcnt_zeroed2[pb] = s->d_qcnt2[pb].n;
     }
     SS_HIP(ctx, ensure(s->d_hits, (size_t)n_q * k));
     SS_HIP(ctx, ensure(s->d_nhits, n_q));
@@ -2012,9 +2021,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.cb_flat = cb_flat;
     p.kth_j = kth_j;
     p.exact_all = exact_all ? 1 : 0;
-    p.so_key = s->d_so_key.p; p.so_doc = s->d_so_doc.p; p.so_cnt = s->d_so_cnt.p;
+    p.so_key = s->d_so_key2[pb].p; p.so_doc = s->d_so_doc2[pb].p; p.so_cnt = s->d_so_cnt.p;
     p.q_ticket = fused ? s->d_qticket.p : nullptr;
-    p.qc_cnt = s->d_qcnt.p;
+    p.qc_cnt = s->d_qcnt2[pb].p;
     p.merge_q = reinterpret_cast<const uint32_t*>(dp + o_mergeq);
     p.q_fast = reinterpret_cast<const uint8_t*>(dp + o_qfast);
     p.hits = dev_out ? hits_out : s->d_hits.p;
@@ -2023,7 +2032,6 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // The upload goes out on the context's SECOND stream as soon as the plan is staged — beside the kernels of the previous
     // batch, which read the other device buffer.  (On the one stream the copy sat
     // between two batches: 39 us per batch in the kernel trace with the counter memset, 6 % of the wall time at config 3.)
-    if (s->batch_ev_pending[pb]) SS_HIP(ctx, hipEventSynchronize(s->batch_ev[pb]));   // the batch two calls ago read this device buffer: the host runs at most two batches ahead
     if (n_fast_slices) SS_HIP(ctx, ensure(s->d_wprep2[pb], ss::score_wave_prep_bytes((unsigned)n_fast_slices)));
     bool prep_done = false;
     if (!dev_out) {
@@ -2042,6 +2050,14 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         // with no cross-stream dependency in front of them (a hipStreamWaitEvent there left 21 us between two batches, and two of
         // them per batch ran the runtime out of signals every ~80 batches: an 8 ms stall)
         SS_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+    }
+    // "score.pipeline": a batch that is all k_score_wave, results in device memory: its k_merge_flat goes to the context's merge stream
+    // behind an event and the caller's stream does not wait for it — the next batch's k_score_wave starts under it.  The hits are
+    // complete after ss_synchronize (and before the call after next returns).  Any other call first waits for the merges still out.
+    const bool pipe = dev_out && n_fast_slices == n_slices && !h_mergeq.empty() && !any_phrase && ctx->opt("score.pipeline", 0) != 0;
+    if (!pipe && s->merge_pending) {
+        SS_HIP(ctx, hipStreamSynchronize(ctx->merge_stream));
+        s->merge_pending = false;
     }
     const auto th4 = t_now();
     const size_t lds_score = score_lds_bytes(cb), lds_merge = merge_lds_bytes(k, cb);
@@ -2067,19 +2083,30 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         hipLaunchKernelGGL(k_score_slices, dim3((unsigned)(n_slices - n_fast_slices)), dim3(TPB), lds_score, st, ps);
     }
     if (!fused && n_slices > n_fast_slices) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
-    if (!h_mergeq.empty()) hipLaunchKernelGGL(k_merge_flat, dim3((unsigned)h_mergeq.size()), dim3(TPB_MF), merge_lds_bytes(k, cb_flat), st, p);
-    if (timed) {
+    hipStream_t mst = st;
+    if (pipe) {
+        if (!ctx->merge_stream) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->merge_stream, hipStreamNonBlocking));
+        if (!s->wave_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->wave_ev[pb], hipEventDisableTiming));
+        SS_HIP(ctx, hipEventRecord(s->wave_ev[pb], st));
+        SS_HIP(ctx, hipStreamWaitEvent(ctx->merge_stream, s->wave_ev[pb], 0));
+        mst = ctx->merge_stream;
+        s->merge_pending = true;
+    }
+    if (timed && pipe) {                         // ss_last_kernel_ms(1) then covers the kernels on the caller's stream only
         SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
         ctx->ev_valid[1] = true;
     }
-#ifndef SS_EXP_NOBATCHEV
-    SS_HIP(ctx, hipEventRecord(s->batch_ev[pb], st));
+    if (!h_mergeq.empty()) hipLaunchKernelGGL(k_merge_flat, dim3((unsigned)h_mergeq.size()), dim3(TPB_MF), merge_lds_bytes(k, cb_flat), mst, p);
+    if (timed && !pipe) {
+        SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
+        ctx->ev_valid[1] = true;
+    }
+    SS_HIP(ctx, hipEventRecord(s->batch_ev[pb], mst));
     s->batch_ev_pending[pb] = true;
-#endif
     SS_HIP(ctx, hipGetLastError());
     if (trace)
-        fprintf(stderr, "[score trace] copies in + checks %.0f us, plan (%zu slices) %.0f us, staging %.0f us, H2D + allocs + params %.0f us, launches %.0f us\n",
-                t_us(th0, th1), n_slices, t_us(th1, th2), t_us(th2, th3), t_us(th3, th4), t_us(th4, t_now()));
+        fprintf(stderr, "[score trace] copies in + checks %.0f us, plan (%zu slices) %.0f us, staging %.0f us, H2D + allocs + params %.0f us, launches %.0f us%s\n",
+                t_us(th0, th1), n_slices, t_us(th1, th2), t_us(th2, th3), t_us(th3, th4), t_us(th4, t_now()), pipe ? " (merge on the merge stream)" : "");
     if (dev_out) return SS_OK;                   // ordered on the ctx stream; ss_synchronize (or the stream's owner) waits
     SS_HIP(ctx, hipMemcpyAsync(hits_out, s->d_hits.p, (size_t)n_q * k * sizeof(ss_hit), hipMemcpyDefault, st));
     SS_HIP(ctx, hipMemcpyAsync(n_hits_out, s->d_nhits.p, n_q * sizeof(int32_t), hipMemcpyDefault, st));

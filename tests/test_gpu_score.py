@@ -10,7 +10,7 @@ import math
 import numpy as np
 import pytest
 
-from spaghettisearch_amd import synth
+from spaghettisearch_amd import engine, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -391,6 +391,56 @@ def test_wave_graded_slices_agree(ss_ctx, oracle, grade):
         assert_same_hits(hits, n_hits, ref, ref_n)
     finally:
         close_all(sc, ti, bi)
+
+
+def test_pipelined_batches_agree(ss_ctx, oracle):
+    """Option "score.pipeline": a batch's k_merge_flat runs on the context's merge stream under the next batch's k_score_wave, and the
+    hits are complete after ss_synchronize.  Six different batches back to back into six device buffers (stream shared with the
+    caller, so the calls only enqueue), then one synchronize: every batch must equal the oracle; then a non-pipelined call and a
+    prior change right behind pipelined ones (both must wait for the merges still out)."""
+    import torch
+    n_docs, n_terms = 300000, 20000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 6000000, 400000, seed=51)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ss_ctx.set_stream(stream.cuda_stream)
+    sc = ti = bi = None
+    try:
+        with torch.cuda.stream(stream):
+            sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+            batches = [synth.make_queries(96 + 16 * i, 3, 300, seed=60 + i) for i in range(6)]
+            k = 40
+            outs = [(torch.zeros(len(qp) * k * 40, dtype=torch.uint8, device=dev), torch.zeros(len(qp), dtype=torch.int32, device=dev))
+                    for qp, _ in batches]
+            with ss_ctx.options(score__wave_min_list=0, score__pipeline=1):
+                for (qp, qt), out in zip(batches, outs):
+                    sc.score_topk(qp, qt, k, out=out)
+                ss_ctx.synchronize()
+                for (qp, qt), (dh, dn) in zip(batches, outs):
+                    nq = len(qp) - 1
+                    ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, qp, qt, k)
+                    hits = dh.cpu().numpy()[: nq * k * 40].view(engine.HIT_DTYPE).reshape(nq, k)
+                    assert_same_hits(hits, dn.cpu().numpy()[:nq], ref, ref_n)
+                # a host-output call right behind two pipelined ones, and a prior change behind a pipelined one
+                qp, qt = batches[0]
+                sc.score_topk(qp, qt, k, out=outs[0])
+                sc.score_topk(batches[1][0], batches[1][1], k, out=outs[1])
+                hits, n_hits = sc.score_topk(qp, qt, k)
+                ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, qp, qt, k)
+                assert_same_hits(hits, n_hits, ref, ref_n)
+                sc.score_topk(qp, qt, k, out=outs[0])
+                rng = np.random.default_rng(5)
+                prior = rng.random((4, n_docs)) * 1e-3
+                sc.set_prior(prior)
+                ss_ctx.synchronize()
+                nq = len(qp) - 1
+                hits0 = outs[0][0].cpu().numpy()[: nq * k * 40].view(engine.HIT_DTYPE).reshape(nq, k)
+                assert_same_hits(hits0, outs[0][1].cpu().numpy()[:nq], ref, ref_n)       # scored before the prior changed
+    finally:
+        for x in (sc, ti, bi):
+            if x is not None:
+                x.close()
+        ss_ctx.set_stream(None)
 
 
 def test_wave_round_makes_progress_beside_much_denser_lists(ss_ctx, oracle):

@@ -27,6 +27,7 @@ for mode in os.environ.get("MODES", "wave,slices").split(","):
         if os.environ.get(env): ctx.set_option(opt, int(os.environ[env]))
     if os.environ.get("ST"): ctx.set_option("score.slice_target", int(os.environ["ST"]))
     if os.environ.get("WML"): ctx.set_option("score.wave_min_list", int(os.environ["WML"]))
+    if os.environ.get("PIPE"): ctx.set_option("score.pipeline", 1 if mode == "wave" else 0)
     d_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev); d_n = torch.empty(nq, dtype=torch.int32, device=dev)
     ms = []
     for i in range(int(os.environ.get("R", "25"))):
