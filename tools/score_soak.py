@@ -35,9 +35,16 @@ while time.time() < t_end:
         q_terms[1::nterm] = q_terms[0::nterm]                      # a duplicate token in every query
     probs = rng.dirichlet(np.ones(4), size=nq) if blend else None
     sc.set_prior(prior if blend else None)
-    print(f"batch {n_batches}: nq={nq} terms={nterm} ranks<{ranks} k={k} wave_slice={wt} wave_min_list={wml} blend={blend} dup={dup}", flush=True)
-    with ctx.options(score__wave_min_list=wml, score__wave_max_terms=12 if wml == 0 else None, score__wave_slice_target=None if wt is None else int(wt)):
-        h1, n1 = sc.score_topk(q_ptr, q_terms, k, topic_probs=probs)
+    print(f"batch {n_batches}: nq={nq} terms={nterm} ranks<{ranks} k={k} wave_slice={wt} wave_min_list={wml} blend={blend} dup={dup}" + (" pipelined" if False else ""), flush=True)
+    pipe = bool(rng.integers(0, 3) == 0)                               # device outputs, merge on the merge stream ("score.pipeline")
+    with ctx.options(score__wave_min_list=wml, score__wave_max_terms=12 if wml == 0 else None, score__wave_slice_target=None if wt is None else int(wt),
+                     score__pipeline=1 if pipe else None):
+        if pipe:
+            d_h = torch.zeros(nq * k * 40, dtype=torch.uint8, device=dev); d_n = torch.zeros(nq, dtype=torch.int32, device=dev)
+            sc.score_topk(q_ptr, q_terms, k, topic_probs=probs, out=(d_h, d_n))          # (own stream: the binding synchronises)
+            h1 = d_h.cpu().numpy().view(engine.HIT_DTYPE).reshape(nq, k); n1 = d_n.cpu().numpy()
+        else:
+            h1, n1 = sc.score_topk(q_ptr, q_terms, k, topic_probs=probs)
         ms1 = ctx.last_kernel_ms(1)
     with ctx.options(score__wave=0):
         h0, n0 = sc.score_topk(q_ptr, q_terms, k, topic_probs=probs)
