@@ -1176,6 +1176,21 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     const bool trace = ctx->opt("pr.trace", 0) != 0;
     auto t_now = [] { return std::chrono::steady_clock::now(); };
     auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    // the large tables first: the device zeroes them (gigabytes at config 4) while the host builds and deals the work items below
+    if (((uint64_t)g->nd_int + 1) * GW * 8 >= (1ull << 32))
+        return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_create: contribution table of %llu rows x %d topics exceeds 4 GiB (shard the graph over more ranks)",
+                         (unsigned long long)g->nd_int, GW);
+    SS_HIP(ctx, pr->x.alloc_streaming(n_local * GW));
+    // + the all-zero row k_pr_sweep's unused slots gather from (never written: the exchange and the sweeps stop at nd_int)
+    SS_HIP(ctx, pr->tab0.alloc(((size_t)g->nd_int + 1) * GW));
+    SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, std::max<size_t>(pr->tab0.bytes(), 8), st));
+    if (g->world == 1) {
+        SS_HIP(ctx, pr->tab1.alloc(((size_t)g->nd_int + 1) * GW));
+        SS_HIP(ctx, hipMemsetAsync(pr->tab1.p, 0, std::max<size_t>(pr->tab1.bytes(), 8), st));
+    } else {
+        SS_HIP(ctx, pr->send.alloc((size_t)g->sl_nd * GW));
+        SS_HIP(ctx, hipMemsetAsync(pr->send.p, 0, std::max<size_t>(pr->send.bytes(), 8), st));
+    }
     const auto tc0 = t_now();
     std::vector<WorkItem> items;
     uint32_t nsegs = 0, nmulti = 0, seg_edges = 0, pos_nd = 0, pos_d = 0;
@@ -1274,20 +1289,6 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     }
 
     const auto tc2 = t_now();
-    if (((uint64_t)g->nd_int + 1) * GW * 8 >= (1ull << 32))
-        return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pr_create: contribution table of %llu rows x %d topics exceeds 4 GiB (shard the graph over more ranks)",
-                         (unsigned long long)g->nd_int, GW);
-    SS_HIP(ctx, pr->x.alloc_streaming(n_local * GW));
-    // + the all-zero row k_pr_sweep's unused slots gather from (never written: the exchange and the sweeps stop at nd_int)
-    SS_HIP(ctx, pr->tab0.alloc(((size_t)g->nd_int + 1) * GW));
-    SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, std::max<size_t>(pr->tab0.bytes(), 8), st));
-    if (g->world == 1) {
-        SS_HIP(ctx, pr->tab1.alloc(((size_t)g->nd_int + 1) * GW));
-        SS_HIP(ctx, hipMemsetAsync(pr->tab1.p, 0, std::max<size_t>(pr->tab1.bytes(), 8), st));
-    } else {
-        SS_HIP(ctx, pr->send.alloc((size_t)g->sl_nd * GW));
-        SS_HIP(ctx, hipMemsetAsync(pr->send.p, 0, std::max<size_t>(pr->send.bytes(), 8), st));
-    }
     const unsigned begin_blocks = std::max(1u, std::min(2048u, ss::div_up(n_local * GW, TPB)));
     SS_HIP(ctx, pr->partials.alloc(((size_t)std::max(pr->nblocks, begin_blocks) + 8) * 2 * GW));   // block rows + 8 group rows
     SS_HIP(ctx, pr->segpart.alloc((size_t)std::max(nsegs, 1u) * GW));
