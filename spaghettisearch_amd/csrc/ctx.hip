@@ -243,6 +243,7 @@ static const char* const k_option_names[] = {
     "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
     "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 65536, 0 = off)
+    "pr.deal_snake",        // work items dealt to the waves in alternating direction (1) or least-loaded-first (0); default: 1 from 8 items per wave on
     "pr.item_turns",        // turns per V_DEG work item of k_pr_sweep (V_QUAD: twice that); default 4 up to 4M local rows, 8 beyond
     "pr.trace",             // 1: ss_graph_create / ss_pr_create print their phase times to stderr
     "score.timing",         // 0: ss_score_topk records no timing events (ss_last_kernel_ms(1) keeps its last value)

@@ -10,6 +10,7 @@ ctx = engine.Context(0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 import os
 if os.environ.get('TRACE'): ctx.set_option('pr.trace', 1)
+if os.environ.get('SNAKE'): ctx.set_option('pr.deal_snake', 1)
 if os.environ.get('SHARED_STREAM'):
     _st = torch.cuda.Stream(device=dev); ctx.set_stream(_st.cuda_stream); torch.cuda.set_stream(_st)
 for name, n, e, k in (("config2", 1 << 20, 5_000_000, 1), ("config4", 10_000_000, 50_000_000, 16)):

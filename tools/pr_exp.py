@@ -9,6 +9,7 @@ ctx = engine.Context(0)
 n, e = int(os.environ.get("N", 10_000_000)), int(os.environ.get("E", 50_000_000))
 kt = int(os.environ.get("K", "16"))
 out_ptr, out_dst = synth.rmat_graph_torch(n, e, seed=42, device=dev)
+if os.environ.get("SNAKE"): ctx.set_option("pr.deal_snake", int(os.environ["SNAKE"]))
 g = engine.Graph(ctx, n, out_ptr, out_dst)
 pr = engine.PageRankState(g, 0.75, -1.0, synth.topic_sizes(n, kt), max_iter=0)
 if os.environ.get("TS"):      # opt-in topic-sensitive teleport: topic k teleports to a random 1/16 of the nodes
