@@ -1080,7 +1080,14 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
         if (non_dangling)
             for (uint32_t r = c; r < cnt; r += ZERO_ROWS) zer.push_back({W_ZERO, row0 + r, std::min<uint32_t>(ZERO_ROWS, cnt - r), 0, 0, 0});
     };
+    {
+        const size_t rows_all = g->h_indeg_nd.size() + g->h_indeg_d.size();
+        vquad.reserve(rows_all / 64 + 1024);
+        for (auto& v : vdeg) v.reserve(rows_all / 256 + 1024);
+        vzero.reserve(rows_all / 64 + 1024);
+    }
     emit(g->h_indeg_nd, 0, true, pos_nd);
+    const size_t vquad_split = vquad.size();            // the non-dangling rows' groups (falling length), then the dangling rows'
     emit(g->h_indeg_d, g->sl_nd, false, pos_d);
     items.clear();
     items.reserve(seg.size() + rwg.size() + wav.size() + grp.size() + zer.size());
@@ -1096,7 +1103,9 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
     items.insert(items.end(), vroww.begin(), vroww.end());
     vbeg[1] = (uint32_t)items.size();
     // row groups by falling length (the dangling class was appended after the non-dangling one)
-    std::stable_sort(vquad.begin(), vquad.end(), [](const WorkItem& a, const WorkItem& b) { return a.nseg > b.nseg; });
+    // (each of the two classes is in falling length already: one stable merge, not a sort)
+    std::inplace_merge(vquad.begin(), vquad.begin() + (ptrdiff_t)vquad_split, vquad.end(),
+                       [](const WorkItem& a, const WorkItem& b) { return a.nseg > b.nseg; });
     items.insert(items.end(), vquad.begin(), vquad.end());
     for (int k = 0; k < 3; k++) {
         vbeg[2 + k] = (uint32_t)items.size();
