@@ -1929,7 +1929,13 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_plan[pb]), plan_bytes * 2, hipHostMallocDefault));
         s->h_plan_cap[pb] = plan_bytes * 2;
     }
-    if (!s->batch_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->batch_ev[pb], hipEventDisableTiming | hipEventReleaseToDevice));
+    if (!s->batch_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->batch_ev[pb], hipEventDisableTiming));
+    // the batch two calls ago used this turn's device buffers (plan, prep, candidates) and may still be running — in pipelined mode its
+    // merge certainly may: the host runs at most two batches ahead, and waits here BEFORE any of those buffers is grown or rewritten
+    if (s->batch_ev_pending[pb]) {
+        SS_HIP(ctx, hipEventSynchronize(s->batch_ev[pb]));
+        s->batch_ev_pending[pb] = false;
+    }
     SS_HIP(ctx, ensure(s->d_plan2[pb], plan_bytes));
     unsigned char* hp = s->h_plan[pb];
     std::memcpy(hp + o_qoff, h_qoff.data(), (n_q + 1) * sizeof(uint32_t));

@@ -393,8 +393,11 @@ def test_wave_graded_slices_agree(ss_ctx, oracle, grade):
         close_all(sc, ti, bi)
 
 
-def test_pipelined_batches_agree(ss_ctx, oracle):
-    """Option "score.pipeline": a batch's k_merge_flat runs on the context's merge stream under the next batch's k_score_wave, and the
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_pipelined_batches_agree(ss_ctx, oracle, pipeline):
+    """(pipeline = 0: the same stream of calls in the default mode — batches of different sizes back to back reuse and regrow the
+    per-turn device buffers while earlier batches are still running, which once went unguarded.)
+    Option "score.pipeline": a batch's k_merge_flat runs on the context's merge stream under the next batch's k_score_wave, and the
     hits are complete after ss_synchronize.  Six different batches back to back into six device buffers (stream shared with the
     caller, so the calls only enqueue), then one synchronize: every batch must equal the oracle; then a non-pipelined call and a
     prior change right behind pipelined ones (both must wait for the merges still out)."""
@@ -408,11 +411,11 @@ def test_pipelined_batches_agree(ss_ctx, oracle):
     try:
         with torch.cuda.stream(stream):
             sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
-            batches = [synth.make_queries(96 + 16 * i, 3, 300, seed=60 + i) for i in range(6)]
+            batches = [synth.make_queries(96 + 48 * (i % 5), 3, 300, seed=60 + i) for i in range(12)]
             k = 40
             outs = [(torch.zeros(len(qp) * k * 40, dtype=torch.uint8, device=dev), torch.zeros(len(qp), dtype=torch.int32, device=dev))
                     for qp, _ in batches]
-            with ss_ctx.options(score__wave_min_list=0, score__pipeline=1):
+            with ss_ctx.options(score__wave_min_list=0, score__pipeline=pipeline):
                 for (qp, qt), out in zip(batches, outs):
                     sc.score_topk(qp, qt, k, out=out)
                 ss_ctx.synchronize()
