@@ -265,9 +265,12 @@ int32_t ss_index_set_positions(ss_index* idx, const uint64_t* pos_ptr, const flo
  * the device — no re-flatten, no re-upload — and every list is re-validated to be strictly ascending by doc; on any
  * error the table is unchanged.  Weights are taken as given (the reference stores whatever listPos[0] holds).
  * Magnitudes: when the table's squared magnitudes are resident (after ss_tfidf_build or ss_index_refresh_magnitudes), the
- * delta updates the magnitudes of the docs it touches itself, in O(delta): what left is subtracted, what came is added
- * (float64 sums of float32 squares are exact, so the result is the one a full pass gives; ss_index_read_magnitudes reads
- * them back for the forw[4] rows).  After ss_index_set_weighted (magnitudes given from outside) they are NOT touched: call
+ * delta brings the magnitudes of the docs it touches (deleted docs, docs of deleted pairs, docs of new postings) up to date
+ * itself: their squares are summed AGAIN from the merged table, in ascending term order — the order in which
+ * term_weighting.go:29-46 reaches a doc — so they are what a full pass over the updated table gives, bit for bit, for any
+ * weights (idf = log2(N/df) with N the PageRank node count can be 20, 1e-5 or negative: squares dozens of binary orders
+ * apart, which a "subtract what left" patch would not survive); a doc left without postings has magnitude exactly 0;
+ * ss_index_read_magnitudes reads them back for the forw[4] rows.  After ss_index_set_weighted (magnitudes given from outside) they are NOT touched: call
  * ss_index_refresh_magnitudes.  Positional postings: kept postings keep theirs; ss_index_apply_delta gives the new postings
  * empty position lists, ss_index_apply_delta_pos takes theirs (add_pos_ptr[n_add+1] into add_pos, in the order of the add
  * arrays; parser.go:195-207).  Doc and term ids must exist: grow the table first (ss_index_resize) when a re-indexed page

@@ -50,9 +50,13 @@ struct ss_ctx {
     struct PinBlock { void* p; size_t cap; };
     std::vector<PinBlock> pin_cache;
     template <typename T>
-    T* pin(size_t count = 1) {                       // scratch for `count` T (never fails over: 8 KB, callers ask for bytes)
+    T* pin(size_t count = 1) {                       // scratch for `count` T; callers ask for bytes, not kilobytes
         const size_t bytes = (count * sizeof(T) + 15) & ~(size_t)15;
-        if (!h_pin || pin_used + bytes > PIN_SCRATCH) pin_used = 0;      // (wraps: nothing is held across calls)
+        if (!h_pin || bytes > PIN_SCRATCH) {                              // a request the scratch cannot hold is a bug in the caller
+            fprintf(stderr, "libspaghetti_rank: ss_ctx::pin(%zu bytes) exceeds the %zu-byte scratch\n", bytes, PIN_SCRATCH);
+            abort();
+        }
+        if (pin_used + bytes > PIN_SCRATCH) pin_used = 0;                 // (wraps: nothing is held across calls)
         T* r = reinterpret_cast<T*>(h_pin + pin_used);
         pin_used += bytes;
         return r;
@@ -98,19 +102,40 @@ struct ss_ctx {
 
 namespace ss {
 // Small results back from the device: into the context's pinned scratch, wait, copy out (see ss_ctx::h_pin for why never straight
-// into the caller's pageable variables).  Up to two values per call; waits for `st`.
+// into the caller's pageable variables).  Up to two values per call; waits for `st`.  The sources may be host or device memory
+// (the ABI's "host OR device" input arrays): the copy is ordered on `st`, so a device array produced on the context's stream —
+// what ss_set_stream's contract allows — is read after its producer (a null-stream hipMemcpy is not ordered behind a
+// non-blocking stream).
 inline hipError_t fetch(ss_ctx* ctx, hipStream_t st, void* d1, const void* s1, size_t n1, void* d2 = nullptr, const void* s2 = nullptr, size_t n2 = 0) {
     ctx->pin_used = 0;
     unsigned char* const p1 = ctx->pin<unsigned char>(n1);
     unsigned char* const p2 = n2 ? ctx->pin<unsigned char>(n2) : nullptr;
-    hipError_t e = hipMemcpyAsync(p1, s1, n1, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && n2) e = hipMemcpyAsync(p2, s2, n2, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(p1, s1, n1, hipMemcpyDefault, st);
+    if (e == hipSuccess && n2) e = hipMemcpyAsync(p2, s2, n2, hipMemcpyDefault, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) {
         std::memcpy(d1, p1, n1);
         if (n2) std::memcpy(d2, p2, n2);
     }
     return e;
+}
+// An input array of the ABI ("host OR device memory") copied to a host vector.  Host memory: a plain memcpy.  Device memory:
+// ordered on `st` (the context's stream is non-blocking, so a null-stream hipMemcpy would not wait for a producer on it) and
+// waited for.
+inline hipError_t copy_in(hipStream_t st, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, src) != hipSuccess) {              // plain malloc'ed memory on older runtimes
+        (void)hipGetLastError();
+        std::memcpy(dst, src, bytes);
+        return hipSuccess;
+    }
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) {
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+        return e == hipSuccess ? hipStreamSynchronize(st) : e;
+    }
+    std::memcpy(dst, src, bytes);
+    return hipSuccess;
 }
 }  // namespace ss
 
@@ -135,11 +160,12 @@ namespace ss {
 // Device memory pool (ctx.hip): freed blocks are kept and handed out again, by size class.  One call of the offline entry
 // points allocates and frees some thirty temporaries; hipMalloc + hipFree cost ~0.1 ms a pair and hipFree waits for the
 // device, which is most of what a caller of ss_graph_create + ss_pagerank_run waited for on a small graph.  The pool holds at
-// most 8 GiB (of 288; option "mem.pool_mb" on any context changes it for the process, 0 switches it off).
+// most 64 GiB (of 288; option "mem.pool_mb" on any context changes it for the process, 0 switches it off).
 hipError_t pool_alloc(void** p, size_t bytes);
 void pool_free(void* p);
 void pool_set_limit(size_t bytes);
 void pool_trim();
+void pool_context_count(int delta);
 void pool_stats(uint64_t* misses, double* miss_ms);      // really free everything the pool holds
 
 // Device allocation that frees itself; raw pointers are handed to kernels.

@@ -15,9 +15,10 @@ struct Pool {
     // default limit: 64 GiB of the 288 GB — the library's own working set at the benchmark sizes is ~20 GB, and a limit that the
     // working set exceeds turns every release into an eviction and every large allocation into a fresh hipMalloc (the scorer's
     // 8 GB of combined lists took 0.96 s to create that way, 40 ms from the pool); hipMalloc failures trim the pool and retry
-    size_t held = 0, limit = (size_t)64 << 30;
+    size_t held = 0, limit = (size_t)64 << 30;   // (all fields: under mu)
     double miss_ms = 0.0;            // time spent in hipMalloc on pool misses (pr.trace prints it)
     uint64_t misses = 0;
+    int contexts = 0;                // live ss_ctx of the process: the last ss_shutdown gives the held blocks back
 };
 Pool& pool() { static Pool* p = new Pool(); return *p; }   // never destroyed: DevBufs of static objects may outlive main
 // size classes: powers of two below 1 MiB, then eighths of the power of two (at most 12.5 % over)
@@ -49,8 +50,11 @@ hipError_t pool_alloc(void** out, size_t bytes) {
     }
     const auto tm0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, cls);
-    P.miss_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count();
-    P.misses++;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.miss_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count();
+        P.misses++;
+    }
     if (e != hipSuccess) {                               // give the pool's memory back and try once more
         (void)hipGetLastError();
         pool_trim();
@@ -66,17 +70,17 @@ hipError_t pool_alloc(void** out, size_t bytes) {
 void pool_free(void* p) {
     if (!p) return;
     Pool& P = pool();
-    size_t cls = 0;
+    size_t cls = 0, limit = 0;
     int dev = 0;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.live.find(p);
         if (it != P.live.end()) { dev = it->second.first; cls = it->second.second; P.live.erase(it); }
-        // a block larger than half the limit is not worth holding
+        limit = P.limit;
     }
     // hipFree waits for the device before the memory goes; the pool keeps that guarantee (work of ANY stream that still uses
     // the block is over before somebody else can get it) and saves the unmap / map that follows.
-    if (cls && cls <= P.limit / 2) {
+    if (cls && cls <= limit / 2) {                         // a block larger than half the limit is not worth holding
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (cur != dev) (void)hipSetDevice(dev);
@@ -106,7 +110,22 @@ void pool_free(void* p) {
     (void)hipFree(p);
 }
 
-void pool_stats(uint64_t* misses, double* miss_ms) { *misses = pool().misses; *miss_ms = pool().miss_ms; }
+void pool_stats(uint64_t* misses, double* miss_ms) {
+    std::lock_guard<std::mutex> lk(pool().mu);
+    *misses = pool().misses;
+    *miss_ms = pool().miss_ms;
+}
+// ss_init / ss_shutdown: when the last context of the process goes, so do the blocks the pool holds (a crawler or torch in the
+// same process, or beside it on the same GPU, must not find 64 GiB parked by a library nobody is using)
+void pool_context_count(int delta) {
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lk(pool().mu);
+        pool().contexts += delta;
+        last = delta < 0 && pool().contexts <= 0;
+    }
+    if (last) pool_trim();
+}
 
 void pool_trim() {
     Pool& P = pool();
@@ -208,6 +227,7 @@ int32_t ss_init(int32_t device_id, ss_ctx** out) {
         delete ctx;
         return SS_ERR_HIP;
     }
+    ss::pool_context_count(+1);
     *out = ctx;
     return SS_OK;
 }
@@ -226,6 +246,7 @@ int32_t ss_shutdown(ss_ctx* ctx) {
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (auto& b : ctx->pin_cache) (void)hipHostFree(b.p);
     delete ctx;
+    ss::pool_context_count(-1);
     return SS_OK;
 }
 

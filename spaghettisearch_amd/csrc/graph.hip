@@ -448,7 +448,7 @@ int32_t ss_graph_apply_delta(ss_graph* g, uint64_t n_nodes_new, uint64_t n_chang
     hipStream_t st = ctx->stream;
     const uint64_t n_old = g->n, n_new = n_nodes_new;
     std::vector<uint64_t> h_nptr(n_changed + 1, 0);
-    if (n_changed) SS_HIP(ctx, hipMemcpy(h_nptr.data(), new_ptr, (n_changed + 1) * sizeof(uint64_t), hipMemcpyDefault));
+    if (n_changed) SS_HIP(ctx, ss::copy_in(st, h_nptr.data(), new_ptr, (n_changed + 1) * sizeof(uint64_t)));
     if (h_nptr[0] != 0) return ctx->fail(SS_ERR_INVALID, "ss_graph_apply_delta: new_ptr[0] != 0");
     for (uint64_t i = 0; i < n_changed; i++)
         if (h_nptr[i + 1] < h_nptr[i]) return ctx->fail(SS_ERR_INVALID, "ss_graph_apply_delta: new_ptr is not non-decreasing");

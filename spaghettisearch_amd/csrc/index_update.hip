@@ -33,24 +33,39 @@ __global__ void k_mark_docs(const uint32_t* __restrict__ del_docs, uint64_t n_de
         atomicOr(&bitmap[d >> 5], 1u << (d & 31));
     }
 }
-// keep[i] = 1 unless the posting's doc is deleted
-__global__ void k_keep_from_bitmap(const uint32_t* __restrict__ post_doc, uint64_t n_post, const uint32_t* __restrict__ bitmap, uint8_t* __restrict__ keep) {
+// touched docs = every doc whose magnitude the delta can change (deleted docs, docs of deleted pairs, docs of new postings);
+// ids out of range are reported by the kernels that own the array's error bit
+__global__ void k_mark_touched(const uint32_t* __restrict__ docs, uint64_t n, uint64_t n_docs, uint32_t* __restrict__ touched) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t d = docs[i];
+        if ((uint64_t)d < n_docs) atomicOr(&touched[d >> 5], 1u << (d & 31));
+    }
+}
+// keep[i] = 1 unless the posting's doc is deleted; *n_touched += surviving postings of touched docs (an upper bound of what
+// k_place_kept will hand to the magnitude pass: pair deletes only lower it)
+__global__ void k_keep_from_bitmap(const uint32_t* __restrict__ post_doc, uint64_t n_post, const uint32_t* __restrict__ bitmap, uint8_t* __restrict__ keep,
+                                   const uint32_t* __restrict__ touched /*nullable*/, unsigned long long* __restrict__ n_touched) {
+    uint32_t mine = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_post; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t d = post_doc[i];
-        keep[i] = (bitmap[d >> 5] >> (d & 31)) & 1u ? 0 : 1;
+        const uint32_t k = (bitmap[d >> 5] >> (d & 31)) & 1u ? 0 : 1;
+        keep[i] = (uint8_t)k;
+        if (touched) mine += k & (touched[d >> 5] >> (d & 31));
+    }
+    if (touched) {
+        for (int off = 32; off; off >>= 1) mine += __shfl_down(mine, off);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_touched, (unsigned long long)mine);
     }
 }
 // single postings to delete: locate (term, doc) by binary search; a pair that does not exist is ignored, like the
 // reference's delete(docP, docHash) on a map without the key
-// (pair_sq[i] = float32(w*w) of the posting pair i removed, or -1: nothing live was there — the magnitude update subtracts it;
-//  the keep flag is cleared with an atomic on its word so that a pair listed twice, or a pair of a deleted doc, counts once)
-__global__ void k_unkeep_pairs(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w,
+// (the keep flag is cleared with an atomic on its word: neighbouring flags belong to other threads' pairs)
+__global__ void k_unkeep_pairs(const uint64_t* __restrict__ term_ptr, const uint32_t* __restrict__ post_doc,
                                uint64_t n_terms, uint64_t n_docs,
                                const uint32_t* __restrict__ del_term, const uint32_t* __restrict__ del_doc, uint64_t n_del,
-                               uint8_t* __restrict__ keep, float* __restrict__ pair_sq, uint32_t* __restrict__ err) {
+                               uint8_t* __restrict__ keep, uint32_t* __restrict__ err) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_del; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t t = del_term[i], d = del_doc[i];
-        pair_sq[i] = -1.0f;
         if ((uint64_t)t >= n_terms || (uint64_t)d >= n_docs) { atomicOr(err, 2u); continue; }
         uint64_t lo = term_ptr[t], hi = term_ptr[t + 1];
         const uint64_t end = hi;
@@ -61,31 +76,30 @@ __global__ void k_unkeep_pairs(const uint64_t* __restrict__ term_ptr, const uint
         if (lo < end && post_doc[lo] == d) {
             uint32_t* word = reinterpret_cast<uint32_t*>(keep + (lo & ~(uint64_t)3));
             const uint32_t sh = (uint32_t)(lo & 3) * 8u;
-            const uint32_t old = atomicAnd(word, ~(0xFFu << sh));
-            if ((old >> sh) & 0xFFu) {
-                const float w = post_w[lo];
-                pair_sq[i] = w * w;                                   // term_weighting.go:44 (float32 product)
-            }
+            atomicAnd(word, ~(0xFFu << sh));
         }
     }
 }
-// magnitudes of the touched docs (term_weighting.go:44,72), O(delta): the squared magnitudes are resident (float64 sums of
-// float32 squares: exact, so subtracting what left and adding what came gives the sum a full pass would give)
-__global__ void k_mag_zero_docs(const uint32_t* __restrict__ docs, uint64_t n, double* __restrict__ mag2) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mag2[docs[i]] = 0.0;
+// Magnitudes of the touched docs (term_weighting.go:44,72).  They are RECOMPUTED from the docs' postings in the merged table,
+// never patched: a float64 sum of float32 squares is exact only while the squares span fewer than 29 binary orders, and
+// tf-idf weights do not promise that (idf = log2(N/df) with N the PageRank node count, term_weighting.go:13-17,37: it can be
+// 20 for one word and 1e-5, or negative, for another), so "subtract what left" can cancel to garbage or to a negative
+// number.  k_place_kept / k_place_adds hand every posting of a touched doc to a list {doc << 32 | term, float32(w*w)}; the
+// list is sorted and every doc's squares are summed by one thread in ascending term order — the order in which the
+// reference's pass over the inverted table reaches a doc (term_weighting.go:29-46) — so the result is the full pass's, bit
+// for bit, whatever the weights.
+__global__ void k_mag_zero_docs(const uint32_t* __restrict__ docs, uint64_t n, double* __restrict__ mag2, double* __restrict__ mag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { mag2[docs[i]] = 0.0; mag[docs[i]] = 0.0; }
 }
-__global__ void k_mag_sub_pairs(const uint32_t* __restrict__ del_doc, const float* __restrict__ pair_sq, uint64_t n, double* __restrict__ mag2) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        if (pair_sq[i] >= 0.0f) unsafeAtomicAdd(&mag2[del_doc[i]], -(double)pair_sq[i]);
-}
-__global__ void k_mag_add(const uint32_t* __restrict__ add_doc, const float* __restrict__ add_w, uint64_t n, double* __restrict__ mag2) {
+__global__ void k_mag_segments(const uint64_t* __restrict__ keys, const float* __restrict__ sq, uint64_t n, double* __restrict__ mag2, double* __restrict__ mag) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const float sq = add_w[i] * add_w[i];
-        unsafeAtomicAdd(&mag2[add_doc[i]], (double)sq);
+        const uint32_t d = (uint32_t)(keys[i] >> 32);
+        if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == d) continue;          // not the first posting of its doc
+        double sum = 0.0;
+        for (uint64_t j = i; j < n && (uint32_t)(keys[j] >> 32) == d; j++) sum += (double)sq[j];   // :44 float32 product, float64 sum
+        mag2[d] = sum;
+        mag[d] = sqrt(sum);                                                  // :72
     }
-}
-__global__ void k_mag_sqrt_docs(const uint32_t* __restrict__ docs, uint64_t n, const double* __restrict__ mag2, double* __restrict__ mag) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) mag[docs[i]] = sqrt(mag2[docs[i]]);
 }
 __global__ void k_gather_f64(const double* __restrict__ v, const uint32_t* __restrict__ idx, uint64_t n, uint64_t limit, double* __restrict__ out) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint64_t)idx[i] < limit ? v[idx[i]] : 0.0;
@@ -133,6 +147,22 @@ __global__ void k_new_counts(const uint64_t* __restrict__ term_ptr, const uint32
 // every surviving posting writes itself to its slot in the merged list.  One block per CHUNK consecutive postings: the
 // block finds the terms its chunk spans with two binary searches, each posting finds its own term inside that short
 // range (a chunk of a long list is one term); a term without additions needs nothing more.
+// where the placement kernels leave the postings of touched docs for the magnitude pass (k_mag_segments)
+struct TouchedList {
+    const uint32_t* bitmap;        // NULL: magnitudes are not maintained by this delta
+    unsigned long long* cursor;
+    uint64_t cap;
+    uint64_t* keys;                // doc << 32 | term
+    float* sq;                     // float32(w * w), term_weighting.go:44
+    uint32_t* err;
+    __device__ __forceinline__ void take(uint32_t t, uint32_t d, float w) const {
+        if (!bitmap || !((bitmap[d >> 5] >> (d & 31)) & 1u)) return;
+        const unsigned long long slot = atomicAdd(cursor, 1ull);
+        if (slot >= cap) { atomicOr(err, 64u); return; }
+        keys[slot] = ((uint64_t)d << 32) | t;
+        sq[slot] = w * w;
+    }
+};
 constexpr int PK_PT = 8;
 constexpr int PK_CHUNK = TPB * PK_PT;
 __global__ __launch_bounds__(TPB) void k_place_kept(const uint64_t* __restrict__ term_ptr, uint64_t n_terms, const uint32_t* __restrict__ post_doc,
@@ -140,7 +170,8 @@ __global__ __launch_bounds__(TPB) void k_place_kept(const uint64_t* __restrict__
                                                     const uint32_t* __restrict__ kept_before, const uint64_t* __restrict__ add_keys,
                                                     const uint32_t* __restrict__ add_ptr, const uint64_t* __restrict__ new_ptr,
                                                     uint32_t* __restrict__ out_doc, float* __restrict__ out_w,
-                                                    const uint64_t* __restrict__ pos_ptr /*nullable*/, uint64_t* __restrict__ len_out, uint64_t* __restrict__ src_start) {
+                                                    const uint64_t* __restrict__ pos_ptr /*nullable*/, uint64_t* __restrict__ len_out, uint64_t* __restrict__ src_start,
+                                                    TouchedList tl) {
     __shared__ uint64_t s_t[2];
     const uint64_t base = (uint64_t)blockIdx.x * PK_CHUNK;
     const uint64_t last = min(base + PK_CHUNK, n_post) - 1;
@@ -171,9 +202,11 @@ __global__ __launch_bounds__(TPB) void k_place_kept(const uint64_t* __restrict__
         const uint32_t a0 = add_ptr[t], a1 = add_ptr[t + 1];
         const uint32_t adds_below = a1 > a0 ? add_lower(add_keys, a0, a1, (t << 32) | d) - a0 : 0u;
         const uint64_t o = new_ptr[t] + rank_kept + adds_below;
+        const float w = post_w[i];
         out_doc[o] = d;
-        out_w[o] = post_w[i];
+        out_w[o] = w;
         if (pos_ptr) { len_out[o] = pos_ptr[i + 1] - pos_ptr[i]; src_start[o] = pos_ptr[i]; }
+        tl.take((uint32_t)t, d, w);
     }
 }
 // every new posting: its rank among the additions of its term + the survivors of the term with a smaller doc id
@@ -181,7 +214,8 @@ __global__ void k_place_adds(const uint64_t* __restrict__ term_ptr, const uint32
                              const uint32_t* __restrict__ kept_before, const uint64_t* __restrict__ add_keys, const uint32_t* __restrict__ add_order,
                              const float* __restrict__ add_w, uint64_t n_add, const uint32_t* __restrict__ add_ptr, const uint64_t* __restrict__ new_ptr,
                              uint32_t* __restrict__ out_doc, float* __restrict__ out_w, uint32_t* __restrict__ err,
-                             const uint64_t* __restrict__ add_pos_ptr /*nullable*/, uint64_t* __restrict__ len_out /*nullable*/, uint64_t* __restrict__ src_start) {
+                             const uint64_t* __restrict__ add_pos_ptr /*nullable*/, uint64_t* __restrict__ len_out /*nullable*/, uint64_t* __restrict__ src_start,
+                             TouchedList tl) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_add) return;
     const uint64_t key = add_keys[j];
@@ -197,8 +231,10 @@ __global__ void k_place_adds(const uint64_t* __restrict__ term_ptr, const uint32
     if (lo < end && post_doc[lo] == d && keep[lo]) { atomicOr(err, 16u); return; }   // the posting already exists and was not deleted
     const uint32_t kept_below = kept_before[lo] - kept_before[term_ptr[t]];
     const uint64_t o = new_ptr[t] + ((uint32_t)j - add_ptr[t]) + kept_below;
+    const float w = add_w[add_order[j]];
     out_doc[o] = d;
-    out_w[o] = add_w[add_order[j]];
+    out_w[o] = w;
+    tl.take((uint32_t)t, d, w);
     if (len_out) {
         const uint32_t a = add_order[j];
         len_out[o] = add_pos_ptr ? add_pos_ptr[a + 1] - add_pos_ptr[a] : 0ull;
@@ -296,14 +332,13 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
 
     ss::DevBuf<uint32_t> bitmap, err, d_del_docs, d_del_term, d_del_doc, d_add_term, d_add_doc, order_in, order, kept_before, add_ptr;
     ss::DevBuf<uint8_t> keep;
-    ss::DevBuf<float> d_add_w, pair_sq, d_add_pos;
+    ss::DevBuf<float> d_add_w, d_add_pos;
     ss::DevBuf<uint64_t> keys_in, keys, cnt, new_ptr, d_add_pos_ptr, len_out, src_start, new_pos_ptr;
     const bool has_pos = idx->pos_ptr.p != nullptr;
     uint64_t n_add_pos = 0;
     if (has_pos && add_pos_ptr && n_add) {
-        std::vector<uint64_t> ends(2);
-        SS_HIP(ctx, hipMemcpy(&ends[0], add_pos_ptr, sizeof(uint64_t), hipMemcpyDefault));
-        SS_HIP(ctx, hipMemcpy(&ends[1], add_pos_ptr + n_add, sizeof(uint64_t), hipMemcpyDefault));
+        uint64_t ends[2] = {0, 0};
+        SS_HIP(ctx, ss::fetch(ctx, st, &ends[0], add_pos_ptr, sizeof(uint64_t), &ends[1], add_pos_ptr + n_add, sizeof(uint64_t)));
         if (ends[0] != 0 || (ends[1] && !add_pos)) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: add_pos_ptr[0] != 0 or add_pos NULL");
         n_add_pos = ends[1];
         SS_HIP(ctx, d_add_pos_ptr.alloc(n_add + 1));
@@ -318,29 +353,36 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
         SS_HIP(ctx, ss::fetch(ctx, st, &h_perr, perr.p, sizeof(uint32_t)));
         if (h_perr) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: add_pos_ptr is not non-decreasing");
     }
-    SS_HIP(ctx, pair_sq.alloc(n_del));
+    const bool keep_mag = idx->mag2_valid;
+    ss::DevBuf<uint32_t> touched;
+    ss::DevBuf<unsigned long long> tcount;                        // [0] upper bound from k_keep_from_bitmap, [1] cursor of the placement kernels
     SS_HIP(ctx, bitmap.alloc((N + 31) / 32));
     SS_HIP(ctx, keep.alloc(((P + 1) + 3) & ~(uint64_t)3));
     SS_HIP(ctx, kept_before.alloc(P + 1));
     SS_HIP(ctx, err.alloc(1));
+    SS_HIP(ctx, tcount.alloc(2));
     SS_HIP(ctx, hipMemsetAsync(bitmap.p, 0, std::max<size_t>(bitmap.bytes(), 4), st));
     SS_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(uint32_t), st));
+    SS_HIP(ctx, hipMemsetAsync(tcount.p, 0, 2 * sizeof(unsigned long long), st));
     SS_HIP(ctx, hipMemsetAsync(keep.p + P, 0, 1, st));
+    if (keep_mag) {
+        SS_HIP(ctx, touched.alloc((N + 31) / 32));
+        SS_HIP(ctx, hipMemsetAsync(touched.p, 0, std::max<size_t>(touched.bytes(), 4), st));
+    }
+    // the delta's arrays go up first: the touched-doc bitmap needs all three doc arrays before the pass over the postings
     if (n_del_docs) {
         SS_HIP(ctx, d_del_docs.alloc(n_del_docs));
         SS_HIP(ctx, hipMemcpyAsync(d_del_docs.p, del_docs, n_del_docs * sizeof(uint32_t), hipMemcpyDefault, st));
         hipLaunchKernelGGL(k_mark_docs, dim3(grid_for(n_del_docs)), dim3(TPB), 0, st, (const uint32_t*)d_del_docs.p, n_del_docs, N, bitmap.p, err.p);
+        if (keep_mag) hipLaunchKernelGGL(k_mark_touched, dim3(grid_for(n_del_docs)), dim3(TPB), 0, st, (const uint32_t*)d_del_docs.p, n_del_docs, N, touched.p);
     }
-    if (P) hipLaunchKernelGGL(k_keep_from_bitmap, dim3(grid_for(P)), dim3(TPB), 0, st, (const uint32_t*)idx->post_doc.p, P, (const uint32_t*)bitmap.p, keep.p);
     if (n_del) {
         SS_HIP(ctx, d_del_term.alloc(n_del));
         SS_HIP(ctx, d_del_doc.alloc(n_del));
         SS_HIP(ctx, hipMemcpyAsync(d_del_term.p, del_term, n_del * sizeof(uint32_t), hipMemcpyDefault, st));
         SS_HIP(ctx, hipMemcpyAsync(d_del_doc.p, del_doc, n_del * sizeof(uint32_t), hipMemcpyDefault, st));
-        hipLaunchKernelGGL(k_unkeep_pairs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint32_t*)idx->post_doc.p,
-                           (const float*)idx->post_w.p, T, N, (const uint32_t*)d_del_term.p, (const uint32_t*)d_del_doc.p, n_del, keep.p, pair_sq.p, err.p);
+        if (keep_mag) hipLaunchKernelGGL(k_mark_touched, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint32_t*)d_del_doc.p, n_del, N, touched.p);
     }
-    // additions sorted by (term, doc); the order array carries the weights along
     SS_HIP(ctx, keys_in.alloc(n_add));
     SS_HIP(ctx, keys.alloc(n_add));
     SS_HIP(ctx, order_in.alloc(n_add));
@@ -352,6 +394,15 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
         SS_HIP(ctx, hipMemcpyAsync(d_add_term.p, add_term, n_add * sizeof(uint32_t), hipMemcpyDefault, st));
         SS_HIP(ctx, hipMemcpyAsync(d_add_doc.p, add_doc, n_add * sizeof(uint32_t), hipMemcpyDefault, st));
         SS_HIP(ctx, hipMemcpyAsync(d_add_w.p, add_w, n_add * sizeof(float), hipMemcpyDefault, st));
+        if (keep_mag) hipLaunchKernelGGL(k_mark_touched, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint32_t*)d_add_doc.p, n_add, N, touched.p);
+    }
+    if (P) hipLaunchKernelGGL(k_keep_from_bitmap, dim3(grid_for(P)), dim3(TPB), 0, st, (const uint32_t*)idx->post_doc.p, P, (const uint32_t*)bitmap.p, keep.p,
+                              keep_mag ? (const uint32_t*)touched.p : nullptr, tcount.p);
+    if (n_del)
+        hipLaunchKernelGGL(k_unkeep_pairs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint32_t*)idx->post_doc.p,
+                           T, N, (const uint32_t*)d_del_term.p, (const uint32_t*)d_del_doc.p, n_del, keep.p, err.p);
+    // additions sorted by (term, doc); the order array carries the weights along
+    if (n_add) {
         hipLaunchKernelGGL(k_add_keys, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint32_t*)d_add_term.p, (const uint32_t*)d_add_doc.p, n_add, T, N, keys_in.p, err.p);
         hipLaunchKernelGGL(k_iota, dim3(grid_for(n_add)), dim3(TPB), 0, st, order_in.p, n_add);
         size_t tmp_bytes = 0;
@@ -369,6 +420,20 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
         if (h_early & 1) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: del_docs holds a doc id >= n_docs (table unchanged)");
         if (h_early & 2) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a (term, doc) to delete is out of range (table unchanged)");
         if (h_early & 4) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a posting to add is out of range (table unchanged)");
+    }
+    // room for the postings of the touched docs (their squares are summed again after the merge)
+    TouchedList tl{nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    ss::DevBuf<uint64_t> t_keys_in, t_keys;
+    ss::DevBuf<float> t_sq_in, t_sq;
+    if (keep_mag) {
+        unsigned long long h_bound = 0;
+        SS_HIP(ctx, ss::fetch(ctx, st, &h_bound, tcount.p, sizeof(h_bound)));
+        const uint64_t cap = (uint64_t)h_bound + n_add;
+        SS_HIP(ctx, t_keys_in.alloc(cap));
+        SS_HIP(ctx, t_keys.alloc(cap));
+        SS_HIP(ctx, t_sq_in.alloc(cap));
+        SS_HIP(ctx, t_sq.alloc(cap));
+        tl = TouchedList{touched.p, tcount.p + 1, cap, t_keys_in.p, t_sq_in.p, err.p};
     }
     // survivors before every posting, the delta as a CSR over the terms, new list lengths, new term_ptr
     {
@@ -399,11 +464,11 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
     if (P) hipLaunchKernelGGL(k_place_kept, dim3(ss::div_up(P, PK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, T, (const uint32_t*)idx->post_doc.p,
                               (const float*)idx->post_w.p, P, (const uint8_t*)keep.p, (const uint32_t*)kept_before.p, (const uint64_t*)keys.p,
                               (const uint32_t*)add_ptr.p, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p,
-                              has_pos ? (const uint64_t*)idx->pos_ptr.p : nullptr, len_out.p, src_start.p);
+                              has_pos ? (const uint64_t*)idx->pos_ptr.p : nullptr, len_out.p, src_start.p, tl);
     if (n_add) hipLaunchKernelGGL(k_place_adds, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint64_t*)idx->term_ptr.p, (const uint32_t*)idx->post_doc.p,
                                   (const uint8_t*)keep.p, (const uint32_t*)kept_before.p, (const uint64_t*)keys.p, (const uint32_t*)order.p,
                                   (const float*)d_add_w.p, n_add, (const uint32_t*)add_ptr.p, (const uint64_t*)new_ptr.p, out_doc.p, out_w.p, err.p,
-                                  (const uint64_t*)d_add_pos_ptr.p, has_pos ? len_out.p : nullptr, src_start.p);
+                                  (const uint64_t*)d_add_pos_ptr.p, has_pos ? len_out.p : nullptr, src_start.p, tl);
     if (P2) hipLaunchKernelGGL(k_check_merged, dim3(ss::div_up(P2, PK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)new_ptr.p, T, (const uint32_t*)out_doc.p, P2, err.p);
     SS_HIP(ctx, hipGetLastError());
     uint32_t h_err = 0;
@@ -414,6 +479,7 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
     if (h_err & 8) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: the same (term, doc) is added twice (table unchanged)");
     if (h_err & 16) return ctx->fail(SS_ERR_INVALID, "ss_index_apply_delta: a posting to add already exists and is not deleted by this delta (table unchanged)");
     if (h_err & 32) return ctx->fail(SS_ERR_UNSORTED, "ss_index_apply_delta: merged list not strictly ascending (table unchanged)");
+    if (h_err & 64) return ctx->fail(SS_ERR_STATE, "ss_index_apply_delta: internal: more postings of touched docs than counted (table unchanged)");
     // positional postings follow their postings (listPos[1:] of every kept row entry; the re-indexed page brings its own)
     ss::DevBuf<float> new_pos;
     if (has_pos) {
@@ -425,14 +491,22 @@ int32_t ss_index_apply_delta_pos(ss_index* idx, uint64_t n_del_docs, const uint3
                                    (const float*)idx->pos.p, (const float*)d_add_pos.p, new_pos.p);
         SS_HIP(ctx, hipGetLastError());
     }
-    // magnitudes of the touched docs: what left is subtracted from, what came is added to the resident squared magnitudes
-    if (idx->mag2_valid) {
-        if (n_del_docs) hipLaunchKernelGGL(k_mag_zero_docs, dim3(grid_for(n_del_docs)), dim3(TPB), 0, st, (const uint32_t*)d_del_docs.p, n_del_docs, idx->mag2.p);
-        if (n_del) hipLaunchKernelGGL(k_mag_sub_pairs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint32_t*)d_del_doc.p, (const float*)pair_sq.p, n_del, idx->mag2.p);
-        if (n_add) hipLaunchKernelGGL(k_mag_add, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint32_t*)d_add_doc.p, (const float*)d_add_w.p, n_add, idx->mag2.p);
-        if (n_del_docs) hipLaunchKernelGGL(k_mag_sqrt_docs, dim3(grid_for(n_del_docs)), dim3(TPB), 0, st, (const uint32_t*)d_del_docs.p, n_del_docs, (const double*)idx->mag2.p, idx->mag.p);
-        if (n_del) hipLaunchKernelGGL(k_mag_sqrt_docs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint32_t*)d_del_doc.p, n_del, (const double*)idx->mag2.p, idx->mag.p);
-        if (n_add) hipLaunchKernelGGL(k_mag_sqrt_docs, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint32_t*)d_add_doc.p, n_add, (const double*)idx->mag2.p, idx->mag.p);
+    // magnitudes of the touched docs: zero (a doc may be left without postings), then every doc's squares summed in term order
+    if (keep_mag) {
+        unsigned long long h_n = 0;
+        SS_HIP(ctx, ss::fetch(ctx, st, &h_n, tcount.p + 1, sizeof(h_n)));
+        if (h_n) {
+            size_t tmp_bytes = 0;
+            SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, t_keys_in.p, t_keys.p, t_sq_in.p, t_sq.p, (size_t)h_n, 0u, 64u, st));
+            ss::DevBuf<char> tmp;
+            SS_HIP(ctx, tmp.alloc(tmp_bytes));
+            SS_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, t_keys_in.p, t_keys.p, t_sq_in.p, t_sq.p, (size_t)h_n, 0u, 64u, st));
+            SS_HIP(ctx, hipStreamSynchronize(st));                 // tmp leaves scope
+        }
+        if (n_del_docs) hipLaunchKernelGGL(k_mag_zero_docs, dim3(grid_for(n_del_docs)), dim3(TPB), 0, st, (const uint32_t*)d_del_docs.p, n_del_docs, idx->mag2.p, idx->mag.p);
+        if (n_del) hipLaunchKernelGGL(k_mag_zero_docs, dim3(grid_for(n_del)), dim3(TPB), 0, st, (const uint32_t*)d_del_doc.p, n_del, idx->mag2.p, idx->mag.p);
+        if (n_add) hipLaunchKernelGGL(k_mag_zero_docs, dim3(grid_for(n_add)), dim3(TPB), 0, st, (const uint32_t*)d_add_doc.p, n_add, idx->mag2.p, idx->mag.p);
+        if (h_n) hipLaunchKernelGGL(k_mag_segments, dim3(grid_for(h_n)), dim3(TPB), 0, st, (const uint64_t*)t_keys.p, (const float*)t_sq.p, (uint64_t)h_n, idx->mag2.p, idx->mag.p);
         SS_HIP(ctx, hipGetLastError());
     }
     SS_HIP(ctx, hipStreamSynchronize(st));

@@ -1389,7 +1389,7 @@ int32_t ss_pr_set_teleport(ss_pr* pr, const uint64_t* set_ptr, const uint32_t* s
     const ss_graph* g = pr->g;
     const int K = pr->k;
     std::vector<uint64_t> h_ptr(K + 1);
-    SS_HIP(ctx, hipMemcpy(h_ptr.data(), set_ptr, (K + 1) * sizeof(uint64_t), hipMemcpyDefault));
+    SS_HIP(ctx, ss::copy_in(ctx->stream, h_ptr.data(), set_ptr, (K + 1) * sizeof(uint64_t)));
     if (h_ptr[0] != 0) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: set_ptr[0] != 0");
     for (int k = 0; k < K; k++)
         if (h_ptr[k + 1] < h_ptr[k]) return ctx->fail(SS_ERR_INVALID, "ss_pr_set_teleport: set_ptr not non-decreasing");

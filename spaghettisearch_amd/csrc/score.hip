@@ -1646,37 +1646,37 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const auto th0 = t_now();
     // ---- host-side plan (the host keeps df per term; queries are tiny) -------------
     std::vector<uint32_t> h_qptr(n_q + 1);
-    SS_HIP(ctx, hipMemcpy(h_qptr.data(), q_ptr, (n_q + 1) * sizeof(uint32_t), hipMemcpyDefault));
+    SS_HIP(ctx, ss::copy_in(ctx->stream, h_qptr.data(), q_ptr, (n_q + 1) * sizeof(uint32_t)));
     const uint32_t n_tok = h_qptr[n_q];
     for (int q = 0; q < n_q; q++)
         if (h_qptr[q + 1] < h_qptr[q]) return ctx->fail(SS_ERR_INVALID, "ss_score_topk: q_ptr not non-decreasing");
     if (n_tok && !q_terms) return ctx->fail(SS_ERR_INVALID, "ss_score_topk: q_terms is NULL");
     std::vector<uint32_t> h_terms(n_tok);
-    if (n_tok) SS_HIP(ctx, hipMemcpy(h_terms.data(), q_terms, n_tok * sizeof(uint32_t), hipMemcpyDefault));
+    if (n_tok) SS_HIP(ctx, ss::copy_in(ctx->stream, h_terms.data(), q_terms, n_tok * sizeof(uint32_t)));
     // phrase part (retrieval/phrase.go): tokens of all quoted phrases of a query, concatenated
     std::vector<uint32_t> h_pptr(n_q + 1, 0), h_pterms, h_pdrv(n_q, 0xFFFFFFFFu), h_xoff(n_q + 1, 0), h_pbase(n_q + 1, 0);
     std::vector<uint4> h_parts;                 // k_phrase_match work: {query, pass, first candidate, candidates}
     if (p_ptr) {
         if (!s->title->pos_ptr.p || !s->body->pos_ptr.p)
             return ctx->fail(SS_ERR_STATE, "ss_score_topk_phrase: positional postings not loaded (ss_index_set_positions on both tables)");
-        SS_HIP(ctx, hipMemcpy(h_pptr.data(), p_ptr, (n_q + 1) * sizeof(uint32_t), hipMemcpyDefault));
+        SS_HIP(ctx, ss::copy_in(ctx->stream, h_pptr.data(), p_ptr, (n_q + 1) * sizeof(uint32_t)));
         for (int q = 0; q < n_q; q++)
             if (h_pptr[q + 1] < h_pptr[q]) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_phrase: p_ptr not non-decreasing");
         h_pterms.resize(h_pptr[n_q]);
         if (h_pptr[n_q]) {
             if (!p_terms) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_phrase: p_terms is NULL");
-            SS_HIP(ctx, hipMemcpy(h_pterms.data(), p_terms, h_pterms.size() * sizeof(uint32_t), hipMemcpyDefault));
+            SS_HIP(ctx, ss::copy_in(ctx->stream, h_pterms.data(), p_terms, h_pterms.size() * sizeof(uint32_t)));
         }
     }
     std::vector<int32_t> h_qlen(n_q);
-    if (query_len) SS_HIP(ctx, hipMemcpy(h_qlen.data(), query_len, n_q * sizeof(int32_t), hipMemcpyDefault));
+    if (query_len) SS_HIP(ctx, ss::copy_in(ctx->stream, h_qlen.data(), query_len, n_q * sizeof(int32_t)));
     else for (int q = 0; q < n_q; q++)     // len(queryTokenised)+len(phraseTokenised), main_retrieve.go:90
         h_qlen[q] = (int32_t)(h_qptr[q + 1] - h_qptr[q]) + (int32_t)(h_pptr[q + 1] - h_pptr[q]);
     std::vector<double> h_probs;
     const int K = s->k_topics;
     if (topic_probs) {
         h_probs.resize((size_t)n_q * K);
-        SS_HIP(ctx, hipMemcpy(h_probs.data(), topic_probs, h_probs.size() * sizeof(double), hipMemcpyDefault));
+        SS_HIP(ctx, ss::copy_in(ctx->stream, h_probs.data(), topic_probs, h_probs.size() * sizeof(double)));
     }
 
     // The filter of k_score_slices assumes non-negative finite addends (see there).  Anything else — tables or priors

@@ -55,6 +55,7 @@ class Context:
         check(self.lib.ss_init(device_id, C.byref(h)))
         self.h = h
         self.device_id = device_id
+        self._options = {}           # name -> value of the options set through this object (options() restores from it)
 
     def set_stream(self, hip_stream: Optional[int]) -> None:
         check(self.lib.ss_set_stream(self.h, C.c_void_p(hip_stream)), self.h)
@@ -104,19 +105,25 @@ class Context:
     def set_option(self, name: str, value: Optional[int]) -> None:
         """ss_set_option: tuning / diagnostic switch of this context; None restores the default."""
         check(self.lib.ss_set_option(self.h, name.encode(), -(1 << 63) if value is None else int(value)), self.h)
+        if value is None:
+            self._options.pop(name, None)
+        else:
+            self._options[name] = int(value)
 
     def options(self, **kv):
-        """Context manager: set options (dots written as double underscores: pr__force_narrow=1), restore the defaults on exit."""
+        """Context manager: set options (dots written as double underscores: pr__force_narrow=1); on exit every option gets back
+        the value it had when the scope was entered (the default if it had none), so scopes nest."""
         ctx = self
 
         class _Scope:
             def __enter__(self_inner):
+                self_inner.before = {k.replace("__", "."): ctx._options.get(k.replace("__", ".")) for k in kv}
                 for k, v in kv.items():
                     ctx.set_option(k.replace("__", "."), v)
 
             def __exit__(self_inner, *exc):
-                for k in kv:
-                    ctx.set_option(k.replace("__", "."), None)
+                for name, old in self_inner.before.items():
+                    ctx.set_option(name, old)
                 return False
         return _Scope()
 

@@ -72,7 +72,8 @@ PYBIND11_MODULE(_host, m) {
             auto f = as_dbs(forward);
             r.Run(ctx, d, eps, f);
         })
-        .def_readonly("name", &ranking::ResidentPagerank::name);
+        .def_readonly("name", &ranking::ResidentPagerank::name)
+        .def_readonly("rebuilds", &ranking::ResidentPagerank::rebuilds);
     auto page_info = [](const py::dict& d) {
         retrieval::PageIndexInfo p;
         p.docHash = d["docHash"].cast<std::string>();

@@ -113,11 +113,19 @@ inline std::map<std::string, std::vector<std::string>> TopicTeleportSets(db::Con
 // The link graph kept on the device between crawls: Build flattens forw[2] once, ApplyDelta patches the
 // resident adjacency with the re-crawled parents' new rows (ss_graph_apply_delta: no re-flatten, no re-upload), Run is the
 // compute + write-back half of UpdateTopicSensitivePagerank.  New pages get ids at the end, so ids are stable across deltas.
+// The reference rebuilds its node set = parents U children from forw[2] on every run (pagerank.go:17-44), and the node COUNT
+// enters every rank (totalValue = ... + teleportProbs * len(currentRank), :111): a page that a delta leaves neither a parent
+// nor anybody's child must leave the node set.  The host therefore keeps every parent's child list and every node's
+// in-degree; a delta that orphans a node falls back to Build (ids are compacted, `rebuilds` counts it).
 class ResidentPagerank {
 public:
     std::vector<std::string> name;
     std::unordered_map<std::string, uint32_t> id;
     ss_graph* g = nullptr;
+    std::vector<std::vector<uint32_t>> kids_of;      // [node] children as uploaded (empty for frontier pages)
+    std::vector<uint8_t> is_parent;                  // [node] has a forw[2] row
+    std::vector<uint32_t> indeg;                     // [node] references from the child lists
+    int rebuilds = 0;                                // ApplyDelta calls that had to re-flatten (a node was orphaned)
 
     ResidentPagerank() = default;
     ResidentPagerank(const ResidentPagerank&) = delete;
@@ -146,9 +154,20 @@ public:
         for (size_t i = 0; i < nodes.size(); i++) out_ptr[id[nodes[i].first] + 1] = children[i].size();
         for (size_t v = 0; v < n; v++) out_ptr[v + 1] += out_ptr[v];
         std::vector<uint32_t> out_dst(out_ptr[n]);
+        kids_of.assign(n, {});
+        is_parent.assign(n, 0);
+        indeg.assign(n, 0);
         for (size_t i = 0; i < nodes.size(); i++) {
-            uint64_t base = out_ptr[id[nodes[i].first]];
-            for (auto& c : children[i]) out_dst[base++] = id[c];
+            const uint32_t p = id[nodes[i].first];
+            uint64_t base = out_ptr[p];
+            is_parent[p] = 1;
+            kids_of[p].reserve(children[i].size());
+            for (auto& c : children[i]) {
+                const uint32_t v = id[c];
+                out_dst[base++] = v;
+                kids_of[p].push_back(v);
+                indeg[v]++;
+            }
         }
         check(ss_graph_create(default_ctx(), n, out_dst.size(), out_ptr.data(), out_dst.data(), 0, 1, &g), "ss_graph_create");
     }
@@ -171,11 +190,35 @@ public:
         const size_t n_before = name.size();
         std::vector<uint32_t> changed, kids;
         std::vector<uint64_t> ptr{0};
+        std::vector<uint8_t> has_row;
         for (auto& p : uniq) {
             changed.push_back(node(p));
-            if (forward[2]->Has(ctx, p))
+            has_row.push_back(forward[2]->Has(ctx, p) ? 1 : 0);
+            if (has_row.back())
                 for (auto& c : jsonmini::parse_string_list(forward[2]->Get(ctx, p))) kids.push_back(node(c));
             ptr.push_back(kids.size());
+        }
+        // would the delta leave a node that is neither a parent nor a child?  (counted on copies: nothing changes on failure)
+        std::vector<uint32_t> deg(indeg);
+        deg.resize(name.size(), 0);
+        std::vector<uint8_t> par(is_parent);
+        par.resize(name.size(), 0);
+        for (size_t i = 0; i < changed.size(); i++) {
+            if (changed[i] < n_before)
+                for (uint32_t c : kids_of[changed[i]]) deg[c]--;
+            for (uint64_t j = ptr[i]; j < ptr[i + 1]; j++) deg[kids[j]]++;
+            par[changed[i]] = has_row[i];
+        }
+        bool orphan = false;
+        for (size_t i = 0; i < changed.size() && !orphan; i++) {
+            orphan = !par[changed[i]] && deg[changed[i]] == 0;
+            if (changed[i] < n_before)
+                for (uint32_t c : kids_of[changed[i]]) orphan = orphan || (!par[c] && deg[c] == 0);
+        }
+        if (orphan) {                              // the node set shrinks: re-flatten (pagerank.go:17-44 does so on every run)
+            rebuilds++;
+            Build(ctx, forward);
+            return;
         }
         const int32_t rc = ss_graph_apply_delta(g, name.size(), changed.size(), changed.data(), ptr.data(), kids.data());
         if (rc != SS_OK) {                         // the graph is unchanged: so are the ids
@@ -183,6 +226,10 @@ public:
             name.resize(n_before);
         }
         check(rc, "ss_graph_apply_delta");
+        indeg = std::move(deg);
+        is_parent = std::move(par);
+        kids_of.resize(name.size());
+        for (size_t i = 0; i < changed.size(); i++) kids_of[changed[i]].assign(kids.begin() + ptr[i], kids.begin() + ptr[i + 1]);
     }
 
     // pagerank.go:46-82 — one power iteration per category (all of them in one K-wide run), forw[3][doc] = map[category]rank

@@ -331,26 +331,6 @@ public:
         for (int t = 0; t < 2; t++)
             for (auto& a : add[t])
                 if (a.listPos.empty()) throw std::runtime_error("ApplyDelta: posting without a weight entry");
-        // --- tables -----------------------------------------------------------------------------------------------------
-        for (int t = 0; t < 2; t++) {
-            std::map<std::string, std::map<std::string, std::vector<float>>> rows;   // the rows this delta touches
-            auto row_of = [&](const std::string& w) -> std::map<std::string, std::vector<float>>& {
-                auto it = rows.find(w);
-                if (it != rows.end()) return it->second;
-                auto& r = rows[w];
-                if (inv[t]->Has(ctx, w)) r = jsonmini::parse_map_f32list(inv[t]->Get(ctx, w));
-                return r;
-            };
-            for (auto& d : del[t]) row_of(d.first).erase(d.second);
-            for (auto& a : add[t]) row_of(a.term)[a.doc] = a.listPos;
-            auto bw = inv[t]->BatchWrite_init(ctx);
-            for (auto& r : rows) {
-                if (r.second.empty()) { if (inv[t]->Has(ctx, r.first)) inv[t]->Delete(ctx, r.first); }   // "delete this row" (:484-489)
-                else bw->BatchSet(ctx, r.first, jsonmini::dump(r.second));
-            }
-            bw->Flush(ctx);
-        }
-        forw[2]->Set(ctx, after.docHash, jsonmini::dump(after.children));
         // --- device -----------------------------------------------------------------------------------------------------
         auto grow = [](DenseIds& ids, const std::string& h) {
             auto it = ids.id.find(h);
@@ -360,15 +340,51 @@ public:
             ids.id[h] = v;
             return v;
         };
+        // The device goes FIRST and the tables follow only once both resident tables have taken their delta: a failing
+        // library call must not leave inv[] / forw[2] ahead of the index that answers queries.  Whatever happens, the index
+        // stays servable: the scorer is re-created on every way out (ScorerGuard), and ids grown for a delta that did not
+        // happen are taken back while the device tables still have their old size.
         const size_t n_before = docs.name.size(), t_before = terms.name.size();
         for (int t = 0; t < 2; t++)
             for (auto& a : add[t]) { grow(docs, a.doc); grow(terms, a.term); }
         for (auto& c : after.children) grow(docs, c);
         const size_t n = docs.name.size(), T = terms.name.size();
+        struct ScorerGuard {
+            DeviceIndex& di;
+            ~ScorerGuard() {
+                if (di.scorer || !di.title || !di.body) return;
+                const size_t K = di.categories.size(), nd = di.docs.name.size();
+                if (ss_scorer_create(spaghetti::default_ctx(), di.title, di.body, &di.scorer) != SS_OK) { di.scorer = nullptr; return; }
+                if (K > 0 && K <= SS_MAX_TOPICS && di.flat.prior.size() == K * nd) (void)ss_scorer_set_prior(di.scorer, (int32_t)K, di.flat.prior.data());
+            }
+        } scorer_guard{*this};
+        bool resized = false;
+        auto shrink_ids = [&] {
+            if (resized) return;                                          // the device tables hold the new ids (as empty docs / terms)
+            for (size_t v = n_before; v < docs.name.size(); v++) docs.id.erase(docs.name[v]);
+            docs.name.resize(n_before);
+            for (size_t v = t_before; v < terms.name.size(); v++) terms.id.erase(terms.name[v]);
+            terms.name.resize(t_before);
+        };
         if (scorer) { ss_scorer_destroy(scorer); scorer = nullptr; }      // scorers on a table go before its delta
-        if (n != n_before || T != t_before) {
-            check(ss_index_resize(title, n, T), "ss_index_resize(title)");
-            check(ss_index_resize(body, n, T), "ss_index_resize(body)");
+        try {
+            if (n != n_before || T != t_before) {
+                check(ss_index_resize(title, n, T), "ss_index_resize(title)");
+                resized = true;
+                check(ss_index_resize(body, n, T), "ss_index_resize(body)");
+            }
+        } catch (...) {
+            if (resized) (void)ss_index_resize(body, n, T);               // title grew: body must follow or the ids diverge
+            shrink_ids();
+            throw;
+        }
+        // the PageRank table follows the doc space at once (the guard's scorer needs a table of the new size): new docs hold 0
+        // until the next PageRank run (ReloadPrior)
+        if (n != n_before && !categories.empty()) {
+            const size_t K = categories.size();
+            std::vector<double> grown(K * n, 0.0);
+            for (size_t k = 0; k < K; k++) std::copy(flat.prior.begin() + k * n_before, flat.prior.begin() + (k + 1) * n_before, grown.begin() + k * n);
+            flat.prior.swap(grown);
         }
         if (update_magnitudes && !mags_resident) {                        // once: squared magnitudes of the stored weights
             check(ss_index_refresh_magnitudes(title, nullptr), "ss_index_refresh_magnitudes(title)");
@@ -404,10 +420,36 @@ public:
                 add_pos_ptr.push_back(add_pos.size());
                 touched.push_back(kv.first.second);
             }
-            check(ss_index_apply_delta_pos(table[t], 0, nullptr, del_term.size(), del_term.data(), del_doc.data(), add_term.size(),
-                                           add_term.data(), add_doc.data(), add_w.data(), add_pos_ptr.data(), add_pos.data()),
-                  t == 0 ? "ss_index_apply_delta_pos(title)" : "ss_index_apply_delta_pos(body)");
+            const int32_t rc = ss_index_apply_delta_pos(table[t], 0, nullptr, del_term.size(), del_term.data(), del_doc.data(), add_term.size(),
+                                                        add_term.data(), add_doc.data(), add_w.data(), add_pos_ptr.data(), add_pos.data());
+            if (rc != SS_OK) {
+                flat_stale = true;
+                const std::string why = ss_last_error(default_ctx());
+                if (t == 0) { shrink_ids(); throw std::runtime_error("ss_index_apply_delta_pos(title): " + why + " (nothing changed)"); }
+                throw std::runtime_error("ss_index_apply_delta_pos(body): " + why + " — the resident title table already holds its delta and the tables do not: load() again");
+            }
         }
+        // --- tables (the device has taken both deltas) -----------------------------------------------------------------------------------------------------
+        for (int t = 0; t < 2; t++) {
+            std::map<std::string, std::map<std::string, std::vector<float>>> rows;   // the rows this delta touches
+            auto row_of = [&](const std::string& w) -> std::map<std::string, std::vector<float>>& {
+                auto it = rows.find(w);
+                if (it != rows.end()) return it->second;
+                auto& r = rows[w];
+                if (inv[t]->Has(ctx, w)) r = jsonmini::parse_map_f32list(inv[t]->Get(ctx, w));
+                return r;
+            };
+            for (auto& d : del[t]) row_of(d.first).erase(d.second);
+            for (auto& a : add[t]) row_of(a.term)[a.doc] = a.listPos;
+            auto bw = inv[t]->BatchWrite_init(ctx);
+            for (auto& r : rows) {
+                if (r.second.empty()) { if (inv[t]->Has(ctx, r.first)) inv[t]->Delete(ctx, r.first); }   // "delete this row" (:484-489)
+                else bw->BatchSet(ctx, r.first, jsonmini::dump(r.second));
+            }
+            bw->Flush(ctx);
+        }
+        forw[2]->Set(ctx, after.docHash, jsonmini::dump(after.children));
+
         std::sort(touched.begin(), touched.end());
         touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
         if (update_magnitudes && !touched.empty()) {
@@ -425,14 +467,8 @@ public:
             }
             bw->Flush(ctx);
         }
-        // the PageRank table follows the doc space: new docs hold 0 until the next PageRank run (ReloadPrior)
-        const size_t K = categories.size();
-        if (n != n_before && K) {
-            std::vector<double> grown(K * n, 0.0);
-            for (size_t k = 0; k < K; k++) std::copy(flat.prior.begin() + k * n_before, flat.prior.begin() + (k + 1) * n_before, grown.begin() + k * n);
-            flat.prior.swap(grown);
-        }
         flat_stale = true;
+        const size_t K = categories.size();
         check(ss_scorer_create(default_ctx(), title, body, &scorer), "ss_scorer_create");
         if (K > 0 && K <= SS_MAX_TOPICS) check(ss_scorer_set_prior(scorer, (int32_t)K, flat.prior.data()), "ss_scorer_set_prior");
     }
@@ -638,21 +674,37 @@ private:
             }
             std::vector<std::string> queries;
             for (auto& p : batch) queries.push_back(p.first);
+            // done[i]: caller i has its answer (a promise takes exactly one value or exception: a second set_* throws
+            // future_error, which inside a catch block would end the serving thread)
+            std::vector<char> done(batch.size(), 0);
             bool whole = true;
             try {
                 auto res = di_.RetrieveBatch(queries, k_);
-                for (size_t i = 0; i < batch.size(); i++) batch[i].second.set_value(std::move(res[i]));
+                if (res.size() != batch.size()) throw std::runtime_error("RetrieveBatch: result count differs from the batch");
+                for (size_t i = 0; i < batch.size(); i++) {
+                    batch[i].second.set_value(std::move(res[i]));
+                    done[i] = 1;
+                }
             } catch (...) {
                 whole = false;
             }
             // The library refuses a batch as a whole (e.g. one quoted phrase beyond SS_MAX_PHRASE_TERMS): answer the
-            // callers one by one, so that only the caller of the offending query gets the error.
+            // remaining callers one by one, so that only the caller of the offending query gets the error.
             if (!whole)
-                for (auto& p : batch) {
+                for (size_t i = 0; i < batch.size(); i++) {
+                    if (done[i]) continue;
+                    std::exception_ptr err;
                     try {
-                        p.second.set_value(std::move(di_.RetrieveBatch({p.first}, k_)[0]));
+                        auto one = di_.RetrieveBatch({batch[i].first}, k_);
+                        if (one.size() != 1) throw std::runtime_error("RetrieveBatch: no result for a single query");
+                        batch[i].second.set_value(std::move(one[0]));
+                        done[i] = 1;
                     } catch (...) {
-                        p.second.set_exception(std::current_exception());
+                        err = std::current_exception();
+                    }
+                    if (!done[i]) {
+                        try { batch[i].second.set_exception(err); } catch (...) {}   // promise already satisfied: nothing left to tell
+                        done[i] = 1;
                     }
                 }
             n_batches_++;

@@ -414,6 +414,56 @@ def test_recrawl_one_page_apply_delta(host, oracle, corpus):
     assert r.PageRank == 0.5 * row["Arts"] + 0.25 * row["Science"] + 0.25 * row["Sports"]
 
 
+def test_resident_pagerank_drops_a_page_nobody_links_to_any_more(host, oracle, corpus):
+    """the reference rebuilds its node set = parents U children from forw[2] on every run (pagerank.go:17-44) and
+    the node COUNT enters every rank (pagerank.go:111).  A child that only the re-crawled page linked to, and that is no
+    parent itself, must leave the resident graph when the link goes — not stay behind as an isolated node."""
+    forw, inv = make_tables(host, corpus)
+    doc = corpus["doc"]
+    children = dict(corpus["children"])
+    indeg = {}
+    for p, cs in children.items():
+        for c in cs:
+            indeg[c] = indeg.get(c, 0) + 1
+    page, lonely = next((p, c) for p, cs in sorted(children.items()) for c in cs if indeg[c] == 1 and c not in children)
+    pr = host.ResidentPagerank()
+    pr.Build(forw)
+    assert lonely in pr.name
+    cats = sorted(corpus["cats"])
+    n_topic = [int(corpus["cats"][c]["numPages"]) for c in cats]
+
+    def check_against_oracle(ch):
+        names, idx, ptr, dst = oracle_graph({"children": ch})
+        ref, _ = oracle.pagerank(len(names), ptr, dst, 0.75, 1e-9, n_topic)
+        assert sorted(pr.name) == names
+        for v, name in enumerate(names):
+            row = json.loads(forw[3].get(name))
+            for k, c in enumerate(cats):
+                assert row[c] == pytest.approx(ref[k, v], rel=1e-11)
+    # 1. the page drops its link to `lonely`: the node set shrinks, the resident graph is re-flattened
+    children[page] = [c for c in children[page] if c != lonely]
+    forw[2].set(page, json.dumps(children[page]))
+    pr.ApplyDelta(forw, [page])
+    assert pr.rebuilds == 1 and lonely not in pr.name
+    pr.Run(0.75, 1e-9, forw)
+    check_against_oracle(children)
+    # 2. a delta that orphans nobody is patched on the device (no rebuild), also when it brings a new page
+    newcomer = h("http://site/newcomer")
+    children[page] = children[page] + [newcomer, doc[3]]
+    forw[2].set(page, json.dumps(children[page]))
+    pr.ApplyDelta(forw, [page])
+    assert pr.rebuilds == 1 and newcomer in pr.name
+    pr.Run(0.75, 1e-9, forw)
+    check_against_oracle(children)
+    # 3. ... and the newcomer goes again with its only link
+    children[page] = [c for c in children[page] if c != newcomer]
+    forw[2].set(page, json.dumps(children[page]))
+    pr.ApplyDelta(forw, [page])
+    assert pr.rebuilds == 2 and newcomer not in pr.name
+    pr.Run(0.75, 1e-9, forw)
+    check_against_oracle(children)
+
+
 def test_opt_in_topic_sensitive_wiring(host, oracle, corpus):
     """SURVEY.md §8f-3 above the C ABI: OFF by default (reference-identical tables and answers), ON = teleport sets from the
     stored ODP keyword vectors (forw[5], inv[2]) for UpdateTopicSensitivePagerank and live computeTopicProbs for Retrieve."""

@@ -288,3 +288,105 @@ def test_refresh_magnitudes_bucketed_pass(ss_ctx):
             ix.close()
         ref = np.sqrt(np.bincount(pd, weights=(tf * tf).astype(np.float32).astype(np.float64), minlength=n_docs))
         assert np.array_equal(mag, ref)
+
+
+def oracle_order_magnitudes(pd, w, n_docs):
+    """sqrt of the float64 sum of float32 squares, summed in table (= ascending term) order like orc_tfidf / term_weighting.go:40-46"""
+    return np.sqrt(np.bincount(pd, weights=(w * w).astype(np.float32).astype(np.float64), minlength=n_docs))
+
+
+def test_delta_magnitudes_with_squares_forty_binary_orders_apart(ss_ctx, oracle):
+    """VERDICT r3 #1 / ADVICE r3: idf = log2(N/df) with N = the PageRank node count (term_weighting.go:13-17,37) can be 20 for one
+    word, 1e-5 for another and negative for a third.  A doc that holds all three has squares 40+ binary orders apart: a float64
+    sum of them is not exact, so a magnitude patched by "subtract what left" is wrong by far more than the 1e-6 gate (or negative
+    -> NaN) once the big posting is deleted.  The delta must give what a full pass over the updated table gives."""
+    from spaghettisearch_amd import engine
+    total = 1_000_007
+    n_docs = 1_100_000
+    rng = np.random.default_rng(5)
+    lists = [np.array([5], np.uint32),                                   # df 1        idf 19.93
+             np.arange(1_000_000, dtype=np.uint32),                      # df 1e6      idf 1.0e-5
+             np.arange(1_050_000, dtype=np.uint32),                      # df 1.05e6   idf -0.070  (df > N)
+             np.array([5, 7], np.uint32),                                # df 2        idf 18.93
+             np.array([3, 5, 9, 11], np.uint32)]                         # df 4        idf 17.93
+    tp = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.uint64)
+    pd = np.concatenate(lists)
+    tf = (rng.integers(1, 17, size=len(pd)) / np.float32(16)).astype(np.float32)
+    w_ref, mag_ref, idf_ref = oracle.tfidf(tp, pd, tf, total, n_docs)
+    assert idf_ref[0] > 19 and 0 < idf_ref[1] < 2e-5 and idf_ref[2] < 0
+    assert np.array_equal(oracle_order_magnitudes(pd, w_ref, n_docs), mag_ref)          # the helper IS the oracle's arithmetic
+    idx = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, tf)
+    try:
+        w, mag, _ = idx.tfidf_build(total)
+        assert np.array_equal(w, w_ref)
+        np.testing.assert_allclose(mag, mag_ref, rtol=1e-12)
+        sq5 = (w_ref[pd == 5].astype(np.float64)) ** 2
+        assert sq5.max() / sq5.min() > 2.0 ** 40
+        rows = rows_of(tp, pd, w_ref)
+        # delta 1: doc 5 loses its three large postings (single-pair deletes, the anchor-word path indexer.go:533-616), doc 7 its
+        # only large one, doc 9 EVERYTHING by pair deletes (magnitude must become exactly 0, not sqrt(-tiny)); doc 11 gains one
+        del_t = np.array([0, 3, 4, 3, 1, 2, 4, 4], np.uint32)
+        del_d = np.array([5, 5, 5, 7, 9, 9, 9, 1], np.uint32)            # the last pair does not exist: ignored
+        add = (np.array([0, 3], np.uint32), np.array([11, 11], np.uint32), np.array([25.0, 3e-7], np.float32))
+        idx.apply_delta(del_pairs=(del_t, del_d), add=add)
+        rows = apply_model(rows, np.zeros(0, np.uint32), (del_t, del_d), add)
+        tp2, pd2, w2 = csr_of(rows)
+        ref = oracle_order_magnitudes(pd2, w2, n_docs)
+        touched = np.array([5, 7, 9, 11, 1], np.uint32)
+        got = idx.read_magnitudes(touched)
+        assert np.all(np.isfinite(got)) and got[2] == 0.0
+        np.testing.assert_allclose(got, ref[touched], rtol=1e-12)
+        assert np.array_equal(got, ref[touched])                         # summed in the oracle's order: the same bits
+        # delta 2: the page of doc 11 is re-crawled (all its postings go, two come back), doc 5 gets a large posting again
+        add = (np.array([0, 1, 4], np.uint32), np.array([5, 11, 11], np.uint32), np.array([19.5, 2e-6, -0.3], np.float32))
+        idx.apply_delta(del_docs=np.array([11], np.uint32), add=add)
+        rows = apply_model(rows, np.array([11], np.uint32), (np.zeros(0, np.uint32),) * 2, add)
+        tp3, pd3, w3 = csr_of(rows)
+        g = idx.read()
+        assert np.array_equal(g[0], tp3) and np.array_equal(g[1], pd3) and np.array_equal(g[2], w3)
+        ref = oracle_order_magnitudes(pd3, w3, n_docs)
+        got = idx.read_magnitudes(touched)
+        assert np.array_equal(got, ref[touched])
+        # and a full pass over the table agrees with both (its summation order inside a doc is not the oracle's: 1e-12, not bits)
+        full = idx.refresh_magnitudes()
+        np.testing.assert_allclose(full, ref, rtol=1e-12)
+    finally:
+        idx.close()
+
+
+def test_delta_magnitudes_random_weights_over_many_orders(ss_ctx):
+    """random tables whose weights span 1e-7 .. 30 (and negatives), random deltas with docs emptied by pair deletes: the touched
+    docs' magnitudes equal the float64 sums over the updated table in term order, bit for bit; untouched docs are untouched"""
+    from spaghettisearch_amd import engine
+    rng = np.random.default_rng(77)
+    for n_docs, n_terms, n_post in ((300, 40, 4000), (20000, 3000, 400000)):
+        tp, pd, _ = synth.zipf_index(n_docs, n_terms, n_post, seed=n_docs)
+        w = (np.float32(10.0) ** rng.uniform(-7, 1.5, size=len(pd)).astype(np.float32) * rng.choice(np.array([1, 1, 1, -1], np.float32), size=len(pd))).astype(np.float32)
+        idx = engine.InvertedIndex(ss_ctx, n_docs, tp, pd, w)
+        try:
+            mag0 = idx.refresh_magnitudes()
+            rows = rows_of(tp, pd, w)
+            for _ in range(3):
+                cur = csr_of(rows)
+                changed, del_pairs, add = random_delta(rng, cur[0], cur[1], n_docs, n_terms, max(n_docs // 50, 2), n_post // 40, n_post // 30)
+                # empty two docs completely through pair deletes
+                term_of = np.repeat(np.arange(n_terms, dtype=np.uint32), np.diff(cur[0].astype(np.int64)))
+                victims = np.setdiff1d(rng.choice(n_docs, 4, replace=False).astype(np.uint32), changed)[:2]
+                sel = np.isin(cur[1], victims)
+                del_pairs = (np.concatenate([del_pairs[0], term_of[sel]]), np.concatenate([del_pairs[1], cur[1][sel]]))
+                add = (add[0], add[1], (add[2] * np.float32(10.0) ** rng.uniform(-6, 1.4, size=len(add[2])).astype(np.float32)).astype(np.float32))
+                idx.apply_delta(del_docs=changed, del_pairs=del_pairs, add=add)
+                rows = apply_model(rows, changed, del_pairs, add)
+                _, pd2, w2 = csr_of(rows)
+                ref = oracle_order_magnitudes(pd2, w2, n_docs)
+                touched = np.unique(np.concatenate([changed, del_pairs[1], add[1]])).astype(np.uint32)
+                got = idx.read_magnitudes(touched)
+                assert np.all(np.isfinite(got))
+                assert np.array_equal(got, ref[touched])
+                assert np.all(got[np.isin(touched, victims) & ~np.isin(touched, add[1])] == 0.0)
+                rest = np.setdiff1d(np.arange(n_docs, dtype=np.uint32), touched)
+                assert np.array_equal(idx.read_magnitudes(rest), mag0[rest])
+                mag0 = idx.refresh_magnitudes()
+                np.testing.assert_allclose(mag0, ref, rtol=1e-12)
+        finally:
+            idx.close()
