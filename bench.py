@@ -39,8 +39,47 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# the OpenMP baselines are sized to the GPU box's CPU share for one GPU
-os.environ.setdefault("OMP_NUM_THREADS", "16")
+
+
+def cpu_share():
+    """-> (threads for the OpenMP baselines, how that number came about).  SURVEY.md §8d B2 says "all host cores": all the
+    cores THIS PROCESS may use — its affinity mask, cut by a cgroup CPU quota when there is one (a GPU box hands a one-GPU job a
+    share of the host, not the host)."""
+    host = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = host
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = max(1, int(int(txt[0]) / int(txt[1])))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    quota = max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    n = min(aff, quota) if quota else aff
+    share = 16                                   # a one-GPU job's CPU share on the 8-GPU host (the pool's rule for worker pools)
+    capped = n > share
+    n = min(n, share)
+    if "OMP_NUM_THREADS" in os.environ:
+        n = int(os.environ["OMP_NUM_THREADS"])
+        how = f"OMP_NUM_THREADS={n} from the environment (host {host} cores, affinity {aff}, cgroup quota {quota})"
+    else:
+        how = (f"{n}: host {host} cores, affinity mask {aff}, cgroup CPU quota {quota if quota else 'none'}" +
+               (f", capped at the {share}-core CPU share of a one-GPU job on this host (set OMP_NUM_THREADS to override)" if capped else
+                " - every core this process may use"))
+    return n, how
+
+
+OMP_THREADS, OMP_HOW = cpu_share()
+os.environ["OMP_NUM_THREADS"] = str(OMP_THREADS)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 N_BLOCKS = 5            # timed blocks of --steps per measurement: the first is `value`, all give min/median
@@ -474,7 +513,7 @@ def main() -> None:
                 odt = time.perf_counter() - t0
                 result["cpu_baseline"]["strong_cpu"] = {
                     "value": it_omp / odt, "unit": "topic-iterations/s", "cores": th,
-                    "sample": "10 iterations (incl. building the in-edge lists), flat arrays, OpenMP pull SpMV, oracle/oracle.c:orc_pagerank_topic_omp"}
+                    "sample": f"10 iterations (incl. building the in-edge lists), flat arrays, OpenMP pull SpMV, oracle/oracle.c:orc_pagerank_topic_omp; threads = {OMP_HOW}"}
                 # the same end-to-end calls on the CPU, extrapolated from the measured per-iteration costs (the reference runs
                 # the topics one after the other, pagerank.go:54-63, so its iterations add up)
                 for key_, rec_ in result.get("pagerank_end_to_end", {}).get("config4", {}).items():
@@ -797,7 +836,7 @@ def main() -> None:
                 _, _, th = pyoracle.score_topk_batch(nd, title, body, mt, mb, q_ptr, q_terms, k, omp=True)
                 odt = time.perf_counter() - t0
                 topk["cpu_baseline"]["strong_cpu"] = {"value": nq / odt, "unit": "queries/s", "cores": th,
-                                                      "sample": f"all {nq} queries, one query per thread, oracle/oracle.c:orc_score_topk_batch_omp"}
+                                                      "sample": f"all {nq} queries, one query per thread, oracle/oracle.c:orc_score_topk_batch_omp; threads = {OMP_HOW}"}
                 same = all(hits["doc"][q, :n_hits[q]].tolist() == ref["doc"][q, :ref_n[q]].tolist() for q in range(ns))
                 same &= all(np.array_equal(hits["final"][q, :n_hits[q]], ref["final"][q, :ref_n[q]]) for q in range(ns))
                 topk["cpu_baseline"]["gpu_matches_oracle"] = bool(same)

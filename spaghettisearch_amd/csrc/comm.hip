@@ -14,6 +14,12 @@
 
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <thread>
+
 static_assert(SS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ss_comm_unique_id hands out an ncclUniqueId");
 
 namespace ss {
@@ -38,6 +44,39 @@ int32_t comm_allreduce_f64_on(ss_ctx* ctx, const double* send, double* recv, siz
     SS_NCCL(ctx, ncclAllReduce(send, recv, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(ctx->comm), st));
     return SS_OK;
 }
+// ---- bounded waits --------------------------------------------------------------------------------------------------------
+// A collective that a rank never joins, or that runs over a dead link, never completes: the stream behind it never drains and a
+// plain hipStreamSynchronize turns a rendezvous mistake into a hang that only a watchdog ends.  Wherever the library itself waits
+// for a stream that may carry a collective it polls instead, for at most "comm.timeout_ms" (default 120 s), and then fails with
+// SS_ERR_COMM.  After such a time-out the device still holds the stuck work: `g_wedged` makes the memory pool and the sharded
+// loop's clean-up skip their device-wide waits (they would hang in turn), so that the error reaches the caller, who can report it
+// and end the process.
+static std::atomic<bool> g_wedged{false};
+bool device_wedged() { return g_wedged.load(std::memory_order_relaxed); }
+
+int32_t sync_bounded(ss_ctx* ctx, hipStream_t st, const char* what) {
+    if (!ctx->comm) {                                        // nothing on this context can wait for another rank
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        return SS_OK;
+    }
+    const int64_t timeout_ms = ctx->opt("comm.timeout_ms", 120000);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return SS_OK;
+        (void)hipGetLastError();
+        if (e != hipErrorNotReady) return ctx->fail(SS_ERR_HIP, "%s: hipStreamQuery -> %s", what, hipGetErrorString(e));
+        if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));     // the first milliseconds: spin
+        if ((spins & 255) == 255 &&
+            std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) {
+            g_wedged.store(true);
+            return ctx->fail(SS_ERR_COMM, "%s: rank %d of %d: the stream did not drain within %lld ms with a collective on it — a rank never "
+                             "joined the collective or a link is down; this context cannot be used any more", what, ctx->comm_rank, ctx->comm_world,
+                             (long long)timeout_ms);
+        }
+    }
+}
+
 int32_t comm_allgather(ss_ctx* ctx, const void* send, void* recv, size_t bytes) { return comm_allgather_on(ctx, send, recv, bytes, ctx->stream); }
 int32_t comm_allreduce_f64(ss_ctx* ctx, const double* send, double* recv, size_t count) { return comm_allreduce_f64_on(ctx, send, recv, count, ctx->stream); }
 
@@ -65,8 +104,49 @@ int32_t ss_comm_init(ss_ctx* ctx, const void* id, int32_t rank, int32_t world) {
     SS_HIP(ctx, hipSetDevice(ctx->device));
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
-    ncclComm_t comm = nullptr;
-    SS_NCCL(ctx, ncclCommInitRank(&comm, world, uid, rank));      // blocks until every rank has joined
+    // ncclCommInitRank blocks until every rank has joined, with no time-out of its own: a rank that never arrives (wrong id,
+    // wrong rank/world, a crashed peer, an unreachable bootstrap address) would hang every other rank for good.  The call runs
+    // on a helper thread and this thread waits for it for at most "comm.timeout_ms" (default 120 s); after that the caller gets
+    // SS_ERR_COMM and the helper is left behind (it owns everything it touches; should it ever finish, it aborts the
+    // communicator nobody is waiting for).  The blocking call itself is RCCL's ordinary, most travelled initialisation path —
+    // the non-blocking configuration (ncclCommInitRankConfig + ncclCommGetAsyncError) would also turn every later collective
+    // into a poll loop.
+    struct Job {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false, abandoned = false;
+        ncclResult_t r = ncclSuccess;
+        ncclComm_t comm = nullptr;
+    };
+    auto job = std::make_shared<Job>();
+    const int device = ctx->device;
+    std::thread([job, uid, rank, world, device] {
+        (void)hipSetDevice(device);
+        ncclComm_t c = nullptr;
+        const ncclResult_t r = ncclCommInitRank(&c, world, uid, rank);
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (job->abandoned) {
+            lk.unlock();
+            if (r == ncclSuccess && c) (void)ncclCommAbort(c);
+            return;
+        }
+        job->r = r;
+        job->comm = c;
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    const int64_t timeout_ms = ctx->opt("comm.timeout_ms", 120000);
+    {
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) {
+            job->abandoned = true;
+            return ctx->fail(SS_ERR_COMM, "ss_comm_init: rank %d of %d: the other ranks did not join within %lld ms (every rank needs rank 0's id, "
+                             "its own rank, the same world size, and a reachable bootstrap address; multi-process GPU work on this host also "
+                             "needs HSA_ENABLE_IPC_MODE_LEGACY=0)", rank, world, (long long)timeout_ms);
+        }
+    }
+    if (job->r != ncclSuccess) return ss::comm_fail(ctx, "ncclCommInitRank", job->r);
+    ncclComm_t comm = job->comm;
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
@@ -100,11 +180,14 @@ int32_t ss_comm_destroy(ss_ctx* ctx) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ctx->comm) return SS_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->comm_stream);
-    ncclResult_t r = ncclCommDestroy(static_cast<ncclComm_t>(ctx->comm));
+    const bool wedged = ss::device_wedged();                 // a collective timed out: nothing on the streams will ever finish
+    if (!wedged) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->comm_stream);
+    }
+    ncclResult_t r = wedged ? ncclCommAbort(static_cast<ncclComm_t>(ctx->comm)) : ncclCommDestroy(static_cast<ncclComm_t>(ctx->comm));
     if (ctx->comm_parent) {
-        const ncclResult_t r2 = ncclCommDestroy(static_cast<ncclComm_t>(ctx->comm_parent));
+        const ncclResult_t r2 = wedged ? ncclCommAbort(static_cast<ncclComm_t>(ctx->comm_parent)) : ncclCommDestroy(static_cast<ncclComm_t>(ctx->comm_parent));
         if (r == ncclSuccess) r = r2;
         ctx->comm_parent = nullptr;
     }
@@ -138,7 +221,7 @@ int32_t ss_comm_allreduce_u64(ss_ctx* ctx, uint64_t* buf, uint64_t n) {
     SS_HIP(ctx, hipMemcpyAsync(tmp.p, buf, n * sizeof(uint64_t), hipMemcpyDefault, ctx->stream));
     SS_NCCL(ctx, ncclAllReduce(tmp.p, tmp.p, n, ncclUint64, ncclSum, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
     SS_HIP(ctx, hipMemcpyAsync(buf, tmp.p, n * sizeof(uint64_t), hipMemcpyDefault, ctx->stream));
-    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SS_TRY(ss::sync_bounded(ctx, ctx->stream, "ss_comm_allreduce_u64"));
     return SS_OK;
 }
 
@@ -164,7 +247,7 @@ int32_t ss_comm_allgather(ss_ctx* ctx, const void* send, void* recv, uint64_t by
     SS_HIP(ctx, hipMemcpyAsync(ds.p, send, bytes_per_rank, hipMemcpyDefault, ctx->stream));
     SS_TRY(ss::comm_allgather(ctx, ds.p, dr.p, bytes_per_rank));
     SS_HIP(ctx, hipMemcpyAsync(recv, dr.p, bytes_per_rank * (size_t)ctx->comm_world, hipMemcpyDefault, ctx->stream));
-    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SS_TRY(ss::sync_bounded(ctx, ctx->stream, "ss_comm_allgather"));
     return SS_OK;
 }
 

@@ -212,6 +212,10 @@ inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) /
 // comm.hip: collectives on the context's stream (enqueue only); SS_ERR_STATE without a communicator
 int32_t comm_allgather(ss_ctx* ctx, const void* send, void* recv, size_t bytes);
 int32_t comm_allreduce_f64(ss_ctx* ctx, const double* send, double* recv, size_t count);
+// wait for a stream that may carry a collective: bounded by option "comm.timeout_ms" when the context has a communicator
+// (SS_ERR_COMM instead of a hang), a plain hipStreamSynchronize otherwise; device_wedged(): such a wait has timed out
+int32_t sync_bounded(ss_ctx* ctx, hipStream_t st, const char* what);
+bool device_wedged();
 // the same on a given stream (the pipelined sharded sweep puts its exchanges on ctx->comm_stream)
 int32_t comm_allgather_on(ss_ctx* ctx, const void* send, void* recv, size_t bytes, hipStream_t st);
 int32_t comm_allreduce_f64_on(ss_ctx* ctx, const double* send, double* recv, size_t count, hipStream_t st);

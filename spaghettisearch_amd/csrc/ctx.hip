@@ -80,6 +80,7 @@ void pool_free(void* p) {
     }
     // hipFree waits for the device before the memory goes; the pool keeps that guarantee (work of ANY stream that still uses
     // the block is over before somebody else can get it) and saves the unmap / map that follows.
+    if (device_wedged()) return;                           // a collective timed out: any device-wide wait would hang; the process is on its way out
     if (cls && cls <= limit / 2) {                         // a block larger than half the limit is not worth holding
         int cur = 0;
         (void)hipGetDevice(&cur);
@@ -260,6 +261,7 @@ int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream) {
 
 // Every option a call site reads; ss_set_option refuses anything else, so a typo cannot silently do nothing.
 static const char* const k_option_names[] = {
+    "comm.timeout_ms",      // longest wait for the other ranks: ss_comm_init, and every wait of the library for a stream that carries a collective (default 120000)
     "pr.force_narrow",      // 1: K <= 2 always runs the block-item kernel k_pr_step (tests reach it on small graphs)
     "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
@@ -307,7 +309,7 @@ int32_t ss_synchronize(ss_ctx* ctx) {
     if (!ctx) return SS_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SS_HIP(ctx, hipSetDevice(ctx->device));
-    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SS_TRY(ss::sync_bounded(ctx, ctx->stream, "ss_synchronize"));
     if (ctx->merge_stream) SS_HIP(ctx, hipStreamSynchronize(ctx->merge_stream));      // "score.pipeline": the last batches' merges
     return SS_OK;
 }

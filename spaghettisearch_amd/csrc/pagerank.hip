@@ -1453,8 +1453,10 @@ int32_t ss_pr_destroy(ss_pr* pr) {
     ss_ctx* ctx = pr->g->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->comm_stream);
+    if (!ss::device_wedged()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->comm_stream);
+    }
     pr->g->users--;
     delete pr;
     return SS_OK;
@@ -1569,8 +1571,10 @@ int32_t run_pipelined(ss_ctx* ctx, std::vector<ShardBlocks>& sh, int32_t max_ite
         SS_HIP(ctx, hipEventCreateWithFlags(&ev_xchg[b], hipEventDisableTiming));
     }
     auto cleanup = [&] {
-        (void)hipStreamSynchronize(xs);
-        (void)hipStreamSynchronize(cs);
+        if (!ss::device_wedged()) {                       // (after a timed-out collective neither stream will ever drain)
+            (void)hipStreamSynchronize(xs);
+            (void)hipStreamSynchronize(cs);
+        }
         for (int b = 0; b < B; b++) { (void)hipEventDestroy(ev_step[b]); (void)hipEventDestroy(ev_xchg[b]); }
     };
     int32_t rc = SS_OK;
@@ -1618,8 +1622,8 @@ int32_t run_pipelined(ss_ctx* ctx, std::vector<ShardBlocks>& sh, int32_t max_ite
         for (int b = 0; b < B && rc == SS_OK; b++) {
             ctx->pin_used = 0;
             PrCtl* const hp = ctx->pin<PrCtl>();
-            if (hipMemcpyAsync(hp, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess ||
-                hipStreamSynchronize(cs) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: status read failed"); break; }
+            if (hipMemcpyAsync(hp, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: status read failed"); break; }
+            if ((rc = ss::sync_bounded(ctx, cs, "sharded sweep (waiting for the exchange)")) != SS_OK) break;
             n_active += hp->n_active;
         }
         if (n_active == 0) break;
@@ -1636,8 +1640,8 @@ int32_t run_pipelined(ss_ctx* ctx, std::vector<ShardBlocks>& sh, int32_t max_ite
         for (int b = 0; b < B && rc == SS_OK; b++) {
             ctx->pin_used = 0;
             PrCtl* const hp = ctx->pin<PrCtl>();
-            if (hipMemcpyAsync(hp, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess ||
-                hipStreamSynchronize(cs) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: status read failed"); break; }
+            if (hipMemcpyAsync(hp, sh[0].blk[b]->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, cs) != hipSuccess) { rc = ctx->fail(SS_ERR_HIP, "sharded sweep: status read failed"); break; }
+            if ((rc = ss::sync_bounded(ctx, cs, "sharded sweep (last exchange)")) != SS_OK) break;
             for (int k = 0; k < sh[0].blk[b]->k; k++) iters_out[blk_k0[b] + k] = hp->iters[k];
         }
     }
@@ -1767,7 +1771,7 @@ int32_t ss_pr_status(ss_pr* pr, int32_t* iters_out, int32_t* n_active, int32_t* 
     ctx->pin_used = 0;
     PrCtl* const hp = ctx->pin<PrCtl>();               // pinned: a read-back into pageable memory pins the page per call (ss_ctx::h_pin)
     SS_HIP(ctx, hipMemcpyAsync(hp, pr->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, ctx->stream));
-    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SS_TRY(ss::sync_bounded(ctx, ctx->stream, "ss_pr_status"));
     const PrCtl h = *hp;
     for (int k = 0; k < pr->k; k++) {
         if (iters_out) iters_out[k] = h.iters[k];

@@ -94,3 +94,55 @@ def test_exchange_state_machine(ctx1):
     assert ei.value.code == 6 and "does not match" in str(ei.value)
     st.close()
     g2.close()
+
+
+_TIMEOUT_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+from spaghettisearch_amd import SpaghettiError, engine, synth
+ctx = engine.Context(0)
+ctx.set_option("comm.timeout_ms", 1500)
+# 1. a rank that waits for a peer which never comes: SS_ERR_COMM after the bound, not a hang
+t0 = time.time()
+try:
+    ctx.comm_init(engine.Context.comm_unique_id(), 0, 2)
+    print("FAIL: init of rank 0 of 2 returned without rank 1"); os._exit(1)
+except SpaghettiError as e:
+    dt = time.time() - t0
+    assert e.code == 8 and "did not join" in str(e), (e.code, str(e))
+    assert 1.0 < dt < 30.0, dt
+assert ctx.comm_info() == (-1, 0)
+# 2. the context is still usable: a world of one joins at once ...
+ctx.comm_init(engine.Context.comm_unique_id(), 0, 1)
+assert ctx.comm_info() == (0, 1)
+# 3. ... and a wait for a stream that does not drain in time (here: a long queue of sweeps, standing in for a collective that a
+#    rank never joined) ends with SS_ERR_COMM as well
+n, e = 2_000_000, 10_000_000
+ptr, dst = synth.rmat_graph_torch(n, e, seed=3)
+g = engine.Graph(ctx, n, ptr, dst)
+st = engine.PageRankState(g, 0.75, -1.0, synth.topic_sizes(n, 16), max_iter=1 << 30)
+st.begin()
+ctx.set_option("comm.timeout_ms", 20)
+st.step(4000)                      # enqueue only: seconds of work
+t0 = time.time()
+try:
+    ctx.synchronize()
+    print("FAIL: synchronize returned"); os._exit(1)
+except SpaghettiError as e:
+    assert e.code == 8 and "did not drain" in str(e), (e.code, str(e))
+    assert time.time() - t0 < 5.0
+print("TIMEOUT_PATHS_OK")
+sys.stdout.flush()
+os._exit(0)                         # the helper thread of step 1 is still waiting for rank 1, the device still busy: leave at once
+"""
+
+
+def test_rendezvous_and_collective_waits_are_bounded():
+    """VERDICT r3 #6a: ss_comm_init and the library's waits behind a collective end with SS_ERR_COMM after "comm.timeout_ms".
+    In a process of its own: the abandoned rendezvous thread and the busy device must not outlive into the test session."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TIMEOUT_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TIMEOUT_PATHS_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
