@@ -649,23 +649,25 @@ def main() -> None:
                 sc.score_topk(d_qptr, d_qterms, k, out=(d_hits, d_nhits))
                 kms.append(ctx.last_kernel_ms(1))
             kern_ms = sum(kms) / len(kms)
-            # option "score.pipeline" (off by default, NOT the headline): a batch's merge runs on a third stream under the next
-            # batch's k_score_wave; the hits are complete after ss_synchronize instead of in stream order.  Same batches, same check.
+            # option "score.pipeline" = 0 for comparison: every scoring kernel on the one stream (round 3's default).  Same batches,
+            # same hits.  [The default since round 4 keeps the stream-order contract: the merge — the kernel that writes the hits —
+            # stays on the caller's stream, k_score_wave moves to an internal one.]
             pipelined = None
             if world == 1:
                 ctx.synchronize(); torch.cuda.synchronize()
                 ref_h, ref_n = d_hits.clone(), d_nhits.clone()
                 ctx.set_option("score.timing", 0)
-                ctx.set_option("score.pipeline", 1)
+                ctx.set_option("score.pipeline", 0)
                 dtp, blocks_p = timed_blocks(batches)
                 ctx.synchronize(); torch.cuda.synchronize()
                 same_p = bool(torch.equal(ref_h, d_hits) and torch.equal(ref_n, d_nhits))
                 ctx.set_option("score.pipeline", None)
                 ctx.set_option("score.timing", None)
                 pipelined = {"value": nq * K / dtp, "unit": "queries/s", "ms_per_step": dtp * 1e3 / K, "ms_per_step_blocks": summarize(blocks_p),
-                             "hits_equal_unpipelined": same_p,
-                             "what": "option score.pipeline=1: k_merge_flat of batch i on the context's merge stream under k_score_wave of "
-                                     "batch i+1; hits complete after ss_synchronize (not in stream order) — opt-in, not the headline"}
+                             "hits_equal_default": same_p,
+                             "what": "option score.pipeline=0: k_wave_prep, k_score_wave and k_merge_flat of a batch all on the caller's stream, "
+                                     "one batch after the other (the default runs k_score_wave of batch i+1 on an internal stream under k_merge_flat of batch i)"}
+                assert same_p
                 del ref_h, ref_n
             t0 = time.perf_counter()
             for _ in range(K):
@@ -704,7 +706,7 @@ def main() -> None:
                     "tfidf_build_ms": tfidf_ms, "scorer_create_ms": scorer_create_ms,
                     "queries_per_sec_host_in_host_out": nq * K / dt_pcie}
             if pipelined is not None:
-                topk["pipelined_option"] = pipelined
+                topk["one_stream_option"] = pipelined
 
             # ---- one query through the ABI, host in / host out (the reference's call shape: one Retrieve per request,
             #      k = 50, main_retrieve.go:99-100)

@@ -26,7 +26,11 @@ struct ss_ctx {
     hipStream_t stream = nullptr;      // stream all work is enqueued on
     hipStream_t own_stream = nullptr;  // created by ss_init
     hipStream_t comm_stream = nullptr; // the exchange steps of the sharded sweep run here, beside the sweeps on `stream`
-    hipStream_t merge_stream = nullptr; // option "score.pipeline": k_merge_flat of a batch runs here, under the next batch's k_score_wave
+    static constexpr int N_WAVE_STREAMS = 3;
+    hipStream_t wave_stream[N_WAVE_STREAMS] = {};   // option "score.pipeline" (default on): k_wave_prep + k_score_wave of a batch run here; the batch's k_merge_flat
+                                        // follows on `stream` behind an event, so the NEXT batch's k_score_wave starts under it and the hits are still
+                                        // complete in the order of `stream`.  Consecutive batches take different wave streams: batch i+1's
+                                        // k_score_wave then also fills the slots that batch i's tail leaves idle.
     std::recursive_mutex mu;           // serialises calls on this ctx
     std::string last_error;
     // timing hook (ss_last_kernel_ms): [kind][0]=start, [1]=stop

@@ -242,7 +242,8 @@ int32_t ss_shutdown(ss_ctx* ctx) {
         for (int j = 0; j < 2; j++)
             if (ctx->ev[k][j]) (void)hipEventDestroy(ctx->ev[k][j]);
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
-    if (ctx->merge_stream) { (void)hipStreamSynchronize(ctx->merge_stream); (void)hipStreamDestroy(ctx->merge_stream); }
+    for (hipStream_t ws : ctx->wave_stream)
+        if (ws) { (void)hipStreamSynchronize(ws); (void)hipStreamDestroy(ws); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (auto& b : ctx->pin_cache) (void)hipHostFree(b.p);
@@ -283,8 +284,9 @@ static const char* const k_option_names[] = {
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
     "score.wave_big_pct",   // graded slices: this share of a batch's postings goes into slices of wave_big_x100 % of the target, the rest into wave_small_x100 % (defaults 85 / 115 / 40; 0 = one size)
     "score.wave_big_x100",
-    "score.pipeline",       // 1: device-output batches of k_score_wave are pipelined: a batch's k_merge_flat runs on a third stream under the next batch's
-                            //    k_score_wave; its hits are complete after ss_synchronize (or two calls later), NOT when the call's stream work is done (default 0)
+    "score.pipeline",       // 0: every scoring kernel on the context's stream.  Default 1: device-output batches that are all k_score_wave run k_wave_prep and
+                            //    k_score_wave on an internal stream and only k_merge_flat (behind an event) on the context's stream: the next batch's
+                            //    k_score_wave starts under this batch's merge, and the hits are complete in stream order as before
     "score.grade_slices",   // 1: k_score_slices' slices are graded the same way (default 0)
     "score.wave_small_x100",
     "score.exact_all",      // 1: switch the upper-bound filter off (every record takes the exact stage)
@@ -309,8 +311,7 @@ int32_t ss_synchronize(ss_ctx* ctx) {
     if (!ctx) return SS_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SS_HIP(ctx, hipSetDevice(ctx->device));
-    SS_TRY(ss::sync_bounded(ctx, ctx->stream, "ss_synchronize"));
-    if (ctx->merge_stream) SS_HIP(ctx, hipStreamSynchronize(ctx->merge_stream));      // "score.pipeline": the last batches' merges
+    SS_TRY(ss::sync_bounded(ctx, ctx->stream, "ss_synchronize"));       // (the wave stream's kernels are all in front of a merge on this stream)
     return SS_OK;
 }
 

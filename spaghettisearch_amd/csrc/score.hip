@@ -1391,7 +1391,11 @@ struct ss_scorer {
     // Turns of per-batch buffers: the host runs at most TURNS batches ahead.  (Three were measured for the pipelined mode, so that a
     // batch's plan upload and k_wave_prep — which do not fit beside k_score_wave's three waves of 168 VGPRs per SIMD — are enqueued
     // one batch earlier: 0.395 against 0.399 ms per batch, not worth a third set of buffers.)
-    static constexpr int TURNS = 2;
+#ifndef SS_TURNS
+#define SS_TURNS 3
+#endif
+    static constexpr int TURNS = SS_TURNS;
+    unsigned wave_turn = 0;                    // which wave stream the next pipelined batch takes
     ss::DevBuf<unsigned char> d_plan2[TURNS], d_wprep2[TURNS];   // the plan on the device, one buffer per turn: batch i+1's upload runs beside batch i's kernels
     // pinned staging for the plan, double-buffered: a call that returns results in device memory does not wait
     // for the GPU, so the next call plans (and fills the other buffer) while this one's copy and kernels run
@@ -1408,8 +1412,7 @@ struct ss_scorer {
     ss::DevBuf<uint32_t> d_xcnt, d_pcnt;
     ss::DevBuf<uint64_t> d_so_key2[TURNS];           // the slices' candidates, one set per turn ("score.pipeline": batch i's merge reads its set while batch i+1 fills the other)
     ss::DevBuf<uint32_t> d_so_doc2[TURNS], d_so_cnt, d_qticket, d_qcnt2[TURNS];
-    hipEvent_t wave_ev[TURNS] = {};  // "score.pipeline": behind k_score_wave on the caller's stream; the merge stream waits for it
-    bool merge_pending = false;                 // a merge may still be running on the context's merge stream
+    hipEvent_t wave_ev[TURNS] = {};  // "score.pipeline": behind k_score_wave on the context's wave stream; the merge on the caller's stream waits for it
     size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
     ss::DevBuf<ss_hit> d_hits;
     ss::DevBuf<int32_t> d_nhits;
@@ -1517,7 +1520,8 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->merge_stream) (void)hipStreamSynchronize(ctx->merge_stream);
+    for (hipStream_t ws : ctx->wave_stream)
+        if (ws) (void)hipStreamSynchronize(ws);
 #if defined(SSW_PHASES) && !defined(SS_DIAG)
     ss::score_wave_diag_dump();
 #endif
@@ -1554,8 +1558,7 @@ int32_t ss_scorer_set_prior(ss_scorer* s, int32_t k_topics, const double* rank) 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SS_HIP(ctx, hipSetDevice(ctx->device));
     if (k_topics < 0 || k_topics > SS_MAX_TOPICS) return ctx->fail(SS_ERR_INVALID, "ss_scorer_set_prior: bad k_topics");
-    if (ctx->merge_stream) SS_HIP(ctx, hipStreamSynchronize(ctx->merge_stream));   // a pipelined merge may still read the prior
-    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (every k_score_wave on the wave stream has a merge behind it on this one)
     if (k_topics == 0 || !rank) {
         s->prior.release();
         s->k_topics = 0;
@@ -1987,6 +1990,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_mergeq.empty() && s->qcnt_zeroed2[pb] < (size_t)n_q) {    // k_merge_flat hands every counter back at zero
         SS_HIP(ctx, ensure(s->d_qcnt2[pb], (size_t)n_q));
         SS_HIP(ctx, hipMemsetAsync(s->d_qcnt2[pb].p, 0, s->d_qcnt2[pb].bytes(), st));
+        SS_HIP(ctx, hipStreamSynchronize(st));                        // (first use or growth only) k_score_wave may run on another stream
         s->qcnt_zeroed2[pb] = s->d_qcnt2[pb].n;
     }
     SS_HIP(ctx, ensure(s->d_hits, (size_t)n_q * k));
@@ -2035,6 +2039,14 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.hits = dev_out ? hits_out : s->d_hits.p;
     p.n_hits = dev_out ? n_hits_out : s->d_nhits.p;
 
+    // "score.pipeline" (default): a batch that is all k_score_wave, results in device memory.  Its k_wave_prep and k_score_wave go
+    // to the context's WAVE stream, its k_merge_flat to the caller's stream behind an event: the next batch's k_score_wave (which
+    // needs nothing the caller's stream produces — queries arrive in host memory, the index is immutable while a scorer holds it,
+    // candidate lists and counters exist once per turn) starts under this batch's merge, and since the merge — the kernel that
+    // writes the hits — sits on the caller's stream, the results are complete in stream order like before.  [Round 3 had it the
+    // other way round (merge on a side stream that the caller's stream did not wait for): faster by the same amount, but the hits
+    // were only complete after ss_synchronize.]
+    const bool pipe = dev_out && n_fast_slices == n_slices && !h_mergeq.empty() && !any_phrase && ctx->opt("score.pipeline", 2) != 0;
     // The upload goes out on the context's SECOND stream as soon as the plan is staged — beside the kernels of the previous
     // batch, which read the other device buffer.  (On the one stream the copy sat
     // between two batches: 39 us per batch in the kernel trace with the counter memset, 6 % of the wall time at config 3.)
@@ -2046,24 +2058,18 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, st));
     } else {
         SS_HIP(ctx, hipMemcpyAsync(s->d_plan2[pb].p, hp, plan_bytes, hipMemcpyHostToDevice, ctx->comm_stream));
-        // k_wave_prep reads the plan and the index, nothing of an earlier batch: it follows the copy on the second stream and so
-        // runs beside the previous batch's kernels too (12 us of kernel and one launch gap per batch off the caller's stream)
-        if (n_fast_slices) {
+        // k_wave_prep reads the plan and the index, nothing of an earlier batch.  Unpipelined it follows the copy on the second
+        // stream and so runs beside the previous batch's kernels (12 us of kernel and one launch gap per batch off the caller's
+        // stream); pipelined it is enqueued on the wave stream in front of its k_score_wave (it finds no room beside the previous
+        // batch's k_score_wave anyway: 3 x 168 VGPRs per SIMD).
+        if (n_fast_slices && !pipe) {
             ss::launch_wave_prep(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, ctx->comm_stream);
             prep_done = true;
         }
-        // ... and the HOST waits for both (~30 us; it has 0.4 ms to spare per batch): the kernels then go out on the caller's stream
-        // with no cross-stream dependency in front of them (a hipStreamWaitEvent there left 21 us between two batches, and two of
+        // ... and the HOST waits for the second stream (~30 us; it has 0.4 ms to spare per batch): the kernels then go out with no
+        // cross-stream dependency in front of them (a hipStreamWaitEvent there left 21 us between two batches, and two of
         // them per batch ran the runtime out of signals every ~80 batches: an 8 ms stall)
         SS_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
-    }
-    // "score.pipeline": a batch that is all k_score_wave, results in device memory: its k_merge_flat goes to the context's merge stream
-    // behind an event and the caller's stream does not wait for it — the next batch's k_score_wave starts under it.  The hits are
-    // complete after ss_synchronize (and before the call after next returns).  Any other call first waits for the merges still out.
-    const bool pipe = dev_out && n_fast_slices == n_slices && !h_mergeq.empty() && !any_phrase && ctx->opt("score.pipeline", 0) != 0;
-    if (!pipe && s->merge_pending) {
-        SS_HIP(ctx, hipStreamSynchronize(ctx->merge_stream));
-        s->merge_pending = false;
     }
     const auto th4 = t_now();
     const size_t lds_score = score_lds_bytes(cb), lds_merge = merge_lds_bytes(k, cb);
@@ -2079,9 +2085,17 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, st, p);
         hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
     }
+    hipStream_t wst = st;                        // where k_wave_prep / k_score_wave go
+    if (pipe) {
+        const int n_ws = (int)std::min<int64_t>(ss_ctx::N_WAVE_STREAMS, std::max<int64_t>(1, ctx->opt("score.pipeline", 2)));
+        const int wi = (int)(s->wave_turn++ % (unsigned)n_ws);
+        if (!ctx->wave_stream[wi]) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->wave_stream[wi], hipStreamNonBlocking));
+        if (!s->wave_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->wave_ev[pb], hipEventDisableTiming));
+        wst = ctx->wave_stream[wi];
+    }
     if (n_fast_slices) {
-        if (!prep_done) ss::launch_wave_prep(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, st);
-        ss::launch_score_wave(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, st);
+        if (!prep_done) ss::launch_wave_prep(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, wst);
+        ss::launch_score_wave(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, wst);
     }
     if (n_slices > n_fast_slices) {
         ScoreParams ps = p;
@@ -2089,30 +2103,21 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         hipLaunchKernelGGL(k_score_slices, dim3((unsigned)(n_slices - n_fast_slices)), dim3(TPB), lds_score, st, ps);
     }
     if (!fused && n_slices > n_fast_slices) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
-    hipStream_t mst = st;
-    if (pipe) {
-        if (!ctx->merge_stream) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->merge_stream, hipStreamNonBlocking));
-        if (!s->wave_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->wave_ev[pb], hipEventDisableTiming));
-        SS_HIP(ctx, hipEventRecord(s->wave_ev[pb], st));
-        SS_HIP(ctx, hipStreamWaitEvent(ctx->merge_stream, s->wave_ev[pb], 0));
-        mst = ctx->merge_stream;
-        s->merge_pending = true;
+    if (pipe) {                                  // the merge, on the caller's stream, behind this batch's k_score_wave
+        SS_HIP(ctx, hipEventRecord(s->wave_ev[pb], wst));
+        SS_HIP(ctx, hipStreamWaitEvent(st, s->wave_ev[pb], 0));
     }
-    if (timed && pipe) {                         // ss_last_kernel_ms(1) then covers the kernels on the caller's stream only
+    if (!h_mergeq.empty()) hipLaunchKernelGGL(k_merge_flat, dim3((unsigned)h_mergeq.size()), dim3(TPB_MF), merge_lds_bytes(k, cb_flat), st, p);
+    if (timed) {                                 // (pipelined: from the end of the previous batch's merge to the end of this one's)
         SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
         ctx->ev_valid[1] = true;
     }
-    if (!h_mergeq.empty()) hipLaunchKernelGGL(k_merge_flat, dim3((unsigned)h_mergeq.size()), dim3(TPB_MF), merge_lds_bytes(k, cb_flat), mst, p);
-    if (timed && !pipe) {
-        SS_HIP(ctx, hipEventRecord(ctx->ev[1][1], st));
-        ctx->ev_valid[1] = true;
-    }
-    SS_HIP(ctx, hipEventRecord(s->batch_ev[pb], mst));
+    SS_HIP(ctx, hipEventRecord(s->batch_ev[pb], st));
     s->batch_ev_pending[pb] = true;
     SS_HIP(ctx, hipGetLastError());
     if (trace)
         fprintf(stderr, "[score trace] copies in + checks %.0f us, plan (%zu slices) %.0f us, staging %.0f us, H2D + allocs + params %.0f us, launches %.0f us%s\n",
-                t_us(th0, th1), n_slices, t_us(th1, th2), t_us(th2, th3), t_us(th3, th4), t_us(th4, t_now()), pipe ? " (merge on the merge stream)" : "");
+                t_us(th0, th1), n_slices, t_us(th1, th2), t_us(th2, th3), t_us(th3, th4), t_us(th4, t_now()), pipe ? " (k_score_wave on the wave stream)" : "");
     if (dev_out) return SS_OK;                   // ordered on the ctx stream; ss_synchronize (or the stream's owner) waits
     SS_HIP(ctx, hipMemcpyAsync(hits_out, s->d_hits.p, (size_t)n_q * k * sizeof(ss_hit), hipMemcpyDefault, st));
     SS_HIP(ctx, hipMemcpyAsync(n_hits_out, s->d_nhits.p, n_q * sizeof(int32_t), hipMemcpyDefault, st));

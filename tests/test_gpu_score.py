@@ -397,10 +397,12 @@ def test_wave_graded_slices_agree(ss_ctx, oracle, grade):
 def test_pipelined_batches_agree(ss_ctx, oracle, pipeline):
     """(pipeline = 0: the same stream of calls in the default mode — batches of different sizes back to back reuse and regrow the
     per-turn device buffers while earlier batches are still running, which once went unguarded.)
-    Option "score.pipeline": a batch's k_merge_flat runs on the context's merge stream under the next batch's k_score_wave, and the
-    hits are complete after ss_synchronize.  Six different batches back to back into six device buffers (stream shared with the
-    caller, so the calls only enqueue), then one synchronize: every batch must equal the oracle; then a non-pipelined call and a
-    prior change right behind pipelined ones (both must wait for the merges still out)."""
+    Option "score.pipeline" (default 1 since round 4): a batch's k_wave_prep / k_score_wave run on the context's wave stream and its
+    k_merge_flat on the caller's stream behind an event, so the next batch's k_score_wave starts under this batch's merge — and the
+    hits are still complete IN STREAM ORDER: right behind every call the test enqueues a copy of the output buffers on the same
+    stream (no synchronize in between) and checks the COPIES against the oracle.  Twelve batches of changing size back to back
+    (stream shared with the caller, so the calls only enqueue); then a host-output call and a prior change right behind
+    pipelined ones."""
     import torch
     n_docs, n_terms = 300000, 20000
     title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 6000000, 400000, seed=51)
@@ -416,10 +418,13 @@ def test_pipelined_batches_agree(ss_ctx, oracle, pipeline):
             outs = [(torch.zeros(len(qp) * k * 40, dtype=torch.uint8, device=dev), torch.zeros(len(qp), dtype=torch.int32, device=dev))
                     for qp, _ in batches]
             with ss_ctx.options(score__wave_min_list=0, score__pipeline=pipeline):
+                snaps = []
                 for (qp, qt), out in zip(batches, outs):
                     sc.score_topk(qp, qt, k, out=out)
-                ss_ctx.synchronize()
-                for (qp, qt), (dh, dn) in zip(batches, outs):
+                    snaps.append((out[0].clone(), out[1].clone()))      # ordered behind the call on the shared stream, nothing else
+                    out[0].fill_(0xEE)                                   # ... and the buffer is scribbled over right behind the copy
+                stream.synchronize()
+                for (qp, qt), (dh, dn) in zip(batches, snaps):
                     nq = len(qp) - 1
                     ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, qp, qt, k)
                     hits = dh.cpu().numpy()[: nq * k * 40].view(engine.HIT_DTYPE).reshape(nq, k)

@@ -26,7 +26,7 @@ with torch.cuda.stream(stream):
     ref_hits = None
     if os.environ.get('PIPE'):
         torch.cuda.synchronize(); ref_hits = (d_hits.cpu().numpy().copy(), d_n.cpu().numpy().copy())
-        ctx.set_option('score.pipeline', 1)
+        ctx.set_option('score.pipeline', int(os.environ['PIPE']))
     out = []
     for blk in range(8):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -35,7 +35,7 @@ with torch.cuda.stream(stream):
         torch.cuda.synchronize(); out.append((time.perf_counter() - t0) / 20 * 1e3)
     if ref_hits is not None:
         ctx.synchronize(); torch.cuda.synchronize()
-        print("pipelined hits identical:", bool(np.array_equal(ref_hits[0], d_hits.cpu().numpy()) and np.array_equal(ref_hits[1], d_n.cpu().numpy())), flush=True)
+        print("one-stream hits identical:", bool(np.array_equal(ref_hits[0], d_hits.cpu().numpy()) and np.array_equal(ref_hits[1], d_n.cpu().numpy())), flush=True)
     print("ms per batch by block:", ["%.3f" % x for x in out], "kernels", "%.3f" % ctx.last_kernel_ms(1), flush=True)
     sc.close(); ti.close(); bi.close()
 ctx.set_stream(None); ctx.close()
