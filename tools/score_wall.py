@@ -23,6 +23,8 @@ with torch.cuda.stream(stream):
         sc.score_topk(q_ptr, q_terms, k, out=(d_hits, d_n))
     import os
     if os.environ.get('NOTIMING'): ctx.set_option('score.timing', 0)
+    for kv in os.environ.get('OPTS', '').split(','):
+        if kv: ctx.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     ref_hits = None
     if os.environ.get('PIPE'):
         torch.cuda.synchronize(); ref_hits = (d_hits.cpu().numpy().copy(), d_n.cpu().numpy().copy())
