@@ -380,24 +380,43 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
         hipLaunchKernelGGL(k_gather_u32, dim3(ss::div_up(g->sl_nd, TPB)), dim3(TPB), 0, st, d_outdeg.p, g->old_id.p + id0_nd,
                            (uint64_t)g->sl_nd, g->outdeg.p);
 
-    // host copies of local in-degrees (already sorted descending inside each class slice)
+    // the local in-degrees (already sorted descending inside each class slice) go to the host run-length encoded
     {
-        const size_t need = ((size_t)g->cnt_nd + g->cnt_d + 1) * sizeof(uint32_t);
-        if (g->h_indeg_cap < need) {
-            if (g->h_indeg_block) ctx->pin_free(g->h_indeg_block, g->h_indeg_cap);
-            g->h_indeg_block = ctx->pin_alloc(need, &g->h_indeg_cap);
-            if (!g->h_indeg_block) { g->h_indeg_cap = 0; return ctx->fail(SS_ERR_OOM, "ss_graph_create: no pinned host memory for %zu bytes of in-degrees", need); }
+        const uint32_t cnt[2] = {g->cnt_nd, g->cnt_d};
+        const uint64_t id0[2] = {id0_nd, id0_d};
+        ss_graph::SortedDegrees* dst[2] = {&g->h_indeg_nd, &g->h_indeg_d};
+        ss::DevBuf<uint32_t> r_val, r_cnt, r_n;
+        ss::DevBuf<char> r_tmp;
+        const uint32_t cap = std::max(cnt[0], cnt[1]);
+        SS_HIP(ctx, r_val.alloc(cap));
+        SS_HIP(ctx, r_cnt.alloc(cap));
+        SS_HIP(ctx, r_n.alloc(2));
+        SS_HIP(ctx, hipMemsetAsync(r_n.p, 0, 2 * sizeof(uint32_t), st));
+        std::vector<uint32_t> h_cnt;
+        for (int c = 0; c < 2; c++) {
+            dst[c]->val.clear();
+            dst[c]->start.assign(1, 0u);
+            if (!cnt[c]) continue;
+            size_t tmp_bytes = 0;
+            SS_HIP(ctx, rocprim::run_length_encode(nullptr, tmp_bytes, indeg_int.p + id0[c], cnt[c], r_val.p, r_cnt.p, r_n.p + c, st));
+            SS_HIP(ctx, r_tmp.alloc(tmp_bytes));
+            SS_HIP(ctx, rocprim::run_length_encode(r_tmp.p, tmp_bytes, indeg_int.p + id0[c], cnt[c], r_val.p, r_cnt.p, r_n.p + c, st));
+            uint32_t n_runs = 0;
+            SS_HIP(ctx, ss::fetch(ctx, st, &n_runs, r_n.p + c, sizeof(uint32_t)));
+            dst[c]->val.resize(n_runs);
+            h_cnt.resize(n_runs);
+            SS_HIP(ctx, hipMemcpyAsync(dst[c]->val.data(), r_val.p, n_runs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            SS_HIP(ctx, hipMemcpyAsync(h_cnt.data(), r_cnt.p, n_runs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            SS_HIP(ctx, hipStreamSynchronize(st));
+            dst[c]->start.resize((size_t)n_runs + 1);
+            for (uint32_t j = 0; j < n_runs; j++) dst[c]->start[j + 1] = dst[c]->start[j] + h_cnt[j];
+            if (dst[c]->start.back() != cnt[c]) return ctx->fail(SS_ERR_STATE, "ss_graph_create: internal: run-length encoded in-degrees cover %u of %u rows", dst[c]->start.back(), cnt[c]);
         }
-        uint32_t* const hb = static_cast<uint32_t*>(g->h_indeg_block);
-        g->h_indeg_nd = ss_graph::HostU32{hb, g->cnt_nd};
-        g->h_indeg_d = ss_graph::HostU32{hb + g->cnt_nd, g->cnt_d};
-        if (g->cnt_nd) SS_HIP(ctx, hipMemcpyAsync(hb, indeg_int.p + id0_nd, g->cnt_nd * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        if (g->cnt_d) SS_HIP(ctx, hipMemcpyAsync(hb + g->cnt_nd, indeg_int.p + id0_d, g->cnt_d * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
     SS_HIP(ctx, hipStreamSynchronize(st));
     g->max_indeg = 0;
-    if (g->cnt_nd) g->max_indeg = std::max(g->max_indeg, g->h_indeg_nd[0]);
-    if (g->cnt_d) g->max_indeg = std::max(g->max_indeg, g->h_indeg_d[0]);
+    if (g->cnt_nd) g->max_indeg = std::max(g->max_indeg, g->h_indeg_nd.val[0]);
+    if (g->cnt_d) g->max_indeg = std::max(g->max_indeg, g->h_indeg_d.val[0]);
     SS_HIP(ctx, hipGetLastError());
     if (trace) { uint64_t pm = 0; double pms = 0; ss::pool_stats(&pm, &pms); fprintf(stderr, "[pr trace] pool: %llu hipMalloc so far, %.2f ms in them\n", (unsigned long long)pm, pms); }
     if (trace) fprintf(stderr, "[pr trace] ss_graph_create: upload + degrees %.2f ms, node order %.2f ms, edge sort %.2f ms, local rows %.2f ms\n", t_ms(tg0, tg1), t_ms(tg1, tg2), t_ms(tg2, tg3), t_ms(tg3, t_now()));

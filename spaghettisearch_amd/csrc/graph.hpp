@@ -40,20 +40,32 @@ struct ss_graph {
     ss::DevBuf<uint32_t> in_ptr;  // [sl_nd + sl_d + 1]
     ss::DevBuf<uint32_t> in_src;  // [e_local] internal ids, all < nd_int
     ss::DevBuf<uint32_t> outdeg;  // [sl_nd] out-degree of the local non-dangling rows
-    // host copies of the local in-degrees (sorted descending per class) for work-table building: two spans of ONE pinned block
-    // (from the context's cache; a std::vector cost a 40 MB zero fill + page faults + a copy into pageable memory per create)
-    struct HostU32 {
-        const uint32_t* p = nullptr;
-        size_t n = 0;
-        size_t size() const { return n; }
-        uint32_t operator[](size_t i) const { return p[i]; }
-        const uint32_t* begin() const { return p; }
-        const uint32_t* end() const { return p + n; }
+    // The local in-degrees, sorted descending per class, as the HOST sees them for work-table building: run-length encoded on the
+    // device (a few thousand distinct values at 10M rows: a few KB over PCIe instead of 40 MB, and a table the host's searches
+    // find in its L1 instead of a 40 MB array they miss in).  val[j] = in-degree of rows [start[j], start[j + 1]).
+    struct SortedDegrees {
+        std::vector<uint32_t> val, start;     // start has val.size() + 1 entries; start.back() = number of rows
+        size_t size() const { return start.empty() ? 0 : start.back(); }
+        size_t run_of(size_t i) const {        // the run that holds row i (i < size())
+            size_t lo = 0, hi = val.size();
+            while (hi - lo > 1) {
+                const size_t mid = (lo + hi) >> 1;
+                if (start[mid] <= i) lo = mid; else hi = mid;
+            }
+            return lo;
+        }
+        uint32_t operator[](size_t i) const { return val[run_of(i)]; }
+        // number of rows with in-degree > lim = index of the first row whose in-degree is <= lim
+        uint32_t first_at_most(uint32_t lim) const {
+            size_t lo = 0, hi = val.size();   // first run with val <= lim (val is strictly descending)
+            while (lo < hi) {
+                const size_t mid = (lo + hi) >> 1;
+                if (val[mid] > lim) lo = mid + 1; else hi = mid;
+            }
+            return start.empty() ? 0u : start[lo];
+        }
     };
-    HostU32 h_indeg_nd, h_indeg_d;
-    void* h_indeg_block = nullptr;
-    size_t h_indeg_cap = 0;
-    ~ss_graph() { if (ctx && h_indeg_block) ctx->pin_free(h_indeg_block, h_indeg_cap); }
+    SortedDegrees h_indeg_nd, h_indeg_d;
 
     uint32_t n_local() const { return sl_nd + sl_d; }
     // internal id of local row

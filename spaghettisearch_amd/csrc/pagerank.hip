@@ -997,20 +997,12 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
 
     // gw >= 8: wave-owned items of k_pr_sweep.  deg is sorted descending.
     std::vector<WorkItem> vseg, vroww, vquad, vdeg[3], vzero;
-    // deg is sorted descending: rows from r on with deg > lim (i.e. deg >= lim + 1), by galloping — the runs are short against the
-    // array (a plain upper_bound over millions of rows per item was most of this function's 2.5 ms at 10M nodes)
-    auto run_above = [](const ss_graph::HostU32& deg, uint32_t r, uint32_t lim) -> uint32_t {
-        const uint32_t cnt = (uint32_t)deg.size();
-        uint32_t step = 1, lo = r;                     // deg[lo] > lim (the caller's row)
-        while (lo + step < cnt && deg[lo + step] > lim) { lo += step; step <<= 1; }
-        uint32_t hi = std::min(cnt, lo + step);        // deg[hi] <= lim or hi == cnt
-        while (hi - lo > 1) {
-            const uint32_t mid = lo + (hi - lo) / 2;
-            if (deg[mid] > lim) lo = mid; else hi = mid;
-        }
-        return hi - r;
+    // deg is sorted descending and run-length encoded: rows from r on with deg > lim (the caller's row r is one of them)
+    auto run_above = [](const ss_graph::SortedDegrees& deg, uint32_t r, uint32_t lim) -> uint32_t {
+        const uint32_t end = deg.first_at_most(lim);
+        return end > r ? end - r : 0u;
     };
-    auto emit_v = [&](const ss_graph::HostU32& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
+    auto emit_v = [&](const ss_graph::SortedDegrees& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
         const uint32_t T_MULTI = 4096, T_DEG = 8;
         const uint32_t T_QUAD = (uint32_t)g->ctx->opt("pr.t_quad", 256);
@@ -1052,14 +1044,12 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
         if (non_dangling)
             for (uint32_t o = r; o < cnt; o += ZERO_ROWS) vzero.push_back({V_ZERO, row0 + o, std::min<uint32_t>(ZERO_ROWS, cnt - o), 0, 0, 0});
     };
-    auto emit = [&](const ss_graph::HostU32& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
+    auto emit = [&](const ss_graph::SortedDegrees& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         if (gw >= 8) { emit_v(deg, row0, non_dangling, n_pos); return; }
         const uint32_t cnt = (uint32_t)deg.size();
-        // deg is sorted descending: find class boundaries
-        uint32_t a = 0;
-        while (a < cnt && deg[a] > T_SEG) a++;
-        uint32_t c = a;
-        while (c < cnt && deg[c] > 0) c++;
+        // deg is sorted descending: class boundaries
+        const uint32_t a = deg.first_at_most(T_SEG);
+        const uint32_t c = std::max(a, deg.first_at_most(0));
         for (uint32_t r = 0; r < a; r++) {
             const uint32_t ns = (deg[r] + seg_edges - 1) / seg_edges;
             const uint32_t tix = ns > 1 ? nmulti++ : 0;
@@ -1067,8 +1057,7 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
             nsegs += ns;
         }
         {
-            uint32_t b = a;
-            while (b < c && deg[b] > T_WAVE) b++;
+            const uint32_t b = std::min(c, std::max(a, deg.first_at_most(T_WAVE)));
             for (uint32_t r = a; r < b; r += WAVES) wav.push_back({W_WAVE, row0 + r, std::min<uint32_t>(WAVES, b - r), 0, 0, 0});
             const uint32_t GROUP_ROWS = WAVES * NSLOT * 4;   // 4 rows per lane group per block
             for (uint32_t r = b; r < c; r += GROUP_ROWS) grp.push_back({W_GROUP, row0 + r, std::min<uint32_t>(GROUP_ROWS, c - r), 0, 0, 0});
@@ -1137,11 +1126,47 @@ template <int GW>
 void launch_finalize(ss_pr* pr, hipStream_t st, int is_begin) {
     hipLaunchKernelGGL(k_pr_finalize<GW>, dim3(1), dim3(64), 0, st, pr->prm, (const double*)pr->tab0.p, is_begin);
 }
+// The same by ORIGINAL id on an unsharded graph (ss_pr_read: rank_out[k][v]): one thread per original node v.  k_pr_read above
+// walks the rows in internal order and scatters 8-byte values into K topic planes at random original ids (every store a partial
+// line: 3.0 ms for the 1.28 GB of config 4, 3.05 GB fetched); here the WRITES are the coalesced side — for every topic the 64
+// lanes of a wave store 64 consecutive doubles — and the reads gather whole rows (GW doubles, one 128-byte line at GW = 16).
+template <int GW>
+__global__ __launch_bounds__(TPB) void k_pr_read_orig(const double* __restrict__ x, const PrCtl* __restrict__ ctl, const uint32_t* __restrict__ new_id,
+                                                      uint64_t n, uint32_t sl_nd, uint32_t pos_nd, uint32_t pos_d, int k_topics,
+                                                      double* __restrict__ out, const uint32_t* __restrict__ memb, uint32_t ts_mask) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t lrow = new_id[v];                  // world == 1: internal id == local row
+    const bool zero = lrow < sl_nd ? lrow >= pos_nd : (lrow - sl_nd) >= pos_d;
+    double r[GW];
+    if (!zero) {
+        if constexpr (GW >= 2) {
+            const double2* const row = reinterpret_cast<const double2*>(x + (size_t)lrow * GW);
+#pragma unroll
+            for (int j = 0; j < GW / 2; j++) { const double2 t = row[j]; r[2 * j] = t.x; r[2 * j + 1] = t.y; }
+        } else {
+            r[0] = x[lrow];
+        }
+    } else {
+        const uint32_t mb = memb ? memb[lrow] & ts_mask : 0u;
+#pragma unroll
+        for (int k = 0; k < GW; k++) r[k] = ((mb >> k) & 1u) ? ctl->xz_in[k] : ctl->xz[k];
+    }
+#pragma unroll
+    for (int k = 0; k < GW; k++)
+        if (k < k_topics) out[(size_t)k * n + v] = r[k];
+}
+
 template <int GW>
 void launch_read(ss_pr* pr, hipStream_t st, int by_orig, uint64_t stride, uint32_t* ids, double* out) {
     const ss_graph* g = pr->g;
     const size_t n_rows = (size_t)g->cnt_nd + g->cnt_d;
     if (!n_rows) return;
+    if (by_orig && g->world == 1 && !ids && stride == g->n) {
+        hipLaunchKernelGGL(k_pr_read_orig<GW>, dim3(ss::div_up(g->n, TPB)), dim3(TPB), 0, st, (const double*)pr->x.p, (const PrCtl*)pr->ctl.p,
+                           (const uint32_t*)g->new_id.p, g->n, g->sl_nd, pr->prm.pos_nd, pr->prm.pos_d, pr->k, out, pr->prm.memb, pr->prm.ts_mask);
+        return;
+    }
     hipLaunchKernelGGL(k_pr_read<GW>, dim3(ss::div_up(n_rows, TPB)), dim3(TPB), 0, st, (const double*)pr->x.p,
                        (const PrCtl*)pr->ctl.p, (const uint32_t*)g->old_id.p, g->sl_nd, g->cnt_nd, pr->prm.pos_nd, g->sl_d, g->cnt_d,
                        pr->prm.pos_d,
