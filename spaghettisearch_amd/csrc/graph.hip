@@ -34,16 +34,19 @@ __global__ __launch_bounds__(TPB) void k_outdeg(const uint64_t* __restrict__ out
     }
 }
 
-// in-degree histogram + range check of out_dst
-__global__ void k_indeg(const uint32_t* __restrict__ out_dst, uint64_t e, uint64_t n,
-                        uint32_t* __restrict__ indeg, uint32_t* __restrict__ err) {
+// range check of out_dst (the in-degrees come out of the edge sort: see build)
+__global__ void k_check_dst(const uint32_t* __restrict__ out_dst, uint64_t e, uint64_t n, uint32_t* __restrict__ err) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < e; i += stride) {
-        uint32_t c = out_dst[i];
-        if (c >= n) { atomicOr(err, 2u); continue; }
-        atomicAdd(&indeg[c], 1u);
-    }
+    bool bad = false;
+    for (; i < e; i += stride) bad = bad || out_dst[i] >= n;
+    if (bad) atomicOr(err, 2u);
+}
+// indeg[uniq[j]] = cnt[j] for the runs of the destination-sorted edge keys (indeg is zero elsewhere)
+__global__ void k_scatter_runs(const uint32_t* __restrict__ uniq, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ n_runs,
+                               uint32_t* __restrict__ indeg) {
+    const uint32_t n = *n_runs;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) indeg[uniq[j]] = cnt[j];
 }
 
 // sort key per node: class (dangling last), in-degree descending; the sort is stable and the values start as the ids in
@@ -79,12 +82,10 @@ __global__ void k_assign_ids(const uint32_t* __restrict__ sorted_ids, uint64_t n
     indeg_int[id] = indeg[v];
 }
 
-// Edge i of the out-edge CSR -> (key = internal id of its child, value = internal id of its parent).  A block takes EK_CHUNK
-// consecutive edges, finds the rows they span with two binary searches, and every edge finds its row inside that short range.
+// Edge i of the out-edge CSR -> its parent (original id).  A block takes EK_CHUNK consecutive edges, finds the rows they span
+// with two binary searches, and every edge finds its row inside that short range.
 constexpr int EK_PT = 8, EK_CHUNK = TPB * EK_PT;
-__global__ __launch_bounds__(TPB) void k_edge_keys(const uint64_t* __restrict__ out_ptr, const uint32_t* __restrict__ out_dst,
-                                                   uint64_t n, uint64_t e, const uint32_t* __restrict__ new_id,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ __launch_bounds__(TPB) void k_edge_parents(const uint64_t* __restrict__ out_ptr, uint64_t n, uint64_t e, uint32_t* __restrict__ parent) {
     __shared__ uint64_t s_r[2];
     const uint64_t base = (uint64_t)blockIdx.x * EK_CHUNK;
     if (base >= e) return;
@@ -109,8 +110,44 @@ __global__ __launch_bounds__(TPB) void k_edge_keys(const uint64_t* __restrict__ 
             const uint64_t mid = (lo + hi) >> 1;
             if (out_ptr[mid] <= i) lo = mid; else hi = mid;
         }
-        keys[i] = new_id[out_dst[i]];
-        vals[i] = new_id[lo];
+        parent[i] = (uint32_t)lo;
+    }
+}
+// The in-edge lists of this rank's rows, in internal ids, from the edges sorted by ORIGINAL destination (srcs_by_dst: the
+// parents of node v are srcs_by_dst[ptr_orig[v] .. ptr_orig[v + 1]), ascending original id): local row r is original node
+// old_id[int_id(r)], its list moves as a piece and every parent is renamed.  One thread per local edge slot; the block finds the
+// rows its chunk spans like k_edge_parents.
+__global__ __launch_bounds__(TPB) void k_permute_rows(const uint32_t* __restrict__ in_ptr, uint32_t n_local, uint64_t e_local,
+                                                      const uint32_t* __restrict__ old_id, uint32_t sl_nd, uint64_t id0_nd, uint64_t id0_d,
+                                                      const uint64_t* __restrict__ ptr_orig, const uint32_t* __restrict__ srcs_by_dst,
+                                                      const uint32_t* __restrict__ new_id, uint32_t* __restrict__ in_src) {
+    __shared__ uint32_t s_r[2];
+    const uint64_t base = (uint64_t)blockIdx.x * EK_CHUNK;
+    if (base >= e_local) return;
+    const uint64_t last = min(base + EK_CHUNK, e_local) - 1;
+    if (threadIdx.x < 2) {
+        const uint64_t target = threadIdx.x == 0 ? base : last;      // largest r with in_ptr[r] <= target
+        uint32_t lo = 0, hi = n_local;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)in_ptr[mid] <= target) lo = mid; else hi = mid;
+        }
+        s_r[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const uint32_t r_lo = s_r[0], r_hi = s_r[1];
+#pragma unroll 4
+    for (int j = 0; j < EK_PT; j++) {
+        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+        if (i > last) break;
+        uint32_t lo = r_lo, hi = r_hi + 1;                            // in_ptr[lo] <= i < in_ptr[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)in_ptr[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint64_t iid = lo < sl_nd ? id0_nd + lo : id0_d + (lo - sl_nd);
+        const uint32_t v = old_id[iid];                               // a real row: it has in-edges
+        in_src[i] = new_id[srcs_by_dst[ptr_orig[v] + (i - in_ptr[lo])]];
     }
 }
 
@@ -131,13 +168,6 @@ __global__ void k_local_ptr(const uint64_t* __restrict__ in_ptr_int, uint32_t sl
     if (l < sl_nd) v = in_ptr_int[id0_nd + l] - off_nd;
     else v = e_nd + in_ptr_int[id0_d + (l - sl_nd)] - off_d;   // l == n_local: id0_d + sl_d is valid (n_int+1 entries)
     in_ptr_local[l] = (uint32_t)v;
-}
-
-__global__ void k_extract_src(const uint32_t* __restrict__ srcs, uint64_t off_nd, uint64_t e_nd, uint64_t off_d,
-                              uint64_t e_loc, uint32_t* __restrict__ in_src) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < e_loc; i += stride) in_src[i] = i < e_nd ? srcs[off_nd + i] : srcs[off_d + (i - e_nd)];
 }
 
 // bit 31 of the last in-edge entry of every row marks the row end (pagerank.hip walks rows by it)
@@ -258,10 +288,10 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     const uint64_t* d_out_ptr = g->out_ptr.p;
     const uint32_t* d_out_dst = g->out_dst.p;
     SS_HIP(ctx, d_outdeg.alloc(n));
-    SS_HIP(ctx, d_indeg.alloc(n));
+    SS_HIP(ctx, d_indeg.alloc(n + 1));
     SS_HIP(ctx, d_cnt.alloc(1));
     SS_HIP(ctx, d_err.alloc(1));
-    SS_HIP(ctx, hipMemsetAsync(d_indeg.p, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), st));
+    SS_HIP(ctx, hipMemsetAsync(d_indeg.p, 0, (n + 1) * sizeof(uint32_t), st));
     SS_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned long long), st));
     SS_HIP(ctx, hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), st));
 
@@ -275,7 +305,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     SS_HIP(ctx, hipMemcpyAsync(hp_last, d_out_ptr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 
     if (n) hipLaunchKernelGGL(k_outdeg, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_out_ptr, n, d_outdeg.p, d_cnt.p, d_err.p);
-    if (e) hipLaunchKernelGGL(k_indeg, dim3(grid_for(e, 8192)), dim3(TPB), 0, st, d_out_dst, e, n, d_indeg.p, d_err.p);
+    if (e) hipLaunchKernelGGL(k_check_dst, dim3(grid_for(e, 8192)), dim3(TPB), 0, st, d_out_dst, e, n, d_err.p);
     SS_HIP(ctx, hipMemcpyAsync(hp_nd, d_cnt.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(hp_err, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     const auto tgb = t_now();
@@ -304,15 +334,46 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     g->cnt_d = (uint32_t)((n_d + W - 1 - g->rank) / W);
 
     const auto tg1 = t_now();
-    // ---- node order ---------------------------------------------------------
-    // The in-edge lists are sorted by destination only (stable: inside a row the parents keep the order of the input CSR, i.e.
-    // ascending original parent id): 32-bit keys over the bits the ids need instead of 64-bit (destination, source) keys.
+    // ---- edges sorted by (original) destination: the in-degrees are the run lengths ------------------------------------------
+    // One stable radix sort of (destination, parent) pairs over the bits the node ids need serves twice: its run lengths ARE the
+    // in-degrees (a histogram by 50M atomics on 10M random words took 2.1 ms of the 6.4 ms this function needed at config 4), and
+    // the sorted parents are the in-edge lists, which only have to move row by row into the internal order (k_permute_rows).
+    // Inside a row the parents keep the order of the input CSR, i.e. ascending original id.
     ss::DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b;
     ss::DevBuf<char> sort_tmp1, sort_tmp2;
-    SS_HIP(ctx, keys_a.alloc(std::max<uint64_t>(n, e)));
-    SS_HIP(ctx, keys_b.alloc(std::max<uint64_t>(n, e)));
-    SS_HIP(ctx, vals_a.alloc(std::max<uint64_t>(n, e)));
-    SS_HIP(ctx, vals_b.alloc(std::max<uint64_t>(n, e)));
+    SS_HIP(ctx, keys_a.alloc(n));                         // node sort keys; before that the run values of the edge sort (at most n runs)
+    SS_HIP(ctx, keys_b.alloc(n));
+    SS_HIP(ctx, vals_a.alloc(std::max<uint64_t>(n, e)));  // the edges' parents, then the node sort's values
+    SS_HIP(ctx, vals_b.alloc(n));
+    if (e >= 0xFFFFFFFFull) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_graph_create: more than 2^32 - 2 edges");
+    ss::DevBuf<uint32_t> e_dst, e_src;           // the sorted pairs (kept until the rows are permuted)
+    ss::DevBuf<uint64_t> ptr_orig;               // [n + 1] exclusive scan of the in-degrees over original ids
+    ss::DevBuf<uint32_t> n_runs;                 // (temporaries of the enqueued primitives live to the end of the function: no wait in between)
+    ss::DevBuf<char> rle_tmp, scan_tmp1, scan_tmp2;
+    SS_HIP(ctx, ptr_orig.alloc(n + 1));
+    if (e) {
+        SS_HIP(ctx, e_dst.alloc(e));
+        SS_HIP(ctx, e_src.alloc(e));
+        hipLaunchKernelGGL(k_edge_parents, dim3(ss::div_up(e, EK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)d_out_ptr, n, e, vals_a.p);
+        SS_TRY(sort_pairs_u32(ctx, const_cast<uint32_t*>(d_out_dst), e_dst.p, vals_a.p, e_src.p, e, bits_for(n), sort_tmp2));
+        SS_HIP(ctx, n_runs.alloc(1));
+        size_t tmp_bytes = 0;
+        SS_HIP(ctx, rocprim::run_length_encode(nullptr, tmp_bytes, e_dst.p, (size_t)e, keys_a.p, keys_b.p, n_runs.p, st));
+        SS_HIP(ctx, rle_tmp.alloc(tmp_bytes));
+        SS_HIP(ctx, rocprim::run_length_encode(rle_tmp.p, tmp_bytes, e_dst.p, (size_t)e, keys_a.p, keys_b.p, n_runs.p, st));
+        hipLaunchKernelGGL(k_scatter_runs, dim3(grid_for(std::min<uint64_t>(n, e), 4096)), dim3(TPB), 0, st, (const uint32_t*)keys_a.p, (const uint32_t*)keys_b.p,
+                           (const uint32_t*)n_runs.p, d_indeg.p);
+    }
+    {
+        size_t tmp_bytes = 0;
+        auto in_it = rocprim::make_transform_iterator(d_indeg.p, [] __device__(uint32_t x) { return (uint64_t)x; });
+        // (entry n of the scan reads one word past d_indeg: allocate n + 1 and keep the last at zero)
+        SS_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, in_it, ptr_orig.p, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), st));
+        SS_HIP(ctx, scan_tmp1.alloc(tmp_bytes));
+        SS_HIP(ctx, rocprim::exclusive_scan(scan_tmp1.p, tmp_bytes, in_it, ptr_orig.p, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), st));
+    }
+    const auto tg1b = t_now();
+    // ---- node order ---------------------------------------------------------
     if (n) hipLaunchKernelGGL(k_row_keys, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_outdeg.p, d_indeg.p, n, keys_a.p, vals_a.p);
     SS_TRY(sort_pairs_u32(ctx, keys_a.p, keys_b.p, vals_a.p, vals_b.p, n, 32, sort_tmp1));
 
@@ -333,19 +394,9 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
         auto in_it = rocprim::make_transform_iterator(indeg_int.p, [] __device__(uint32_t x) { return (uint64_t)x; });
         SS_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, in_it, in_ptr_int.p, (uint64_t)0, (size_t)(g->n_int + 1),
                                             rocprim::plus<uint64_t>(), st));
-        ss::DevBuf<char> tmp;
-        SS_HIP(ctx, tmp.alloc(tmp_bytes));
-        SS_HIP(ctx, rocprim::exclusive_scan(tmp.p, tmp_bytes, in_it, in_ptr_int.p, (uint64_t)0, (size_t)(g->n_int + 1),
+        SS_HIP(ctx, scan_tmp2.alloc(tmp_bytes));
+        SS_HIP(ctx, rocprim::exclusive_scan(scan_tmp2.p, tmp_bytes, in_it, in_ptr_int.p, (uint64_t)0, (size_t)(g->n_int + 1),
                                             rocprim::plus<uint64_t>(), st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
-    }
-
-    const auto tg2 = t_now();
-    // ---- edges: (dst_int, src_int) sorted ------------------------------------
-    if (e) {
-        hipLaunchKernelGGL(k_edge_keys, dim3(ss::div_up(e, EK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)d_out_ptr, (const uint32_t*)d_out_dst, n, e,
-                           (const uint32_t*)g->new_id.p, keys_a.p, vals_a.p);
-        SS_TRY(sort_pairs_u32(ctx, keys_a.p, keys_b.p, vals_a.p, vals_b.p, e, bits_for(g->n_int), sort_tmp2));
     }
 
     if (trace) SS_HIP(ctx, hipStreamSynchronize(st));
@@ -371,8 +422,9 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     hipLaunchKernelGGL(k_local_ptr, dim3(ss::div_up((uint64_t)n_local + 1, TPB)), dim3(TPB), 0, st, in_ptr_int.p, g->sl_nd,
                        g->sl_d, id0_nd, id0_d, h_ptr[0], h_ptr[2], e_nd, g->in_ptr.p);
     if (g->e_local)
-        hipLaunchKernelGGL(k_extract_src, dim3(grid_for(g->e_local, 16384)), dim3(TPB), 0, st, (const uint32_t*)vals_b.p, h_ptr[0], e_nd,
-                           h_ptr[2], g->e_local, g->in_src.p);
+        hipLaunchKernelGGL(k_permute_rows, dim3(ss::div_up(g->e_local, EK_CHUNK)), dim3(TPB), 0, st, (const uint32_t*)g->in_ptr.p, n_local, g->e_local,
+                           (const uint32_t*)g->old_id.p, g->sl_nd, id0_nd, id0_d, (const uint64_t*)ptr_orig.p, (const uint32_t*)e_src.p,
+                           (const uint32_t*)g->new_id.p, g->in_src.p);
     if (g->e_local)
         hipLaunchKernelGGL(k_flag_row_ends, dim3(ss::div_up((uint64_t)n_local, TPB)), dim3(TPB), 0, st, (const uint32_t*)g->in_ptr.p,
                            (uint64_t)n_local, g->in_src.p);
@@ -419,7 +471,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     if (g->cnt_d) g->max_indeg = std::max(g->max_indeg, g->h_indeg_d.val[0]);
     SS_HIP(ctx, hipGetLastError());
     if (trace) { uint64_t pm = 0; double pms = 0; ss::pool_stats(&pm, &pms); fprintf(stderr, "[pr trace] pool: %llu hipMalloc so far, %.2f ms in them\n", (unsigned long long)pm, pms); }
-    if (trace) fprintf(stderr, "[pr trace] ss_graph_create: upload + degrees %.2f ms, node order %.2f ms, edge sort %.2f ms, local rows %.2f ms\n", t_ms(tg0, tg1), t_ms(tg1, tg2), t_ms(tg2, tg3), t_ms(tg3, t_now()));
+    if (trace) fprintf(stderr, "[pr trace] ss_graph_create: upload + out-degrees %.2f ms, edge sort + in-degrees %.2f ms, node order %.2f ms, local rows %.2f ms\n", t_ms(tg0, tg1), t_ms(tg1, tg1b), t_ms(tg1b, tg3), t_ms(tg3, t_now()));
     return SS_OK;
 }
 

@@ -1238,8 +1238,18 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     // persistent grid, each block (gw < 8) or wave (gw >= 8) walks the work table round-robin: gw < 8: 8 blocks per CU at
     // most; gw >= 8: exactly the waves the chip holds at once
     int per_cu = 8;
-    SS_GW_DISPATCH(GW, sweep_occupancy, &per_cu);
-    if (per_cu < 1) per_cu = 1;
+    {
+        // (the occupancy query is a runtime call of ~0.3 ms: asked once per kernel width and process)
+        static std::mutex occ_mu;
+        static int occ_cache[17] = {0};
+        std::lock_guard<std::mutex> lk_occ(occ_mu);
+        if (!occ_cache[GW]) {
+            SS_GW_DISPATCH(GW, sweep_occupancy, &per_cu);
+            occ_cache[GW] = per_cu < 1 ? 1 : per_cu;
+        }
+        per_cu = occ_cache[GW];
+    }
+    const auto tc1a = t_now();
     per_cu = (int)std::max<int64_t>(1, ctx->opt("pr.blocks_per_cu", per_cu));
     pr->nblocks = GW >= 8 ? (unsigned)std::min<size_t>(ss::div_up(items.size(), (size_t)WAVES), (size_t)ctx->cu_count * per_cu)
                           : (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
@@ -1253,6 +1263,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                                    : (lrow - g->sl_nd < g->h_indeg_d.size() ? g->h_indeg_d[lrow - g->sl_nd] : 0u);
         };
         std::vector<double> cost(items.size());
+        const auto td0 = t_now();
         for (size_t i = 0; i < items.size(); i++) {
             const WorkItem& w = items[i];
             double turns = 1.0;
@@ -1308,6 +1319,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                 }
             }
         }
+        const auto td1 = t_now();
+        if (trace) fprintf(stderr, "[pr trace]   deal: occupancy query %.2f ms, costs + owners %.2f ms\n", t_ms(tc1, tc1a), t_ms(td0, td1));
         // table order inside a wave's list = item order = class order: count per (wave, class), offsets, place
         auto cls = [&](size_t i) { int k = 0; while (k < 5 && i >= vbeg[k + 1]) k++; return k; };
         woff.assign((size_t)nw * 8, 0);
