@@ -301,7 +301,7 @@ def main() -> None:
                 tr = profiled_traffic("k_pr_sweep<16") if (n, e, kt) == (10_000_000, 50_000_000, 16) else None
                 result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": ach / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
-                                      "kernel": (f"k_pr_step<{1 if kt == 1 else 2}>" if kt <= 2 else f"k_pr_sweep<{8 if kt <= 8 else 16}, false>"),
+                                      "kernel": (f"k_pr_sweep_n<{kt}, false>" if kt <= 2 else f"k_pr_sweep<{8 if kt <= 8 else 16}, false>"),
                                       "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes}
                 if tr:
                     result["roofline"]["traffic_detail"] = tr
@@ -560,7 +560,7 @@ def main() -> None:
                       "value": K / dt2, "unit": "iterations/s", "ms_per_step": dt2 * 1e3 / K, "ms_per_step_blocks": summarize(blocks2),
                       "to_convergence_eps1e-6": {"iters": int(it2[0]), "seconds": conv_s},
                       "roofline": {"bound": "hbm", "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS,
-                                   "traffic": None, "kernel": "k_pr_sweep<8> (one topic + 7 padded: the 22 MB table is cache-resident)", "kernel_ms": k2_ms, "algorithmic_bytes": b2}}
+                                   "traffic": None, "kernel": "k_pr_sweep_n<1, false> (one lane per row / per edge, no padded topics)", "kernel_ms": k2_ms, "algorithmic_bytes": b2}}
                 if not args.no_cpu_baseline:
                     from oracle import pyoracle
                     h2p = o2p.cpu().numpy().view(np.uint64)

@@ -264,6 +264,7 @@ int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream) {
 static const char* const k_option_names[] = {
     "comm.timeout_ms",      // longest wait for the other ranks: ss_comm_init, and every wait of the library for a stream that carries a collective (default 120000)
     "pr.force_narrow",      // 1: K <= 2 always runs the block-item kernel k_pr_step (tests reach it on small graphs)
+    "pr.narrow_wave",       // 0: K <= 2 as before round 4 (padded to the 8-wide sweep on small graphs, k_pr_step on large ones); default 1: k_pr_sweep_n
     "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
     "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 65536, 0 = off)

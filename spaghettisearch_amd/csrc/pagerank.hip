@@ -783,6 +783,265 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     block_reduce_and_publish<GW>(p, c.dsum, c.csum, c.Tw, false);
 }
 
+// ---- the sweep for K <= 2, wave-owned items (round 4) ------------------------------------------------------------------------
+// k_pr_sweep's lane group holds the GW topic values of ONE table row; with one or two topics that geometry either pads to eight
+// (seven of eight lanes gather, add and DIVIDE for padding: config 2 was issue-bound at 7.6 % of the roofline) or shrinks the
+// group to one or two lanes (nothing coalesces).  Here the lanes hold ROWS and EDGES instead: the table row is one double
+// (K = 1) or one double2 (K = 2), a lane gathers it whole, and
+//   V_DEG    rows of exactly D <= 8 in-edges (almost all rows of a power-law graph): one LANE per row — D index words, D gathers,
+//            and every lane finishes a row of its own (the two float64 divisions of pagerank.go:117,136 run on 64 real rows);
+//   V_QUAD   9 .. 256 in-edges: one row per 8-lane group, the lanes stride the row's edges, three-step butterfly at its end;
+//   V_ROWW / V_SEG   long rows and 2048-edge pieces of the longest: the wave strides the edges, six-step butterfly;
+//   V_ZERO   one lane per row.
+// The items, their classes and the static deal to the waves are those of the 8-wide sweep (build_work with NS = 8).  Nothing is
+// software-pipelined: a lane holds a handful of registers, so eight waves per SIMD hide the latency instead.
+// Summation order: a row's in-edges are added in a fixed order that depends only on the row's class — deterministic, and
+// within the last bits of the other kernels' orders (parity gate 1e-6; iteration counts as the oracle's).
+#ifndef SS_PRN_MINW
+#define SS_PRN_MINW 6
+#endif
+template <int KW>
+struct NVec { double v[KW]; };
+template <int KW>
+__device__ __forceinline__ NVec<KW> ntab(const double* __restrict__ T, uint32_t row) {
+    NVec<KW> r;
+    if constexpr (KW == 1) {
+        r.v[0] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(T) + (size_t)(row * 8u));
+    } else {
+        const double2 t = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(T) + (size_t)(row * 16u));
+        r.v[0] = t.x;
+        r.v[1] = t.y;
+    }
+    return r;
+}
+template <int KW, bool TS>
+struct NCtx {
+    const PrParams& p;
+    const double* __restrict__ T;
+    double* __restrict__ Tw;
+    double S[KW], x0[KW], dsum[KW], csum[KW];
+    bool act[KW];
+};
+template <int KW, bool TS>
+__device__ __forceinline__ void finish_n(NCtx<KW, TS>& c, uint32_t lrow, const NVec<KW>& y, const NVec<KW>& xo, uint32_t od) {
+    const PrParams& p = c.p;
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+        const double yk = y.v[k] + c.x0[k];
+        double tele = p.teleport;
+        if constexpr (TS) tele = teleport_of(p, lrow, k);
+        double xn = (yk + tele) / c.S[k];                         // pagerank.go:117
+        const size_t xi = (size_t)lrow * KW + k;
+        if (c.act[k]) {
+            NT_STORE(xn, &p.x[xi]);
+            c.dsum[k] += fabs(xn - xo.v[k]);                      // pagerank.go:118
+        } else {
+            xn = xo.v[k];                                         // converged topic: frozen
+        }
+        if (lrow < p.sl_nd) {                                     // non-dangling row: next sweep's contribution
+            const double cc = p.d * xn / (double)od;              // pagerank.go:136
+            NT_STORE(cc, &c.Tw[xi]);
+            c.csum[k] += cc;                                      // pagerank.go:137
+        }
+    }
+}
+template <int KW>
+__device__ __forceinline__ NVec<KW> load_x(const double* __restrict__ x, uint32_t lrow) {
+    NVec<KW> r;
+#pragma unroll
+    for (int k = 0; k < KW; k++) r.v[k] = NT_LOAD(&x[(size_t)lrow * KW + k]);
+    return r;
+}
+
+// rows of exactly D = w.nseg <= ND in-edges: lane l of pass r0 owns row r0 + l of the item
+template <int KW, bool TS, int ND>
+__device__ __forceinline__ void deg_lane_rows(NCtx<KW, TS>& c, const WorkItem& w, int lane) {
+    const PrParams& p = c.p;
+    const uint32_t D = w.nseg;
+    for (uint32_t r0 = 0; r0 < w.count; r0 += 64) {
+        const uint32_t rr = r0 + (uint32_t)lane;
+        const bool valid = rr < w.count;
+        const uint32_t lrow = w.row + (valid ? rr : 0u);
+        const uint32_t e0 = w.beg + (valid ? rr : 0u) * D;
+        uint32_t src[ND];
+#pragma unroll
+        for (int u = 0; u < ND; u++) {
+            const bool ok = valid && (uint32_t)u < D;
+            const uint32_t raw = NT_LOAD(&p.in_src[ok ? e0 + (uint32_t)u : w.beg]);
+            src[u] = ok ? (raw & SRC_MASK) : p.zrow;
+        }
+        const NVec<KW> xo = load_x<KW>(p.x, lrow);
+        const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
+        NVec<KW> v[ND];
+#pragma unroll
+        for (int u = 0; u < ND; u++) v[u] = ntab<KW>(c.T, src[u]);
+        NVec<KW> acc;
+#pragma unroll
+        for (int k = 0; k < KW; k++) acc.v[k] = 0.0;
+#pragma unroll
+        for (int u = 0; u < ND; u++)
+#pragma unroll
+            for (int k = 0; k < KW; k++) acc.v[k] += v[u].v[k];
+        if (valid) finish_n<KW, TS>(c, lrow, acc, xo, od);
+    }
+}
+
+template <int KW, bool TS>
+__global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
+    PrCtl* ctl = p.ctl;
+    if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
+    const int sweep = ctl->sweep;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    NCtx<KW, TS> c{p, p.tab_rd[sweep & 1], p.tab_wr[sweep & 1], {}, {}, {}, {}, {}};
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+        c.S[k] = ctl->S[k];
+        c.act[k] = ctl->active[k] != 0;
+        c.x0[k] = sweep == 0 ? p.x0[k] : 0.0;                     // Q4: iteration 1 accumulates onto 1/n
+        c.dsum[k] = 0.0;
+        c.csum[k] = 0.0;
+    }
+    const uint32_t* __restrict__ off = p.woff + (size_t)(blockIdx.x * WAVES + wave) * 8;
+    const uint32_t* __restrict__ in_src = p.in_src;
+
+    // ---- V_SEG / V_ROWW: the wave strides the row's (piece's) edges, four gathers per lane in flight
+    for (uint32_t it = off[0]; it < off[1]; it++) {
+        const WorkItem w = p.work[it];
+        const uint32_t lrow = w.row;
+        NVec<KW> xo = load_x<KW>(p.x, lrow);
+        const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
+        NVec<KW> acc;
+#pragma unroll
+        for (int k = 0; k < KW; k++) acc.v[k] = 0.0;
+        for (uint32_t e = w.beg; e < w.end; e += 256) {
+            uint32_t src[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = e + (uint32_t)(u * 64 + lane);
+                const uint32_t raw = NT_LOAD(&in_src[j < w.end ? j : w.beg]);
+                src[u] = j < w.end ? (raw & SRC_MASK) : p.zrow;
+            }
+            NVec<KW> v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = ntab<KW>(c.T, src[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int k = 0; k < KW; k++) acc.v[k] += v[u].v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < KW; k++)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) acc.v[k] += __shfl_xor(acc.v[k], o, 64);
+        if (w.kind == V_ROWW) {
+            if (lane == 0) finish_n<KW, TS>(c, lrow, acc, xo, od);
+        } else {
+            // several waves (of any blocks) share this row: publish the piece's sum write-through, drain, take the ticket; the
+            // last to arrive adds the pieces in order with sc1 loads (no fences — see block_reduce_and_publish)
+            const double mine = (KW == 2 && (lane & 1)) ? acc.v[KW - 1] : acc.v[0];
+            if (lane < KW) __hip_atomic_store(&p.segpart[(size_t)(w.sbase + w.count) * KW + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(&p.rowticket[w.tix], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+            if (prev == w.nseg - 1) {
+                if (lane == 0) {
+                    __hip_atomic_store(&p.rowticket[w.tix], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    NVec<KW> ys;
+#pragma unroll
+                    for (int k = 0; k < KW; k++) {
+                        ys.v[k] = 0.0;
+                        for (uint32_t q = 0; q < w.nseg; q++)
+                            ys.v[k] += __hip_atomic_load(&p.segpart[(size_t)(w.sbase + q) * KW + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    finish_n<KW, TS>(c, lrow, ys, xo, od);
+                }
+            }
+        }
+    }
+
+    // ---- V_QUAD: one row per 8-lane group; the rows of an item are all nch 16-edge turns long
+    {
+        const int gl = lane & 7, grp = lane >> 3;
+        for (uint32_t it = off[1]; it < off[2]; it++) {
+            const WorkItem w = p.work[it];
+            const uint32_t nq = (w.count + 7) / 8;
+            for (uint32_t q = 0; q < nq; q++) {
+                const uint32_t rr = q * 8 + (uint32_t)grp;
+                const bool valid = rr < w.count;
+                const uint32_t lrow = w.row + (valid ? rr : 0u);
+                const uint32_t b = p.in_ptr[lrow], e_end = valid ? p.in_ptr[lrow + 1] : b;
+                NVec<KW> xo = load_x<KW>(p.x, lrow);
+                const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
+                NVec<KW> acc;
+#pragma unroll
+                for (int k = 0; k < KW; k++) acc.v[k] = 0.0;
+                for (uint32_t ch = 0; ch < w.nseg; ch += 2) {           // two turns (32 edge slots of the row) per trip: four gathers per lane
+                    uint32_t src[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t j = b + ch * 16u + (uint32_t)(u * 8 + gl);
+                        const uint32_t raw = NT_LOAD(&in_src[j < e_end ? j : b]);
+                        src[u] = j < e_end ? (raw & SRC_MASK) : p.zrow;
+                    }
+                    NVec<KW> v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = ntab<KW>(c.T, src[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int k = 0; k < KW; k++) acc.v[k] += v[u].v[k];
+                }
+#pragma unroll
+                for (int k = 0; k < KW; k++)
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) acc.v[k] += __shfl_xor(acc.v[k], o, 64);
+                if (valid && gl == 0) finish_n<KW, TS>(c, lrow, acc, xo, od);
+            }
+        }
+    }
+
+    // ---- V_DEG (all three classes): rows of exactly D <= 8 in-edges, their edges contiguous from item.beg: one lane per row
+    for (uint32_t it = off[2]; it < off[5]; it++) {
+        const WorkItem w = p.work[it];
+        if (w.nseg <= 2) deg_lane_rows<KW, TS, 2>(c, w, lane);          // (wave-uniform: most rows of a power-law graph)
+        else if (w.nseg <= 4) deg_lane_rows<KW, TS, 4>(c, w, lane);
+        else deg_lane_rows<KW, TS, 8>(c, w, lane);
+    }
+
+    // ---- V_ZERO: non-dangling rows without in-edges: their rank is the shared value, only the next contribution is written
+    for (uint32_t it = off[5]; it < off[6]; it++) {
+        const WorkItem w = p.work[it];
+        for (uint32_t r0 = 0; r0 < w.count; r0 += 64) {
+            const uint32_t rr = r0 + (uint32_t)lane;
+            if (rr >= w.count) continue;
+            const uint32_t lrow = w.row + rr;
+            const uint32_t od = NT_LOAD(&p.outdeg[lrow]);
+#pragma unroll
+            for (int k = 0; k < KW; k++) {
+                const bool ts = TS && p.memb && ((p.ts_mask >> k) & 1u);
+                const double xz_out = c.act[k] ? (ts ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], 0.0) : zero_row_rank(p, sweep, c.S[k], p.x0[k])) : ctl->xz[k];
+                const double xz_inn = ts ? (c.act[k] ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], p.tin[k]) : ctl->xz_in[k]) : xz_out;
+                const double xz = ts && ((p.memb[lrow] >> k) & 1u) ? xz_inn : xz_out;
+                const double cc = p.d * xz / (double)od;                      // pagerank.go:136
+                NT_STORE(cc, &c.Tw[(size_t)lrow * KW + k]);
+                c.csum[k] += cc;                                               // pagerank.go:137
+            }
+        }
+    }
+
+    // block_reduce_and_publish<KW> expects lane l to hold a partial of topic l % KW
+    double ds = c.dsum[0], cs = c.csum[0];
+    if constexpr (KW == 2) {
+        const double d0o = __shfl_xor(c.dsum[0], 1, 64), d1o = __shfl_xor(c.dsum[1], 1, 64);
+        const double c0o = __shfl_xor(c.csum[0], 1, 64), c1o = __shfl_xor(c.csum[1], 1, 64);
+        ds = (lane & 1) ? c.dsum[1] + d1o : c.dsum[0] + d0o;
+        cs = (lane & 1) ? c.csum[1] + c1o : c.csum[0] + c0o;
+    }
+    block_reduce_and_publish<KW>(p, ds, cs, c.Tw, false);
+}
+
 // k_pr_sweep's items: their in-edge ranges from the device's in_ptr (the host deals the items by their turn counts, which it
 // knows from the sorted in-degrees; copying in_ptr itself to the host cost 14 of the 17 ms of ss_pr_create at 10M nodes)
 __global__ void k_pr_item_ranges(WorkItem* __restrict__ work, uint32_t n_items, const uint32_t* __restrict__ in_ptr) {
@@ -955,6 +1214,7 @@ __global__ __launch_bounds__(TPB) void k_pr_probe(const double* __restrict__ T, 
 struct ss_pr {
     ss_graph* g = nullptr;
     int gw = 1;            // lane-group width = padded topic count
+    bool nwave = false;    // K <= 2 on the wave-item kernel k_pr_sweep_n (gw = K; the work items are those of the 8-wide sweep)
     int k = 1;
     PrParams prm{};
     unsigned nblocks = 0;
@@ -972,18 +1232,20 @@ struct ss_pr {
 
 namespace {
 
-int pick_gw(int k, uint64_t table_rows, bool force_narrow) {
+int pick_gw(int k, uint64_t table_rows, bool force_narrow, bool narrow_wave) {
     // K = 3, 4 run the wave-item sweep padded to 8 topics (measured on the 10M/50M R-MAT at K=4: 0.77 ms against 0.94 ms
-    // for the 4-wide block-item kernel; at K=1 the narrow kernel wins there, 0.55 against 0.79 ms).  K <= 2 on a graph whose
-    // padded table stays cache-resident (<= 64 MB of 64-byte rows) also takes it: the padding costs no HBM traffic then
-    // and the wave-item pipeline is quicker than the block-item one (2^20 nodes / 5M edges, K=1: 0.134 against 0.19 ms)
+    // for the 4-wide block-item kernel).  K <= 2: the wave-item kernel for one or two topics, k_pr_sweep_n, unpadded (round 4).
+    // Before it (option "pr.narrow_wave" = 0): padded to 8 when the padded table stays cache-resident (<= 64 MB of 64-byte
+    // rows: the padding costs no HBM traffic then; 2^20 nodes / 5M edges, K=1: 0.074 ms), else the block-item kernel k_pr_step
+    // (10M/50M, K=1: 0.55 ms against 0.79 ms padded).  "pr.force_narrow": always k_pr_step (tests reach it on small graphs).
     if (k >= 3 && k <= 8) return 8;
-    if (k <= 2 && table_rows * 64 <= (64ull << 20) && !force_narrow) return 8;   // "pr.force_narrow": tests reach k_pr_step on small graphs
+    if (k <= 2 && (narrow_wave || force_narrow)) return k;
+    if (k <= 2 && table_rows * 64 <= (64ull << 20)) return 8;
     if (k <= 2) return k;
     return 16;
 }
 
-void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
+void build_work(const ss_graph* g, int gw, bool lane_rows, int64_t item_turns_default, std::vector<WorkItem>& items, uint32_t& nsegs, uint32_t& nmulti,
                 uint32_t& seg_edges, uint32_t& pos_nd, uint32_t& pos_d, uint32_t (&vbeg)[7]) {
     const uint32_t NSLOT = 64 / gw;
     // gw < 8: rows above T_SEG in-edges get block(s) of their own, then wave-per-row / group-per-row classes.
@@ -1035,7 +1297,8 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
             // deg is sorted descending: the run of rows with exactly D in-edges ends at the first smaller degree
             const uint32_t run = run_above(deg, r, D - 1);
             const uint32_t R = D <= 2 ? 8 : D <= 4 ? 4 : 2;
-            const uint32_t per_item = NSLOT * R * item_turns;
+            // (k_pr_sweep_n gives every LANE a row: whole waves of 64 rows per item there)
+            const uint32_t per_item = lane_rows ? 64u * item_turns : NSLOT * R * item_turns;
             for (uint32_t o = 0; o < run; o += per_item) vdeg[R == 2 ? 0 : R == 4 ? 1 : 2].push_back({V_DEG, row0 + r + o, std::min(per_item, run - o), D, 0, 0});
             r += run;
         }
@@ -1107,6 +1370,13 @@ void build_work(const ss_graph* g, int gw, int64_t item_turns_default, std::vect
 
 template <int GW>
 void launch_step(ss_pr* pr, hipStream_t st) {
+    if constexpr (GW <= 2) {
+        if (pr->nwave) {
+            if (pr->prm.memb) hipLaunchKernelGGL((k_pr_sweep_n<GW, true>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+            else hipLaunchKernelGGL((k_pr_sweep_n<GW, false>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+            return;
+        }
+    }
     if constexpr (GW >= 8) {
         if (pr->prm.memb) hipLaunchKernelGGL((k_pr_sweep<GW, true>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
         else hipLaunchKernelGGL((k_pr_sweep<GW, false>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
@@ -1203,8 +1473,12 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     std::unique_ptr<ss_pr> guard(pr);
     pr->g = g;
     pr->k = k_topics;
-    pr->gw = pick_gw(k_topics, g->nd_int, ctx->opt("pr.force_narrow", 0) != 0);
+    const bool force_narrow = ctx->opt("pr.force_narrow", 0) != 0;
+    pr->gw = pick_gw(k_topics, g->nd_int, force_narrow, ctx->opt("pr.narrow_wave", 1) != 0);
+    pr->nwave = pr->gw <= 2 && !force_narrow && ctx->opt("pr.narrow_wave", 1) != 0;
     const int GW = pr->gw;
+    const bool vitems = GW >= 8 || pr->nwave;          // wave-owned items (k_pr_sweep / k_pr_sweep_n); otherwise k_pr_step's block items
+    const int GI = pr->nwave ? 8 : GW;                 // lane-group width the ITEMS are cut for
     const size_t n_local = g->n_local();
 
     const bool trace = ctx->opt("pr.trace", 0) != 0;
@@ -1232,7 +1506,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     // item granularity (measured, sweep ms at 2 / 4 / 8 / 16 / 32 turns per V_DEG item): 2^20 nodes, 5M edges, K=1: 0.078 / 0.077 / 0.096 /
     // 0.102 / 0.158; 10M nodes, 50M edges, K=16: 0.973 / 0.968 / 0.968 / 0.988 / 1.013 — a small graph gives every wave ~20 turns in all,
     // and the deal can only balance what the items let it; the large one pays for more items in the deal itself (host time)
-    build_work(g, GW, n_local <= ((size_t)4 << 20) ? 4 : 8, items, nsegs, nmulti, seg_edges, pos_nd, pos_d, vbeg);
+    build_work(g, GI, pr->nwave, pr->nwave ? (n_local <= ((size_t)4 << 20) ? 1 : 4) : (n_local <= ((size_t)4 << 20) ? 4 : 8), items, nsegs, nmulti, seg_edges, pos_nd, pos_d, vbeg);
     const auto tc1 = t_now();
     if (items.empty()) items.push_back({W_ZERO, 0, 0, 0, 0, 0});
     // persistent grid, each block (gw < 8) or wave (gw >= 8) walks the work table round-robin: gw < 8: 8 blocks per CU at
@@ -1243,21 +1517,27 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         static std::mutex occ_mu;
         static int occ_cache[17] = {0};
         std::lock_guard<std::mutex> lk_occ(occ_mu);
-        if (!occ_cache[GW]) {
-            SS_GW_DISPATCH(GW, sweep_occupancy, &per_cu);
-            occ_cache[GW] = per_cu < 1 ? 1 : per_cu;
+        const int slot = pr->nwave ? 2 + GW : GW;      // (3, 4: the narrow wave-item kernels)
+        if (!occ_cache[slot]) {
+            if (pr->nwave) {
+                if (GW == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pr_sweep_n<1, false>, TPB, 0);
+                else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pr_sweep_n<2, false>, TPB, 0);
+            } else {
+                SS_GW_DISPATCH(GW, sweep_occupancy, &per_cu);
+            }
+            occ_cache[slot] = per_cu < 1 ? 1 : per_cu;
         }
-        per_cu = occ_cache[GW];
+        per_cu = occ_cache[slot];
     }
     const auto tc1a = t_now();
     per_cu = (int)std::max<int64_t>(1, ctx->opt("pr.blocks_per_cu", per_cu));
-    pr->nblocks = GW >= 8 ? (unsigned)std::min<size_t>(ss::div_up(items.size(), (size_t)WAVES), (size_t)ctx->cu_count * per_cu)
+    pr->nblocks = vitems ? (unsigned)std::min<size_t>(ss::div_up(items.size(), (size_t)WAVES), (size_t)ctx->cu_count * per_cu)
                           : (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
     std::vector<uint32_t> woff;
-    if (GW >= 8) {
+    if (vitems) {
         // k_pr_sweep: the items' turn counts (from the sorted in-degrees the graph keeps on the host), then the items dealt to the
         // grid's waves; the edge ranges are filled in on the device (k_pr_item_ranges)
-        const uint32_t NS = 64 / GW;
+        const uint32_t NS = 64 / GI;
         auto deg_of = [&](uint32_t lrow) -> uint32_t {
             return lrow < g->sl_nd ? (lrow < g->h_indeg_nd.size() ? g->h_indeg_nd[lrow] : 0u)
                                    : (lrow - g->sl_nd < g->h_indeg_d.size() ? g->h_indeg_d[lrow - g->sl_nd] : 0u);
@@ -1272,6 +1552,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                 case V_SEG: turns = ss::div_up(std::min<uint32_t>(SEGW, deg_of(w.row) - w.count * SEGW), NS * CH) + 2.0; break;
                 case V_QUAD: turns = (double)ss::div_up(w.count, NS) * w.nseg; break;
                 case V_DEG: {
+                    if (pr->nwave) { turns = (double)ss::div_up(w.count, 64u) * (0.6 + 0.2 * (w.nseg <= 2 ? 2 : w.nseg <= 4 ? 4 : 8)); break; }   // a pass of 64 rows: 2, 4 or 8 gathers per lane + a row each
                     const uint32_t R = w.nseg <= 2 ? 8 : w.nseg <= 4 ? 4 : 2;
                     turns = (double)ss::div_up(w.count, NS * R) * (R == 8 ? 2.5 : R == 4 ? 1.7 : 1.3);   // a turn finishes R rows per lane group
                     break;
@@ -1351,7 +1632,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     if (!woff.empty()) SS_HIP(ctx, hipMemcpyAsync(pr->woff.p, woff.data(), woff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     SS_HIP(ctx, pr->work.alloc(items.size()));
     SS_HIP(ctx, hipMemcpyAsync(pr->work.p, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, st));
-    if (GW >= 8)
+    if (vitems)
         hipLaunchKernelGGL(k_pr_item_ranges, dim3(ss::div_up(items.size(), TPB)), dim3(TPB), 0, st, pr->work.p, (uint32_t)items.size(), (const uint32_t*)g->in_ptr.p);
     SS_HIP(ctx, pr->ctl.alloc(1));
     SS_HIP(ctx, hipMemsetAsync(pr->ctl.p, 0, sizeof(PrCtl), st));

@@ -133,9 +133,12 @@ def test_edge_cases(ss_ctx, oracle):
     np.testing.assert_allclose(rank, ref, rtol=1e-13)
 
 
-# ---- the block-item kernel k_pr_step<1/2> (K <= 2 on graphs whose padded table would leave the caches) --------------
-# pick_gw sends K <= 2 on small graphs to k_pr_sweep<8>; option "pr.force_narrow" keeps the narrow kernel so that its
-# classes (W_SEG with the multi-segment ticket path, W_WAVE, W_GROUP, W_ZERO) meet the oracle directly.
+# ---- the three kernels of K <= 2 -----------------------------------------------------------------------------------------
+# default (round 4): k_pr_sweep_n<1/2>, wave-owned items, a lane per row / per edge (classes V_SEG with the multi-piece ticket
+# path, V_ROWW, V_QUAD, V_DEG by lane, V_ZERO); "pr.narrow_wave" = 0: the choice before it (small graphs: k_pr_sweep<8> with padded
+# topics); "pr.force_narrow" = 1: the block-item kernel k_pr_step<1/2> (W_SEG, W_WAVE, W_GROUP, W_ZERO).  Every one of them meets
+# the oracle directly.
+NARROW_VARIANTS = {"wave_items": {}, "padded_8_wide": {"pr__narrow_wave": 0}, "block_items": {"pr__force_narrow": 1}}
 def _skewed_graph():
     rng = np.random.default_rng(3)
     n = 70000
@@ -146,25 +149,27 @@ def _skewed_graph():
     return (n,) + csr(n, list(edges))
 
 
+@pytest.mark.parametrize("variant", list(NARROW_VARIANTS))
 @pytest.mark.parametrize("k_topics", [1, 2])
-def test_narrow_kernel_skewed_rows(ss_ctx, oracle, k_topics):
+def test_narrow_kernel_skewed_rows(ss_ctx, oracle, k_topics, variant):
     n, ptr, dst = _skewed_graph()
     n_topic = [n, 7][:k_topics]
-    with ss_ctx.options(pr__force_narrow=1):
+    with ss_ctx.options(**NARROW_VARIANTS[variant]):
         rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
         rank2, iters2, _, _ = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
     assert iters.tolist() == ref_iters.tolist()
     np.testing.assert_allclose(rank, ref, rtol=1e-12)
     assert rank.tobytes() == rank2.tobytes() and iters.tolist() == iters2.tolist()     # run-to-run bit-identical
-    # and the wide kernel the default picks for this size gives the same ranks
+    # and the kernel the default picks gives the same ranks
     wide, wide_it, _, _ = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
     assert wide_it.tolist() == iters.tolist()
     np.testing.assert_allclose(wide, rank, rtol=1e-13)
 
 
+@pytest.mark.parametrize("variant", list(NARROW_VARIANTS))
 @pytest.mark.parametrize("k_topics", [1, 2])
-def test_narrow_kernel_rmat_and_edge_cases(ss_ctx, oracle, k_topics):
-    with ss_ctx.options(pr__force_narrow=1):
+def test_narrow_kernel_rmat_and_edge_cases(ss_ctx, oracle, k_topics, variant):
+    with ss_ctx.options(**NARROW_VARIANTS[variant]):
         n, e = 20000, 100000
         ptr, dst = synth.rmat_graph(n, e, seed=100 + k_topics)
         n_topic = synth.topic_sizes(n, k_topics)
@@ -229,13 +234,14 @@ def test_sharded_layout_single_process(ss_ctx, oracle):
     from spaghettisearch_amd.sharding import LocalExchange, run_sharded
     n, e = 30000, 160000
     ptr, dst = synth.rmat_graph(n, e, seed=77)
-    n_topic = synth.topic_sizes(n, 5)
-    ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-9, n_topic)
     stream = torch.cuda.Stream()          # library kernels and the torch copies share one stream
     ss_ctx.set_stream(stream.cuda_stream)
     try:
         with torch.cuda.stream(stream):
-            for world in (2, 4):
+            # (K = 5: the 8-wide sweep; K = 2, 1: the wave-item kernel of one or two topics, whose shards also end in the two tail rows)
+            for world, kt in ((2, 5), (4, 5), (2, 2), (3, 1)):
+                n_topic = synth.topic_sizes(n, kt)
+                ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-9, n_topic)
                 graphs = [engine.Graph(ss_ctx, n, ptr, dst, rank=r, world=world) for r in range(world)]
                 infos = [g.info() for g in graphs]
                 assert sum(i.n_rows_local for i in infos) == n
