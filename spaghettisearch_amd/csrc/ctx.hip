@@ -275,6 +275,7 @@ static const char* const k_option_names[] = {
     "score.trace",          // 1: ss_score_topk prints the host phases of a call (copies in, plan, staging, launches) to stderr
     "pr.probe_hot",         // ss_pr_probe policies 3/4: rows below this index use the default cache policy
     "pr.topic_blocks",      // ss_pagerank_run_sharded: split K into this many topic blocks whose exchanges overlap the next block's sweep
+    "tfidf.fused",          // 0: weight + count pass, then a scatter over the weighted postings (round 3); default 1: count pass over the doc ids, weights multiplied inside the scatter
     "tfidf.blocks",         // workgroups of the bucketed magnitude pass (default 4096)
     "tfidf.bucket_shift",   // log2 docs per bucket (default 13, 14 beyond 33M docs)
     "tfidf.head_min_run",   // head lists (summed bucket-major in place): average postings per bucket run, 0 = off (default 64)

@@ -477,13 +477,29 @@ constexpr int SC_BPT_MAX = NB_MAX / SC_TPB;
 // LDS: rec[SC_CH] (8 B), then four tables of nbp = bpt * SC_TPB words (hist, loff, gout, cur), part[16], bkt[SC_CH] (2 B).
 // 10M docs (1221 buckets, bpt = 2): 64 + 32 + 16 KB, one workgroup per CU (4096-record chunks and two workgroups per CU measured 5 % slower).
 inline size_t scatter_lds_bytes(uint32_t bpt) { return (size_t)SC_CH * 8 + (size_t)4 * bpt * SC_TPB * 4 + 64 + (size_t)SC_CH * 2; }
-__global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__ post_doc, const float* __restrict__ post_w, uint64_t n_post,
-                                                 uint64_t per, int shift, uint32_t nb, uint32_t nblk, uint32_t bpt,
-                                                 const uint32_t* __restrict__ mat, const uint32_t* __restrict__ off, uint2* __restrict__ out,
-                                                 HeadArgs head) {
+// WEIGHT (round 4: weight and scatter in ONE pass over the postings): w = tf * idf is computed here, written back in place and
+// squared on the way into the record — the separate weighting pass read and wrote every tail posting once more (12 of its 36
+// bytes; the count pass in front of this kernel now reads doc ids only).  A thread takes SC_PT CONSECUTIVE postings, finds the
+// term of its first one in the chunk's term window (term starts relative to the chunk and their idf, staged in the LDS that holds
+// the sorted records later in the chunk) and walks on from there.
+#ifdef SS_SC_NO_NT
+#define SC_NT_LOAD(p) (*(p))
+#else
+#define SC_NT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+constexpr int SC_WIN = SC_CH;                  // term-window entries staged per chunk (a chunk spans at most SC_CH + 1 non-empty terms; beyond: global search)
+template <bool WEIGHT>
+__global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__ post_doc, float* __restrict__ post_w, uint64_t n_post,
+                                                    uint64_t per, int shift, uint32_t nb, uint32_t nblk, uint32_t bpt,
+                                                    const uint32_t* __restrict__ mat, const uint32_t* __restrict__ off, uint2* __restrict__ out,
+                                                    HeadArgs head, const uint64_t* __restrict__ term_ptr, uint64_t n_terms, const float* __restrict__ idf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_smem[];
+    __shared__ uint64_t s_t0;
+    __shared__ uint32_t s_need;
     const uint32_t nbp = bpt * SC_TPB;
     uint2* const L_rec = reinterpret_cast<uint2*>(sc_smem);
+    uint32_t* const s_tp = reinterpret_cast<uint32_t*>(sc_smem);            // [SC_WIN] WEIGHT: the chunk's term starts, relative to `base` ...
+    float* const s_idf = reinterpret_cast<float*>(sc_smem) + SC_WIN;         // [SC_WIN] ... and their idf (both in L_rec's bytes: used before the records are staged)
     uint32_t* const L_hist = reinterpret_cast<uint32_t*>(L_rec + SC_CH);   // records of the chunk per bucket (the returning add is also the record's rank)
     uint32_t* const L_loff = L_hist + nbp;                                 // first staging position of the bucket
     uint32_t* const L_gout = L_loff + nbp;                                 // where this chunk's run of the bucket starts in the output
@@ -496,6 +512,14 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
     }
     const uint64_t r0 = (uint64_t)blockIdx.x * per, r1 = min(n_post, r0 + per);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (WEIGHT && threadIdx.x == 0) {
+        uint64_t lo = 0, hi = n_terms;                                // largest t with term_ptr[t] <= r0 (once per block)
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (term_ptr[mid] <= r0) lo = mid; else hi = mid;
+        }
+        s_t0 = lo;
+    }
     // the next chunk's postings are requested before the current chunk goes through its LDS phases
     uint32_t ndoc[SC_PT];
     float nw[SC_PT];
@@ -504,37 +528,170 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
     uint32_t hcur = nh ? head_first(head, nh, r0) : 0u;
     bool n_empty = false;                                                  // the fetched chunk holds head postings only (uniform)
     HeadSkip hk = nh ? HeadSkip{0ull, 0ull, 0ull, 0ull} : HeadSkip{~0ull, ~0ull, ~0ull, ~0ull};
+    const uint32_t x0 = threadIdx.x * SC_PT;                               // this thread's first posting inside a chunk
     auto fetch = [&](uint64_t base) __attribute__((always_inline)) {
         n_empty = base >= r1;
         if (nh && base < r1) {
             head_skip(head, nh, hcur, base, hk);
             n_empty = hk.a_lo <= base && hk.a_hi >= min(r1, base + SC_CH);
         }
+        const uint64_t i0 = base + x0;
+        if (!n_empty && i0 + SC_PT <= r1) {                                // whole group inside the range: vector loads
 #pragma unroll
-        for (int j = 0; j < SC_PT; j++) {
-            const uint64_t i = base + (uint64_t)j * SC_TPB + threadIdx.x;
-            const bool ok = !n_empty && i < r1 && !(nh && hk.hit(i));
-            ndoc[j] = ok ? post_doc[i] : 0xFFFFFFFFu;
-            nw[j] = ok ? post_w[i] : 0.f;
+            for (int v4 = 0; v4 < SC_PT / 4; v4++) {
+                // streamed once: non-temporal, so that the postings do not push the half-written lines of the 1221 bucket runs this
+                // block keeps open out of the XCD's L2 before the next chunk completes them
+                typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+                typedef float f4_t __attribute__((ext_vector_type(4)));
+                const u4_t d = SC_NT_LOAD(reinterpret_cast<const u4_t*>(&post_doc[i0 + v4 * 4]));
+                const f4_t f = SC_NT_LOAD(reinterpret_cast<const f4_t*>(&post_w[i0 + v4 * 4]));
+                ndoc[v4 * 4] = d.x; ndoc[v4 * 4 + 1] = d.y; ndoc[v4 * 4 + 2] = d.z; ndoc[v4 * 4 + 3] = d.w;
+                nw[v4 * 4] = f.x; nw[v4 * 4 + 1] = f.y; nw[v4 * 4 + 2] = f.z; nw[v4 * 4 + 3] = f.w;
+            }
+#pragma unroll
+            for (int j = 0; j < SC_PT; j++)
+                if (nh && hk.hit(i0 + j)) ndoc[j] = 0xFFFFFFFFu;
+        } else {
+#pragma unroll
+            for (int j = 0; j < SC_PT; j++) {
+                const uint64_t i = i0 + j;
+                const bool ok = !n_empty && i < r1 && !(nh && hk.hit(i));
+                ndoc[j] = ok ? post_doc[i] : 0xFFFFFFFFu;
+                nw[j] = ok ? post_w[i] : 0.f;
+            }
         }
     };
     fetch(r0);
     __syncthreads();
+    // WEIGHT: the term window of the NEXT chunk is fetched while the current chunk goes through its LDS phases (two dependent loads —
+    // how far the terms reach, then their starts and idf — that cost every chunk ~4k cycles in front of the weight phase when they
+    // were made there).  One entry per thread: windows above SC_TPB terms (lists of under eight postings on average) are staged
+    // the slow way.  pf_ok: pf_tp / pf_idf hold the window of the chunk that starts at `base`, pf_need entries, first term pf_t0.
+    bool pf_ok = false;
+    uint32_t pf_need = 0;
+    uint64_t pf_t0 = 0, pf_tp = 0, pf_probe = 0;
+    float pf_idf = 0.f;
+    __shared__ uint32_t s_need_n;
     for (uint64_t base = r0; base < r1; base += SC_CH) {
         uint32_t doc[SC_PT], rank[SC_PT];
         float w[SC_PT];
 #pragma unroll
         for (int j = 0; j < SC_PT; j++) { doc[j] = ndoc[j]; w[j] = nw[j]; }
         const bool empty = n_empty;
+        const uint32_t h_here = hcur;                                      // the head range running at `base` (before the fetch moves on)
         fetch(base + SC_CH);
-        if (empty) continue;
+        const bool next_live = WEIGHT && !n_empty && base + SC_CH < r1;     // the next chunk will want a window
+        if (empty) {
+            if (WEIGHT) {                                                  // a chunk inside a head list: the next chunk's terms start at that list
+                __syncthreads();
+                if (threadIdx.x == 0) s_t0 = head.term[h_here];
+                __syncthreads();
+                pf_ok = false;
+            }
+            continue;
+        }
 #if defined(SS_EXP_SC) && SS_EXP_SC == 3      // timing experiments only (wrong results): loads alone
         if (doc[0] == 0x12345678u) out[0] = make_uint2(0u, __float_as_uint(w[0]));
         continue;
 #endif
+        if (WEIGHT) {
+            // (0) the chunk's term window, then w = tf * idf (term_weighting.go:42) for this thread's postings, written back in place
+            const uint32_t n_here = (uint32_t)min((uint64_t)SC_CH, r1 - base);
+            __syncthreads();                                               // the previous chunk's records (same bytes) have been written out
+            uint64_t t0;
+            uint32_t need;
+            if (pf_ok) {
+                t0 = pf_t0;
+                need = pf_need;
+                if (threadIdx.x < need) {
+                    s_tp[threadIdx.x] = pf_tp <= base ? 0u : (pf_tp - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(pf_tp - base));
+                    s_idf[threadIdx.x] = pf_idf;
+                }
+                if (threadIdx.x == 0) s_need_n = 0;
+            } else {
+                t0 = s_t0;                                                 // term of posting `base` or an earlier one
+                if (threadIdx.x == 0) { s_need = 0; s_need_n = 0; }
+                __syncthreads();
+                {                                                          // coarse probe: how far do the chunk's terms reach?
+                    const uint64_t t = t0 + 1 + (uint64_t)threadIdx.x * 8;
+                    const uint64_t v = t <= n_terms ? term_ptr[t] : ~0ull;
+                    if (v < base + n_here) atomicMax(&s_need, threadIdx.x + 1);
+                }
+                __syncthreads();
+                need = min((uint32_t)SC_WIN, s_need * 8 + 10);
+                for (uint32_t q = threadIdx.x; q < need; q += SC_TPB) {
+                    const uint64_t t = t0 + q;
+                    const uint64_t v = t <= n_terms ? term_ptr[t] : ~0ull;
+                    s_tp[q] = v <= base ? 0u : (v - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(v - base));
+                    s_idf[q] = t < n_terms ? idf[t] : 0.f;
+                }
+            }
+            __syncthreads();
+            if (x0 < n_here) {
+                uint32_t k = 0;
+                {
+                    uint32_t lo = 0, hi = need;                            // largest k with s_tp[k] <= x0 (s_tp[0] = 0)
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_tp[mid] <= x0) lo = mid; else hi = mid;
+                    }
+                    k = lo;
+                }
+                uint64_t t = t0 + k;
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < SC_PT; j++) {
+                    const uint32_t x = x0 + j;
+                    if (x >= n_here || doc[j] == 0xFFFFFFFFu) continue;    // past the range, or a head posting (weighted by k_bucket_sum)
+                    while (k + 1 < need && s_tp[k + 1] <= x) k++;
+                    t = t0 + k;
+                    float f = s_idf[k];
+                    if (k + 1 >= need) {                                   // past the staged window: rare (long runs of empty terms)
+                        uint64_t lo = t, hi = n_terms;
+                        const uint64_t i = base + x;
+                        if (term_ptr[hi] <= i) lo = hi;
+                        while (hi - lo > 1) {
+                            const uint64_t mid = (lo + hi) >> 1;
+                            if (term_ptr[mid] <= i) lo = mid; else hi = mid;
+                        }
+                        t = lo;
+                        f = idf[t];
+                    }
+                    w[j] = w[j] * f;                                       // term_weighting.go:42
+                    any = true;
+                }
+                const uint64_t i0 = base + x0;
+                bool all = x0 + SC_PT <= n_here;
+#pragma unroll
+                for (int j = 0; j < SC_PT; j++) all = all && doc[j] != 0xFFFFFFFFu;
+                if (all) {
+#pragma unroll
+                    for (int v4 = 0; v4 < SC_PT / 4; v4++)
+                        *reinterpret_cast<float4*>(&post_w[i0 + v4 * 4]) = make_float4(w[v4 * 4], w[v4 * 4 + 1], w[v4 * 4 + 2], w[v4 * 4 + 3]);
+                } else if (any) {
+#pragma unroll
+                    for (int j = 0; j < SC_PT; j++)
+                        if (x0 + j < n_here && doc[j] != 0xFFFFFFFFu) post_w[i0 + j] = w[j];
+                }
+                // the thread that holds the chunk's last posting knows where the next chunk's terms start (a lower bound is enough)
+                if (x0 + SC_PT >= n_here) s_t0 = t;
+            }
+            __syncthreads();                                               // the window's bytes become the record staging area
+            // the next chunk's window, first load: how far do its terms reach? (s_t0 now names its first term)
+            pf_ok = false;
+            if (next_live) {
+                pf_t0 = s_t0;
+                const uint64_t t = pf_t0 + 1 + (uint64_t)threadIdx.x * 8;
+                pf_probe = t <= n_terms ? term_ptr[t] : ~0ull;
+            }
+        }
         // (1) count; the returned value is the record's rank inside its bucket
 #pragma unroll
         for (int j = 0; j < SC_PT; j++) rank[j] = doc[j] != 0xFFFFFFFFu ? atomicAdd(&L_hist[doc[j] >> shift], 1u) : 0u;
+        if (WEIGHT && next_live) {
+            const uint64_t base_n = base + SC_CH;
+            if (pf_probe < base_n + min((uint64_t)SC_CH, r1 - base_n)) atomicMax(&s_need_n, threadIdx.x + 1);
+        }
         __syncthreads();
         // (2) exclusive scan of the counts -> staging offsets; claim this chunk's runs from the block's cursors
         uint32_t c[SC_BPT_MAX], run = 0;
@@ -565,6 +722,16 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
                 L_hist[b] = 0;
             }
         }
+        if (WEIGHT && next_live) {
+            // ... second load: the window itself (s_need_n is complete since the barrier behind the count phase)
+            pf_need = s_need_n * 8 + 10;
+            pf_ok = pf_need <= (uint32_t)SC_TPB;
+            if (pf_ok && threadIdx.x < pf_need) {
+                const uint64_t t = pf_t0 + threadIdx.x;
+                pf_tp = t <= n_terms ? term_ptr[t] : ~0ull;
+                pf_idf = t < n_terms ? idf[t] : 0.f;
+            }
+        }
         __syncthreads();
 #if defined(SS_EXP_SC) && SS_EXP_SC == 2      // ... loads, count and scan
         continue;
@@ -583,17 +750,17 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
         __syncthreads();
         // (4) out, in staging order: consecutive lanes write consecutive records of a bucket's run
         // (the staged records end where the last bucket's run ends; head postings were never staged)
-        const uint32_t n_here = nh ? L_loff[nbp - 1] + (L_cur[nbp - 1] - L_gout[nbp - 1]) : (uint32_t)min((uint64_t)SC_CH, r1 - base);
+        const uint32_t n_staged = L_loff[nbp - 1] + (L_cur[nbp - 1] - L_gout[nbp - 1]);
 #if defined(SS_EXP_SC) && SS_EXP_SC == 1      // ... everything but the stores
-        if (n_here == 0x12345678u) out[0] = L_rec[0];
+        if (n_staged == 0x12345678u) out[0] = L_rec[0];
         continue;
 #endif
-        for (uint32_t pos = threadIdx.x; pos < n_here; pos += SC_TPB) {
+        for (uint32_t pos = threadIdx.x; pos < n_staged; pos += SC_TPB) {
             const uint32_t b = L_bkt[pos];
             out[(uint64_t)L_gout[b] + (pos - L_loff[b])] = L_rec[pos];
         }
         // the next chunk's phase (1) only touches hist; its phase (2) rewrites loff / gout after the barrier that follows (1),
-        // by which time every thread has left (4)
+        // by which time every thread has left (4)  [WEIGHT: the barrier at the top of the weight phase comes before the window is staged]
     }
 }
 
@@ -783,7 +950,8 @@ int32_t bucket_pass_prepare(ss_ctx* ctx, uint64_t P, uint32_t nb, int shift, Buc
     }
     bp.bpt = ss::div_up(nb, (uint32_t)SC_TPB);
     if (ctx->tfidf_scatter_lds < (int)scatter_lds_bytes(bp.bpt)) {
-        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(bp.bpt)));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(bp.bpt)));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(bp.bpt)));
         ctx->tfidf_scatter_lds = (int)scatter_lds_bytes(bp.bpt);
     }
     if (ctx->tfidf_bucket_lds < (int)bucket_lds_bytes(shift)) {
@@ -808,14 +976,21 @@ void bucket_pass_launch(ss_index* idx, hipStream_t st, BucketPass& bp, bool weig
                            (const uint64_t*)bp.h_hs.p, (const uint64_t*)bp.h_he.p, bp.shift, bp.nb, bp.h_bounds.p);
         head = HeadArgs{bp.h_n.p, bp.h_term.p, bp.h_hs.p, bp.h_he.p, bp.h_bounds.p};
     }
-    if (weight) hipLaunchKernelGGL(k_weight_count<true>, dim3(bp.nblk), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
-                                   idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p, head);
+    // the count pass reads doc ids only; the weights are multiplied by k_scatter<true> on its way through the postings (option
+    // "tfidf.fused" = 0: the round-3 order — weight + count, then a scatter that reads the weighted postings again)
+    const bool fused = weight && idx->ctx->opt("tfidf.fused", 1) != 0;
+    if (weight && !fused) hipLaunchKernelGGL(k_weight_count<true>, dim3(bp.nblk), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
+                                             idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p, head);
     else hipLaunchKernelGGL(k_weight_count<false>, dim3(bp.nblk), dim3(TPB), 0, st, idx->term_ptr.p, T, idx->post_doc.p, idx->post_w.p,
                             idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p, head);
     hipLaunchKernelGGL(k_bucket_rowscan, dim3(bp.nb), dim3(64), 0, st, bp.mat.p, bp.nblk, bp.cnt.p);
     hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, bp.cnt.p, bp.nb, bp.off.p, bp.cur.p);
-    hipLaunchKernelGGL(k_scatter, dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.bpt), st, idx->post_doc.p, idx->post_w.p, P, bp.per, bp.shift, bp.nb,
-                       bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p, head);
+    if (fused) hipLaunchKernelGGL(k_scatter<true>, dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.bpt), st, (const uint32_t*)idx->post_doc.p, idx->post_w.p, P, bp.per,
+                                  bp.shift, bp.nb, bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p, head,
+                                  (const uint64_t*)idx->term_ptr.p, T, idf);
+    else hipLaunchKernelGGL(k_scatter<false>, dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.bpt), st, (const uint32_t*)idx->post_doc.p, idx->post_w.p, P, bp.per,
+                            bp.shift, bp.nb, bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p, head,
+                            (const uint64_t*)idx->term_ptr.p, T, idf);
     if (weight) hipLaunchKernelGGL(k_bucket_sum<true>, dim3(bp.nb), dim3(TPB_B), bucket_lds_bytes(bp.shift), st, bp.packed.p, bp.off.p, N, bp.shift,
                                    idx->mag.p, idx->mag2.p, (const uint32_t*)idx->post_doc.p, idx->post_w.p, idf, head);
     else hipLaunchKernelGGL(k_bucket_sum<false>, dim3(bp.nb), dim3(TPB_B), bucket_lds_bytes(bp.shift), st, bp.packed.p, bp.off.p, N, bp.shift,
