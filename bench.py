@@ -960,6 +960,22 @@ def main() -> None:
                         del rk_lib
                     except Exception as exc:
                         decomp["doc_range_shards_lib_pipelined"] = {"value": 0.0, "error": repr(exc)}
+                    # the same loop with float32 on the wire (option "pr.wire_f32": half the bytes per link; inside the 1e-6 gate but not
+                    # the reference's float64 arithmetic) — reported here only, never as `value`
+                    try:
+                        ctx.set_option("pr.wire_f32", 1)
+                        ent, rk32 = lib_pipelined(g2, n_topic, f"doc-range shards x{world}, topic blocks pipelined inside the library, contribution "
+                                                               f"slices as FLOAT32 on the wire (opt-in pr.wire_f32; not eligible as the headline)")
+                        if ent.get("exchange_bytes_per_rank"):
+                            ent["exchange_bytes_per_rank"] /= 2
+                            ent["predicted_exchange_ms_at_7x50GBs"] /= 2
+                        ent["never_the_headline"] = True
+                        decomp["f32_wire_doc_range_shards_lib_pipelined"] = ent
+                        del rk32
+                    except Exception as exc:
+                        decomp["f32_wire_doc_range_shards_lib_pipelined"] = {"value": 0.0, "error": repr(exc)}
+                    finally:
+                        ctx.set_option("pr.wire_f32", None)
                     for G in (2, 4):
                         S = world // G
                         if world % G or S < 2 or kt % G:

@@ -264,6 +264,8 @@ int32_t ss_set_stream(ss_ctx* ctx, void* hip_stream) {
 static const char* const k_option_names[] = {
     "comm.timeout_ms",      // longest wait for the other ranks: ss_comm_init, and every wait of the library for a stream that carries a collective (default 120000)
     "pr.force_narrow",      // 1: K <= 2 always runs the block-item kernel k_pr_step (tests reach it on small graphs)
+    "pr.wire_f32",          // 1: the doc-range-sharded sweep exchanges its contribution slices as float32 (half the bytes per link; inside the 1e-6 gate, not the
+                            //    reference's float64 arithmetic: opt-in, reported under bench.py's `decompositions` only).  Every rank must set it alike.
     "pr.narrow_wave",       // 0: K <= 2 as before round 4 (padded to the 8-wide sweep on small graphs, k_pr_step on large ones); default 1: k_pr_sweep_n
     "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)

@@ -1214,6 +1214,7 @@ __global__ __launch_bounds__(TPB) void k_pr_probe(const double* __restrict__ T, 
 struct ss_pr {
     ss_graph* g = nullptr;
     int gw = 1;            // lane-group width = padded topic count
+    ss::DevBuf<float> wire_send, wire_recv;   // option "pr.wire_f32": the contribution slice as float32 on the wire
     bool nwave = false;    // K <= 2 on the wave-item kernel k_pr_sweep_n (gw = K; the work items are those of the 8-wide sweep)
     int k = 1;
     PrParams prm{};
@@ -1442,6 +1443,51 @@ void launch_read(ss_pr* pr, hipStream_t st, int by_orig, uint64_t stride, uint32
                        pr->prm.pos_d,
                        (uint64_t)g->rank * g->sl_nd, g->nd_int + (uint64_t)g->rank * g->sl_d, pr->k, stride, by_orig, ids, out,
                        pr->prm.memb, pr->prm.ts_mask);
+}
+
+// ---- float32 on the wire (option "pr.wire_f32", opt-in; bench.py reports it under `decompositions` only) --------------------
+// The doc-range-sharded sweep is bound by the bytes a rank receives per sweep over its point-to-point xGMI links (VERDICT r3:
+// 52 MB per link at K = 16 whatever the world size).  With this option a rank's contribution slice travels as float32 — half the
+// bytes — and is widened again on arrival; the two tail rows of the slice (the rank's partial sums: normaliser and L1 change,
+// which every rank must combine identically and which decide the stop rule) travel as (hi, lo) float pairs, i.e. to ~2^-48.
+// Every rank decodes the SAME gathered floats, its own slice included, so the ranks stay in lockstep.  The ranks differ from the
+// float64 exchange by the rounding of the contributions (2^-24 relative each, averaging out in the sums): inside the 1e-6 parity
+// gate, not the reference's float64 arithmetic — which is why it is not the default.  Arithmetic on the device stays float64.
+__global__ void k_wire_pack(const double* __restrict__ send, uint32_t n_body, uint32_t n_tail, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_body) out[i] = (float)send[i];
+    else if (i < n_body + n_tail) {
+        const double d = send[i];
+        const float hi = (float)d;
+        out[n_body + 2 * (i - n_body)] = hi;
+        out[n_body + 2 * (i - n_body) + 1] = (float)(d - (double)hi);
+    }
+}
+// in: [world][n_body + 2 n_tail] floats -> table [world][n_body + n_tail] doubles
+__global__ void k_wire_unpack(const float* __restrict__ in, uint32_t world, uint32_t n_body, uint32_t n_tail, double* __restrict__ table) {
+    const uint64_t per_out = (uint64_t)n_body + n_tail, per_in = (uint64_t)n_body + 2ull * n_tail;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_out * world) return;
+    const uint64_t r = i / per_out, j = i % per_out;
+    const float* src = in + r * per_in;
+    table[i] = j < n_body ? (double)src[j] : (double)src[n_body + 2 * (j - n_body)] + (double)src[n_body + 2 * (j - n_body) + 1];
+}
+// floats a rank sends: the slice's body rows + its two tail rows as pairs
+size_t wire_floats(const ss_pr* pr) { return (size_t)pr->g->sl_nd * pr->gw + 2 * (size_t)pr->gw; }
+hipError_t wire_alloc(ss_pr* pr) {
+    if (pr->wire_send.p) return hipSuccess;
+    hipError_t e = pr->wire_send.alloc(wire_floats(pr));
+    if (e == hipSuccess) e = pr->wire_recv.alloc(wire_floats(pr) * (size_t)pr->g->world);
+    return e;
+}
+void wire_pack(ss_pr* pr, hipStream_t st) {
+    const uint32_t n_tail = 2u * (uint32_t)pr->gw, n_body = pr->g->sl_nd * (uint32_t)pr->gw - n_tail;
+    hipLaunchKernelGGL(k_wire_pack, dim3(ss::div_up((size_t)n_body + n_tail, TPB)), dim3(TPB), 0, st, (const double*)pr->send.p, n_body, n_tail, pr->wire_send.p);
+}
+void wire_unpack(ss_pr* pr, hipStream_t st) {
+    const uint32_t n_tail = 2u * (uint32_t)pr->gw, n_body = pr->g->sl_nd * (uint32_t)pr->gw - n_tail;
+    hipLaunchKernelGGL(k_wire_unpack, dim3(ss::div_up(((size_t)n_body + n_tail) * pr->g->world, TPB)), dim3(TPB), 0, st, (const float*)pr->wire_recv.p,
+                       (uint32_t)pr->g->world, n_body, n_tail, pr->tab0.p);
 }
 
 #define SS_GW_DISPATCH(gw, fn, ...)          \
@@ -1857,6 +1903,13 @@ int32_t ss_pr_exchange(ss_pr* pr, int32_t allreduce) {
         return ctx->fail(SS_ERR_STATE, "ss_pr_exchange: the context's communicator (rank %d of %d) does not match the graph's shard (rank %d of %d)",
                          ctx->comm ? ctx->comm_rank : -1, ctx->comm ? ctx->comm_world : 0, g->rank, g->world);
     const size_t slice = (size_t)g->sl_nd * pr->gw;            // doubles per rank
+    if (!allreduce && ctx->opt("pr.wire_f32", 0) != 0) {       // opt-in: float32 on the wire (see k_wire_pack)
+        SS_HIP(ctx, wire_alloc(pr));
+        wire_pack(pr, ctx->stream);
+        SS_TRY(ss::comm_allgather(ctx, pr->wire_send.p, pr->wire_recv.p, wire_floats(pr) * sizeof(float)));
+        wire_unpack(pr, ctx->stream);
+        return SS_OK;
+    }
     if (!allreduce) return ss::comm_allgather(ctx, pr->send.p, pr->tab0.p, slice * sizeof(double));
     // north-star form: own slice inside a zeroed full-size table, tables summed
     SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, pr->tab0.bytes(), ctx->stream));
@@ -2004,10 +2057,18 @@ int32_t ss_pagerank_run_sharded(ss_graph* g, double damping, double eps, int32_t
         rc = ss_pr_create(g, damping, eps, max_iter, k0[b + 1] - k0[b], n_topic + k0[b], &pr);
         if (rc == SS_OK) sh[0].blk.push_back(pr);
     }
+    const bool wire_f32 = ctx->opt("pr.wire_f32", 0) != 0;
     if (rc == SS_OK) {
         auto exchange = [&](int b, hipStream_t xs) -> int32_t {
             ss_pr* pr = sh[0].blk[b];
             const size_t slice = (size_t)g->sl_nd * pr->gw;            // doubles per rank
+            if (!allreduce && wire_f32) {
+                SS_HIP(ctx, wire_alloc(pr));
+                wire_pack(pr, xs);
+                SS_TRY(ss::comm_allgather_on(ctx, pr->wire_send.p, pr->wire_recv.p, wire_floats(pr) * sizeof(float), xs));
+                wire_unpack(pr, xs);
+                return SS_OK;
+            }
             if (!allreduce) return ss::comm_allgather_on(ctx, pr->send.p, pr->tab0.p, slice * sizeof(double), xs);
             // north-star form: own slice inside a zeroed full-size table, tables summed
             SS_HIP(ctx, hipMemsetAsync(pr->tab0.p, 0, pr->tab0.bytes(), xs));
@@ -2050,7 +2111,24 @@ int32_t ss_pagerank_run_group(ss_graph* const* shards, int32_t world, double dam
         }
     if (rc == SS_OK) {
         // the all-gather, by hand: every shard's slice into every shard's table, rank order
+        const bool wire_f32 = ctx->opt("pr.wire_f32", 0) != 0;
         auto exchange = [&](int b, hipStream_t xs) -> int32_t {
+            if (wire_f32) {                                         // the float32 wire format, played by device-to-device copies
+                for (int src = 0; src < world; src++) {
+                    SS_HIP(ctx, wire_alloc(sh[src].blk[b]));
+                    wire_pack(sh[src].blk[b], xs);
+                }
+                for (int dst = 0; dst < world; dst++) {
+                    ss_pr* to = sh[dst].blk[b];
+                    for (int src = 0; src < world; src++) {
+                        ss_pr* from = sh[src].blk[b];
+                        SS_HIP(ctx, hipMemcpyAsync(to->wire_recv.p + (size_t)src * wire_floats(from), from->wire_send.p, wire_floats(from) * sizeof(float),
+                                                   hipMemcpyDeviceToDevice, xs));
+                    }
+                    wire_unpack(to, xs);
+                }
+                return SS_OK;
+            }
             for (int dst = 0; dst < world; dst++)
                 for (int src = 0; src < world; src++) {
                     ss_pr* from = sh[src].blk[b];

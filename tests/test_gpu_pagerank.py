@@ -297,6 +297,36 @@ def test_in_library_pipelined_sharded_run(ss_ctx, oracle, world):
             g.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_float32_wire_exchange_stays_inside_the_gate(ss_ctx, oracle, world):
+    """VERDICT r3 #6b, option "pr.wire_f32" (opt-in): the sharded sweep's contribution slices cross the links as float32, the tail
+    rows (partial sums) as (hi, lo) float pairs.  Not the reference's float64 arithmetic, so not the default — but inside the
+    parity gate: ranks within 1e-6 relative of the oracle, iteration counts within one; and deterministic run to run."""
+    from spaghettisearch_amd import engine
+    n, e = 60000, 400000
+    ptr, dst = synth.rmat_graph(n, e, seed=91)
+    graphs = [engine.Graph(ss_ctx, n, ptr, dst, rank=r, world=world) for r in range(world)]
+    try:
+        for k_topics in (16, 5, 2, 1):
+            n_topic = synth.topic_sizes(n, k_topics)
+            ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-6, n_topic)
+            exact, exact_iters = engine.Graph.pagerank_group(graphs, D, 1e-6, n_topic)
+            with ss_ctx.options(pr__wire_f32=1):
+                rank, iters = engine.Graph.pagerank_group(graphs, D, 1e-6, n_topic)
+                rank2, iters2 = engine.Graph.pagerank_group(graphs, D, 1e-6, n_topic)
+            assert np.abs(iters - ref_iters).max() <= 1, (k_topics, iters, ref_iters)
+            same_it = iters == ref_iters
+            if same_it.any():
+                np.testing.assert_allclose(rank[same_it], ref[same_it], rtol=1e-6)
+            assert rank.tobytes() == rank2.tobytes() and iters.tolist() == iters2.tolist()
+            assert rank.tobytes() != exact.tobytes()                     # the option took effect ...
+            assert exact_iters.tolist() == ref_iters.tolist()            # ... and the default is untouched
+            np.testing.assert_allclose(exact, ref, rtol=1e-12)
+    finally:
+        for g in graphs:
+            g.close()
+
+
 def _mp_worker(rank, world, port, n, e, n_topic, out_path):
     """One process per shard, all on cuda:0: the production driver (sharding.iterate + DistExchange +
     gather_ranks) with the real HIP states; gloo + host-staged exchange stand in for RCCL."""
