@@ -135,7 +135,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--edges", type=int, default=50_000_000)
     ap.add_argument("--topics", type=int, default=16)
@@ -748,6 +748,21 @@ def main() -> None:
             tail_df = int(sum((h_bptr[t + 1] - h_bptr[t]) + (h_tptr[t + 1] - h_tptr[t]) for t in tq_terms.astype(np.int64)))
             topk["tail_queries"] = {"value": world * nq * K / dtt, "unit": "queries/s", "ms_per_step": dtt * 1e3 / K,
                                     "workload": f"{nq} x 3-term OR queries, term ranks U[1,{nt}]", "postings_per_query": tail_df / nq}
+
+            # ---- mixed batches: term ranks over the first 100k terms (long and short lists in one query: the batch runs in
+            #      k_score_slices), and a batch that is half head / half tail queries (split per query between the two scoring kernels,
+            #      which run side by side on two streams)
+            mq_ptr, mq_terms = synth.make_queries(nq, 3, min(100_000, nt), seed=2045 + rank)
+            hq = nq // 2
+            hh_ptr = np.concatenate([q_ptr[:hq + 1], tq_ptr[1:nq - hq + 1] + q_ptr[hq]]).astype(np.uint32)
+            hh_terms = np.concatenate([q_terms[:q_ptr[hq]], tq_terms[:tq_ptr[nq - hq]]]).astype(np.uint32)
+            ctx.set_option("score.timing", 0)
+            for key_, (qp_, qt_), what_ in (("mixed_queries", (mq_ptr, mq_terms), f"{nq} x 3-term OR queries, term ranks U[1,{min(100_000, nt)}]"),
+                                            ("half_head_half_tail", (hh_ptr, hh_terms), f"{hq} queries of term ranks U[1,10000] + {nq - hq} of U[1,{nt}] in one batch")):
+                dtm, _ = timed_blocks(lambda m: batches(m, qp_, qt_), n_blocks=1)
+                dfm = int(sum((h_bptr[t + 1] - h_bptr[t]) + (h_tptr[t + 1] - h_tptr[t]) for t in qt_.astype(np.int64)))
+                topk[key_] = {"value": world * nq * K / dtm, "unit": "queries/s", "ms_per_step": dtm * 1e3 / K, "workload": what_, "postings_per_query": dfm / nq}
+            ctx.set_option("score.timing", None)
 
             # ---- blended run (BASELINE config 5): same index and queries + PageRank prior, per-query topicProbs
             kt5 = args.topics

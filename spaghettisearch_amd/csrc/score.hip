@@ -1802,7 +1802,11 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
         // (a lone query or two — under ~400k postings — finish sooner in k_score_slices: 0.143 against 0.166 ms for two head queries,
         //  host in / host out; from four queries on the wave kernel leads, 0.21 against 0.31 ms)
-        batch_wave = wml == 0 ? fit > 0 : (fit * 10 >= all * 9 && all >= 400000);
+        // "score.wave_share_pct": the share of the batch's postings the suited queries must carry (default 90; with device outputs
+        // the two kernels of a split batch run side by side on two streams, so a split no longer pays two ramp-ups and tails one
+        // after the other)
+        const uint64_t share = (uint64_t)std::max<int64_t>(0, std::min<int64_t>(100, ctx->opt("score.wave_share_pct", 90)));
+        batch_wave = wml == 0 ? fit > 0 : (fit * 100 >= all * share && fit >= 400000);
     }
     std::vector<uint8_t> h_fast(n_q, 0);
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
@@ -2046,7 +2050,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // writes the hits — sits on the caller's stream, the results are complete in stream order like before.  [Round 3 had it the
     // other way round (merge on a side stream that the caller's stream did not wait for): faster by the same amount, but the hits
     // were only complete after ss_synchronize.]
-    const bool pipe = dev_out && n_fast_slices == n_slices && !h_mergeq.empty() && !any_phrase && ctx->opt("score.pipeline", 2) != 0;
+    // A batch split between the two scoring kernels (queries that do not suit k_score_wave: short lists, phrases, many terms) is
+    // pipelined too: its k_score_slices part — which writes its queries' hits itself — runs on the caller's stream BESIDE the wave
+    // kernel, the wave queries' merge follows behind both.
+    const bool pipe = dev_out && n_fast_slices > 0 && !h_mergeq.empty() && ctx->opt("score.pipeline", 2) != 0;
     // The upload goes out on the context's SECOND stream as soon as the plan is staged — beside the kernels of the previous
     // batch, which read the other device buffer.  (On the one stream the copy sat
     // between two batches: 39 us per batch in the kernel trace with the counter memset, 6 % of the wall time at config 3.)

@@ -7,8 +7,8 @@ set -u
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
-args="bench.py --steps 20 --warmup 3 --cpu-seconds 2"
-pmc_args="bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+args="bench.py"
+pmc_args="bench.py --no-cpu-baseline"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt -o kt -- python3 $args > $out/${tag}_bench_line_under_rocprof.json 2> $out/${tag}_kt.err || exit 1
 find $out/${tag}_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats_bench_full.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do
