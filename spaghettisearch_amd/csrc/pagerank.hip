@@ -914,14 +914,22 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
         NVec<KW> acc;
 #pragma unroll
         for (int k = 0; k < KW; k++) acc.v[k] = 0.0;
-        for (uint32_t e = w.beg; e < w.end; e += 256) {
-            uint32_t src[4];
+        // (the index words of the next 256 edges are requested before the gathers of the current ones are consumed)
+        uint32_t src_n[4];
+        auto idx256 = [&](uint32_t e, uint32_t (&src)[4]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t j = e + (uint32_t)(u * 64 + lane);
                 const uint32_t raw = NT_LOAD(&in_src[j < w.end ? j : w.beg]);
                 src[u] = j < w.end ? (raw & SRC_MASK) : p.zrow;
             }
+        };
+        idx256(w.beg, src_n);
+        for (uint32_t e = w.beg; e < w.end; e += 256) {
+            uint32_t src[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) src[u] = src_n[u];
+            idx256(e + 256, src_n);                                       // (past the end: four loads of the first edge, dropped)
             NVec<KW> v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) v[u] = ntab<KW>(c.T, src[u]);
@@ -977,14 +985,21 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
                 NVec<KW> acc;
 #pragma unroll
                 for (int k = 0; k < KW; k++) acc.v[k] = 0.0;
-                for (uint32_t ch = 0; ch < w.nseg; ch += 2) {           // two turns (32 edge slots of the row) per trip: four gathers per lane
-                    uint32_t src[4];
+                uint32_t src_n[4];
+                auto idx32 = [&](uint32_t ch, uint32_t (&src)[4]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const uint32_t j = b + ch * 16u + (uint32_t)(u * 8 + gl);
                         const uint32_t raw = NT_LOAD(&in_src[j < e_end ? j : b]);
                         src[u] = j < e_end ? (raw & SRC_MASK) : p.zrow;
                     }
+                };
+                idx32(0, src_n);
+                for (uint32_t ch = 0; ch < w.nseg; ch += 2) {           // two turns (32 edge slots of the row) per trip: four gathers per lane
+                    uint32_t src[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) src[u] = src_n[u];
+                    idx32(ch + 2, src_n);                               // the next trip's index words travel with this trip's gathers
                     NVec<KW> v[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) v[u] = ntab<KW>(c.T, src[u]);
