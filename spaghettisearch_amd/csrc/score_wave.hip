@@ -207,6 +207,19 @@ __device__ __noinline__ void wave_compact(int k) {
     topk_compact_inl(tk, k);
 }
 
+// sqd for the benchmark's 16 topics: the row's 16 doubles and the 16 probabilities requested together (the loop of runtime length
+// waits for every product's two loads in turn), the products added in topic order as the loop adds them.  A CALL, so that its
+// 64 registers of operands are not live beside the exact stage's own.
+__device__ __noinline__ double prior_dot16(gptr_f64 pr, gptr_f64 pb) {
+    double r[16], q[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) { r[t] = pr[t]; q[t] = pb[t]; }
+    double sqd = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) sqd += q[t] * r[t];
+    return sqd;
+}
+
 // ---- exact stage of one wave (flush_pending / score_owned of score.hip for 64 threads) ------------------------------
 __device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& tk, const SliceQuery& Q, const RareArgs& ra, int lane,
                                                  uint32_t doc, uint32_t slot) {
@@ -231,6 +244,8 @@ __device__ __forceinline__ void wave_score_owned(const WaveLds& S, const TopK& t
             if (fkey(fin) >= thr0 || fin != fin) {
                 double sqd = 0.0;                        // topic_dot (get_metadata.go:39-42, topic order) through global pointers
                 const gptr_f64 pr = (gptr_f64)kp->prior + (size_t)e_doc * kp->k_topics, pb = (gptr_f64)Q.probs;
+                if (kp->k_topics == 16) sqd = prior_dot16(pr, pb);
+                else
                 for (int t = 0; t < kp->k_topics; t++) sqd += pb[t] * pr[t];
                 final_rank(T, B, mt, mb, Q.qmag, sqd, title, body, fin);
             }
