@@ -167,6 +167,7 @@ namespace ss {
 // most 64 GiB (of 288; option "mem.pool_mb" on any context changes it for the process, 0 switches it off).
 hipError_t pool_alloc(void** p, size_t bytes);
 void pool_free(void* p);
+void pool_free_batch(void* const* blocks, size_t count);   // one device-wide wait for all of them
 void pool_set_limit(size_t bytes);
 void pool_trim();
 void pool_context_count(int delta);
@@ -190,6 +191,12 @@ struct DevBuf {
         if (p) pool_free(p);
         p = nullptr;
         n = 0;
+    }
+    void* detach() {                                  // the block changes owner (ss_graph::defer)
+        void* q = p;
+        p = nullptr;
+        n = 0;
+        return q;
     }
     hipError_t alloc(size_t count) {
         release();

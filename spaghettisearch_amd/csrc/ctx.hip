@@ -67,6 +67,18 @@ hipError_t pool_alloc(void** out, size_t bytes) {
     return e;
 }
 
+static thread_local bool t_device_idle = false;     // pool_free_batch: one device-wide wait covers the whole batch
+
+void pool_free_batch(void* const* blocks, size_t count) {
+    if (!count) return;
+    if (device_wedged()) return;
+    // (one device at a time: the blocks of a batch belong to one graph)
+    (void)hipDeviceSynchronize();
+    t_device_idle = true;
+    for (size_t i = 0; i < count; i++) pool_free(blocks[i]);
+    t_device_idle = false;
+}
+
 void pool_free(void* p) {
     if (!p) return;
     Pool& P = pool();
@@ -84,9 +96,11 @@ void pool_free(void* p) {
     if (cls && cls <= limit / 2) {                         // a block larger than half the limit is not worth holding
         int cur = 0;
         (void)hipGetDevice(&cur);
-        if (cur != dev) (void)hipSetDevice(dev);
-        (void)hipDeviceSynchronize();
-        if (cur != dev) (void)hipSetDevice(cur);
+        if (cur != dev || !t_device_idle) {
+            if (cur != dev) (void)hipSetDevice(dev);
+            (void)hipDeviceSynchronize();
+            if (cur != dev) (void)hipSetDevice(cur);
+        }
         // over the limit: the LARGEST held blocks make room (a few big tables of an earlier, larger job must not keep every
         // small block of the current one out of the pool: that cost config 2's create + run 2 ms after config 4 had run)
         std::vector<void*> evict;
@@ -270,8 +284,10 @@ static const char* const k_option_names[] = {
     "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
     "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 65536, 0 = off)
-    "pr.deal_snake",        // work items dealt to the waves in alternating direction (1) or least-loaded-first (0); default: 1 from 8 items per wave on
+    "pr.deal_snake",        // work items dealt to the waves in alternating direction (1) or least-loaded-first (0); default: 1 from 8 items per wave on and for k_pr_sweep_n
     "pr.item_turns",        // turns per V_DEG work item of k_pr_sweep (V_QUAD: twice that); default 4 up to 4M local rows, 8 beyond
+    "graph.late_free",      // 0: ss_graph_create waits for its last kernels and frees its temporaries before it returns (default 1: they are freed
+                            //    at the graph's next use, the caller's host work overlaps the row permutation)
     "pr.trace",             // 1: ss_graph_create / ss_pr_create print their phase times to stderr
     "score.timing",         // 0: ss_score_topk records no timing events (ss_last_kernel_ms(1) keeps its last value)
     "score.trace",          // 1: ss_score_topk prints the host phases of a call (copies in, plan, staging, launches) to stderr

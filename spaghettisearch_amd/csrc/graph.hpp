@@ -67,6 +67,19 @@ struct ss_graph {
     };
     SortedDegrees h_indeg_nd, h_indeg_d;
 
+    // Temporaries of the build that its last kernels may still be reading when ss_graph_create returns (option "graph.late_free"):
+    // freed by settle() — at the graph's next use that allocates (ss_pr_create after its host work, ss_graph_apply_delta) or when
+    // the graph goes.  Everything that reads the graph's arrays runs on the context's stream behind those kernels.
+    std::vector<void*> late_free;
+    template <typename T>
+    void defer(ss::DevBuf<T>& b) { if (b.p) late_free.push_back(b.detach()); }
+    void settle() {
+        if (late_free.empty()) return;
+        ss::pool_free_batch(late_free.data(), late_free.size());
+        late_free.clear();
+    }
+    ~ss_graph() { settle(); }
+
     uint32_t n_local() const { return sl_nd + sl_d; }
     // internal id of local row
     uint64_t int_id(uint32_t lrow) const {

@@ -1271,10 +1271,13 @@ void build_work(const ss_graph* g, int gw, bool lane_rows, int64_t item_turns_de
     seg_edges = 128 * NSLOT;
     nsegs = 0;
     nmulti = 0;
-    std::vector<WorkItem> seg, rwg, wav, grp, zer;
+    // (scratch kept per thread across calls: freshly reserved vectors of a few MB cost more in page faults — 0.7 ms at 10M nodes — than
+    //  the items cost to make)
+    static thread_local std::vector<WorkItem> seg, rwg, wav, grp, zer;
 
     // gw >= 8: wave-owned items of k_pr_sweep.  deg is sorted descending.
-    std::vector<WorkItem> vseg, vroww, vquad, vdeg[3], vzero;
+    static thread_local std::vector<WorkItem> vseg, vroww, vquad, vdeg[3], vzero;
+    for (auto* v : {&seg, &rwg, &wav, &grp, &zer, &vseg, &vroww, &vquad, &vdeg[0], &vdeg[1], &vdeg[2], &vzero}) v->clear();
     // deg is sorted descending and run-length encoded: rows from r on with deg > lim (the caller's row r is one of them)
     auto run_above = [](const ss_graph::SortedDegrees& deg, uint32_t r, uint32_t lim) -> uint32_t {
         const uint32_t end = deg.first_at_most(lim);
@@ -1348,12 +1351,6 @@ void build_work(const ss_graph* g, int gw, bool lane_rows, int64_t item_turns_de
         if (non_dangling)
             for (uint32_t r = c; r < cnt; r += ZERO_ROWS) zer.push_back({W_ZERO, row0 + r, std::min<uint32_t>(ZERO_ROWS, cnt - r), 0, 0, 0});
     };
-    {
-        const size_t rows_all = g->h_indeg_nd.size() + g->h_indeg_d.size();
-        vquad.reserve(rows_all / 64 + 1024);
-        for (auto& v : vdeg) v.reserve(rows_all / 256 + 1024);
-        vzero.reserve(rows_all / 64 + 1024);
-    }
     emit(g->h_indeg_nd, 0, true, pos_nd);
     const size_t vquad_split = vquad.size();            // the non-dangling rows' groups (falling length), then the dangling rows'
     emit(g->h_indeg_d, g->sl_nd, false, pos_d);
@@ -1561,7 +1558,9 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         SS_HIP(ctx, hipMemsetAsync(pr->send.p, 0, std::max<size_t>(pr->send.bytes(), 8), st));
     }
     const auto tc0 = t_now();
-    std::vector<WorkItem> items;
+    static thread_local std::vector<WorkItem> items, dealt;       // (scratch kept per thread across calls, see build_work)
+    static thread_local std::vector<double> cost;
+    static thread_local std::vector<uint32_t> owner;
     uint32_t nsegs = 0, nmulti = 0, seg_edges = 0, pos_nd = 0, pos_d = 0;
     uint32_t vbeg[7] = {0};
     // item granularity (measured, sweep ms at 2 / 4 / 8 / 16 / 32 turns per V_DEG item): 2^20 nodes, 5M edges, K=1: 0.078 / 0.077 / 0.096 /
@@ -1594,7 +1593,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     per_cu = (int)std::max<int64_t>(1, ctx->opt("pr.blocks_per_cu", per_cu));
     pr->nblocks = vitems ? (unsigned)std::min<size_t>(ss::div_up(items.size(), (size_t)WAVES), (size_t)ctx->cu_count * per_cu)
                           : (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
-    std::vector<uint32_t> woff;
+    static thread_local std::vector<uint32_t> woff, cnt;
+    woff.clear();
     if (vitems) {
         // k_pr_sweep: the items' turn counts (from the sorted in-degrees the graph keeps on the host), then the items dealt to the
         // grid's waves; the edge ranges are filled in on the device (k_pr_item_ranges)
@@ -1603,7 +1603,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
             return lrow < g->sl_nd ? (lrow < g->h_indeg_nd.size() ? g->h_indeg_nd[lrow] : 0u)
                                    : (lrow - g->sl_nd < g->h_indeg_d.size() ? g->h_indeg_d[lrow - g->sl_nd] : 0u);
         };
-        std::vector<double> cost(items.size());
+        cost.assign(items.size(), 0.0);
         const auto td0 = t_now();
         for (size_t i = 0; i < items.size(); i++) {
             const WorkItem& w = items[i];
@@ -1629,32 +1629,46 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         // chunk's items in table order (costliest first inside a class) to the least loaded waves first — the longest-processing-
         // time rule applied per chunk, one sort of nw loads per chunk instead of a heap operation per item (3 ms -> 0.4 ms at
         // 60k items / 3072 waves, same balance: every wave ends within one item of the mean).
-        std::vector<uint32_t> owner(items.size());
+        owner.assign(items.size(), 0u);
         {
-            std::vector<double> load(nw, 0.0);
-            std::vector<uint32_t> by_load(nw);
+            static thread_local std::vector<double> load;
+            static thread_local std::vector<uint32_t> by_load, idx;
+            static thread_local std::vector<std::pair<double, uint32_t>> key;
+            load.assign(nw, 0.0);
+            by_load.resize(nw);
             for (uint32_t w = 0; w < nw; w++) by_load[w] = w;
             // Many chunks (a large graph): the loads are not sorted between chunks, every other chunk is dealt in reverse — costs fall
             // smoothly inside a class, so the snake ends as level as the sorted deal (config 4: sweep 0.960 against 0.963 ms) and the
-            // deal takes 0.3 ms of host time instead of 2.8.  Few chunks: least-loaded-first as before (config 2: 0.075 against 0.077 ms).
-            const bool snake = ctx->opt("pr.deal_snake", items.size() >= (size_t)8 * nw ? 1 : 0) != 0;
+            // deal takes 0.3 ms of host time instead of 2.8.  Few chunks: least-loaded-first as before (config 2 on k_pr_sweep<8>: 0.075
+            // against 0.077 ms); k_pr_sweep_n's finer items sweep the same either way and the update is 0.1 ms shorter with the snake.
+            const bool snake = ctx->opt("pr.deal_snake", items.size() >= (size_t)8 * nw || pr->nwave ? 1 : 0) != 0;
             for (size_t i0 = 0; i0 < items.size(); i0 += nw) {
                 const size_t n_chunk = std::min<size_t>(nw, items.size() - i0);
                 if (i0 && snake) {
                     std::reverse(by_load.begin(), by_load.end());
                 } else if (i0) {
                     // (load, wave) pairs sorted by value: several times faster than a comparator that reads load[] through the ids
-                    std::vector<std::pair<double, uint32_t>> key(nw);
+                    key.resize(nw);
                     for (uint32_t w = 0; w < nw; w++) key[w] = {load[w], w};
                     std::sort(key.begin(), key.end());
                     for (uint32_t w = 0; w < nw; w++) by_load[w] = key[w].second;
                 }
                 // the chunk's costliest item to the least loaded wave: order the chunk by falling cost (it already is, except
                 // where it crosses a class boundary)
-                std::vector<uint32_t> idx(n_chunk);
+                // (a few falling runs: merged pairwise, O(chunk) per boundary — a full stable_sort of the chunk through cost[] took
+                //  0.15 ms a chunk, most of config 2's deal)
+                idx.resize(n_chunk);
                 for (size_t j = 0; j < n_chunk; j++) idx[j] = (uint32_t)(i0 + j);
-                if (!std::is_sorted(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; }))
-                    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+                const auto falling = [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; };
+                size_t run_end = 0, n_merge = 0;
+                for (size_t j = 1; j <= n_chunk; j++) {
+                    if (j < n_chunk && !(cost[i0 + j] > cost[i0 + j - 1])) continue;     // still falling (or level)
+                    if (run_end) {
+                        if (++n_merge > 8) { std::stable_sort(idx.begin(), idx.end(), falling); break; }
+                        std::inplace_merge(idx.begin(), idx.begin() + (ptrdiff_t)run_end, idx.begin() + (ptrdiff_t)j, falling);
+                    }
+                    run_end = j;
+                }
                 for (size_t j = 0; j < n_chunk; j++) {
                     owner[idx[j]] = by_load[j];
                     load[by_load[j]] += cost[idx[j]];
@@ -1666,7 +1680,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         // table order inside a wave's list = item order = class order: count per (wave, class), offsets, place
         auto cls = [&](size_t i) { int k = 0; while (k < 5 && i >= vbeg[k + 1]) k++; return k; };
         woff.assign((size_t)nw * 8, 0);
-        std::vector<uint32_t> cnt((size_t)nw * 8, 0);
+        cnt.assign((size_t)nw * 8, 0);
         for (size_t i = 0; i < items.size(); i++) cnt[(size_t)owner[i] * 8 + cls(i)]++;
         uint32_t run_off = 0;
         for (uint32_t w = 0; w < nw; w++) {
@@ -1676,13 +1690,15 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                 cnt[(size_t)w * 8 + k] = woff[(size_t)w * 8 + k];       // becomes the write cursor of (wave, class)
             }
         }
-        std::vector<WorkItem> dealt(items.size());
+        dealt.resize(items.size());
         for (size_t i = 0; i < items.size(); i++) dealt[cnt[(size_t)owner[i] * 8 + cls(i)]++] = items[i];
         dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});              // the pipelines read two items ahead
         dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});
         items.swap(dealt);
     }
 
+    // the graph's build temporaries (ss_graph::late_free): its last kernels ran under the host work above
+    g->settle();
     const auto tc2 = t_now();
     const unsigned begin_blocks = std::max(1u, std::min(2048u, ss::div_up(n_local * GW, TPB)));
     SS_HIP(ctx, pr->partials.alloc(((size_t)std::max(pr->nblocks, begin_blocks) + 8) * 2 * GW));   // block rows + 8 group rows
