@@ -51,13 +51,36 @@ __global__ void k_scatter_runs(const uint32_t* __restrict__ uniq, const uint32_t
 
 // sort key per node: class (dangling last), in-degree descending; the sort is stable and the values start as the ids in
 // ascending order, so equal keys keep ascending original id
-__global__ void k_row_keys(const uint32_t* __restrict__ outdeg, const uint32_t* __restrict__ indeg, uint64_t n,
+// (the in-degree takes deg_bits bits — no in-degree exceeds the edge count —, the class the bit above: the sort runs over deg_bits + 1)
+__global__ void k_row_keys(const uint32_t* __restrict__ outdeg, const uint32_t* __restrict__ indeg, uint64_t n, uint32_t deg_bits,
                            uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const uint32_t cls = outdeg[v] == 0 ? 1u : 0u;
-    keys[v] = (cls << 31) | (0x7FFFFFFFu - min(indeg[v], 0x7FFFFFFFu));
+    const uint32_t top = (1u << deg_bits) - 1u;
+    keys[v] = (cls << deg_bits) | (top - min(indeg[v], top));
     ids[v] = (uint32_t)v;
+}
+
+// Everything the host reads back at the end of the build in one block (one copy, one wait): four row offsets, the two run counts,
+// and the first `spec` (value, length) runs of each class's in-degrees.  Layout: [4 x u64 | 2 x u32 | pad to 64 B | class 0 values |
+// class 0 lengths | class 1 values | class 1 lengths], each run array `spec` words.
+__global__ void k_pack_readback(const uint64_t* __restrict__ in_ptr_int, uint64_t p0, uint64_t p1, uint64_t p2, uint64_t p3,
+                                const uint32_t* __restrict__ r_n, const uint32_t* __restrict__ v0, const uint32_t* __restrict__ c0,
+                                const uint32_t* __restrict__ v1, const uint32_t* __restrict__ c1, uint32_t spec, unsigned char* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(out);
+        o[0] = in_ptr_int[p0]; o[1] = in_ptr_int[p1]; o[2] = in_ptr_int[p2]; o[3] = in_ptr_int[p3];
+        uint32_t* q = reinterpret_cast<uint32_t*>(out + 32);
+        q[0] = r_n[0]; q[1] = r_n[1];
+    }
+    uint32_t* runs = reinterpret_cast<uint32_t*>(out + 64);
+    const uint32_t n0 = min(r_n[0], spec), n1 = min(r_n[1], spec);
+    for (uint32_t j = t; j < spec; j += gridDim.x * blockDim.x) {
+        if (j < n0) { runs[j] = v0[j]; runs[spec + j] = c0[j]; }
+        if (j < n1) { runs[2 * spec + j] = v1[j]; runs[3 * spec + j] = c1[j]; }
+    }
 }
 
 // sorted position -> internal id (round-robin deal over ranks inside each class)
@@ -253,13 +276,16 @@ inline unsigned grid_for(uint64_t n, unsigned cap = 65535u * 16u) {
 }
 
 // stable LSD radix sort of (key, value) pairs on the low `end_bit` bits of the key; enqueues only (tmp must outlive the sort)
+// (rocprim's default hands up to 1M items to its merge sort — ~26 small kernels, 155 us for config 2's 1M nodes; from 128K items on
+//  the radix passes are shorter.  Both are stable: the order is the same.)
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 128 * 1024>;
 int32_t sort_pairs_u32(ss_ctx* ctx, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, uint64_t n, unsigned end_bit,
                        ss::DevBuf<char>& tmp) {
     if (n == 0) return SS_OK;
     size_t tmp_bytes = 0;
-    SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, ctx->stream));
+    SS_HIP(ctx, rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, ctx->stream));
     SS_HIP(ctx, tmp.alloc(tmp_bytes));
-    SS_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, ctx->stream));
+    SS_HIP(ctx, rocprim::radix_sort_pairs<SortConfig>(tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, ctx->stream));
     return SS_OK;
 }
 inline unsigned bits_for(uint64_t n) { unsigned b = 1; while (b < 32 && ((uint64_t)1 << b) < n) b++; return b; }
@@ -375,8 +401,9 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     }
     const auto tg1b = t_now();
     // ---- node order ---------------------------------------------------------
-    if (n) hipLaunchKernelGGL(k_row_keys, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_outdeg.p, d_indeg.p, n, keys_a.p, vals_a.p);
-    SS_TRY(sort_pairs_u32(ctx, keys_a.p, keys_b.p, vals_a.p, vals_b.p, n, 32, sort_tmp1));
+    const uint32_t deg_bits = std::min(31u, bits_for(e + 1));
+    if (n) hipLaunchKernelGGL(k_row_keys, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, d_outdeg.p, d_indeg.p, n, deg_bits, keys_a.p, vals_a.p);
+    SS_TRY(sort_pairs_u32(ctx, keys_a.p, keys_b.p, vals_a.p, vals_b.p, n, deg_bits + 1, sort_tmp1));
 
     ss::DevBuf<uint32_t> indeg_int;
     SS_HIP(ctx, g->new_id.alloc(n));
@@ -436,15 +463,13 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
         SS_HIP(ctx, rocprim::run_length_encode(nullptr, tmp_bytes, indeg_int.p + id0[c], cnt[c], r_val[c].p, r_cnt[c].p, r_n.p + c, st));
         SS_HIP(ctx, r_tmp[c].alloc(tmp_bytes));
         SS_HIP(ctx, rocprim::run_length_encode(r_tmp[c].p, tmp_bytes, indeg_int.p + id0[c], cnt[c], r_val[c].p, r_cnt[c].p, r_n.p + c, st));
-        const size_t spec = std::min<size_t>(RLE_SPEC, cnt[c]);
-        SS_HIP(ctx, hipMemcpyAsync(h_spec + (size_t)(2 * c) * RLE_SPEC, r_val[c].p, spec * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipMemcpyAsync(h_spec + (size_t)(2 * c + 1) * RLE_SPEC, r_cnt[c].p, spec * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
-    SS_HIP(ctx, hipMemcpyAsync(h_nruns, r_n.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_ptr[0], in_ptr_int.p + id0_nd, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_ptr[1], in_ptr_int.p + id0_nd + g->sl_nd, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_ptr[2], in_ptr_int.p + id0_d, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&h_ptr[3], in_ptr_int.p + id0_d + g->sl_d, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ss::DevBuf<unsigned char> d_pack;
+    SS_HIP(ctx, d_pack.alloc(pin_bytes));
+    hipLaunchKernelGGL(k_pack_readback, dim3(ss::div_up(RLE_SPEC, TPB)), dim3(TPB), 0, st, (const uint64_t*)in_ptr_int.p, id0_nd, id0_nd + g->sl_nd,
+                       id0_d, id0_d + g->sl_d, (const uint32_t*)r_n.p, (const uint32_t*)r_val[0].p, (const uint32_t*)r_cnt[0].p,
+                       (const uint32_t*)r_val[1].p, (const uint32_t*)r_cnt[1].p, RLE_SPEC, d_pack.p);
+    SS_HIP(ctx, hipMemcpyAsync(pin_blk, d_pack.p, pin_bytes, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t e_nd = h_ptr[1] - h_ptr[0], e_d = h_ptr[3] - h_ptr[2];
     g->e_local_nd = e_nd;
@@ -500,6 +525,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
         g->defer(e_dst); g->defer(e_src); g->defer(ptr_orig); g->defer(n_runs); g->defer(rle_tmp); g->defer(scan_tmp1); g->defer(scan_tmp2);
         g->defer(indeg_int); g->defer(in_ptr_int); g->defer(r_n);
         for (int c = 0; c < 2; c++) { g->defer(r_val[c]); g->defer(r_cnt[c]); g->defer(r_tmp[c]); }
+        g->defer(d_pack);
     } else {
         SS_HIP(ctx, hipStreamSynchronize(st));
     }

@@ -1278,11 +1278,6 @@ void build_work(const ss_graph* g, int gw, bool lane_rows, int64_t item_turns_de
     // gw >= 8: wave-owned items of k_pr_sweep.  deg is sorted descending.
     static thread_local std::vector<WorkItem> vseg, vroww, vquad, vdeg[3], vzero;
     for (auto* v : {&seg, &rwg, &wav, &grp, &zer, &vseg, &vroww, &vquad, &vdeg[0], &vdeg[1], &vdeg[2], &vzero}) v->clear();
-    // deg is sorted descending and run-length encoded: rows from r on with deg > lim (the caller's row r is one of them)
-    auto run_above = [](const ss_graph::SortedDegrees& deg, uint32_t r, uint32_t lim) -> uint32_t {
-        const uint32_t end = deg.first_at_most(lim);
-        return end > r ? end - r : 0u;
-    };
     auto emit_v = [&](const ss_graph::SortedDegrees& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
         const uint32_t T_MULTI = 4096, T_DEG = 8;
@@ -1290,35 +1285,52 @@ void build_work(const ss_graph* g, int gw, bool lane_rows, int64_t item_turns_de
         // turns per V_DEG item (a V_QUAD item: twice that): small graphs want finer items — with ~20 turns per wave in all, an
         // item of 16 leaves the deal nothing to balance ("pr.item_turns"; default from the graph's size, see ss_pr_create)
         const uint32_t item_turns = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(64, g->ctx->opt("pr.item_turns", item_turns_default)));
+        // (rows and limits only move forward: two cursors over the degree runs instead of a bisection per item — the bisections were
+        //  most of the 0.8 ms this took at config 4)
+        size_t j_at = 0, j_lim = 0;
+        const size_t n_run = deg.val.size();
+        auto deg_at = [&](uint32_t r) -> uint32_t {              // in-degree of row r (r < cnt, never smaller than the last call's)
+            while (deg.start[j_at + 1] <= r) j_at++;
+            return deg.val[j_at];
+        };
+        auto end_above = [&](uint32_t lim) -> uint32_t {         // first row with in-degree <= lim (lim never larger than the last call's)
+            while (j_lim < n_run && deg.val[j_lim] > lim) j_lim++;
+            return deg.start[j_lim];
+        };
         uint32_t r = 0;
-        for (; r < cnt && deg[r] > T_MULTI; r++) {
-            const uint32_t ns = (deg[r] + SEGW - 1) / SEGW;
+        for (; r < cnt && deg_at(r) > T_MULTI; r++) {
+            const uint32_t ns = (deg_at(r) + SEGW - 1) / SEGW;
             const uint32_t tix = nmulti++;
             for (uint32_t s = 0; s < ns; s++) vseg.push_back({V_SEG, row0 + r, s, ns, nsegs, tix});
             nsegs += ns;
         }
-        for (; r < cnt && deg[r] > T_QUAD; r++) vroww.push_back({V_ROWW, row0 + r, 0, 0, 0, 0});
+        {
+            const uint32_t end = std::min(cnt, end_above(T_QUAD));
+            for (; r < end; r++) vroww.push_back({V_ROWW, row0 + r, 0, 0, 0, 0});
+        }
         // one row per lane group and turn; an item's rows all take nch = ceil(longest / 16) turns, at most gw row groups
         // and about 32 turns per item
-        while (r < cnt && deg[r] > T_DEG) {
-            const uint32_t nch = (deg[r] + CH - 1) / CH;
+        while (r < cnt && deg_at(r) > T_DEG) {
+            const uint32_t nch = (deg_at(r) + CH - 1) / CH;
             const uint32_t max_groups = std::min<uint32_t>((uint32_t)gw, std::max<uint32_t>(1u, 2u * item_turns / nch));
-            // rows of the same turn count nch: in-degree > (nch - 1) * CH (and > T_DEG), found by bisection in the sorted degrees
+            // rows of the same turn count nch: in-degree > (nch - 1) * CH (and > T_DEG)
             const uint32_t lim = std::max<uint32_t>(T_DEG, (nch - 1) * CH);
-            const uint32_t same = run_above(deg, r, lim);
+            const uint32_t end = end_above(lim);
+            const uint32_t same = end > r ? end - r : 0u;
             const uint32_t rows = std::min<uint32_t>(same, max_groups * NSLOT);
             vquad.push_back({V_QUAD, row0 + r, rows, nch, 0, 0});
             r += rows;
         }
         // exact-degree runs
-        while (r < cnt && deg[r] > 0) {
-            const uint32_t D = deg[r];
-            // deg is sorted descending: the run of rows with exactly D in-edges ends at the first smaller degree
-            const uint32_t run = run_above(deg, r, D - 1);
+        while (r < cnt && deg_at(r) > 0) {
+            const uint32_t D = deg_at(r);
+            // deg is sorted descending and run-length encoded: the rows with exactly D in-edges end with r's run
+            const uint32_t run = deg.start[j_at + 1] - r;
             const uint32_t R = D <= 2 ? 8 : D <= 4 ? 4 : 2;
             // (k_pr_sweep_n gives every LANE a row: whole waves of 64 rows per item there)
             const uint32_t per_item = lane_rows ? 64u * item_turns : NSLOT * R * item_turns;
-            for (uint32_t o = 0; o < run; o += per_item) vdeg[R == 2 ? 0 : R == 4 ? 1 : 2].push_back({V_DEG, row0 + r + o, std::min(per_item, run - o), D, 0, 0});
+            auto& out = vdeg[R == 2 ? 0 : R == 4 ? 1 : 2];
+            for (uint32_t o = 0; o < run; o += per_item) out.push_back({V_DEG, row0 + r + o, std::min(per_item, run - o), D, 0, 0});
             r += run;
         }
         n_pos = r;
@@ -1599,10 +1611,18 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         // k_pr_sweep: the items' turn counts (from the sorted in-degrees the graph keeps on the host), then the items dealt to the
         // grid's waves; the edge ranges are filled in on the device (k_pr_item_ranges)
         const uint32_t NS = 64 / GI;
-        auto deg_of = [&](uint32_t lrow) -> uint32_t {
-            return lrow < g->sl_nd ? (lrow < g->h_indeg_nd.size() ? g->h_indeg_nd[lrow] : 0u)
-                                   : (lrow - g->sl_nd < g->h_indeg_d.size() ? g->h_indeg_d[lrow - g->sl_nd] : 0u);
-        };
+        // (rows rise inside a class's items: a cursor per degree table, a bisection only when a row steps back)
+        struct DegCursor {
+            const ss_graph::SortedDegrees* d;
+            size_t j = 0;
+            uint32_t at(uint32_t r) {
+                if (r >= d->size()) return 0u;
+                if (d->start[j] > r) j = d->run_of(r);
+                while (d->start[j + 1] <= r) j++;
+                return d->val[j];
+            }
+        } cur_nd{&g->h_indeg_nd}, cur_d{&g->h_indeg_d};
+        auto deg_of = [&](uint32_t lrow) -> uint32_t { return lrow < g->sl_nd ? cur_nd.at(lrow) : cur_d.at(lrow - g->sl_nd); };
         cost.assign(items.size(), 0.0);
         const auto td0 = t_now();
         for (size_t i = 0; i < items.size(); i++) {
@@ -1678,10 +1698,13 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         const auto td1 = t_now();
         if (trace) fprintf(stderr, "[pr trace]   deal: occupancy query %.2f ms, costs + owners %.2f ms\n", t_ms(tc1, tc1a), t_ms(td0, td1));
         // table order inside a wave's list = item order = class order: count per (wave, class), offsets, place
-        auto cls = [&](size_t i) { int k = 0; while (k < 5 && i >= vbeg[k + 1]) k++; return k; };
+        // (the items are in class order: owner[i] * 8 + class, computed once per class range)
         woff.assign((size_t)nw * 8, 0);
         cnt.assign((size_t)nw * 8, 0);
-        for (size_t i = 0; i < items.size(); i++) cnt[(size_t)owner[i] * 8 + cls(i)]++;
+        for (int k = 0; k < 6; k++) {
+            const size_t i1 = k < 5 ? std::min<size_t>(vbeg[k + 1], items.size()) : items.size();
+            for (size_t i = std::min<size_t>(vbeg[k], i1); i < i1; i++) { owner[i] = owner[i] * 8 + (uint32_t)k; cnt[owner[i]]++; }
+        }
         uint32_t run_off = 0;
         for (uint32_t w = 0; w < nw; w++) {
             for (int k = 0; k < 8; k++) {
@@ -1691,7 +1714,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
             }
         }
         dealt.resize(items.size());
-        for (size_t i = 0; i < items.size(); i++) dealt[cnt[(size_t)owner[i] * 8 + cls(i)]++] = items[i];
+        for (size_t i = 0; i < items.size(); i++) dealt[cnt[owner[i]]++] = items[i];
         dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});              // the pipelines read two items ahead
         dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});
         items.swap(dealt);
