@@ -105,72 +105,146 @@ __global__ void k_assign_ids(const uint32_t* __restrict__ sorted_ids, uint64_t n
     indeg_int[id] = indeg[v];
 }
 
-// Edge i of the out-edge CSR -> its parent (original id).  A block takes EK_CHUNK consecutive edges, finds the rows they span
-// with two binary searches, and every edge finds its row inside that short range.
+// The rows of EK_CHUNK consecutive CSR positions [base, last] (the block's chunk): thread t gets the rows of its EK_PT consecutive
+// positions base + EK_PT * t + k, row = the largest r with ptr[r] <= position.  The rows the chunk spans come from k_chunk_first_rows
+// (chunk_row[c] = the row that holds position c * EK_CHUNK); every row that STARTS inside the chunk marks its first position in LDS
+// (atomicMax: of several rows starting at one position — empty rows — the last one owns it), and a running maximum over the
+// positions hands every position its row.  [A bisection per edge over the spanned rows, ~10 dependent loads from L2 each, took
+// 0.52 ms for config 4's 50M edges; two bisections per block by two threads still 0.17 ms.]
 constexpr int EK_PT = 8, EK_CHUNK = TPB * EK_PT;
-__global__ __launch_bounds__(TPB) void k_edge_parents(const uint64_t* __restrict__ out_ptr, uint64_t n, uint64_t e, uint32_t* __restrict__ parent) {
-    __shared__ uint64_t s_r[2];
+template <typename PtrT>
+__global__ void k_chunk_first_rows(const PtrT* __restrict__ ptr, uint64_t n_rows, uint64_t e_total, uint32_t* __restrict__ chunk_row) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint64_t a = ptr[r], b = ptr[r + 1];
+    if (b <= a) return;
+    for (uint64_t c = (a + EK_CHUNK - 1) / EK_CHUNK; c * EK_CHUNK < b; c++) chunk_row[c] = (uint32_t)r;
+    if (b == e_total) chunk_row[(e_total + EK_CHUNK - 1) / EK_CHUNK] = (uint32_t)r;      // the row of the last position: the last chunk's end
+}
+template <typename PtrT>
+__device__ __forceinline__ uint32_t chunk_rows(const PtrT* __restrict__ ptr, const uint32_t* __restrict__ chunk_row, uint64_t base, uint64_t last,
+                                               uint32_t* s_row, uint32_t* s_w, uint32_t (&rel)[EK_PT]) {
+    {
+        uint4* z = reinterpret_cast<uint4*>(s_row) + threadIdx.x * (EK_PT / 4);
+#pragma unroll
+        for (int k = 0; k < EK_PT / 4; k++) z[k] = make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t r_lo = chunk_row[blockIdx.x], r_hi = chunk_row[blockIdx.x + 1];
+    if (r_hi - r_lo > 4u * EK_CHUNK) {
+        // A long stretch of EMPTY rows inside the chunk (the zero-in-degree tail of a class: millions of rows in front of the next
+        // class's first edge): walking them to mark nothing kept one block busy for 2 ms.  A bisection per position instead.
+#pragma unroll
+        for (int k = 0; k < EK_PT; k++) {
+            const uint64_t i = base + (uint64_t)threadIdx.x * EK_PT + k;
+            uint32_t lo = r_lo, hi = r_hi + 1;                         // ptr[lo] <= i < ptr[hi] (positions past `last`: unused)
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if ((uint64_t)ptr[mid] <= i) lo = mid; else hi = mid;
+            }
+            rel[k] = lo - r_lo;
+        }
+        return r_lo;
+    }
+    __syncthreads();
+    // (a row that holds or starts at the NEXT chunk's first position is in the range too: past `last`, skipped)
+    for (uint64_t r = (uint64_t)r_lo + 1 + threadIdx.x; r <= r_hi; r += TPB) {
+        const uint64_t at = ptr[r];
+        if (at <= last) atomicMax(&s_row[at - base], (uint32_t)(r - r_lo));
+    }
+    __syncthreads();
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(s_row) + threadIdx.x * (EK_PT / 4);
+#pragma unroll
+        for (int k = 0; k < EK_PT / 4; k++) {
+            const uint4 v = q[k];
+            rel[4 * k] = v.x; rel[4 * k + 1] = v.y; rel[4 * k + 2] = v.z; rel[4 * k + 3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int k = 1; k < EK_PT; k++) rel[k] = max(rel[k], rel[k - 1]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = rel[EK_PT - 1];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl = max(incl, o);
+    }
+    if (lane == 63) s_w[wave] = incl;
+    uint32_t before = __shfl_up(incl, 1);
+    if (lane == 0) before = 0;
+    __syncthreads();
+    for (int w = 0; w < wave; w++) before = max(before, s_w[w]);
+#pragma unroll
+    for (int k = 0; k < EK_PT; k++) rel[k] = max(rel[k], before);
+    return r_lo;
+}
+
+// Edge i of the out-edge CSR -> its parent (original id): the row of position i.
+__global__ __launch_bounds__(TPB) void k_edge_parents(const uint64_t* __restrict__ out_ptr, const uint32_t* __restrict__ chunk_row, uint64_t e,
+                                                      uint32_t* __restrict__ parent) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_row[EK_CHUNK];
+    __shared__ uint32_t s_w[TPB / 64];
     const uint64_t base = (uint64_t)blockIdx.x * EK_CHUNK;
     if (base >= e) return;
     const uint64_t last = min(base + EK_CHUNK, e) - 1;
-    if (threadIdx.x < 2) {
-        const uint64_t target = threadIdx.x == 0 ? base : last;      // largest p with out_ptr[p] <= target
-        uint64_t lo = 0, hi = n;
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (out_ptr[mid] <= target) lo = mid; else hi = mid;
-        }
-        s_r[threadIdx.x] = lo;
-    }
-    __syncthreads();
-    const uint64_t r_lo = s_r[0], r_hi = s_r[1];
-#pragma unroll 4
-    for (int j = 0; j < EK_PT; j++) {
-        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
-        if (i > last) break;
-        uint64_t lo = r_lo, hi = r_hi + 1;                            // out_ptr[lo] <= i < out_ptr[hi]
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (out_ptr[mid] <= i) lo = mid; else hi = mid;
-        }
-        parent[i] = (uint32_t)lo;
+    uint32_t rel[EK_PT];
+    const uint64_t r_lo = chunk_rows(out_ptr, chunk_row, base, last, s_row, s_w, rel);
+    const uint64_t i0 = base + (uint64_t)threadIdx.x * EK_PT;
+    if (i0 + EK_PT - 1 <= last) {
+        uint4* o = reinterpret_cast<uint4*>(parent + i0);              // (base is a multiple of EK_CHUNK: 32-byte aligned)
+#pragma unroll
+        for (int k = 0; k < EK_PT / 4; k++)
+            o[k] = make_uint4((uint32_t)r_lo + rel[4 * k], (uint32_t)r_lo + rel[4 * k + 1], (uint32_t)r_lo + rel[4 * k + 2], (uint32_t)r_lo + rel[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < EK_PT; k++)
+            if (i0 + k <= last) parent[i0 + k] = (uint32_t)r_lo + rel[k];
     }
 }
 // The in-edge lists of this rank's rows, in internal ids, from the edges sorted by ORIGINAL destination (srcs_by_dst: the
 // parents of node v are srcs_by_dst[ptr_orig[v] .. ptr_orig[v + 1]), ascending original id): local row r is original node
 // old_id[int_id(r)], its list moves as a piece and every parent is renamed.  One thread per local edge slot; the block finds the
 // rows its chunk spans like k_edge_parents.
-__global__ __launch_bounds__(TPB) void k_permute_rows(const uint32_t* __restrict__ in_ptr, uint32_t n_local, uint64_t e_local,
+__global__ __launch_bounds__(TPB) void k_permute_rows(const uint32_t* __restrict__ in_ptr, const uint32_t* __restrict__ chunk_row, uint64_t e_local,
                                                       const uint32_t* __restrict__ old_id, uint32_t sl_nd, uint64_t id0_nd, uint64_t id0_d,
                                                       const uint64_t* __restrict__ ptr_orig, const uint32_t* __restrict__ srcs_by_dst,
                                                       const uint32_t* __restrict__ new_id, uint32_t* __restrict__ in_src) {
-    __shared__ uint32_t s_r[2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_row[EK_CHUNK];
+    __shared__ uint32_t s_w[TPB / 64];
     const uint64_t base = (uint64_t)blockIdx.x * EK_CHUNK;
     if (base >= e_local) return;
     const uint64_t last = min(base + EK_CHUNK, e_local) - 1;
-    if (threadIdx.x < 2) {
-        const uint64_t target = threadIdx.x == 0 ? base : last;      // largest r with in_ptr[r] <= target
-        uint32_t lo = 0, hi = n_local;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint64_t)in_ptr[mid] <= target) lo = mid; else hi = mid;
-        }
-        s_r[threadIdx.x] = lo;
+    uint32_t rel[EK_PT];
+    const uint32_t r_lo = chunk_rows(in_ptr, chunk_row, base, last, s_row, s_w, rel);
+    // the rows go back to LDS and every thread takes slots TPB apart: a wave's loads and stores then fall on consecutive words
+    // (with 8 consecutive slots per thread the lanes sat 32 bytes apart, 16 lines per load instead of 2: 2.2 ms instead of 0.8)
+    {
+        uint4* q = reinterpret_cast<uint4*>(s_row) + threadIdx.x * (EK_PT / 4);
+#pragma unroll
+        for (int k = 0; k < EK_PT / 4; k++) q[k] = make_uint4(rel[4 * k], rel[4 * k + 1], rel[4 * k + 2], rel[4 * k + 3]);
     }
     __syncthreads();
-    const uint32_t r_lo = s_r[0], r_hi = s_r[1];
-#pragma unroll 4
-    for (int j = 0; j < EK_PT; j++) {
-        const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
-        if (i > last) break;
-        uint32_t lo = r_lo, hi = r_hi + 1;                            // in_ptr[lo] <= i < in_ptr[hi]
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint64_t)in_ptr[mid] <= i) lo = mid; else hi = mid;
-        }
+    uint32_t src[EK_PT];
+    uint64_t off[EK_PT];                                               // srcs_by_dst index of slot i = off + i (mod 2^64)
+#pragma unroll
+    for (int k = 0; k < EK_PT; k++) {
+        const uint64_t i = base + (uint64_t)k * TPB + threadIdx.x;
+        const uint32_t lo = i <= last ? r_lo + s_row[k * TPB + threadIdx.x] : r_lo;
         const uint64_t iid = lo < sl_nd ? id0_nd + lo : id0_d + (lo - sl_nd);
-        const uint32_t v = old_id[iid];                               // a real row: it has in-edges
-        in_src[i] = new_id[srcs_by_dst[ptr_orig[v] + (i - in_ptr[lo])]];
+        src[k] = old_id[iid];                                         // a real row: it has in-edges
+        off[k] = (uint64_t)in_ptr[lo];
+    }
+#pragma unroll
+    for (int k = 0; k < EK_PT; k++) off[k] = ptr_orig[src[k]] - off[k];
+#pragma unroll
+    for (int k = 0; k < EK_PT; k++) {
+        const uint64_t i = base + (uint64_t)k * TPB + threadIdx.x;
+        src[k] = i <= last ? srcs_by_dst[off[k] + i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < EK_PT; k++) {
+        const uint64_t i = base + (uint64_t)k * TPB + threadIdx.x;
+        if (i <= last) in_src[i] = new_id[src[k]];
     }
 }
 
@@ -375,13 +449,16 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     if (e >= 0xFFFFFFFFull) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_graph_create: more than 2^32 - 2 edges");
     ss::DevBuf<uint32_t> e_dst, e_src;           // the sorted pairs (kept until the rows are permuted)
     ss::DevBuf<uint64_t> ptr_orig;               // [n + 1] exclusive scan of the in-degrees over original ids
+    ss::DevBuf<uint32_t> chunk_row;              // [chunks + 1] the row that holds each chunk's first edge (k_chunk_first_rows)
     ss::DevBuf<uint32_t> n_runs;                 // (temporaries of the enqueued primitives live to the end of the function: no wait in between)
     ss::DevBuf<char> rle_tmp, scan_tmp1, scan_tmp2;
     SS_HIP(ctx, ptr_orig.alloc(n + 1));
     if (e) {
         SS_HIP(ctx, e_dst.alloc(e));
         SS_HIP(ctx, e_src.alloc(e));
-        hipLaunchKernelGGL(k_edge_parents, dim3(ss::div_up(e, EK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)d_out_ptr, n, e, vals_a.p);
+        SS_HIP(ctx, chunk_row.alloc((size_t)ss::div_up(e, EK_CHUNK) + 1));
+        hipLaunchKernelGGL(k_chunk_first_rows<uint64_t>, dim3(ss::div_up(n, TPB)), dim3(TPB), 0, st, (const uint64_t*)d_out_ptr, n, e, chunk_row.p);
+        hipLaunchKernelGGL(k_edge_parents, dim3(ss::div_up(e, EK_CHUNK)), dim3(TPB), 0, st, (const uint64_t*)d_out_ptr, (const uint32_t*)chunk_row.p, e, vals_a.p);
         SS_TRY(sort_pairs_u32(ctx, const_cast<uint32_t*>(d_out_dst), e_dst.p, vals_a.p, e_src.p, e, bits_for(n), sort_tmp2));
         SS_HIP(ctx, n_runs.alloc(1));
         size_t tmp_bytes = 0;
@@ -482,8 +559,14 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     SS_HIP(ctx, g->outdeg.alloc(g->sl_nd));
     hipLaunchKernelGGL(k_local_ptr, dim3(ss::div_up((uint64_t)n_local + 1, TPB)), dim3(TPB), 0, st, in_ptr_int.p, g->sl_nd,
                        g->sl_d, id0_nd, id0_d, h_ptr[0], h_ptr[2], e_nd, g->in_ptr.p);
+    ss::DevBuf<uint32_t> chunk_row_in;
+    if (g->e_local) {
+        SS_HIP(ctx, chunk_row_in.alloc((size_t)ss::div_up(g->e_local, EK_CHUNK) + 1));
+        hipLaunchKernelGGL(k_chunk_first_rows<uint32_t>, dim3(ss::div_up(n_local, TPB)), dim3(TPB), 0, st, (const uint32_t*)g->in_ptr.p, (uint64_t)n_local,
+                           g->e_local, chunk_row_in.p);
+    }
     if (g->e_local)
-        hipLaunchKernelGGL(k_permute_rows, dim3(ss::div_up(g->e_local, EK_CHUNK)), dim3(TPB), 0, st, (const uint32_t*)g->in_ptr.p, n_local, g->e_local,
+        hipLaunchKernelGGL(k_permute_rows, dim3(ss::div_up(g->e_local, EK_CHUNK)), dim3(TPB), 0, st, (const uint32_t*)g->in_ptr.p, (const uint32_t*)chunk_row_in.p, g->e_local,
                            (const uint32_t*)g->old_id.p, g->sl_nd, id0_nd, id0_d, (const uint64_t*)ptr_orig.p, (const uint32_t*)e_src.p,
                            (const uint32_t*)g->new_id.p, g->in_src.p);
     if (g->e_local)
@@ -525,7 +608,7 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
         g->defer(e_dst); g->defer(e_src); g->defer(ptr_orig); g->defer(n_runs); g->defer(rle_tmp); g->defer(scan_tmp1); g->defer(scan_tmp2);
         g->defer(indeg_int); g->defer(in_ptr_int); g->defer(r_n);
         for (int c = 0; c < 2; c++) { g->defer(r_val[c]); g->defer(r_cnt[c]); g->defer(r_tmp[c]); }
-        g->defer(d_pack);
+        g->defer(d_pack); g->defer(chunk_row); g->defer(chunk_row_in);
     } else {
         SS_HIP(ctx, hipStreamSynchronize(st));
     }
