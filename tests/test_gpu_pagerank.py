@@ -110,6 +110,32 @@ def test_skewed_rows_block_per_segment(ss_ctx, oracle):
     np.testing.assert_allclose(rank16, ref16, rtol=1e-12)
 
 
+@pytest.mark.parametrize("k_topics", [1, 16])
+def test_graph_build_chunk_rows(ss_ctx, oracle, k_topics):
+    # ss_graph_create finds the row of every edge slot per 2048-slot chunk (k_chunk_first_rows + LDS marks + running maximum,
+    # a bisection where a chunk holds a long stretch of empty rows).  A graph built to hit the corners: rows that start exactly
+    # on chunk boundaries, rows spanning several chunks, > 8192 edge-less rows inside one chunk in BOTH directions (dangling
+    # sources in id order; non-dangling pages nobody links to, which sort to the end of their class), an edge count that is a
+    # multiple of the chunk, and the last row ending at the last slot.
+    n = 120000
+    edges = []
+    hubs = list(range(100000, 100008))
+    for s in range(3):                                             # three sources with exactly 2048 children: rows on chunk boundaries
+        edges += [(s, 50000 + j) for j in range(2048)]
+    edges += [(3, 20000 + j) for j in range(5000)]                 # a row over several chunks
+    # sources 4 .. 29999 have no out-edges (dangling, a 26k-row empty stretch in the out-edge CSR)
+    edges += [(s, hubs[s % 8]) for s in range(30000, 60000)]       # 30k non-dangling pages with no in-edges of their own (50000.. get some)
+    edges += [(s, s + 1) for s in range(110000, 110100)]
+    fill = (-len(edges)) % 2048
+    edges += [(n - 1, 70000 + j) for j in range(fill)]             # the last row ends at the last slot of the last chunk
+    assert len(edges) % 2048 == 0 and len(set(edges)) == len(edges)
+    ptr, dst = csr(n, edges)
+    n_topic = synth.topic_sizes(n, k_topics)
+    rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-12)
+
+
 def test_edge_cases(ss_ctx, oracle):
     # no edges at all: every node dangling (pagerank.go:131-134)
     ptr = np.zeros(11, dtype=np.uint64)
