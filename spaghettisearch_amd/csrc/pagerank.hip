@@ -1642,6 +1642,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
             }
             cost[i] = turns + 1.0;                                   // + the item's own overhead
         }
+        const auto td0a = t_now();
         // Longest-processing-time deal: items in table order (classes by falling item length), each to the wave with the
         // least work so far — every wave ends up with the same number of turns (+- one item), whatever the degree mix.
         const uint32_t nw = pr->nblocks * WAVES;
@@ -1662,6 +1663,21 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
             // deal takes 0.3 ms of host time instead of 2.8.  Few chunks: least-loaded-first as before (config 2 on k_pr_sweep<8>: 0.075
             // against 0.077 ms); k_pr_sweep_n's finer items sweep the same either way and the update is 0.1 ms shorter with the snake.
             const bool snake = ctx->opt("pr.deal_snake", items.size() >= (size_t)8 * nw || pr->nwave ? 1 : 0) != 0;
+            // All items by falling cost first ("pr.deal_global", default on): a counting sort on the cost in sixteenths of a turn,
+            // stable (table order inside a bucket), O(items).  The chunks below then come sorted.  [Sorting each chunk took 0.2 of
+            // config 2's 0.4 ms here: inside a class the costs fall, but every run of equal rows ends in a short item, so a chunk
+            // is dozens of falling runs, not one.]
+            static thread_local std::vector<uint32_t> order, bucket;
+            const bool global_order = ctx->opt("pr.deal_global", 1) != 0;
+            if (global_order) {
+                constexpr uint32_t NB = 1u << 14;
+                const auto key = [&](size_t i) { return NB - 1 - (uint32_t)std::min<double>(cost[i] * 16.0, (double)(NB - 1)); };
+                bucket.assign(NB + 1, 0u);
+                for (size_t i = 0; i < items.size(); i++) bucket[key(i) + 1]++;
+                for (uint32_t b = 0; b < NB; b++) bucket[b + 1] += bucket[b];
+                order.resize(items.size());
+                for (size_t i = 0; i < items.size(); i++) order[bucket[key(i)]++] = (uint32_t)i;
+            }
             for (size_t i0 = 0; i0 < items.size(); i0 += nw) {
                 const size_t n_chunk = std::min<size_t>(nw, items.size() - i0);
                 if (i0 && snake) {
@@ -1678,10 +1694,10 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                 // (a few falling runs: merged pairwise, O(chunk) per boundary — a full stable_sort of the chunk through cost[] took
                 //  0.15 ms a chunk, most of config 2's deal)
                 idx.resize(n_chunk);
-                for (size_t j = 0; j < n_chunk; j++) idx[j] = (uint32_t)(i0 + j);
+                for (size_t j = 0; j < n_chunk; j++) idx[j] = global_order ? order[i0 + j] : (uint32_t)(i0 + j);
                 const auto falling = [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; };
                 size_t run_end = 0, n_merge = 0;
-                for (size_t j = 1; j <= n_chunk; j++) {
+                for (size_t j = 1; j <= n_chunk && !global_order; j++) {
                     if (j < n_chunk && !(cost[i0 + j] > cost[i0 + j - 1])) continue;     // still falling (or level)
                     if (run_end) {
                         if (++n_merge > 8) { std::stable_sort(idx.begin(), idx.end(), falling); break; }
@@ -1696,7 +1712,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
             }
         }
         const auto td1 = t_now();
-        if (trace) fprintf(stderr, "[pr trace]   deal: occupancy query %.2f ms, costs + owners %.2f ms\n", t_ms(tc1, tc1a), t_ms(td0, td1));
+        if (trace) fprintf(stderr, "[pr trace]   deal: occupancy query %.2f ms, costs %.3f ms, owners %.3f ms\n", t_ms(tc1, tc1a), t_ms(td0, td0a), t_ms(td0a, td1));
         // table order inside a wave's list = item order = class order: count per (wave, class), offsets, place
         // (the items are in class order: owner[i] * 8 + class, computed once per class range)
         woff.assign((size_t)nw * 8, 0);
@@ -1718,6 +1734,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
         dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});              // the pipelines read two items ahead
         dealt.push_back({V_ZERO, 0, 0, 0, 0, 0, 0, 0});
         items.swap(dealt);
+        if (trace) fprintf(stderr, "[pr trace]   deal: placement %.3f ms\n", t_ms(td1, t_now()));
     }
 
     // the graph's build temporaries (ss_graph::late_free): its last kernels ran under the host work above
