@@ -130,7 +130,11 @@ int32_t ss_comm_allgather(ss_ctx* ctx, const void* send, void* recv, uint64_t by
  * HBM layout (in-edge lists, degree-binned row order, non-dangling-first
  * numbering) on the device.  rank/world: this process owns the destination
  * rows of shard `rank` of `world` (doc-range sharding);
- * single GPU = (0, 1). */
+ * single GPU = (0, 1).  The input arrays (host or device memory) have been
+ * read when the call returns; the last kernels of the layout build may still
+ * be running on the context's stream — everything else that touches the
+ * graph is ordered behind them there (ss_synchronize to time the build;
+ * option "graph.late_free" = 0 makes the call wait itself). */
 int32_t ss_graph_create(ss_ctx* ctx, uint64_t n_nodes, uint64_t n_edges,
                         const uint64_t* out_ptr /*[n_nodes+1]*/, const uint32_t* out_dst /*[n_edges]*/,
                         int32_t rank, int32_t world, ss_graph** out);
