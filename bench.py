@@ -688,6 +688,21 @@ def main() -> None:
             for _ in range(K):
                 hits, n_hits = sc.score_topk(q_ptr, q_terms, k)      # host in, host out: PCIe-inclusive
             dt_pcie = time.perf_counter() - t0
+            # the same host-in / host-out batches with three in flight (ss_score_topk_submit / _collect): what a server with the
+            # next requests ready gets; the hits must be the synchronous call's
+            outs3 = [(np.zeros((nq, k), dtype=hits.dtype), np.zeros(nq, dtype=np.int32)) for _ in range(3)]
+            def in_flight(n):
+                fl = []
+                for i in range(n):
+                    if len(fl) == 3:
+                        tk, o = fl.pop(0); sc.collect(tk, out=o)
+                    fl.append((sc.submit(q_ptr, q_terms, k), outs3[i % 3]))
+                for tk, o in fl: sc.collect(tk, out=o)
+            in_flight(6)
+            t0 = time.perf_counter()
+            in_flight(K)
+            dt_flight = time.perf_counter() - t0
+            assert all(np.array_equal(o[0], hits) and np.array_equal(o[1], n_hits) for o in outs3)
             algo_q = 8 * sum_df + 36 * k * nq           # SURVEY.md §8d B_q without the per-candidate magnitude term
             ach = algo_q / (period_ms * 1e-3) / 1e9
             full = (nd, nt, nq, k) == (10_000_000, 1_000_000, 1024, 100)
@@ -723,7 +738,8 @@ def main() -> None:
                                            "traffic": tw_traffic, "kernel": "k_idf + head-list set-up + k_weight_count + k_scatter + k_bucket_sum",
                                            "kernel_ms": tfidf_ms, "algorithmic_bytes": algo_tw}},
                     "tfidf_build_ms": tfidf_ms, "scorer_create_ms": scorer_create_ms,
-                    "queries_per_sec_host_in_host_out": nq * K / dt_pcie}
+                    "queries_per_sec_host_in_host_out": nq * K / dt_pcie,
+                    "queries_per_sec_host_in_host_out_3_in_flight": nq * K / dt_flight}
             if pipelined is not None:
                 topk["one_stream_option"] = pipelined
 

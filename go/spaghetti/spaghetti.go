@@ -434,6 +434,44 @@ func (s *Scorer) ScoreTopK(qPtr, qTerms []uint32, queryLen []int32, topicProbs [
 	return out, nil
 }
 
+// Ticket names a batch in flight (Submit .. Collect).
+type Ticket struct {
+	id    C.uint64_t
+	nq, k int
+}
+
+// Submit enqueues a batch of OR queries and returns at once; up to C.SS_SCORE_INFLIGHT batches may be in flight.  A server
+// goroutine that has the next batch of requests ready calls Submit for it before it Collects the previous one: the host-side
+// plan of batch i+1 and the copy-out of batch i-1 then run under the kernels of batch i.
+func (s *Scorer) Submit(qPtr, qTerms []uint32, queryLen []int32, topicProbs []float64, k int) (Ticket, error) {
+	nq := len(qPtr) - 1
+	var id C.uint64_t
+	rc := C.ss_score_topk_submit(s.h, C.int32_t(nq), u32p(qPtr), u32p(qTerms), i32p(queryLen), f64p(topicProbs), C.int32_t(k), &id)
+	if err := statusErr(s.ctx, rc, "ss_score_topk_submit"); err != nil {
+		return Ticket{}, err
+	}
+	return Ticket{id, nq, k}, nil
+}
+
+// Collect waits for the batch of t and returns its hits like ScoreTopK.
+func (s *Scorer) Collect(t Ticket) ([][]Hit, error) {
+	raw := make([]C.ss_hit, t.nq*t.k+1)
+	nHits := make([]int32, t.nq+1)
+	rc := C.ss_score_topk_collect(s.h, t.id, (*C.ss_hit)(unsafe.Pointer(&raw[0])), i32p(nHits))
+	if err := statusErr(s.ctx, rc, "ss_score_topk_collect"); err != nil {
+		return nil, err
+	}
+	out := make([][]Hit, t.nq)
+	for q := 0; q < t.nq; q++ {
+		out[q] = make([]Hit, nHits[q])
+		for i := range out[q] {
+			r := raw[q*t.k+i]
+			out[q][i] = Hit{uint32(r.doc), float64(r.title), float64(r.body), float64(r.pagerank), float64(r.final)}
+		}
+	}
+	return out, nil
+}
+
 // MergeHits: multi-GPU doc-range shards only — parts[p] holds shard p's rows of one query batch as returned
 // by ScoreTopK (local doc ids), docBase[p] the shard's first corpus doc id.  Returns the k best of the union
 // per query in the order of appendSort (util.go:48-54).

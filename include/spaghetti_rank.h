@@ -324,6 +324,17 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
                       const int32_t* query_len, const double* topic_probs, int32_t k,
                       ss_hit* hits_out, int32_t* n_hits_out);
 
+/* The same batch with results in HOST memory and several batches in flight (a server that has the next batch of requests
+ * ready while this one runs): ss_score_topk_submit enqueues the batch and the copy of its hits to pinned host memory and
+ * returns a ticket (never 0) without waiting; ss_score_topk_collect waits for THAT batch and writes hits_out [n_q][k],
+ * n_hits_out [n_q] (host memory, the n_q and k of the submit).  Up to SS_SCORE_INFLIGHT tickets may be outstanding
+ * (SS_ERR_STATE beyond); collect them in any order.  The host's plan for batch i+1 and its copy-out of batch i-1 run under the
+ * kernels of batch i: 1024-query batches go host-to-host at the device's batch rate instead of one batch alone plus the copies. */
+#define SS_SCORE_INFLIGHT 3
+int32_t ss_score_topk_submit(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
+                             const int32_t* query_len, const double* topic_probs, int32_t k, uint64_t* ticket_out);
+int32_t ss_score_topk_collect(ss_scorer* s, uint64_t ticket, ss_hit* hits_out, int32_t* n_hits_out);
+
 /* ss_score_topk plus the quoted-phrase part of retrieval.Retrieve (retrieval/phrase.go:11-170,
  * util.go:162-203, merged at main_retrieve.go:73-78).  p_ptr[n_q+1] into p_terms: the tokens of ALL quoted
  * phrases of a query, concatenated into one phrase as the reference does (main_retrieve.go:26); a doc

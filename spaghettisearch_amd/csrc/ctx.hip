@@ -291,6 +291,8 @@ static const char* const k_option_names[] = {
     "graph.late_free",      // 0: ss_graph_create waits for its last kernels and frees its temporaries before it returns (default 1: they are freed
                             //    at the graph's next use, the caller's host work overlaps the row permutation)
     "pr.trace",             // 1: ss_graph_create / ss_pr_create print their phase times to stderr
+    "score.collect_pinned", // ss_score_topk_collect: 1 = device -> pinned block on the copy engine, then a host memcpy (measured slower: 0.50 against 0.41 ms
+                            //    per batch with three in flight); default 0 = hipMemcpy straight into the caller's memory
     "score.timing",         // 0: ss_score_topk records no timing events (ss_last_kernel_ms(1) keeps its last value)
     "score.trace",          // 1: ss_score_topk prints the host phases of a call (copies in, plan, staging, launches) to stderr
     "pr.probe_hot",         // ss_pr_probe policies 3/4: rows below this index use the default cache policy

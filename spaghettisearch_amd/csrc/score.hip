@@ -1415,8 +1415,28 @@ struct ss_scorer {
     hipEvent_t wave_ev[TURNS] = {};  // "score.pipeline": behind k_score_wave on the context's wave stream; the merge on the caller's stream waits for it
     size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
     ss::DevBuf<ss_hit> d_hits;
+    // ss_score_topk_submit / _collect: batches in flight whose hits go to HOST memory.  A slot: device buffers the kernels write and
+    // an event behind them.
+    static constexpr int INFLIGHT = SS_SCORE_INFLIGHT;
+    struct AsyncSlot {
+        ss::DevBuf<ss_hit> hits;
+        ss::DevBuf<int32_t> n_hits;
+        hipEvent_t ev = nullptr;             // behind the batch's kernels on the caller's stream
+        void* pin = nullptr;                 // "score.collect_pinned": the copy-out lands here first
+        size_t pin_cap = 0;
+        bool pin_mode = false;
+        uint64_t ticket = 0;                 // 0 = free
+        int32_t n_q = 0, k = 0;
+    } aslot[INFLIGHT];
+    uint64_t next_ticket = 1;
+    hipStream_t out_stream = nullptr;        // collect's copies
     ss::DevBuf<int32_t> d_nhits;
     ~ss_scorer() {
+        if (out_stream) { (void)hipStreamSynchronize(out_stream); (void)hipStreamDestroy(out_stream); }
+        for (auto& a : aslot) {
+            if (a.ev) (void)hipEventDestroy(a.ev);
+            if (a.pin) ctx->pin_free(a.pin, a.pin_cap);
+        }
         for (int i = 0; i < TURNS; i++) {
             if (h_plan[i]) (void)hipHostFree(h_plan[i]);
             if (plan_ev[i]) (void)hipEventDestroy(plan_ev[i]);
@@ -1608,6 +1628,100 @@ int32_t ss_score_topk_phrase(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, c
                              ss_hit* hits_out, int32_t* n_hits_out) {
     if (s && !p_ptr) return s->ctx->fail(SS_ERR_INVALID, "ss_score_topk_phrase: p_ptr is NULL");
     return score_impl(s, n_q, q_ptr, q_terms, p_ptr, p_terms, query_len, topic_probs, k, hits_out, n_hits_out);
+}
+
+// Batches in flight with HOST results: submit runs the batch like a call with device outputs (nothing waits, consecutive batches
+// overlap on the device) into the slot's own device buffers; collect waits for that batch alone and copies its rows to the caller.
+// The host's plan for batch i+1 and the copy-out of batch i-1 then run under the kernels of batch i.
+int32_t ss_score_topk_submit(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const int32_t* query_len,
+                             const double* topic_probs, int32_t k, uint64_t* ticket_out) {
+    if (!s) return SS_ERR_INVALID;
+    ss_ctx* ctx = s->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!ticket_out) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_submit: ticket_out is NULL");
+    *ticket_out = 0;
+    if (n_q < 0 || k < 1 || k > SS_MAX_TOPK) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_submit: n_q < 0 or k outside 1 .. %d", SS_MAX_TOPK);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    ss_scorer::AsyncSlot* a = nullptr;
+    for (auto& c : s->aslot)
+        if (!c.ticket) { a = &c; break; }
+    if (!a) return ctx->fail(SS_ERR_STATE, "ss_score_topk_submit: %d batches in flight already (ss_score_topk_collect one first)", (int)ss_scorer::INFLIGHT);
+    const size_t rows = (size_t)n_q * (size_t)k;
+    if (a->hits.n < rows) SS_HIP(ctx, a->hits.alloc(rows + rows / 4));
+    if (a->n_hits.n < (size_t)n_q) SS_HIP(ctx, a->n_hits.alloc((size_t)n_q + 64));
+    if (!a->ev) SS_HIP(ctx, hipEventCreateWithFlags(&a->ev, hipEventDisableTiming));
+    a->pin_mode = ctx->opt("score.collect_pinned", 0) != 0;
+    if (a->pin_mode) {
+        const size_t bytes = rows * sizeof(ss_hit) + (size_t)n_q * sizeof(int32_t);
+        if (a->pin_cap < bytes) {
+            ctx->pin_free(a->pin, a->pin_cap);
+            a->pin = ctx->pin_alloc(bytes, &a->pin_cap);
+            if (!a->pin) { a->pin_cap = 0; return ctx->fail(SS_ERR_OOM, "ss_score_topk_submit: no pinned host memory for %zu bytes of results", bytes); }
+        }
+        if (!s->out_stream) SS_HIP(ctx, hipStreamCreateWithFlags(&s->out_stream, hipStreamNonBlocking));
+    }
+    if (n_q) {
+        const int32_t rc = score_impl(s, n_q, q_ptr, q_terms, nullptr, nullptr, query_len, topic_probs, k, a->hits.p, a->n_hits.p);
+        if (rc != SS_OK) return rc;
+        // Only an event behind the batch's kernels is recorded here; the rows are copied when they are COLLECTED.  [Enqueued at
+        // submit, the device-to-host copy waits in the copy engine's in-order queue for this batch's merge and holds up the NEXT
+        // batch's plan upload behind it (submit then took 0.41 ms instead of 0.13); done by a kernel on the caller's stream it sat
+        // between two merges that the wave kernel stretches (period 0.48 ms instead of 0.345), on a stream of its own it shared a
+        // hardware queue with a wave stream (0.59).  At collect time the batch is finished, the copy takes its 85 us and blocks
+        // nothing: the host spends 0.13 ms in submit and 0.09 in collect per batch, under the 0.345 ms the device needs.]
+        SS_HIP(ctx, hipEventRecord(a->ev, ctx->stream));
+    }
+    a->n_q = n_q;
+    a->k = k;
+    a->ticket = s->next_ticket++;
+    *ticket_out = a->ticket;
+    return SS_OK;
+}
+
+int32_t ss_score_topk_collect(ss_scorer* s, uint64_t ticket, ss_hit* hits_out, int32_t* n_hits_out) {
+    if (!s) return SS_ERR_INVALID;
+    ss_ctx* ctx = s->ctx;
+    ss_scorer::AsyncSlot* a = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        if (!hits_out || !n_hits_out) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_collect: NULL output");
+        for (auto& c : s->aslot)
+            if (ticket && c.ticket == ticket) { a = &c; break; }
+        if (!a) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_collect: no batch in flight with ticket %llu", (unsigned long long)ticket);
+        SS_HIP(ctx, hipSetDevice(ctx->device));
+    }
+    // (the wait and the copies run outside the context's lock: another thread may submit the next batch meanwhile)
+    if (a->n_q) {
+        const bool trace = ctx->opt("score.trace", 0) != 0;
+        const auto tw0 = std::chrono::steady_clock::now();
+        hipError_t e = hipEventSynchronize(a->ev);
+        const auto tw1 = std::chrono::steady_clock::now();
+        const size_t rows = (size_t)a->n_q * (size_t)a->k;
+        const size_t hb = rows * sizeof(ss_hit), nb = (size_t)a->n_q * sizeof(int32_t);
+        if (a->pin_mode) {
+            // through the slot's pinned block on the copy engine, then a host memcpy
+            if (e == hipSuccess) e = hipMemcpyAsync(a->pin, a->hits.p, hb, hipMemcpyDeviceToHost, s->out_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(static_cast<unsigned char*>(a->pin) + hb, a->n_hits.p, nb, hipMemcpyDeviceToHost, s->out_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->out_stream);
+            if (e == hipSuccess) {
+                std::memcpy(hits_out, a->pin, hb);
+                std::memcpy(n_hits_out, static_cast<unsigned char*>(a->pin) + hb, nb);
+            }
+        } else {
+            if (e == hipSuccess) e = hipMemcpy(hits_out, a->hits.p, hb, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(n_hits_out, a->n_hits.p, nb, hipMemcpyDeviceToHost);
+        }
+        if (trace) fprintf(stderr, "[score trace] collect: waited %.0f us for the batch, copies %.0f us\n", std::chrono::duration<double, std::micro>(tw1 - tw0).count(),
+                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count());
+        if (e != hipSuccess) {
+            std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+            a->ticket = 0;
+            return ctx->fail(SS_ERR_HIP, "ss_score_topk_collect: %s", hipGetErrorString(e));
+        }
+    }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    a->ticket = 0;
+    return SS_OK;
 }
 
 static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const uint32_t* p_ptr,

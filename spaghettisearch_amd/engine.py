@@ -508,6 +508,26 @@ class Scorer:
                                          hits.ctypes.data, _ptr(n_hits)), self.ctx.h)
         return hits, n_hits
 
+    def submit(self, q_ptr, q_terms, k: int, query_len=None, topic_probs=None):
+        """ss_score_topk_submit: enqueue a batch whose hits go to host memory; -> ticket for collect()."""
+        q_ptr = _as(q_ptr, "uint32")
+        q_terms = _as(q_terms, "uint32")
+        query_len = _as(query_len, "int32")
+        topic_probs = _as(topic_probs, "float64")
+        n_q = int(q_ptr.shape[0]) - 1
+        self.ctx.ready(q_ptr, q_terms, query_len, topic_probs)
+        ticket = C.c_uint64(0)
+        check(self.ctx.lib.ss_score_topk_submit(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(query_len), _ptr(topic_probs), k,
+                                                C.addressof(ticket)), self.ctx.h)
+        return (int(ticket.value), n_q, k)
+
+    def collect(self, ticket, out=None):
+        """ss_score_topk_collect: wait for the batch of `ticket` (from submit) -> (hits [n_q][k], n_hits [n_q]) in host memory."""
+        t, n_q, k = ticket
+        hits, n_hits = out if out is not None else (np.zeros((n_q, k), dtype=HIT_DTYPE), np.zeros(n_q, dtype=np.int32))
+        check(self.ctx.lib.ss_score_topk_collect(self.h, t, hits.ctypes.data, n_hits.ctypes.data), self.ctx.h)
+        return hits, n_hits
+
     def close(self) -> None:
         if self.h:
             self.ctx.lib.ss_scorer_destroy(self.h)

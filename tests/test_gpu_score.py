@@ -393,6 +393,48 @@ def test_wave_graded_slices_agree(ss_ctx, oracle, grade):
         close_all(sc, ti, bi)
 
 
+def test_batches_in_flight_with_host_results(ss_ctx, oracle):
+    """ss_score_topk_submit / ss_score_topk_collect: up to SS_SCORE_INFLIGHT batches in flight, hits to host memory.  Batches of changing
+    size and k are submitted ahead and collected late and out of order; every batch must equal the oracle's.  A fourth submit is
+    refused, an unknown or spent ticket too, and a synchronous call between submits does not disturb the batches in flight."""
+    from spaghettisearch_amd import SpaghettiError
+    n_docs, n_terms = 300000, 20000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 6000000, 400000, seed=52)
+    sc = ti = bi = None
+    try:
+        sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+        batches = [synth.make_queries(64 + 40 * (i % 4), 3, 300, seed=80 + i) for i in range(9)]
+        ks = [40, 10, 100, 40, 7, 40, 64, 40, 40]
+        refs = [oracle.score_topk_batch(n_docs, title, body, mt, mb, qp, qt, k) for (qp, qt), k in zip(batches, ks)]
+        with ss_ctx.options(score__wave_min_list=0):
+            flight = []
+            done = {}
+            for i, ((qp, qt), k) in enumerate(zip(batches, ks)):
+                if len(flight) == 3:
+                    with pytest.raises(SpaghettiError):
+                        sc.submit(qp, qt, k)                           # SS_SCORE_INFLIGHT batches out already
+                    j, t = flight.pop(1 if i % 2 else 0)               # collect out of order
+                    done[j] = sc.collect(t)
+                    with pytest.raises(SpaghettiError):
+                        sc.collect(t)                                  # spent
+                flight.append((i, sc.submit(qp, qt, k)))
+                if i == 4:                                             # a synchronous call in between
+                    hits, n_hits = sc.score_topk(batches[0][0], batches[0][1], ks[0])
+                    assert_same_hits(hits, n_hits, *refs[0])
+            for j, t in reversed(flight):
+                done[j] = sc.collect(t)
+            with pytest.raises(SpaghettiError):
+                sc.collect((12345, 1, 1))
+            for j in range(len(batches)):
+                assert_same_hits(done[j][0], done[j][1], *refs[j])
+            # an empty batch has a ticket too
+            t = sc.submit(np.zeros(1, np.uint32), np.zeros(0, np.uint32), 5)
+            hits, n_hits = sc.collect(t)
+            assert hits.shape == (0, 5) and n_hits.shape == (0,)
+    finally:
+        close_all(sc, ti, bi)
+
+
 @pytest.mark.parametrize("pipeline", [1, 0])
 def test_pipelined_batches_agree(ss_ctx, oracle, pipeline):
     """(pipeline = 0: the same stream of calls in the default mode — batches of different sizes back to back reuse and regrow the
