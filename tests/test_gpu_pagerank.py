@@ -136,6 +136,21 @@ def test_graph_build_chunk_rows(ss_ctx, oracle, k_topics):
     np.testing.assert_allclose(rank, ref, rtol=1e-12)
 
 
+@pytest.mark.parametrize("opts", [{"graph__late_free": 0}, {"pr__deal_global": 0}, {"pr__deal_global": 0, "pr__deal_snake": 1},
+                                  {"pr__deal_global": 1, "pr__deal_snake": 0}, {"graph__late_free": 0, "pr__deal_global": 0, "pr__deal_snake": 0}])
+@pytest.mark.parametrize("k_topics", [1, 16])
+def test_build_and_deal_options_agree(ss_ctx, oracle, opts, k_topics):
+    # the switches of round 4's set-up path (build temporaries freed late or at once; work items dealt from one global order or
+    # chunk by chunk, in alternating direction or least-loaded-first) only move work: same ranks, same iteration counts
+    n, e = 60000, 400000
+    ptr, dst = synth.rmat_graph(n, e, seed=321)
+    n_topic = synth.topic_sizes(n, k_topics)
+    with ss_ctx.options(**opts):
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, 1e-10)
+    assert iters.tolist() == ref_iters.tolist()
+    np.testing.assert_allclose(rank, ref, rtol=1e-12)
+
+
 def test_edge_cases(ss_ctx, oracle):
     # no edges at all: every node dangling (pagerank.go:131-134)
     ptr = np.zeros(11, dtype=np.uint64)
