@@ -285,8 +285,9 @@ static const char* const k_option_names[] = {
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
     "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 65536, 0 = off)
     "pr.deal_snake",        // work items dealt to the waves in alternating direction (1) or least-loaded-first (0); default: 1 from 8 items per wave on and for k_pr_sweep_n
-    "pr.deal_global",       // 0: the work items are dealt chunk by chunk in table order, each chunk sorted by cost (before round 4); default 1: all items
-                            //    by falling cost first (one counting sort)
+    "pr.deal_global",       // 0: the work items are dealt chunk by chunk in table order, each chunk sorted by cost (before round 4); 1: all items by
+                            //    falling cost first (one counting sort; default for k_pr_sweep_n); 2: by falling cost inside each class, the classes in
+                            //    table order (default for k_pr_sweep)
     "pr.item_turns",        // turns per V_DEG work item of k_pr_sweep (V_QUAD: twice that); default 4 up to 4M local rows, 8 beyond
     "graph.late_free",      // 0: ss_graph_create waits for its last kernels and frees its temporaries before it returns (default 1: they are freed
                             //    at the graph's next use, the caller's host work overlaps the row permutation)

@@ -1663,20 +1663,31 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
             // deal takes 0.3 ms of host time instead of 2.8.  Few chunks: least-loaded-first as before (config 2 on k_pr_sweep<8>: 0.075
             // against 0.077 ms); k_pr_sweep_n's finer items sweep the same either way and the update is 0.1 ms shorter with the snake.
             const bool snake = ctx->opt("pr.deal_snake", items.size() >= (size_t)8 * nw || pr->nwave ? 1 : 0) != 0;
-            // All items by falling cost first ("pr.deal_global", default on): a counting sort on the cost in sixteenths of a turn,
-            // stable (table order inside a bucket), O(items).  The chunks below then come sorted.  [Sorting each chunk took 0.2 of
+            // All items by falling cost first ("pr.deal_global": 1 = one order over all classes, 2 = class by class in table order): a
+            // counting sort on the cost in sixteenths of a turn, stable (table order inside a bucket), O(items).  The chunks below
+            // then come sorted.  [Sorting each chunk took 0.2 of
             // config 2's 0.4 ms here: inside a class the costs fall, but every run of equal rows ends in a short item, so a chunk
             // is dozens of falling runs, not one.]
             static thread_local std::vector<uint32_t> order, bucket;
-            const bool global_order = ctx->opt("pr.deal_global", 1) != 0;
+            // (`tools/pr_deal.py`, sweep ms at 10M / 50M: K = 16 chunks 0.959, global 0.963, class-major 0.955; K = 1 chunks 0.383, global
+            //  0.379, class-major 0.389 — k_pr_sweep takes class-major, k_pr_sweep_n the one global order)
+            const int64_t deal_mode = ctx->opt("pr.deal_global", pr->nwave ? 1 : 2);
+            const bool global_order = deal_mode != 0;
             if (global_order) {
                 constexpr uint32_t NB = 1u << 14;
+                // (mode 2: class-major — the table's class order kept, falling cost inside a class)
                 const auto key = [&](size_t i) { return NB - 1 - (uint32_t)std::min<double>(cost[i] * 16.0, (double)(NB - 1)); };
                 bucket.assign(NB + 1, 0u);
-                for (size_t i = 0; i < items.size(); i++) bucket[key(i) + 1]++;
-                for (uint32_t b = 0; b < NB; b++) bucket[b + 1] += bucket[b];
                 order.resize(items.size());
-                for (size_t i = 0; i < items.size(); i++) order[bucket[key(i)]++] = (uint32_t)i;
+                size_t c0 = 0;
+                for (int kcls = 0; kcls < (deal_mode == 2 ? 6 : 1); kcls++) {
+                    const size_t c1 = deal_mode == 2 ? (kcls < 5 ? std::min<size_t>(vbeg[kcls + 1], items.size()) : items.size()) : items.size();
+                    if (kcls) std::fill(bucket.begin(), bucket.end(), 0u);
+                    for (size_t i = c0; i < c1; i++) bucket[key(i) + 1]++;
+                    for (uint32_t b = 0; b < NB; b++) bucket[b + 1] += bucket[b];
+                    for (size_t i = c0; i < c1; i++) order[c0 + bucket[key(i)]++] = (uint32_t)i;
+                    c0 = c1;
+                }
             }
             for (size_t i0 = 0; i0 < items.size(); i0 += nw) {
                 const size_t n_chunk = std::min<size_t>(nw, items.size() - i0);

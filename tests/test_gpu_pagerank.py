@@ -137,7 +137,8 @@ def test_graph_build_chunk_rows(ss_ctx, oracle, k_topics):
 
 
 @pytest.mark.parametrize("opts", [{"graph__late_free": 0}, {"pr__deal_global": 0}, {"pr__deal_global": 0, "pr__deal_snake": 1},
-                                  {"pr__deal_global": 1, "pr__deal_snake": 0}, {"graph__late_free": 0, "pr__deal_global": 0, "pr__deal_snake": 0}])
+                                  {"pr__deal_global": 1, "pr__deal_snake": 0}, {"pr__deal_global": 2}, {"pr__deal_global": 1},
+                                  {"graph__late_free": 0, "pr__deal_global": 0, "pr__deal_snake": 0}])
 @pytest.mark.parametrize("k_topics", [1, 16])
 def test_build_and_deal_options_agree(ss_ctx, oracle, opts, k_topics):
     # the switches of round 4's set-up path (build temporaries freed late or at once; work items dealt from one global order or

@@ -10,7 +10,7 @@ for n, e, kt in ((1 << 20, 5_000_000, 1), (1 << 20, 5_000_000, 16), (10_000_000,
     out_ptr, out_dst = synth.rmat_graph_torch(n, e, seed=42, device=dev)
     g = engine.Graph(ctx, n, out_ptr, out_dst)
     ref = None
-    for name, opts in (("global", {}), ("chunks", {"pr.deal_global": 0}), ("global", {}), ("chunks", {"pr.deal_global": 0})):
+    for name, opts in (("global", {}), ("chunks", {"pr.deal_global": 0}), ("class-major", {"pr.deal_global": 2}), ("global", {}), ("chunks", {"pr.deal_global": 0}), ("class-major", {"pr.deal_global": 2})):
         for k, v in opts.items(): ctx.set_option(k, v)
         pr = engine.PageRankState(g, 0.75, -1.0, synth.topic_sizes(n, kt), max_iter=0)
         pr.begin(); pr.step(5)
