@@ -727,11 +727,20 @@ __device__ __forceinline__ void deg_rows(SweepCtx<GW, TS>& c, const WorkItem* __
 #ifndef SS_PR_MINW
 #define SS_PR_MINW 1
 #endif
+#ifdef SS_PR_WAVETIME
+// variant build (tools/build_variant.sh wt -DSS_PR_WAVETIME): when every wave of the last sweep started and ran out of items
+// (100 MHz realtime counter), printed by ss_pr_destroy — how level the deal is in TIME, not in modelled turns
+__device__ unsigned long long g_pr_wt[65536][2];
+#endif
 template <int GW, bool TS>
 __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     constexpr int NS = 64 / GW;
     PrCtl* ctl = p.ctl;
     if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
+#ifdef SS_PR_WAVETIME
+    unsigned long long wt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt0));
+#endif
     const int sweep = ctl->sweep;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -780,6 +789,14 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
             }
         }
     }
+#ifdef SS_PR_WAVETIME
+    {
+        unsigned long long wt1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt1));
+        const uint32_t wid = (blockIdx.x * WAVES + wave) & 65535u;
+        if (lane == 0) { g_pr_wt[wid][0] = wt0; g_pr_wt[wid][1] = wt1; }
+    }
+#endif
     block_reduce_and_publish<GW>(p, c.dsum, c.csum, c.Tw, false);
 }
 
@@ -1689,6 +1706,11 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                     c0 = c1;
                 }
             }
+            // (Equal modelled loads do not end together: the hardware issues oldest-first, so of a CU's four resident blocks the one
+            //  that arrived first is out of items after 623 us at config 4 and the last one after 906 — -DSS_PR_WAVETIME,
+            //  tools/pr_wavetime.py.  Shares weighted by those speeds were tried and dropped: the late blocks end where they ended
+            //  before, the early ones later, the sweep 0.985-1.0 ms instead of 0.955 — the sweep is bound by the memory system's
+            //  throughput, and who finishes first is the scheduler's business.)
             for (size_t i0 = 0; i0 < items.size(); i0 += nw) {
                 const size_t n_chunk = std::min<size_t>(nw, items.size() - i0);
                 if (i0 && snake) {
@@ -1722,6 +1744,19 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
                 }
             }
         }
+#ifdef SS_PR_WAVETIME
+        if (FILE* f = fopen("gpurun_out/pr_load.csv", "w")) {
+            static thread_local std::vector<double> wl, wcls;
+            wl.assign(nw, 0.0); wcls.assign((size_t)nw * 6, 0.0);
+            for (size_t i = 0; i < items.size(); i++) {
+                int kc = 0; while (kc < 5 && i >= vbeg[kc + 1]) kc++;
+                wl[owner[i]] += cost[i]; wcls[(size_t)owner[i] * 6 + kc] += cost[i];
+            }
+            fprintf(f, "wave,load,c0,c1,c2,c3,c4,c5\n");
+            for (uint32_t w = 0; w < nw; w++) fprintf(f, "%u,%.2f,%.2f,%.2f,%.2f,%.2f,%.2f,%.2f\n", w, wl[w], wcls[(size_t)w * 6], wcls[(size_t)w * 6 + 1], wcls[(size_t)w * 6 + 2], wcls[(size_t)w * 6 + 3], wcls[(size_t)w * 6 + 4], wcls[(size_t)w * 6 + 5]);
+            fclose(f);
+        }
+#endif
         const auto td1 = t_now();
         if (trace) fprintf(stderr, "[pr trace]   deal: occupancy query %.2f ms, costs %.3f ms, owners %.3f ms\n", t_ms(tc1, tc1a), t_ms(td0, td0a), t_ms(td0a, td1));
         // table order inside a wave's list = item order = class order: count per (wave, class), offsets, place
@@ -1896,6 +1931,28 @@ int32_t ss_pr_set_teleport(ss_pr* pr, const uint64_t* set_ptr, const uint32_t* s
 }
 
 int32_t ss_pr_destroy(ss_pr* pr) {
+#ifdef SS_PR_WAVETIME
+    if (pr && pr->gw >= 8) {
+        (void)hipDeviceSynchronize();
+        const uint32_t nwv = std::min<uint32_t>(65536u, pr->nblocks * WAVES);
+        std::vector<unsigned long long> h((size_t)nwv * 2);
+        if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pr_wt), h.size() * sizeof(unsigned long long)) == hipSuccess && nwv) {
+            unsigned long long t0 = ~0ull;
+            for (uint32_t w = 0; w < nwv; w++) t0 = std::min(t0, h[2 * w]);
+            std::vector<double> st(nwv), en(nwv);
+            for (uint32_t w = 0; w < nwv; w++) { st[w] = (double)(h[2 * w] - t0) / 100.0; en[w] = (double)(h[2 * w + 1] - t0) / 100.0; }
+            std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+            if (FILE* f = fopen("gpurun_out/pr_wt.csv", "w")) {
+                fprintf(f, "wave,start_us,end_us\n");
+                for (uint32_t w = 0; w < nwv; w++) fprintf(f, "%u,%.2f,%.2f\n", w, (double)(h[2 * w] - t0) / 100.0, (double)(h[2 * w + 1] - t0) / 100.0);
+                fclose(f);
+            }
+            fprintf(stderr, "[pr wavetime] %u waves: start us median %.1f max %.1f | out of items us min %.1f p10 %.1f median %.1f p90 %.1f p99 %.1f max %.1f\n", nwv,
+                    st[nwv / 2], st[nwv - 1], en[0], en[nwv / 10], en[nwv / 2], en[nwv * 9 / 10], en[(size_t)nwv * 99 / 100], en[nwv - 1]);
+        }
+    }
+#endif
+
     if (!pr) return SS_ERR_INVALID;
     ss_ctx* ctx = pr->g->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
