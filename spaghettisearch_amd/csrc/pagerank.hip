@@ -1711,13 +1711,44 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
             //  tools/pr_wavetime.py.  Shares weighted by those speeds were tried and dropped: the late blocks end where they ended
             //  before, the early ones later, the sweep 0.985-1.0 ms instead of 0.955 — the sweep is bound by the memory system's
             //  throughput, and who finishes first is the scheduler's business.)
+#ifdef SS_PR_WAVETIME
+            // experiment (SS_PR_HEAP="123,106,92,85"): exact weighted longest-first — every item to the wave whose load / share is least
+            bool heap_done = false;
+            if (const char* ws = getenv("SS_PR_HEAP")) {
+                double wg[8] = {100, 100, 100, 100, 100, 100, 100, 100};
+                sscanf(ws, "%lf,%lf,%lf,%lf", &wg[0], &wg[1], &wg[2], &wg[3]);
+                const uint32_t wpr = (uint32_t)std::max(ctx->cu_count, 1) * WAVES;
+                typedef std::pair<double, uint32_t> E;
+                std::priority_queue<E, std::vector<E>, std::greater<E>> pq;
+                for (uint32_t w = 0; w < nw; w++) pq.push({0.0, w});
+                for (size_t j = 0; j < items.size(); j++) {
+                    const uint32_t it = global_order ? order[j] : (uint32_t)j;
+                    const E top = pq.top(); pq.pop();
+                    owner[it] = top.second;
+                    load[top.second] += cost[it];
+                    pq.push({load[top.second] / wg[std::min<uint32_t>(7, top.second / wpr)], top.second});
+                }
+                heap_done = true;
+            }
+            for (size_t i0 = 0; i0 < items.size() && !heap_done; i0 += nw) {
+#else
             for (size_t i0 = 0; i0 < items.size(); i0 += nw) {
+#endif
                 const size_t n_chunk = std::min<size_t>(nw, items.size() - i0);
                 if (i0 && snake) {
                     std::reverse(by_load.begin(), by_load.end());
                 } else if (i0) {
                     // (load, wave) pairs sorted by value: several times faster than a comparator that reads load[] through the ids
                     key.resize(nw);
+#ifdef SS_PR_WAVETIME
+                    // experiment: loads normalised by the share of the wave's block round (SS_PR_WEIGHTS="123,106,92,85")
+                    if (const char* ws = getenv("SS_PR_WEIGHTS")) {
+                        double wg[8] = {100, 100, 100, 100, 100, 100, 100, 100};
+                        sscanf(ws, "%lf,%lf,%lf,%lf", &wg[0], &wg[1], &wg[2], &wg[3]);
+                        const uint32_t wpr = (uint32_t)std::max(ctx->cu_count, 1) * WAVES;
+                        for (uint32_t w = 0; w < nw; w++) key[w] = {load[w] / wg[std::min<uint32_t>(7, w / wpr)], w};
+                    } else
+#endif
                     for (uint32_t w = 0; w < nw; w++) key[w] = {load[w], w};
                     std::sort(key.begin(), key.end());
                     for (uint32_t w = 0; w < nw; w++) by_load[w] = key[w].second;
