@@ -174,7 +174,10 @@ __device__ __forceinline__ void chunk_term_range(const uint64_t* __restrict__ te
 // altogether: k_weight_count and k_scatter pass over them, and k_bucket_sum reads bucket b's run of every head list straight
 // from post_doc / post_w, weighting it on the way (w = tf*idf written once) — 12 bytes per head posting, the algorithmic
 // minimum, instead of the 36 a partitioned posting costs.  Which lists are head only moves work between two exact paths.
-constexpr int HEAD_CAP = 1024;               // most head lists (their run table sits in LDS beside the accumulators: 12 B each)
+#ifndef SS_HEAD_CAP
+#define SS_HEAD_CAP 1024
+#endif
+constexpr int HEAD_CAP = SS_HEAD_CAP;               // most head lists (their run table sits in LDS beside the accumulators: 12 B each)
 struct HeadArgs {
     const uint32_t* n;                       // number of head lists (device word; 0 = no head path)
     const uint32_t* term;                    // [HEAD_CAP] their term ids, ascending
