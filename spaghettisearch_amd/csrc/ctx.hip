@@ -308,7 +308,7 @@ static const char* const k_option_names[] = {
     "score.wave_min_list",  // a query suits k_score_wave if EVERY list of it has this many x k' postings (k' = k rounded up to 2^j; default 16)
     "score.wave_share_pct", // a batch uses k_score_wave if the queries that suit it carry at least this share of the batch's postings (default 90)
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
-    "score.wave_big_pct",   // graded slices: this share of a batch's postings goes into slices of wave_big_x100 % of the target, the rest into wave_small_x100 % (defaults 85 / 115 / 40; 0 = one size)
+    "score.wave_big_pct",   // graded slices: this share of a batch's postings goes into slices of wave_big_x100 % of the target, the rest into wave_small_x100 % (defaults 92 / 115 / 60; 0 = one size)
     "score.wave_big_x100",
     "score.pipeline",       // 0: every scoring kernel on the context's stream.  Default 1: device-output batches that are all k_score_wave run k_wave_prep and
                             //    k_score_wave on an internal stream and only k_merge_flat (behind an event) on the context's stream: the next batch's

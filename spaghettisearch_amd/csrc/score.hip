@@ -1865,8 +1865,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // everything else runs k_score_slices.  Option "score.wave" = 0 switches the wave kernel off (tests, A/B).
     const bool wave_ok = ctx->opt("score.wave", 1) != 0 && s->has_combined && !exact_all && k <= ss::score_wave_max_k();
     uint64_t wave_target = 0;
-    const int64_t grade_pct = ctx->opt("score.wave_big_pct", 85), grade_big = ctx->opt("score.wave_big_x100", 115),
-                  grade_small = ctx->opt("score.wave_small_x100", 40);
+    // (85 / 115 / 40 suited one batch at a time; with consecutive batches overlapping the next batch's kernel fills this one's tail
+    //  and fewer, larger tail slices pay: 0.334-0.338 ms per batch at config 3 against 0.341-0.345, `tools/score_wall.py` with OPTS)
+    const int64_t grade_pct = ctx->opt("score.wave_big_pct", 92), grade_big = ctx->opt("score.wave_big_x100", 115),
+                  grade_small = ctx->opt("score.wave_small_x100", 60);
     if (wave_ok) {
         // about 5.5 slices per nine-wave-per-CU slot (four rounds of the 12 waves a CU holds), 8k .. 48k postings each
         const uint64_t slots = (uint64_t)std::max(ctx->cu_count, 1) * 9;
