@@ -470,16 +470,28 @@ __global__ __launch_bounds__(1024) void k_bucket_offsets(const uint32_t* __restr
 // 641M-posting table, 1.9x write amplification).  The block therefore sorts its SC_CH records by bucket in LDS first
 // (histogram -> exclusive scan -> LDS ticket per record) and then writes them out in LDS order: consecutive lanes write
 // consecutive records of a bucket's run.
-constexpr int SC_TPB = 1024;
+#ifndef SS_SC_TPB
+#define SS_SC_TPB 1024
+#endif
+constexpr int SC_TPB = SS_SC_TPB;
 #ifndef SS_SC_PT
-#define SS_SC_PT 8
+#define SS_SC_PT (8192 / SS_SC_TPB)
 #endif
 constexpr int SC_PT = SS_SC_PT;                // records per thread
 constexpr int SC_CH = SC_TPB * SC_PT;         // records per chunk (staged in LDS)
 constexpr int SC_BPT_MAX = NB_MAX / SC_TPB;
-// LDS: rec[SC_CH] (8 B), then four tables of nbp = bpt * SC_TPB words (hist, loff, gout, cur), part[16], bkt[SC_CH] (2 B).
-// 10M docs (1221 buckets, bpt = 2): 64 + 32 + 16 KB, one workgroup per CU (4096-record chunks and two workgroups per CU measured 5 % slower).
-inline size_t scatter_lds_bytes(uint32_t bpt) { return (size_t)SC_CH * 8 + (size_t)4 * bpt * SC_TPB * 4 + 64 + (size_t)SC_CH * 2; }
+constexpr int SC_PF = (1024 + SC_TPB - 1) / SC_TPB;   // entries of the next chunk's term window a thread prefetches (windows up to 1024 terms)
+static_assert(SC_CH <= 65535, "staging positions are 16-bit");
+// LDS: rec[SC_CH] (8 B: doc, float32 square), then per bucket (nbt = the bucket count rounded up to even): the chunk's count (16 bits,
+// two buckets to a word — the returning ds_add of the count is also the record's rank), the first staging position (16 bits) and the
+// output position of the chunk's run (32 bits); the block's output cursors live in the registers of the buckets' owner threads and a
+// record's bucket is read off its doc id.  10M docs (1222 buckets): 64 + 9.6 KB (before late round 4: 64 + 32 + 16 KB with 32-bit
+// tables, a bucket word per record and the cursors in LDS).  ONE workgroup of 1024 threads per CU all the same: the smaller layout
+// was made so that two fit, and two measured SLOWER — 2 x 512 threads with 16 postings each 6.6 ms for the build, 2 x 1024 capped at
+// 64 VGPRs 6.6, one workgroup of 1024 5.4-5.6 (5.85 with the old layout; 4096-record chunks in two workgroups had measured 5 % slower
+// in round 3).  Every resident block keeps a half-written line open per bucket, and twice the blocks are twice the lines an XCD's L2
+// has to hold until the block's next chunk completes them (DESIGN K2/K3).
+inline size_t scatter_lds_bytes(uint32_t nbt) { return (size_t)SC_CH * 8 + (size_t)nbt * 8 + 64; }
 // WEIGHT (round 4: weight and scatter in ONE pass over the postings): w = tf * idf is computed here, written back in place and
 // squared on the way into the record — the separate weighting pass read and wrote every tail posting once more (12 of its 36
 // bytes; the count pass in front of this kernel now reads doc ids only).  A thread takes SC_PT CONSECUTIVE postings, finds the
@@ -491,28 +503,34 @@ inline size_t scatter_lds_bytes(uint32_t bpt) { return (size_t)SC_CH * 8 + (size
 #define SC_NT_LOAD(p) __builtin_nontemporal_load(p)
 #endif
 constexpr int SC_WIN = SC_CH;                  // term-window entries staged per chunk (a chunk spans at most SC_CH + 1 non-empty terms; beyond: global search)
-template <bool WEIGHT>
-__global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__ post_doc, float* __restrict__ post_w, uint64_t n_post,
-                                                    uint64_t per, int shift, uint32_t nb, uint32_t nblk, uint32_t bpt,
+template <bool WEIGHT, int BPT>
+#ifndef SS_SC_MINW
+#define SS_SC_MINW 1
+#endif
+__global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* __restrict__ post_doc, float* __restrict__ post_w, uint64_t n_post,
+                                                    uint64_t per, int shift, uint32_t nb, uint32_t nblk, uint32_t bpt, uint32_t nbt,
                                                     const uint32_t* __restrict__ mat, const uint32_t* __restrict__ off, uint2* __restrict__ out,
                                                     HeadArgs head, const uint64_t* __restrict__ term_ptr, uint64_t n_terms, const float* __restrict__ idf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_smem[];
     __shared__ uint64_t s_t0;
     __shared__ uint32_t s_need;
-    const uint32_t nbp = bpt * SC_TPB;
+    __shared__ uint32_t s_nstaged;
     uint2* const L_rec = reinterpret_cast<uint2*>(sc_smem);
     uint32_t* const s_tp = reinterpret_cast<uint32_t*>(sc_smem);            // [SC_WIN] WEIGHT: the chunk's term starts, relative to `base` ...
     float* const s_idf = reinterpret_cast<float*>(sc_smem) + SC_WIN;         // [SC_WIN] ... and their idf (both in L_rec's bytes: used before the records are staged)
-    uint32_t* const L_hist = reinterpret_cast<uint32_t*>(L_rec + SC_CH);   // records of the chunk per bucket (the returning add is also the record's rank)
-    uint32_t* const L_loff = L_hist + nbp;                                 // first staging position of the bucket
-    uint32_t* const L_gout = L_loff + nbp;                                 // where this chunk's run of the bucket starts in the output
-    uint32_t* const L_cur = L_gout + nbp;                                  // next output position of THIS block in the bucket
-    uint32_t* const L_part = L_cur + nbp;
-    uint16_t* const L_bkt = reinterpret_cast<uint16_t*>(L_part + 16);      // bucket of the record at each staging position
-    for (uint32_t b = threadIdx.x; b < nbp; b += SC_TPB) {
-        L_hist[b] = 0;
-        L_cur[b] = b < nb ? off[b] + mat[(size_t)b * nblk + blockIdx.x] : 0u;
+    uint32_t* const L_gout = reinterpret_cast<uint32_t*>(L_rec + SC_CH);   // [nbt] where this chunk's run of the bucket starts in the output
+    uint32_t* const L_hist = L_gout + nbt;                                 // [nbt / 2] records of the chunk per bucket, 16 bits each (bucket b: word b >> 1, half b & 1)
+    uint16_t* const L_loff = reinterpret_cast<uint16_t*>(L_hist + nbt / 2);// [nbt] first staging position of the bucket
+    uint32_t* const L_part = reinterpret_cast<uint32_t*>(L_loff + nbt);    // [16]
+    // thread t owns buckets t * bpt .. t * bpt + bpt - 1 (bpt is even: whole words of L_hist): it scans their counts, keeps their
+    // output cursors (next output position of THIS block in the bucket) in registers and zeroes their counts
+    uint32_t cur[BPT];
+#pragma unroll
+    for (int q = 0; q < BPT; q++) {
+        const uint32_t b = threadIdx.x * bpt + q;
+        cur[q] = ((uint32_t)q < bpt && b < nb) ? off[b] + mat[(size_t)b * nblk + blockIdx.x] : 0u;
     }
+    for (uint32_t i = threadIdx.x; i < nbt / 2; i += SC_TPB) L_hist[i] = 0;
     const uint64_t r0 = (uint64_t)blockIdx.x * per, r1 = min(n_post, r0 + per);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (WEIGHT && threadIdx.x == 0) {
@@ -523,21 +541,26 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
         }
         s_t0 = lo;
     }
-    // the next chunk's postings are requested before the current chunk goes through its LDS phases
-    uint32_t ndoc[SC_PT];
-    float nw[SC_PT];
+    // The next chunk's postings are requested when the current chunk's records are staged (phase 3), into the same registers: the
+    // write-out (phase 4) and the window staging run under the loads.  (Round 3/4 loaded them a whole chunk ahead into a second set
+    // of registers; the late loads measured no slower and leave the registers to the compiler.)
+    uint32_t doc[SC_PT];
+    float w[SC_PT];
     // head lists are not partitioned (k_bucket_sum reads them in place): their postings count as absent here
     const uint32_t nh = head.n ? *head.n : 0u;
     uint32_t hcur = nh ? head_first(head, nh, r0) : 0u;
-    bool n_empty = false;                                                  // the fetched chunk holds head postings only (uniform)
+    bool n_empty = false;                                                  // the chunk whose head ranges were looked up last holds head postings only (uniform)
     HeadSkip hk = nh ? HeadSkip{0ull, 0ull, 0ull, 0ull} : HeadSkip{~0ull, ~0ull, ~0ull, ~0ull};
     const uint32_t x0 = threadIdx.x * SC_PT;                               // this thread's first posting inside a chunk
-    auto fetch = [&](uint64_t base) __attribute__((always_inline)) {
+    // meta: the head ranges over the chunk at `base` (moves hcur / hk on); loads: its postings, after meta(base)
+    auto meta = [&](uint64_t base) __attribute__((always_inline)) {
         n_empty = base >= r1;
         if (nh && base < r1) {
             head_skip(head, nh, hcur, base, hk);
             n_empty = hk.a_lo <= base && hk.a_hi >= min(r1, base + SC_CH);
         }
+    };
+    auto loads = [&](uint64_t base) __attribute__((always_inline)) {
         const uint64_t i0 = base + x0;
         if (!n_empty && i0 + SC_PT <= r1) {                                // whole group inside the range: vector loads
 #pragma unroll
@@ -548,23 +571,25 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
                 typedef float f4_t __attribute__((ext_vector_type(4)));
                 const u4_t d = SC_NT_LOAD(reinterpret_cast<const u4_t*>(&post_doc[i0 + v4 * 4]));
                 const f4_t f = SC_NT_LOAD(reinterpret_cast<const f4_t*>(&post_w[i0 + v4 * 4]));
-                ndoc[v4 * 4] = d.x; ndoc[v4 * 4 + 1] = d.y; ndoc[v4 * 4 + 2] = d.z; ndoc[v4 * 4 + 3] = d.w;
-                nw[v4 * 4] = f.x; nw[v4 * 4 + 1] = f.y; nw[v4 * 4 + 2] = f.z; nw[v4 * 4 + 3] = f.w;
+                doc[v4 * 4] = d.x; doc[v4 * 4 + 1] = d.y; doc[v4 * 4 + 2] = d.z; doc[v4 * 4 + 3] = d.w;
+                w[v4 * 4] = f.x; w[v4 * 4 + 1] = f.y; w[v4 * 4 + 2] = f.z; w[v4 * 4 + 3] = f.w;
             }
 #pragma unroll
             for (int j = 0; j < SC_PT; j++)
-                if (nh && hk.hit(i0 + j)) ndoc[j] = 0xFFFFFFFFu;
+                if (nh && hk.hit(i0 + j)) doc[j] = 0xFFFFFFFFu;
         } else {
 #pragma unroll
             for (int j = 0; j < SC_PT; j++) {
                 const uint64_t i = i0 + j;
                 const bool ok = !n_empty && i < r1 && !(nh && hk.hit(i));
-                ndoc[j] = ok ? post_doc[i] : 0xFFFFFFFFu;
-                nw[j] = ok ? post_w[i] : 0.f;
+                doc[j] = ok ? post_doc[i] : 0xFFFFFFFFu;
+                w[j] = ok ? post_w[i] : 0.f;
             }
         }
     };
-    fetch(r0);
+    meta(r0);
+    loads(r0);
+    bool cur_empty = n_empty;
     __syncthreads();
     // WEIGHT: the term window of the NEXT chunk is fetched while the current chunk goes through its LDS phases (two dependent loads —
     // how far the terms reach, then their starts and idf — that cost every chunk ~4k cycles in front of the weight phase when they
@@ -572,17 +597,15 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
     // the slow way.  pf_ok: pf_tp / pf_idf hold the window of the chunk that starts at `base`, pf_need entries, first term pf_t0.
     bool pf_ok = false;
     uint32_t pf_need = 0;
-    uint64_t pf_t0 = 0, pf_tp = 0, pf_probe = 0;
-    float pf_idf = 0.f;
+    uint64_t pf_t0 = 0, pf_tp[SC_PF] = {}, pf_probe = 0;
+    float pf_idf[SC_PF] = {};
     __shared__ uint32_t s_need_n;
     for (uint64_t base = r0; base < r1; base += SC_CH) {
-        uint32_t doc[SC_PT], rank[SC_PT];
-        float w[SC_PT];
-#pragma unroll
-        for (int j = 0; j < SC_PT; j++) { doc[j] = ndoc[j]; w[j] = nw[j]; }
-        const bool empty = n_empty;
-        const uint32_t h_here = hcur;                                      // the head range running at `base` (before the fetch moves on)
-        fetch(base + SC_CH);
+        uint32_t rank2[SC_PT / 2];                                        // two 16-bit ranks to a register
+        const bool empty = cur_empty;
+        const uint32_t h_here = hcur;                                      // the head range running at `base` (before meta moves on)
+        meta(base + SC_CH);
+        cur_empty = n_empty;                                               // ... of the next chunk, for the next turn
         const bool next_live = WEIGHT && !n_empty && base + SC_CH < r1;     // the next chunk will want a window
         if (empty) {
             if (WEIGHT) {                                                  // a chunk inside a head list: the next chunk's terms start at that list
@@ -591,10 +614,12 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
                 __syncthreads();
                 pf_ok = false;
             }
+            loads(base + SC_CH);
             continue;
         }
 #if defined(SS_EXP_SC) && SS_EXP_SC == 3      // timing experiments only (wrong results): loads alone
         if (doc[0] == 0x12345678u) out[0] = make_uint2(0u, __float_as_uint(w[0]));
+        loads(base + SC_CH);
         continue;
 #endif
         if (WEIGHT) {
@@ -606,9 +631,13 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
             if (pf_ok) {
                 t0 = pf_t0;
                 need = pf_need;
-                if (threadIdx.x < need) {
-                    s_tp[threadIdx.x] = pf_tp <= base ? 0u : (pf_tp - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(pf_tp - base));
-                    s_idf[threadIdx.x] = pf_idf;
+#pragma unroll
+                for (int u = 0; u < SC_PF; u++) {
+                    const uint32_t e = threadIdx.x + (uint32_t)u * SC_TPB;
+                    if (e < need) {
+                        s_tp[e] = pf_tp[u] <= base ? 0u : (pf_tp[u] - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(pf_tp[u] - base));
+                        s_idf[e] = pf_idf[u];
+                    }
                 }
                 if (threadIdx.x == 0) s_need_n = 0;
             } else {
@@ -616,12 +645,12 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
                 if (threadIdx.x == 0) { s_need = 0; s_need_n = 0; }
                 __syncthreads();
                 {                                                          // coarse probe: how far do the chunk's terms reach?
-                    const uint64_t t = t0 + 1 + (uint64_t)threadIdx.x * 8;
+                    const uint64_t t = t0 + 1 + (uint64_t)threadIdx.x * SC_PT;
                     const uint64_t v = t <= n_terms ? term_ptr[t] : ~0ull;
                     if (v < base + n_here) atomicMax(&s_need, threadIdx.x + 1);
                 }
                 __syncthreads();
-                need = min((uint32_t)SC_WIN, s_need * 8 + 10);
+                need = min((uint32_t)SC_WIN, s_need * SC_PT + SC_PT + 2);
                 for (uint32_t q = threadIdx.x; q < need; q += SC_TPB) {
                     const uint64_t t = t0 + q;
                     const uint64_t v = t <= n_terms ? term_ptr[t] : ~0ull;
@@ -684,23 +713,28 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
             pf_ok = false;
             if (next_live) {
                 pf_t0 = s_t0;
-                const uint64_t t = pf_t0 + 1 + (uint64_t)threadIdx.x * 8;
+                const uint64_t t = pf_t0 + 1 + (uint64_t)threadIdx.x * SC_PT;
                 pf_probe = t <= n_terms ? term_ptr[t] : ~0ull;
             }
         }
         // (1) count; the returned value is the record's rank inside its bucket
 #pragma unroll
-        for (int j = 0; j < SC_PT; j++) rank[j] = doc[j] != 0xFFFFFFFFu ? atomicAdd(&L_hist[doc[j] >> shift], 1u) : 0u;
+        for (int j = 0; j < SC_PT; j++) {
+            const uint32_t b = doc[j] >> shift, sh = (b & 1u) << 4;
+            const uint32_t r = doc[j] != 0xFFFFFFFFu ? (atomicAdd(&L_hist[b >> 1], 1u << sh) >> sh) & 0xFFFFu : 0u;
+            rank2[j >> 1] = (j & 1) ? (rank2[j >> 1] | (r << 16)) : r;
+        }
         if (WEIGHT && next_live) {
             const uint64_t base_n = base + SC_CH;
             if (pf_probe < base_n + min((uint64_t)SC_CH, r1 - base_n)) atomicMax(&s_need_n, threadIdx.x + 1);
         }
         __syncthreads();
         // (2) exclusive scan of the counts -> staging offsets; claim this chunk's runs from the block's cursors
-        uint32_t c[SC_BPT_MAX], run = 0;
+        uint32_t c[BPT], run = 0;
 #pragma unroll
-        for (int q = 0; q < SC_BPT_MAX; q++) {
-            c[q] = (uint32_t)q < bpt ? L_hist[threadIdx.x * bpt + q] : 0u;
+        for (int q = 0; q < BPT; q++) {
+            const uint32_t b = threadIdx.x * bpt + q;
+            c[q] = ((uint32_t)q < bpt && b < nbt) ? (L_hist[b >> 1] >> ((b & 1u) << 4)) & 0xFFFFu : 0u;
             run += c[q];
         }
         uint32_t incl = run;
@@ -714,29 +748,36 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
         uint32_t o = incl - run;
         for (int q = 0; q < wv; q++) o += L_part[q];
 #pragma unroll
-        for (int q = 0; q < SC_BPT_MAX; q++) {
-            if ((uint32_t)q < bpt) {
-                const uint32_t b = threadIdx.x * bpt + q;
-                L_loff[b] = o;
+        for (int q = 0; q < BPT; q++) {
+            const uint32_t b = threadIdx.x * bpt + q;
+            if ((uint32_t)q < bpt && b < nbt) {
+                L_loff[b] = (uint16_t)o;
                 o += c[q];
-                const uint32_t g = L_cur[b];
-                L_gout[b] = g;
-                L_cur[b] = g + c[q];
-                L_hist[b] = 0;
+                L_gout[b] = cur[q];
+                cur[q] += c[q];
+                if ((q & 1) == 0) L_hist[b >> 1] = 0;                      // (bpt and nbt are even: the word is this thread's alone)
             }
         }
+        if (threadIdx.x == SC_TPB - 1) s_nstaged = o;                      // (the last thread's running offset ends behind the last bucket)
         if (WEIGHT && next_live) {
             // ... second load: the window itself (s_need_n is complete since the barrier behind the count phase)
-            pf_need = s_need_n * 8 + 10;
-            pf_ok = pf_need <= (uint32_t)SC_TPB;
-            if (pf_ok && threadIdx.x < pf_need) {
-                const uint64_t t = pf_t0 + threadIdx.x;
-                pf_tp = t <= n_terms ? term_ptr[t] : ~0ull;
-                pf_idf = t < n_terms ? idf[t] : 0.f;
+            pf_need = s_need_n * SC_PT + SC_PT + 2;
+            pf_ok = pf_need <= (uint32_t)(SC_PF * SC_TPB);
+            if (pf_ok) {
+#pragma unroll
+                for (int u = 0; u < SC_PF; u++) {
+                    const uint32_t e = threadIdx.x + (uint32_t)u * SC_TPB;
+                    if (e < pf_need) {
+                        const uint64_t t = pf_t0 + e;
+                        pf_tp[u] = t <= n_terms ? term_ptr[t] : ~0ull;
+                        pf_idf[u] = t < n_terms ? idf[t] : 0.f;
+                    }
+                }
             }
         }
         __syncthreads();
 #if defined(SS_EXP_SC) && SS_EXP_SC == 2      // ... loads, count and scan
+        loads(base + SC_CH);
         continue;
 #endif
         // (3) records to their staging positions
@@ -745,22 +786,23 @@ __global__ __launch_bounds__(SC_TPB) void k_scatter(const uint32_t* __restrict__
             if (doc[j] != 0xFFFFFFFFu) {
                 const uint32_t b = doc[j] >> shift;
                 const float sq = w[j] * w[j];                          // term_weighting.go:44 (float32 product)
-                const uint32_t pos = L_loff[b] + rank[j];
+                const uint32_t pos = (uint32_t)L_loff[b] + ((rank2[j >> 1] >> ((j & 1) << 4)) & 0xFFFFu);
                 L_rec[pos] = make_uint2(doc[j], __float_as_uint(sq));
-                L_bkt[pos] = (uint16_t)b;
             }
         }
+        loads(base + SC_CH);                                               // (doc / w are free: the next chunk's postings travel under phase 4)
         __syncthreads();
         // (4) out, in staging order: consecutive lanes write consecutive records of a bucket's run
         // (the staged records end where the last bucket's run ends; head postings were never staged)
-        const uint32_t n_staged = L_loff[nbp - 1] + (L_cur[nbp - 1] - L_gout[nbp - 1]);
+        const uint32_t n_staged = s_nstaged;
 #if defined(SS_EXP_SC) && SS_EXP_SC == 1      // ... everything but the stores
         if (n_staged == 0x12345678u) out[0] = L_rec[0];
         continue;
 #endif
         for (uint32_t pos = threadIdx.x; pos < n_staged; pos += SC_TPB) {
-            const uint32_t b = L_bkt[pos];
-            out[(uint64_t)L_gout[b] + (pos - L_loff[b])] = L_rec[pos];
+            const uint2 r = L_rec[pos];
+            const uint32_t b = r.x >> shift;
+            out[(uint64_t)L_gout[b] + (pos - (uint32_t)L_loff[b])] = r;
         }
         // the next chunk's phase (1) only touches hist; its phase (2) rewrites loff / gout after the barrier that follows (1),
         // by which time every thread has left (4)  [WEIGHT: the barrier at the top of the weight phase comes before the window is staged]
@@ -921,7 +963,7 @@ struct BucketPass {
     ss::DevBuf<uint32_t> h_n, h_term, h_bounds, h_hist;  // head lists (see HeadArgs)
     ss::DevBuf<uint64_t> h_hs, h_he;
     uint64_t head_thr = 0;                       // shortest list that takes the head path; 0 = no head path
-    uint32_t nb = 0, nblk = 0, bpt = 1;
+    uint32_t nb = 0, nblk = 0, bpt = 2, nbt = 2;
     uint64_t per = 0;
     int shift = 13;
 };
@@ -951,11 +993,18 @@ int32_t bucket_pass_prepare(ss_ctx* ctx, uint64_t P, uint32_t nb, int shift, Buc
         SS_HIP(ctx, bp.h_he.alloc(HEAD_CAP));
         SS_HIP(ctx, bp.h_bounds.alloc((size_t)(nb + 1) * HEAD_CAP));
     }
-    bp.bpt = ss::div_up(nb, (uint32_t)SC_TPB);
-    if (ctx->tfidf_scatter_lds < (int)scatter_lds_bytes(bp.bpt)) {
-        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(bp.bpt)));
-        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(bp.bpt)));
-        ctx->tfidf_scatter_lds = (int)scatter_lds_bytes(bp.bpt);
+    bp.bpt = (ss::div_up(nb, (uint32_t)SC_TPB) + 1u) & ~1u;                  // even: a thread's buckets are whole words of the packed counts
+    bp.nbt = (nb + 1u) & ~1u;
+    if (bp.bpt > (uint32_t)SC_BPT_MAX) return ctx->fail(SS_ERR_UNSUPPORTED, "tfidf: %u buckets exceed the partition's %d", nb, NB_MAX);
+    if (ctx->tfidf_scatter_lds < (int)scatter_lds_bytes(bp.nbt)) {
+        const int lds = (int)scatter_lds_bytes(bp.nbt);
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<true, SC_BPT_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<false, SC_BPT_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ctx->tfidf_scatter_lds = lds;
     }
     if (ctx->tfidf_bucket_lds < (int)bucket_lds_bytes(shift)) {
         SS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sum<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_bytes(shift)));
@@ -988,12 +1037,17 @@ void bucket_pass_launch(ss_index* idx, hipStream_t st, BucketPass& bp, bool weig
                             idf, P, bp.per, bp.shift, bp.nb, bp.nblk, bp.mat.p, head);
     hipLaunchKernelGGL(k_bucket_rowscan, dim3(bp.nb), dim3(64), 0, st, bp.mat.p, bp.nblk, bp.cnt.p);
     hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(1024), 0, st, bp.cnt.p, bp.nb, bp.off.p, bp.cur.p);
-    if (fused) hipLaunchKernelGGL(k_scatter<true>, dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.bpt), st, (const uint32_t*)idx->post_doc.p, idx->post_w.p, P, bp.per,
-                                  bp.shift, bp.nb, bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p, head,
-                                  (const uint64_t*)idx->term_ptr.p, T, idf);
-    else hipLaunchKernelGGL(k_scatter<false>, dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.bpt), st, (const uint32_t*)idx->post_doc.p, idx->post_w.p, P, bp.per,
-                            bp.shift, bp.nb, bp.nblk, bp.bpt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p, head,
-                            (const uint64_t*)idx->term_ptr.p, T, idf);
+    // (the owner threads' cursor registers are sized by the buckets per thread: 2 up to 1024 buckets, 4 up to 2048, 8 beyond)
+#define SS_SCATTER_LAUNCH(W, B)                                                                                                                     \
+    hipLaunchKernelGGL((k_scatter<W, B>), dim3(bp.nblk), dim3(SC_TPB), scatter_lds_bytes(bp.nbt), st, (const uint32_t*)idx->post_doc.p, idx->post_w.p, P, \
+                       bp.per, bp.shift, bp.nb, bp.nblk, bp.bpt, bp.nbt, (const uint32_t*)bp.mat.p, (const uint32_t*)bp.off.p, bp.packed.p, head,   \
+                       (const uint64_t*)idx->term_ptr.p, T, idf)
+    if (fused) {
+        if (bp.bpt <= 2) SS_SCATTER_LAUNCH(true, 2); else if (bp.bpt <= 4) SS_SCATTER_LAUNCH(true, 4); else SS_SCATTER_LAUNCH(true, SC_BPT_MAX);
+    } else {
+        if (bp.bpt <= 2) SS_SCATTER_LAUNCH(false, 2); else if (bp.bpt <= 4) SS_SCATTER_LAUNCH(false, 4); else SS_SCATTER_LAUNCH(false, SC_BPT_MAX);
+    }
+#undef SS_SCATTER_LAUNCH
     if (weight) hipLaunchKernelGGL(k_bucket_sum<true>, dim3(bp.nb), dim3(TPB_B), bucket_lds_bytes(bp.shift), st, bp.packed.p, bp.off.p, N, bp.shift,
                                    idx->mag.p, idx->mag2.p, (const uint32_t*)idx->post_doc.p, idx->post_w.p, idf, head);
     else hipLaunchKernelGGL(k_bucket_sum<false>, dim3(bp.nb), dim3(TPB_B), bucket_lds_bytes(bp.shift), st, bp.packed.p, bp.off.p, N, bp.shift,
