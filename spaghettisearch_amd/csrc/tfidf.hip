@@ -699,7 +699,17 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
                 if (all) {
 #pragma unroll
                     for (int v4 = 0; v4 < SC_PT / 4; v4++)
+                    {
+#ifdef SS_SC_W_PLAIN_STORE
                         *reinterpret_cast<float4*>(&post_w[i0 + v4 * 4]) = make_float4(w[v4 * 4], w[v4 * 4 + 1], w[v4 * 4 + 2], w[v4 * 4 + 3]);
+#else
+                        // (streamed out, never read again here: non-temporal, so that the weights do not push the half-written lines of
+                        //  the block's bucket runs out of the L2)
+                        typedef float f4s_t __attribute__((ext_vector_type(4)));
+                        f4s_t wv; wv.x = w[v4 * 4]; wv.y = w[v4 * 4 + 1]; wv.z = w[v4 * 4 + 2]; wv.w = w[v4 * 4 + 3];
+                        __builtin_nontemporal_store(wv, reinterpret_cast<f4s_t*>(&post_w[i0 + v4 * 4]));
+#endif
+                    }
                 } else if (any) {
 #pragma unroll
                     for (int j = 0; j < SC_PT; j++)
