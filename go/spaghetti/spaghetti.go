@@ -440,13 +440,13 @@ type Ticket struct {
 	nq, k int
 }
 
-// Submit enqueues a batch of OR queries and returns at once; up to C.SS_SCORE_INFLIGHT batches may be in flight.  A server
+// Submit enqueues a batch of queries (pPtr / pTerms nil: no quoted phrases) and returns at once; up to C.SS_SCORE_INFLIGHT batches may be in flight.  A server
 // goroutine that has the next batch of requests ready calls Submit for it before it Collects the previous one: the host-side
 // plan of batch i+1 and the copy-out of batch i-1 then run under the kernels of batch i.
-func (s *Scorer) Submit(qPtr, qTerms []uint32, queryLen []int32, topicProbs []float64, k int) (Ticket, error) {
+func (s *Scorer) Submit(qPtr, qTerms, pPtr, pTerms []uint32, queryLen []int32, topicProbs []float64, k int) (Ticket, error) {
 	nq := len(qPtr) - 1
 	var id C.uint64_t
-	rc := C.ss_score_topk_submit(s.h, C.int32_t(nq), u32p(qPtr), u32p(qTerms), i32p(queryLen), f64p(topicProbs), C.int32_t(k), &id)
+	rc := C.ss_score_topk_submit(s.h, C.int32_t(nq), u32p(qPtr), u32p(qTerms), u32p(pPtr), u32p(pTerms), i32p(queryLen), f64p(topicProbs), C.int32_t(k), &id)
 	if err := statusErr(s.ctx, rc, "ss_score_topk_submit"); err != nil {
 		return Ticket{}, err
 	}

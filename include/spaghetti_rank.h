@@ -332,7 +332,9 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
  * kernels of batch i: 1024-query batches go host-to-host at the device's batch rate instead of one batch alone plus the copies. */
 #define SS_SCORE_INFLIGHT 3
 int32_t ss_score_topk_submit(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms,
-                             const int32_t* query_len, const double* topic_probs, int32_t k, uint64_t* ticket_out);
+                             const uint32_t* p_ptr /* NULL: no quoted phrases (ss_score_topk); else as ss_score_topk_phrase */,
+                             const uint32_t* p_terms, const int32_t* query_len, const double* topic_probs, int32_t k,
+                             uint64_t* ticket_out);
 int32_t ss_score_topk_collect(ss_scorer* s, uint64_t ticket, ss_hit* hits_out, int32_t* n_hits_out);
 
 /* ss_score_topk plus the quoted-phrase part of retrieval.Retrieve (retrieval/phrase.go:11-170,

@@ -97,7 +97,7 @@ PROTOTYPES = {
     "ss_scorer_set_prior": (_i32, [_vp, _i32, _vp]),
     "ss_score_topk": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ss_score_topk_phrase": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
-    "ss_score_topk_submit": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ss_score_topk_submit": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ss_score_topk_collect": (_i32, [_vp, C.c_uint64, _vp, _vp]),
     "ss_merge_hits": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ss_last_kernel_ms": (_i32, [_vp, _i32, C.POINTER(C.c_float)]),

@@ -1633,8 +1633,8 @@ int32_t ss_score_topk_phrase(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, c
 // Batches in flight with HOST results: submit runs the batch like a call with device outputs (nothing waits, consecutive batches
 // overlap on the device) into the slot's own device buffers; collect waits for that batch alone and copies its rows to the caller.
 // The host's plan for batch i+1 and the copy-out of batch i-1 then run under the kernels of batch i.
-int32_t ss_score_topk_submit(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const int32_t* query_len,
-                             const double* topic_probs, int32_t k, uint64_t* ticket_out) {
+int32_t ss_score_topk_submit(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const uint32_t* q_terms, const uint32_t* p_ptr,
+                             const uint32_t* p_terms, const int32_t* query_len, const double* topic_probs, int32_t k, uint64_t* ticket_out) {
     if (!s) return SS_ERR_INVALID;
     ss_ctx* ctx = s->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1661,7 +1661,7 @@ int32_t ss_score_topk_submit(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, c
         if (!s->out_stream) SS_HIP(ctx, hipStreamCreateWithFlags(&s->out_stream, hipStreamNonBlocking));
     }
     if (n_q) {
-        const int32_t rc = score_impl(s, n_q, q_ptr, q_terms, nullptr, nullptr, query_len, topic_probs, k, a->hits.p, a->n_hits.p);
+        const int32_t rc = score_impl(s, n_q, q_ptr, q_terms, p_ptr, p_terms, query_len, topic_probs, k, a->hits.p, a->n_hits.p);
         if (rc != SS_OK) return rc;
         // Only an event behind the batch's kernels is recorded here; the rows are copied when they are COLLECTED.  [Enqueued at
         // submit, the device-to-host copy waits in the copy engine's in-order queue for this batch's merge and holds up the NEXT

@@ -508,17 +508,20 @@ class Scorer:
                                          hits.ctypes.data, _ptr(n_hits)), self.ctx.h)
         return hits, n_hits
 
-    def submit(self, q_ptr, q_terms, k: int, query_len=None, topic_probs=None):
-        """ss_score_topk_submit: enqueue a batch whose hits go to host memory; -> ticket for collect()."""
+    def submit(self, q_ptr, q_terms, k: int, query_len=None, topic_probs=None, p_ptr=None, p_terms=None):
+        """ss_score_topk_submit: enqueue a batch whose hits go to host memory; -> ticket for collect().
+        p_ptr / p_terms: the queries' quoted phrases as in score_topk_phrase (None: plain OR queries)."""
         q_ptr = _as(q_ptr, "uint32")
         q_terms = _as(q_terms, "uint32")
+        p_ptr = _as(p_ptr, "uint32")
+        p_terms = _as(p_terms, "uint32")
         query_len = _as(query_len, "int32")
         topic_probs = _as(topic_probs, "float64")
         n_q = int(q_ptr.shape[0]) - 1
-        self.ctx.ready(q_ptr, q_terms, query_len, topic_probs)
+        self.ctx.ready(q_ptr, q_terms, p_ptr, p_terms, query_len, topic_probs)
         ticket = C.c_uint64(0)
-        check(self.ctx.lib.ss_score_topk_submit(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(query_len), _ptr(topic_probs), k,
-                                                C.addressof(ticket)), self.ctx.h)
+        check(self.ctx.lib.ss_score_topk_submit(self.h, n_q, _ptr(q_ptr), _ptr(q_terms), _ptr(p_ptr), _ptr(p_terms), _ptr(query_len),
+                                                _ptr(topic_probs), k, C.addressof(ticket)), self.ctx.h)
         return (int(ticket.value), n_q, k)
 
     def collect(self, ticket, out=None):
