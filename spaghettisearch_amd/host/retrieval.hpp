@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <fstream>
 #include <functional>
+#include <deque>
 #include <future>
 #include <mutex>
 #include <thread>
@@ -564,12 +565,17 @@ public:
     // category -> probability, or empty (nil map in the shipped reference, main_retrieve.go:88: sqd = 0).
     // live_topic_probs (opt-in, default off = the reference's nil map): every query's probabilities come from
     // liveTopicProbs over its non-phrase words (the argument of the commented-out call, main_retrieve.go:43).
-    std::vector<std::vector<Rank_combined>> RetrieveBatch(const std::vector<std::string>& queries, int k = 50,
-                                                          const std::vector<std::map<std::string, double>>* topicProbs = nullptr,
-                                                          bool live_topic_probs = false) {
-        using namespace spaghetti;
+    // what a batch of query strings becomes on its way to the device (main_retrieve.go:17-36,88-90)
+    struct Tokenised {
         std::vector<uint32_t> q_ptr{0}, q_terms, p_ptr{0}, p_terms;
         std::vector<int32_t> q_len;
+        std::vector<double> probs;
+        int nq = 0;
+    };
+    Tokenised tokenise(const std::vector<std::string>& queries, const std::vector<std::map<std::string, double>>* topicProbs,
+                       bool live_topic_probs) const {
+        using namespace spaghetti;
+        Tokenised t;
         std::vector<std::map<std::string, double>> live;
         if (live_topic_probs) {
             if (topicProbs) throw std::runtime_error("RetrieveBatch: explicit and live topic probabilities are exclusive");
@@ -589,38 +595,36 @@ public:
             for (auto& tok : queryTokenised) {
                 hashed.push_back(md5::hex(tok));
                 auto it = terms.id.find(hashed.back());
-                q_terms.push_back(it == terms.id.end() ? SS_UNKNOWN_TERM : it->second);   // ErrKeyNotFound tolerated (:193,:218)
+                t.q_terms.push_back(it == terms.id.end() ? SS_UNKNOWN_TERM : it->second);   // ErrKeyNotFound tolerated (:193,:218)
             }
             if (live_topic_probs) live.push_back(liveTopicProbs(hashed));
-            q_ptr.push_back((uint32_t)q_terms.size());
+            t.q_ptr.push_back((uint32_t)t.q_terms.size());
             // all quoted phrases form ONE phrase (main_retrieve.go:26), matched on the device (retrieval/phrase.go)
             for (auto& tok : phraseTokenised) {
                 auto it = terms.id.find(md5::hex(tok));
-                p_terms.push_back(it == terms.id.end() ? SS_UNKNOWN_TERM : it->second);
+                t.p_terms.push_back(it == terms.id.end() ? SS_UNKNOWN_TERM : it->second);
             }
-            p_ptr.push_back((uint32_t)p_terms.size());
-            q_len.push_back((int32_t)(queryTokenised.size() + phraseTokenised.size()));   // :90
+            t.p_ptr.push_back((uint32_t)t.p_terms.size());
+            t.q_len.push_back((int32_t)(queryTokenised.size() + phraseTokenised.size()));   // :90
         }
-        const int nq = (int)queries.size();
-        std::vector<double> probs;
+        t.nq = (int)queries.size();
         const size_t K = categories.size();
         if (live_topic_probs) topicProbs = &live;
         if (topicProbs && K) {
-            probs.assign((size_t)nq * K, 0.0);
-            for (int q = 0; q < nq; q++)
+            t.probs.assign((size_t)t.nq * K, 0.0);
+            for (int q = 0; q < t.nq; q++)
                 for (auto& kv : (*topicProbs)[q]) {
                     auto it = std::lower_bound(categories.begin(), categories.end(), kv.first);
-                    if (it != categories.end() && *it == kv.first) probs[(size_t)q * K + (it - categories.begin())] = kv.second;
+                    if (it != categories.end() && *it == kv.first) t.probs[(size_t)q * K + (it - categories.begin())] = kv.second;
                 }
         }
-        std::vector<ss_hit> hits((size_t)nq * k);
-        std::vector<int32_t> n_hits(nq);
-        check(ss_score_topk_phrase(scorer, nq, q_ptr.data(), q_terms.data(), p_ptr.data(), p_terms.data(), q_len.data(),
-                                   probs.empty() ? nullptr : probs.data(), k, hits.data(), n_hits.data()), "ss_score_topk_phrase");
+        return t;
+    }
+    std::vector<std::vector<Rank_combined>> to_ranks(int nq, int k, const std::vector<ss_hit>& hits, const std::vector<int32_t>& n_hits) const {
         std::vector<std::vector<Rank_combined>> out(nq);
         for (int q = 0; q < nq; q++)
             for (int i = 0; i < n_hits[q]; i++) {
-                const ss_hit& h = hits[(size_t)q * k + i];
+                const auto& h = hits[(size_t)q * k + i];
                 Rank_combined r;
                 r.DocHash = docs.name[h.doc];
                 r.PageRank = h.pagerank;      // get_metadata.go:68
@@ -630,6 +634,37 @@ public:
                 out[q].push_back(r);
             }
         return out;
+    }
+    std::vector<std::vector<Rank_combined>> RetrieveBatch(const std::vector<std::string>& queries, int k = 50,
+                                                          const std::vector<std::map<std::string, double>>* topicProbs = nullptr,
+                                                          bool live_topic_probs = false) {
+        using namespace spaghetti;
+        const Tokenised t = tokenise(queries, topicProbs, live_topic_probs);
+        std::vector<ss_hit> hits((size_t)t.nq * k);
+        std::vector<int32_t> n_hits(t.nq);
+        check(ss_score_topk_phrase(scorer, t.nq, t.q_ptr.data(), t.q_terms.data(), t.p_ptr.data(), t.p_terms.data(), t.q_len.data(),
+                                   t.probs.empty() ? nullptr : t.probs.data(), k, hits.data(), n_hits.data()), "ss_score_topk_phrase");
+        return to_ranks(t.nq, k, hits, n_hits);
+    }
+    // The same in two halves, for a caller that has the next batch ready while this one runs (RetrieveBatcher): BeginBatch tokenises
+    // and enqueues (ss_score_topk_submit; up to SS_SCORE_INFLIGHT batches), FinishBatch waits for that batch and converts its rows.
+    struct PendingBatch { uint64_t ticket = 0; int nq = 0, k = 0; };
+    PendingBatch BeginBatch(const std::vector<std::string>& queries, int k = 50) {
+        using namespace spaghetti;
+        const Tokenised t = tokenise(queries, nullptr, false);
+        PendingBatch pb;
+        pb.nq = t.nq;
+        pb.k = k;
+        check(ss_score_topk_submit(scorer, t.nq, t.q_ptr.data(), t.q_terms.data(), t.p_ptr.data(), t.p_terms.data(), t.q_len.data(), nullptr, k,
+                                   &pb.ticket), "ss_score_topk_submit");
+        return pb;
+    }
+    std::vector<std::vector<Rank_combined>> FinishBatch(const PendingBatch& pb) {
+        using namespace spaghetti;
+        std::vector<ss_hit> hits((size_t)pb.nq * pb.k + 1);
+        std::vector<int32_t> n_hits((size_t)pb.nq + 1);
+        check(ss_score_topk_collect(scorer, pb.ticket, hits.data(), n_hits.data()), "ss_score_topk_collect");
+        return to_ranks(pb.nq, pb.k, hits, n_hits);
     }
 };
 
@@ -660,55 +695,88 @@ public:
     size_t largest_batch() const { return largest_; }
 
 private:
+    typedef std::vector<std::pair<std::string, std::promise<std::vector<Rank_combined>>>> Batch;
+    struct InFlight { DeviceIndex::PendingBatch pb; Batch batch; };
+    // every caller of `batch` that has no answer yet is served on its own: only the caller of an offending query gets the error
+    // (done[i]: caller i has its answer — a promise takes exactly one value or exception: a second set_* throws future_error,
+    // which inside a catch block would end the serving thread)
+    void one_by_one(Batch& batch, std::vector<char>& done) {
+        for (size_t i = 0; i < batch.size(); i++) {
+            if (done[i]) continue;
+            std::exception_ptr err;
+            try {
+                auto one = di_.RetrieveBatch({batch[i].first}, k_);
+                if (one.size() != 1) throw std::runtime_error("RetrieveBatch: no result for a single query");
+                batch[i].second.set_value(std::move(one[0]));
+                done[i] = 1;
+            } catch (...) {
+                err = std::current_exception();
+            }
+            if (!done[i]) {
+                try { batch[i].second.set_exception(err); } catch (...) {}   // promise already satisfied: nothing left to tell
+                done[i] = 1;
+            }
+        }
+    }
+    void finish(InFlight& f) {
+        std::vector<char> done(f.batch.size(), 0);
+        bool whole = true;
+        try {
+            auto res = di_.FinishBatch(f.pb);
+            if (res.size() != f.batch.size()) throw std::runtime_error("RetrieveBatch: result count differs from the batch");
+            for (size_t i = 0; i < f.batch.size(); i++) {
+                f.batch[i].second.set_value(std::move(res[i]));
+                done[i] = 1;
+            }
+        } catch (...) {
+            whole = false;
+        }
+        if (!whole) one_by_one(f.batch, done);
+    }
+    // Up to TWO batches in flight: while the device scores batch i, this thread tokenises and enqueues batch i+1 (if callers are
+    // waiting), then hands batch i back.  With nobody waiting a batch is handed back as soon as it is done, as before.
     void run() {
+        std::deque<InFlight> flight;
         for (;;) {
-            std::vector<std::pair<std::string, std::promise<std::vector<Rank_combined>>>> batch;
+            Batch batch;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [this] { return stop_ || !pending_.empty(); });
-                if (stop_ && pending_.empty()) return;
-                // first request in: wait a little for company
-                const auto deadline = std::chrono::steady_clock::now() + max_wait_;
-                cv_.wait_until(lk, deadline, [this] { return stop_ || pending_.size() >= max_batch_; });
-                batch.swap(pending_);
-            }
-            std::vector<std::string> queries;
-            for (auto& p : batch) queries.push_back(p.first);
-            // done[i]: caller i has its answer (a promise takes exactly one value or exception: a second set_* throws
-            // future_error, which inside a catch block would end the serving thread)
-            std::vector<char> done(batch.size(), 0);
-            bool whole = true;
-            try {
-                auto res = di_.RetrieveBatch(queries, k_);
-                if (res.size() != batch.size()) throw std::runtime_error("RetrieveBatch: result count differs from the batch");
-                for (size_t i = 0; i < batch.size(); i++) {
-                    batch[i].second.set_value(std::move(res[i]));
-                    done[i] = 1;
+                if (flight.empty()) {
+                    cv_.wait(lk, [this] { return stop_ || !pending_.empty(); });
+                    if (stop_ && pending_.empty()) return;
+                    // first request in: wait a little for company
+                    const auto deadline = std::chrono::steady_clock::now() + max_wait_;
+                    cv_.wait_until(lk, deadline, [this] { return stop_ || pending_.size() >= max_batch_; });
                 }
-            } catch (...) {
-                whole = false;
+                batch.swap(pending_);                                      // (a batch is running: whoever waits now rides the next one)
             }
-            // The library refuses a batch as a whole (e.g. one quoted phrase beyond SS_MAX_PHRASE_TERMS): answer the
-            // remaining callers one by one, so that only the caller of the offending query gets the error.
-            if (!whole)
-                for (size_t i = 0; i < batch.size(); i++) {
-                    if (done[i]) continue;
-                    std::exception_ptr err;
-                    try {
-                        auto one = di_.RetrieveBatch({batch[i].first}, k_);
-                        if (one.size() != 1) throw std::runtime_error("RetrieveBatch: no result for a single query");
-                        batch[i].second.set_value(std::move(one[0]));
-                        done[i] = 1;
-                    } catch (...) {
-                        err = std::current_exception();
-                    }
-                    if (!done[i]) {
-                        try { batch[i].second.set_exception(err); } catch (...) {}   // promise already satisfied: nothing left to tell
-                        done[i] = 1;
-                    }
+            if (!batch.empty()) {
+                std::vector<std::string> queries;
+                for (auto& p : batch) queries.push_back(p.first);
+                n_batches_++;
+                largest_ = std::max(largest_, batch.size());
+                InFlight f;
+                bool begun = true;
+                try {
+                    f.pb = di_.BeginBatch(queries, k_);
+                } catch (...) {
+                    begun = false;                                         // the library refuses the batch as a whole (e.g. one phrase beyond SS_MAX_PHRASE_TERMS)
                 }
-            n_batches_++;
-            largest_ = std::max(largest_, batch.size());
+                if (begun) {
+                    f.batch = std::move(batch);
+                    flight.push_back(std::move(f));
+                } else {
+                    std::vector<char> done(batch.size(), 0);
+                    one_by_one(batch, done);
+                }
+            }
+            // hand back the oldest batch when a second one is behind it, or when nobody is waiting to be batched
+            bool more;
+            { std::lock_guard<std::mutex> lk(mu_); more = !pending_.empty(); }
+            while (!flight.empty() && (flight.size() >= 2 || !more)) {
+                finish(flight.front());
+                flight.pop_front();
+            }
         }
     }
     DeviceIndex& di_;

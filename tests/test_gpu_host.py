@@ -292,6 +292,35 @@ def test_concurrent_requests_are_batched(host, corpus):
     assert [(r.DocHash, r.FinalRank) for r in one] == [(r.DocHash, r.FinalRank) for r in want[0]]
 
 
+def test_batcher_keeps_batches_in_flight(host, corpus):
+    """Under a steady stream of callers the batcher enqueues the next batch (ss_score_topk_submit) before it hands the previous one back
+    (ss_score_topk_collect): 24 threads x 12 requests with a short window make many overlapping batches, quoted phrases included;
+    every caller still gets exactly its own result."""
+    import threading
+    forw, inv = _weighted_tables(host, corpus)
+    di = host.DeviceIndex()
+    di.load(forw, inv)
+    queries = [(f'w{i % 150} "w{(5 * i + 1) % 150} w{(5 * i + 2) % 150}" w{(11 * i + 7) % 150}' if i % 3 == 0
+                else f"w{i % 150} w{(7 * i + 3) % 150} w{(13 * i + 5) % 150}") for i in range(24 * 12)]
+    want = di.RetrieveBatch(queries, 50)
+    batcher = host.RetrieveBatcher(di, 50, 200, 64)
+    got = [None] * len(queries)
+
+    def worker(t):
+        for j in range(12):
+            i = t * 12 + j
+            got[i] = batcher.Retrieve(queries[i])
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(24)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for a, b in zip(want, got):
+        assert [(r.DocHash, r.FinalRank, r.TitleRank, r.BodyRank) for r in a] == [(r.DocHash, r.FinalRank, r.TitleRank, r.BodyRank) for r in b]
+    assert 12 <= batcher.batches < len(queries)
+
+
 def _retrieve_key(res):
     """sort.Slice on FinalRank is unstable in the reference (main_retrieve.go:96) and dense ids differ between a patched
     and a freshly loaded index: compare up to the order of equal FinalRanks."""
