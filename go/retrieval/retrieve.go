@@ -170,11 +170,10 @@ var (
 	batchers sync.Once
 )
 
-// score answers `batch` (all on one snapshot) with one library call.
-func score(snap *deviceIndex, batch []*request) ([][]spaghetti.Hit, error) {
-	qPtr, pPtr := []uint32{0}, []uint32{0}
-	var qTerms, pTerms []uint32
-	qLen := make([]int32, 0, len(batch))
+// concat lays the batch's token lists end to end (the library's CSR form of a query batch).
+func concat(batch []*request) (qPtr, qTerms, pPtr, pTerms []uint32, qLen []int32) {
+	qPtr, pPtr = []uint32{0}, []uint32{0}
+	qLen = make([]int32, 0, len(batch))
 	for _, r := range batch {
 		qTerms = append(qTerms, r.qTerms...)
 		pTerms = append(pTerms, r.pTerms...)
@@ -182,8 +181,59 @@ func score(snap *deviceIndex, batch []*request) ([][]spaghetti.Hit, error) {
 		pPtr = append(pPtr, uint32(len(pTerms)))
 		qLen = append(qLen, r.qLen)
 	}
+	return
+}
+
+// score answers `batch` (all on one snapshot) with one synchronous library call.
+func score(snap *deviceIndex, batch []*request) ([][]spaghetti.Hit, error) {
+	qPtr, qTerms, pPtr, pTerms, qLen := concat(batch)
 	// topicProbs stays nil as in the shipped reference (main_retrieve.go:40,87-88): sqd = 0.
 	return snap.scorer.ScoreTopKPhrase(qPtr, qTerms, pPtr, pTerms, qLen, nil, topK)
+}
+
+// Batches in flight: batchLoop submits a batch (the library enqueues it and returns) and goes back to collecting requests;
+// collectLoop waits for the batches in the order they were submitted and answers their callers.  The channel holds two batches
+// while a third is being collected: SS_SCORE_INFLIGHT = 3 tickets at most.  The host's plan for batch i+1 and the copy-out of
+// batch i-1 then run under the kernels of batch i (INTEGRATION.md §4).
+type inflight struct {
+	snap   *deviceIndex
+	ticket spaghetti.Ticket
+	batch  []*request
+}
+
+var flights = make(chan inflight, 2)
+
+// replyAll hands every request of a collected batch its hits; a panic on the way still leaves every waiter with a reply.
+func replyAll(batch []*request, hits [][]spaghetti.Hit) {
+	for i, r := range batch {
+		r.reply <- reply{hits[i], nil}
+	}
+}
+
+func collectLoop() {
+	for f := range flights {
+		func() {
+			answered := false
+			defer func() {
+				if p := recover(); p != nil && !answered {
+					for _, r := range f.batch {
+						select {
+						case r.reply <- reply{nil, fmt.Errorf("retrieval batch failed: %v", p)}:
+						default: // this caller already has its reply
+						}
+					}
+				}
+			}()
+			hits, err := f.snap.scorer.Collect(f.ticket)
+			if err == nil {
+				replyAll(f.batch, hits)
+				answered = true
+				return
+			}
+			serve(f.snap, f.batch) // the batch failed as a whole: one synchronous call per request
+			answered = true
+		}()
+	}
 }
 
 // serve answers one batch; every waiter gets a reply or an error, whatever happens (a panic below the library
@@ -243,7 +293,13 @@ func batchLoop() {
 					rest = append(rest, r)
 				}
 			}
-			serve(snap, same)
+			// enqueue and move on; if the library refuses the batch as a whole, serve it request by request right here
+			qPtr, qTerms, pPtr, pTerms, qLen := concat(same)
+			if t, err := snap.scorer.Submit(qPtr, qTerms, pPtr, pTerms, qLen, nil, topK); err == nil {
+				flights <- inflight{snap, t, same}
+			} else {
+				serve(snap, same)
+			}
 			batch = rest
 		}
 	}
@@ -284,7 +340,7 @@ func acquire(ctx context.Context, forw []db.DB, inv []db.DB) *deviceIndex {
 func Retrieve(query string, ctx context.Context, forw []db.DB, inv []db.DB) []Rank_combined {
 	snap := acquire(ctx, forw, inv)
 	defer snap.users.Done()
-	batchers.Do(func() { go batchLoop() })
+	batchers.Do(func() { go batchLoop(); go collectLoop() })
 
 	// main_retrieve.go:17-36 — query parsing, unchanged
 	phrases := getPhrase(query)
