@@ -285,6 +285,8 @@ static const char* const k_option_names[] = {
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
     "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 65536, 0 = off)
     "pr.deal_snake",        // work items dealt to the waves in alternating direction (1) or least-loaded-first (0); default: 1 from 8 items per wave on and for k_pr_sweep_n
+    "pr.affine",            // 1: ss_pagerank_run computes every topic from TWO vectors (the reference's topics differ only in their start value 1/n_k,
+                            //    and its recurrence maps (p*u + q) / (r*u + s) onto itself): opt-in, not the reference's operation order (~1e-13)
     "pr.deal_global",       // 0: the work items are dealt chunk by chunk in table order, each chunk sorted by cost (before round 4); 1: all items by
                             //    falling cost first (one counting sort; default for k_pr_sweep_n); 2: by falling cost inside each class, the classes in
                             //    table order (default for k_pr_sweep)

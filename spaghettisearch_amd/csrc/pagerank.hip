@@ -46,6 +46,7 @@ struct PrCtl {
     double csum[MAXK];    // last contribution sum (diagnostics)
     double xz[MAXK];      // rank of EVERY row without in-edges (they all share one value per topic)
     double xz_in[MAXK];   // topic-sensitive teleport only: that rank for the rows INSIDE the topic's teleport set (xz: outside)
+    double tele[MAXK];    // two-vector form only ("pr.affine"): the teleport of each COLUMN for the next sweep
     int32_t active[MAXK];
     int32_t iters[MAXK];
     int32_t sweep;        // sweeps completed
@@ -53,6 +54,24 @@ struct PrCtl {
     uint32_t ticket;      // last-group arrival counter
     uint32_t pad;
     uint32_t gticket[8];  // last-block-of-a-group arrival counters
+};
+
+// The two-vector form of the reference's recurrence (option "pr.affine", opt-in; DESIGN K1b).  Every topic of pagerank.go:85-124 runs
+// the SAME linear map on the same graph and differs only in its start value u_k = 1/n_k (:104); with x = (p*u + q) / (r*u + s)
+// elementwise (p, q vectors over the nodes, r, s scalars) one iteration maps (p, q, r, s) to
+//     p' = M p + tau*r*1,  q' = M q + tau*s*1,  r' = W p + tau*N*r,  s' = W q + tau*N*s        (M: the inherited part, W: the sum of
+// the contributions, tau = 1 - d; iteration 1 adds the start vector: p += 1) — so TWO vectors carry every topic, whatever K is.
+// The state is kept scaled to s = 1.  Per-topic ranks, L1 changes and stop decisions are evaluated from (p, q, r) by streaming
+// kernels; a topic's ranks are written out in the iteration it stops.  Not the reference's float64 operation order: ranks agree
+// with the oracle to ~1e-13, iteration counts where the stop rule is not at a rounding tie.
+constexpr int AFF_MAXK = 256;
+struct AffCtl {
+    double u[AFF_MAXK];       // 1 / n_topic
+    double delta[AFF_MAXK];   // last L1 change of the topic
+    int32_t active[AFF_MAXK], iters[AFF_MAXK], just[AFF_MAXK];   // just: stopped in the iteration that has just been evaluated
+    double r_x, r_prev, r_next;      // r of the stored vectors, of the previous ones, of the next sweep's result (s = 1 throughout)
+    double xz_prev[2];               // the edge-less rows' (p, q) before the last sweep
+    int32_t n_active, n_just, k_real, it;
 };
 
 enum : uint32_t { W_SEG = 0, W_WAVE = 1, W_GROUP = 2, W_ZERO = 3,   // GW < 8 (k_pr_step): block-owned items
@@ -97,6 +116,9 @@ struct PrParams {
     uint32_t ts_mask;         // bit k: topic k has a teleport set (others keep the uniform teleport)
     uint32_t zrow;            // index of the table's all-zero row (= nd_int): where the unused slots of a chunk gather from
     const uint32_t* woff;     // k_pr_sweep: [waves][8]: wave w's items of class c are work[woff[8w+c] .. woff[8w+c+1])
+    double* x_alt;            // two-vector form: sweep s reads x (s even) / x_alt (s odd) and writes the other one; null otherwise
+    AffCtl* aff;              // two-vector form ("pr.affine"): its control block; null otherwise
+    const double* tele_col;   // ... and the per-column teleport (ctl->tele); null = the uniform p.teleport
 #ifdef SS_PR_EXP_KINDMASK
     uint32_t kind_mask;       // experiment builds only: run just these work classes (bit = kind)
 #endif
@@ -130,6 +152,50 @@ __device__ __forceinline__ double zero_row_rank_ts(const PrParams& p, int sweep,
 
 __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl, const double* cs, bool is_begin) {
     PrCtl* ctl = p.ctl;
+    if (p.aff) {
+        // columns 0 / 1 = p / q.  Both are divided by the common s' = W q + tau*N (s = 1), their teleports are tau*r and tau.
+        AffCtl* a = p.aff;
+        if (is_begin) {
+            for (int k = 0; k < MAXK; k++) {
+                const bool real = k < 2;
+                ctl->xz[k] = real ? p.x0[k] : 0.0;
+                ctl->xz_in[k] = ctl->xz[k];
+                ctl->S[k] = real ? cs[1] + p.tele_n : 1.0;
+                ctl->csum[k] = real ? cs[k] : 0.0;
+                ctl->delta[k] = 0.0;
+                ctl->active[k] = real ? 1 : 0;
+                ctl->iters[k] = 0;
+                ctl->tele[k] = 0.0;
+            }
+            ctl->tele[1] = p.teleport;                                // tau * s, s = 1; tele[0] = tau * r with r = 0
+            a->r_x = 0.0;
+            a->r_prev = 0.0;
+            a->r_next = cs[0] / (cs[1] + p.tele_n);
+            a->xz_prev[0] = ctl->xz[0];
+            a->xz_prev[1] = ctl->xz[1];
+            a->it = 0;
+            ctl->sweep = 0;
+            ctl->n_active = 2;
+            return;
+        }
+        const int it = ctl->sweep + 1;
+        a->r_prev = a->r_x;
+        a->r_x = a->r_next;                                           // r of the vectors this sweep has written
+        for (int k = 0; k < 2; k++) {
+            a->xz_prev[k] = ctl->xz[k];
+            ctl->xz[k] = zero_row_rank_ts(p, ctl->sweep, ctl->S[k], p.x0[k], ctl->tele[k]);
+            ctl->xz_in[k] = ctl->xz[k];
+            ctl->iters[k] = it;
+            ctl->csum[k] = cs[k];
+        }
+        const double s_next = cs[1] + p.tele_n;                       // W q + tau*N*s
+        a->r_next = (cs[0] + p.tele_n * a->r_x) / s_next;             // (W p + tau*N*r) / s'
+        ctl->tele[0] = p.teleport * a->r_x;
+        ctl->tele[1] = p.teleport;
+        ctl->S[0] = ctl->S[1] = s_next;
+        ctl->sweep = it;
+        return;
+    }
     if (is_begin) {
         for (int k = 0; k < MAXK; k++) {
             const bool real = k < p.k_topics;
@@ -836,8 +902,10 @@ struct NCtx {
     const PrParams& p;
     const double* __restrict__ T;
     double* __restrict__ Tw;
-    double S[KW], x0[KW], dsum[KW], csum[KW];
+    double S[KW], x0[KW], dsum[KW], csum[KW], tele[KW];
     bool act[KW];
+    const double* __restrict__ xr;      // ranks before this sweep
+    double* __restrict__ xw;            // ... and after it (the same array, except in the two-vector form: PrParams::x_alt)
 };
 template <int KW, bool TS>
 __device__ __forceinline__ void finish_n(NCtx<KW, TS>& c, uint32_t lrow, const NVec<KW>& y, const NVec<KW>& xo, uint32_t od) {
@@ -845,12 +913,12 @@ __device__ __forceinline__ void finish_n(NCtx<KW, TS>& c, uint32_t lrow, const N
 #pragma unroll
     for (int k = 0; k < KW; k++) {
         const double yk = y.v[k] + c.x0[k];
-        double tele = p.teleport;
+        double tele = c.tele[k];
         if constexpr (TS) tele = teleport_of(p, lrow, k);
         double xn = (yk + tele) / c.S[k];                         // pagerank.go:117
         const size_t xi = (size_t)lrow * KW + k;
         if (c.act[k]) {
-            NT_STORE(xn, &p.x[xi]);
+            NT_STORE(xn, &c.xw[xi]);
             c.dsum[k] += fabs(xn - xo.v[k]);                      // pagerank.go:118
         } else {
             xn = xo.v[k];                                         // converged topic: frozen
@@ -887,7 +955,7 @@ __device__ __forceinline__ void deg_lane_rows(NCtx<KW, TS>& c, const WorkItem& w
             const uint32_t raw = NT_LOAD(&p.in_src[ok ? e0 + (uint32_t)u : w.beg]);
             src[u] = ok ? (raw & SRC_MASK) : p.zrow;
         }
-        const NVec<KW> xo = load_x<KW>(p.x, lrow);
+        const NVec<KW> xo = load_x<KW>(c.xr, lrow);
         const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
         NVec<KW> v[ND];
 #pragma unroll
@@ -910,9 +978,12 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
     const int sweep = ctl->sweep;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    NCtx<KW, TS> c{p, p.tab_rd[sweep & 1], p.tab_wr[sweep & 1], {}, {}, {}, {}, {}};
+    // (two-vector form: the vectors alternate between x and x_alt, so that the previous ones are still there for the topics' L1 changes)
+    NCtx<KW, TS> c{p, p.tab_rd[sweep & 1], p.tab_wr[sweep & 1], {}, {}, {}, {}, {}, {},
+                   (p.x_alt && (sweep & 1)) ? p.x_alt : p.x, p.x_alt ? ((sweep & 1) ? p.x : p.x_alt) : p.x};
 #pragma unroll
     for (int k = 0; k < KW; k++) {
+        c.tele[k] = p.tele_col ? p.tele_col[k] : p.teleport;          // (per column only in the two-vector form)
         c.S[k] = ctl->S[k];
         c.act[k] = ctl->active[k] != 0;
         c.x0[k] = sweep == 0 ? p.x0[k] : 0.0;                     // Q4: iteration 1 accumulates onto 1/n
@@ -926,7 +997,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
     for (uint32_t it = off[0]; it < off[1]; it++) {
         const WorkItem w = p.work[it];
         const uint32_t lrow = w.row;
-        NVec<KW> xo = load_x<KW>(p.x, lrow);
+        NVec<KW> xo = load_x<KW>(c.xr, lrow);
         const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
         NVec<KW> acc;
 #pragma unroll
@@ -997,7 +1068,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
                 const bool valid = rr < w.count;
                 const uint32_t lrow = w.row + (valid ? rr : 0u);
                 const uint32_t b = p.in_ptr[lrow], e_end = valid ? p.in_ptr[lrow + 1] : b;
-                NVec<KW> xo = load_x<KW>(p.x, lrow);
+                NVec<KW> xo = load_x<KW>(c.xr, lrow);
                 const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
                 NVec<KW> acc;
 #pragma unroll
@@ -1053,7 +1124,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
 #pragma unroll
             for (int k = 0; k < KW; k++) {
                 const bool ts = TS && p.memb && ((p.ts_mask >> k) & 1u);
-                const double xz_out = c.act[k] ? (ts ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], 0.0) : zero_row_rank(p, sweep, c.S[k], p.x0[k])) : ctl->xz[k];
+                const double xz_out = c.act[k] ? (ts ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], 0.0) : zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], c.tele[k])) : ctl->xz[k];
                 const double xz_inn = ts ? (c.act[k] ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], p.tin[k]) : ctl->xz_in[k]) : xz_out;
                 const double xz = ts && ((p.memb[lrow] >> k) & 1u) ? xz_inn : xz_out;
                 const double cc = p.d * xz / (double)od;                      // pagerank.go:136
@@ -1467,6 +1538,132 @@ __global__ __launch_bounds__(TPB) void k_pr_read_orig(const double* __restrict__
 #pragma unroll
     for (int k = 0; k < GW; k++)
         if (k < k_topics) out[(size_t)k * n + v] = r[k];
+}
+
+
+// ---- two-vector form: per-topic L1 change, stop rule, write-out ("pr.affine"; see AffCtl) ---------------------------------------
+// x holds (p, q) of the rows WITH in-edges; the edge-less rows share one (p, q) per class position (ctl->xz).  A topic's rank
+// of a row is (p*u + q) / (r*u + 1).
+constexpr int AFF_KC = 16;        // topics a thread accumulates per pass over the rows
+constexpr unsigned AFF_NB = 512;  // blocks of k_aff_delta (their partial sums are added in a fixed order)
+__global__ __launch_bounds__(TPB) void k_aff_delta(const double2* __restrict__ xp, const double2* __restrict__ xn, const AffCtl* __restrict__ a,
+                                                   uint32_t sl_nd, uint32_t pos_nd, uint32_t pos_d, double* __restrict__ partials) {
+    __shared__ double red[WAVES][AFF_KC];
+    if (a->n_active == 0) return;                                     // every topic has stopped: the enqueued iterations are no-ops
+    const int k_real = a->k_real;
+    const double r_old = a->r_prev, r_new = a->r_x;
+    const uint32_t n_rows = pos_nd + pos_d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k0 = 0; k0 < k_real; k0 += AFF_KC) {
+        double u[AFF_KC], d_old[AFF_KC], d_new[AFF_KC], acc[AFF_KC];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < AFF_KC; j++) {
+            const bool on = k0 + j < k_real && a->active[k0 + j] != 0;
+            any = any || on;
+            u[j] = on ? a->u[k0 + j] : 0.0;
+            d_old[j] = r_old * u[j] + 1.0;
+            d_new[j] = r_new * u[j] + 1.0;
+            acc[j] = 0.0;
+        }
+        if (any) {
+            for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_rows; i += gridDim.x * TPB) {
+                const uint32_t lrow = i < pos_nd ? i : sl_nd + (i - pos_nd);
+                const double2 o = xp[lrow], n = xn[lrow];
+#pragma unroll
+                for (int j = 0; j < AFF_KC; j++) acc[j] += fabs((n.x * u[j] + n.y) / d_new[j] - (o.x * u[j] + o.y) / d_old[j]);   // pagerank.go:118
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < AFF_KC; j++) {
+            double v = acc[j];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[wave][j] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < AFF_KC && k0 + (int)threadIdx.x < k_real) {
+            double v = 0.0;
+            for (int w = 0; w < WAVES; w++) v += red[w][threadIdx.x];
+            partials[(size_t)blockIdx.x * AFF_MAXK + k0 + threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
+}
+// one block: the topics' L1 changes (block partials in block order + the edge-less rows, which all hold one value), pagerank.go:93
+// and the max_iter cut, per topic
+__global__ __launch_bounds__(AFF_MAXK) void k_aff_ctl(AffCtl* __restrict__ a, PrCtl* __restrict__ ctl, const double* __restrict__ partials, unsigned nb,
+                                                      double n_zero, double eps, int max_iter) {
+    __shared__ int s_na, s_nj;
+    __shared__ double s_part[16][AFF_KC];
+    __shared__ double s_dl[AFF_MAXK];
+    const int k = threadIdx.x;
+    if (a->n_active == 0) {
+        if (k == 0) a->n_just = 0;
+        return;
+    }
+    if (k == 0) { s_na = 0; s_nj = 0; }
+    const int k_real = a->k_real;
+    // the blocks' partial sums, 16 topics at a time: thread (part, j) adds blocks part, part + 16, ... of topic j in block order, thread
+    // j then adds the 16 parts in order — fixed order, and nobody adds 256 numbers alone
+    for (int k0 = 0; k0 < k_real; k0 += AFF_KC) {
+        const int j = k & (AFF_KC - 1), part = k >> 4;
+        double v = 0.0;
+        if (k0 + j < k_real)
+            for (unsigned b = (unsigned)part; b < nb; b += 16) v += partials[(size_t)b * AFF_MAXK + k0 + j];
+        s_part[part][j] = v;
+        __syncthreads();
+        if (k < AFF_KC) {
+            double t = 0.0;
+            for (int q = 0; q < 16; q++) t += s_part[q][k];
+            s_dl[k0 + k] = t;
+        }
+        __syncthreads();
+    }
+    const int it = a->it + 1;
+    if (k < k_real) {
+        a->just[k] = 0;
+        if (a->active[k]) {
+            double dl = s_dl[k];
+            const double u = a->u[k];
+            const double z_new = (ctl->xz[0] * u + ctl->xz[1]) / (a->r_x * u + 1.0);
+            const double z_old = (a->xz_prev[0] * u + a->xz_prev[1]) / (a->r_prev * u + 1.0);
+            dl += n_zero * fabs(z_new - z_old);
+            a->delta[k] = dl;
+            a->iters[k] = it;
+            bool cont = dl > eps;                                       // pagerank.go:93
+            if (max_iter > 0 && it >= max_iter) cont = false;
+            if (cont) atomicAdd(&s_na, 1);
+            else { a->active[k] = 0; a->just[k] = 1; atomicAdd(&s_nj, 1); }
+        }
+    }
+    __syncthreads();
+    if (k == 0) {
+        a->it = it;
+        a->n_active = s_na;
+        a->n_just = s_nj;
+        if (s_na == 0) ctl->n_active = 0;                             // the sweeps that are already enqueued return at once
+    }
+}
+// ranks of the topics that have just stopped, by ORIGINAL id (rank_out[k][v]): one thread per node, its row's (p, q) once
+__global__ __launch_bounds__(TPB) void k_aff_emit(const double2* __restrict__ x, const PrCtl* __restrict__ ctl, const AffCtl* __restrict__ a,
+                                                  const uint32_t* __restrict__ new_id, uint64_t n, uint32_t sl_nd, uint32_t pos_nd, uint32_t pos_d,
+                                                  double* __restrict__ out) {
+    if (a->n_just == 0) return;
+    const double r = a->r_x;
+    const int k_real = a->k_real;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t lrow = new_id[v];
+        const bool zero = lrow < sl_nd ? lrow >= pos_nd : (lrow - sl_nd) >= pos_d;
+        double2 pq;
+        if (zero) pq = make_double2(ctl->xz[0], ctl->xz[1]);
+        else pq = x[lrow];
+        for (int k = 0; k < k_real; k++)
+            if (a->just[k]) {
+                const double u = a->u[k];
+                out[(size_t)k * n + v] = (pq.x * u + pq.y) / (r * u + 1.0);
+            }
+    }
 }
 
 template <int GW>
@@ -2431,6 +2628,77 @@ int32_t ss_pr_probe(ss_pr* pr, int32_t mode, int32_t n_reps, float* ms_out) {
     return SS_OK;
 }
 
+// ss_pagerank_run in the two-vector form (option "pr.affine" = 1; world 1, the reference's uniform teleport): every topic of the
+// reference's recurrence from TWO vectors (AffCtl).  One iteration = a copy of the stored vectors, one K = 2 sweep (k_pr_sweep_n<2>),
+// one streaming pass for the topics' L1 changes, the stop rule, and the write-out of the topics that have just stopped.
+static int32_t run_affine(ss_graph* g, double damping, double eps, int32_t max_iter, int32_t k_topics, const int32_t* n_topic,
+                          double* rank_out, int32_t* iters_out) {
+    ss_ctx* ctx = g->ctx;
+    hipStream_t st = ctx->stream;
+    if (k_topics > AFF_MAXK) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pagerank_run (pr.affine): at most %d topics", AFF_MAXK);
+    for (int k = 0; k < k_topics; k++)
+        if (n_topic[k] < 1) return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run: n_topic[%d] < 1", k);
+    const int32_t two[2] = {1, 1};
+    ss_pr* pr = nullptr;
+    SS_TRY(ss_pr_create(g, damping, -1.0, 0, 2, two, &pr));
+    struct Guard { ss_pr* p; ~Guard() { ss_pr_destroy(p); } } guard{pr};
+    if (!pr->nwave || pr->gw != 2) return ctx->fail(SS_ERR_UNSUPPORTED, "ss_pagerank_run (pr.affine): needs the wave-item K = 2 sweep (pr.narrow_wave / pr.force_narrow at their defaults)");
+    const uint32_t n_local = g->n_local();
+    ss::DevBuf<AffCtl> aff;
+    ss::DevBuf<double> x_prev, partials, d_out;
+    SS_HIP(ctx, aff.alloc(1));
+    SS_HIP(ctx, x_prev.alloc((size_t)n_local * 2));
+    SS_HIP(ctx, partials.alloc((size_t)AFF_NB * AFF_MAXK));
+    std::vector<AffCtl> h(1);
+    std::memset(h.data(), 0, sizeof(AffCtl));
+    for (int k = 0; k < k_topics; k++) { h[0].u[k] = 1.0 / (double)n_topic[k]; h[0].active[k] = 1; }   // pagerank.go:104
+    h[0].k_real = k_topics;
+    h[0].n_active = k_topics;
+    SS_HIP(ctx, hipMemcpyAsync(aff.p, h.data(), sizeof(AffCtl), hipMemcpyHostToDevice, st));
+    const double x0[MAXK] = {1.0, 0.0};                            // p = 1, q = 0: the start vector is u * 1
+    SS_HIP(ctx, hipMemcpyAsync(pr->x0.p, x0, sizeof(x0), hipMemcpyHostToDevice, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));                         // (h, x0: host temporaries)
+    pr->prm.aff = aff.p;
+    pr->prm.tele_col = pr->ctl.p->tele;
+    pr->prm.x_alt = x_prev.p;
+    // results: straight into the caller's array when it lives on the device
+    hipPointerAttribute_t at{};
+    const bool dev_out = hipPointerGetAttributes(&at, rank_out) == hipSuccess && at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    double* out = rank_out;
+    if (!dev_out) {
+        SS_HIP(ctx, d_out.alloc((size_t)k_topics * g->n));
+        out = d_out.p;
+    }
+    SS_TRY(ss_pr_begin(pr));
+    const double n_zero = (double)((g->cnt_nd - pr->prm.pos_nd) + (g->cnt_d - pr->prm.pos_d));
+    int32_t n_active = k_topics, it = 0;
+    const int BATCH = 4;
+    while (n_active > 0) {
+        for (int b = 0; b < BATCH; b++) {
+            // sweep number `it` (from 0) reads x / x_alt (even / odd) and writes the other one
+            const double2* const x_old = reinterpret_cast<const double2*>((it & 1) ? x_prev.p : pr->x.p);
+            const double2* const x_new = reinterpret_cast<const double2*>((it & 1) ? pr->x.p : x_prev.p);
+            launch_step<2>(pr, st);
+            hipLaunchKernelGGL(k_aff_delta, dim3(AFF_NB), dim3(TPB), 0, st, x_old, x_new, (const AffCtl*)aff.p, g->sl_nd, pr->prm.pos_nd, pr->prm.pos_d, partials.p);
+            hipLaunchKernelGGL(k_aff_ctl, dim3(1), dim3(AFF_MAXK), 0, st, aff.p, pr->ctl.p, (const double*)partials.p, AFF_NB, n_zero, eps, max_iter);
+            hipLaunchKernelGGL(k_aff_emit, dim3((unsigned)std::min<uint64_t>(4096, ss::div_up(g->n, TPB))), dim3(TPB), 0, st, x_new, (const PrCtl*)pr->ctl.p,
+                               (const AffCtl*)aff.p, (const uint32_t*)g->new_id.p, g->n, g->sl_nd, pr->prm.pos_nd, pr->prm.pos_d, out);
+            it++;
+            if (max_iter > 0 && it >= max_iter) break;
+        }
+        SS_HIP(ctx, hipGetLastError());
+        SS_HIP(ctx, ss::fetch(ctx, st, &n_active, &aff.p->n_active, sizeof(int32_t)));
+        if (max_iter > 0 && it >= max_iter) break;                 // (the stop rule has closed every topic at max_iter)
+    }
+    SS_HIP(ctx, hipMemcpyAsync(h.data(), aff.p, sizeof(AffCtl), hipMemcpyDeviceToHost, st));
+    if (!dev_out) SS_HIP(ctx, hipMemcpyAsync(rank_out, d_out.p, (size_t)k_topics * g->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (iters_out)
+        for (int k = 0; k < k_topics; k++) iters_out[k] = h[0].iters[k];
+    return SS_OK;
+}
+
 int32_t ss_pagerank_run(ss_graph* g, double damping, double eps, int32_t max_iter, int32_t k_topics,
                         const int32_t* n_topic, double* rank_out, int32_t* iters_out) {
     if (!g) return SS_ERR_INVALID;
@@ -2441,6 +2709,7 @@ int32_t ss_pagerank_run(ss_graph* g, double damping, double eps, int32_t max_ite
         return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run: bad k_topics / NULL argument");
     if (!(eps >= 0.0) && max_iter <= 0 && !(eps != eps))
         return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run: eps < 0 (never converges) needs max_iter > 0");
+    if (ctx->opt("pr.affine", 0) != 0) return run_affine(g, damping, eps, max_iter, k_topics, n_topic, rank_out, iters_out);
     // topics are independent power iterations (pagerank.go:54-63): run them MAXK at a time
     for (int k0 = 0; k0 < k_topics; k0 += MAXK) {
         const int kk = std::min(MAXK, k_topics - k0);

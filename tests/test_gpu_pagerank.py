@@ -152,6 +152,46 @@ def test_build_and_deal_options_agree(ss_ctx, oracle, opts, k_topics):
     np.testing.assert_allclose(rank, ref, rtol=1e-12)
 
 
+# ---- the two-vector form (option "pr.affine"): every topic of the reference's recurrence from two vectors ---------------------
+@pytest.mark.parametrize("k_topics", [1, 3, 16, 40])
+def test_two_vector_form_matches_the_oracle(ss_ctx, oracle, k_topics):
+    """x_k = (p*u_k + q) / (r*u_k + s) is closed under pagerank.go:104-119, so two vectors carry all topics.  Not the reference's
+    operation order: ranks to 1e-12 (gate 1e-6), the inherited part too; iteration counts equal here (no stop decision of these
+    runs sits at a rounding tie)."""
+    n, e = 30000, 160000
+    ptr, dst = synth.rmat_graph(n, e, seed=500 + k_topics)
+    n_topic = synth.topic_sizes(n, k_topics)
+    for eps, max_iter in ((1e-9, 0), (1e-30, 6)):
+        with ss_ctx.options(pr__affine=1):
+            rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, n_topic, eps, max_iter=max_iter)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-12)
+
+
+def test_two_vector_form_on_hard_graphs(ss_ctx, oracle):
+    with ss_ctx.options(pr__affine=1):
+        # the hand-worked graph of test_kat_graph: first iteration exact, then to convergence with very different topic sizes
+        ptr, dst = csr(5, [(0, 1), (0, 2), (1, 2), (2, 0), (2, 3), (4, 4)])
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 5, ptr, dst, [4], 0.0, max_iter=1)
+        np.testing.assert_allclose(rank[0], [19 / 58, 19 / 58, 25 / 58, 19 / 58, 22 / 58], rtol=1e-15)
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 5, ptr, dst, [4, 5, 1000, 1], 1e-12)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-13)
+        # no edges at all, a single self loop, a hub with 60k in-edges and many edge-less rows
+        ptr = np.zeros(11, dtype=np.uint64)
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 10, ptr, np.zeros(0, np.uint32), [10, 3], 1e-12)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-14)
+        ptr, dst = csr(1, [(0, 0)])
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 1, ptr, dst, [1], 1e-12)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-14)
+        n, ptr, dst = _skewed_graph()
+        rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, synth.topic_sizes(n, 16), 1e-10)
+        assert iters.tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(rank, ref, rtol=1e-12)
+
+
 def test_edge_cases(ss_ctx, oracle):
     # no edges at all: every node dangling (pagerank.go:131-134)
     ptr = np.zeros(11, dtype=np.uint64)
