@@ -61,7 +61,7 @@ struct PrCtl {
 // elementwise (p, q vectors over the nodes, r, s scalars) one iteration maps (p, q, r, s) to
 //     p' = M p + tau*r*1,  q' = M q + tau*s*1,  r' = W p + tau*N*r,  s' = W q + tau*N*s        (M: the inherited part, W: the sum of
 // the contributions, tau = 1 - d; iteration 1 adds the start vector: p += 1) — so TWO vectors carry every topic, whatever K is.
-// The state is kept scaled to s = 1.  Per-topic ranks, L1 changes and stop decisions are evaluated from (p, q, r) by streaming
+// The state is kept scaled to r + s = 1.  Per-topic ranks, L1 changes and stop decisions are evaluated from (p, q, r) by streaming
 // kernels; a topic's ranks are written out in the iteration it stops.  Not the reference's float64 operation order: ranks agree
 // with the oracle to ~1e-13, iteration counts where the stop rule is not at a rounding tie.
 constexpr int AFF_MAXK = 256;
@@ -69,7 +69,8 @@ struct AffCtl {
     double u[AFF_MAXK];       // 1 / n_topic
     double delta[AFF_MAXK];   // last L1 change of the topic
     int32_t active[AFF_MAXK], iters[AFF_MAXK], just[AFF_MAXK];   // just: stopped in the iteration that has just been evaluated
-    double r_x, r_prev, r_next;      // r of the stored vectors, of the previous ones, of the next sweep's result (s = 1 throughout)
+    double r_x, r_prev, r_next;      // r of the stored vectors, of the previous ones, of the next sweep's result
+    double s_x, s_prev, s_next;      // ... and s (the state is kept scaled to r + s = 1: s alone vanishes when d = 1)
     double xz_prev[2];               // the edge-less rows' (p, q) before the last sweep
     int32_t n_active, n_just, k_real, it;
 };
@@ -153,24 +154,27 @@ __device__ __forceinline__ double zero_row_rank_ts(const PrParams& p, int sweep,
 __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl, const double* cs, bool is_begin) {
     PrCtl* ctl = p.ctl;
     if (p.aff) {
-        // columns 0 / 1 = p / q.  Both are divided by the common s' = W q + tau*N (s = 1), their teleports are tau*r and tau.
+        // columns 0 / 1 = p / q.  Both are divided by the common sigma = r' + s' (r' = W p + tau*N*r, s' = W q + tau*N*s), their
+        // teleports are tau*r and tau*s.
         AffCtl* a = p.aff;
         if (is_begin) {
+            // start: p = 1, q = 0, r = 0, s = 1
+            const double r1 = cs[0], s1 = cs[1] + p.tele_n, sigma = r1 + s1;
             for (int k = 0; k < MAXK; k++) {
                 const bool real = k < 2;
                 ctl->xz[k] = real ? p.x0[k] : 0.0;
                 ctl->xz_in[k] = ctl->xz[k];
-                ctl->S[k] = real ? cs[1] + p.tele_n : 1.0;
+                ctl->S[k] = real ? sigma : 1.0;
                 ctl->csum[k] = real ? cs[k] : 0.0;
                 ctl->delta[k] = 0.0;
                 ctl->active[k] = real ? 1 : 0;
                 ctl->iters[k] = 0;
                 ctl->tele[k] = 0.0;
             }
-            ctl->tele[1] = p.teleport;                                // tau * s, s = 1; tele[0] = tau * r with r = 0
-            a->r_x = 0.0;
-            a->r_prev = 0.0;
-            a->r_next = cs[0] / (cs[1] + p.tele_n);
+            ctl->tele[1] = p.teleport;                                // tau * s with s = 1; tele[0] = tau * r with r = 0
+            a->r_x = 0.0; a->s_x = 1.0;
+            a->r_prev = 0.0; a->s_prev = 1.0;
+            a->r_next = r1 / sigma; a->s_next = s1 / sigma;
             a->xz_prev[0] = ctl->xz[0];
             a->xz_prev[1] = ctl->xz[1];
             a->it = 0;
@@ -179,8 +183,8 @@ __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl
             return;
         }
         const int it = ctl->sweep + 1;
-        a->r_prev = a->r_x;
-        a->r_x = a->r_next;                                           // r of the vectors this sweep has written
+        a->r_prev = a->r_x; a->s_prev = a->s_x;
+        a->r_x = a->r_next; a->s_x = a->s_next;                       // (r, s) of the vectors this sweep has written
         for (int k = 0; k < 2; k++) {
             a->xz_prev[k] = ctl->xz[k];
             ctl->xz[k] = zero_row_rank_ts(p, ctl->sweep, ctl->S[k], p.x0[k], ctl->tele[k]);
@@ -188,11 +192,14 @@ __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl
             ctl->iters[k] = it;
             ctl->csum[k] = cs[k];
         }
-        const double s_next = cs[1] + p.tele_n;                       // W q + tau*N*s
-        a->r_next = (cs[0] + p.tele_n * a->r_x) / s_next;             // (W p + tau*N*r) / s'
+        const double r1 = cs[0] + p.tele_n * a->r_x;                  // W p + tau*N*r
+        const double s1 = cs[1] + p.tele_n * a->s_x;                  // W q + tau*N*s
+        const double sigma = r1 + s1;
+        a->r_next = r1 / sigma;
+        a->s_next = s1 / sigma;
         ctl->tele[0] = p.teleport * a->r_x;
-        ctl->tele[1] = p.teleport;
-        ctl->S[0] = ctl->S[1] = s_next;
+        ctl->tele[1] = p.teleport * a->s_x;
+        ctl->S[0] = ctl->S[1] = sigma;
         ctl->sweep = it;
         return;
     }
@@ -1543,7 +1550,7 @@ __global__ __launch_bounds__(TPB) void k_pr_read_orig(const double* __restrict__
 
 // ---- two-vector form: per-topic L1 change, stop rule, write-out ("pr.affine"; see AffCtl) ---------------------------------------
 // x holds (p, q) of the rows WITH in-edges; the edge-less rows share one (p, q) per class position (ctl->xz).  A topic's rank
-// of a row is (p*u + q) / (r*u + 1).
+// of a row is (p*u + q) / (r*u + s).
 constexpr int AFF_KC = 16;        // topics a thread accumulates per pass over the rows
 constexpr unsigned AFF_NB = 512;  // blocks of k_aff_delta (their partial sums are added in a fixed order)
 __global__ __launch_bounds__(TPB) void k_aff_delta(const double2* __restrict__ xp, const double2* __restrict__ xn, const AffCtl* __restrict__ a,
@@ -1551,7 +1558,7 @@ __global__ __launch_bounds__(TPB) void k_aff_delta(const double2* __restrict__ x
     __shared__ double red[WAVES][AFF_KC];
     if (a->n_active == 0) return;                                     // every topic has stopped: the enqueued iterations are no-ops
     const int k_real = a->k_real;
-    const double r_old = a->r_prev, r_new = a->r_x;
+    const double r_old = a->r_prev, r_new = a->r_x, s_old = a->s_prev, s_new = a->s_x;
     const uint32_t n_rows = pos_nd + pos_d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k0 = 0; k0 < k_real; k0 += AFF_KC) {
@@ -1562,8 +1569,8 @@ __global__ __launch_bounds__(TPB) void k_aff_delta(const double2* __restrict__ x
             const bool on = k0 + j < k_real && a->active[k0 + j] != 0;
             any = any || on;
             u[j] = on ? a->u[k0 + j] : 0.0;
-            d_old[j] = r_old * u[j] + 1.0;
-            d_new[j] = r_new * u[j] + 1.0;
+            d_old[j] = on ? r_old * u[j] + s_old : 1.0;
+            d_new[j] = on ? r_new * u[j] + s_new : 1.0;
             acc[j] = 0.0;
         }
         if (any) {
@@ -1626,8 +1633,8 @@ __global__ __launch_bounds__(AFF_MAXK) void k_aff_ctl(AffCtl* __restrict__ a, Pr
         if (a->active[k]) {
             double dl = s_dl[k];
             const double u = a->u[k];
-            const double z_new = (ctl->xz[0] * u + ctl->xz[1]) / (a->r_x * u + 1.0);
-            const double z_old = (a->xz_prev[0] * u + a->xz_prev[1]) / (a->r_prev * u + 1.0);
+            const double z_new = (ctl->xz[0] * u + ctl->xz[1]) / (a->r_x * u + a->s_x);
+            const double z_old = (a->xz_prev[0] * u + a->xz_prev[1]) / (a->r_prev * u + a->s_prev);
             dl += n_zero * fabs(z_new - z_old);
             a->delta[k] = dl;
             a->iters[k] = it;
@@ -1650,7 +1657,7 @@ __global__ __launch_bounds__(TPB) void k_aff_emit(const double2* __restrict__ x,
                                                   const uint32_t* __restrict__ new_id, uint64_t n, uint32_t sl_nd, uint32_t pos_nd, uint32_t pos_d,
                                                   double* __restrict__ out) {
     if (a->n_just == 0) return;
-    const double r = a->r_x;
+    const double r = a->r_x, sx = a->s_x;
     const int k_real = a->k_real;
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t lrow = new_id[v];
@@ -1661,7 +1668,7 @@ __global__ __launch_bounds__(TPB) void k_aff_emit(const double2* __restrict__ x,
         for (int k = 0; k < k_real; k++)
             if (a->just[k]) {
                 const double u = a->u[k];
-                out[(size_t)k * n + v] = (pq.x * u + pq.y) / (r * u + 1.0);
+                out[(size_t)k * n + v] = (pq.x * u + pq.y) / (r * u + sx);
             }
     }
 }

@@ -190,6 +190,12 @@ def test_two_vector_form_on_hard_graphs(ss_ctx, oracle):
         rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, n, ptr, dst, synth.topic_sizes(n, 16), 1e-10)
         assert iters.tolist() == ref_iters.tolist()
         np.testing.assert_allclose(rank, ref, rtol=1e-12)
+        # damping 1 (no teleport: the form's s vanishes, every topic is p / r) and a small damping
+        ptr, dst = synth.rmat_graph(5000, 40000, seed=9)
+        for dd in (1.0, 0.15):
+            rank, iters, ref, ref_iters = run_both(ss_ctx, oracle, 5000, ptr, dst, [5000, 40, 1], 1e-9, max_iter=60, d=dd)
+            assert iters.tolist() == ref_iters.tolist()
+            np.testing.assert_allclose(rank, ref, rtol=1e-11)
 
 
 def test_edge_cases(ss_ctx, oracle):
