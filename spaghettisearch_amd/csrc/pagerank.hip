@@ -1673,6 +1673,58 @@ __global__ __launch_bounds__(TPB) void k_aff_emit(const double2* __restrict__ x,
     }
 }
 
+// sharded two-vector form: this rank's per-topic sums (its blocks' partials in a fixed order + its own edge-less rows); the ranks'
+// sums are all-gathered and k_aff_ctl adds them in rank order (nb = world, n_zero = 0), so every rank decides alike
+__global__ __launch_bounds__(AFF_MAXK) void k_aff_local(const AffCtl* __restrict__ a, const PrCtl* __restrict__ ctl, const double* __restrict__ partials, unsigned nb,
+                                                        double n_zero, double* __restrict__ loc) {
+    __shared__ double s_part[16][AFF_KC];
+    const int k = threadIdx.x;
+    const int k_real = a->k_real;
+    if (a->n_active == 0) return;
+    for (int k0 = 0; k0 < k_real; k0 += AFF_KC) {
+        const int j = k & (AFF_KC - 1), part = k >> 4;
+        double v = 0.0;
+        if (k0 + j < k_real)
+            for (unsigned b = (unsigned)part; b < nb; b += 16) v += partials[(size_t)b * AFF_MAXK + k0 + j];
+        s_part[part][j] = v;
+        __syncthreads();
+        if (k < AFF_KC && k0 + k < k_real) {
+            double t = 0.0;
+            for (int q = 0; q < 16; q++) t += s_part[q][k];
+            const int kk = k0 + k;
+            if (a->active[kk]) {
+                const double u = a->u[kk];
+                const double z_new = (ctl->xz[0] * u + ctl->xz[1]) / (a->r_x * u + a->s_x);
+                const double z_old = (a->xz_prev[0] * u + a->xz_prev[1]) / (a->r_prev * u + a->s_prev);
+                t += n_zero * fabs(z_new - z_old);
+            }
+            loc[kk] = t;
+        }
+        __syncthreads();
+    }
+}
+// ... and the ranks of the topics that have just stopped, for this rank's rows in local order (out[k][row], as ss_pr_read_local)
+__global__ __launch_bounds__(TPB) void k_aff_emit_local(const double2* __restrict__ x, const PrCtl* __restrict__ ctl, const AffCtl* __restrict__ a,
+                                                        uint32_t sl_nd, uint32_t cnt_nd, uint32_t cnt_d, uint32_t pos_nd, uint32_t pos_d,
+                                                        double* __restrict__ out) {
+    if (a->n_just == 0) return;
+    const double r = a->r_x, sx = a->s_x;
+    const int k_real = a->k_real;
+    const uint32_t n_rows = cnt_nd + cnt_d;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
+        const uint32_t lrow = i < cnt_nd ? i : sl_nd + (i - cnt_nd);
+        const bool zero = lrow < sl_nd ? lrow >= pos_nd : (lrow - sl_nd) >= pos_d;
+        double2 pq;
+        if (zero) pq = make_double2(ctl->xz[0], ctl->xz[1]);
+        else pq = x[lrow];
+        for (int k = 0; k < k_real; k++)
+            if (a->just[k]) {
+                const double u = a->u[k];
+                out[(size_t)k * n_rows + i] = (pq.x * u + pq.y) / (r * u + sx);
+            }
+    }
+}
+
 template <int GW>
 void launch_read(ss_pr* pr, hipStream_t st, int by_orig, uint64_t stride, uint32_t* ids, double* out) {
     const ss_graph* g = pr->g;
@@ -2403,6 +2455,112 @@ int topic_blocks_for(ss_ctx* ctx, int k_topics) {
     return std::max(1, std::min(B, k_topics));
 }
 
+// ---- the two-vector form on a sharded graph (option "pr.affine"): a TWO-column exchange per iteration, whatever K is -------------
+// One K = 2 state per shard; per iteration: sweep (local rows) -> all-gather of the 2-wide contribution slices -> k_pr_finalize
+// (affine branch: r, s, the column teleports; identical on every rank) -> the topics' L1 changes over the local rows -> all-gather
+// of the ranks' K sums -> stop rule (k_aff_ctl adds them in rank order) -> write-out of the topics that have just stopped.
+struct AffShard {
+    ss::DevBuf<AffCtl> aff;
+    ss::DevBuf<double> x_alt, partials, loc, gath, out;
+    double n_zero = 0.0;
+};
+int32_t aff_attach(ss_pr* pr, AffShard& A, int32_t k_topics, const int32_t* n_topic, int world) {
+    ss_ctx* ctx = pr->g->ctx;
+    hipStream_t st = ctx->stream;
+    if (!pr->nwave || pr->gw != 2) return ctx->fail(SS_ERR_UNSUPPORTED, "pr.affine: needs the wave-item K = 2 sweep (pr.narrow_wave / pr.force_narrow at their defaults)");
+    const ss_graph* g = pr->g;
+    const size_t n_rows = (size_t)g->cnt_nd + g->cnt_d;
+    SS_HIP(ctx, A.aff.alloc(1));
+    SS_HIP(ctx, A.x_alt.alloc((size_t)g->n_local() * 2));
+    SS_HIP(ctx, A.partials.alloc((size_t)AFF_NB * AFF_MAXK));
+    SS_HIP(ctx, A.loc.alloc(AFF_MAXK));
+    SS_HIP(ctx, A.gath.alloc((size_t)world * AFF_MAXK));
+    SS_HIP(ctx, A.out.alloc(std::max<size_t>(1, (size_t)k_topics * n_rows)));
+    SS_HIP(ctx, hipMemsetAsync(A.loc.p, 0, A.loc.bytes(), st));
+    std::vector<AffCtl> h(1);
+    std::memset(h.data(), 0, sizeof(AffCtl));
+    for (int k = 0; k < k_topics; k++) { h[0].u[k] = 1.0 / (double)n_topic[k]; h[0].active[k] = 1; }   // pagerank.go:104
+    h[0].k_real = k_topics;
+    h[0].n_active = k_topics;
+    SS_HIP(ctx, hipMemcpyAsync(A.aff.p, h.data(), sizeof(AffCtl), hipMemcpyHostToDevice, st));
+    const double x0[MAXK] = {1.0, 0.0};
+    SS_HIP(ctx, hipMemcpyAsync(pr->x0.p, x0, sizeof(x0), hipMemcpyHostToDevice, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    pr->prm.aff = A.aff.p;
+    pr->prm.tele_col = pr->ctl.p->tele;
+    pr->prm.x_alt = A.x_alt.p;
+    A.n_zero = (double)((g->cnt_nd - pr->prm.pos_nd) + (g->cnt_d - pr->prm.pos_d));
+    return SS_OK;
+}
+template <typename Exchange, typename ExchangeSums>
+int32_t run_affine_sharded(ss_ctx* ctx, std::vector<ShardBlocks>& sh, std::vector<AffShard>& A, int world, double eps, int32_t max_iter, int32_t k_topics,
+                           Exchange&& exchange, ExchangeSums&& exchange_sums, int32_t* iters_out) {
+    const int S = (int)sh.size();
+    hipStream_t st = ctx->stream;
+    for (int s = 0; s < S; s++) {
+        ss_pr* pr = sh[s].blk[0];
+        const size_t n_el = (size_t)pr->g->n_local() * pr->gw;
+        const unsigned nb = std::max(1u, std::min(2048u, ss::div_up(n_el, TPB)));
+        SS_HIP(ctx, hipMemsetAsync(&pr->ctl.p->ticket, 0, sizeof(uint32_t), st));
+        launch_begin<2>(pr, st, nb);
+        pr->begun = true;
+    }
+    SS_TRY(exchange(0, st));
+    for (int s = 0; s < S; s++) launch_finalize<2>(sh[s].blk[0], st, 1);
+    int32_t n_active = k_topics, it = 0;
+    const int BATCH = 4;
+    while (n_active > 0) {
+        for (int b = 0; b < BATCH; b++) {
+            for (int s = 0; s < S; s++) launch_step<2>(sh[s].blk[0], st);
+            SS_TRY(exchange(0, st));
+            for (int s = 0; s < S; s++) launch_finalize<2>(sh[s].blk[0], st, 0);
+            for (int s = 0; s < S; s++) {
+                ss_pr* pr = sh[s].blk[0];
+                const ss_graph* g = pr->g;
+                const double2* const x_old = reinterpret_cast<const double2*>((it & 1) ? A[s].x_alt.p : pr->x.p);
+                const double2* const x_new = reinterpret_cast<const double2*>((it & 1) ? pr->x.p : A[s].x_alt.p);
+                hipLaunchKernelGGL(k_aff_delta, dim3(AFF_NB), dim3(TPB), 0, st, x_old, x_new, (const AffCtl*)A[s].aff.p, g->sl_nd, pr->prm.pos_nd, pr->prm.pos_d,
+                                   A[s].partials.p);
+                hipLaunchKernelGGL(k_aff_local, dim3(1), dim3(AFF_MAXK), 0, st, (const AffCtl*)A[s].aff.p, (const PrCtl*)pr->ctl.p, (const double*)A[s].partials.p,
+                                   AFF_NB, A[s].n_zero, A[s].loc.p);
+            }
+            SS_TRY(exchange_sums(st));
+            for (int s = 0; s < S; s++) {
+                ss_pr* pr = sh[s].blk[0];
+                const ss_graph* g = pr->g;
+                const double2* const x_new = reinterpret_cast<const double2*>((it & 1) ? pr->x.p : A[s].x_alt.p);
+                hipLaunchKernelGGL(k_aff_ctl, dim3(1), dim3(AFF_MAXK), 0, st, A[s].aff.p, pr->ctl.p, (const double*)A[s].gath.p, (unsigned)world, 0.0, eps, max_iter);
+                const unsigned nbe = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(4096, ss::div_up((uint64_t)g->cnt_nd + g->cnt_d, TPB)));
+                hipLaunchKernelGGL(k_aff_emit_local, dim3(nbe), dim3(TPB), 0, st, x_new, (const PrCtl*)pr->ctl.p, (const AffCtl*)A[s].aff.p, g->sl_nd, g->cnt_nd,
+                                   g->cnt_d, pr->prm.pos_nd, pr->prm.pos_d, A[s].out.p);
+            }
+            it++;
+            if (max_iter > 0 && it >= max_iter) break;
+        }
+        SS_HIP(ctx, hipGetLastError());
+        ctx->pin_used = 0;
+        int32_t* const hn = ctx->pin<int32_t>();
+        SS_HIP(ctx, hipMemcpyAsync(hn, &A[0].aff.p->n_active, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        SS_TRY(ss::sync_bounded(ctx, st, "sharded two-vector sweep (waiting for the exchange)"));
+        n_active = *hn;
+        if (max_iter > 0 && it >= max_iter) break;
+    }
+    for (int s = 0; s < S; s++) sh[s].blk[0]->need_finalize = false;
+    if (iters_out) {
+        std::vector<AffCtl> h(1);
+        SS_HIP(ctx, hipMemcpyAsync(h.data(), A[0].aff.p, sizeof(AffCtl), hipMemcpyDeviceToHost, st));
+        SS_TRY(ss::sync_bounded(ctx, st, "sharded two-vector sweep (status)"));
+        for (int k = 0; k < k_topics; k++) iters_out[k] = h[0].iters[k];
+    }
+    return SS_OK;
+}
+// the ids of a shard's rows in local order (what ss_pr_read_local returns beside the ranks)
+int32_t local_ids(ss_pr* pr, uint32_t* ids_out) {
+    const size_t n_rows = (size_t)pr->g->cnt_nd + pr->g->cnt_d;
+    std::vector<double> scratch(std::max<size_t>(1, n_rows * (size_t)pr->k));
+    return ss_pr_read_local(pr, ids_out, scratch.data());
+}
+
 }  // namespace
 
 extern "C" {
@@ -2413,24 +2571,32 @@ int32_t ss_pagerank_run_sharded(ss_graph* g, double damping, double eps, int32_t
     ss_ctx* ctx = g->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (g->world < 2) return ctx->fail(SS_ERR_STATE, "ss_pagerank_run_sharded: needs a sharded graph (world > 1); use ss_pagerank_run");
-    if (k_topics < 1 || k_topics > MAXK || !n_topic || !rank_out)
-        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_sharded: k_topics must be 1..%d, n_topic/rank_out not NULL", MAXK);
+    const bool affine = ctx->opt("pr.affine", 0) != 0 && !allreduce;      // the two-vector form: a 2-column exchange whatever K is
+    const int k_max = affine ? AFF_MAXK : MAXK;
+    if (k_topics < 1 || k_topics > k_max || !n_topic || !rank_out)
+        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_sharded: k_topics must be 1..%d, n_topic/rank_out not NULL", k_max);
     if (!(eps >= 0.0) && max_iter <= 0 && !(eps != eps))
         return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_sharded: eps < 0 (never converges) needs max_iter > 0");
     if (!ctx->comm || ctx->comm_world != g->world || ctx->comm_rank != g->rank)
         return ctx->fail(SS_ERR_STATE, "ss_pagerank_run_sharded: the context's communicator (rank %d of %d) does not match the graph's shard (rank %d of %d)",
                          ctx->comm ? ctx->comm_rank : -1, ctx->comm ? ctx->comm_world : 0, g->rank, g->world);
     SS_HIP(ctx, hipSetDevice(ctx->device));
-    const int B = topic_blocks_for(ctx, k_topics);
+    const int B = affine ? 1 : topic_blocks_for(ctx, k_topics);
     std::vector<ShardBlocks> sh(1);
+    std::vector<AffShard> aff(affine ? 1 : 0);
     std::vector<int> k0(B + 1);
     for (int b = 0; b <= B; b++) k0[b] = (int)((int64_t)k_topics * b / B);
     int32_t rc = SS_OK;
+    const int32_t two[2] = {1, 1};
     for (int b = 0; b < B && rc == SS_OK; b++) {
         ss_pr* pr = nullptr;
-        rc = ss_pr_create(g, damping, eps, max_iter, k0[b + 1] - k0[b], n_topic + k0[b], &pr);
+        rc = affine ? ss_pr_create(g, damping, -1.0, 0, 2, two, &pr) : ss_pr_create(g, damping, eps, max_iter, k0[b + 1] - k0[b], n_topic + k0[b], &pr);
         if (rc == SS_OK) sh[0].blk.push_back(pr);
     }
+    if (affine && rc == SS_OK)
+        for (int k = 0; k < k_topics && rc == SS_OK; k++)
+            if (n_topic[k] < 1) rc = ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_sharded: n_topic[%d] < 1", k);
+    if (affine && rc == SS_OK) rc = aff_attach(sh[0].blk[0], aff[0], k_topics, n_topic, g->world);
     const bool wire_f32 = ctx->opt("pr.wire_f32", 0) != 0;
     if (rc == SS_OK) {
         auto exchange = [&](int b, hipStream_t xs) -> int32_t {
@@ -2449,10 +2615,25 @@ int32_t ss_pagerank_run_sharded(ss_graph* g, double damping, double eps, int32_t
             SS_HIP(ctx, hipMemcpyAsync(pr->tab0.p + (size_t)g->rank * slice, pr->send.p, slice * sizeof(double), hipMemcpyDeviceToDevice, xs));
             return ss::comm_allreduce_f64_on(ctx, pr->tab0.p, pr->tab0.p, slice * (size_t)g->world, xs);
         };
-        rc = run_pipelined(ctx, sh, max_iter, exchange, iters_out, k0);
+        if (affine) {
+            auto exchange_sums = [&](hipStream_t xs) -> int32_t {
+                return ss::comm_allgather_on(ctx, aff[0].loc.p, aff[0].gath.p, (size_t)AFF_MAXK * sizeof(double), xs);
+            };
+            rc = run_affine_sharded(ctx, sh, aff, g->world, eps, max_iter, k_topics, exchange, exchange_sums, iters_out);
+        } else {
+            rc = run_pipelined(ctx, sh, max_iter, exchange, iters_out, k0);
+        }
     }
     // this rank's rows: ids once, ranks block by block (topic-major: rank_out[k][rows])
     const size_t n_rows = (size_t)g->cnt_nd + g->cnt_d;
+    if (affine) {
+        if (rc == SS_OK && ids_out) rc = local_ids(sh[0].blk[0], ids_out);
+        if (rc == SS_OK && n_rows) {
+            if (hipMemcpyAsync(rank_out, aff[0].out.p, (size_t)k_topics * n_rows * sizeof(double), hipMemcpyDefault, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                rc = ctx->fail(SS_ERR_HIP, "ss_pagerank_run_sharded: copy of the ranks failed");
+        }
+    } else
     for (int b = 0; b < (int)sh[0].blk.size() && rc == SS_OK; b++)
         rc = ss_pr_read_local(sh[0].blk[b], b == 0 ? ids_out : nullptr, rank_out + (size_t)k0[b] * n_rows);
     for (ss_pr* pr : sh[0].blk) ss_pr_destroy(pr);
@@ -2464,24 +2645,32 @@ int32_t ss_pagerank_run_group(ss_graph* const* shards, int32_t world, double dam
     if (!shards || world < 2 || !shards[0]) return SS_ERR_INVALID;
     ss_ctx* ctx = shards[0]->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    if (k_topics < 1 || k_topics > MAXK || !n_topic || !rank_out)
-        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_group: k_topics must be 1..%d, n_topic/rank_out not NULL", MAXK);
+    const bool affine = ctx->opt("pr.affine", 0) != 0;
+    const int k_max = affine ? AFF_MAXK : MAXK;
+    if (k_topics < 1 || k_topics > k_max || !n_topic || !rank_out)
+        return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_group: k_topics must be 1..%d, n_topic/rank_out not NULL", k_max);
     if (!(eps >= 0.0) && max_iter <= 0 && !(eps != eps))
         return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_group: eps < 0 (never converges) needs max_iter > 0");
     for (int s = 0; s < world; s++)
         if (!shards[s] || shards[s]->ctx != ctx || shards[s]->world != world || shards[s]->rank != s || shards[s]->n != shards[0]->n)
             return ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_group: shards[%d] is not shard %d of %d of the same graph on this context", s, s, world);
     SS_HIP(ctx, hipSetDevice(ctx->device));
-    const int B = topic_blocks_for(ctx, k_topics);
+    const int B = affine ? 1 : topic_blocks_for(ctx, k_topics);
     std::vector<ShardBlocks> sh(world);
+    std::vector<AffShard> aff(affine ? world : 0);
     std::vector<int> k0(B + 1);
     for (int b = 0; b <= B; b++) k0[b] = (int)((int64_t)k_topics * b / B);
     int32_t rc = SS_OK;
+    const int32_t two[2] = {1, 1};
+    for (int k = 0; k < k_topics && affine && rc == SS_OK; k++)
+        if (n_topic[k] < 1) rc = ctx->fail(SS_ERR_INVALID, "ss_pagerank_run_group: n_topic[%d] < 1", k);
     for (int s = 0; s < world && rc == SS_OK; s++)
         for (int b = 0; b < B && rc == SS_OK; b++) {
             ss_pr* pr = nullptr;
-            rc = ss_pr_create(shards[s], damping, eps, max_iter, k0[b + 1] - k0[b], n_topic + k0[b], &pr);
+            rc = affine ? ss_pr_create(shards[s], damping, -1.0, 0, 2, two, &pr)
+                        : ss_pr_create(shards[s], damping, eps, max_iter, k0[b + 1] - k0[b], n_topic + k0[b], &pr);
             if (rc == SS_OK) sh[s].blk.push_back(pr);
+            if (rc == SS_OK && affine) rc = aff_attach(pr, aff[s], k_topics, n_topic, world);
         }
     if (rc == SS_OK) {
         // the all-gather, by hand: every shard's slice into every shard's table, rank order
@@ -2512,11 +2701,35 @@ int32_t ss_pagerank_run_group(ss_graph* const* shards, int32_t world, double dam
                 }
             return SS_OK;
         };
-        rc = run_pipelined(ctx, sh, max_iter, exchange, iters_out, k0);
+        if (affine) {
+            auto exchange_sums = [&](hipStream_t xs) -> int32_t {     // the K sums of every shard into every shard's table, rank order
+                for (int dst = 0; dst < world; dst++)
+                    for (int src = 0; src < world; src++)
+                        SS_HIP(ctx, hipMemcpyAsync(aff[dst].gath.p + (size_t)src * AFF_MAXK, aff[src].loc.p, (size_t)AFF_MAXK * sizeof(double),
+                                                   hipMemcpyDeviceToDevice, xs));
+                return SS_OK;
+            };
+            rc = run_affine_sharded(ctx, sh, aff, world, eps, max_iter, k_topics, exchange, exchange_sums, iters_out);
+        } else {
+            rc = run_pipelined(ctx, sh, max_iter, exchange, iters_out, k0);
+        }
     }
     // assemble [K][N] by original id
     const uint64_t n = shards[0]->n;
-    for (int s = 0; s < world && rc == SS_OK; s++) {
+    for (int s = 0; s < world && rc == SS_OK && affine; s++) {
+        const size_t n_rows = (size_t)shards[s]->cnt_nd + shards[s]->cnt_d;
+        std::vector<uint32_t> ids(n_rows);
+        std::vector<double> part((size_t)k_topics * n_rows);
+        rc = local_ids(sh[s].blk[0], ids.data());
+        if (rc == SS_OK && n_rows) {
+            if (hipMemcpyAsync(part.data(), aff[s].out.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                rc = ctx->fail(SS_ERR_HIP, "ss_pagerank_run_group: copy of the ranks failed");
+        }
+        for (int k = 0; k < k_topics && rc == SS_OK; k++)
+            for (size_t i = 0; i < n_rows; i++) rank_out[(size_t)k * n + ids[i]] = part[(size_t)k * n_rows + i];
+    }
+    for (int s = 0; s < world && rc == SS_OK && !affine; s++) {
         const size_t n_rows = (size_t)shards[s]->cnt_nd + shards[s]->cnt_d;
         std::vector<uint32_t> ids(n_rows);
         for (int b = 0; b < B && rc == SS_OK; b++) {
