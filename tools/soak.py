@@ -134,6 +134,9 @@ def round_phrase(ctx, rng):
     sc.close(); ti.close(); bi.close()
 
 
+N_AFF = [0, 0]      # two-vector rounds, topics whose iteration count moved by one
+
+
 def round_pagerank(ctx, rng):
     n = int(rng.choice([1, 2, 5, 64, 1000, 30000, 200000]))
     e = int(rng.integers(0, max(1, min(n * n, 8 * n)) + 1))
@@ -151,10 +154,23 @@ def round_pagerank(ctx, rng):
     mi = int(rng.choice([0, 0, 1, 4]))
     g = engine.Graph(ctx, n, ptr, dst)
     rank, iters = g.pagerank(d, eps, n_topic, max_iter=mi)
+    # the two-vector form (option pr.affine): the same ranks from two vectors; a different operation order, so an iteration count
+    # may move by one where a topic's L1 change sits within rounding of eps — then its ranks are compared an iteration apart
+    ctx.set_option("pr.affine", 1)
+    try:
+        rank2, iters2 = g.pagerank(d, eps, n_topic, max_iter=mi)
+    finally:
+        ctx.set_option("pr.affine", None)
     g.close()
     ref, ref_it = pyoracle.pagerank(n, ptr, dst, d, eps, n_topic, max_iter=mi)
     assert iters.tolist() == ref_it.tolist(), ("pr iters", n, len(dst), kt, d, eps, mi, iters.tolist(), ref_it.tolist())
     np.testing.assert_allclose(rank, ref, rtol=1e-11, atol=0, err_msg=str(("pr", n, len(dst), kt)))
+    assert np.max(np.abs(iters2.astype(np.int64) - ref_it.astype(np.int64))) <= 1, ("affine iters", n, len(dst), kt, d, eps, mi, iters2.tolist(), ref_it.tolist())
+    same = iters2 == ref_it
+    if same.any():
+        np.testing.assert_allclose(rank2[same], ref[same], rtol=1e-10, atol=0, err_msg=str(("affine", n, len(dst), kt, d, eps, mi)))
+    N_AFF[0] += 1
+    N_AFF[1] += int((~same).sum())
 
 
 def main():
@@ -175,7 +191,8 @@ def main():
             round_pagerank(ctx, rng); n[1] += 1
         if time.time() - last > 30:
             print(f"[soak] {n[0]} scoring rounds, {n[1]} pagerank rounds, {time.time() - t0:.0f}s", flush=True); last = time.time()
-    print(f"[soak] PASSED: {n[0]} scoring rounds, {n[1]} pagerank rounds", flush=True)
+    print(f"[soak] PASSED: {n[0]} scoring rounds, {n[1]} pagerank rounds (each also in the two-vector form: {N_AFF[1]} topic runs ended one "
+          f"iteration apart from the oracle)", flush=True)
     ctx.close()
 
 
