@@ -27,6 +27,9 @@ type denseIDs struct {
 	name []string
 }
 
+// TwoVectors switches UpdateTopicSensitivePagerank to the library's two-vector form (see updatePagerank).
+var TwoVectors = false
+
 func newDenseIDs(keys map[string]struct{}) *denseIDs {
 	d := &denseIDs{id: make(map[string]uint32, len(keys)), name: make([]string, 0, len(keys))}
 	for k := range keys {
@@ -225,6 +228,13 @@ func updatePagerank(ctx context.Context, dampingFactor float64, convergenceCrite
 		defer g.Close()
 		var rank []float64
 		if teleport == nil {
+			// TwoVectors (opt-in, off by default): every category's ranks from two vectors — the categories differ only in their
+			// start value 1/numPages and the recurrence maps a ratio of affine forms in it onto itself (library option "pr.affine";
+			// same ranks to ~1e-15, not the reference's operation order; the cost no longer grows with the category count)
+			if TwoVectors {
+				spaghetti.Default().SetOption("pr.affine", 1)
+				defer spaghetti.Default().SetOption("pr.affine", spaghetti.OptionDefault)
+			}
 			rank, _ = g.PageRank(dampingFactor, convergenceCriterion, nTopic) // all categories, device-resident loop
 		} else {
 			sets := make([][]uint32, len(cats))

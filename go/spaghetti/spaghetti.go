@@ -22,6 +22,7 @@ import "C"
 
 import (
 	"fmt"
+	"math"
 	"os"
 	"strconv"
 	"sync"
@@ -156,6 +157,9 @@ func Default() *Ctx {
 	})
 	return global
 }
+
+// OptionDefault restores an option's default (SS_OPTION_DEFAULT).
+const OptionDefault = int64(math.MinInt64)
 
 // SetOption sets a named tuning option of the context (ss_set_option; the names are listed in the header).
 func (c *Ctx) SetOption(name string, value int64) {

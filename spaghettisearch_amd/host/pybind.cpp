@@ -41,15 +41,16 @@ PYBIND11_MODULE(_host, m) {
         return out;
     };
     m.def("UpdateTopicSensitivePagerank", [as_dbs](double d, double eps, std::vector<db::MemDB*> forward, bool teleport_sets,
-                                                   std::vector<db::MemDB*> inv) {
+                                                   std::vector<db::MemDB*> inv, bool two_vectors) {
         db::Context ctx;
         auto f = as_dbs(forward), i = as_dbs(inv);
         ranking::TopicSensitive ts;
         ts.teleport_sets = teleport_sets;
         ts.inv = &i;
+        ts.two_vectors = two_vectors;
         ranking::UpdateTopicSensitivePagerank(ctx, d, eps, f, ts);
     }, py::arg("dampingFactor"), py::arg("convergenceCriterion"), py::arg("forward"), py::arg("teleport_sets") = false,
-       py::arg("inv") = std::vector<db::MemDB*>());
+       py::arg("inv") = std::vector<db::MemDB*>(), py::arg("two_vectors") = false);
     m.def("TopicTeleportSets", [as_dbs](std::vector<db::MemDB*> forward, std::vector<db::MemDB*> inv) {
         db::Context ctx;
         auto f = as_dbs(forward), i = as_dbs(inv);

@@ -67,6 +67,10 @@ namespace ranking {
 struct TopicSensitive {
     bool teleport_sets = false;
     std::vector<db::DB*>* inv = nullptr;      // needed with teleport_sets: inv[0], inv[1], inv[2]
+    // opt-in: every category's ranks from TWO vectors (library option "pr.affine": the reference's categories differ only in their
+    // start value 1/numPages, and its recurrence maps a ratio of affine forms in it onto itself).  Same ranks to ~1e-15, not the
+    // reference's operation order; the cost no longer grows with the number of categories.  Not with teleport_sets.
+    bool two_vectors = false;
 };
 
 // category -> the doc hashes of its teleport set (sorted), by the rule above
@@ -251,7 +255,10 @@ public:
         std::vector<double> rank((size_t)K * n);
         if (K > 0 && !ts.teleport_sets) {
             std::vector<int32_t> iters(K);
-            check(ss_pagerank_run(g, dampingFactor, convergenceCriterion, 0, K, n_topic.data(), rank.data(), iters.data()), "ss_pagerank_run");
+            if (ts.two_vectors) check(ss_set_option(default_ctx(), "pr.affine", 1), "ss_set_option");
+            const int32_t rc = ss_pagerank_run(g, dampingFactor, convergenceCriterion, 0, K, n_topic.data(), rank.data(), iters.data());
+            if (ts.two_vectors) (void)ss_set_option(default_ctx(), "pr.affine", SS_OPTION_DEFAULT);
+            check(rc, "ss_pagerank_run");
         } else if (K > 0) {
             if (!ts.inv) throw std::runtime_error("UpdateTopicSensitivePagerank: teleport_sets needs the inverted tables");
             const auto sets = TopicTeleportSets(ctx, forward, *ts.inv);

@@ -146,6 +146,14 @@ def test_offline_then_online_like_start_crawl_and_server(host, oracle, corpus):
         assert sorted(row) == cats
         for k, c in enumerate(cats):
             assert row[c] == pytest.approx(ref[k, v], rel=1e-12)
+    # the same call with every category's ranks from two vectors (TopicSensitive::two_vectors, library option pr.affine)
+    forw2, _inv2 = make_tables(host, corpus)
+    host.UpdateTopicSensitivePagerank(0.75, 1e-9, forw2, two_vectors=True)
+    for v, name in enumerate(names):
+        row = json.loads(forw2[3].get(name))
+        assert sorted(row) == cats
+        for k, c in enumerate(cats):
+            assert row[c] == pytest.approx(ref[k, v], rel=1e-12)
     # --- start_crawl.go:176-177 ----------------------------------------------------------
     host.UpdateTermWeights(inv[0], forw, "title")
     host.UpdateTermWeights(inv[1], forw, "body")
