@@ -414,6 +414,13 @@ def test_two_vector_form_on_a_sharded_graph(ss_ctx, oracle, world):
             rank, iters = engine.Graph.pagerank_group(graphs, D, 1e-30, n_topic, max_iter=5)
             assert iters.tolist() == [5] * 6 == ref_iters.tolist()
             np.testing.assert_allclose(rank, ref, rtol=1e-13)
+            # both opt-ins at once: two columns on the wire, as float32 (inside the 1e-6 gate, iteration counts within one)
+            n_topic = synth.topic_sizes(n, 16)
+            ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-7, n_topic)
+            with ss_ctx.options(pr__wire_f32=1):
+                rank, iters = engine.Graph.pagerank_group(graphs, D, 1e-7, n_topic)
+            assert np.max(np.abs(iters.astype(int) - ref_iters.astype(int))) <= 1
+            np.testing.assert_allclose(rank, ref, rtol=1e-6)
     finally:
         one.close()
         for g in graphs:
