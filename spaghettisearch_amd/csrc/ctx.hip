@@ -296,6 +296,8 @@ static const char* const k_option_names[] = {
     "pr.trace",             // 1: ss_graph_create / ss_pr_create print their phase times to stderr
     "score.collect_pinned", // ss_score_topk_collect: 1 = device -> pinned block on the copy engine, then a host memcpy (measured slower: 0.50 against 0.41 ms
                             //    per batch with three in flight); default 0 = hipMemcpy straight into the caller's memory
+    "score.pipeline_slices",// 0: a batch that is all k_score_slices runs on the caller's stream with the fused merge (before late round 4); default 1: its
+                            //    scoring kernel on an internal stream, k_merge_topk on the caller's stream behind an event (device outputs only)
     "score.timing",         // 0: ss_score_topk records no timing events (ss_last_kernel_ms(1) keeps its last value)
     "score.trace",          // 1: ss_score_topk prints the host phases of a call (copies in, plan, staging, launches) to stderr
     "pr.probe_hot",         // ss_pr_probe policies 3/4: rows below this index use the default cache policy

@@ -1411,7 +1411,7 @@ struct ss_scorer {
     ss::DevBuf<float> d_xw[4];                  // ... and their float32 weight sums
     ss::DevBuf<uint32_t> d_xcnt, d_pcnt;
     ss::DevBuf<uint64_t> d_so_key2[TURNS];           // the slices' candidates, one set per turn ("score.pipeline": batch i's merge reads its set while batch i+1 fills the other)
-    ss::DevBuf<uint32_t> d_so_doc2[TURNS], d_so_cnt, d_qticket, d_qcnt2[TURNS];
+    ss::DevBuf<uint32_t> d_so_doc2[TURNS], d_so_cnt2[TURNS], d_qticket, d_qcnt2[TURNS];
     hipEvent_t wave_ev[TURNS] = {};  // "score.pipeline": behind k_score_wave on the context's wave stream; the merge on the caller's stream waits for it
     size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
     ss::DevBuf<ss_hit> d_hits;
@@ -2100,8 +2100,16 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     }
     SS_HIP(ctx, ensure(s->d_so_key2[pb], n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_doc2[pb], n_slices * k));
-    SS_HIP(ctx, ensure(s->d_so_cnt, n_slices));
-    const bool fused = ctx->opt("score.separate_merge", 0) == 0;
+    SS_HIP(ctx, ensure(s->d_so_cnt2[pb], n_slices));
+    // A batch that is all k_score_slices, results in device memory ("score.pipeline" != 0 and "score.pipeline_slices", default on):
+    // pipelined like the wave batches — the slices kernel on an internal stream, the merge (k_merge_topk, the kernel that writes
+    // the hits) as a launch of its own on the caller's stream behind an event.  Small slices leave the last third of their kernel
+    // on a thinning machine; the next batch's kernel now starts under it.  (The fused merge — the last slice of a query merges it
+    // inside k_score_slices — cannot move off the caller's stream: it writes the hits, and a consumer the caller enqueued between
+    // two calls must see the first call's hits before the second call's kernel touches the buffer.)
+    const bool pipe_s = dev_out && n_fast_slices == 0 && n_slices > 0 && !any_phrase && ctx->opt("score.pipeline", 2) != 0 &&
+                        ctx->opt("score.pipeline_slices", 1) != 0;
+    const bool fused = ctx->opt("score.separate_merge", 0) == 0 && !pipe_s;
     if (fused && s->qticket_zeroed < (size_t)n_q) {
         SS_HIP(ctx, ensure(s->d_qticket, (size_t)n_q));
         SS_HIP(ctx, hipMemsetAsync(s->d_qticket.p, 0, (size_t)n_q * sizeof(uint32_t), st));
@@ -2151,7 +2159,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.cb_flat = cb_flat;
     p.kth_j = kth_j;
     p.exact_all = exact_all ? 1 : 0;
-    p.so_key = s->d_so_key2[pb].p; p.so_doc = s->d_so_doc2[pb].p; p.so_cnt = s->d_so_cnt.p;
+    p.so_key = s->d_so_key2[pb].p; p.so_doc = s->d_so_doc2[pb].p; p.so_cnt = s->d_so_cnt2[pb].p;
     p.q_ticket = fused ? s->d_qticket.p : nullptr;
     p.qc_cnt = s->d_qcnt2[pb].p;
     p.merge_q = reinterpret_cast<const uint32_t*>(dp + o_mergeq);
@@ -2208,8 +2216,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, st, p);
         hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
     }
-    hipStream_t wst = st;                        // where k_wave_prep / k_score_wave go
-    if (pipe) {
+    hipStream_t wst = st;                        // where k_wave_prep / k_score_wave (or, pipe_s, k_score_slices) go
+    if (pipe || pipe_s) {
         const int n_ws = (int)std::min<int64_t>(ss_ctx::N_WAVE_STREAMS, std::max<int64_t>(1, ctx->opt("score.pipeline", 2)));
         const int wi = (int)(s->wave_turn++ % (unsigned)n_ws);
         if (!ctx->wave_stream[wi]) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->wave_stream[wi], hipStreamNonBlocking));
@@ -2223,7 +2231,11 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (n_slices > n_fast_slices) {
         ScoreParams ps = p;
         ps.order = p.order + n_fast_slices;
-        hipLaunchKernelGGL(k_score_slices, dim3((unsigned)(n_slices - n_fast_slices)), dim3(TPB), lds_score, st, ps);
+        hipLaunchKernelGGL(k_score_slices, dim3((unsigned)(n_slices - n_fast_slices)), dim3(TPB), lds_score, pipe_s ? wst : st, ps);
+    }
+    if (pipe_s) {                                // the merge, on the caller's stream, behind this batch's k_score_slices
+        SS_HIP(ctx, hipEventRecord(s->wave_ev[pb], wst));
+        SS_HIP(ctx, hipStreamWaitEvent(st, s->wave_ev[pb], 0));
     }
     if (!fused && n_slices > n_fast_slices) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     if (pipe) {                                  // the merge, on the caller's stream, behind this batch's k_score_wave

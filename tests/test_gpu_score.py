@@ -435,8 +435,8 @@ def test_batches_in_flight_with_host_results(ss_ctx, oracle):
         close_all(sc, ti, bi)
 
 
-@pytest.mark.parametrize("pipeline", [1, 0])
-def test_pipelined_batches_agree(ss_ctx, oracle, pipeline):
+@pytest.mark.parametrize("pipeline,wave", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_pipelined_batches_agree(ss_ctx, oracle, pipeline, wave):
     """(pipeline = 0: the same stream of calls in the default mode — batches of different sizes back to back reuse and regrow the
     per-turn device buffers while earlier batches are still running, which once went unguarded.)
     Option "score.pipeline" (default 1 since round 4): a batch's k_wave_prep / k_score_wave run on the context's wave stream and its
@@ -459,7 +459,9 @@ def test_pipelined_batches_agree(ss_ctx, oracle, pipeline):
             k = 40
             outs = [(torch.zeros(len(qp) * k * 40, dtype=torch.uint8, device=dev), torch.zeros(len(qp), dtype=torch.int32, device=dev))
                     for qp, _ in batches]
-            with ss_ctx.options(score__wave_min_list=0, score__pipeline=pipeline):
+            # (wave = 0: every batch is all k_score_slices — pipelined too since late round 4: the slices kernel on an internal stream,
+            #  k_merge_topk on the caller's stream behind an event)
+            with ss_ctx.options(score__wave_min_list=0, score__pipeline=pipeline, score__wave=wave):
                 snaps = []
                 for (qp, qt), out in zip(batches, outs):
                     sc.score_topk(qp, qt, k, out=out)
