@@ -1839,6 +1839,15 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
         h_pbase[q + 1] = (uint32_t)h_parts.size();
     }
+    // results straight into the caller's buffers when both live in device memory (then the call does not wait either)
+    bool dev_out = false;
+    {
+        hipPointerAttribute_t a1{}, a2{};
+        const bool d1 = hipPointerGetAttributes(&a1, hits_out) == hipSuccess && a1.type == hipMemoryTypeDevice;
+        const bool d2 = hipPointerGetAttributes(&a2, n_hits_out) == hipSuccess && a2.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();                 // plain host memory is reported as an error: not one
+        dev_out = d1 && d2;
+    }
     // Slice size: SLICE_TARGET postings when the batch fills the chip several times over; smaller (down to
     // SLICE_MIN) for small batches, so that one query's lists are spread over many CUs instead of being
     // walked by a single workgroup (latency of a lone query: 0.72 ms -> see DESIGN.md K4).
@@ -1857,6 +1866,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         // 1.5x the batch's postings per resident workgroup slot, never below SLICE_MIN (a slice costs ~45 us of
         // threshold warm-up whatever its size) nor above SLICE_TARGET
         slice_target = std::min<uint64_t>(SLICE_TARGET, std::max<uint64_t>(SLICE_MIN, batch_tot * 3 / (2 * slots)));
+        // (results in device memory: consecutive batches overlap — "score.pipeline_slices" —, the next batch's kernel fills this one's
+        //  tail and larger slices pay: mixed batch 0.164 ms at 2.6x this target against 0.170)
+        if (dev_out && ctx->opt("score.pipeline", 2) != 0 && ctx->opt("score.pipeline_slices", 1) != 0)
+            slice_target = std::min<uint64_t>(SLICE_TARGET, slice_target * 5 / 2);
         slice_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.slice_target", (int64_t)slice_target));   // experiments only
         grade_tot = batch_tot;
     }
@@ -2081,15 +2094,6 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_mergeq.empty()) std::memcpy(hp + o_mergeq, h_mergeq.data(), h_mergeq.size() * sizeof(uint32_t));
     std::memcpy(hp + o_qfast, h_fast.data(), (size_t)n_q);
     const auto th3 = t_now();
-    // results straight into the caller's buffers when both live in device memory (then the call does not wait either)
-    bool dev_out = false;
-    {
-        hipPointerAttribute_t a1{}, a2{};
-        const bool d1 = hipPointerGetAttributes(&a1, hits_out) == hipSuccess && a1.type == hipMemoryTypeDevice;
-        const bool d2 = hipPointerGetAttributes(&a2, n_hits_out) == hipSuccess && a2.type == hipMemoryTypeDevice;
-        (void)hipGetLastError();                 // plain host memory is reported as an error: not one
-        dev_out = d1 && d2;
-    }
     if (any_phrase) {
         for (int x = 0; x < 4; x++) {
             SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
