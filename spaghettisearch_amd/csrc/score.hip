@@ -1407,9 +1407,9 @@ struct ss_scorer {
     size_t qcnt_zeroed2[TURNS] = {};           // counters known to be zero (k_merge_flat leaves its query's counter at zero)
     bool plan_ev_pending[TURNS] = {};
     int plan_turn = 0;
-    ss::DevBuf<Rec> d_x[4];                     // phrase result lists: scoring records
-    ss::DevBuf<float> d_xw[4];                  // ... and their float32 weight sums
-    ss::DevBuf<uint32_t> d_xcnt, d_pcnt;
+    ss::DevBuf<Rec> d_x[TURNS][4];              // phrase result lists: scoring records (one set per turn: batches overlap)
+    ss::DevBuf<float> d_xw[TURNS][4];           // ... and their float32 weight sums
+    ss::DevBuf<uint32_t> d_xcnt[TURNS], d_pcnt[TURNS];
     ss::DevBuf<uint64_t> d_so_key2[TURNS];           // the slices' candidates, one set per turn ("score.pipeline": batch i's merge reads its set while batch i+1 fills the other)
     ss::DevBuf<uint32_t> d_so_doc2[TURNS], d_so_cnt2[TURNS], d_qticket, d_qcnt2[TURNS];
     hipEvent_t wave_ev[TURNS] = {};  // "score.pipeline": behind k_score_wave on the context's wave stream; the merge on the caller's stream waits for it
@@ -2096,11 +2096,11 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const auto th3 = t_now();
     if (any_phrase) {
         for (int x = 0; x < 4; x++) {
-            SS_HIP(ctx, ensure(s->d_x[x], (size_t)h_xoff[n_q]));
-            SS_HIP(ctx, ensure(s->d_xw[x], (size_t)h_xoff[n_q]));
+            SS_HIP(ctx, ensure(s->d_x[pb][x], (size_t)h_xoff[n_q]));
+            SS_HIP(ctx, ensure(s->d_xw[pb][x], (size_t)h_xoff[n_q]));
         }
-        SS_HIP(ctx, ensure(s->d_xcnt, (size_t)n_q * 4));
-        SS_HIP(ctx, ensure(s->d_pcnt, std::max<size_t>(h_parts.size(), 1) * 2));
+        SS_HIP(ctx, ensure(s->d_xcnt[pb], (size_t)n_q * 4));
+        SS_HIP(ctx, ensure(s->d_pcnt[pb], std::max<size_t>(h_parts.size(), 1) * 2));
     }
     SS_HIP(ctx, ensure(s->d_so_key2[pb], n_slices * k));
     SS_HIP(ctx, ensure(s->d_so_doc2[pb], n_slices * k));
@@ -2111,8 +2111,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // on a thinning machine; the next batch's kernel now starts under it.  (The fused merge — the last slice of a query merges it
     // inside k_score_slices — cannot move off the caller's stream: it writes the hits, and a consumer the caller enqueued between
     // two calls must see the first call's hits before the second call's kernel touches the buffer.)
-    const bool pipe_s = dev_out && n_fast_slices == 0 && n_slices > 0 && !any_phrase && ctx->opt("score.pipeline", 2) != 0 &&
-                        ctx->opt("score.pipeline_slices", 1) != 0;
+    const bool pipe_s = dev_out && n_fast_slices == 0 && n_slices > 0 && ctx->opt("score.pipeline", 2) != 0 &&
+                        ctx->opt("score.pipeline_slices", 1) != 0;       // (phrase queries included: their match kernels go in front of the slices kernel)
     const bool fused = ctx->opt("score.separate_merge", 0) == 0 && !pipe_s;
     if (fused && s->qticket_zeroed < (size_t)n_q) {
         SS_HIP(ctx, ensure(s->d_qticket, (size_t)n_q));
@@ -2141,11 +2141,11 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         p.ph_terms = reinterpret_cast<const uint32_t*>(dp + o_pterms);
         p.ph_drv = reinterpret_cast<const uint32_t*>(dp + o_pdrv);
         p.x_off = reinterpret_cast<const uint32_t*>(dp + o_xoff);
-        for (int x = 0; x < 4; x++) { p.x_rec[x] = s->d_x[x].p; p.x_w[x] = s->d_xw[x].p; }
-        p.x_cnt = s->d_xcnt.p;
+        for (int x = 0; x < 4; x++) { p.x_rec[x] = s->d_x[pb][x].p; p.x_w[x] = s->d_xw[pb][x].p; }
+        p.x_cnt = s->d_xcnt[pb].p;
         p.ph_parts = reinterpret_cast<const uint4*>(dp + o_parts);
         p.ph_pbase = reinterpret_cast<const uint32_t*>(dp + o_pbase);
-        p.ph_pcnt = s->d_pcnt.p;
+        p.ph_pcnt = s->d_pcnt[pb].p;
     }
     p.prior = K ? s->prior.p : nullptr;
     p.k_topics = K;
@@ -2216,10 +2216,6 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     }
     const bool timed = ctx->opt("score.timing", 1) != 0;       // the two timing events of ss_last_kernel_ms(1) (each costs the stream a few us)
     if (timed) SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
-    if (any_phrase) {
-        if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, st, p);
-        hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, st, p);
-    }
     hipStream_t wst = st;                        // where k_wave_prep / k_score_wave (or, pipe_s, k_score_slices) go
     if (pipe || pipe_s) {
         const int n_ws = (int)std::min<int64_t>(ss_ctx::N_WAVE_STREAMS, std::max<int64_t>(1, ctx->opt("score.pipeline", 2)));
@@ -2227,6 +2223,11 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         if (!ctx->wave_stream[wi]) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->wave_stream[wi], hipStreamNonBlocking));
         if (!s->wave_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->wave_ev[pb], hipEventDisableTiming));
         wst = ctx->wave_stream[wi];
+    }
+    if (any_phrase) {                            // the phrase matches, in front of the kernel that merges them in (k_score_slices)
+        hipStream_t pst = pipe_s ? wst : st;
+        if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, pst, p);
+        hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, pst, p);
     }
     if (n_fast_slices) {
         if (!prep_done) ss::launch_wave_prep(&p, (unsigned)n_fast_slices, s->d_wprep2[pb].p, wst);

@@ -76,14 +76,20 @@ def test_phrase_matches_oracle(ss_ctx, oracle):
             for f in ("title", "body", "final"):
                 assert np.array_equal(hits[f][qi, :n], ref[f]), (qi, f)
     assert n_phrase_docs > 20          # the cases do exercise real phrase matches
-    # the same batch in flight (ss_score_topk_submit with phrases) and collected: the synchronous call's hits
-    t1 = sc.submit(q_ptr, q_terms, 200, p_ptr=p_ptr, p_terms=p_terms)
-    t2 = sc.submit(q_ptr, q_terms, 20, p_ptr=p_ptr, p_terms=p_terms)
-    hc2, nc2 = sc.collect(t2)
-    hc1, nc1 = sc.collect(t1)
-    assert np.array_equal(hc1, hits) and np.array_equal(nc1, n_hits)
+    # the same batch in flight (ss_score_topk_submit with phrases) and collected: the synchronous call's hits.  Three batches at
+    # once: their phrase-match and scoring kernels overlap on internal streams (per-turn phrase result lists), the merges follow
+    # in order on the context's stream
     hs, ns = sc.score_topk_phrase(q_ptr, q_terms, p_ptr, p_terms, 20)
-    assert np.array_equal(hc2, hs) and np.array_equal(nc2, ns)
+    for _ in range(3):
+        t1 = sc.submit(q_ptr, q_terms, 200, p_ptr=p_ptr, p_terms=p_terms)
+        t2 = sc.submit(q_ptr, q_terms, 20, p_ptr=p_ptr, p_terms=p_terms)
+        t3 = sc.submit(q_ptr, q_terms, 200, p_ptr=p_ptr, p_terms=p_terms)
+        hc2, nc2 = sc.collect(t2)
+        hc3, nc3 = sc.collect(t3)
+        hc1, nc1 = sc.collect(t1)
+        assert np.array_equal(hc1, hits) and np.array_equal(nc1, n_hits)
+        assert np.array_equal(hc3, hits) and np.array_equal(nc3, n_hits)
+        assert np.array_equal(hc2, hs) and np.array_equal(nc2, ns)
     # the plain entry point is the phrase entry point without phrases
     h1, n1 = sc.score_topk(q_ptr, q_terms, 20)
     h2, n2 = sc.score_topk_phrase(q_ptr, q_terms, np.zeros(len(cases) + 1, np.uint32), np.zeros(0, np.uint32), 20)
