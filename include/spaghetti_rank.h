@@ -95,8 +95,8 @@ int32_t ss_synchronize(ss_ctx* ctx);
  * "score.pipeline" (default 2 internal streams; 0 = every scoring kernel on the context's stream): ss_score_topk calls whose outputs
  * are device buffers run their scoring kernel on an internal stream and only the per-query merge — the kernel that writes the
  * hits — on the context's stream, behind an event: the next batch's scoring starts under this batch's merge and tail.  Batches of
- * the wave kernel since round 4; batches that are all k_score_slices (short lists, many terms) too unless "score.pipeline_slices" = 0;
- * batches with phrase queries never.  Nothing changes for the caller: the hits are complete in the order of the context's stream,
+ * the wave kernel since round 4; batches that are all k_score_slices (short lists, many terms, quoted phrases) too unless
+ * "score.pipeline_slices" = 0.  Nothing changes for the caller: the hits are complete in the order of the context's stream,
  * and a consumer enqueued between two calls sees the first call's hits. */
 #define SS_OPTION_DEFAULT INT64_MIN
 int32_t ss_set_option(ss_ctx* ctx, const char* name, int64_t value);
