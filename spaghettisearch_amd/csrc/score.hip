@@ -1413,6 +1413,7 @@ struct ss_scorer {
     ss::DevBuf<uint64_t> d_so_key2[TURNS];           // the slices' candidates, one set per turn ("score.pipeline": batch i's merge reads its set while batch i+1 fills the other)
     ss::DevBuf<uint32_t> d_so_doc2[TURNS], d_so_cnt2[TURNS], d_qticket, d_qcnt2[TURNS];
     hipEvent_t wave_ev[TURNS] = {};  // "score.pipeline": behind k_score_wave on the context's wave stream; the merge on the caller's stream waits for it
+    hipEvent_t slice_ev[TURNS] = {}; // ... and behind the k_score_slices part of a split batch on ANOTHER wave stream
     size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
     ss::DevBuf<ss_hit> d_hits;
     // ss_score_topk_submit / _collect: batches in flight whose hits go to HOST memory.  A slot: device buffers the kernels write and
@@ -1442,6 +1443,7 @@ struct ss_scorer {
             if (plan_ev[i]) (void)hipEventDestroy(plan_ev[i]);
             if (batch_ev[i]) (void)hipEventDestroy(batch_ev[i]);
             if (wave_ev[i]) (void)hipEventDestroy(wave_ev[i]);
+            if (slice_ev[i]) (void)hipEventDestroy(slice_ev[i]);
         }
     }
 };
@@ -2113,7 +2115,11 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     // two calls must see the first call's hits before the second call's kernel touches the buffer.)
     const bool pipe_s = dev_out && n_fast_slices == 0 && n_slices > 0 && ctx->opt("score.pipeline", 2) != 0 &&
                         ctx->opt("score.pipeline_slices", 1) != 0;       // (phrase queries included: their match kernels go in front of the slices kernel)
-    const bool fused = ctx->opt("score.separate_merge", 0) == 0 && !pipe_s;
+    // ... and the k_score_slices part of a SPLIT batch (some queries on the wave kernel, the rest here): on a second internal stream
+    // beside the wave kernel, unfused, its k_merge_topk on the caller's stream in front of the wave queries' k_merge_flat
+    const bool pipe_split = dev_out && n_fast_slices > 0 && n_slices > n_fast_slices && !h_mergeq.empty() && ctx->opt("score.pipeline", 2) >= 2 &&
+                            ctx->opt("score.pipeline_slices", 1) != 0;
+    const bool fused = ctx->opt("score.separate_merge", 0) == 0 && !pipe_s && !pipe_split;
     if (fused && s->qticket_zeroed < (size_t)n_q) {
         SS_HIP(ctx, ensure(s->d_qticket, (size_t)n_q));
         SS_HIP(ctx, hipMemsetAsync(s->d_qticket.p, 0, (size_t)n_q * sizeof(uint32_t), st));
@@ -2216,16 +2222,24 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     }
     const bool timed = ctx->opt("score.timing", 1) != 0;       // the two timing events of ss_last_kernel_ms(1) (each costs the stream a few us)
     if (timed) SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
-    hipStream_t wst = st;                        // where k_wave_prep / k_score_wave (or, pipe_s, k_score_slices) go
+    hipStream_t wst = st;                        // where k_wave_prep / k_score_wave go
+    hipStream_t sst = st;                        // ... and k_score_slices (with the phrase kernels in front of it)
     if (pipe || pipe_s) {
         const int n_ws = (int)std::min<int64_t>(ss_ctx::N_WAVE_STREAMS, std::max<int64_t>(1, ctx->opt("score.pipeline", 2)));
         const int wi = (int)(s->wave_turn++ % (unsigned)n_ws);
         if (!ctx->wave_stream[wi]) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->wave_stream[wi], hipStreamNonBlocking));
         if (!s->wave_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->wave_ev[pb], hipEventDisableTiming));
         wst = ctx->wave_stream[wi];
+        if (pipe_split) {
+            const int si = (wi + 1) % n_ws;                        // (n_ws >= 2: "score.pipeline" >= 2)
+            if (!ctx->wave_stream[si]) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->wave_stream[si], hipStreamNonBlocking));
+            if (!s->slice_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->slice_ev[pb], hipEventDisableTiming));
+            sst = ctx->wave_stream[si];
+        }
     }
+    if (pipe_s) sst = wst;
     if (any_phrase) {                            // the phrase matches, in front of the kernel that merges them in (k_score_slices)
-        hipStream_t pst = pipe_s ? wst : st;
+        hipStream_t pst = sst;
         if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, pst, p);
         hipLaunchKernelGGL(k_phrase_close, dim3((unsigned)n_q), dim3(PH_TPB), 0, pst, p);
     }
@@ -2236,11 +2250,15 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (n_slices > n_fast_slices) {
         ScoreParams ps = p;
         ps.order = p.order + n_fast_slices;
-        hipLaunchKernelGGL(k_score_slices, dim3((unsigned)(n_slices - n_fast_slices)), dim3(TPB), lds_score, pipe_s ? wst : st, ps);
+        hipLaunchKernelGGL(k_score_slices, dim3((unsigned)(n_slices - n_fast_slices)), dim3(TPB), lds_score, sst, ps);
     }
     if (pipe_s) {                                // the merge, on the caller's stream, behind this batch's k_score_slices
         SS_HIP(ctx, hipEventRecord(s->wave_ev[pb], wst));
         SS_HIP(ctx, hipStreamWaitEvent(st, s->wave_ev[pb], 0));
+    }
+    if (pipe_split) {
+        SS_HIP(ctx, hipEventRecord(s->slice_ev[pb], sst));
+        SS_HIP(ctx, hipStreamWaitEvent(st, s->slice_ev[pb], 0));
     }
     if (!fused && n_slices > n_fast_slices) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     if (pipe) {                                  // the merge, on the caller's stream, behind this batch's k_score_wave

@@ -435,7 +435,7 @@ def test_batches_in_flight_with_host_results(ss_ctx, oracle):
         close_all(sc, ti, bi)
 
 
-@pytest.mark.parametrize("pipeline,wave", [(1, 1), (0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("pipeline,wave", [(1, 1), (0, 1), (1, 0), (0, 0), (2, 2)])
 def test_pipelined_batches_agree(ss_ctx, oracle, pipeline, wave):
     """(pipeline = 0: the same stream of calls in the default mode — batches of different sizes back to back reuse and regrow the
     per-turn device buffers while earlier batches are still running, which once went unguarded.)
@@ -456,6 +456,15 @@ def test_pipelined_batches_agree(ss_ctx, oracle, pipeline, wave):
         with torch.cuda.stream(stream):
             sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
             batches = [synth.make_queries(96 + 48 * (i % 5), 3, 300, seed=60 + i) for i in range(12)]
+            if wave == 2:
+                # SPLIT batches: 3-term queries (wave kernel) and 8-term queries (more than score.wave_max_terms: k_score_slices, on a
+                # second internal stream, unfused) in one batch
+                split = []
+                for i, (qp, qt) in enumerate(batches):
+                    lp, lt = synth.make_queries(40 + 8 * (i % 3), 8, 300, seed=160 + i)
+                    split.append((np.concatenate([qp, lp[1:] + qp[-1]]).astype(np.uint32), np.concatenate([qt, lt]).astype(np.uint32)))
+                batches = split
+                wave = 1
             k = 40
             outs = [(torch.zeros(len(qp) * k * 40, dtype=torch.uint8, device=dev), torch.zeros(len(qp), dtype=torch.int32, device=dev))
                     for qp, _ in batches]
