@@ -288,8 +288,8 @@ static const char* const k_option_names[] = {
     "pr.affine",            // 1: ss_pagerank_run computes every topic from TWO vectors (the reference's topics differ only in their start value 1/n_k,
                             //    and its recurrence maps (p*u + q) / (r*u + s) onto itself): opt-in, not the reference's operation order (~1e-13)
     "pr.deal_global",       // 0: the work items are dealt chunk by chunk in table order, each chunk sorted by cost (before round 4); 1: all items by
-                            //    falling cost first (one counting sort; default for k_pr_sweep_n); 2: by falling cost inside each class, the classes in
-                            //    table order (default for k_pr_sweep)
+                            //    falling cost first (one counting sort; default for k_pr_sweep_n<1>); 2: by falling cost inside each class, the classes in
+                            //    table order (default for k_pr_sweep and k_pr_sweep_n<2>)
     "pr.item_turns",        // turns per V_DEG work item of k_pr_sweep (V_QUAD: twice that); default 4 up to 4M local rows, 8 beyond
     "graph.late_free",      // 0: ss_graph_create waits for its last kernels and frees its temporaries before it returns (default 1: they are freed
                             //    at the graph's next use, the caller's host work overlaps the row permutation)

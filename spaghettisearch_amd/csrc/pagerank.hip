@@ -1943,8 +1943,9 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
             // is dozens of falling runs, not one.]
             static thread_local std::vector<uint32_t> order, bucket;
             // (`tools/pr_deal.py`, sweep ms at 10M / 50M: K = 16 chunks 0.959, global 0.963, class-major 0.955; K = 1 chunks 0.383, global
-            //  0.379, class-major 0.389 — k_pr_sweep takes class-major, k_pr_sweep_n the one global order)
-            const int64_t deal_mode = ctx->opt("pr.deal_global", pr->nwave ? 1 : 2);
+            //  0.379, class-major 0.389 — k_pr_sweep and k_pr_sweep_n<2> take class-major, k_pr_sweep_n<1> the one global order)
+            // (K = 2 on k_pr_sweep_n at 10M / 50M: class-major 0.471, global 0.481, chunks 0.483)
+            const int64_t deal_mode = ctx->opt("pr.deal_global", pr->nwave && pr->gw == 1 ? 1 : 2);
             const bool global_order = deal_mode != 0;
             if (global_order) {
                 constexpr uint32_t NB = 1u << 14;
