@@ -281,7 +281,7 @@ static const char* const k_option_names[] = {
     "pr.wire_f32",          // 1: the doc-range-sharded sweep exchanges its contribution slices as float32 (half the bytes per link; inside the 1e-6 gate, not the
                             //    reference's float64 arithmetic: opt-in, reported under bench.py's `decompositions` only).  Every rank must set it alike.
     "pr.narrow_wave",       // 0: K <= 2 as before round 4 (padded to the 8-wide sweep on small graphs, k_pr_step on large ones); default 1: k_pr_sweep_n
-    "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 256)
+    "pr.t_quad",            // in-degree above which a row gets a wave of its own in k_pr_sweep (default 128 — with the class stagger 96 .. 192 measure alike, 256 0.5 % slower —; k_pr_sweep_n 256)
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
     "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 65536, 0 = off)
     "pr.deal_snake",        // work items dealt to the waves in alternating direction (1) or least-loaded-first (0); default: 1 from 8 items per wave on and for k_pr_sweep_n

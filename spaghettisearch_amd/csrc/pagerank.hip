@@ -1390,7 +1390,7 @@ void build_work(const ss_graph* g, int gw, bool lane_rows, int64_t item_turns_de
     auto emit_v = [&](const ss_graph::SortedDegrees& deg, uint32_t row0, bool non_dangling, uint32_t& n_pos) {
         const uint32_t cnt = (uint32_t)deg.size();
         const uint32_t T_MULTI = 4096, T_DEG = 8;
-        const uint32_t T_QUAD = (uint32_t)g->ctx->opt("pr.t_quad", 256);
+        const uint32_t T_QUAD = (uint32_t)g->ctx->opt("pr.t_quad", lane_rows ? 256 : 128);   // (k_pr_sweep_n keeps 256)
         // turns per V_DEG item (a V_QUAD item: twice that): small graphs want finer items — with ~20 turns per wave in all, an
         // item of 16 leaves the deal nothing to balance ("pr.item_turns"; default from the graph's size, see ss_pr_create)
         const uint32_t item_turns = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(64, g->ctx->opt("pr.item_turns", item_turns_default)));
