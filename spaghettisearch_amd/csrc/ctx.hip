@@ -288,7 +288,7 @@ static const char* const k_option_names[] = {
     "pr.affine",            // 1: ss_pagerank_run computes every topic from TWO vectors (the reference's topics differ only in their start value 1/n_k,
                             //    and its recurrence maps (p*u + q) / (r*u + s) onto itself): opt-in, not the reference's operation order (~1e-13)
     "pr.stagger",           // 0: every block of k_pr_sweep walks the work classes in the same order; default 1: the resident blocks of a CU start at
-                            //    different classes (by arrival round)
+                            //    different classes (by arrival round); >= 10, experiments: 10 + the rounds' start classes as base-6 digits
     "pr.deal_global",       // 0: the work items are dealt chunk by chunk in table order, each chunk sorted by cost (before round 4); 1: all items by
                             //    falling cost first (one counting sort; default for k_pr_sweep_n<1>); 2: by falling cost inside each class, the classes in
                             //    table order (default for k_pr_sweep and k_pr_sweep_n<2>)

@@ -118,6 +118,7 @@ struct PrParams {
     uint32_t zrow;            // index of the table's all-zero row (= nd_int): where the unused slots of a chunk gather from
     const uint32_t* woff;     // k_pr_sweep: [waves][8]: wave w's items of class c are work[woff[8w+c] .. woff[8w+c+1])
     uint32_t stagger_div;     // k_pr_sweep: blocks per arrival round (= CUs); 0 = every block walks the classes in the same order
+    uint32_t stagger_code;    // experiments: start classes of the rounds as base-6 digits (0 = round r starts at class r)
     double* x_alt;            // two-vector form: sweep s reads x (s even) / x_alt (s odd) and writes the other one; null otherwise
     AffCtl* aff;              // two-vector form ("pr.affine"): its control block; null otherwise
     const double* tele_col;   // ... and the per-column teleport (ctl->tele); null = the uniform p.teleport
@@ -837,7 +838,12 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     // that a CU — and the memory system behind it — sees the long rows' index streams, the mid rows and the short rows' gathers side
     // by side instead of one access pattern at a time: 0.932-0.934 ms per sweep at config 4 against 0.957-0.961 in class order
     // everywhere (rotating per wave or per block index, or permuting the class order: 0.96-0.99; option "pr.stagger" = 0: off).
-    const int rot = p.stagger_div ? (int)((blockIdx.x / p.stagger_div) % 6u) : 0;
+    int rot = p.stagger_div ? (int)((blockIdx.x / p.stagger_div) % 6u) : 0;
+    if (p.stagger_code) {                       // experiments ("pr.stagger" >= 10): round r starts at base-6 digit r of the code
+        uint32_t cdv = p.stagger_code;
+        for (uint32_t r = blockIdx.x / p.stagger_div; r > 0; r--) cdv /= 6u;
+        rot = (int)(cdv % 6u);
+    }
     for (int s6 = 0; s6 < 6; s6++) {
     const int cls = (s6 + rot) % 6;
     switch (cls) {
@@ -2145,6 +2151,7 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     p.zrow = (uint32_t)g->nd_int;
     p.woff = pr->woff.p;
     p.stagger_div = ctx->opt("pr.stagger", 1) != 0 ? (uint32_t)std::max(ctx->cu_count, 1) : 0u;
+    p.stagger_code = ctx->opt("pr.stagger", 1) >= 10 ? (uint32_t)(ctx->opt("pr.stagger", 1) - 10) : 0u;
 #ifdef SS_PR_EXP_KINDMASK
     p.kind_mask = getenv("SS_PR_KIND_MASK") ? (uint32_t)strtoul(getenv("SS_PR_KIND_MASK"), nullptr, 0) : 0xFFFFFFFFu;
     {
