@@ -123,6 +123,92 @@ class NumpyShardState:
 
 
 # ------------------------------------------------------------------------------------------------
+# CPU model of ONE shard of the TWO-VECTOR form on doc-range shards (library option "pr.affine", csrc/pagerank.hip
+# run_affine_sharded): every topic's ranks are (p*u_k + q) / (r*u_k + s) with u_k = 1/n_k; the shards exchange the 2-wide
+# contribution slices and, per iteration, their K local L1 sums.  Same layout as NumpyShardState (k = 2, start vector (1, 0)).
+
+class NumpyAffineShard(NumpyShardState):
+    def __init__(self, n_nodes, out_ptr, out_dst, d, eps, n_topic, rank, world, max_iter=0):
+        super().__init__(n_nodes, out_ptr, out_dst, d, -1.0, [1, 1], rank, world, max_iter=0)
+        self.x0 = np.array([1.0, 0.0])
+        self.u = 1.0 / np.asarray(n_topic, dtype=np.float64)
+        self.K = len(self.u)
+        self.eps_t, self.max_iter_t = eps, max_iter
+        self.t_active = np.ones(self.K, dtype=bool)
+        self.t_iters = np.zeros(self.K, dtype=np.int32)
+        self.out = np.zeros((self.K, len(self.own)))
+        self.tele = np.array([0.0, 1.0 - d])
+        self.r_x, self.s_x, self.r_next, self.s_next = 0.0, 1.0, 0.0, 1.0
+
+    def _gather(self, send, recv):
+        import torch.distributed as dist
+        parts = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(parts, send)
+        recv.copy_(torch.cat(parts))
+
+    def _exchange_table(self):
+        snd, tab = self.exchange_tensors()
+        self._gather(snd, tab)
+
+    def _sums(self):
+        t = self.table.reshape(self.world, self.sl_nd, self.k)
+        return t[:, -2].sum(axis=0)
+
+    def run(self):
+        tele_n = (1.0 - self.d) * self.n_nodes
+        tau = 1.0 - self.d
+        # begin
+        self.x[:] = self.x0
+        c = self.d * self.x[:len(self.own_nd)] / self.outdeg_nd[:, None]
+        self._publish(c, np.zeros(self.k))
+        self._exchange_table()
+        cs = self._sums()
+        r1, s1 = cs[0], cs[1] + tele_n
+        sigma = r1 + s1
+        self.r_next, self.s_next = r1 / sigma, s1 / sigma
+        it = 0
+        while self.t_active.any():
+            y = np.zeros_like(self.x)
+            np.add.at(y, self.e_row, self.table[self.e_src])
+            if it == 0:
+                y += self.x0
+            xo = self.x
+            xn = (y + self.tele) / sigma
+            self.x = xn
+            c = self.d * xn[:len(self.own_nd)] / self.outdeg_nd[:, None]
+            self._publish(c, np.zeros(self.k))
+            self._exchange_table()
+            cs = self._sums()
+            r_prev, s_prev = self.r_x, self.s_x
+            self.r_x, self.s_x = self.r_next, self.s_next
+            r1, s1 = cs[0] + tele_n * self.r_x, cs[1] + tele_n * self.s_x
+            sigma = r1 + s1
+            self.r_next, self.s_next = r1 / sigma, s1 / sigma
+            self.tele = np.array([tau * self.r_x, tau * self.s_x])
+            # the topics' L1 changes: local sums, gathered, added in rank order
+            new = (xn[:, :1] * self.u + xn[:, 1:2]) / (self.r_x * self.u + self.s_x)
+            old = (xo[:, :1] * self.u + xo[:, 1:2]) / (r_prev * self.u + s_prev)
+            loc = torch.from_numpy(np.abs(new - old).sum(axis=0))
+            allv = torch.empty(self.world * self.K, dtype=torch.float64)
+            self._gather(loc, allv)
+            dl = allv.reshape(self.world, self.K).numpy()
+            tot = np.zeros(self.K)
+            for r in range(self.world):
+                tot += dl[r]
+            it += 1
+            for k in range(self.K):
+                if self.t_active[k]:
+                    self.t_iters[k] = it
+                    cont = tot[k] > self.eps_t
+                    if self.max_iter_t > 0 and it >= self.max_iter_t:
+                        cont = False
+                    if not cont:
+                        self.t_active[k] = False
+                        self.out[k] = new[:, k]
+        return self.own.astype(np.uint32), self.out, self.t_iters
+
+
+# ------------------------------------------------------------------------------------------------
 # CPU model of ONE doc-range shard of the inverted index (test infrastructure): the oracle's arithmetic
 # applied to the shard's slice, with the idf taken from whole-corpus document frequencies — what
 # ss_index_set_doc_freq + ss_tfidf_build + ss_score_topk do on the GPU.

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from oracle import pyoracle
 from spaghettisearch_amd import sharding, synth
-from tests.shard_model import NumpyShardState
+from tests.shard_model import NumpyAffineShard, NumpyShardState
 
 D, EPS = 0.75, 1e-10
 
@@ -106,3 +106,50 @@ def test_pipelined_topic_blocks_gloo_match_oracle(tmp_path, world):
     ptr, dst = synth.rmat_graph(n, e, seed=21)
     ref, _ = pyoracle.pagerank(n, ptr, dst, D, -1.0, n_topic, max_iter=sweeps)
     np.testing.assert_allclose(got["rank"], ref, rtol=1e-12)
+
+
+# ---- the two-vector form on doc-range shards (library option "pr.affine", csrc/pagerank.hip run_affine_sharded) ---------------------
+def _worker_affine(rank, world, port, n, e, n_topic, eps, max_iter, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ptr, dst = synth.rmat_graph(n, e, seed=31)
+        st = NumpyAffineShard(n, ptr, dst, D, eps, n_topic, rank, world, max_iter=max_iter)
+        ids, ranks, iters = st.run()
+        # assemble by original id on rank 0
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([len(ids)], dtype=torch.int64))
+        m = int(max(int(x) for x in sizes))
+        pad_ids = torch.full((m,), -1, dtype=torch.int64)
+        pad_ids[:len(ids)] = torch.from_numpy(ids.astype(np.int64))
+        pad_rk = torch.zeros((len(n_topic), m), dtype=torch.float64)
+        pad_rk[:, :len(ids)] = torch.from_numpy(ranks)
+        all_ids = [torch.empty_like(pad_ids) for _ in range(world)]
+        all_rk = [torch.empty_like(pad_rk) for _ in range(world)]
+        dist.all_gather(all_ids, pad_ids)
+        dist.all_gather(all_rk, pad_rk)
+        if rank == 0:
+            full = np.zeros((len(n_topic), n))
+            for i_, r_ in zip(all_ids, all_rk):
+                i_ = i_.numpy()
+                ok = i_ >= 0
+                full[:, i_[ok]] = r_.numpy()[:, ok]
+            np.savez(out_path, rank=full, iters=iters)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_vector_form_on_gloo_shards_matches_oracle(tmp_path, world):
+    """The sharded two-vector protocol (a 2-column exchange and an all-gather of the ranks' K local L1 sums per iteration, stop
+    rule from the sums added in rank order) between real processes: every topic's ranks and iteration count as the oracle's."""
+    n, e = 4000, 22000
+    for n_topic, eps, max_iter in ((synth.topic_sizes(n, 9), EPS, 0), ([n, 7, 123], 1e-30, 4)):
+        out = str(tmp_path / f"aff{len(n_topic)}.npz")
+        mp.spawn(_worker_affine, args=(world, _free_port(), n, e, list(n_topic), eps, max_iter, out), nprocs=world, join=True)
+        got = np.load(out)
+        ptr, dst = synth.rmat_graph(n, e, seed=31)
+        ref, ref_iters = pyoracle.pagerank(n, ptr, dst, D, eps, n_topic, max_iter=max_iter)
+        assert got["iters"].tolist() == ref_iters.tolist()
+        np.testing.assert_allclose(got["rank"], ref, rtol=1e-12)
