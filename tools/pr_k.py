@@ -1,9 +1,11 @@
-"""Sweep time of the PageRank kernel by number of topic vectors (10M nodes / 50M edges)."""
-import time, sys, torch
+"""Sweep time of the PageRank kernel by number of topic vectors (10M nodes / 50M edges).  OPTS="pr.stagger=0" sets options."""
+import os, time, sys, torch
 sys.path.insert(0, '.')
 from spaghettisearch_amd import engine, synth
 dev = torch.device('cuda', 0)
 ctx = engine.Context(0)
+for kv in os.environ.get("OPTS", "").split(","):
+    if kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 n, e = 10_000_000, 50_000_000
 ptr, dst = synth.rmat_graph_torch(n, e, seed=42, device=dev)
 torch.cuda.synchronize()
