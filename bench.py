@@ -1058,23 +1058,6 @@ def main() -> None:
                         decomp["f32_wire_doc_range_shards_lib_pipelined"] = {"value": 0.0, "error": repr(exc)}
                     finally:
                         ctx.set_option("pr.wire_f32", None)
-                    # the two-vector form on the shards (option "pr.affine": a TWO-column exchange per iteration whatever K is — 2/kt of the
-                    # table's bytes per link; opt-in, not the reference's operation order) — reported here only, never as `value`
-                    try:
-                        ctx.set_option("pr.affine", 1)
-                        ent, rk2 = lib_pipelined(g2, n_topic, f"doc-range shards x{world}, two-vector form (opt-in pr.affine): all {kt} topics from two "
-                                                              f"vectors, a 2-column exchange per iteration; not eligible as the headline")
-                        if ent.get("exchange_bytes_per_rank"):
-                            ent["exchange_bytes_per_rank"] *= 2.0 / kt
-                            ent["predicted_exchange_ms_at_7x50GBs"] *= 2.0 / kt
-                        ent["never_the_headline"] = True
-                        ent["topic_blocks"] = "none (one K = 2 state per shard)"
-                        decomp["two_vector_form_doc_range_shards"] = ent
-                        del rk2
-                    except Exception as exc:
-                        decomp["two_vector_form_doc_range_shards"] = {"value": 0.0, "error": repr(exc)}
-                    finally:
-                        ctx.set_option("pr.affine", None)
                     for G in (2, 4):
                         S = world // G
                         if world % G or S < 2 or kt % G:
@@ -1111,6 +1094,25 @@ def main() -> None:
                         result["config"]["parallelism"] = decomp[best]["parallelism"]
                         result["config"]["sweeps_per_sec"] = result["value"] / kt
                         decomp["headline"] = best
+                    # the two-vector form on the shards (option "pr.affine": a TWO-column exchange per iteration whatever K is — 2/kt of the
+                    # table's bytes per link; opt-in, not the reference's operation order) — reported here only, never as `value`
+                    # (after the choice above and last of all: this variant is the newest code on the multi-rank path — if it stalls, the watchdog
+                    # prints everything measured before it)
+                    try:
+                        ctx.set_option("pr.affine", 1)
+                        ent, rk2 = lib_pipelined(g2, n_topic, f"doc-range shards x{world}, two-vector form (opt-in pr.affine): all {kt} topics from two "
+                                                              f"vectors, a 2-column exchange per iteration; not eligible as the headline")
+                        if ent.get("exchange_bytes_per_rank"):
+                            ent["exchange_bytes_per_rank"] *= 2.0 / kt
+                            ent["predicted_exchange_ms_at_7x50GBs"] *= 2.0 / kt
+                        ent["never_the_headline"] = True
+                        ent["topic_blocks"] = "none (one K = 2 state per shard)"
+                        decomp["two_vector_form_doc_range_shards"] = ent
+                        del rk2
+                    except Exception as exc:
+                        decomp["two_vector_form_doc_range_shards"] = {"value": 0.0, "error": repr(exc)}
+                    finally:
+                        ctx.set_option("pr.affine", None)
                 g2.close()
         except Exception as exc:
             result["pipelined_error"] = repr(exc)
