@@ -81,15 +81,20 @@ def cpu_share():
 OMP_THREADS, OMP_HOW = cpu_share()
 os.environ["OMP_NUM_THREADS"] = str(OMP_THREADS)
 
+TFIDF_KERNELS = ("k_weight_count", "k_scatter", "k_bucket_sum")   # the three passes over the body table's postings
+SCORE_WARM = 50         # untimed scoring batches in front of every timed scoring region, whatever --warmup says (see timed_blocks)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 N_BLOCKS = 5            # timed blocks of --steps per measurement: the first is `value`, all give min/median
 
 
-def profiled_traffic(kernel: str):
+def profiled_traffic(kernel: str, pick: str = "median"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/*_pmc_hbm_bytes.json: FETCH_SIZE and WRITE_SIZE in KB, separate passes).  FETCH_SIZE counts
     128-byte requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section; checked on k_weight here), so the
-    read side is doubled for these wide-request kernels.  None if no profile is committed."""
+    read side is doubled for these wide-request kernels.  None if no profile is committed.
+    `pick`: which dispatch of the run stands for the timed launch — "median" for a kernel launched hundreds of times on one
+    workload (the sweep, the scoring kernels), "max" for the TF-IDF build kernels, which run exactly twice per bench (the 41M-posting
+    title table, then the 641M-posting body table the roofline is quoted on: the median of two is their mean, VERDICT r4 #2)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_bytes.json")))
     for path in reversed(files):
@@ -99,8 +104,10 @@ def profiled_traffic(kernel: str):
             wr = [r for r in rows if r["counter"] == "WRITE_SIZE" and kernel in r["kernel"]]
             if not rd or not wr:
                 continue
-            return {"bytes": 2.0 * rd[0]["median_KB"] * 1024 + wr[0]["median_KB"] * 1024,
-                    "fetch_size_raw_bytes": rd[0]["median_KB"] * 1024, "write_size_bytes": wr[0]["median_KB"] * 1024,
+            key = "max_KB" if pick == "max" else "median_KB"
+            return {"bytes": 2.0 * rd[0][key] * 1024 + wr[0][key] * 1024,
+                    "fetch_size_raw_bytes": rd[0][key] * 1024, "write_size_bytes": wr[0][key] * 1024,
+                    "dispatch": "the run's largest (body table)" if pick == "max" else "median over the run's dispatches",
                     "source": os.path.relpath(path, ROOT)}
         except Exception:
             continue
@@ -200,10 +207,13 @@ def main() -> None:
 
     K, W = args.steps, args.warmup
 
-    def timed_blocks(step_k, warm=None, n_blocks=N_BLOCKS):
+    def timed_blocks(step_k, warm=None, n_blocks=N_BLOCKS, min_warm=0):
         """W untimed warm-up steps, then N_BLOCKS blocks of EXACTLY K steps, each bracketed by barrier + synchronize on
-        both sides and reduced with max over ranks.  -> (seconds of the first block, [ms per step of every block])."""
-        (warm or step_k)(max(W, 1))
+        both sides and reduced with max over ranks.  -> (seconds of the first block, [ms per step of every block]).
+        `min_warm`: the scoring sections ask for at least SCORE_WARM untimed batches whatever --warmup says — back-to-back batches
+        take ~40 calls after an idle stream to reach their steady rate (0.375 / 0.355 / 0.343 ms for the first three blocks of 20),
+        and the driver's command has --warmup 5; the line says so (`topk.untimed_warmup_batches`)."""
+        (warm or step_k)(max(W, 1, min_warm))
         secs = []
         for _ in range(n_blocks):
             barrier()
@@ -240,6 +250,39 @@ def main() -> None:
         if invalid:
             out["valid"] = False
             out["invalid_because"] = invalid
+        # compact digest as the LAST key: a reader that keeps only the tail of the line (the driver keeps 2000 characters) still gets
+        # both halves of the metric and every nested roofline fraction
+        def dig(o, *path):
+            for k_ in path:
+                if not isinstance(o, dict) or k_ not in o:
+                    return None
+                o = o[k_]
+            return round(o, 4) if isinstance(o, float) else o
+        tk = out if out.get("metric") == "topk_queries_per_sec" else out.get("topk", {})
+        summ = {"pagerank": {"topic_iters_per_s": dig(out, "value") if out.get("metric") == "pagerank_iters_per_sec" else None,
+                             "ms_per_sweep": dig(out, "ms_per_step") if out.get("metric") == "pagerank_iters_per_sec" else None,
+                             "kernel_ms": dig(out, "roofline", "kernel_ms"), "frac": dig(out, "roofline", "frac"),
+                             "e2e_ms": dig(out, "pagerank_end_to_end", "config4", "eps1e-6", "device_csr", "total_ms"),
+                             "two_vector_ms": dig(out, "pagerank_two_vector_form", "ms_per_iteration_of_all_topics")},
+                "topk": {"queries_per_s": dig(tk, "value"), "ms_per_batch": dig(tk, "ms_per_step"),
+                         "kernel_ms_one_batch": dig(tk, "roofline", "kernel_ms"), "frac_one_batch": dig(tk, "roofline", "frac"),
+                         "period_ms": dig(tk, "roofline", "pipelined_period_ms"), "frac_steady": dig(tk, "roofline", "frac_steady_state"),
+                         "warm_batches": dig(tk, "untimed_warmup_batches"),
+                         "blended_q_per_s": dig(tk, "blended_config5", "value"), "mixed_ms": dig(tk, "mixed_queries", "ms_per_step"),
+                         "tail_ms": dig(tk, "tail_queries", "ms_per_step"), "half_half_ms": dig(tk, "half_head_half_tail", "ms_per_step"),
+                         "one_query_ms": dig(tk, "latency_single_query_ms", "median"),
+                         "host_io_q_per_s": dig(tk, "queries_per_sec_host_in_host_out"),
+                         "host_io_3_in_flight_q_per_s": dig(tk, "queries_per_sec_host_in_host_out_3_in_flight")},
+                "tfidf": {"ms": dig(tk, "tfidf", "ms"), "frac": dig(tk, "tfidf", "roofline", "frac"),
+                          "traffic_over_algorithmic": (round(tk["tfidf"]["roofline"]["traffic"] / tk["tfidf"]["roofline"]["algorithmic_bytes"], 3)
+                                                       if dig(tk, "tfidf", "roofline", "traffic") else None)},
+                "config2": {"ms_per_iter": dig(out, "config2", "ms_per_step"), "kernel_ms": dig(out, "config2", "roofline", "kernel_ms"),
+                            "frac": dig(out, "config2", "roofline", "frac"),
+                            "e2e_ms": dig(out, "config2", "end_to_end", "eps1e-6", "device_csr", "total_ms")},
+                "cpu": {"pagerank_B1": dig(out, "cpu_baseline", "value") if out.get("metric") == "pagerank_iters_per_sec" else None,
+                        "topk_B1": dig(tk, "cpu_baseline", "value")},
+                "valid": not invalid}
+        out["summary"] = summ
         print(json.dumps(out), flush=True)
 
     if world > 1:
@@ -693,13 +736,13 @@ def main() -> None:
                     sc.score_topk(qp, qt, k, out=(d_hits, d_nhits), **kw)     # overlaps the kernels of batch i
 
             ctx.set_option("score.timing", 0)        # the timed regions run without the library's two timing events per call
-            dt, blocks = timed_blocks(batches)       # (instrumentation: each costs the stream a few us; they are switched on again for
+            dt, blocks = timed_blocks(batches, min_warm=SCORE_WARM)       # (instrumentation: each costs the stream a few us; they are switched on again for
             ctx.set_option("score.timing", None)     #  the kernel-time loop below and for everything that reads ss_last_kernel_ms)
             # Device time per batch of the SAME back-to-back calls, by HIP events on the stream the hits are produced on (the merge of
             # every batch runs on it, in call order: the interval from the first call's start to the last merge's end is the time the
             # device spent on K batches with its pipelining as it is in production) — the roofline's `achieved` uses this figure ...
             ctx.set_option("score.timing", 0)
-            batches(max(W, 1))
+            batches(max(W, 1, SCORE_WARM))
             ctx.synchronize(); torch.cuda.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(stream)
@@ -724,7 +767,7 @@ def main() -> None:
                 ref_h, ref_n = d_hits.clone(), d_nhits.clone()
                 ctx.set_option("score.timing", 0)
                 ctx.set_option("score.pipeline", 0)
-                dtp, blocks_p = timed_blocks(batches)
+                dtp, blocks_p = timed_blocks(batches, min_warm=SCORE_WARM)
                 ctx.synchronize(); torch.cuda.synchronize()
                 same_p = bool(torch.equal(ref_h, d_hits) and torch.equal(ref_n, d_nhits))
                 ctx.set_option("score.pipeline", None)
@@ -755,16 +798,24 @@ def main() -> None:
             dt_flight = time.perf_counter() - t0
             assert all(np.array_equal(o[0], hits) and np.array_equal(o[1], n_hits) for o in outs3)
             algo_q = 8 * sum_df + 36 * k * nq           # SURVEY.md §8d B_q without the per-candidate magnitude term
-            ach = algo_q / (period_ms * 1e-3) / 1e9
+            ach = algo_q / (period_ms * 1e-3) / 1e9      # steady state: device time per batch of K overlapping batches
+            ach1 = algo_q / (kern_ms * 1e-3) / 1e9       # one batch's kernels alone
             full = (nd, nt, nq, k) == (10_000_000, 1_000_000, 1024, 100)
             algo_tw = 12 * Pb + 8 * nt + 8 * nd         # SURVEY.md §8d B_tw = 12P + 8T + 8N (body table)
             ach_tw = algo_tw / (tfidf_ms * 1e-3) / 1e9
             tw_traffic = None
+            tw_detail = None
             sc_traffic = None
             if full:
-                parts = [profiled_traffic(kn) for kn in ("k_weight_count", "k_scatter", "k_bucket_sum")]
+                parts = [profiled_traffic(kn, pick="max") for kn in TFIDF_KERNELS]
                 if all(parts):
                     tw_traffic = sum(p["bytes"] for p in parts)
+                    tw_detail = {kn: {"fetch_size_raw_bytes": p["fetch_size_raw_bytes"], "write_size_bytes": p["write_size_bytes"]} for kn, p in zip(TFIDF_KERNELS, parts)}
+                    tw_detail["source"] = parts[0]["source"]
+                    tw_detail["dispatch"] = parts[0]["dispatch"]
+                    # a full pass cannot move fewer bytes than it must read and write: such a figure is a selection error
+                    if tw_traffic < algo_tw:
+                        invalid.append(f"tfidf roofline.traffic {tw_traffic:.3e} B below the algorithmic bytes {algo_tw:.3e} B")
                 parts = [profiled_traffic(kn) for kn in ("k_wave_prep", "k_score_wave", "k_merge_flat")]
                 if all(parts):
                     sc_traffic = sum(p["bytes"] for p in parts)
@@ -774,19 +825,21 @@ def main() -> None:
                                            f"(term ranks U[1,10000]), cosine top-{k} (BASELINE config 3)",
                                "postings_per_query": sum_df / nq,
                                "parallelism": "single GPU" if world == 1 else f"query-split replicas x{world}"},
-                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ach / HBM_PEAK_GBS,
+                    "roofline": {"bound": "hbm", "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ach1 / HBM_PEAK_GBS,
                                  "traffic": sc_traffic,
-                                 "kernel": "scoring kernels of one batch (k_wave_prep + k_score_wave + k_merge_flat); `kernel_ms` = device time per batch of "
-                                           "K back-to-back batches (HIP events on the stream that carries every batch's merge): consecutive batches' "
-                                           "kernels overlap (k_score_wave of batch i+1 runs under k_merge_flat of batch i)",
-                                 "kernel_ms": period_ms, "algorithmic_bytes": algo_q,
-                                 "one_batch_alone": {"kernel_ms": kern_ms, "kernel_ms_min": min(kms), "frac": algo_q / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                     "what": "one batch's kernels with nothing beside them (what a kernel trace of score.pipeline=0 shows per kernel, summed)"}},
+                                 "kernel": "scoring kernels of one batch (k_wave_prep + k_score_wave + k_merge_flat); `kernel_ms` = their summed device time "
+                                           "for ONE batch with nothing beside it (HIP events on the library's stream; what a kernel trace of score.pipeline=0 "
+                                           "shows per kernel, summed).  Back-to-back batches overlap (k_score_wave of batch i+1 runs under k_merge_flat of "
+                                           "batch i): that steady-state period is `pipelined_period_ms` / `frac_steady_state`, not a kernel time",
+                                 "kernel_ms": kern_ms, "kernel_ms_min": min(kms), "algorithmic_bytes": algo_q,
+                                 "pipelined_period_ms": period_ms, "achieved_steady_state": ach, "frac_steady_state": ach / HBM_PEAK_GBS},
+                    "untimed_warmup_batches": max(W, 1, SCORE_WARM),
                     "tfidf": {"ms": tfidf_ms, "title_ms": tfidf_title_ms,
                               "what": "ss_tfidf_build of the body table: device time between HIP events (allocations outside)",
                               "roofline": {"bound": "hbm", "achieved": ach_tw, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_tw / HBM_PEAK_GBS,
-                                           "traffic": tw_traffic, "kernel": "k_idf + head-list set-up + k_weight_count + k_scatter + k_bucket_sum",
+                                           "traffic": tw_traffic, "traffic_detail": tw_detail,
+                                           "kernel": "k_idf + head-list set-up + k_weight_count + k_scatter + k_bucket_sum",
                                            "kernel_ms": tfidf_ms, "algorithmic_bytes": algo_tw}},
                     "tfidf_build_ms": tfidf_ms, "scorer_create_ms": scorer_create_ms,
                     "queries_per_sec_host_in_host_out": nq * K / dt_pcie,
@@ -810,7 +863,7 @@ def main() -> None:
             # ---- tail queries: term ranks uniform over the whole vocabulary, reported separately
             tq_ptr, tq_terms = synth.make_queries(nq, 3, nt, seed=1045 + rank)
             ctx.set_option("score.timing", 0)
-            dtt, _ = timed_blocks(lambda m: batches(m, tq_ptr, tq_terms), n_blocks=1)
+            dtt, _ = timed_blocks(lambda m: batches(m, tq_ptr, tq_terms), n_blocks=1, min_warm=SCORE_WARM)
             ctx.set_option("score.timing", None)
             tail_df = int(sum((h_bptr[t + 1] - h_bptr[t]) + (h_tptr[t + 1] - h_tptr[t]) for t in tq_terms.astype(np.int64)))
             topk["tail_queries"] = {"value": world * nq * K / dtt, "unit": "queries/s", "ms_per_step": dtt * 1e3 / K,
@@ -826,7 +879,7 @@ def main() -> None:
             ctx.set_option("score.timing", 0)
             for key_, (qp_, qt_), what_ in (("mixed_queries", (mq_ptr, mq_terms), f"{nq} x 3-term OR queries, term ranks U[1,{min(100_000, nt)}]"),
                                             ("half_head_half_tail", (hh_ptr, hh_terms), f"{hq} queries of term ranks U[1,10000] + {nq - hq} of U[1,{nt}] in one batch")):
-                dtm, _ = timed_blocks(lambda m: batches(m, qp_, qt_), n_blocks=1)
+                dtm, _ = timed_blocks(lambda m: batches(m, qp_, qt_), n_blocks=1, min_warm=SCORE_WARM)
                 dfm = int(sum((h_bptr[t + 1] - h_bptr[t]) + (h_tptr[t + 1] - h_tptr[t]) for t in qt_.astype(np.int64)))
                 topk[key_] = {"value": world * nq * K / dtm, "unit": "queries/s", "ms_per_step": dtm * 1e3 / K, "workload": what_, "postings_per_query": dfm / nq}
             ctx.set_option("score.timing", None)
@@ -842,7 +895,7 @@ def main() -> None:
             sc.set_prior(prior5)
             probs5 = np.random.default_rng(46 + rank).dirichlet(np.ones(kt5), size=nq)
             ctx.set_option("score.timing", 0)
-            dt5, blocks5 = timed_blocks(lambda m: batches(m, topic_probs=probs5))
+            dt5, blocks5 = timed_blocks(lambda m: batches(m, topic_probs=probs5), min_warm=SCORE_WARM)
             ctx.set_option("score.timing", None)
             topk["blended_config5"] = {"value": world * nq * K / dt5, "unit": "queries/s", "ms_per_step": dt5 * 1e3 / K,
                                        "ms_per_step_blocks": summarize(blocks5),
@@ -1068,10 +1121,10 @@ def main() -> None:
                             ctx2 = engine.Context(local_rank)
                             ctx2.set_stream(stream.cuda_stream)
                             sharding.init_lib_comm(ctx2, rank, world)
-                            color, key = rank % G, rank // G
+                            color, key, S, t_lo, t_hi = sharding.topic_group_layout(rank, world, G, kt)
                             ctx2.comm_split(color, key)                    # the context's communicator is now its topic group's
                             gs = engine.Graph(ctx2, n, out_ptr, out_dst, rank=key, world=S)
-                            mine = n_topic[color * (kt // G):(color + 1) * (kt // G)]
+                            mine = n_topic[t_lo:t_hi]
                             decomp[name2], _rk = lib_pipelined(
                                 gs, mine, f"{G} topic groups x {S} doc shards: every group runs {kt // G} topics on its own communicator "
                                           f"(ss_comm_split), exchange = 1/{G} of the table over {S} ranks", n_groups=G)

@@ -192,16 +192,21 @@ func score(snap *deviceIndex, batch []*request) ([][]spaghetti.Hit, error) {
 }
 
 // Batches in flight: batchLoop submits a batch (the library enqueues it and returns) and goes back to collecting requests;
-// collectLoop waits for the batches in the order they were submitted and answers their callers.  The channel holds two batches
-// while a third is being collected: SS_SCORE_INFLIGHT = 3 tickets at most.  The host's plan for batch i+1 and the copy-out of
-// batch i-1 then run under the kernels of batch i (INTEGRATION.md §4).
+// collectLoop waits for the batches in the order they were submitted and answers their callers.  A batch holds one of
+// spaghetti.ScoreInflight (= SS_SCORE_INFLIGHT = 3) slots from BEFORE its Submit until its Collect has returned, so that the
+// library never sees a fourth ticket: under sustained load batchLoop waits for a slot here (back-pressure) instead of being
+// refused with SS_ERR_STATE and falling back to synchronous calls.  The host's plan for batch i+1 and the copy-out of batch i-1
+// then run under the kernels of batch i (INTEGRATION.md §4).
 type inflight struct {
 	snap   *deviceIndex
 	ticket spaghetti.Ticket
 	batch  []*request
 }
 
-var flights = make(chan inflight, 2)
+var flights = make(chan inflight, spaghetti.ScoreInflight)
+
+// slots: one token per batch between Submit and the end of its Collect (see above)
+var slots = make(chan struct{}, spaghetti.ScoreInflight)
 
 // replyAll hands every request of a collected batch its hits; a panic on the way still leaves every waiter with a reply.
 func replyAll(batch []*request, hits [][]spaghetti.Hit) {
@@ -224,7 +229,16 @@ func collectLoop() {
 					}
 				}
 			}()
+			released := false
+			release := func() { // the ticket is spent whatever Collect did (a panic included): the next Submit may go ahead
+				if !released {
+					released = true
+					<-slots
+				}
+			}
+			defer release()
 			hits, err := f.snap.scorer.Collect(f.ticket)
+			release()
 			if err == nil {
 				replyAll(f.batch, hits)
 				answered = true
@@ -295,9 +309,11 @@ func batchLoop() {
 			}
 			// enqueue and move on; if the library refuses the batch as a whole, serve it request by request right here
 			qPtr, qTerms, pPtr, pTerms, qLen := concat(same)
+			slots <- struct{}{} // waits while ScoreInflight batches are between Submit and Collect
 			if t, err := snap.scorer.Submit(qPtr, qTerms, pPtr, pTerms, qLen, nil, topK); err == nil {
-				flights <- inflight{snap, t, same}
+				flights <- inflight{snap, t, same} // never blocks: the channel holds as many batches as there are slots
 			} else {
+				<-slots
 				serve(snap, same)
 			}
 			batch = rest

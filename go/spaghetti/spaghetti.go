@@ -109,6 +109,11 @@ func Job() JobInfo {
 //     never came up exits non-zero instead of hanging.
 func Default() *Ctx {
 	once.Do(func() {
+		// the header this package was compiled against and the library that got loaded must be the same ABI (4: submit / collect,
+		// late-completing ss_graph_create)
+		if v := int(C.ss_abi_version()); v != int(C.SS_ABI_VERSION) {
+			panic(fmt.Errorf("libspaghetti_rank: ABI version %d, this package was built against %d", v, int(C.SS_ABI_VERSION)))
+		}
 		var h *C.ss_ctx
 		check(nil, C.ss_init(0, &h), "ss_init")
 		global = &Ctx{h}
@@ -443,6 +448,10 @@ type Ticket struct {
 	id    C.uint64_t
 	nq, k int
 }
+
+// ScoreInflight is the number of submitted batches one scorer holds at a time (SS_SCORE_INFLIGHT): a further Submit is refused
+// with SS_ERR_STATE until one has been collected.
+const ScoreInflight = int(C.SS_SCORE_INFLIGHT)
 
 // Submit enqueues a batch of queries (pPtr / pTerms nil: no quoted phrases) and returns at once; up to C.SS_SCORE_INFLIGHT batches may be in flight.  A server
 // goroutine that has the next batch of requests ready calls Submit for it before it Collects the previous one: the host-side

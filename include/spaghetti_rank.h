@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 3
+/* 4 (round 5): ss_score_topk_submit / ss_score_topk_collect exist; ss_graph_create may return while its last build kernels
+ * still run on the context's stream (everything that reads the graph is ordered behind them); "score.pipeline" defaults to 2
+ * internal wave streams and ss_last_kernel_ms(1) is the device time of the last scoring call's kernels on the stream that
+ * carries its merge.  A binding checks ss_abi_version() == SS_ABI_VERSION at load. */
+#define SS_ABI_VERSION 4
 
 enum {
     SS_OK = 0,
@@ -46,7 +50,7 @@ enum {
 };
 
 #define SS_MAX_TOPK 1024     /* largest k accepted by ss_score_topk */
-#define SS_MAX_TOPICS 64     /* largest k_topics accepted */
+#define SS_MAX_TOPICS 64     /* largest k_topics accepted by every entry point (also by the opt-in two-vector form, "pr.affine") */
 #define SS_MAX_QUERY_TERMS 64
 #define SS_UNKNOWN_TERM 0xFFFFFFFFu /* term id for "key not found" (main_retrieve.go:193,218) */
 
@@ -327,8 +331,10 @@ int32_t ss_score_topk(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, const ui
                       ss_hit* hits_out, int32_t* n_hits_out);
 
 /* The same batch with results in HOST memory and several batches in flight (a server that has the next batch of requests
- * ready while this one runs): ss_score_topk_submit enqueues the batch and the copy of its hits to pinned host memory and
- * returns a ticket (never 0) without waiting; ss_score_topk_collect waits for THAT batch and writes hits_out [n_q][k],
+ * ready while this one runs): ss_score_topk_submit enqueues the batch into device buffers that belong to the ticket, records an event
+ * behind its kernels and returns the ticket (never 0) without waiting; ss_score_topk_collect waits for THAT batch's event, copies the
+ * rows to the caller (a plain device-to-host copy at collect time; option "score.collect_pinned" = 1 stages it through pinned
+ * memory) and writes hits_out [n_q][k],
  * n_hits_out [n_q] (host memory, the n_q and k of the submit).  Up to SS_SCORE_INFLIGHT tickets may be outstanding
  * (SS_ERR_STATE beyond); collect them in any order.  The host's plan for batch i+1 and its copy-out of batch i-1 run under the
  * kernels of batch i: 1024-query batches go host-to-host at the device's batch rate instead of one batch alone plus the copies. */

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "ss_last_kernel_ms": (_i32, [_vp, _i32, C.POINTER(C.c_float)]),
 }
 
+ABI_VERSION = 4   # SS_ABI_VERSION of include/spaghetti_rank.h this binding follows (tests/test_abi.py compares the two)
 _lib = None
 
 
@@ -129,6 +130,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.ss_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.ss_abi_version()}, this binding was written for {ABI_VERSION} "
+                          "(include/spaghetti_rank.h: SS_ABI_VERSION) - rebuild the library")
     _lib = lib
     return lib
 

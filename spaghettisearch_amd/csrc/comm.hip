@@ -48,11 +48,29 @@ int32_t comm_allreduce_f64_on(ss_ctx* ctx, const double* send, double* recv, siz
 // A collective that a rank never joins, or that runs over a dead link, never completes: the stream behind it never drains and a
 // plain hipStreamSynchronize turns a rendezvous mistake into a hang that only a watchdog ends.  Wherever the library itself waits
 // for a stream that may carry a collective it polls instead, for at most "comm.timeout_ms" (default 120 s), and then fails with
-// SS_ERR_COMM.  After such a time-out the device still holds the stuck work: `g_wedged` makes the memory pool and the sharded
-// loop's clean-up skip their device-wide waits (they would hang in turn), so that the error reaches the caller, who can report it
-// and end the process.
-static std::atomic<bool> g_wedged{false};
-bool device_wedged() { return g_wedged.load(std::memory_order_relaxed); }
+// SS_ERR_COMM.  After such a time-out THAT device still holds the stuck work: its bit in `g_wedged` makes the memory pool and the
+// sharded loop's clean-up skip their waits for that device (they would hang in turn), so that the error reaches the caller, who can
+// report it and end the process.  Other devices of the process (in-process shard groups, the tests' contexts) are not affected:
+// their blocks go back to the pool and their communicators are destroyed in the ordinary way (the flag used to be one
+// for the whole process and was never cleared).
+// The state is cleared again when the context whose wait timed out finds its streams drained after all (a slow rank that did
+// join in the end): try_unwedge, called by its next bounded wait and by ss_shutdown.
+static std::atomic<int> g_wedged[64];       // contexts with a timed-out wait, per device
+bool device_wedged(int device) { return device >= 0 && device < 64 && g_wedged[device].load(std::memory_order_relaxed) > 0; }
+static void mark_wedged(ss_ctx* ctx) {
+    if (!ctx->wedged && ctx->device >= 0 && ctx->device < 64) {
+        ctx->wedged = true;
+        g_wedged[ctx->device].fetch_add(1);
+    }
+}
+bool try_unwedge(ss_ctx* ctx) {
+    if (!ctx->wedged) return true;
+    for (hipStream_t st : {ctx->stream, ctx->comm_stream})
+        if (st && hipStreamQuery(st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    ctx->wedged = false;
+    g_wedged[ctx->device].fetch_sub(1);
+    return true;
+}
 
 int32_t sync_bounded(ss_ctx* ctx, hipStream_t st, const char* what) {
     if (!ctx->comm) {                                        // nothing on this context can wait for another rank
@@ -63,13 +81,13 @@ int32_t sync_bounded(ss_ctx* ctx, hipStream_t st, const char* what) {
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0;; spins++) {
         const hipError_t e = hipStreamQuery(st);
-        if (e == hipSuccess) return SS_OK;
+        if (e == hipSuccess) { (void)try_unwedge(ctx); return SS_OK; }
         (void)hipGetLastError();
         if (e != hipErrorNotReady) return ctx->fail(SS_ERR_HIP, "%s: hipStreamQuery -> %s", what, hipGetErrorString(e));
         if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));     // the first milliseconds: spin
         if ((spins & 255) == 255 &&
             std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) {
-            g_wedged.store(true);
+            mark_wedged(ctx);
             return ctx->fail(SS_ERR_COMM, "%s: rank %d of %d: the stream did not drain within %lld ms with a collective on it — a rank never "
                              "joined the collective or a link is down; this context cannot be used any more", what, ctx->comm_rank, ctx->comm_world,
                              (long long)timeout_ms);
@@ -180,7 +198,7 @@ int32_t ss_comm_destroy(ss_ctx* ctx) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ctx->comm) return SS_OK;
     (void)hipSetDevice(ctx->device);
-    const bool wedged = ss::device_wedged();                 // a collective timed out: nothing on the streams will ever finish
+    const bool wedged = ss::device_wedged(ctx->device);                 // a collective timed out: nothing on the streams will ever finish
     if (!wedged) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ctx->comm_stream);

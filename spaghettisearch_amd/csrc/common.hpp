@@ -43,6 +43,7 @@ struct ss_ctx {
     void* comm = nullptr;              // RCCL communicator of this rank (ss_comm_init), ncclComm_t
     void* comm_parent = nullptr;       // the communicator `comm` was split from (ss_comm_split)
     int comm_rank = 0, comm_world = 1;
+    bool wedged = false;               // a bounded wait of this context timed out (comm.hip: device_wedged / try_unwedge)
     // tuning / diagnostic options (ss_set_option); the defaults live at the point of use
     // Pinned host memory for what comes back from the device.  hipMemcpyAsync into PAGEABLE host memory pins the caller's page on
     // the fly — an mm-lock round trip that took 5-10 ms PER COPY on a loaded 256-core host (ss_graph_create: 7 ms on a quiet box,
@@ -224,9 +225,10 @@ inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) /
 int32_t comm_allgather(ss_ctx* ctx, const void* send, void* recv, size_t bytes);
 int32_t comm_allreduce_f64(ss_ctx* ctx, const double* send, double* recv, size_t count);
 // wait for a stream that may carry a collective: bounded by option "comm.timeout_ms" when the context has a communicator
-// (SS_ERR_COMM instead of a hang), a plain hipStreamSynchronize otherwise; device_wedged(): such a wait has timed out
+// (SS_ERR_COMM instead of a hang), a plain hipStreamSynchronize otherwise; device_wedged(dev): such a wait has timed out on that device
 int32_t sync_bounded(ss_ctx* ctx, hipStream_t st, const char* what);
-bool device_wedged();
+bool device_wedged(int device);
+bool try_unwedge(ss_ctx* ctx);      // the context's streams have drained after a timed-out wait: its device counts as usable again
 // the same on a given stream (the pipelined sharded sweep puts its exchanges on ctx->comm_stream)
 int32_t comm_allgather_on(ss_ctx* ctx, const void* send, void* recv, size_t bytes, hipStream_t st);
 int32_t comm_allreduce_f64_on(ss_ctx* ctx, const double* send, double* recv, size_t count, hipStream_t st);

@@ -71,7 +71,11 @@ static thread_local bool t_device_idle = false;     // pool_free_batch: one devi
 
 void pool_free_batch(void* const* blocks, size_t count) {
     if (!count) return;
-    if (device_wedged()) return;
+    {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (device_wedged(cur)) return;
+    }
     // (one device at a time: the blocks of a batch belong to one graph)
     (void)hipDeviceSynchronize();
     t_device_idle = true;
@@ -92,7 +96,7 @@ void pool_free(void* p) {
     }
     // hipFree waits for the device before the memory goes; the pool keeps that guarantee (work of ANY stream that still uses
     // the block is over before somebody else can get it) and saves the unmap / map that follows.
-    if (device_wedged()) return;                           // a collective timed out: any device-wide wait would hang; the process is on its way out
+    if (device_wedged(dev)) return;                        // a collective timed out on THIS device: a device-wide wait would hang; the block leaks
     if (cls && cls <= limit / 2) {                         // a block larger than half the limit is not worth holding
         int cur = 0;
         (void)hipGetDevice(&cur);
@@ -249,16 +253,17 @@ int32_t ss_init(int32_t device_id, ss_ctx** out) {
 
 int32_t ss_shutdown(ss_ctx* ctx) {
     if (!ctx) return SS_ERR_INVALID;
-    (void)ss_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    const bool stuck = !ss::try_unwedge(ctx);              // a collective timed out and its stream still has not drained: wait for nothing
+    (void)ss_comm_destroy(ctx);
+    if (!stuck) (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 3; k++)
         for (int j = 0; j < 2; j++)
             if (ctx->ev[k][j]) (void)hipEventDestroy(ctx->ev[k][j]);
-    if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
+    if (ctx->comm_stream && !stuck) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
     for (hipStream_t ws : ctx->wave_stream)
-        if (ws) { (void)hipStreamSynchronize(ws); (void)hipStreamDestroy(ws); }
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+        if (ws && !stuck) { (void)hipStreamSynchronize(ws); (void)hipStreamDestroy(ws); }
+    if (ctx->own_stream && !stuck) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (auto& b : ctx->pin_cache) (void)hipHostFree(b.p);
     delete ctx;
@@ -287,8 +292,9 @@ static const char* const k_option_names[] = {
     "pr.deal_snake",        // work items dealt to the waves in alternating direction (1) or least-loaded-first (0); default: 1 from 8 items per wave on and for k_pr_sweep_n
     "pr.affine",            // 1: ss_pagerank_run computes every topic from TWO vectors (the reference's topics differ only in their start value 1/n_k,
                             //    and its recurrence maps (p*u + q) / (r*u + s) onto itself): opt-in, not the reference's operation order (~1e-13)
-    "pr.stagger",           // 0: every block of k_pr_sweep walks the work classes in the same order; default 1: the resident blocks of a CU start at
-                            //    different classes (by arrival round); >= 10, experiments: 10 + the rounds' start classes as base-6 digits
+    "pr.class_order",       // k_pr_sweep: the order in which a wave walks its work classes, six decimal digits naming the classes 0 = long rows, 1 = mid rows, 2 / 3 / 4 = rows of <= 2 / 4 / 8 in-edges, 5 = edge-less rows (default 235401: short rows first)
+    "pr.stagger",           // default 0: every block of k_pr_sweep walks the work classes in the same order ("pr.class_order"); 1: the resident blocks of a CU
+                            //    start at different positions of it (by arrival round; round 4's default); >= 10: 10 + the rounds' start positions as base-6 digits
     "pr.deal_global",       // 0: the work items are dealt chunk by chunk in table order, each chunk sorted by cost (before round 4); 1: all items by
                             //    falling cost first (one counting sort; default for k_pr_sweep_n<1>); 2: by falling cost inside each class, the classes in
                             //    table order (default for k_pr_sweep and k_pr_sweep_n<2>)
@@ -316,8 +322,9 @@ static const char* const k_option_names[] = {
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
     "score.wave_big_pct",   // graded slices: this share of a batch's postings goes into slices of wave_big_x100 % of the target, the rest into wave_small_x100 % (defaults 92 / 115 / 60; 0 = one size)
     "score.wave_big_x100",
-    "score.pipeline",       // 0: every scoring kernel on the context's stream.  Default 1: device-output batches that are all k_score_wave run k_wave_prep and
-                            //    k_score_wave on an internal stream and only k_merge_flat (behind an event) on the context's stream: the next batch's
+    "score.pipeline",       // 0: every scoring kernel on the context's stream.  n >= 1: device-output batches that are all k_score_wave run k_wave_prep and
+                            //    k_score_wave on one of n internal streams taken in turn (default 2, as include/spaghetti_rank.h says; at most 3) and
+                            //    only k_merge_flat (behind an event) on the context's stream: the next batch's
                             //    k_score_wave starts under this batch's merge, and the hits are complete in stream order as before
     "score.grade_slices",   // 1: k_score_slices' slices are graded the same way (default 0)
     "score.wave_small_x100",

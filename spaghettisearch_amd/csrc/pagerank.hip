@@ -118,7 +118,8 @@ struct PrParams {
     uint32_t zrow;            // index of the table's all-zero row (= nd_int): where the unused slots of a chunk gather from
     const uint32_t* woff;     // k_pr_sweep: [waves][8]: wave w's items of class c are work[woff[8w+c] .. woff[8w+c+1])
     uint32_t stagger_div;     // k_pr_sweep: blocks per arrival round (= CUs); 0 = every block walks the classes in the same order
-    uint32_t stagger_code;    // experiments: start classes of the rounds as base-6 digits (0 = round r starts at class r)
+    uint32_t stagger_code;    // start classes of the rounds as base-6 digits (0 = round r starts at position r of the class order)
+    uint32_t class_order;     // k_pr_sweep: the order in which a wave walks its six work classes, 3 bits per position
     double* x_alt;            // two-vector form: sweep s reads x (s even) / x_alt (s odd) and writes the other one; null otherwise
     AffCtl* aff;              // two-vector form ("pr.affine"): its control block; null otherwise
     const double* tele_col;   // ... and the per-column teleport (ctl->tele); null = the uniform p.teleport
@@ -799,6 +800,11 @@ __device__ __forceinline__ void deg_rows(SweepCtx<GW, TS>& c, const WorkItem* __
     }
 }
 
+#ifdef SS_PR_EXP_KINDMASK
+#define SS_PR_CLASS_ON(c) ((p.kind_mask >> (8 + (c))) & 1u)
+#else
+#define SS_PR_CLASS_ON(c) true
+#endif
 #ifndef SS_PR_MINW
 #define SS_PR_MINW 1
 #endif
@@ -828,16 +834,13 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
     // gets the same number of turns (ss_pr_create); one loop per class, so that the register allocator sees each
     // pipeline on its own instead of the union of all of them.
     const uint32_t* __restrict__ off = p.woff + (size_t)(blockIdx.x * WAVES + wave) * 8;
-#ifdef SS_PR_EXP_KINDMASK
-#define SS_PR_CLASS_ON(c) ((p.kind_mask >> (8 + (c))) & 1u)
-#else
-#define SS_PR_CLASS_ON(c) true
-#endif
-    // The resident blocks of a CU start at DIFFERENT classes: block index / CUs is the block's arrival round on its CU (the hardware
-    // places the grid's first <CUs> blocks one per CU, then the next <CUs> ...), and round r walks the classes from class r on, so
-    // that a CU — and the memory system behind it — sees the long rows' index streams, the mid rows and the short rows' gathers side
-    // by side instead of one access pattern at a time: 0.932-0.934 ms per sweep at config 4 against 0.957-0.961 in class order
-    // everywhere (rotating per wave or per block index, or permuting the class order: 0.96-0.99; option "pr.stagger" = 0: off).
+    // The ORDER in which a wave walks its classes matters more than anything tried on the deal (round 5: all 720 orders, 4 blocks per
+    // CU, config 4): short rows first, long rows last — 2, 3, 5, 4, 0, 1 = rows of <= 2 in-edges, <= 4, edge-less, <= 8, long, mid —
+    // 0.902-0.904 ms per sweep against 0.947 in the order the classes are numbered (worst order 0.961).  Round 4's "stagger" (the
+    // resident blocks of a CU start at different positions of the order: option "pr.stagger", now off by default) had found a part
+    // of this by accident — its best start vectors were the ones that began most blocks at the short rows —; on top of the best
+    // orders no start vector gains anything (every vector of 1296 measured for the best four orders: the all-equal one wins).
+    // The loop below walks the order; "pr.class_order" = six digits, "pr.stagger" as before.
     int rot = p.stagger_div ? (int)((blockIdx.x / p.stagger_div) % 6u) : 0;
     if (p.stagger_code) {                       // experiments ("pr.stagger" >= 10): round r starts at base-6 digit r of the code
         uint32_t cdv = p.stagger_code;
@@ -845,7 +848,16 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
         rot = (int)(cdv % 6u);
     }
     for (int s6 = 0; s6 < 6; s6++) {
-    const int cls = (s6 + rot) % 6;
+    const int cls = (int)((p.class_order >> (3 * ((s6 + rot) % 6))) & 7u);
+    {
+        // everything a class pipeline derives from the lane id is recomputed behind an opaque copy per round: hoisted out of this loop,
+        // the per-lane invariants of all six pipelines were live at once (164 VGPRs = 3 waves per SIMD instead of 114 = 4)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        c.t = ln % GW;
+        c.gbase = ln - ln % GW;
+        c.slot = ln / GW;
+    }
     switch (cls) {
     case 0: if (SS_PR_CLASS_ON(0)) long_rows<GW>(c, p.work, off[0], off[1], lane); break;
     case 1: if (SS_PR_CLASS_ON(1)) quad_rows<GW>(c, p.work, off[1], off[2]); break;
@@ -1021,6 +1033,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
     const uint32_t* __restrict__ in_src = p.in_src;
 
     // ---- V_SEG / V_ROWW: the wave strides the row's (piece's) edges, four gathers per lane in flight
+    if (SS_PR_CLASS_ON(0))
     for (uint32_t it = off[0]; it < off[1]; it++) {
         const WorkItem w = p.work[it];
         const uint32_t lrow = w.row;
@@ -1087,6 +1100,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
     // ---- V_QUAD: one row per 8-lane group; the rows of an item are all nch 16-edge turns long
     {
         const int gl = lane & 7, grp = lane >> 3;
+        if (SS_PR_CLASS_ON(1))
         for (uint32_t it = off[1]; it < off[2]; it++) {
             const WorkItem w = p.work[it];
             const uint32_t nq = (w.count + 7) / 8;
@@ -1133,6 +1147,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
     }
 
     // ---- V_DEG (all three classes): rows of exactly D <= 8 in-edges, their edges contiguous from item.beg: one lane per row
+    if (SS_PR_CLASS_ON(2))
     for (uint32_t it = off[2]; it < off[5]; it++) {
         const WorkItem w = p.work[it];
         if (w.nseg <= 2) deg_lane_rows<KW, TS, 2>(c, w, lane);          // (wave-uniform: most rows of a power-law graph)
@@ -1141,6 +1156,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
     }
 
     // ---- V_ZERO: non-dangling rows without in-edges: their rank is the shared value, only the next contribution is written
+    if (SS_PR_CLASS_ON(5))
     for (uint32_t it = off[5]; it < off[6]; it++) {
         const WorkItem w = p.work[it];
         for (uint32_t r0 = 0; r0 < w.count; r0 += 64) {
@@ -2150,8 +2166,21 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     p.pos_d = pos_d;
     p.zrow = (uint32_t)g->nd_int;
     p.woff = pr->woff.p;
-    p.stagger_div = ctx->opt("pr.stagger", 1) != 0 ? (uint32_t)std::max(ctx->cu_count, 1) : 0u;
-    p.stagger_code = ctx->opt("pr.stagger", 1) >= 10 ? (uint32_t)(ctx->opt("pr.stagger", 1) - 10) : 0u;
+    p.stagger_div = ctx->opt("pr.stagger", 0) != 0 ? (uint32_t)std::max(ctx->cu_count, 1) : 0u;
+    p.stagger_code = ctx->opt("pr.stagger", 0) >= 10 ? (uint32_t)(ctx->opt("pr.stagger", 0) - 10) : 0u;
+    {
+        // "pr.class_order": six decimal digits, position by position (012345 = long rows, mid rows, the three short-row classes,
+        // edge-less rows); anything that is not a permutation of 0..5 falls back to that order
+        int64_t code = ctx->opt("pr.class_order", 235401);
+        uint32_t packed = 0, seen = 0;
+        for (int pos = 5; pos >= 0; pos--) {
+            const uint32_t c = (uint32_t)(code % 10);
+            code /= 10;
+            packed |= (c & 7u) << (3 * pos);
+            if (c < 6) seen |= 1u << c;
+        }
+        p.class_order = seen == 0x3Fu ? packed : (0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u << 15);
+    }
 #ifdef SS_PR_EXP_KINDMASK
     p.kind_mask = getenv("SS_PR_KIND_MASK") ? (uint32_t)strtoul(getenv("SS_PR_KIND_MASK"), nullptr, 0) : 0xFFFFFFFFu;
     {
@@ -2267,7 +2296,7 @@ int32_t ss_pr_destroy(ss_pr* pr) {
     ss_ctx* ctx = pr->g->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
-    if (!ss::device_wedged()) {
+    if (!ss::device_wedged(ctx->device)) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ctx->comm_stream);
     }
@@ -2392,7 +2421,7 @@ int32_t run_pipelined(ss_ctx* ctx, std::vector<ShardBlocks>& sh, int32_t max_ite
         SS_HIP(ctx, hipEventCreateWithFlags(&ev_xchg[b], hipEventDisableTiming));
     }
     auto cleanup = [&] {
-        if (!ss::device_wedged()) {                       // (after a timed-out collective neither stream will ever drain)
+        if (!ss::device_wedged(ctx->device)) {                       // (after a timed-out collective neither stream will ever drain)
             (void)hipStreamSynchronize(xs);
             (void)hipStreamSynchronize(cs);
         }

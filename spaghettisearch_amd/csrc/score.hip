@@ -1427,6 +1427,7 @@ struct ss_scorer {
         size_t pin_cap = 0;
         bool pin_mode = false;
         uint64_t ticket = 0;                 // 0 = free
+        bool collecting = false;             // a collect call is waiting for / copying this slot outside the lock
         int32_t n_q = 0, k = 0;
     } aslot[INFLIGHT];
     uint64_t next_ticket = 1;
@@ -1684,45 +1685,61 @@ int32_t ss_score_topk_collect(ss_scorer* s, uint64_t ticket, ss_hit* hits_out, i
     if (!s) return SS_ERR_INVALID;
     ss_ctx* ctx = s->ctx;
     ss_scorer::AsyncSlot* a = nullptr;
+    // everything the unlocked part needs is read HERE, under the context's lock: the options map, the slot's fields and the scorer's
+    // stream may be written by a thread that submits or sets an option meanwhile (ctx->opt() is an unlocked map lookup)
+    bool trace = false, pin_mode = false;
+    int32_t n_q = 0, k = 0;
+    hipEvent_t ev = nullptr;
+    hipStream_t out_stream = nullptr;
+    const ss_hit* d_hits = nullptr;
+    const int32_t* d_n = nullptr;
+    void* pin = nullptr;
     {
         std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         if (!hits_out || !n_hits_out) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_collect: NULL output");
         for (auto& c : s->aslot)
-            if (ticket && c.ticket == ticket) { a = &c; break; }
+            if (ticket && c.ticket == ticket && !c.collecting) { a = &c; break; }
         if (!a) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_collect: no batch in flight with ticket %llu", (unsigned long long)ticket);
         SS_HIP(ctx, hipSetDevice(ctx->device));
+        a->collecting = true;                   // (a second collect of the same ticket from another thread is refused, not raced)
+        trace = ctx->opt("score.trace", 0) != 0;
+        pin_mode = a->pin_mode;
+        n_q = a->n_q; k = a->k; ev = a->ev; out_stream = s->out_stream;
+        d_hits = a->hits.p; d_n = a->n_hits.p; pin = a->pin;
     }
-    // (the wait and the copies run outside the context's lock: another thread may submit the next batch meanwhile)
-    if (a->n_q) {
-        const bool trace = ctx->opt("score.trace", 0) != 0;
+    // (the wait and the copies run outside the context's lock: another thread may submit the next batch meanwhile; the slot itself
+    // stays this call's until its ticket is cleared below)
+    if (n_q) {
         const auto tw0 = std::chrono::steady_clock::now();
-        hipError_t e = hipEventSynchronize(a->ev);
+        hipError_t e = hipEventSynchronize(ev);
         const auto tw1 = std::chrono::steady_clock::now();
-        const size_t rows = (size_t)a->n_q * (size_t)a->k;
-        const size_t hb = rows * sizeof(ss_hit), nb = (size_t)a->n_q * sizeof(int32_t);
-        if (a->pin_mode) {
+        const size_t rows = (size_t)n_q * (size_t)k;
+        const size_t hb = rows * sizeof(ss_hit), nb = (size_t)n_q * sizeof(int32_t);
+        if (pin_mode) {
             // through the slot's pinned block on the copy engine, then a host memcpy
-            if (e == hipSuccess) e = hipMemcpyAsync(a->pin, a->hits.p, hb, hipMemcpyDeviceToHost, s->out_stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(static_cast<unsigned char*>(a->pin) + hb, a->n_hits.p, nb, hipMemcpyDeviceToHost, s->out_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(s->out_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(pin, d_hits, hb, hipMemcpyDeviceToHost, out_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(static_cast<unsigned char*>(pin) + hb, d_n, nb, hipMemcpyDeviceToHost, out_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(out_stream);
             if (e == hipSuccess) {
-                std::memcpy(hits_out, a->pin, hb);
-                std::memcpy(n_hits_out, static_cast<unsigned char*>(a->pin) + hb, nb);
+                std::memcpy(hits_out, pin, hb);
+                std::memcpy(n_hits_out, static_cast<unsigned char*>(pin) + hb, nb);
             }
         } else {
-            if (e == hipSuccess) e = hipMemcpy(hits_out, a->hits.p, hb, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(n_hits_out, a->n_hits.p, nb, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(hits_out, d_hits, hb, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(n_hits_out, d_n, nb, hipMemcpyDeviceToHost);
         }
         if (trace) fprintf(stderr, "[score trace] collect: waited %.0f us for the batch, copies %.0f us\n", std::chrono::duration<double, std::micro>(tw1 - tw0).count(),
                            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count());
         if (e != hipSuccess) {
             std::lock_guard<std::recursive_mutex> lk(ctx->mu);
             a->ticket = 0;
+            a->collecting = false;
             return ctx->fail(SS_ERR_HIP, "ss_score_topk_collect: %s", hipGetErrorString(e));
         }
     }
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     a->ticket = 0;
+    a->collecting = false;
     return SS_OK;
 }
 

@@ -809,6 +809,10 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
         if (n_staged == 0x12345678u) out[0] = L_rec[0];
         continue;
 #endif
+#if defined(SS_EXP_SC) && SS_EXP_SC == 4      // ... the stores as one coalesced stream (what perfectly joined bucket runs would cost)
+        for (uint32_t pos = threadIdx.x; pos < n_staged; pos += SC_TPB) out[base + pos] = L_rec[pos];
+        continue;
+#endif
         for (uint32_t pos = threadIdx.x; pos < n_staged; pos += SC_TPB) {
             const uint2 r = L_rec[pos];
             const uint32_t b = r.x >> shift;

@@ -124,6 +124,19 @@ def init_lib_comm(ctx, rank: int, world: int, group=None) -> None:
     ctx.comm_init(box[0], rank, world)
 
 
+def topic_group_layout(rank: int, world: int, groups: int, k_topics: int):
+    """The 2-D decomposition of the sharded PageRank (include/spaghetti_rank.h: ss_comm_split): `groups` topic groups x
+    world/groups doc shards.  Rank r belongs to topic group `color` = r % groups and is doc shard `key` = r // groups of it
+    (so that the shards of one group sit `groups` ranks apart: with 8 ranks and 2 groups, group 0 = ranks 0, 2, 4, 6);
+    its group runs topics [lo, hi) on a graph sharded world/groups ways.
+    -> (color, key, shards, lo, hi).  bench.py --gpus N and tests/test_gpu_world8.py take the layout from here."""
+    if groups < 1 or world % groups or k_topics % groups:
+        raise ValueError(f"{groups} topic groups do not divide world {world} / {k_topics} topics")
+    color, key, shards = rank % groups, rank // groups, world // groups
+    per = k_topics // groups
+    return color, key, shards, color * per, (color + 1) * per
+
+
 class LocalExchange:
     """All shards live in ONE process (tests on a single GPU / CPU): plays the all-gather by copies."""
 

@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"not exported: {missing}"
     # the Python binding covers exactly the declared set
     assert sorted(_lib.PROTOTYPES) == declared_symbols()
-    assert _lib.load().ss_abi_version() == 3
+    header_abi = int(re.search(r"#define SS_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert _lib.load().ss_abi_version() == header_abi == _lib.ABI_VERSION == 4
 
 
 def test_no_cpu_fallback_without_device():
@@ -72,4 +73,4 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
                     "-lspaghetti_rank", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
-    assert out.startswith("abi=3 init=")
+    assert out.startswith("abi=4 init=")

@@ -39,7 +39,7 @@ def _worker(rank, world, port, n, e, n_topic, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_two_process_gloo_matches_oracle(tmp_path, world):
     n, e = 4000, 22000
     n_topic = synth.topic_sizes(n, 4)
@@ -95,7 +95,7 @@ def _worker_pipelined(rank, world, port, n, e, n_topic, sweeps, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_pipelined_topic_blocks_gloo_match_oracle(tmp_path, world):
     # two topic blocks per rank, the all-gather of one block in flight while the other block is swept
     n, e, sweeps = 3000, 16000, 6
@@ -140,7 +140,7 @@ def _worker_affine(rank, world, port, n, e, n_topic, eps, max_iter, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_two_vector_form_on_gloo_shards_matches_oracle(tmp_path, world):
     """The sharded two-vector protocol (a 2-column exchange and an all-gather of the ranks' K local L1 sums per iteration, stop
     rule from the sums added in rank order) between real processes: every topic's ranks and iteration count as the oracle's."""
@@ -153,3 +153,19 @@ def test_two_vector_form_on_gloo_shards_matches_oracle(tmp_path, world):
         ref, ref_iters = pyoracle.pagerank(n, ptr, dst, D, eps, n_topic, max_iter=max_iter)
         assert got["iters"].tolist() == ref_iters.tolist()
         np.testing.assert_allclose(got["rank"], ref, rtol=1e-12)
+
+
+def test_topic_group_layout_at_world_8():
+    """bench.py's 2-D variants at 8 ranks (ss_comm_split(color, key)): 2 x 4 and 4 x 2 — every (group, shard) pair exactly once,
+    a group's ranks `groups` apart, the groups' topic ranges a partition of the 16 topics."""
+    for G in (1, 2, 4, 8):
+        lay = [sharding.topic_group_layout(r, 8, G, 16) for r in range(8)]
+        assert sorted((c, k) for c, k, *_ in lay) == [(c, k) for c in range(G) for k in range(8 // G)]
+        assert all(s_ == 8 // G and hi - lo == 16 // G for _, _, s_, lo, hi in lay)
+        for c in range(G):
+            members = [r for r in range(8) if lay[r][0] == c]
+            assert members == list(range(c, 8, G)) and [lay[r][1] for r in members] == list(range(8 // G))
+        assert sorted({(lo, hi) for *_, lo, hi in lay}) == [(i * 16 // G, (i + 1) * 16 // G) for i in range(G)]
+    for bad in ((8, 3, 16), (8, 2, 15), (6, 4, 16)):
+        with pytest.raises(ValueError):
+            sharding.topic_group_layout(0, *bad)

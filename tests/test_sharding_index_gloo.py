@@ -60,7 +60,7 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_doc_sharded_index_gloo_matches_unsharded_oracle(tmp_path, world):
     out = str(tmp_path / "out.npz")
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)

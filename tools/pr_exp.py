@@ -11,17 +11,25 @@ kt = int(os.environ.get("K", "16"))
 out_ptr, out_dst = synth.rmat_graph_torch(n, e, seed=42, device=dev)
 if os.environ.get("SNAKE"): ctx.set_option("pr.deal_snake", int(os.environ["SNAKE"]))
 g = engine.Graph(ctx, n, out_ptr, out_dst)
-pr = engine.PageRankState(g, 0.75, -1.0, synth.topic_sizes(n, kt), max_iter=0)
-if os.environ.get("TS"):      # opt-in topic-sensitive teleport: topic k teleports to a random 1/16 of the nodes
-    rng = np.random.default_rng(3)
-    pr.set_teleport([rng.choice(n, size=n // 16, replace=False).astype(np.uint32) for _ in range(kt)])
-pr.begin()
-pr.step(5)
-ms = []
-for _ in range(int(os.environ.get("R", "7"))):
-    pr.step(20)
-    ctx.synchronize()
-    ms.append(ctx.last_kernel_ms(0) / 20)
-probe = [pr.probe(m, 5) for m in (0, 1, 2)] if kt >= 5 else []
-print(f"lib={os.path.basename(os.environ.get('SS_LIB_PATH', 'product'))} N={n} E={e} K={kt}: sweep median {statistics.median(ms):.4f} ms  min {min(ms):.4f} ms  probe {probe}", flush=True)
-pr.close(); g.close(); ctx.close()
+def run(tag):
+    pr = engine.PageRankState(g, 0.75, -1.0, synth.topic_sizes(n, kt), max_iter=0)
+    if os.environ.get("TS"):      # opt-in topic-sensitive teleport: topic k teleports to a random 1/16 of the nodes
+        rng = np.random.default_rng(3)
+        pr.set_teleport([rng.choice(n, size=n // 16, replace=False).astype(np.uint32) for _ in range(kt)])
+    pr.begin()
+    pr.step(5)
+    ms = []
+    for _ in range(int(os.environ.get("R", "7"))):
+        pr.step(20)
+        ctx.synchronize()
+        ms.append(ctx.last_kernel_ms(0) / 20)
+    probe = [pr.probe(m, 5) for m in (0, 1, 2)] if kt >= 5 and not tag else []
+    print(f"lib={os.path.basename(os.environ.get('SS_LIB_PATH', 'product'))} N={n} E={e} K={kt} {tag}: sweep median {statistics.median(ms):.4f} ms  min {min(ms):.4f} ms  probe {probe}", flush=True)
+    pr.close()
+# OPTSETS="pr.stagger=0;pr.stagger=1,pr.blocks_per_cu=3": one timing per ';'-separated option set (options reset in between)
+for oset in os.environ.get("OPTSETS", "").split(";"):
+    kv = [x.split("=") for x in oset.split(",") if x]
+    for k, v in kv: ctx.set_option(k, int(v))
+    run(oset)
+    for k, v in kv: ctx.set_option(k, None)
+g.close(); ctx.close()
