@@ -52,7 +52,7 @@ struct PrCtl {
     int32_t sweep;        // sweeps completed
     int32_t n_active;
     uint32_t ticket;      // last-group arrival counter
-    uint32_t pad;
+    uint32_t stuck;       // k_pr_multi_n: a wait between two sweeps ran out of patience (the grid was not resident): the state is void
     uint32_t gticket[8];  // last-block-of-a-group arrival counters
 };
 
@@ -154,6 +154,21 @@ __device__ __forceinline__ double zero_row_rank_ts(const PrParams& p, int sweep,
     return ((sweep == 0 ? x0 : 0.0) + tele) / S;
 }
 
+// The control block as the persistent multi-sweep kernel (k_pr_multi_n) needs it: written by the last block of sweep i, read by every
+// block of sweep i + 1 INSIDE one launch, i.e. across CUs and XCDs with no kernel boundary in between — write-through stores and
+// L1-bypassing loads (sc1; scalar loads would come from the never-refreshed scalar cache).  The one-sweep kernels use plain accesses.
+template <int PS, typename T>
+__device__ __forceinline__ T ctl_ld(const T* q) {
+    if constexpr (PS) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *q;
+}
+template <int PS, typename T>
+__device__ __forceinline__ void ctl_st(T* q, T v) {
+    if constexpr (PS) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *q = v;
+}
+
+template <int PS = 0>
 __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl, const double* cs, bool is_begin) {
     PrCtl* ctl = p.ctl;
     if (p.aff) {
@@ -221,35 +236,42 @@ __device__ __forceinline__ void finalize_ctl(const PrParams& p, const double* dl
         ctl->n_active = p.k_topics;
         return;
     }
-    const int it = ctl->sweep + 1;
+    const int sw = ctl_ld<PS>(&ctl->sweep);
+    const int it = sw + 1;
     int na = 0;
     for (int k = 0; k < p.k_topics; k++) {
-        if (ctl->active[k]) {
-            ctl->iters[k] = it;
-            ctl->delta[k] = dl[k];                          // includes the rows without in-edges (added by the caller)
+        if (ctl_ld<PS>(&ctl->active[k])) {
+            const double Sk = ctl_ld<PS>(&ctl->S[k]);
+            ctl_st<PS>(&ctl->iters[k], it);
+            ctl_st<PS>(&ctl->delta[k], dl[k]);              // includes the rows without in-edges (added by the caller)
             if (p.memb && ((p.ts_mask >> k) & 1u)) {
-                ctl->xz[k] = zero_row_rank_ts(p, ctl->sweep, ctl->S[k], p.x0[k], 0.0);
-                ctl->xz_in[k] = zero_row_rank_ts(p, ctl->sweep, ctl->S[k], p.x0[k], p.tin[k]);
+                ctl_st<PS>(&ctl->xz[k], zero_row_rank_ts(p, sw, Sk, p.x0[k], 0.0));
+                ctl_st<PS>(&ctl->xz_in[k], zero_row_rank_ts(p, sw, Sk, p.x0[k], p.tin[k]));
             } else {
-                ctl->xz[k] = zero_row_rank(p, ctl->sweep, ctl->S[k], p.x0[k]);
-                ctl->xz_in[k] = ctl->xz[k];
+                const double xz = zero_row_rank(p, sw, Sk, p.x0[k]);
+                ctl_st<PS>(&ctl->xz[k], xz);
+                ctl_st<PS>(&ctl->xz_in[k], xz);
             }
             bool cont = dl[k] > p.eps;                      // pagerank.go:93
             if (p.max_iter > 0 && it >= p.max_iter) cont = false;
-            ctl->active[k] = cont ? 1 : 0;
+            ctl_st<PS>(&ctl->active[k], cont ? 1 : 0);
             na += cont ? 1 : 0;
-            ctl->S[k] = cs[k] + p.tele_n;                   // pagerank.go:111-112
-            ctl->csum[k] = cs[k];
+            ctl_st<PS>(&ctl->S[k], cs[k] + p.tele_n);       // pagerank.go:111-112
+            ctl_st<PS>(&ctl->csum[k], cs[k]);
         }
     }
-    ctl->sweep = it;
-    ctl->n_active = na;
+    ctl_st<PS>(&ctl->n_active, na);
+    if constexpr (PS) {
+        // `sweep` is what the other blocks poll between two sweeps: it goes last, behind everything else this thread has stored
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    ctl_st<PS>(&ctl->sweep, it);
 }
 
 // Block partial -> global partials; the last block to arrive sums all partials in a
 // fixed order and either finalises the control block (world==1) or leaves this
 // rank's totals in the tail rows of the send buffer (world>1).
-template <int GW>
+template <int GW, int PS = 0>
 __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, double dsum, double csum, double* tail,
                                                          bool is_begin) {
     __shared__ double red[WAVES][2][MAXK];
@@ -289,6 +311,12 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
     const unsigned members = (gridDim.x - grp + ng - 1) / ng;         // blocks b = grp, grp + ng, ...
     double* const gpart = p.partials + (size_t)gridDim.x * NCOL;      // [NG][NCOL] behind the block rows
     if (threadIdx.x == 0) {
+        if constexpr (PS == 2) {
+            // fence form of k_pr_multi_n: this block's table and rank stores (plain: they stay in the XCD's L2 for its own gathers) are
+            // written back before the block counts as arrived; the wait behind the fence is spelled out (ROCm 7.2 can drop the fence's own)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const unsigned prev = __hip_atomic_fetch_add(&p.ctl->gticket[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev == members - 1;
     }
@@ -316,10 +344,10 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
         for (int q = 0; q < NPART; q++) v += colsum[q * NCOL + threadIdx.x];
         __hip_atomic_store(&gpart[(size_t)grp * NCOL + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (threadIdx.x == 0) ctl_st<PS>(&p.ctl->gticket[grp], 0u);       // every member has arrived: ready for the next sweep (drained below, in front of this block's ticket)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        p.ctl->gticket[grp] = 0;                                      // ready for the next launch (kernel boundary)
         const unsigned prev = __hip_atomic_fetch_add(&p.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev == ng - 1;
     }
@@ -333,17 +361,17 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
     }
     __syncthreads();
     // rows without in-edges: all equal, so their L1 change is count * |new - old| (not streamed, see zero_row_rank)
-    if (!is_begin && threadIdx.x < GW && p.ctl->active[threadIdx.x]) {
+    if (!is_begin && threadIdx.x < GW && ctl_ld<PS>(&p.ctl->active[threadIdx.x])) {
         const double n_zero = (double)((p.cnt_nd - p.pos_nd) + (p.cnt_d - p.pos_d));
         if (p.memb && ((p.ts_mask >> threadIdx.x) & 1u)) {
             // two values per topic: inside and outside the teleport set
             const int k = threadIdx.x;
-            const double out_new = zero_row_rank_ts(p, p.ctl->sweep, p.ctl->S[k], p.x0[k], 0.0);
-            const double in_new = zero_row_rank_ts(p, p.ctl->sweep, p.ctl->S[k], p.x0[k], p.tin[k]);
-            tot[0][k] += (n_zero - p.nz_in[k]) * fabs(out_new - p.ctl->xz[k]) + p.nz_in[k] * fabs(in_new - p.ctl->xz_in[k]);
+            const double out_new = zero_row_rank_ts(p, ctl_ld<PS>(&p.ctl->sweep), ctl_ld<PS>(&p.ctl->S[k]), p.x0[k], 0.0);
+            const double in_new = zero_row_rank_ts(p, ctl_ld<PS>(&p.ctl->sweep), ctl_ld<PS>(&p.ctl->S[k]), p.x0[k], p.tin[k]);
+            tot[0][k] += (n_zero - p.nz_in[k]) * fabs(out_new - ctl_ld<PS>(&p.ctl->xz[k])) + p.nz_in[k] * fabs(in_new - ctl_ld<PS>(&p.ctl->xz_in[k]));
         } else {
-            const double xz_new = zero_row_rank(p, p.ctl->sweep, p.ctl->S[threadIdx.x], p.x0[threadIdx.x]);
-            tot[0][threadIdx.x] += n_zero * fabs(xz_new - p.ctl->xz[threadIdx.x]);
+            const double xz_new = zero_row_rank(p, ctl_ld<PS>(&p.ctl->sweep), ctl_ld<PS>(&p.ctl->S[threadIdx.x]), p.x0[threadIdx.x]);
+            tot[0][threadIdx.x] += n_zero * fabs(xz_new - ctl_ld<PS>(&p.ctl->xz[threadIdx.x]));
         }
     }
     __syncthreads();
@@ -354,8 +382,8 @@ __device__ __forceinline__ void block_reduce_and_publish(const PrParams& p, doub
                 dl[k] = k < GW ? tot[0][k] : 0.0;
                 cs[k] = k < GW ? tot[1][k] : 0.0;
             }
-            finalize_ctl(p, dl, cs, is_begin);
-            p.ctl->ticket = 0;
+            ctl_st<PS>(&p.ctl->ticket, 0u);                          // (in front of finalize_ctl: its last store releases the next sweep)
+            finalize_ctl<PS>(p, dl, cs, is_begin);
         }
     } else {
         // tail rows of this rank's all-gather piece: row sl_nd-2 = contribution sums, row sl_nd-1 = deltas
@@ -924,10 +952,16 @@ __global__ __launch_bounds__(TPB, SS_PR_MINW) void k_pr_sweep(PrParams p) {
 #endif
 template <int KW>
 struct NVec { double v[KW]; };
-template <int KW>
+// PS (k_pr_multi_n: several sweeps inside one launch): the table row was written by another CU earlier in this launch, so it is read
+// with L1-bypassing sc1 loads (and stored write-through, tab_store below) instead of relying on a kernel boundary
+template <int KW, int PS = 0>
 __device__ __forceinline__ NVec<KW> ntab(const double* __restrict__ T, uint32_t row) {
     NVec<KW> r;
-    if constexpr (KW == 1) {
+    if constexpr (PS == 1) {
+        const double* q = reinterpret_cast<const double*>(reinterpret_cast<const char*>(T) + (size_t)(row * (8u * KW)));
+#pragma unroll
+        for (int k = 0; k < KW; k++) r.v[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (KW == 1) {
         r.v[0] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(T) + (size_t)(row * 8u));
     } else {
         const double2 t = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(T) + (size_t)(row * 16u));
@@ -935,6 +969,11 @@ __device__ __forceinline__ NVec<KW> ntab(const double* __restrict__ T, uint32_t 
         r.v[1] = t.y;
     }
     return r;
+}
+template <int PS>
+__device__ __forceinline__ void tab_store(double v, double* q) {
+    if constexpr (PS == 1) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else NT_STORE(v, q);
 }
 template <int KW, bool TS>
 struct NCtx {
@@ -946,7 +985,9 @@ struct NCtx {
     const double* __restrict__ xr;      // ranks before this sweep
     double* __restrict__ xw;            // ... and after it (the same array, except in the two-vector form: PrParams::x_alt)
 };
-template <int KW, bool TS>
+// XS: also the row's RANK is stored write-through — the rows that are cut into pieces (V_SEG) are finished by whichever wave hands its
+// piece in last, a different wave (and CU) from sweep to sweep, so inside k_pr_multi_n their ranks are handed from CU to CU like the table
+template <int KW, bool TS, int PS = 0, bool XS = false>
 __device__ __forceinline__ void finish_n(NCtx<KW, TS>& c, uint32_t lrow, const NVec<KW>& y, const NVec<KW>& xo, uint32_t od) {
     const PrParams& p = c.p;
 #pragma unroll
@@ -957,14 +998,15 @@ __device__ __forceinline__ void finish_n(NCtx<KW, TS>& c, uint32_t lrow, const N
         double xn = (yk + tele) / c.S[k];                         // pagerank.go:117
         const size_t xi = (size_t)lrow * KW + k;
         if (c.act[k]) {
-            NT_STORE(xn, &c.xw[xi]);
+            if constexpr (XS) __hip_atomic_store(&c.xw[xi], xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else NT_STORE(xn, &c.xw[xi]);
             c.dsum[k] += fabs(xn - xo.v[k]);                      // pagerank.go:118
         } else {
             xn = xo.v[k];                                         // converged topic: frozen
         }
         if (lrow < p.sl_nd) {                                     // non-dangling row: next sweep's contribution
             const double cc = p.d * xn / (double)od;              // pagerank.go:136
-            NT_STORE(cc, &c.Tw[xi]);
+            tab_store<PS>(cc, &c.Tw[xi]);
             c.csum[k] += cc;                                      // pagerank.go:137
         }
     }
@@ -978,7 +1020,7 @@ __device__ __forceinline__ NVec<KW> load_x(const double* __restrict__ x, uint32_
 }
 
 // rows of exactly D = w.nseg <= ND in-edges: lane l of pass r0 owns row r0 + l of the item
-template <int KW, bool TS, int ND>
+template <int KW, bool TS, int ND, int PS = 0>
 __device__ __forceinline__ void deg_lane_rows(NCtx<KW, TS>& c, const WorkItem& w, int lane) {
     const PrParams& p = c.p;
     const uint32_t D = w.nseg;
@@ -998,7 +1040,7 @@ __device__ __forceinline__ void deg_lane_rows(NCtx<KW, TS>& c, const WorkItem& w
         const uint32_t od = lrow < p.sl_nd ? NT_LOAD(&p.outdeg[lrow]) : 1u;
         NVec<KW> v[ND];
 #pragma unroll
-        for (int u = 0; u < ND; u++) v[u] = ntab<KW>(c.T, src[u]);
+        for (int u = 0; u < ND; u++) v[u] = ntab<KW, PS>(c.T, src[u]);
         NVec<KW> acc;
 #pragma unroll
         for (int k = 0; k < KW; k++) acc.v[k] = 0.0;
@@ -1006,15 +1048,14 @@ __device__ __forceinline__ void deg_lane_rows(NCtx<KW, TS>& c, const WorkItem& w
         for (int u = 0; u < ND; u++)
 #pragma unroll
             for (int k = 0; k < KW; k++) acc.v[k] += v[u].v[k];
-        if (valid) finish_n<KW, TS>(c, lrow, acc, xo, od);
+        if (valid) finish_n<KW, TS, PS>(c, lrow, acc, xo, od);
     }
 }
 
-template <int KW, bool TS>
-__global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
+// one sweep of this block's waves; `sweep` = ctl->sweep as the caller read it.  PS: inside k_pr_multi_n (see ntab)
+template <int KW, bool TS, int PS>
+__device__ __forceinline__ void sweep_n_body(const PrParams& p, const int sweep, const double (&S_in)[KW], const int (&act_in)[KW]) {
     PrCtl* ctl = p.ctl;
-    if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
-    const int sweep = ctl->sweep;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // (two-vector form: the vectors alternate between x and x_alt, so that the previous ones are still there for the topics' L1 changes)
@@ -1023,8 +1064,8 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
 #pragma unroll
     for (int k = 0; k < KW; k++) {
         c.tele[k] = p.tele_col ? p.tele_col[k] : p.teleport;          // (per column only in the two-vector form)
-        c.S[k] = ctl->S[k];
-        c.act[k] = ctl->active[k] != 0;
+        c.S[k] = S_in[k];
+        c.act[k] = act_in[k] != 0;
         c.x0[k] = sweep == 0 ? p.x0[k] : 0.0;                     // Q4: iteration 1 accumulates onto 1/n
         c.dsum[k] = 0.0;
         c.csum[k] = 0.0;
@@ -1060,7 +1101,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
             idx256(e + 256, src_n);                                       // (past the end: four loads of the first edge, dropped)
             NVec<KW> v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = ntab<KW>(c.T, src[u]);
+            for (int u = 0; u < 4; u++) v[u] = ntab<KW, PS>(c.T, src[u]);
 #pragma unroll
             for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -1071,7 +1112,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) acc.v[k] += __shfl_xor(acc.v[k], o, 64);
         if (w.kind == V_ROWW) {
-            if (lane == 0) finish_n<KW, TS>(c, lrow, acc, xo, od);
+            if (lane == 0) finish_n<KW, TS, PS>(c, lrow, acc, xo, od);
         } else {
             // several waves (of any blocks) share this row: publish the piece's sum write-through, drain, take the ticket; the
             // last to arrive adds the pieces in order with sc1 loads (no fences — see block_reduce_and_publish)
@@ -1091,7 +1132,15 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
                         for (uint32_t q = 0; q < w.nseg; q++)
                             ys.v[k] += __hip_atomic_load(&p.segpart[(size_t)(w.sbase + q) * KW + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    finish_n<KW, TS>(c, lrow, ys, xo, od);
+                    if constexpr (PS == 1) {
+                        // (the rank this row got in the previous sweep may have been written by another CU: read it now, past its L1)
+                        NVec<KW> xs;
+#pragma unroll
+                        for (int k = 0; k < KW; k++) xs.v[k] = __hip_atomic_load(&c.xr[(size_t)lrow * KW + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        finish_n<KW, TS, PS, true>(c, lrow, ys, xs, od);
+                    } else {
+                        finish_n<KW, TS, PS>(c, lrow, ys, xo, od);
+                    }
                 }
             }
         }
@@ -1131,7 +1180,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
                     idx32(ch + 2, src_n);                               // the next trip's index words travel with this trip's gathers
                     NVec<KW> v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) v[u] = ntab<KW>(c.T, src[u]);
+                    for (int u = 0; u < 4; u++) v[u] = ntab<KW, PS>(c.T, src[u]);
 #pragma unroll
                     for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -1141,7 +1190,7 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
                 for (int k = 0; k < KW; k++)
 #pragma unroll
                     for (int o = 1; o < 8; o <<= 1) acc.v[k] += __shfl_xor(acc.v[k], o, 64);
-                if (valid && gl == 0) finish_n<KW, TS>(c, lrow, acc, xo, od);
+                if (valid && gl == 0) finish_n<KW, TS, PS>(c, lrow, acc, xo, od);
             }
         }
     }
@@ -1150,9 +1199,9 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
     if (SS_PR_CLASS_ON(2))
     for (uint32_t it = off[2]; it < off[5]; it++) {
         const WorkItem w = p.work[it];
-        if (w.nseg <= 2) deg_lane_rows<KW, TS, 2>(c, w, lane);          // (wave-uniform: most rows of a power-law graph)
-        else if (w.nseg <= 4) deg_lane_rows<KW, TS, 4>(c, w, lane);
-        else deg_lane_rows<KW, TS, 8>(c, w, lane);
+        if (w.nseg <= 2) deg_lane_rows<KW, TS, 2, PS>(c, w, lane);          // (wave-uniform: most rows of a power-law graph)
+        else if (w.nseg <= 4) deg_lane_rows<KW, TS, 4, PS>(c, w, lane);
+        else deg_lane_rows<KW, TS, 8, PS>(c, w, lane);
     }
 
     // ---- V_ZERO: non-dangling rows without in-edges: their rank is the shared value, only the next contribution is written
@@ -1167,11 +1216,11 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
 #pragma unroll
             for (int k = 0; k < KW; k++) {
                 const bool ts = TS && p.memb && ((p.ts_mask >> k) & 1u);
-                const double xz_out = c.act[k] ? (ts ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], 0.0) : zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], c.tele[k])) : ctl->xz[k];
-                const double xz_inn = ts ? (c.act[k] ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], p.tin[k]) : ctl->xz_in[k]) : xz_out;
+                const double xz_out = c.act[k] ? (ts ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], 0.0) : zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], c.tele[k])) : ctl_ld<PS>(&ctl->xz[k]);
+                const double xz_inn = ts ? (c.act[k] ? zero_row_rank_ts(p, sweep, c.S[k], p.x0[k], p.tin[k]) : ctl_ld<PS>(&ctl->xz_in[k])) : xz_out;
                 const double xz = ts && ((p.memb[lrow] >> k) & 1u) ? xz_inn : xz_out;
                 const double cc = p.d * xz / (double)od;                      // pagerank.go:136
-                NT_STORE(cc, &c.Tw[(size_t)lrow * KW + k]);
+                tab_store<PS>(cc, &c.Tw[(size_t)lrow * KW + k]);
                 c.csum[k] += cc;                                               // pagerank.go:137
             }
         }
@@ -1185,7 +1234,77 @@ __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
         ds = (lane & 1) ? c.dsum[1] + d1o : c.dsum[0] + d0o;
         cs = (lane & 1) ? c.csum[1] + c1o : c.csum[0] + c0o;
     }
-    block_reduce_and_publish<KW>(p, ds, cs, c.Tw, false);
+    block_reduce_and_publish<KW, PS>(p, ds, cs, c.Tw, false);
+}
+
+template <int KW, bool TS>
+__global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
+    const PrCtl* ctl = p.ctl;
+    if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
+    double S_in[KW];
+    int act_in[KW];
+#pragma unroll
+    for (int k = 0; k < KW; k++) { S_in[k] = ctl->S[k]; act_in[k] = ctl->active[k]; }
+    sweep_n_body<KW, TS, false>(p, ctl->sweep, S_in, act_in);
+}
+
+// ---- several sweeps in ONE launch (round 5: graphs whose sweep is all fixed cost) -------------------------------------------------
+// BASELINE config 2 (2^20 nodes / 5M edges, one vector) sweeps in 54 us of which 33 us are an EMPTY grid's: launch, control-block
+// reads, the two-level hand-in of the partial sums, kernel end.  pagerank.go:93-119 is a loop; here the loop runs inside the launch:
+// every block walks its waves' items, hands its partial sums in exactly as k_pr_sweep_n does, and then WAITS until the last block to
+// arrive has applied the stop rule and published the next sweep's number (finalize_ctl<true>: write-through stores, drained, the
+// sweep counter last) — that wait is the grid-wide barrier between two sweeps.  Nothing is fenced: whatever one sweep writes for
+// another CU to read in the next (the contribution table, the control block, the partial sums, the row pieces' tickets) is stored
+// write-through (sc1) and read with L1-bypassing sc1 loads (MI355X_MICROARCH.md, hand-offs without fences; the ranks x are read and
+// written by the same lane of the same wave in every sweep — the deal is static — and need nothing).  The arithmetic and its order
+// are those of k_pr_sweep_n: ranks and iteration counts are bit-identical to one launch per sweep.
+// Residency: the grid is sized by the host to HALF of what the occupancy query admits (ss_pr_create), so that it is resident whatever
+// else runs; a wait that still ends without the counter moving (SPIN_MAX polls, seconds) sets ctl->stuck and every block leaves — the
+// host reports SS_ERR_STATE instead of a hung device.
+constexpr uint32_t MULTI_SPIN_MAX = 1u << 24;
+// PSM 1: write-through / sc1 form (above).  PSM 2: plain stores and loads with an agent-scope release in front of every block's arrival
+// and an acquire behind every block's wait (the table then stays in the XCD's L2 for the block's own gathers, as between launches).
+template <int KW, int PSM>
+__global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_multi_n(PrParams p, int n_steps) {
+    __shared__ int s_go, s_na, s_sw, s_act[KW];
+    __shared__ double s_S[KW];
+    PrCtl* ctl = p.ctl;
+    // ONE lane per block reads the control block (write-through data: sc1 loads that all land on one L2 channel — every lane of 4096 waves
+    // reading it was 20k requests to that channel per sweep) and hands it to the block through LDS
+    auto read_ctl = [&]() __attribute__((always_inline)) {
+        s_na = ctl_ld<1>(&ctl->n_active) == 0 || ctl_ld<1>(&ctl->stuck) ? 0 : 1;
+        s_sw = ctl_ld<1>(&ctl->sweep);
+#pragma unroll
+        for (int k = 0; k < KW; k++) { s_S[k] = ctl_ld<1>(&ctl->S[k]); s_act[k] = ctl_ld<1>(&ctl->active[k]); }
+    };
+    if (threadIdx.x == 0) read_ctl();
+    __syncthreads();
+    for (int s = 0; s < n_steps; s++) {
+        // (every block reads the same control block: it only changes when ALL blocks have handed in the sweep)
+        if (s_na == 0) return;                                    // every topic has stopped: the remaining sweeps are no-ops
+        const int sweep = s_sw;
+        double S_in[KW];
+        int act_in[KW];
+#pragma unroll
+        for (int k = 0; k < KW; k++) { S_in[k] = s_S[k]; act_in[k] = s_act[k]; }
+        __syncthreads();                                          // (everybody has its copy: lane 0 may rewrite the LDS words below)
+        sweep_n_body<KW, false, PSM>(p, sweep, S_in, act_in);
+        if (s + 1 == n_steps) return;                             // the kernel boundary is the last barrier
+        if (threadIdx.x == 0) {
+            uint32_t spins = 0;
+            while (ctl_ld<1>(&ctl->sweep) == sweep && ++spins < MULTI_SPIN_MAX) __builtin_amdgcn_s_sleep(8);
+            const bool ok = spins < MULTI_SPIN_MAX;
+            if (!ok) ctl_st<1>(&ctl->stuck, 1u);
+            s_go = ok ? 1 : 0;
+            if (ok) read_ctl();
+            if constexpr (PSM == 2) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drops this CU's L1 lines: the other blocks' table rows and ranks
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (holds the barrier until the invalidate has completed)
+            }
+        }
+        __syncthreads();
+        if (!s_go) return;
+    }
 }
 
 // k_pr_sweep's items: their in-edge ranges from the device's in_ptr (the host deals the items by their turn counts, which it
@@ -1362,6 +1481,8 @@ struct ss_pr {
     int gw = 1;            // lane-group width = padded topic count
     ss::DevBuf<float> wire_send, wire_recv;   // option "pr.wire_f32": the contribution slice as float32 on the wire
     bool nwave = false;    // K <= 2 on the wave-item kernel k_pr_sweep_n (gw = K; the work items are those of the 8-wide sweep)
+    int persist_mode = 1;  // 1: write-through hand-offs, 2: release / acquire fences around the wait
+    bool persist = false;  // ... with ss_pr_step's sweeps inside ONE launch (k_pr_multi_n): small graphs, whose sweep is mostly fixed cost
     int k = 1;
     PrParams prm{};
     unsigned nblocks = 0;
@@ -1538,6 +1659,13 @@ void launch_step(ss_pr* pr, hipStream_t st) {
         else hipLaunchKernelGGL((k_pr_sweep<GW, false>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
     }
     else hipLaunchKernelGGL(k_pr_step<GW>, dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm);
+}
+template <int GW>
+void launch_multi(ss_pr* pr, hipStream_t st, int n_steps) {
+    if constexpr (GW <= 2) {
+        if (pr->persist_mode == 2) hipLaunchKernelGGL((k_pr_multi_n<GW, 2>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm, n_steps);
+        else hipLaunchKernelGGL((k_pr_multi_n<GW, 1>), dim3(pr->nblocks), dim3(TPB), 0, st, pr->prm, n_steps);
+    }
 }
 template <int GW>
 void sweep_occupancy(int* blocks_per_cu) {
@@ -1912,7 +2040,40 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     }
     const auto tc1a = t_now();
     per_cu = (int)std::max<int64_t>(1, ctx->opt("pr.blocks_per_cu", per_cu));
-    pr->nblocks = vitems ? (unsigned)std::min<size_t>(ss::div_up(items.size(), (size_t)WAVES), (size_t)ctx->cu_count * per_cu)
+    // Several sweeps per launch (k_pr_multi_n), OPT-IN ("pr.persistent" = 1: write-through hand-offs, 2: release / acquire fences): one
+    // rank, the reference's uniform teleport, K <= 2 on the wave-item kernel.  The blocks wait for each other between two sweeps, so ALL
+    // of them must be resident: half of what the occupancy query admits per CU, at most "pr.persistent_blocks" (default 4).
+    // Measured and therefore off by default (round 5, config 2: 2^20 nodes / 5M edges, K = 1): 0.054 ms per sweep with one launch per
+    // sweep against 0.113 (write-through) / 0.152 (fences) inside one launch at 4 blocks per CU, 0.075 / 0.094 at 2, 0.078 / 0.082 at 1 —
+    // the wait costs ~25 us per 256 resident blocks, far more than the 33 us an empty launch of this sweep costs in all; 10M / 50M:
+    // 0.38 against 0.51 ms.  Results are bit-identical in every mode (test_sweeps_inside_one_launch_are_bit_identical).
+    {
+        const int64_t want = ctx->opt("pr.persistent", 0);
+        pr->persist_mode = want == 2 ? 2 : 1;
+        pr->persist = pr->nwave && g->world == 1 && !ctx->opt("pr.affine", 0) && want > 0;
+        if (pr->persist) {
+            // what the runtime admits of k_pr_multi_n itself, less two: the query answers one block per CU too many for kernels with
+            // 97-112 SGPRs (MI355X_MICROARCH.md, residency), and a block that is not resident would be waited for in vain
+            static std::mutex occ2_mu;
+            static int occ_multi[3] = {0, 0, 0};
+            std::lock_guard<std::mutex> lk2(occ2_mu);
+            if (!occ_multi[GW <= 2 ? GW : 0]) {
+                int o = 0;
+                if (GW == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_pr_multi_n<1, 1>, TPB, 0);
+                else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_pr_multi_n<2, 1>, TPB, 0);
+                occ_multi[GW <= 2 ? GW : 0] = std::max(o, 1);
+            }
+            const int admit = std::max(1, occ_multi[GW <= 2 ? GW : 0] - 2);
+            per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(admit, std::max(1, per_cu / 2)), ctx->opt("pr.persistent_blocks", 4)));
+        }
+    }
+    // How many waves: k_pr_sweep gives every wave at least one item; k_pr_sweep_n at least "pr.items_per_wave" (default 4: 0.0537 / 0.0531 / 0.0522 / 0.0483 / 0.0523 ms at 1 / 2 / 3 / 4 / 6) — on a small
+    // graph what a sweep costs is mostly per WAVE (launch, control-block and offset reads, the hand-in of the partial sums), and a wave
+    // with a single pass of 64 rows is all overhead.  Config 2 (2^20 nodes / 5M edges, K = 1), ms per sweep by resident blocks per CU:
+    // 8: 0.0533, 6: 0.0513, 4: 0.0485, 3: 0.0461, 2: 0.0468.  [Built, measured, removed: the same waves in 1024-thread blocks (a quarter
+    // of the arrivals at the hand-in): 0.067 against 0.054 — sixteen waves wait for their slowest at every workgroup barrier.]
+    const size_t ipw = pr->nwave ? (size_t)std::max<int64_t>(1, ctx->opt("pr.items_per_wave", 4)) : 1;
+    pr->nblocks = vitems ? (unsigned)std::min<size_t>(std::max<size_t>(1, ss::div_up(items.size(), (size_t)WAVES * ipw)), (size_t)ctx->cu_count * per_cu)
                           : (unsigned)std::min<size_t>(items.size(), (size_t)ctx->cu_count * 8);
     static thread_local std::vector<uint32_t> woff, cnt;
     woff.clear();
@@ -2334,7 +2495,11 @@ int32_t ss_pr_step(ss_pr* pr, int32_t n_steps) {
     if (n_steps < 1) return ctx->fail(SS_ERR_INVALID, "ss_pr_step: n_steps < 1");
     if (pr->g->world > 1 && n_steps != 1) return ctx->fail(SS_ERR_INVALID, "ss_pr_step: world>1 needs an exchange after every step");
     SS_HIP(ctx, hipEventRecord(ctx->ev[0][0], ctx->stream));
-    for (int i = 0; i < n_steps; i++) SS_GW_DISPATCH(pr->gw, launch_step, pr, ctx->stream);
+    if (pr->persist && !pr->prm.memb && !pr->prm.aff) {
+        SS_GW_DISPATCH(pr->gw, launch_multi, pr, ctx->stream, (int)n_steps);   // the sweeps wait for each other inside the launch
+    } else {
+        for (int i = 0; i < n_steps; i++) SS_GW_DISPATCH(pr->gw, launch_step, pr, ctx->stream);
+    }
     SS_HIP(ctx, hipEventRecord(ctx->ev[0][1], ctx->stream));
     ctx->ev_valid[0] = true;
     SS_HIP(ctx, hipGetLastError());
@@ -2809,6 +2974,8 @@ int32_t ss_pr_status(ss_pr* pr, int32_t* iters_out, int32_t* n_active, int32_t* 
     SS_HIP(ctx, hipMemcpyAsync(hp, pr->ctl.p, sizeof(PrCtl), hipMemcpyDeviceToHost, ctx->stream));
     SS_TRY(ss::sync_bounded(ctx, ctx->stream, "ss_pr_status"));
     const PrCtl h = *hp;
+    if (h.stuck) return ctx->fail(SS_ERR_STATE, "ss_pr_status: the multi-sweep kernel gave up waiting between two sweeps (its grid of %u blocks was not resident: "
+                                  "other kernels held the CUs for seconds); the state is void — set option pr.persistent = 0 and run again", pr->nblocks);
     for (int k = 0; k < pr->k; k++) {
         if (iters_out) iters_out[k] = h.iters[k];
         if (last_delta_out) last_delta_out[k] = h.delta[k];

@@ -502,6 +502,14 @@ inline size_t scatter_lds_bytes(uint32_t nbt) { return (size_t)SC_CH * 8 + (size
 #else
 #define SC_NT_LOAD(p) __builtin_nontemporal_load(p)
 #endif
+#ifdef SS_SC_PHASES
+// variant build (tools/build_variant.sh scph -DSS_SC_PHASES): cycles wave 0 of every block spends in each phase of a chunk, summed over
+// the grid and printed by the build (s_memtime; the kernel's time is unchanged within 1 %)
+__device__ unsigned long long g_sc_ph[8];
+#define SC_PH(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t; ph_t = t_; } } while (0)
+#else
+#define SC_PH(i) do { } while (0)
+#endif
 constexpr int SC_WIN = SC_CH;                  // term-window entries staged per chunk (a chunk spans at most SC_CH + 1 non-empty terms; beyond: global search)
 template <bool WEIGHT, int BPT>
 #ifndef SS_SC_MINW
@@ -600,8 +608,12 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
     uint64_t pf_t0 = 0, pf_tp[SC_PF] = {}, pf_probe = 0;
     float pf_idf[SC_PF] = {};
     __shared__ uint32_t s_need_n;
+#ifdef SS_SC_PHASES
+    unsigned long long ph_acc[8] = {}, ph_t = __builtin_readcyclecounter();
+#endif
     for (uint64_t base = r0; base < r1; base += SC_CH) {
         uint32_t rank2[SC_PT / 2];                                        // two 16-bit ranks to a register
+        SC_PH(7);
         const bool empty = cur_empty;
         const uint32_t h_here = hcur;                                      // the head range running at `base` (before meta moves on)
         meta(base + SC_CH);
@@ -626,6 +638,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
             // (0) the chunk's term window, then w = tf * idf (term_weighting.go:42) for this thread's postings, written back in place
             const uint32_t n_here = (uint32_t)min((uint64_t)SC_CH, r1 - base);
             __syncthreads();                                               // the previous chunk's records (same bytes) have been written out
+            SC_PH(0);
             uint64_t t0;
             uint32_t need;
             if (pf_ok) {
@@ -659,6 +672,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
                 }
             }
             __syncthreads();
+            SC_PH(1);
             if (x0 < n_here) {
                 uint32_t k = 0;
                 {
@@ -719,6 +733,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
                 if (x0 + SC_PT >= n_here) s_t0 = t;
             }
             __syncthreads();                                               // the window's bytes become the record staging area
+            SC_PH(2);
             // the next chunk's window, first load: how far do its terms reach? (s_t0 now names its first term)
             pf_ok = false;
             if (next_live) {
@@ -739,6 +754,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
             if (pf_probe < base_n + min((uint64_t)SC_CH, r1 - base_n)) atomicMax(&s_need_n, threadIdx.x + 1);
         }
         __syncthreads();
+        SC_PH(3);
         // (2) exclusive scan of the counts -> staging offsets; claim this chunk's runs from the block's cursors
         uint32_t c[BPT], run = 0;
 #pragma unroll
@@ -786,6 +802,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
             }
         }
         __syncthreads();
+        SC_PH(4);
 #if defined(SS_EXP_SC) && SS_EXP_SC == 2      // ... loads, count and scan
         loads(base + SC_CH);
         continue;
@@ -802,6 +819,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
         }
         loads(base + SC_CH);                                               // (doc / w are free: the next chunk's postings travel under phase 4)
         __syncthreads();
+        SC_PH(5);
         // (4) out, in staging order: consecutive lanes write consecutive records of a bucket's run
         // (the staged records end where the last bucket's run ends; head postings were never staged)
         const uint32_t n_staged = s_nstaged;
@@ -820,7 +838,12 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
         }
         // the next chunk's phase (1) only touches hist; its phase (2) rewrites loff / gout after the barrier that follows (1),
         // by which time every thread has left (4)  [WEIGHT: the barrier at the top of the weight phase comes before the window is staged]
+        SC_PH(6);
     }
+#ifdef SS_SC_PHASES
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_sc_ph[i], ph_acc[i]);
+#endif
 }
 
 // magnitudes only (ss_index_refresh_magnitudes): small tables
@@ -1062,6 +1085,21 @@ void bucket_pass_launch(ss_index* idx, hipStream_t st, BucketPass& bp, bool weig
         if (bp.bpt <= 2) SS_SCATTER_LAUNCH(false, 2); else if (bp.bpt <= 4) SS_SCATTER_LAUNCH(false, 4); else SS_SCATTER_LAUNCH(false, SC_BPT_MAX);
     }
 #undef SS_SCATTER_LAUNCH
+#ifdef SS_SC_PHASES
+    {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sc_ph), sizeof(h));
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; i++) tot += h[i];
+        fprintf(stderr, "[k_scatter phases, %u blocks, cycles of wave 0 summed] wait-for-previous-write-out+barrier %.1f%%  window staged %.1f%%  weights %.1f%%  count %.1f%%  scan %.1f%%  "
+                        "stage+next loads issued %.1f%%  write-out %.1f%%  loop top %.1f%%  (total %.3g cycles = %.1f k per block)\n", bp.nblk,
+                100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, 100.0 * h[5] / tot, 100.0 * h[6] / tot, 100.0 * h[7] / tot,
+                (double)tot, (double)tot / bp.nblk / 1e3);
+        unsigned long long z[8] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sc_ph), z, sizeof(z));
+    }
+#endif
     if (weight) hipLaunchKernelGGL(k_bucket_sum<true>, dim3(bp.nb), dim3(TPB_B), bucket_lds_bytes(bp.shift), st, bp.packed.p, bp.off.p, N, bp.shift,
                                    idx->mag.p, idx->mag2.p, (const uint32_t*)idx->post_doc.p, idx->post_w.p, idf, head);
     else hipLaunchKernelGGL(k_bucket_sum<false>, dim3(bp.nb), dim3(TPB_B), bucket_lds_bytes(bp.shift), st, bp.packed.p, bp.off.p, N, bp.shift,

@@ -541,3 +541,56 @@ def test_run_to_run_bit_identical(ss_ctx):
         assert i1.tolist() == i2.tolist() == i3.tolist()
         assert r1.tobytes() == r2.tobytes() == r3.tobytes()
         outs.append(r1)
+
+
+@pytest.mark.parametrize("k_topics", [1, 2])
+def test_sweeps_inside_one_launch_are_bit_identical(ss_ctx, oracle, k_topics):
+    """k_pr_multi_n (round 5; option "pr.persistent", on by default for K <= 2 on graphs whose contribution table is cache-resident):
+    ss_pr_step's sweeps run inside one launch, the blocks waiting for each other between two sweeps.  Same arithmetic in the same
+    order as one launch per sweep: ranks and iteration counts bit for bit, also against the oracle, for eps stops inside a batch of
+    sweeps, max_iter cuts, a hub whose row is cut into pieces (tickets reused sweep after sweep), and graphs without edges."""
+    from spaghettisearch_amd import engine
+    cases = [synth.rmat_graph(30000, 160000, seed=77), synth.rmat_graph(1 << 18, 1_500_000, seed=5)]
+    # a 70k-edge hub (V_SEG pieces) beside short rows
+    rng = np.random.default_rng(4)
+    n = 90000
+    src = np.concatenate([rng.integers(0, n, 70000), rng.integers(0, n, 200000)])
+    dst = np.concatenate([np.full(70000, 17), rng.integers(0, n, 200000)])
+    pairs = np.unique(np.stack([src, dst], 1), axis=0)
+    ptr = np.zeros(n + 1, dtype=np.uint64)
+    np.add.at(ptr, pairs[:, 0] + 1, 1)
+    cases.append((np.cumsum(ptr).astype(np.uint64), pairs[:, 1].astype(np.uint32)))
+    cases.append((np.zeros(1001, dtype=np.uint64), np.zeros(0, dtype=np.uint32)))          # no edges at all
+    for ptr, dst in cases:
+        n = len(ptr) - 1
+        n_topic = synth.topic_sizes(n, k_topics)
+        for eps, max_iter in ((1e-9, 0), (1e-20, 300), (-1.0, 11)):
+            ref, ref_it = oracle.pagerank(n, ptr, dst, D, eps, n_topic, max_iter=max_iter)
+            got = {}
+            for mode in (0, 1, 2):                # one launch per sweep; write-through hand-offs; release / acquire fences
+                with ss_ctx.options(pr__persistent=mode):
+                    g = engine.Graph(ss_ctx, n, ptr, dst)
+                    got[mode] = g.pagerank(D, eps, n_topic, max_iter=max_iter)
+                    g.close()
+            for mode in (1, 2):
+                assert got[0][1].tolist() == got[mode][1].tolist(), (mode, eps)
+                assert got[0][0].tobytes() == got[mode][0].tobytes(), (mode, eps)
+            assert np.abs(got[1][1].astype(int) - ref_it.astype(int)).max() <= (1 if eps == 1e-20 else 0)
+            np.testing.assert_allclose(got[1][0], ref, rtol=1e-12)
+    # stepping by hand: 3 + 1 + 5 sweeps inside launches == 9 launches
+    ptr, dst = cases[0]
+    n = len(ptr) - 1
+    n_topic = synth.topic_sizes(n, k_topics)
+    xs = {}
+    for mode in (0, 1, 2):
+        with ss_ctx.options(pr__persistent=mode):
+            g = engine.Graph(ss_ctx, n, ptr, dst)
+            st = engine.PageRankState(g, D, -1.0, n_topic, max_iter=0)
+            st.begin()
+            for m in (3, 1, 5):
+                st.step(m)
+            assert st.status()["sweeps"] == 9
+            xs[mode] = st.read()
+            st.close()
+            g.close()
+    assert xs[0].tobytes() == xs[1].tobytes() == xs[2].tobytes()
