@@ -326,6 +326,10 @@ static const char* const k_option_names[] = {
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
     "score.wave_big_pct",   // graded slices: this share of a batch's postings goes into slices of wave_big_x100 % of the target, the rest into wave_small_x100 % (defaults 92 / 115 / 60; 0 = one size)
     "score.wave_big_x100",
+    "score.small",          // 1: queries without a phrase part and with at most "score.small_cap" postings (default and most: 2304) are scored by
+                            //    k_score_small — one workgroup per query, every posting exactly, the hits written by the kernel itself.  Default 0:
+                            //    bit-identical hits, measured slower than k_score_slices (DESIGN K4c)
+    "score.small_cap",
     "score.pipeline",       // 0: every scoring kernel on the context's stream.  n >= 1: device-output batches that are all k_score_wave run k_wave_prep and
                             //    k_score_wave on one of n internal streams taken in turn (default 2, as include/spaghetti_rank.h says; at most 3) and
                             //    only k_merge_flat (behind an event) on the context's stream: the next batch's

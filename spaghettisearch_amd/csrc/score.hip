@@ -1165,7 +1165,7 @@ size_t score_lds_bytes(int cb) { return score_lds_layout(cb).total; }
 // ---- K5: merge a query's slices, explain the winners ------------------------------
 __global__ __launch_bounds__(TPB_M) void k_merge_topk(ScoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (p.q_fast && p.q_fast[blockIdx.x]) return;          // k_merge_flat's
+    if (p.q_fast && p.q_fast[blockIdx.x]) return;          // k_merge_flat's (bit 0) or k_score_small's (bit 1): their hits come from there
     merge_query<TPB_M, false>(p, blockIdx.x, smem, p.cb);
 }
 // the queries scored by k_score_wave: one candidate list per query
@@ -1364,6 +1364,12 @@ void launch_wave_prep(const void* params, unsigned n_slices, void* prep, hipStre
 void launch_score_wave(const void* params, unsigned n_slices, const void* prep, hipStream_t st);
 int score_wave_max_lists();
 int score_wave_max_k();
+// score_small.hip: one workgroup per small query (every posting scored exactly, hits written by the kernel itself)
+uint32_t score_small_cap();
+uint32_t score_small_cap_a();
+int score_small_max_k();
+int32_t launch_score_small(const void* params, unsigned n_a, unsigned n_b, hipStream_t st);
+void score_small_report();
 void score_wave_diag_dump();
 }  // namespace ss
 
@@ -1547,6 +1553,9 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
         if (ws) (void)hipStreamSynchronize(ws);
 #if defined(SSW_PHASES) && !defined(SS_DIAG)
     ss::score_wave_diag_dump();
+#endif
+#ifdef SSS_PHASES
+    ss::score_small_report();
 #endif
 #ifdef SS_DIAG
     ss::score_wave_diag_dump();
@@ -1957,6 +1966,15 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         batch_wave = wml == 0 ? fit > 0 : (fit * 100 >= all * share && fit >= 400000);
     }
     std::vector<uint8_t> h_fast(n_q, 0);
+    // k_score_small (one workgroup per query, every posting scored exactly, no slices and no merge: score_small.hip) takes the queries
+    // without a phrase part whose lists hold at most score_small_cap() postings in all.  OPT-IN (option "score.small" = 1): bit-identical
+    // hits, but measured slower than the slice kernel it was meant to relieve (round 5, config-3 index: tail batch 0.155 against 0.094 ms,
+    // mixed 0.207 against 0.166, 8 tail queries host to host 0.165 against 0.098, one query 0.091 against 0.092): a query's workgroup is a
+    // chain of ~10 short phases — list bounds, postings, table, magnitudes, scores, admission, a 512-entry bitonic sort, hits — each a
+    // memory or barrier latency with nothing to overlap (50 us per workgroup at five per CU: phase clocks in DESIGN K4c).
+    const bool small_ok = ctx->opt("score.small", 0) != 0 && k <= ss::score_small_max_k();
+    const uint64_t small_cap = (uint64_t)std::min<int64_t>(ss::score_small_cap(), std::max<int64_t>(0, ctx->opt("score.small_cap", ss::score_small_cap())));
+    std::vector<uint32_t> h_smallq, h_smallq_b;         // by table size: up to score_small_cap_a() postings, and beyond
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
     std::vector<double> h_qmag(n_q), h_ub(n_q, 0.0);
     std::vector<SliceDesc> h_slices;
@@ -1995,6 +2013,12 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         const uint64_t plan_cap = std::max<uint64_t>(TARGET, (uint64_t)(TBL_CAP / n_lists > 2 ? TBL_CAP / n_lists - 2 : 1) * TARGET * 7 / 8);
         uint64_t q_target = slice_target;
         uint64_t max_slices = MAX_SLICES_PER_Q;
+        if (small_ok && tot <= small_cap && !(p_ptr && h_pptr[q + 1] > h_pptr[q])) {
+            (tot <= ss::score_small_cap_a() ? h_smallq : h_smallq_b).push_back((uint32_t)q);   // no slices: k_score_small reads the lists whole and writes the hits
+            h_fast[q] = 2;
+            h_sbase[q + 1] = (uint32_t)h_slices.size();
+            continue;
+        }
         const bool fast = batch_wave && h_suits[q] && h_dterm.size() > d0 && (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists();
         if (fast) {
             h_fast[q] = 1;
@@ -2022,6 +2046,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
         h_sbase[q + 1] = (uint32_t)h_slices.size();
     }
+    const size_t n_small_a = h_smallq.size(), n_small_b = h_smallq_b.size();
+    h_smallq.insert(h_smallq.end(), h_smallq_b.begin(), h_smallq_b.end());
     const size_t n_slices = h_slices.size();
     const size_t n_d = h_dterm.size();
     // launch order: the wave kernel's slices first, then k_score_slices' (each group longest first); merge list = the wave queries
@@ -2032,16 +2058,16 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         std::vector<uint32_t> q_order(n_q);
         for (int q = 0; q < n_q; q++) q_order[q] = (uint32_t)q;
         std::stable_sort(q_order.begin(), q_order.end(), [&](uint32_t a, uint32_t b) {
-            return h_fast[a] != h_fast[b] ? h_fast[a] > h_fast[b] : h_qcost[a] > h_qcost[b];
+            return (h_fast[a] & 1) != (h_fast[b] & 1) ? (h_fast[a] & 1) > (h_fast[b] & 1) : h_qcost[a] > h_qcost[b];
         });
         size_t o = 0;
         for (int i = 0; i < n_q; i++)
             for (uint32_t sl = h_sbase[q_order[i]]; sl < h_sbase[q_order[i] + 1]; sl++) h_order[o++] = sl;
     }
     size_t n_fast_slices = 0;
-    for (size_t i = 0; i < n_slices; i++) n_fast_slices += h_fast[h_slices[i].q];
+    for (size_t i = 0; i < n_slices; i++) n_fast_slices += h_fast[h_slices[i].q] & 1;
     for (int q = 0; q < n_q; q++)
-        if (h_fast[q]) h_mergeq.push_back((uint32_t)q);
+        if (h_fast[q] & 1) h_mergeq.push_back((uint32_t)q);
 
     int cb = SS_CB_MIN;
     while (cb < 2 * k) cb <<= 1;
@@ -2069,6 +2095,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const size_t o_probs = o;  o = align16(o + h_probs.size() * sizeof(double));
     const size_t o_mergeq = o; o = align16(o + h_mergeq.size() * sizeof(uint32_t));
     const size_t o_qfast = o;  o = align16(o + (size_t)n_q);
+    const size_t o_smallq = o; o = align16(o + h_smallq.size() * sizeof(uint32_t));
     const size_t plan_bytes = o;
     const int pb = s->plan_turn;
     s->plan_turn = (s->plan_turn + 1) % ss_scorer::TURNS;
@@ -2112,6 +2139,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_probs.empty()) std::memcpy(hp + o_probs, h_probs.data(), h_probs.size() * sizeof(double));
     if (!h_mergeq.empty()) std::memcpy(hp + o_mergeq, h_mergeq.data(), h_mergeq.size() * sizeof(uint32_t));
     std::memcpy(hp + o_qfast, h_fast.data(), (size_t)n_q);
+    if (!h_smallq.empty()) std::memcpy(hp + o_smallq, h_smallq.data(), h_smallq.size() * sizeof(uint32_t));
     const auto th3 = t_now();
     if (any_phrase) {
         for (int x = 0; x < 4; x++) {
@@ -2191,6 +2219,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.qc_cnt = s->d_qcnt2[pb].p;
     p.merge_q = reinterpret_cast<const uint32_t*>(dp + o_mergeq);
     p.q_fast = reinterpret_cast<const uint8_t*>(dp + o_qfast);
+    p.small_q = reinterpret_cast<const uint32_t*>(dp + o_smallq);
     p.hits = dev_out ? hits_out : s->d_hits.p;
     p.n_hits = dev_out ? n_hits_out : s->d_nhits.p;
 
@@ -2255,6 +2284,10 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
     }
     if (pipe_s) sst = wst;
+    if (!h_smallq.empty()) {                     // writes its queries' hits itself: the caller's stream, like every kernel that does
+        const int32_t rc_s = ss::launch_score_small(&p, (unsigned)n_small_a, (unsigned)n_small_b, st);
+        if (rc_s != 0) return ctx->fail(SS_ERR_HIP, "k_score_small: %s", hipGetErrorString((hipError_t)rc_s));
+    }
     if (any_phrase) {                            // the phrase matches, in front of the kernel that merges them in (k_score_slices)
         hipStream_t pst = sst;
         if (!h_parts.empty()) hipLaunchKernelGGL(k_phrase_match, dim3((unsigned)h_parts.size()), dim3(PH_TPB), 0, pst, p);

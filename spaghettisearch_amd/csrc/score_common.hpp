@@ -139,6 +139,7 @@ struct ScoreParams {
     const uint8_t* q_fast;    // [n_q] 1: the query is scored by k_score_wave
     uint32_t* qc_cnt;         // [n_q] candidates the wave slices of query q have appended (from entry slice_base[q] * k of so_key / so_doc)
     ss_hit* hits; int32_t* n_hits;
+    const uint32_t* small_q;  // k_score_small: query of workgroup b (queries it scores have no slices; q_fast[q] & 2)
 };
 
 using ss::fkey;

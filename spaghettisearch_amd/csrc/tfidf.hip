@@ -526,7 +526,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
     uint2* const L_rec = reinterpret_cast<uint2*>(sc_smem);
     uint32_t* const s_tp = reinterpret_cast<uint32_t*>(sc_smem);            // [SC_WIN] WEIGHT: the chunk's term starts, relative to `base` ...
     float* const s_idf = reinterpret_cast<float*>(sc_smem) + SC_WIN;         // [SC_WIN] ... and their idf (both in L_rec's bytes: used before the records are staged)
-    uint32_t* const L_gout = reinterpret_cast<uint32_t*>(L_rec + SC_CH);   // [nbt] where this chunk's run of the bucket starts in the output
+    uint32_t* const L_gout = reinterpret_cast<uint32_t*>(L_rec + SC_CH);   // [nbt] where this chunk's run of the bucket starts in the output MINUS where it starts in the staging area
     uint32_t* const L_hist = L_gout + nbt;                                 // [nbt / 2] records of the chunk per bucket, 16 bits each (bucket b: word b >> 1, half b & 1)
     uint16_t* const L_loff = reinterpret_cast<uint16_t*>(L_hist + nbt / 2);// [nbt] first staging position of the bucket
     uint32_t* const L_part = reinterpret_cast<uint32_t*>(L_loff + nbt);    // [16]
@@ -772,14 +772,25 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
         if (lane == 63) L_part[wv] = incl;
         __syncthreads();
         uint32_t o = incl - run;
-        for (int q = 0; q < wv; q++) o += L_part[q];
+        {
+            // the earlier waves' totals: all SC_TPB / 64 words with wide loads issued together (a loop of `wv` dependent 4-byte reads
+            // was up to 15 LDS latencies for the last wave, 15 % of a chunk's cycles in the phase clocks of round 5)
+            constexpr int NW4 = (SC_TPB / 64 + 3) / 4;
+            uint4 pw[NW4];
+#pragma unroll
+            for (int q4 = 0; q4 < NW4; q4++) pw[q4] = reinterpret_cast<const uint4*>(L_part)[q4];
+#pragma unroll
+            for (int q4 = 0; q4 < NW4; q4++) {
+                o += (4 * q4 + 0 < wv ? pw[q4].x : 0u) + (4 * q4 + 1 < wv ? pw[q4].y : 0u) + (4 * q4 + 2 < wv ? pw[q4].z : 0u) + (4 * q4 + 3 < wv ? pw[q4].w : 0u);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < BPT; q++) {
             const uint32_t b = threadIdx.x * bpt + q;
             if ((uint32_t)q < bpt && b < nbt) {
                 L_loff[b] = (uint16_t)o;
+                L_gout[b] = cur[q] - o;                                    // (output position of a staged record = this + its staging position)
                 o += c[q];
-                L_gout[b] = cur[q];
                 cur[q] += c[q];
                 if ((q & 1) == 0) L_hist[b >> 1] = 0;                      // (bpt and nbt are even: the word is this thread's alone)
             }
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
         for (uint32_t pos = threadIdx.x; pos < n_staged; pos += SC_TPB) {
             const uint2 r = L_rec[pos];
             const uint32_t b = r.x >> shift;
-            out[(uint64_t)L_gout[b] + (pos - (uint32_t)L_loff[b])] = r;
+            out[(uint64_t)(L_gout[b] + pos)] = r;                          // (L_gout = run start - staging start, modulo 2^32: the sum is exact)
         }
         // the next chunk's phase (1) only touches hist; its phase (2) rewrites loff / gout after the barrier that follows (1),
         // by which time every thread has left (4)  [WEIGHT: the barrier at the top of the weight phase comes before the window is staged]

@@ -15,6 +15,16 @@ from spaghettisearch_amd import engine, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["small-kernel-off", "small-kernel-on"])
+def _small_query_routing(request, ss_ctx):
+    """Every test of this file runs twice: with k_score_small switched off (option "score.small" = 0: the queries of these small
+    tables then reach k_score_slices / k_score_wave, the kernels most tests were written for) and with the default routing, where
+    queries of up to 2304 postings take k_score_small."""
+    ss_ctx.set_option("score.small", request.param)
+    yield
+    ss_ctx.set_option("score.small", None)
+
+
 def make_scorer(ss_ctx, n_docs, title, body, mag_t, mag_b):
     from spaghettisearch_amd import engine
     ti = engine.InvertedIndex(ss_ctx, n_docs, *title)
@@ -549,3 +559,65 @@ def test_wave_kernel_forced_many_terms(ss_ctx, oracle):
         assert_same_hits(hits, n_hits, ref, ref_n)
     finally:
         close_all(sc, ti, bi)
+
+
+def test_small_query_kernel_edges(ss_ctx, oracle):
+    """k_score_small (one workgroup per query; every posting exactly, no filter): the cap boundary (a query of exactly / one over
+    score.small_cap postings), duplicates (Q8 multiplicity), unknown and repeated unknown terms, empty queries, hostile inputs the
+    filter of the other kernels would need switched off (negative and NaN weights, zero / NaN / infinite magnitudes), a blended
+    prior with hostile probabilities, k = 1 / 100 / 256 (its largest) and 257 (one over: the other kernels), one batch that holds
+    small, wave and slice queries at once; and the same hits whether the small kernel or the big ones score a query."""
+    rng = np.random.default_rng(7)
+    n_docs, n_terms = 60000, 500
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 900000, 60000, seed=5)
+    # hostile corner: a few negative / NaN weights and odd magnitudes
+    bw = body[2].copy()
+    bw[rng.integers(0, len(bw), 50)] *= -1.0
+    bw[rng.integers(0, len(bw), 5)] = np.nan
+    body_h = (body[0], body[1], bw)
+    mb_h = mb.copy()
+    mb_h[rng.integers(0, n_docs, 40)] = 0.0
+    mb_h[rng.integers(0, n_docs, 5)] = np.nan
+    mb_h[rng.integers(0, n_docs, 5)] = np.inf
+    b_len = np.diff(body[0].astype(np.int64)) + np.diff(title[0].astype(np.int64))
+    order = np.argsort(b_len)
+    for (tt, bb, m_t, m_b), exact in (((title, body, mt, mb), True), ((title, body_h, mt, mb_h), True)):
+        sc, ti, bi = make_scorer(ss_ctx, n_docs, tt, bb, m_t, m_b)
+        try:
+            qs = []
+            qs.append([])                                                # no token at all
+            qs.append([n_terms + 5])                                     # only unknown words
+            qs.append([int(order[3]), int(order[3]), n_terms + 1, int(order[3])])   # a triple token beside an unknown one
+            qs += [list(rng.choice(order[:200], size=int(rng.integers(1, 6)))) for _ in range(40)]        # tail terms
+            qs += [list(rng.choice(order[-30:], size=3)) for _ in range(6)]                                # head terms: the big kernels
+            qs += [[int(order[-1]), int(order[5])], [int(order[100]), int(order[101]), int(order[-2])]]    # mixed
+            q_ptr = np.concatenate([[0], np.cumsum([len(x) for x in qs])]).astype(np.uint32)
+            q_terms = np.array([t for x in qs for t in x], dtype=np.uint32)
+            for k in (1, 100, 256, 257):
+                ref, ref_n = oracle.score_topk_batch(n_docs, tt, bb, m_t, m_b, q_ptr, q_terms, k)
+                hits, n_hits = sc.score_topk(q_ptr, q_terms, k)
+                assert_same_hits(hits, n_hits, ref, ref_n, exact=exact)
+                with ss_ctx.options(score__small=0):
+                    h0, n0 = sc.score_topk(q_ptr, q_terms, k)
+                assert h0.tobytes() == hits.tobytes() and n0.tolist() == n_hits.tolist()
+            # the cap boundary: shrink the cap to the postings of one query, then to one below
+            tq = [int(order[150]), int(order[151]), int(order[152])]
+            tot = int(b_len[tq].sum())
+            qp, qt = np.array([0, 3], dtype=np.uint32), np.array(tq, dtype=np.uint32)
+            ref, ref_n = oracle.score_topk_batch(n_docs, tt, bb, m_t, m_b, qp, qt, 10)
+            for cap in (tot, tot - 1, 0):
+                with ss_ctx.options(score__small_cap=cap):
+                    hits, n_hits = sc.score_topk(qp, qt, 10)
+                assert_same_hits(hits, n_hits, ref, ref_n, exact=exact)
+            # blended with a prior and hostile topic probabilities (negative, zero): exact stage semantics, no filter to switch off
+            prior = rng.random((4, n_docs)) * 1e-3
+            prior[:, rng.integers(0, n_docs, 20)] = -1.0
+            sc.set_prior(prior)
+            probs = rng.dirichlet(np.ones(4), size=len(qs))
+            probs[3] = [-0.5, 0.0, 2.0, 0.1]
+            ref, ref_n = oracle.score_topk_batch(n_docs, tt, bb, m_t, m_b, q_ptr, q_terms, 50, prior=np.ascontiguousarray(prior.T), topic_probs=probs)
+            hits, n_hits = sc.score_topk(q_ptr, q_terms, 50, topic_probs=probs)
+            assert_same_hits(hits, n_hits, ref, ref_n, exact=exact)
+            sc.set_prior(None)
+        finally:
+            close_all(sc, ti, bi)
