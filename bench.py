@@ -100,8 +100,10 @@ def profiled_traffic(kernel: str, pick: str = "median"):
     for path in reversed(files):
         try:
             rows = json.load(open(path))
-            rd = [r for r in rows if r["counter"] == "FETCH_SIZE" and kernel in r["kernel"]]
-            wr = [r for r in rows if r["counter"] == "WRITE_SIZE" and kernel in r["kernel"]]
+            # (the kernel itself or one of its template instances: "k_scatter" must not pick up the graph build's "k_scatter_runs")
+            is_k = lambda name: name == kernel or name.startswith(kernel + "<") or (kernel.endswith("<16") and name.startswith(kernel))
+            rd = [r for r in rows if r["counter"] == "FETCH_SIZE" and is_k(r["kernel"])]
+            wr = [r for r in rows if r["counter"] == "WRITE_SIZE" and is_k(r["kernel"])]
             if not rd or not wr:
                 continue
             key = "max_KB" if pick == "max" else "median_KB"

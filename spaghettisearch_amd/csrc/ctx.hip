@@ -290,6 +290,8 @@ static const char* const k_option_names[] = {
     "pr.blocks_per_cu",     // resident workgroups per CU of the sweep grid (default: the occupancy query)
     "mem.pool_mb",          // MiB of freed device blocks the library keeps for reuse (process-wide; default 65536, 0 = off)
     "pr.deal_snake",        // work items dealt to the waves in alternating direction (1) or least-loaded-first (0); default: 1 from 8 items per wave on and for k_pr_sweep_n
+    "pr.affine_lag",        // two-vector form on shards: default 1 = ONE collective per iteration (the per-topic sums ride in spare tail rows of the next
+                            //    iteration's all-gather, stop decisions one exchange late); 0 = a second, small all-gather per iteration (round 4)
     "pr.affine",            // 1: ss_pagerank_run computes every topic from TWO vectors (the reference's topics differ only in their start value 1/n_k,
                             //    and its recurrence maps (p*u + q) / (r*u + s) onto itself): opt-in, not the reference's operation order (~1e-13)
     "pr.items_per_wave",    // k_pr_sweep_n (K <= 2): the grid is cut so that every wave gets at least this many work items (default 4: a small graph's sweep costs per wave)

@@ -426,8 +426,9 @@ int32_t build(ss_graph* g, const uint64_t* out_ptr_in, const uint32_t* out_dst_i
     g->n_nd = h_nd;
     const uint64_t n_d = n - h_nd;
     // world>1: every rank's all-gather piece ends in two extra (edge-less) rows that carry
-    // its partial sums (contribution sum, L1 delta) — see pagerank.hip block_reduce_and_publish
-    g->sl_nd = (uint32_t)((h_nd + W - 1) / W) + (W > 1 ? 2u : 0u);
+    // its partial sums (contribution sum, L1 delta) — see pagerank.hip block_reduce_and_publish —, with TAIL_SUM_ROWS spare rows in
+    // front of them (the two-vector form's per-topic sums travel there instead of in a collective of their own)
+    g->sl_nd = (uint32_t)((h_nd + W - 1) / W) + (W > 1 ? 2u + TAIL_SUM_ROWS : 0u);
     g->sl_d = (uint32_t)((n_d + W - 1) / W);
     g->nd_int = (uint64_t)W * g->sl_nd;
     g->n_int = (uint64_t)W * ((uint64_t)g->sl_nd + g->sl_d);

@@ -17,6 +17,10 @@
 #pragma once
 #include "common.hpp"
 
+// world > 1: rows of a rank's all-gather piece in front of its two tail rows that can carry further partial sums of the rank (the
+// two-vector form's per-topic L1 sums ride there: 32 rows of two doubles = SS_MAX_TOPICS sums); zero unless somebody writes them
+constexpr uint32_t TAIL_SUM_ROWS = 32;
+
 struct ss_graph {
     ss_ctx* ctx = nullptr;
     uint64_t n = 0, e = 0;

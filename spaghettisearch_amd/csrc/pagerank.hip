@@ -1763,8 +1763,10 @@ __global__ __launch_bounds__(TPB) void k_aff_delta(const double2* __restrict__ x
 }
 // one block: the topics' L1 changes (block partials in block order + the edge-less rows, which all hold one value), pagerank.go:93
 // and the max_iter cut, per topic
+// `stride`: doubles between two blocks' (ranks') rows of sums — AFF_MAXK for a partials / gather buffer, sl_nd * 2 when the ranks' sums are
+// read where they arrived: in the spare tail rows of the all-gathered contribution table
 __global__ __launch_bounds__(AFF_MAXK) void k_aff_ctl(AffCtl* __restrict__ a, PrCtl* __restrict__ ctl, const double* __restrict__ partials, unsigned nb,
-                                                      double n_zero, double eps, int max_iter) {
+                                                      double n_zero, double eps, int max_iter, size_t stride) {
     __shared__ int s_na, s_nj;
     __shared__ double s_part[16][AFF_KC];
     __shared__ double s_dl[AFF_MAXK];
@@ -1781,7 +1783,7 @@ __global__ __launch_bounds__(AFF_MAXK) void k_aff_ctl(AffCtl* __restrict__ a, Pr
         const int j = k & (AFF_KC - 1), part = k >> 4;
         double v = 0.0;
         if (k0 + j < k_real)
-            for (unsigned b = (unsigned)part; b < nb; b += 16) v += partials[(size_t)b * AFF_MAXK + k0 + j];
+            for (unsigned b = (unsigned)part; b < nb; b += 16) v += partials[(size_t)b * stride + k0 + j];
         s_part[part][j] = v;
         __syncthreads();
         if (k < AFF_KC) {
@@ -1870,16 +1872,19 @@ __global__ __launch_bounds__(AFF_MAXK) void k_aff_local(const AffCtl* __restrict
 // ... and the ranks of the topics that have just stopped, for this rank's rows in local order (out[k][row], as ss_pr_read_local)
 __global__ __launch_bounds__(TPB) void k_aff_emit_local(const double2* __restrict__ x, const PrCtl* __restrict__ ctl, const AffCtl* __restrict__ a,
                                                         uint32_t sl_nd, uint32_t cnt_nd, uint32_t cnt_d, uint32_t pos_nd, uint32_t pos_d,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ out, int lag) {
     if (a->n_just == 0) return;
-    const double r = a->r_x, sx = a->s_x;
+    // lag: the decision arrives one exchange late (its sums rode on the next iteration's all-gather): `x` are the vectors BEFORE the last
+    // sweep, and their r, s and edge-less rows are the control block's "previous" ones
+    const double r = lag ? a->r_prev : a->r_x, sx = lag ? a->s_prev : a->s_x;
+    const double xz0 = lag ? a->xz_prev[0] : ctl->xz[0], xz1 = lag ? a->xz_prev[1] : ctl->xz[1];
     const int k_real = a->k_real;
     const uint32_t n_rows = cnt_nd + cnt_d;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
         const uint32_t lrow = i < cnt_nd ? i : sl_nd + (i - cnt_nd);
         const bool zero = lrow < sl_nd ? lrow >= pos_nd : (lrow - sl_nd) >= pos_d;
         double2 pq;
-        if (zero) pq = make_double2(ctl->xz[0], ctl->xz[1]);
+        if (zero) pq = make_double2(xz0, xz1);
         else pq = x[lrow];
         for (int k = 0; k < k_real; k++)
             if (a->just[k]) {
@@ -1933,8 +1938,9 @@ __global__ void k_wire_unpack(const float* __restrict__ in, uint32_t world, uint
     const float* src = in + r * per_in;
     table[i] = j < n_body ? (double)src[j] : (double)src[n_body + 2 * (j - n_body)] + (double)src[n_body + 2 * (j - n_body) + 1];
 }
-// floats a rank sends: the slice's body rows + its two tail rows as pairs
-size_t wire_floats(const ss_pr* pr) { return (size_t)pr->g->sl_nd * pr->gw + 2 * (size_t)pr->gw; }
+// floats a rank sends: the slice's body rows + its tail rows (the two sums rows and the TAIL_SUM_ROWS in front of them) as pairs
+constexpr uint32_t WIRE_TAIL_ROWS = 2u + TAIL_SUM_ROWS;
+size_t wire_floats(const ss_pr* pr) { return (size_t)pr->g->sl_nd * pr->gw + (size_t)WIRE_TAIL_ROWS * (size_t)pr->gw; }
 hipError_t wire_alloc(ss_pr* pr) {
     if (pr->wire_send.p) return hipSuccess;
     hipError_t e = pr->wire_send.alloc(wire_floats(pr));
@@ -1942,11 +1948,11 @@ hipError_t wire_alloc(ss_pr* pr) {
     return e;
 }
 void wire_pack(ss_pr* pr, hipStream_t st) {
-    const uint32_t n_tail = 2u * (uint32_t)pr->gw, n_body = pr->g->sl_nd * (uint32_t)pr->gw - n_tail;
+    const uint32_t n_tail = WIRE_TAIL_ROWS * (uint32_t)pr->gw, n_body = pr->g->sl_nd * (uint32_t)pr->gw - n_tail;
     hipLaunchKernelGGL(k_wire_pack, dim3(ss::div_up((size_t)n_body + n_tail, TPB)), dim3(TPB), 0, st, (const double*)pr->send.p, n_body, n_tail, pr->wire_send.p);
 }
 void wire_unpack(ss_pr* pr, hipStream_t st) {
-    const uint32_t n_tail = 2u * (uint32_t)pr->gw, n_body = pr->g->sl_nd * (uint32_t)pr->gw - n_tail;
+    const uint32_t n_tail = WIRE_TAIL_ROWS * (uint32_t)pr->gw, n_body = pr->g->sl_nd * (uint32_t)pr->gw - n_tail;
     hipLaunchKernelGGL(k_wire_unpack, dim3(ss::div_up(((size_t)n_body + n_tail) * pr->g->world, TPB)), dim3(TPB), 0, st, (const float*)pr->wire_recv.p,
                        (uint32_t)pr->g->world, n_body, n_tail, pr->tab0.p);
 }
@@ -2726,30 +2732,51 @@ int32_t run_affine_sharded(ss_ctx* ctx, std::vector<ShardBlocks>& sh, std::vecto
     for (int s = 0; s < S; s++) launch_finalize<2>(sh[s].blk[0], st, 1);
     int32_t n_active = k_topics, it = 0;
     const int BATCH = 4;
+    // ONE collective per iteration (option "pr.affine_lag", default 1): the ranks' per-topic L1 sums of iteration i are written into the
+    // spare tail rows of the rank's contribution slice (graph.hpp: TAIL_SUM_ROWS) and travel with iteration i + 1's all-gather, so the
+    // stop decisions of iteration i are taken one exchange later — from the same numbers, added in the same rank order — and the ranks
+    // of a topic that stops are written from the vectors of the iteration it stopped in, which the alternating pair still holds.
+    // A second, 2 KB all-gather per iteration was pure latency on a ~0.25 ms iteration; it survives only as the flush
+    // after the last sweep of a max_iter run.  0: the round-4 protocol (sums in a collective of their own, decisions at once).
+    const bool lag = ctx->opt("pr.affine_lag", 1) != 0;
+    auto sums_row = [&](ss_pr* pr, double* base) { return base + ((size_t)pr->g->sl_nd - 2 - TAIL_SUM_ROWS) * 2; };
+    auto delta_and_local = [&](int s, double* loc) {
+        ss_pr* pr = sh[s].blk[0];
+        const ss_graph* g = pr->g;
+        const double2* const x_old = reinterpret_cast<const double2*>((it & 1) ? A[s].x_alt.p : pr->x.p);
+        const double2* const x_new = reinterpret_cast<const double2*>((it & 1) ? pr->x.p : A[s].x_alt.p);
+        hipLaunchKernelGGL(k_aff_delta, dim3(AFF_NB), dim3(TPB), 0, st, x_old, x_new, (const AffCtl*)A[s].aff.p, g->sl_nd, pr->prm.pos_nd, pr->prm.pos_d,
+                           A[s].partials.p);
+        hipLaunchKernelGGL(k_aff_local, dim3(1), dim3(AFF_MAXK), 0, st, (const AffCtl*)A[s].aff.p, (const PrCtl*)pr->ctl.p, (const double*)A[s].partials.p,
+                           AFF_NB, A[s].n_zero, loc);
+    };
+    auto ctl_and_emit = [&](int s, const double* sums, size_t stride, int emit_lag) {
+        ss_pr* pr = sh[s].blk[0];
+        const ss_graph* g = pr->g;
+        // (emit_lag: the vectors before the last sweep — iteration it - 1 — else the ones it has just written)
+        const bool odd = (it & 1) != 0;
+        const double2* const x_src = reinterpret_cast<const double2*>(emit_lag ? (odd ? A[s].x_alt.p : pr->x.p) : (odd ? pr->x.p : A[s].x_alt.p));
+        hipLaunchKernelGGL(k_aff_ctl, dim3(1), dim3(AFF_MAXK), 0, st, A[s].aff.p, pr->ctl.p, sums, (unsigned)world, 0.0, eps, max_iter, stride);
+        const unsigned nbe = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(4096, ss::div_up((uint64_t)g->cnt_nd + g->cnt_d, TPB)));
+        hipLaunchKernelGGL(k_aff_emit_local, dim3(nbe), dim3(TPB), 0, st, x_src, (const PrCtl*)pr->ctl.p, (const AffCtl*)A[s].aff.p, g->sl_nd, g->cnt_nd,
+                           g->cnt_d, pr->prm.pos_nd, pr->prm.pos_d, A[s].out.p, emit_lag);
+    };
     while (n_active > 0) {
         for (int b = 0; b < BATCH; b++) {
             for (int s = 0; s < S; s++) launch_step<2>(sh[s].blk[0], st);
             SS_TRY(exchange(0, st));
             for (int s = 0; s < S; s++) launch_finalize<2>(sh[s].blk[0], st, 0);
-            for (int s = 0; s < S; s++) {
-                ss_pr* pr = sh[s].blk[0];
-                const ss_graph* g = pr->g;
-                const double2* const x_old = reinterpret_cast<const double2*>((it & 1) ? A[s].x_alt.p : pr->x.p);
-                const double2* const x_new = reinterpret_cast<const double2*>((it & 1) ? pr->x.p : A[s].x_alt.p);
-                hipLaunchKernelGGL(k_aff_delta, dim3(AFF_NB), dim3(TPB), 0, st, x_old, x_new, (const AffCtl*)A[s].aff.p, g->sl_nd, pr->prm.pos_nd, pr->prm.pos_d,
-                                   A[s].partials.p);
-                hipLaunchKernelGGL(k_aff_local, dim3(1), dim3(AFF_MAXK), 0, st, (const AffCtl*)A[s].aff.p, (const PrCtl*)pr->ctl.p, (const double*)A[s].partials.p,
-                                   AFF_NB, A[s].n_zero, A[s].loc.p);
-            }
-            SS_TRY(exchange_sums(st));
-            for (int s = 0; s < S; s++) {
-                ss_pr* pr = sh[s].blk[0];
-                const ss_graph* g = pr->g;
-                const double2* const x_new = reinterpret_cast<const double2*>((it & 1) ? pr->x.p : A[s].x_alt.p);
-                hipLaunchKernelGGL(k_aff_ctl, dim3(1), dim3(AFF_MAXK), 0, st, A[s].aff.p, pr->ctl.p, (const double*)A[s].gath.p, (unsigned)world, 0.0, eps, max_iter);
-                const unsigned nbe = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(4096, ss::div_up((uint64_t)g->cnt_nd + g->cnt_d, TPB)));
-                hipLaunchKernelGGL(k_aff_emit_local, dim3(nbe), dim3(TPB), 0, st, x_new, (const PrCtl*)pr->ctl.p, (const AffCtl*)A[s].aff.p, g->sl_nd, g->cnt_nd,
-                                   g->cnt_d, pr->prm.pos_nd, pr->prm.pos_d, A[s].out.p);
+            if (lag) {
+                for (int s = 0; s < S; s++) {
+                    ss_pr* pr = sh[s].blk[0];
+                    // iteration it - 1: its sums have just arrived with this iteration's table (every rank's slice, rank order)
+                    if (it > 0) ctl_and_emit(s, sums_row(pr, pr->tab0.p), (size_t)pr->g->sl_nd * 2, 1);
+                    delta_and_local(s, sums_row(pr, pr->send.p));              // iteration it: into the slice the NEXT all-gather sends
+                }
+            } else {
+                for (int s = 0; s < S; s++) delta_and_local(s, A[s].loc.p);
+                SS_TRY(exchange_sums(st));
+                for (int s = 0; s < S; s++) ctl_and_emit(s, A[s].gath.p, (size_t)AFF_MAXK, 0);
             }
             it++;
             if (max_iter > 0 && it >= max_iter) break;
@@ -2761,6 +2788,20 @@ int32_t run_affine_sharded(ss_ctx* ctx, std::vector<ShardBlocks>& sh, std::vecto
         SS_TRY(ss::sync_bounded(ctx, st, "sharded two-vector sweep (waiting for the exchange)"));
         n_active = *hn;
         if (max_iter > 0 && it >= max_iter) break;
+    }
+    if (lag && max_iter > 0 && it >= max_iter && n_active > 0) {
+        // the last sweep's sums have no further all-gather to ride on: one small collective of their own, then the decisions (every
+        // topic still running stops here: it >= max_iter) and the ranks from the vectors that sweep has written
+        it--;                                                          // (the lambdas take the parity of the sweep they describe)
+        for (int s = 0; s < S; s++) {
+            ss_pr* pr = sh[s].blk[0];
+            hipLaunchKernelGGL(k_aff_local, dim3(1), dim3(AFF_MAXK), 0, st, (const AffCtl*)A[s].aff.p, (const PrCtl*)pr->ctl.p, (const double*)A[s].partials.p,
+                               AFF_NB, A[s].n_zero, A[s].loc.p);
+        }
+        SS_TRY(exchange_sums(st));
+        for (int s = 0; s < S; s++) ctl_and_emit(s, A[s].gath.p, (size_t)AFF_MAXK, 0);
+        it++;
+        SS_HIP(ctx, hipGetLastError());
     }
     for (int s = 0; s < S; s++) sh[s].blk[0]->need_finalize = false;
     if (iters_out) {
@@ -3120,7 +3161,7 @@ static int32_t run_affine(ss_graph* g, double damping, double eps, int32_t max_i
             const double2* const x_new = reinterpret_cast<const double2*>((it & 1) ? pr->x.p : x_prev.p);
             launch_step<2>(pr, st);
             hipLaunchKernelGGL(k_aff_delta, dim3(AFF_NB), dim3(TPB), 0, st, x_old, x_new, (const AffCtl*)aff.p, g->sl_nd, pr->prm.pos_nd, pr->prm.pos_d, partials.p);
-            hipLaunchKernelGGL(k_aff_ctl, dim3(1), dim3(AFF_MAXK), 0, st, aff.p, pr->ctl.p, (const double*)partials.p, AFF_NB, n_zero, eps, max_iter);
+            hipLaunchKernelGGL(k_aff_ctl, dim3(1), dim3(AFF_MAXK), 0, st, aff.p, pr->ctl.p, (const double*)partials.p, AFF_NB, n_zero, eps, max_iter, (size_t)AFF_MAXK);
             hipLaunchKernelGGL(k_aff_emit, dim3((unsigned)std::min<uint64_t>(4096, ss::div_up(g->n, TPB))), dim3(TPB), 0, st, x_new, (const PrCtl*)pr->ctl.p,
                                (const AffCtl*)aff.p, (const uint32_t*)g->new_id.p, g->n, g->sl_nd, pr->prm.pos_nd, pr->prm.pos_d, out);
             it++;

@@ -11,6 +11,9 @@ import numpy as np
 import torch
 
 
+TAIL_SUM_ROWS = 32
+
+
 class NumpyShardState:
     def __init__(self, n_nodes, out_ptr, out_dst, d, eps, n_topic, rank, world, max_iter=0):
         self.n_nodes, self.rank, self.world = int(n_nodes), rank, world
@@ -25,7 +28,8 @@ class NumpyShardState:
         cls = (outdeg == 0).astype(np.int64)
         order = np.lexsort((np.arange(N), -indeg, cls))            # class, in-degree desc, id asc
         n_nd = int((outdeg > 0).sum())
-        tails = 2 if world > 1 else 0
+        # two tail rows (contribution sum, L1 delta) behind TAIL_SUM_ROWS spare rows (csrc/graph.hpp: the two-vector form's per-topic sums)
+        tails = 2 + TAIL_SUM_ROWS if world > 1 else 0
         self.sl_nd = -(-n_nd // world) + tails
         nd_sorted, d_sorted = order[:n_nd], order[n_nd:]
         # internal (table) id of every non-dangling node
@@ -154,9 +158,36 @@ class NumpyAffineShard(NumpyShardState):
         t = self.table.reshape(self.world, self.sl_nd, self.k)
         return t[:, -2].sum(axis=0)
 
-    def run(self):
+    def run(self, lag=True):
+        """lag (the library's default, option pr.affine_lag): ONE exchange per iteration — the per-topic L1 sums of iteration i ride in
+        the spare tail rows of iteration i + 1's slice, the stop decisions of iteration i are taken one exchange late and the ranks
+        of a topic that stops are taken from the vectors of the iteration it stopped in; after the last sweep of a max_iter run the
+        sums get a small exchange of their own.  lag=False: the round-4 protocol (a second, small exchange per iteration)."""
         tele_n = (1.0 - self.d) * self.n_nodes
         tau = 1.0 - self.d
+        assert self.world == 1 or self.K <= 2 * TAIL_SUM_ROWS
+        sums_lo = self.sl_nd - 2 - TAIL_SUM_ROWS
+
+        def decide(tot, it, new):
+            for k in range(self.K):
+                if self.t_active[k]:
+                    self.t_iters[k] = it
+                    cont = tot[k] > self.eps_t
+                    if self.max_iter_t > 0 and it >= self.max_iter_t:
+                        cont = False
+                    if not cont:
+                        self.t_active[k] = False
+                        self.out[k] = new[:, k]
+
+        def gather_small(loc):
+            allv = torch.empty(self.world * self.K, dtype=torch.float64)
+            self._gather(torch.from_numpy(loc), allv)
+            dl = allv.reshape(self.world, self.K).numpy()
+            tot = np.zeros(self.K)
+            for r in range(self.world):
+                tot += dl[r]
+            return tot
+
         # begin
         self.x[:] = self.x0
         c = self.d * self.x[:len(self.own_nd)] / self.outdeg_nd[:, None]
@@ -167,6 +198,7 @@ class NumpyAffineShard(NumpyShardState):
         sigma = r1 + s1
         self.r_next, self.s_next = r1 / sigma, s1 / sigma
         it = 0
+        pending = None          # (ranks of the vectors of the iteration whose sums are on their way)
         while self.t_active.any():
             y = np.zeros_like(self.x)
             np.add.at(y, self.e_row, self.table[self.e_src])
@@ -177,7 +209,7 @@ class NumpyAffineShard(NumpyShardState):
             self.x = xn
             c = self.d * xn[:len(self.own_nd)] / self.outdeg_nd[:, None]
             self._publish(c, np.zeros(self.k))
-            self._exchange_table()
+            self._exchange_table()                                # (lag: carries the previous iteration's per-topic sums)
             cs = self._sums()
             r_prev, s_prev = self.r_x, self.s_x
             self.r_x, self.s_x = self.r_next, self.s_next
@@ -185,26 +217,25 @@ class NumpyAffineShard(NumpyShardState):
             sigma = r1 + s1
             self.r_next, self.s_next = r1 / sigma, s1 / sigma
             self.tele = np.array([tau * self.r_x, tau * self.s_x])
-            # the topics' L1 changes: local sums, gathered, added in rank order
             new = (xn[:, :1] * self.u + xn[:, 1:2]) / (self.r_x * self.u + self.s_x)
             old = (xo[:, :1] * self.u + xo[:, 1:2]) / (r_prev * self.u + s_prev)
-            loc = torch.from_numpy(np.abs(new - old).sum(axis=0))
-            allv = torch.empty(self.world * self.K, dtype=torch.float64)
-            self._gather(loc, allv)
-            dl = allv.reshape(self.world, self.K).numpy()
-            tot = np.zeros(self.K)
-            for r in range(self.world):
-                tot += dl[r]
-            it += 1
-            for k in range(self.K):
-                if self.t_active[k]:
-                    self.t_iters[k] = it
-                    cont = tot[k] > self.eps_t
-                    if self.max_iter_t > 0 and it >= self.max_iter_t:
-                        cont = False
-                    if not cont:
-                        self.t_active[k] = False
-                        self.out[k] = new[:, k]
+            loc = np.abs(new - old).sum(axis=0)
+            if lag and self.world > 1:
+                if pending is not None:
+                    t = self.table.reshape(self.world, self.sl_nd * self.k)
+                    tot = np.zeros(self.K)
+                    for r in range(self.world):                   # rank order
+                        tot += t[r, sums_lo * self.k: sums_lo * self.k + self.K]
+                    decide(tot, it, pending)
+                flat = self.send.reshape(-1)
+                flat[sums_lo * self.k: sums_lo * self.k + self.K] = loc      # rides with the next slice
+                pending = new
+                it += 1
+                if self.max_iter_t > 0 and it >= self.max_iter_t and self.t_active.any():
+                    decide(gather_small(loc), it, new)            # the flush after the last sweep
+            else:
+                it += 1
+                decide(gather_small(loc), it, new)
         return self.own.astype(np.uint32), self.out, self.t_iters
 
 

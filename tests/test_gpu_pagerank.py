@@ -385,8 +385,8 @@ def test_in_library_pipelined_sharded_run(ss_ctx, oracle, world):
             g.close()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_two_vector_form_on_a_sharded_graph(ss_ctx, oracle, world):
+@pytest.mark.parametrize("world,lag", [(2, 1), (4, 1), (3, 0)])
+def test_two_vector_form_on_a_sharded_graph(ss_ctx, oracle, world, lag):
     """Option "pr.affine" on doc-range shards (ss_pagerank_run_group: all shards in this process, device copies standing in for
     the RCCL all-gathers): ONE K = 2 state per shard, a two-column exchange per iteration whatever the topic count, the topics'
     L1 changes summed over the shards in rank order, every shard writing the ranks of its own rows.  Against the oracle
@@ -397,8 +397,10 @@ def test_two_vector_form_on_a_sharded_graph(ss_ctx, oracle, world):
     graphs = [engine.Graph(ss_ctx, n, ptr, dst, rank=r, world=world) for r in range(world)]
     one = engine.Graph(ss_ctx, n, ptr, dst)
     try:
-        with ss_ctx.options(pr__affine=1):
-            for k_topics in (1, 16, 40):
+        # lag = 1 (default): ONE exchange per iteration — the per-topic sums of iteration i ride in the spare tail rows of iteration
+        # i + 1's slice, decisions one exchange late, a flush after the last sweep of a max_iter run; 0: round 4's second small exchange
+        with ss_ctx.options(pr__affine=1, pr__affine_lag=lag):
+            for k_topics in (1, 16, 40, 64):
                 n_topic = synth.topic_sizes(n, k_topics)
                 ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-9, n_topic)
                 rank, iters = engine.Graph.pagerank_group(graphs, D, 1e-9, n_topic)

@@ -109,14 +109,14 @@ def test_pipelined_topic_blocks_gloo_match_oracle(tmp_path, world):
 
 
 # ---- the two-vector form on doc-range shards (library option "pr.affine", csrc/pagerank.hip run_affine_sharded) ---------------------
-def _worker_affine(rank, world, port, n, e, n_topic, eps, max_iter, out_path):
+def _worker_affine(rank, world, port, n, e, n_topic, eps, max_iter, out_path, lag=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ptr, dst = synth.rmat_graph(n, e, seed=31)
         st = NumpyAffineShard(n, ptr, dst, D, eps, n_topic, rank, world, max_iter=max_iter)
-        ids, ranks, iters = st.run()
+        ids, ranks, iters = st.run(lag=lag)
         # assemble by original id on rank 0
         sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(sizes, torch.tensor([len(ids)], dtype=torch.int64))
@@ -140,14 +140,16 @@ def _worker_affine(rank, world, port, n, e, n_topic, eps, max_iter, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_two_vector_form_on_gloo_shards_matches_oracle(tmp_path, world):
-    """The sharded two-vector protocol (a 2-column exchange and an all-gather of the ranks' K local L1 sums per iteration, stop
-    rule from the sums added in rank order) between real processes: every topic's ranks and iteration count as the oracle's."""
+@pytest.mark.parametrize("world,lag", [(2, True), (3, True), (8, True), (2, False), (8, False)])
+def test_two_vector_form_on_gloo_shards_matches_oracle(tmp_path, world, lag):
+    """The sharded two-vector protocol between real processes: lag = ONE exchange per iteration (the ranks' K local L1 sums of
+    iteration i ride in the spare tail rows of iteration i + 1's 2-column slice; stop decisions one exchange late, from the sums
+    added in rank order; a small exchange of their own only after the last sweep of a max_iter run), or the round-4 form with a
+    second, small all-gather per iteration.  Every topic's ranks and iteration count as the oracle's."""
     n, e = 4000, 22000
-    for n_topic, eps, max_iter in ((synth.topic_sizes(n, 9), EPS, 0), ([n, 7, 123], 1e-30, 4)):
+    for n_topic, eps, max_iter in ((synth.topic_sizes(n, 9), EPS, 0), ([n, 7, 123], 1e-30, 4), (synth.topic_sizes(n, 64), 1e-8, 0)):
         out = str(tmp_path / f"aff{len(n_topic)}.npz")
-        mp.spawn(_worker_affine, args=(world, _free_port(), n, e, list(n_topic), eps, max_iter, out), nprocs=world, join=True)
+        mp.spawn(_worker_affine, args=(world, _free_port(), n, e, list(n_topic), eps, max_iter, out, lag), nprocs=world, join=True)
         got = np.load(out)
         ptr, dst = synth.rmat_graph(n, e, seed=31)
         ref, ref_iters = pyoracle.pagerank(n, ptr, dst, D, eps, n_topic, max_iter=max_iter)
