@@ -554,6 +554,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
     // of registers; the late loads measured no slower and leave the registers to the compiler.)
     uint32_t doc[SC_PT];
     float w[SC_PT];
+    uint32_t head_mask = 0u;                                               // postings of doc[] that belong to a head list (see loads / apply_head)
     // head lists are not partitioned (k_bucket_sum reads them in place): their postings count as absent here
     const uint32_t nh = head.n ? *head.n : 0u;
     uint32_t hcur = nh ? head_first(head, nh, r0) : 0u;
@@ -582,10 +583,17 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
                 doc[v4 * 4] = d.x; doc[v4 * 4 + 1] = d.y; doc[v4 * 4 + 2] = d.z; doc[v4 * 4 + 3] = d.w;
                 w[v4 * 4] = f.x; w[v4 * 4 + 1] = f.y; w[v4 * 4 + 2] = f.z; w[v4 * 4 + 3] = f.w;
             }
+            // Which of these postings belong to a head list is a matter of their POSITIONS: noted here, applied to doc[] where the chunk
+            // is first looked at (apply_head), so that nothing in this phase depends on the loads just issued.  [Round 5 suspected the
+            // select that used to stand here of making every wave sit out the next chunk's memory latency inside the staging phase —
+            // 32-35 % of a chunk's cycles in the phase clocks.  Moving it changed nothing (5.13 ms either way): the phase is long because
+            // its barrier waits for the slowest of sixteen waves on a shared LDS pipe, not because of a stalled load.]
+            head_mask = 0u;
 #pragma unroll
             for (int j = 0; j < SC_PT; j++)
-                if (nh && hk.hit(i0 + j)) doc[j] = 0xFFFFFFFFu;
+                if (nh && hk.hit(i0 + j)) head_mask |= 1u << j;
         } else {
+            head_mask = 0u;
 #pragma unroll
             for (int j = 0; j < SC_PT; j++) {
                 const uint64_t i = i0 + j;
@@ -594,6 +602,12 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
                 w[j] = ok ? post_w[i] : 0.f;
             }
         }
+    };
+    auto apply_head = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SC_PT; j++)
+            if ((head_mask >> j) & 1u) doc[j] = 0xFFFFFFFFu;
+        head_mask = 0u;
     };
     meta(r0);
     loads(r0);
@@ -615,6 +629,7 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
         uint32_t rank2[SC_PT / 2];                                        // two 16-bit ranks to a register
         SC_PH(7);
         const bool empty = cur_empty;
+        apply_head();                                                      // (the chunk's postings have had the previous write-out to arrive)
         const uint32_t h_here = hcur;                                      // the head range running at `base` (before meta moves on)
         meta(base + SC_CH);
         cur_empty = n_empty;                                               // ... of the next chunk, for the next turn
@@ -773,8 +788,8 @@ __global__ __launch_bounds__(SC_TPB, SS_SC_MINW) void k_scatter(const uint32_t* 
         __syncthreads();
         uint32_t o = incl - run;
         {
-            // the earlier waves' totals: all SC_TPB / 64 words with wide loads issued together (a loop of `wv` dependent 4-byte reads
-            // was up to 15 LDS latencies for the last wave, 15 % of a chunk's cycles in the phase clocks of round 5)
+            // the earlier waves' totals: all SC_TPB / 64 words with wide loads issued together instead of a loop of `wv` dependent
+            // 4-byte reads (up to 15 LDS latencies for the last wave; no measurable change in the build time)
             constexpr int NW4 = (SC_TPB / 64 + 3) / 4;
             uint4 pw[NW4];
 #pragma unroll
