@@ -1,7 +1,9 @@
 """CPU check of the cgo shim (go/): there is no Go toolchain in this image, so nothing compiles go/spaghetti/spaghetti.go.
 This test is the mechanical stand-in for the part of `go vet` that matters at the boundary: every `C.ss_*(...)` call in the
 Go sources names a function that include/spaghetti_rank.h declares and passes exactly as many arguments as the prototype has
-parameters; every `C.ss_*` type and every `C.SS_*` constant used exists in the header."""
+parameters; every `C.ss_*` type and every `C.SS_*` constant used exists in the header; and (round 5) every argument whose C type can
+be read off the Go expression — a `C.int32_t(...)`-style conversion, one of the shim's slice-to-pointer helpers (`u32p`, `u64p`, `i32p`,
+`f32p`, `f64p`), a `(*C.ss_hit)(...)` cast — has the type of the parameter it is passed for."""
 import glob
 import os
 import re
@@ -96,3 +98,67 @@ def test_cgo_types_and_constants_exist_in_the_header():
             assert t in types, (path, t)
         for c in set(re.findall(r"\bC\.(SS_[A-Z_0-9]+)\b", body)):
             assert c in consts, (path, c)
+
+
+def prototype_types():
+    """name -> [normalised parameter type] from the header (names and const dropped, spaces squeezed: 'uint32_t*', 'int32_t', 'ss_hit*')"""
+    text = _strip_c_comments(open(HEADER).read())
+    out = {}
+    for m in re.finditer(r"\b(?:int32_t|const\s+char\s*\*)\s*(ss_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        params = m.group(2).strip()
+        types = []
+        if params not in ("", "void"):
+            for prm in _split_top_level(params):
+                prm = re.sub(r"\bconst\b", " ", prm)
+                mm = re.match(r"^\s*([A-Za-z_][A-Za-z0-9_]*(?:\s+[A-Za-z_][A-Za-z0-9_]*)*?)\s*((?:\*\s*(?:const\s*)?)*)\s*([A-Za-z_][A-Za-z0-9_]*)?\s*$", prm)
+                assert mm, (m.group(1), prm)
+                types.append(re.sub(r"\s+", " ", mm.group(1)).strip() + mm.group(2).replace(" ", ""))
+        out[m.group(1)] = types
+    return out
+
+
+HELPERS = {"u32p": "uint32_t*", "u64p": "uint64_t*", "i32p": "int32_t*", "f32p": "float*", "f64p": "double*"}
+
+
+def go_arg_type(expr):
+    """the C type a Go argument expression certainly has, or None"""
+    expr = expr.strip()
+    m = re.match(r"^C\.([a-z0-9_]+)\(", expr)
+    if m:
+        return m.group(1)
+    m = re.match(r"^([a-z0-9]+p)\(", expr)
+    if m and m.group(1) in HELPERS:
+        return HELPERS[m.group(1)]
+    m = re.match(r"^\(\*C\.([a-z0-9_]+)\)\(", expr)
+    if m:
+        return m.group(1) + "*"
+    return None
+
+
+def test_cgo_argument_types_match_the_header():
+    types = prototype_types()
+    assert types["ss_score_topk"] == ["ss_scorer*", "int32_t", "uint32_t*", "uint32_t*", "int32_t*", "double*", "int32_t", "ss_hit*", "int32_t*"]
+    checked, bad = 0, []
+    for path in sorted(glob.glob(os.path.join(ROOT, "go", "*", "*.go"))):
+        src = open(path, encoding="utf-8").read()
+        src = re.sub(r"/\*.*?\*/", lambda m: "\n" * m.group(0).count("\n"), src, flags=re.S)
+        src = "\n".join(re.sub(r"//.*$", "", line) for line in src.split("\n"))
+        for m in re.finditer(r"\bC\.(ss_[a-z0-9_]+)\s*\(", src):
+            name = m.group(1)
+            if name not in types:
+                continue
+            i, depth = m.end(), 1
+            while depth and i < len(src):
+                depth += src[i] in "([{"
+                depth -= src[i] in ")]}"
+                i += 1
+            args = _split_top_level(src[m.end():i - 1].strip()) if src[m.end():i - 1].strip() else []
+            for pos, (arg, want) in enumerate(zip(args, types[name])):
+                got = go_arg_type(arg)
+                if got is None:
+                    continue
+                checked += 1
+                if got != want and not (want == "void*" and got.endswith("*")):
+                    bad.append(f"{os.path.relpath(path, ROOT)}:{src.count(chr(10), 0, m.start()) + 1}: {name} argument {pos + 1} is {got}, the header says {want}")
+    assert not bad, "\n".join(bad)
+    assert checked >= 100          # (110 at the time of writing: every argument spelled with a conversion, a helper or a cast; handles and nil are not)
