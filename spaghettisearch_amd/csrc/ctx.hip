@@ -298,6 +298,7 @@ static const char* const k_option_names[] = {
     "pr.persistent",        // K <= 2 on one rank: ss_pr_step's sweeps run inside ONE launch, the blocks waiting for each other between sweeps (k_pr_multi_n):
                             //    1 = write-through hand-offs, 2 = release / acquire fences.  Default 0 (measured slower than one launch per sweep: DESIGN K1c)
     "pr.persistent_blocks", // ... resident blocks per CU of that launch (default 4, at most half of what the occupancy query admits)
+    "pr.n_class_order",     // k_pr_sweep_n (K <= 2): the order of its four phases, four digits (0 = long rows, 1 = mid rows, 2 = rows of <= 8 in-edges, 3 = edge-less rows)
     "pr.class_order",       // k_pr_sweep: the order in which a wave walks its work classes, six decimal digits naming the classes 0 = long rows, 1 = mid rows, 2 / 3 / 4 = rows of <= 2 / 4 / 8 in-edges, 5 = edge-less rows (default 235401: short rows first)
     "pr.stagger",           // default 0: every block of k_pr_sweep walks the work classes in the same order ("pr.class_order"); 1: the resident blocks of a CU
                             //    start at different positions of it (by arrival round; round 4's default); >= 10: 10 + the rounds' start positions as base-6 digits

@@ -1882,13 +1882,23 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     uint64_t slice_target = SLICE_TARGET;
     uint64_t grade_tot = 0, grade_seen = 0;
     const bool grade_slices = ctx->opt("score.grade_slices", 0) != 0;
+    // The tokens' list lengths, looked up ONCE: the two host copies of term_ptr are 8 MB each at config 3 and a batch's terms are
+    // scattered over them, so every look-up is a cache miss — and the plan used to make them in three passes (batch total, the
+    // wave kernel's suitability test, the per-query slicing): 37k misses per 1024-query batch, most of the 43 us the plan took for a
+    // batch of tail queries (round 5: `score.trace`, tools/host_tail.py).  0 / 0 for unknown terms.
+    static thread_local std::vector<uint32_t> tok_lt, tok_lb;
+    tok_lt.resize(n_tok);
+    tok_lb.resize(n_tok);
+    uint64_t tok_tot = 0;
+    for (uint32_t i = 0; i < n_tok; i++) {
+        const uint32_t t = h_terms[i];
+        const bool known = (uint64_t)t < s->n_terms;
+        tok_lt[i] = known ? (uint32_t)(tp[t + 1] - tp[t]) : 0u;       // (a posting list is shorter than 2^32: ss_index_create)
+        tok_lb[i] = known ? (uint32_t)(bp[t + 1] - bp[t]) : 0u;
+        tok_tot += (uint64_t)tok_lt[i] + tok_lb[i];
+    }
     {
-        uint64_t batch_tot = 0;
-        for (int q = 0; q < n_q; q++)
-            for (uint32_t i = h_qptr[q]; i < h_qptr[q + 1]; i++) {
-                const uint32_t t = h_terms[i];
-                if ((uint64_t)t < s->n_terms) batch_tot += (tp[t + 1] - tp[t]) + (bp[t + 1] - bp[t]);
-            }
+        const uint64_t batch_tot = tok_tot;
         const uint64_t slots = (uint64_t)std::max(ctx->cu_count, 1) * SS_WGS_PER_CU;
         // measured (10M docs, 3-term head queries, batches of 1..4096): one partial wave of slices is best — about
         // 1.5x the batch's postings per resident workgroup slot, never below SLICE_MIN (a slice costs ~45 us of
@@ -1913,9 +1923,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (wave_ok) {
         // about 5.5 slices per nine-wave-per-CU slot (four rounds of the 12 waves a CU holds), 8k .. 48k postings each
         const uint64_t slots = (uint64_t)std::max(ctx->cu_count, 1) * 9;
-        uint64_t batch_tot = 0;
-        for (uint32_t i = 0; i < n_tok; i++)
-            if ((uint64_t)h_terms[i] < s->n_terms) batch_tot += (tp[h_terms[i] + 1] - tp[h_terms[i]]) + (bp[h_terms[i] + 1] - bp[h_terms[i]]);
+        const uint64_t batch_tot = tok_tot;
         wave_target = std::min<uint64_t>(49152, std::max<uint64_t>(8192, batch_tot * 2 / (11 * slots)));          // (config 3, ms per batch at 6k / 8k / 10k / 12k / 14k / 17k / 21k postings: 0.661 / 0.635 / 0.616 / 0.623 / 0.655 / 0.649 / 0.639)
         wave_target = (uint64_t)std::max<int64_t>(1024, ctx->opt("score.wave_slice_target", (int64_t)wave_target));
     }
@@ -1943,8 +1951,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
                 const uint32_t t = h_terms[i];
                 if ((uint64_t)t >= s->n_terms) continue;
                 n_known++;
-                tot += (tp[t + 1] - tp[t]) + (bp[t + 1] - bp[t]);
-                const uint64_t len = std::max(tp[t + 1] - tp[t], bp[t + 1] - bp[t]);
+                tot += (uint64_t)tok_lt[i] + tok_lb[i];
+                const uint64_t len = std::max(tok_lt[i], tok_lb[i]);
                 shortest = std::min(shortest, len);
                 longest = std::max(longest, len);
             }
@@ -1993,7 +2001,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
             if (j < h_dterm.size()) { h_dmult[j]++; continue; } // duplicate token: counted again (Q8)
             h_dterm.push_back(t);
             h_dmult.push_back(1);
-            tot += (tp[t + 1] - tp[t]) + (bp[t + 1] - bp[t]);
+            tot += (uint64_t)tok_lt[i] + tok_lb[i];
         }
         if (h_dterm.size() - d0 > SS_MAX_QUERY_TERMS)
             return ctx->fail(SS_ERR_UNSUPPORTED, "ss_score_topk: query %d has more than %d distinct terms", q, SS_MAX_QUERY_TERMS);
