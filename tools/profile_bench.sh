@@ -9,10 +9,10 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
 args="bench.py"
 pmc_args="bench.py --no-cpu-baseline"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt -o kt -- python3 $args > $out/${tag}_bench_line_under_rocprof.json 2> $out/${tag}_kt.err || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt -o kt -- python3 $args > $out/${tag}_bench_line_under_rocprof.json 2> $out/${tag}_kt.err || exit 1
 find $out/${tag}_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats_bench_full.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_$c -o pmc -- python3 $pmc_args > /dev/null 2> $out/${tag}_$c.err || exit 1
+    timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_$c -o pmc -- python3 $pmc_args > /dev/null 2> $out/${tag}_$c.err || exit 1
 done
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, json, re, statistics, sys, collections
