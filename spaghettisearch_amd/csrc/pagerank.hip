@@ -1256,12 +1256,15 @@ __device__ __forceinline__ void sweep_n_body(const PrParams& p, const int sweep,
 template <int KW, bool TS>
 __global__ __launch_bounds__(TPB, SS_PRN_MINW) void k_pr_sweep_n(PrParams p) {
     const PrCtl* ctl = p.ctl;
-    if (ctl->n_active == 0) return;   // every topic converged: the launch is a no-op
+    // (everything this wave needs of the control block is requested before the first of it is looked at: one scalar-load latency
+    //  at the start of a sweep that is mostly fixed cost on a small graph, instead of two)
+    const int n_active = ctl->n_active, sweep = ctl->sweep;
     double S_in[KW];
     int act_in[KW];
 #pragma unroll
     for (int k = 0; k < KW; k++) { S_in[k] = ctl->S[k]; act_in[k] = ctl->active[k]; }
-    sweep_n_body<KW, TS, false>(p, ctl->sweep, S_in, act_in);
+    if (n_active == 0) return;        // every topic converged: the launch is a no-op
+    sweep_n_body<KW, TS, false>(p, sweep, S_in, act_in);
 }
 
 // ---- several sweeps in ONE launch (round 5: graphs whose sweep is all fixed cost) -------------------------------------------------
