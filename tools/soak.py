@@ -21,6 +21,17 @@ def same_hits(hits, n_hits, ref, ref_n, what):
 
 
 def round_scoring(ctx, rng):
+    # (round 5) k_score_small on or off for the whole round, sometimes with a small cap so that a batch holds queries of both kinds
+    ctx.set_option("score.small", int(rng.integers(0, 2)))
+    ctx.set_option("score.small_cap", int(rng.choice([2304, 2304, 300, 40])))
+    try:
+        _round_scoring(ctx, rng)
+    finally:
+        ctx.set_option("score.small", None)
+        ctx.set_option("score.small_cap", None)
+
+
+def _round_scoring(ctx, rng):
     n_docs = int(rng.choice([1, 2, 7, 300, 5000, 60000]))
     n_terms = int(rng.integers(1, 400))
     pb = int(min(n_docs * n_terms // 3 + 1, rng.integers(1, 800000)))
@@ -153,7 +164,28 @@ def round_pagerank(ctx, rng):
     eps = float(rng.choice([1e-6, 1e-9, 1e-3]))
     mi = int(rng.choice([0, 0, 1, 4]))
     g = engine.Graph(ctx, n, ptr, dst)
-    rank, iters = g.pagerank(d, eps, n_topic, max_iter=mi)
+    pmode = int(rng.integers(0, 3)) if kt <= 2 else 0      # (round 5) K <= 2: one launch per sweep, or the sweeps inside one launch (sc1 / fences)
+    ctx.set_option("pr.persistent", pmode)
+    try:
+        rank, iters = g.pagerank(d, eps, n_topic, max_iter=mi)
+    finally:
+        ctx.set_option("pr.persistent", None)
+    if n >= 64 and rng.random() < 0.35:
+        # (round 5) the two-vector form on in-process doc-range shards, lagged (one exchange per iteration) or not: the oracle's ranks and counts
+        world = int(rng.choice([2, 3, 8]))
+        lagged = int(rng.integers(0, 2))
+        shards = [engine.Graph(ctx, n, ptr, dst, rank=r, world=world) for r in range(world)]
+        ctx.set_option("pr.affine", 1); ctx.set_option("pr.affine_lag", lagged)
+        try:
+            rs, its = engine.Graph.pagerank_group(shards, d, eps, n_topic, max_iter=mi)
+        finally:
+            ctx.set_option("pr.affine", None); ctx.set_option("pr.affine_lag", None)
+            for sg in shards: sg.close()
+        refs, refs_it = pyoracle.pagerank(n, ptr, dst, d, eps, n_topic, max_iter=mi)
+        assert np.max(np.abs(its.astype(np.int64) - refs_it.astype(np.int64))) <= 1, ("sharded affine iters", n, len(dst), kt, world, lagged, its.tolist(), refs_it.tolist())
+        ok = its == refs_it
+        if ok.any():
+            np.testing.assert_allclose(rs[ok], refs[ok], rtol=1e-10, atol=0, err_msg=str(("sharded affine", n, len(dst), kt, world, lagged)))
     # the two-vector form (option pr.affine): the same ranks from two vectors; a different operation order, so an iteration count
     # may move by one where a topic's L1 change sits within rounding of eps — then its ranks are compared an iteration apart
     ctx.set_option("pr.affine", 1)
