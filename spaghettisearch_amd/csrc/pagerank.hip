@@ -2315,6 +2315,8 @@ int32_t ss_pr_create(ss_graph* g, double damping, double eps, int32_t max_iter, 
     SS_HIP(ctx, hipMemcpyAsync(pr->x0.p, h_x0, sizeof(h_x0), hipMemcpyHostToDevice, st));
     SS_HIP(ctx, hipStreamSynchronize(st));   // items / h_x0 are stack/host temporaries
     if (trace) fprintf(stderr, "[pr trace] ss_pr_create: build_work %.2f ms (%zu items), edge ranges + deal %.2f ms, alloc + upload %.2f ms\n", t_ms(tc0, tc1), items.size(), t_ms(tc1, tc2), t_ms(tc2, t_now()));
+    if (trace) fprintf(stderr, "[pr trace] where the state lives: x %p  tab0 %p  tab1 %p  in_src %p  in_ptr %p  outdeg %p  work %p  woff %p\n", (void*)pr->x.p, (void*)pr->tab0.p,
+                       (void*)pr->tab1.p, (void*)g->in_src.p, (void*)g->in_ptr.p, (void*)g->outdeg.p, (void*)pr->work.p, (void*)pr->woff.p);
 
     PrParams& p = pr->prm;
     p.in_ptr = g->in_ptr.p;
