@@ -2771,7 +2771,9 @@ int32_t run_affine_sharded(ss_ctx* ctx, std::vector<ShardBlocks>& sh, std::vecto
     // of a topic that stops are written from the vectors of the iteration it stopped in, which the alternating pair still holds.
     // A second, 2 KB all-gather per iteration was pure latency on a ~0.25 ms iteration; it survives only as the flush
     // after the last sweep of a max_iter run.  0: the round-4 protocol (sums in a collective of their own, decisions at once).
-    const bool lag = ctx->opt("pr.affine_lag", 1) != 0;
+    // (the spare rows hold 2 * TAIL_SUM_ROWS = 64 sums = SS_MAX_TOPICS; these two entry points take up to AFF_MAXK topics in this form, and
+    //  beyond 64 the sums keep their own collective)
+    const bool lag = ctx->opt("pr.affine_lag", 1) != 0 && k_topics <= (int32_t)(2 * TAIL_SUM_ROWS);
     auto sums_row = [&](ss_pr* pr, double* base) { return base + ((size_t)pr->g->sl_nd - 2 - TAIL_SUM_ROWS) * 2; };
     auto delta_and_local = [&](int s, double* loc) {
         ss_pr* pr = sh[s].blk[0];

@@ -400,7 +400,7 @@ def test_two_vector_form_on_a_sharded_graph(ss_ctx, oracle, world, lag):
         # lag = 1 (default): ONE exchange per iteration — the per-topic sums of iteration i ride in the spare tail rows of iteration
         # i + 1's slice, decisions one exchange late, a flush after the last sweep of a max_iter run; 0: round 4's second small exchange
         with ss_ctx.options(pr__affine=1, pr__affine_lag=lag):
-            for k_topics in (1, 16, 40, 64):
+            for k_topics in (1, 16, 40, 64, 100):          # (100: more sums than the spare rows carry — the sums keep their own collective)
                 n_topic = synth.topic_sizes(n, k_topics)
                 ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-9, n_topic)
                 rank, iters = engine.Graph.pagerank_group(graphs, D, 1e-9, n_topic)
@@ -408,9 +408,10 @@ def test_two_vector_form_on_a_sharded_graph(ss_ctx, oracle, world, lag):
                 assert iters.tolist() == ref_iters.tolist(), k_topics
                 np.testing.assert_allclose(rank, ref, rtol=1e-12)
                 assert rank.tobytes() == rank2.tobytes() and iters.tolist() == iters2.tolist()
-                single, it1 = one.pagerank(D, 1e-9, n_topic)
-                assert it1.tolist() == iters.tolist()
-                np.testing.assert_allclose(rank, single, rtol=1e-13)
+                if k_topics <= 64:                 # (ss_pagerank_run takes SS_MAX_TOPICS = 64; the sharded calls take up to 256 in this form)
+                    single, it1 = one.pagerank(D, 1e-9, n_topic)
+                    assert it1.tolist() == iters.tolist()
+                    np.testing.assert_allclose(rank, single, rtol=1e-13)
             n_topic = synth.topic_sizes(n, 6)
             ref, ref_iters = oracle.pagerank(n, ptr, dst, D, 1e-30, n_topic, max_iter=5)
             rank, iters = engine.Graph.pagerank_group(graphs, D, 1e-30, n_topic, max_iter=5)
