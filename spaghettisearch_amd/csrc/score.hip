@@ -1407,6 +1407,8 @@ struct ss_scorer {
     // for the GPU, so the next call plans (and fills the other buffer) while this one's copy and kernels run
     unsigned char* h_plan[TURNS] = {};
     size_t h_plan_cap[TURNS] = {};
+    unsigned char* h_res = nullptr;  // pinned landing block of small host results (one device-to-host copy for hits + counts)
+    static constexpr size_t H_RES_BYTES = 128 << 10;
     hipEvent_t plan_ev[TURNS] = {}; // recorded after the H2D copy of the buffer (on the context's second stream)
     hipEvent_t batch_ev[TURNS] = {};// recorded behind the kernels of the batch that read device buffer [turn]
     bool batch_ev_pending[TURNS] = {};
@@ -1434,6 +1436,8 @@ struct ss_scorer {
         bool pin_mode = false;
         uint64_t ticket = 0;                 // 0 = free
         bool collecting = false;             // a collect call is waiting for / copying this slot outside the lock
+        void* pin_n = nullptr;               // pinned landing block of the counts (a small copy into pageable memory costs ~20 us more)
+        size_t pin_n_cap = 0;
         int32_t n_q = 0, k = 0;
     } aslot[INFLIGHT];
     uint64_t next_ticket = 1;
@@ -1444,9 +1448,11 @@ struct ss_scorer {
         for (auto& a : aslot) {
             if (a.ev) (void)hipEventDestroy(a.ev);
             if (a.pin) ctx->pin_free(a.pin, a.pin_cap);
+            if (a.pin_n) ctx->pin_free(a.pin_n, a.pin_n_cap);
         }
         for (int i = 0; i < TURNS; i++) {
             if (h_plan[i]) (void)hipHostFree(h_plan[i]);
+            if (i == 0 && h_res) (void)hipHostFree(h_res);
             if (plan_ev[i]) (void)hipEventDestroy(plan_ev[i]);
             if (batch_ev[i]) (void)hipEventDestroy(batch_ev[i]);
             if (wave_ev[i]) (void)hipEventDestroy(wave_ev[i]);
@@ -1672,6 +1678,11 @@ int32_t ss_score_topk_submit(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr, c
         }
         if (!s->out_stream) SS_HIP(ctx, hipStreamCreateWithFlags(&s->out_stream, hipStreamNonBlocking));
     }
+    if (a->pin_n_cap < (size_t)n_q * sizeof(int32_t)) {
+        if (a->pin_n) ctx->pin_free(a->pin_n, a->pin_n_cap);
+        a->pin_n = ctx->pin_alloc(std::max<size_t>((size_t)n_q * sizeof(int32_t), 4096), &a->pin_n_cap);
+        if (!a->pin_n) a->pin_n_cap = 0;                                   // (no pinned memory: collect copies the counts straight out)
+    }
     if (n_q) {
         const int32_t rc = score_impl(s, n_q, q_ptr, q_terms, p_ptr, p_terms, query_len, topic_probs, k, a->hits.p, a->n_hits.p);
         if (rc != SS_OK) return rc;
@@ -1703,6 +1714,7 @@ int32_t ss_score_topk_collect(ss_scorer* s, uint64_t ticket, ss_hit* hits_out, i
     const ss_hit* d_hits = nullptr;
     const int32_t* d_n = nullptr;
     void* pin = nullptr;
+    void* pin_n = nullptr;
     {
         std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         if (!hits_out || !n_hits_out) return ctx->fail(SS_ERR_INVALID, "ss_score_topk_collect: NULL output");
@@ -1714,7 +1726,7 @@ int32_t ss_score_topk_collect(ss_scorer* s, uint64_t ticket, ss_hit* hits_out, i
         trace = ctx->opt("score.trace", 0) != 0;
         pin_mode = a->pin_mode;
         n_q = a->n_q; k = a->k; ev = a->ev; out_stream = s->out_stream;
-        d_hits = a->hits.p; d_n = a->n_hits.p; pin = a->pin;
+        d_hits = a->hits.p; d_n = a->n_hits.p; pin = a->pin; pin_n = a->pin_n;
     }
     // (the wait and the copies run outside the context's lock: another thread may submit the next batch meanwhile; the slot itself
     // stays this call's until its ticket is cleared below)
@@ -1735,7 +1747,12 @@ int32_t ss_score_topk_collect(ss_scorer* s, uint64_t ticket, ss_hit* hits_out, i
             }
         } else {
             if (e == hipSuccess) e = hipMemcpy(hits_out, d_hits, hb, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(n_hits_out, d_n, nb, hipMemcpyDeviceToHost);
+            if (pin_n) {                                                   // the counts: device -> the slot's pinned block -> the caller
+                if (e == hipSuccess) e = hipMemcpy(pin_n, d_n, nb, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) std::memcpy(n_hits_out, pin_n, nb);
+            } else if (e == hipSuccess) {
+                e = hipMemcpy(n_hits_out, d_n, nb, hipMemcpyDeviceToHost);
+            }
         }
         if (trace) fprintf(stderr, "[score trace] collect: waited %.0f us for the batch, copies %.0f us\n", std::chrono::duration<double, std::micro>(tw1 - tw0).count(),
                            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count());
@@ -2201,7 +2218,19 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipStreamSynchronize(st));                        // (first use or growth only) k_score_wave may run on another stream
         s->qcnt_zeroed2[pb] = s->d_qcnt2[pb].n;
     }
-    SS_HIP(ctx, ensure(s->d_hits, (size_t)n_q * k));
+    // Small results that go back to the host (a lone query, a handful): hits and counts in ONE device block, one copy into the context's
+    // pinned scratch, two host memcpys — a second device-to-host copy costs a lone query ~8 us of its ~0.12 ms (round 5)
+    const size_t res_rows = (size_t)n_q * k;
+    const size_t res_bytes = res_rows * sizeof(ss_hit) + (size_t)n_q * sizeof(int32_t);
+    // (up to 128 KB — 32 queries at k = 100 —: beyond that the extra host copy costs more than the second transfer; a 4 MB batch through
+    //  a pinned block measured 0.79 against 0.655 ms in round 4)
+    bool one_copy = !dev_out && res_bytes <= ss_scorer::H_RES_BYTES;
+    if (one_copy && !s->h_res && hipHostMalloc(reinterpret_cast<void**>(&s->h_res), ss_scorer::H_RES_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        s->h_res = nullptr;
+        one_copy = false;
+    }
+    SS_HIP(ctx, ensure(s->d_hits, res_rows + (one_copy ? ((size_t)n_q * sizeof(int32_t) + sizeof(ss_hit) - 1) / sizeof(ss_hit) : 0)));
     SS_HIP(ctx, ensure(s->d_nhits, n_q));
 
     const unsigned char* dp = s->d_plan2[pb].p;
@@ -2246,7 +2275,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.q_fast = reinterpret_cast<const uint8_t*>(dp + o_qfast);
     p.small_q = reinterpret_cast<const uint32_t*>(dp + o_smallq);
     p.hits = dev_out ? hits_out : s->d_hits.p;
-    p.n_hits = dev_out ? n_hits_out : s->d_nhits.p;
+    p.n_hits = dev_out ? n_hits_out : one_copy ? reinterpret_cast<int32_t*>(s->d_hits.p + res_rows) : s->d_nhits.p;
 
     // "score.pipeline" (default): a batch that is all k_score_wave, results in device memory.  Its k_wave_prep and k_score_wave go
     // to the context's WAVE stream, its k_merge_flat to the caller's stream behind an event: the next batch's k_score_wave (which
@@ -2352,8 +2381,27 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         fprintf(stderr, "[score trace] copies in + checks %.0f us, plan (%zu slices) %.0f us, staging %.0f us, H2D + allocs + params %.0f us, launches %.0f us%s\n",
                 t_us(th0, th1), n_slices, t_us(th1, th2), t_us(th2, th3), t_us(th3, th4), t_us(th4, t_now()), pipe ? " (k_score_wave on the wave stream)" : "");
     if (dev_out) return SS_OK;                   // ordered on the ctx stream; ss_synchronize (or the stream's owner) waits
+    if (one_copy) {
+        unsigned char* const hp1 = s->h_res;
+        SS_HIP(ctx, hipMemcpyAsync(hp1, s->d_hits.p, res_bytes, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        std::memcpy(hits_out, hp1, res_rows * sizeof(ss_hit));
+        std::memcpy(n_hits_out, hp1 + res_rows * sizeof(ss_hit), (size_t)n_q * sizeof(int32_t));
+        return SS_OK;
+    }
     SS_HIP(ctx, hipMemcpyAsync(hits_out, s->d_hits.p, (size_t)n_q * k * sizeof(ss_hit), hipMemcpyDefault, st));
-    SS_HIP(ctx, hipMemcpyAsync(n_hits_out, s->d_nhits.p, n_q * sizeof(int32_t), hipMemcpyDefault, st));
+    // (the counts through the context's pinned scratch: a small copy into pageable memory is staged and waited for by the runtime on its
+    //  own, ~20 us that a copy into pinned memory does not cost)
+    const size_t nh_bytes = (size_t)n_q * sizeof(int32_t);
+    if (nh_bytes <= ss_ctx::PIN_SCRATCH) {
+        ctx->pin_used = 0;
+        int32_t* const hn = ctx->pin<int32_t>((size_t)n_q);
+        SS_HIP(ctx, hipMemcpyAsync(hn, s->d_nhits.p, nh_bytes, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        std::memcpy(n_hits_out, hn, nh_bytes);
+        return SS_OK;
+    }
+    SS_HIP(ctx, hipMemcpyAsync(n_hits_out, s->d_nhits.p, nh_bytes, hipMemcpyDefault, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     return SS_OK;
 }

@@ -61,9 +61,10 @@ constexpr uint32_t NOREC = 0xFFFFu;                  // "no first record" in a p
 constexpr uint64_t SLICE_TARGET = SS_SLICE_TARGET;
 constexpr uint32_t MAX_SLICES_PER_Q = 256;
 #ifndef SS_SLICE_MIN
-#define SS_SLICE_MIN 16384
+#define SS_SLICE_MIN 8192
 #endif
-constexpr uint64_t SLICE_MIN = SS_SLICE_MIN;         // smallest adaptive slice (postings)
+constexpr uint64_t SLICE_MIN = SS_SLICE_MIN;         // smallest adaptive slice (postings).  8192 since round 5 — it only binds for one or two queries at a time: one head
+                                                     // query (1M postings, k = 50, host in / host out) 0.120 / 0.119 / 0.126 / 0.142 / 0.163 ms at 4k / 8k / 16k / 32k / 64k
 constexpr int MAXCH = PC / 64;                       // chunked windows: most 64-record chunks per window (their records fit the exact stage)
 constexpr int WAVES = TPB / 64;
 constexpr int CPW = (MAXCH + WAVES - 1) / WAVES;     // chunk slots per wave and window
