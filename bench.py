@@ -158,6 +158,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per half")
+    ap.add_argument("--settle", type=float, default=float(os.environ.get("SS_BENCH_SETTLE_S", "8")),
+                    help="seconds to wait before the first GPU call (outside every timed region)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -178,6 +180,12 @@ def main() -> None:
     rehearsal = os.environ.get("SS_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    # A process that makes its allocations within a few seconds of a LARGE GPU process's exit keeps, for its whole life, memory that
+    # is ~3.7 % slower for every kernel (the gather-only probe and the sweep alike: 0.752 / 0.945 ms instead of 0.724 / 0.908); the same
+    # allocations made eight seconds later, even later in that same process, are not (profiles/r05g_after_big_process_*.log; DESIGN.md
+    # K1).  The wait sits in front of the first GPU call, outside every timed region; --settle 0 turns it off.
+    if args.settle > 0 and not rehearsal:
+        time.sleep(args.settle)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -247,7 +255,7 @@ def main() -> None:
         out = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"),
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": res.pop("ms_per_step"),
                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic"}
+               "data": "synthetic", "settle_s": 0.0 if rehearsal else args.settle}
         out.update(res)
         if invalid:
             out["valid"] = False
@@ -712,6 +720,13 @@ def main() -> None:
                     shard = (sti, sbi, engine.Scorer(ctx, sti, sbi))
                 except Exception as exc_:
                     shard, shard_error = None, repr(exc_)
+            # the build is timed ONCE (it weights the table in place), right behind seconds of host-side copies during which the GPU
+            # has clocked down: an untimed build of a throwaway copy of the body table first, as every other section warms up
+            # (tools/tfidf_place.py: the same build 5.3 ms warm, 5.5 behind a 5 s pause)
+            wi = engine.InvertedIndex(ctx, nd, b_ptr, b_doc, b_tf.clone())
+            wi.tfidf_build(nd, want_w=False, want_mag=False, want_idf=False)
+            wi.close()
+            del wi
             del b_ptr, b_doc, b_tf, t_ptr, t_doc, t_tf
             torch.cuda.empty_cache()
             wt, mt, _ = ti.tfidf_build(nd, want_w=keep_host, want_mag=keep_host, want_idf=False)   # title first (start_crawl.go:176)
@@ -838,7 +853,7 @@ def main() -> None:
                                  "pipelined_period_ms": period_ms, "achieved_steady_state": ach, "frac_steady_state": ach / HBM_PEAK_GBS},
                     "untimed_warmup_batches": max(W, 1, SCORE_WARM),
                     "tfidf": {"ms": tfidf_ms, "title_ms": tfidf_title_ms,
-                              "what": "ss_tfidf_build of the body table: device time between HIP events (allocations outside)",
+                              "what": "ss_tfidf_build of the body table: device time between HIP events (allocations outside), after one untimed build of a throwaway copy of the table",
                               "roofline": {"bound": "hbm", "achieved": ach_tw, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_tw / HBM_PEAK_GBS,
                                            "traffic": tw_traffic, "traffic_detail": tw_detail,
                                            "kernel": "k_idf + head-list set-up + k_weight_count + k_scatter + k_bucket_sum",
