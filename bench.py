@@ -281,6 +281,7 @@ def main() -> None:
                          "blended_q_per_s": dig(tk, "blended_config5", "value"), "mixed_ms": dig(tk, "mixed_queries", "ms_per_step"),
                          "tail_ms": dig(tk, "tail_queries", "ms_per_step"), "half_half_ms": dig(tk, "half_head_half_tail", "ms_per_step"),
                          "one_query_ms": dig(tk, "latency_single_query_ms", "median"),
+                         "one_tail_query_ms": dig(tk, "latency_tail_queries_ms", "one_query_ms"),
                          "host_io_q_per_s": dig(tk, "queries_per_sec_host_in_host_out"),
                          "host_io_3_in_flight_q_per_s": dig(tk, "queries_per_sec_host_in_host_out_3_in_flight")},
                 "tfidf": {"ms": dig(tk, "tfidf", "ms"), "frac": dig(tk, "tfidf", "roofline", "frac"),
@@ -879,11 +880,32 @@ def main() -> None:
 
             # ---- tail queries: term ranks uniform over the whole vocabulary, reported separately
             tq_ptr, tq_terms = synth.make_queries(nq, 3, nt, seed=1045 + rank)
+            # ... one at a time and eight at a time first (a web query hits tail terms: a call whose queries are all small takes
+            # k_score_small — one launch that writes the hits; option "score.small" = 0 is the slices kernel + merge)
+            def small_calls(n_per_call):
+                ms_ = []
+                qp_ = (np.arange(n_per_call + 1) * 3).astype(np.uint32)
+                for i in range(40):
+                    qt_ = tq_terms[3 * n_per_call * (i % (nq // n_per_call)):3 * n_per_call * (i % (nq // n_per_call) + 1)]
+                    t0 = time.perf_counter()
+                    sc.score_topk(qp_, qt_, 50)
+                    ms_.append((time.perf_counter() - t0) * 1e3)
+                return statistics.median(ms_[5:])
+            lat_tail = {"one_query_ms": small_calls(1), "eight_queries_ms": small_calls(8)}
+            ctx.set_option("score.small", 0)
+            lat_tail["one_query_ms_small_kernel_off"] = small_calls(1)
+            lat_tail["eight_queries_ms_small_kernel_off"] = small_calls(8)
+            ctx.set_option("score.small", None)
+            lat_tail["what"] = "3-term OR queries of term ranks U[1,1000000], k=50, host buffers in and out through ss_score_topk; medians of 35 calls"
+            topk["latency_tail_queries_ms"] = lat_tail
             ctx.set_option("score.timing", 0)
-            dtt, _ = timed_blocks(lambda m: batches(m, tq_ptr, tq_terms), n_blocks=1, min_warm=SCORE_WARM)
+            # (three blocks of K batches, the median one reported: a single block of these 0.1 ms batches is at the mercy of one host hiccup —
+            #  r05h_bench_full: 0.167 ms in a run whose neighbours measured 0.090-0.096)
+            _, tblocks = timed_blocks(lambda m: batches(m, tq_ptr, tq_terms), n_blocks=3, min_warm=SCORE_WARM)
+            dtt = statistics.median(tblocks) * K / 1e3
             ctx.set_option("score.timing", None)
             tail_df = int(sum((h_bptr[t + 1] - h_bptr[t]) + (h_tptr[t + 1] - h_tptr[t]) for t in tq_terms.astype(np.int64)))
-            topk["tail_queries"] = {"value": world * nq * K / dtt, "unit": "queries/s", "ms_per_step": dtt * 1e3 / K,
+            topk["tail_queries"] = {"value": world * nq * K / dtt, "unit": "queries/s", "ms_per_step": dtt * 1e3 / K, "ms_per_step_blocks": summarize(tblocks),
                                     "workload": f"{nq} x 3-term OR queries, term ranks U[1,{nt}]", "postings_per_query": tail_df / nq}
 
             # ---- mixed batches: term ranks over the first 100k terms (long and short lists in one query: the batch runs in
@@ -896,9 +918,10 @@ def main() -> None:
             ctx.set_option("score.timing", 0)
             for key_, (qp_, qt_), what_ in (("mixed_queries", (mq_ptr, mq_terms), f"{nq} x 3-term OR queries, term ranks U[1,{min(100_000, nt)}]"),
                                             ("half_head_half_tail", (hh_ptr, hh_terms), f"{hq} queries of term ranks U[1,10000] + {nq - hq} of U[1,{nt}] in one batch")):
-                dtm, _ = timed_blocks(lambda m: batches(m, qp_, qt_), n_blocks=1, min_warm=SCORE_WARM)
+                _, mblocks = timed_blocks(lambda m: batches(m, qp_, qt_), n_blocks=3, min_warm=SCORE_WARM)
+                dtm = statistics.median(mblocks) * K / 1e3
                 dfm = int(sum((h_bptr[t + 1] - h_bptr[t]) + (h_tptr[t + 1] - h_tptr[t]) for t in qt_.astype(np.int64)))
-                topk[key_] = {"value": world * nq * K / dtm, "unit": "queries/s", "ms_per_step": dtm * 1e3 / K, "workload": what_, "postings_per_query": dfm / nq}
+                topk[key_] = {"value": world * nq * K / dtm, "unit": "queries/s", "ms_per_step": dtm * 1e3 / K, "ms_per_step_blocks": summarize(mblocks), "workload": what_, "postings_per_query": dfm / nq}
             ctx.set_option("score.timing", None)
 
             # ---- blended run (BASELINE config 5): same index and queries + PageRank prior, per-query topicProbs

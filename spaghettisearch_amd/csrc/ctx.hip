@@ -329,9 +329,12 @@ static const char* const k_option_names[] = {
     "score.wave_slice_target", // postings per slice of k_score_wave (default: from the batch, 8k .. 48k)
     "score.wave_big_pct",   // graded slices: this share of a batch's postings goes into slices of wave_big_x100 % of the target, the rest into wave_small_x100 % (defaults 92 / 115 / 60; 0 = one size)
     "score.wave_big_x100",
-    "score.small",          // 1: queries without a phrase part and with at most "score.small_cap" postings (default and most: 2304) are scored by
-                            //    k_score_small — one workgroup per query, every posting exactly, the hits written by the kernel itself.  Default 0:
-                            //    bit-identical hits, measured slower than k_score_slices (DESIGN K4c)
+    "score.small",          // k_score_small (one workgroup per query, every posting exactly, the hits written by the kernel itself) takes queries without a
+                            //    phrase part, with at most "score.small_cap" postings (default and most: 1664) in at most 16 non-empty lists, k <= 256:
+                            //    2 (default): only in calls of at most "score.small_max_batch" queries that are ALL such queries (one launch instead
+                            //    of a slices kernel and a merge: a lone tail query 0.068 -> 0.050 ms host to host); 1: every such query of every call
+                            //    (tests, A/B: a 1024-query tail batch is slower that way, 0.14 against 0.09 ms); 0: never.  Bit-identical hits (DESIGN K4c)
+    "score.small_max_batch",// "score.small" = 2: longest call (queries) that may take k_score_small (default 64)
     "score.small_cap",
     "score.pipeline",       // 0: every scoring kernel on the context's stream.  n >= 1: device-output batches that are all k_score_wave run k_wave_prep and
                             //    k_score_wave on one of n internal streams taken in turn (default 2, as include/spaghetti_rank.h says; at most 3) and

@@ -1368,6 +1368,7 @@ int score_wave_max_k();
 uint32_t score_small_cap();
 uint32_t score_small_cap_a();
 int score_small_max_k();
+int score_small_max_lists();
 int32_t launch_score_small(const void* params, unsigned n_a, unsigned n_b, hipStream_t st);
 void score_small_report();
 void score_wave_diag_dump();
@@ -1560,9 +1561,7 @@ int32_t ss_scorer_destroy(ss_scorer* s) {
 #if defined(SSW_PHASES) && !defined(SS_DIAG)
     ss::score_wave_diag_dump();
 #endif
-#ifdef SSS_PHASES
-    ss::score_small_report();
-#endif
+    ss::score_small_report();               // (prints only in the -DSSS_PHASES build of score_small.hip)
 #ifdef SS_DIAG
     ss::score_wave_diag_dump();
     {
@@ -1991,15 +1990,30 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         batch_wave = wml == 0 ? fit > 0 : (fit * 100 >= all * share && fit >= 400000);
     }
     std::vector<uint8_t> h_fast(n_q, 0);
-    // k_score_small (one workgroup per query, every posting scored exactly, no slices and no merge: score_small.hip) takes the queries
-    // without a phrase part whose lists hold at most score_small_cap() postings in all.  OPT-IN (option "score.small" = 1): bit-identical
-    // hits, but measured slower than the slice kernel it was meant to relieve (round 5, config-3 index: tail batch 0.155 against 0.094 ms,
-    // mixed 0.207 against 0.166, 8 tail queries host to host 0.165 against 0.098, one query 0.091 against 0.092): a query's workgroup is a
-    // chain of ~10 short phases — list bounds, postings, table, magnitudes, scores, admission, a 512-entry bitonic sort, hits — each a
-    // memory or barrier latency with nothing to overlap (50 us per workgroup at five per CU: phase clocks in DESIGN K4c).
-    const bool small_ok = ctx->opt("score.small", 0) != 0 && k <= ss::score_small_max_k();
+    // k_score_small (one workgroup per query, every posting scored exactly, no slices and no merge: score_small.hip) takes queries without
+    // a phrase part whose lists hold at most score_small_cap() postings in all.  Bit-identical hits.  Round 5 measured both ways: a
+    // workgroup is a chain of short phases (list table, postings -> hash table, magnitudes -> scores, radix selection, placement, hits:
+    // ~20 us with nothing to overlap), so a 1024-query tail batch is SLOWER there than in the slices pipeline that runs batches side by
+    // side (0.14 against 0.09 ms), while a short call — where latency is all there is — is faster (1 .. 32 tail queries host to host
+    // 0.068-0.074 -> 0.050-0.058 ms): DESIGN K4c.
+    // "score.small": 1 = every query that fits (tests, A/B); 2 (default) = only a call that consists of such queries and is at most
+    // "score.small_max_batch" queries long: ONE launch that writes the hits, against a slices kernel and a merge — what a lone query or
+    // a handful gain in latency a 1024-query batch loses in overlap (the slices pipeline runs batches side by side); 0 = never.
+    const int64_t small_mode = ctx->opt("score.small", 2);
     const uint64_t small_cap = (uint64_t)std::min<int64_t>(ss::score_small_cap(), std::max<int64_t>(0, ctx->opt("score.small_cap", ss::score_small_cap())));
-    std::vector<uint32_t> h_smallq, h_smallq_b;         // by table size: up to score_small_cap_a() postings, and beyond
+    bool small_ok = small_mode == 1 && k <= ss::score_small_max_k();
+    if (small_mode == 2 && k <= ss::score_small_max_k() && n_q <= ctx->opt("score.small_max_batch", 64) && !p_ptr) {
+        small_ok = true;                                    // (tokens counted with their repeats: an upper bound of a query's postings)
+        for (int q = 0; q < n_q && small_ok; q++) {
+            uint64_t tq = 0;
+            for (uint32_t i = h_qptr[q]; i < h_qptr[q + 1]; i++) tq += (uint64_t)tok_lt[i] + tok_lb[i];
+            small_ok = tq <= small_cap && h_qptr[q + 1] - h_qptr[q] <= (uint32_t)(ss::score_small_max_lists() / 2);
+        }
+    }
+    struct SmallEnt { SmallHdr h; uint32_t loff; };
+    std::vector<SmallEnt> h_small_a, h_small_b;         // by table size: up to score_small_cap_a() postings, and beyond
+    std::vector<SmallList> h_small_lists;
+    uint32_t small_lmax = 0;
     std::vector<uint32_t> h_qoff(n_q + 1, 0), h_dterm, h_dmult, h_sbase(n_q + 1, 0);
     std::vector<double> h_qmag(n_q), h_ub(n_q, 0.0);
     std::vector<SliceDesc> h_slices;
@@ -2039,10 +2053,33 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         uint64_t q_target = slice_target;
         uint64_t max_slices = MAX_SLICES_PER_Q;
         if (small_ok && tot <= small_cap && !(p_ptr && h_pptr[q + 1] > h_pptr[q])) {
-            (tot <= ss::score_small_cap_a() ? h_smallq : h_smallq_b).push_back((uint32_t)q);   // no slices: k_score_small reads the lists whole and writes the hits
-            h_fast[q] = 2;
-            h_sbase[q + 1] = (uint32_t)h_slices.size();
-            continue;
+            // no slices: k_score_small reads the lists whole and writes the hits.  Its list table is made here — the host holds
+            // term_ptr, and the kernel's own walk (query -> terms -> term_ptr) was three dependent loads at the head of every workgroup
+            SmallList tmp[SS_SMALL_MAX_LISTS];
+            uint32_t nl = 0, run = 0;
+            bool fits = true;
+            for (size_t j = d0; j < h_dterm.size() && fits; j++) {
+                const uint32_t t = h_dterm[j];
+                for (uint32_t field = 0; field < 2; field++) {
+                    const uint64_t* pp = field ? tp.data() : bp.data();
+                    const uint64_t b = pp[t], e = pp[t + 1];
+                    if (e == b) continue;
+                    if (nl == SS_SMALL_MAX_LISTS) { fits = false; break; }
+                    run += (uint32_t)(e - b);
+                    tmp[nl++] = SmallList{b, run, h_dmult[j] << 1 | field};
+                }
+            }
+            if (fits) {
+                SmallEnt en;
+                en.h = SmallHdr{(uint32_t)q, nl, run, 0u, h_qmag[q], 0.0};
+                en.loff = (uint32_t)h_small_lists.size();
+                h_small_lists.insert(h_small_lists.end(), tmp, tmp + nl);
+                small_lmax = std::max(small_lmax, nl);
+                (run <= ss::score_small_cap_a() ? h_small_a : h_small_b).push_back(en);
+                h_fast[q] = 2;
+                h_sbase[q + 1] = (uint32_t)h_slices.size();
+                continue;
+            }
         }
         const bool fast = batch_wave && h_suits[q] && h_dterm.size() > d0 && (h_dterm.size() - d0) <= (size_t)ss::score_wave_max_lists();
         if (fast) {
@@ -2071,8 +2108,12 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
         h_sbase[q + 1] = (uint32_t)h_slices.size();
     }
-    const size_t n_small_a = h_smallq.size(), n_small_b = h_smallq_b.size();
-    h_smallq.insert(h_smallq.end(), h_smallq_b.begin(), h_smallq_b.end());
+    if (small_mode == 2 && !h_small_a.empty() && !h_small_b.empty()) {      // one launch: the larger table takes them all
+        h_small_b.insert(h_small_b.end(), h_small_a.begin(), h_small_a.end());
+        h_small_a.clear();
+    }
+    const size_t n_small_a = h_small_a.size(), n_small_b = h_small_b.size(), n_small = n_small_a + n_small_b;
+    const size_t small_stride = sizeof(SmallHdr) + (size_t)small_lmax * sizeof(SmallList);
     const size_t n_slices = h_slices.size();
     const size_t n_d = h_dterm.size();
     // launch order: the wave kernel's slices first, then k_score_slices' (each group longest first); merge list = the wave queries
@@ -2137,7 +2178,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const size_t o_probs = o;  o = align16(o + h_probs.size() * sizeof(double));
     const size_t o_mergeq = o; o = align16(o + h_mergeq.size() * sizeof(uint32_t));
     const size_t o_qfast = o;  o = align16(o + (size_t)n_q);
-    const size_t o_smallq = o; o = align16(o + h_smallq.size() * sizeof(uint32_t));
+    const size_t o_smalltab = o; o = align16(o + n_small * small_stride);
     const size_t plan_bytes = o;
     const int pb = s->plan_turn;
     s->plan_turn = (s->plan_turn + 1) % ss_scorer::TURNS;
@@ -2181,7 +2222,15 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_probs.empty()) std::memcpy(hp + o_probs, h_probs.data(), h_probs.size() * sizeof(double));
     if (!h_mergeq.empty()) std::memcpy(hp + o_mergeq, h_mergeq.data(), h_mergeq.size() * sizeof(uint32_t));
     std::memcpy(hp + o_qfast, h_fast.data(), (size_t)n_q);
-    if (!h_smallq.empty()) std::memcpy(hp + o_smallq, h_smallq.data(), h_smallq.size() * sizeof(uint32_t));
+    {
+        unsigned char* w = hp + o_smalltab;              // the 1024-slot queries first, then the larger ones (launch_score_small)
+        for (const std::vector<SmallEnt>* v : {&h_small_a, &h_small_b})
+            for (const SmallEnt& en : *v) {
+                std::memcpy(w, &en.h, sizeof(SmallHdr));
+                std::memcpy(w + sizeof(SmallHdr), h_small_lists.data() + en.loff, (size_t)en.h.n_lists * sizeof(SmallList));
+                w += small_stride;
+            }
+    }
     const auto th3 = t_now();
     if (any_phrase) {
         for (int x = 0; x < 4; x++) {
@@ -2273,7 +2322,9 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.qc_cnt = s->d_qcnt2[pb].p;
     p.merge_q = reinterpret_cast<const uint32_t*>(dp + o_mergeq);
     p.q_fast = reinterpret_cast<const uint8_t*>(dp + o_qfast);
-    p.small_q = reinterpret_cast<const uint32_t*>(dp + o_smallq);
+    p.small_q = nullptr;
+    p.small_tab = dp + o_smalltab;
+    p.small_stride = (uint32_t)small_stride;
     p.hits = dev_out ? hits_out : s->d_hits.p;
     p.n_hits = dev_out ? n_hits_out : one_copy ? reinterpret_cast<int32_t*>(s->d_hits.p + res_rows) : s->d_nhits.p;
 
@@ -2338,7 +2389,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
     }
     if (pipe_s) sst = wst;
-    if (!h_smallq.empty()) {                     // writes its queries' hits itself: the caller's stream, like every kernel that does
+    if (n_small) {                     // writes its queries' hits itself: the caller's stream, like every kernel that does
         const int32_t rc_s = ss::launch_score_small(&p, (unsigned)n_small_a, (unsigned)n_small_b, st);
         if (rc_s != 0) return ctx->fail(SS_ERR_HIP, "k_score_small: %s", hipGetErrorString((hipError_t)rc_s));
     }

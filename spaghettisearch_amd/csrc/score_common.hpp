@@ -140,8 +140,16 @@ struct ScoreParams {
     const uint8_t* q_fast;    // [n_q] 1: the query is scored by k_score_wave
     uint32_t* qc_cnt;         // [n_q] candidates the wave slices of query q have appended (from entry slice_base[q] * k of so_key / so_doc)
     ss_hit* hits; int32_t* n_hits;
-    const uint32_t* small_q;  // k_score_small: query of workgroup b (queries it scores have no slices; q_fast[q] & 2)
+    const uint32_t* small_q;  // k_score_small's queries (they have no slices; q_fast[q] & 2)
+    const unsigned char* small_tab;   // k_score_small: entry b (small_stride bytes) = SmallHdr + the query's SmallList rows
+    uint32_t small_stride;
 };
+
+// k_score_small's view of a query, resolved by the host (which holds term_ptr)
+#define SS_SMALL_MAX_LISTS 16
+struct __attribute__((aligned(16))) SmallHdr { uint32_t q, n_lists, tot, pad; double qmag, pad2; };
+struct __attribute__((aligned(16))) SmallList { uint64_t start; uint32_t end, mf; };    // first posting in its table; postings of lists 0..this one; multiplicity << 1 | field (1 = title)
+static_assert(sizeof(SmallHdr) == 32 && sizeof(SmallList) == 16, "small-query table layout");
 
 using ss::fkey;
 using ss::funkey;

@@ -17,15 +17,15 @@
 namespace {
 
 constexpr int ST = 256;                    // threads
-// Two table sizes, 20 bytes per slot (doc, title sum, body sum): 1024 slots = 20 KB (+ 9 KB of top-k buffer and list table: five
-// workgroups per CU) for queries of up to 768 postings — the typical tail query —, 3072 slots = 60 KB (two per CU) up to 2304.
-// A query's postings bound its distinct documents, so a table is never more than 3/4 full.
-constexpr int S_A = 1024, S_B = 3072;
-constexpr uint32_t CAP_A = 768, CAP_B = 2304;
-constexpr int SCB = 512;                   // candidate buffer of the running top-k (>= 2k)
-constexpr int SMALL_MAX_K = SCB / 2;
-constexpr int SL = 2 * SS_MAX_QUERY_TERMS; // (term, field) lists
-constexpr int UNR = 4;                     // postings of a thread in flight
+// Two table sizes, 20 bytes per slot (doc, title sum, body sum): 1024 slots = 20 KB (+ 5 KB of candidate buffer, histogram and list
+// table: six workgroups per CU) for queries of up to 768 postings, 2048 slots = 40 KB (three per CU) up to 1664.
+// A query's postings bound its distinct documents, so a table is never more than 13/16 full.
+constexpr int S_A = 1024, S_B = 2048;
+constexpr uint32_t CAP_A = 768, CAP_B = 1664;
+constexpr int SCB = 256;                   // candidate buffer: what the selection admits (<= max(64, 2^ceil(log2 k)))
+constexpr int SMALL_MAX_K = SCB;
+constexpr int SL = SS_SMALL_MAX_LISTS;     // (term, field) lists with postings
+constexpr int UNR = 8;                     // postings of a thread in flight (2048 per pass: every admitted query in one round of loads)
 
 #ifdef SSS_PHASES
 // variant build (-DSSS_PHASES): cycles thread 0 of every workgroup spends per phase, summed over the grid; printed by ss::score_small_report()
@@ -39,7 +39,17 @@ template <int NS>
 __device__ __forceinline__ uint32_t slot_of(uint32_t doc) { return (uint32_t)(((uint64_t)(doc * 0x9E3779B1u) * (uint64_t)NS) >> 32); }
 
 template <int NS>
-constexpr size_t small_lds_bytes() { return (size_t)NS * 20 + (size_t)SCB * 12 + (size_t)SL * 24 + 64; }
+constexpr size_t small_lds_bytes() { return (size_t)NS * 20 + (size_t)SCB * 12 + (size_t)SL * 24 + 256 * 4 + 96; }
+
+// eight bits of the 96-bit selection key {fkey(FinalRank), ~doc} from bit `sh` (0 .. 88) up: larger = better (order.hpp: FinalRank
+// descending, equal finals by ascending doc id)
+__device__ __forceinline__ uint32_t sel_digit(uint64_t key, uint32_t doc, int sh) {
+    const uint32_t lo = ~doc;
+    if (sh >= 32) return (uint32_t)(key >> (sh - 32)) & 255u;
+    // (sh < 32: the byte may straddle the key's low bits and the doc word)
+    const uint64_t w = ((key & 0xFFFFFFFFull) << 32 | (uint64_t)lo) >> sh;
+    return (uint32_t)w & 255u;
+}
 
 template <int NS>
 __global__ __launch_bounds__(ST) void k_score_small(ScoreParams p, uint32_t first) {
@@ -49,46 +59,36 @@ __global__ __launch_bounds__(ST) void k_score_small(ScoreParams p, uint32_t firs
     uint64_t* cd_key = reinterpret_cast<uint64_t*>(accB + NS);            // [SCB]
     uint64_t* l_rec = cd_key + SCB;                                       // [SL] address of the list's first scoring record
     uint64_t* l_w = l_rec + SL;                                           // [SL] ... and of its first float32 weight
-    uint64_t* sc64 = l_w + SL;                                            // [2]
-    uint32_t* hkey = reinterpret_cast<uint32_t*>(sc64 + 2);               // [NS]
+    uint64_t* sc64 = l_w + SL;                                            // [4]: running threshold (unused here), OR and AND of the candidates' keys
+    uint32_t* hkey = reinterpret_cast<uint32_t*>(sc64 + 4);               // [NS]
     uint32_t* cd_doc = hkey + NS;                                         // [SCB]
     uint32_t* l_end = cd_doc + SCB;                                       // [SL] postings of lists 0 .. l (inclusive prefix)
     uint32_t* l_mf = l_end + SL;                                          // [SL] multiplicity << 1 | field (1 = title)
-    uint32_t* sc32 = l_mf + SL;                                           // [8]
+    uint32_t* hist = l_mf + SL;                                           // [256] selection histogram
+    uint32_t* sc32 = hist + 256;                                          // [12]
     const int tid = threadIdx.x;
 #ifdef SSS_PHASES
     unsigned long long ph_t = __builtin_readcyclecounter();
     if (threadIdx.x == 0) atomicAdd(&g_sss[9], 1ull);
 #endif
-    const uint32_t q = p.small_q[first + blockIdx.x];
-    const uint32_t t0 = p.q_off[q], nd = p.q_off[q + 1] - t0;
-    const uint32_t L = 2 * nd;
+    // the query and its lists as the host resolved them (it holds term_ptr): ONE load latency where the first version walked
+    // small_q -> q_off -> dterm -> term_ptr
+    const unsigned char* const ent = p.small_tab + (size_t)(first + blockIdx.x) * p.small_stride;
+    const SmallHdr hd = *reinterpret_cast<const SmallHdr*>(ent);
+    const uint32_t q = hd.q, L = hd.n_lists, tot = hd.tot;
     TopK tk{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), 0ull, -INFINITY, (uint32_t)SCB};
-    uint32_t* overflow = &sc32[1];
-
-    // the query's lists (title and body of every distinct known term), while the table is cleared
     if ((uint32_t)tid < L) {
-        const uint32_t term = p.dterm[t0 + ((uint32_t)tid >> 1)];
-        const int field = tid & 1;
-        const uint64_t* ptr = field ? p.t_ptr : p.b_ptr;
-        const uint64_t b = ptr[term], e = ptr[term + 1];
-        l_rec[tid] = (uint64_t)((field ? p.t_rec : p.b_rec) + b);
-        l_w[tid] = (uint64_t)((field ? p.t_w : p.b_w) + b);
-        l_end[tid] = (uint32_t)(e - b);
-        l_mf[tid] = p.dmult[t0 + ((uint32_t)tid >> 1)] << 1 | (uint32_t)field;
+        const SmallList sl = reinterpret_cast<const SmallList*>(ent + sizeof(SmallHdr))[tid];
+        const int field = (int)(sl.mf & 1u);
+        l_rec[tid] = (uint64_t)((field ? p.t_rec : p.b_rec) + sl.start);
+        l_w[tid] = (uint64_t)((field ? p.t_w : p.b_w) + sl.start);
+        l_end[tid] = sl.end;                                              // inclusive prefix of the lengths (host)
+        l_mf[tid] = sl.mf;
     }
     for (int i = tid; i < NS; i += ST) { hkey[i] = EMPTY; accT[i] = 0.0; accB[i] = 0.0; }
-    if (tid == 0) { sc32[0] = 0u; sc32[1] = 0u; sc64[0] = 0ull; *tk.thr_f = -INFINITY; }
+    if (tid == 0) { sc32[0] = 0u; sc32[1] = 0u; sc32[5] = 0u; sc64[0] = 0ull; sc64[1] = 0ull; sc64[2] = ~0ull; *tk.thr_f = -INFINITY; }
     __syncthreads();
     SSS_PH(0);
-    if (tid == 0) {                        // inclusive prefix of the lengths (<= 128 lists: the host admitted <= CAP postings in all)
-        uint32_t run = 0;
-        for (uint32_t l = 0; l < L; l++) { run += l_end[l]; l_end[l] = run; }
-        sc32[4] = run;
-    }
-    __syncthreads();
-    const uint32_t tot = sc32[4];
-    SSS_PH(1);
 
     // ---- every posting once: {doc, weight} -> the document's slot (linear probing), weight * multiplicity into its field's sum
     for (uint32_t i0 = 0; i0 < tot; i0 += ST * UNR) {
@@ -124,15 +124,16 @@ __global__ __launch_bounds__(ST) void k_score_small(ScoreParams p, uint32_t firs
         }
     }
     __syncthreads();
-    SSS_PH(2);
+    SSS_PH(1);
 
-    // ---- every candidate document: get_metadata.go:31-69, then the running top-k.  A thread owns the slots tid, tid + 256, ...: the
-    //      magnitudes of ALL of them are requested before any is used (one memory latency for the table, not one per slot)
+    // ---- every candidate document: get_metadata.go:31-69.  A thread owns the slots tid, tid + 256, ...: the magnitudes of ALL of
+    //      them are requested before any is used (one memory latency for the table, not one per slot)
     constexpr int PT = NS / ST;
-    const double qmag = p.qmag[q];
+    const double qmag = hd.qmag;
     const double* probs = (p.probs && p.prior) ? p.probs + (size_t)q * p.k_topics : nullptr;
     uint32_t e_doc[PT];
     uint64_t e_key[PT];
+    uint32_t alive = 0;                     // bit j: candidate j is still in the running for the k-th place
     {
         double T[PT], B[PT], mt[PT], mb[PT];
 #pragma unroll
@@ -158,34 +159,128 @@ __global__ __launch_bounds__(ST) void k_score_small(ScoreParams p, uint32_t firs
                 double title, body, fin;
                 final_rank(T[j], B[j], T[j] != 0.0 ? mt[j] : 1.0, B[j] != 0.0 ? mb[j] : 1.0, qmag, sqd, title, body, fin);
                 e_key[j] = fkey(fin);
+                alive |= 1u << j;
+            }
+        }
+    }
+    if (alive) atomicAdd(&sc32[5], (uint32_t)__popc(alive));
+    __syncthreads();
+    SSS_PH(2);
+
+    // ---- the k best: radix selection on {fkey(FinalRank), ~doc}, most significant byte first.  A pass counts the candidates still
+    //      in the running by their next byte, finds the byte value d that holds the k-th best, admits everything above d, drops
+    //      everything below; it stops as soon as what is admitted plus what is still running fits the (small) buffer that is sorted
+    //      at the end.  FinalRanks of one query share their sign and exponent bytes and spread over the mantissa's: three or four
+    //      passes of three barriers each, where the first version compacted a 512-entry buffer by bitonic sort once per overflow.
+    {
+        uint32_t limit = 64;
+        while (limit < (uint32_t)p.k) limit <<= 1;                 // <= SCB (host: k <= SMALL_MAX_K)
+        uint32_t k_rem = (uint32_t)p.k, n_alive = sc32[5];
+        auto admit = [&](int j) __attribute__((always_inline)) {
+            const uint32_t i = atomicAdd(tk.count, 1u);
+            if (i < (uint32_t)SCB) { tk.key[i] = e_key[j]; tk.doc[i] = e_doc[j]; }      // (always: see the stop rule below)
+        };
+        // where the candidates' keys first differ (FinalRanks of one query share sign and exponent and mostly the first mantissa bits):
+        // the passes start there instead of walking the constant bytes — OR and AND of all keys, two LDS atomics per wave
+        int sh = 88;
+        if (n_alive > limit) {
+            uint64_t ko = 0ull, ka = ~0ull;
+#pragma unroll
+            for (int j = 0; j < PT; j++) if ((alive >> j) & 1u) { ko |= e_key[j]; ka &= e_key[j]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { ko |= __shfl_xor(ko, o, 64); ka &= __shfl_xor(ka, o, 64); }
+            if ((tid & 63) == 0) { atomicOr(reinterpret_cast<unsigned long long*>(&sc64[1]), ko); atomicAnd(reinterpret_cast<unsigned long long*>(&sc64[2]), ka); }
+            __syncthreads();
+            const uint64_t diff = sc64[1] ^ sc64[2];
+            // highest differing key bit hb -> first byte = key bits [hb-7, hb]; equal keys throughout: straight to the doc id's bytes
+            sh = diff ? max(0, 32 + (63 - __clzll((long long)diff)) - 7) : 24;
+        }
+        for (;; sh = sh >= 8 ? sh - 8 : (sh > 0 ? 0 : -1)) {
+            // (admitted so far = k - k_rem: everything above the k-th candidate's bits so far)
+            if ((uint32_t)p.k - k_rem + n_alive <= limit || sh < 0) {
+#pragma unroll
+                for (int j = 0; j < PT; j++) if ((alive >> j) & 1u) admit(j);
+                break;
+            }
+            hist[tid] = 0u;                                         // ST == 256 bins
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PT; j++) if ((alive >> j) & 1u) atomicAdd(&hist[sel_digit(e_key[j], e_doc[j], sh)], 1u);
+            __syncthreads();
+            if (tid < 64) {
+                // lane l owns bins 4l .. 4l+3; `above` = candidates in the bins of the lanes above it
+                const uint4 c = reinterpret_cast<const uint4*>(hist)[tid];
+                const uint32_t s4 = c.x + c.y + c.z + c.w;
+                uint32_t incl = s4;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t y = (uint32_t)__shfl_down((int)incl, o, 64);
+                    if (tid + o < 64) incl += y;
+                }
+                uint32_t a = incl - s4;
+                if (a < k_rem && k_rem <= a + s4) {                 // exactly one lane (n_alive >= k_rem here)
+                    const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int bin = 3; bin >= 0; bin--) {
+                        if (k_rem <= a + cc[bin]) { sc32[6] = 4u * (uint32_t)tid + (uint32_t)bin; sc32[7] = k_rem - a; sc32[8] = cc[bin]; break; }
+                        a += cc[bin];
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t d = sc32[6];
+            k_rem = sc32[7];
+            n_alive = sc32[8];
+#pragma unroll
+            for (int j = 0; j < PT; j++) {
+                if ((alive >> j) & 1u) {
+                    const uint32_t dg = sel_digit(e_key[j], e_doc[j], sh);
+                    if (dg > d) admit(j);
+                    if (dg != d) alive &= ~(1u << j);
+                }
             }
         }
     }
     SSS_PH(3);
-    for (;;) {                              // threshold filter into the candidate buffer; overflow -> compact and retry what is left
-        const uint64_t thr = *tk.thr;
+    // ---- order what was admitted: every entry counts the entries that precede it ({key, doc} pairs are distinct, so the counts are
+    //      the places).  All 256 threads take part: the entries are a power of two n2 <= 256, thread t counts for entry t % n2 over
+    //      the (t / n2)-th part of the list, the parts' counts meet in LDS — three barriers and <= 256 / (256 / n2) broadcast reads per
+    //      thread, eight in flight at a time, where a bitonic network over the same entries is 21 to 36 barrier-separated steps
+    //      (16.6k cycles for 128 entries, measured; one thread per entry over the whole list: 8.5k)
+    __syncthreads();
+    const uint32_t n_adm = min(sc32[0], (uint32_t)SCB);
+    uint32_t n2 = 64;
+    while (n2 < n_adm) n2 <<= 1;
+    hist[tid] = 0u;                             // (the selection is over: its histogram holds the places now)
+    __syncthreads();
+    uint64_t my_k = 0ull;
+    uint32_t my_d = EMPTY;
+    {
+        const uint32_t i = (uint32_t)tid & (n2 - 1u), part = (uint32_t)tid / n2, parts = (uint32_t)ST / n2;
+        if (i < n_adm) {
+            my_k = cd_key[i];
+            my_d = cd_doc[i];
+            const uint32_t per = (n_adm + parts - 1u) / parts, j0 = part * per, j1 = min(n_adm, j0 + per);
+            uint32_t cnt = 0;
+            for (uint32_t j = j0; j < j1; j += 8) {
+                uint64_t kk[8];
+                uint32_t dd[8];
 #pragma unroll
-        for (int j = 0; j < PT; j++) {
-            if (e_doc[j] != EMPTY) {
-                if (e_key[j] >= thr) {
-                    const uint32_t i = atomicAdd(tk.count, 1u);
-                    if (i < tk.cb) { tk.key[i] = e_key[j]; tk.doc[i] = e_doc[j]; e_doc[j] = EMPTY; }
-                    else *overflow = 1;
-                } else {
-                    e_doc[j] = EMPTY;
-                }
+                for (int u = 0; u < 8; u++) { const uint32_t jj = min(j + (uint32_t)u, j1 - 1u); kk[u] = cd_key[jj]; dd[u] = cd_doc[jj]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) cnt += (j + (uint32_t)u < j1 && better(kk[u], dd[u], my_k, my_d)) ? 1u : 0u;
             }
+            if (cnt) atomicAdd(&hist[i], cnt);
         }
-        lds_barrier();
-        if (!*overflow) break;
-        topk_compact_inl(tk, p.k);
-        if (tid == 0) *overflow = 0;
-        lds_barrier();
     }
+    __syncthreads();
+    if ((uint32_t)tid < n_adm) {                // (tid < n_adm <= n2: this thread's entry is entry tid)
+        const uint32_t place = hist[tid];
+        if (place < (uint32_t)p.k) { cd_key[place] = my_k; cd_doc[place] = my_d; }
+    }
+    __syncthreads();
+    const uint32_t n_out = min(n_adm, (uint32_t)p.k);
     SSS_PH(4);
-    topk_compact_inl(tk, p.k);
-    const uint32_t n_out = sc32[0];
-    SSS_PH(5);
 
     // ---- the hits: the winners' sums are still in the table
     for (uint32_t i = tid; i < (uint32_t)p.k; i += ST) {
@@ -205,7 +300,7 @@ __global__ __launch_bounds__(ST) void k_score_small(ScoreParams p, uint32_t firs
         p.hits[(size_t)q * p.k + i] = h;
     }
     if (tid == 0) p.n_hits[q] = (int32_t)n_out;
-    SSS_PH(6);
+    SSS_PH(5);
 }
 
 }  // namespace
@@ -215,6 +310,7 @@ namespace ss {
 uint32_t score_small_cap() { return CAP_B; }
 uint32_t score_small_cap_a() { return CAP_A; }
 int score_small_max_k() { return SMALL_MAX_K; }
+int score_small_max_lists() { return SL; }
 // the queries small_q[0 .. n_a) take the 1024-slot table (<= score_small_cap_a() postings each), small_q[n_a .. n_a + n_b) the 3072-slot one
 int32_t launch_score_small(const void* params, unsigned n_a, unsigned n_b, hipStream_t st) {
     static bool attr_set[64] = {};         // per device: the attribute belongs to the device's copy of the kernel
@@ -236,9 +332,9 @@ void score_small_report() {
 #ifdef SSS_PHASES
     unsigned long long h[10];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sss), sizeof(h)) == hipSuccess && h[9]) {
-        const char* nm[7] = {"lists+clear", "prefix", "postings->table", "magnitudes+scores", "admit", "final sort", "hits"};
+        const char* nm[6] = {"lists+clear", "postings->table", "magnitudes+scores", "select", "sort", "hits"};
         fprintf(stderr, "[k_score_small phases, %llu workgroups] cycles per workgroup:", h[9]);
-        for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.0f", nm[i], (double)h[i] / (double)h[9]);
+        for (int i = 0; i < 6; i++) fprintf(stderr, " %s %.0f", nm[i], (double)h[i] / (double)h[9]);
         fprintf(stderr, "\n");
     }
 #endif

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 def _small_query_routing(request, ss_ctx):
     """Every test of this file runs twice: with k_score_small switched off (option "score.small" = 0: the queries of these small
     tables then reach k_score_slices / k_score_wave, the kernels most tests were written for) and with the default routing, where
-    queries of up to 2304 postings take k_score_small."""
+    queries of up to 1664 postings take k_score_small whatever the call's length; the library's default, 2, sends only short calls
+    that consist of such queries there — tests/test_gpu_score.py::test_small_query_kernel_auto_routing)."""
     ss_ctx.set_option("score.small", request.param)
     yield
     ss_ctx.set_option("score.small", None)
@@ -621,3 +622,69 @@ def test_small_query_kernel_edges(ss_ctx, oracle):
             sc.set_prior(None)
         finally:
             close_all(sc, ti, bi)
+
+
+def test_small_query_kernel_selection_ties_and_many_lists(ss_ctx, oracle):
+    """k_score_small picks its k best by radix selection on {FinalRank, doc id}: whole tiers of EQUAL FinalRanks (the selection then has
+    to go on through the doc id's bytes), k at / around the tier sizes and the buffer sizes (63, 64, 65, 128, 129, 256), and queries
+    with more distinct terms than its list table holds (they take the other kernels) — against the oracle and against the big kernels."""
+    rng = np.random.default_rng(11)
+    n_docs, n_terms = 20000, 12
+    # terms 0..2: 700 / 500 / 300 postings of weight exactly 1 over documents of magnitude 1: every document with the same set of
+    # terms has the same FinalRank; terms 3..11: 40 postings each (an 11-term query has 22 lists with the title's)
+    lens = [700, 500, 300] + [40] * 9
+    docs = [np.sort(rng.choice(n_docs, size=n, replace=False)).astype(np.uint32) for n in lens]
+    b_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    b_doc = np.concatenate(docs)
+    b_w = np.ones(len(b_doc), dtype=np.float32)
+    t_lens = [50, 0, 30] + [5] * 9
+    t_docs = [np.sort(rng.choice(n_docs, size=n, replace=False)).astype(np.uint32) for n in t_lens]
+    t_ptr = np.concatenate([[0], np.cumsum(t_lens)]).astype(np.uint64)
+    t_doc = np.concatenate(t_docs)
+    t_w = np.ones(len(t_doc), dtype=np.float32)
+    mag = np.ones(n_docs, dtype=np.float64)
+    title, body = (t_ptr, t_doc, t_w), (b_ptr, b_doc, b_w)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mag, mag)
+    try:
+        qs = [[0], [1], [0, 1], [0, 1, 2], [2, 2, 1], list(range(3, 12)), list(range(0, 12)), [0, 3, 4, 5, 6, 7, 8, 9, 10]]
+        q_ptr = np.concatenate([[0], np.cumsum([len(x) for x in qs])]).astype(np.uint32)
+        q_terms = np.array([t for x in qs for t in x], dtype=np.uint32)
+        for k in (1, 63, 64, 65, 100, 128, 129, 256):
+            ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mag, mag, q_ptr, q_terms, k)
+            hits, n_hits = sc.score_topk(q_ptr, q_terms, k)
+            assert_same_hits(hits, n_hits, ref, ref_n)
+            with ss_ctx.options(score__small=0):
+                h0, n0 = sc.score_topk(q_ptr, q_terms, k)
+            assert h0.tobytes() == hits.tobytes() and n0.tolist() == n_hits.tolist()
+    finally:
+        close_all(sc, ti, bi)
+
+
+def test_small_query_kernel_auto_routing(ss_ctx, oracle):
+    """The default routing ("score.small" = 2): a call of at most "score.small_max_batch" queries that are all small takes k_score_small
+    in ONE launch (queries of both table sizes together), any other call takes the big kernels — same hits either way, and equal to
+    the oracle's."""
+    rng = np.random.default_rng(3)
+    n_docs, n_terms = 60000, 500
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 900000, 60000, seed=5)
+    b_len = np.diff(body[0].astype(np.int64)) + np.diff(title[0].astype(np.int64))
+    order = np.argsort(b_len)
+    sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+    try:
+        small_terms = order[:250]                                     # a 3-term query of these stays far below the cap
+        mid_terms = order[(b_len[order] > 300) & (b_len[order] < 500)]
+        for n_q, pool in ((1, small_terms), (5, small_terms), (9, mid_terms), (64, small_terms), (65, small_terms)):
+            qs = [list(rng.choice(pool, size=3, replace=False)) for _ in range(n_q)]
+            if n_q == 5:
+                qs[2] = [int(order[-1]), int(order[3])]                 # one long query: the whole call takes the big kernels
+            q_ptr = np.concatenate([[0], np.cumsum([len(x) for x in qs])]).astype(np.uint32)
+            q_terms = np.array([t for x in qs for t in x], dtype=np.uint32)
+            ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, q_ptr, q_terms, 20)
+            with ss_ctx.options(score__small=2):
+                hits, n_hits = sc.score_topk(q_ptr, q_terms, 20)
+            assert_same_hits(hits, n_hits, ref, ref_n)
+            with ss_ctx.options(score__small=0):
+                h0, n0 = sc.score_topk(q_ptr, q_terms, 20)
+            assert h0.tobytes() == hits.tobytes() and n0.tolist() == n_hits.tolist()
+    finally:
+        close_all(sc, ti, bi)

@@ -17,7 +17,9 @@ sc = engine.Scorer(ctx, ti, bi)
 k, nq = 100, 1024
 d_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev); d_n = torch.empty(nq, dtype=torch.int32, device=dev)
 ctx.set_option("score.timing", 0)
+kinds = os.environ.get("KINDS", "tail,mixed,head").split(",")
 for name, rmax, seed in (("tail", 1_000_000, 47), ("mixed", 100_000, 46), ("head", 10_000, 45)):
+    if name not in kinds: continue
     qp, qt = synth.make_queries(nq, 3, rmax, seed=seed)
     for _ in range(10): sc.score_topk(qp, qt, k, out=(d_hits, d_n))
     ctx.synchronize()

@@ -22,8 +22,8 @@ def same_hits(hits, n_hits, ref, ref_n, what):
 
 def round_scoring(ctx, rng):
     # (round 5) k_score_small on or off for the whole round, sometimes with a small cap so that a batch holds queries of both kinds
-    ctx.set_option("score.small", int(rng.integers(0, 2)))
-    ctx.set_option("score.small_cap", int(rng.choice([2304, 2304, 300, 40])))
+    ctx.set_option("score.small", int(rng.integers(0, 3)))                 # off / every query that fits / short all-small calls (the default)
+    ctx.set_option("score.small_cap", int(rng.choice([1664, 1664, 300, 40])))
     try:
         _round_scoring(ctx, rng)
     finally:
