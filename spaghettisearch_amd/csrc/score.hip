@@ -1370,6 +1370,7 @@ uint32_t score_small_cap_a();
 int score_small_max_k();
 int score_small_max_lists();
 int32_t launch_score_small(const void* params, unsigned n_a, unsigned n_b, hipStream_t st);
+void launch_small_copy(const void* params, unsigned n_small, hipStream_t st);
 void score_small_report();
 void score_wave_diag_dump();
 }  // namespace ss
@@ -1421,6 +1422,8 @@ struct ss_scorer {
     ss::DevBuf<uint32_t> d_xcnt[TURNS], d_pcnt[TURNS];
     ss::DevBuf<uint64_t> d_so_key2[TURNS];           // the slices' candidates, one set per turn ("score.pipeline": batch i's merge reads its set while batch i+1 fills the other)
     ss::DevBuf<uint32_t> d_so_doc2[TURNS], d_so_cnt2[TURNS], d_qticket, d_qcnt2[TURNS];
+    ss::DevBuf<ss_hit> d_small_stage[TURNS];         // k_score_small's rows of a pipelined batch (k_small_copy moves them on the caller's stream)
+    ss::DevBuf<int32_t> d_small_stage_n[TURNS];
     hipEvent_t wave_ev[TURNS] = {};  // "score.pipeline": behind k_score_wave on the context's wave stream; the merge on the caller's stream waits for it
     hipEvent_t slice_ev[TURNS] = {}; // ... and behind the k_score_slices part of a split batch on ANOTHER wave stream
     size_t qticket_zeroed = 0;         // tickets known to be zero (every fused call leaves them so)
@@ -2002,6 +2005,11 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const int64_t small_mode = ctx->opt("score.small", 2);
     const uint64_t small_cap = (uint64_t)std::min<int64_t>(ss::score_small_cap(), std::max<int64_t>(0, ctx->opt("score.small_cap", ss::score_small_cap())));
     bool small_ok = small_mode == 1 && k <= ss::score_small_max_k();
+    // "score.small_batch" = 1 (with "score.small" = 2): in a LONGER call with device outputs every query that fits goes there too, the
+    // kernel on an internal stream beside the neighbouring batches like the slices kernel, its rows staged and copied on the caller's stream
+    const bool small_batch = small_mode == 2 && dev_out && k <= ss::score_small_max_k() && ctx->opt("score.pipeline", 2) != 0 &&
+                             ctx->opt("score.small_batch", 0) != 0 && n_q > ctx->opt("score.small_max_batch", 64);
+    if (small_batch) small_ok = true;
     if (small_mode == 2 && k <= ss::score_small_max_k() && n_q <= ctx->opt("score.small_max_batch", 64) && !p_ptr) {
         small_ok = true;                                    // (tokens counted with their repeats: an upper bound of a query's postings)
         for (int q = 0; q < n_q && small_ok; q++) {
@@ -2108,7 +2116,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
         h_sbase[q + 1] = (uint32_t)h_slices.size();
     }
-    if (small_mode == 2 && !h_small_a.empty() && !h_small_b.empty()) {      // one launch: the larger table takes them all
+    if (small_mode == 2 && !(small_batch && ctx->opt("score.small_batch", 0) == 2) && !h_small_a.empty() && !h_small_b.empty()) {      // one launch: the larger table takes them all
         h_small_b.insert(h_small_b.end(), h_small_a.begin(), h_small_a.end());
         h_small_a.clear();
     }
@@ -2256,6 +2264,15 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const bool pipe_split = dev_out && n_fast_slices > 0 && n_slices > n_fast_slices && !h_mergeq.empty() && ctx->opt("score.pipeline", 2) >= 2 &&
                             ctx->opt("score.pipeline_slices", 1) != 0;
     const bool fused = ctx->opt("score.separate_merge", 0) == 0 && !pipe_s && !pipe_split;
+    // k_score_small of a pipelined batch: on the slices kernel's stream if there is one, else on a side stream beside the wave kernel,
+    // else (every query small) on a wave stream of its own
+    const bool small_staged = small_batch && n_small > 0;
+    const bool small_side = small_staged && !pipe_split && dev_out && n_fast_slices > 0 && !h_mergeq.empty() && ctx->opt("score.pipeline", 2) >= 2;
+    const bool small_alone = small_staged && !pipe_s && !pipe_split && !small_side;
+    if (small_staged) {
+        SS_HIP(ctx, ensure(s->d_small_stage[pb], n_small * (size_t)k));
+        SS_HIP(ctx, ensure(s->d_small_stage_n[pb], n_small));
+    }
     if (fused && s->qticket_zeroed < (size_t)n_q) {
         SS_HIP(ctx, ensure(s->d_qticket, (size_t)n_q));
         SS_HIP(ctx, hipMemsetAsync(s->d_qticket.p, 0, (size_t)n_q * sizeof(uint32_t), st));
@@ -2325,6 +2342,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.small_q = nullptr;
     p.small_tab = dp + o_smalltab;
     p.small_stride = (uint32_t)small_stride;
+    p.small_stage = small_staged ? s->d_small_stage[pb].p : nullptr;
+    p.small_stage_n = small_staged ? s->d_small_stage_n[pb].p : nullptr;
     p.hits = dev_out ? hits_out : s->d_hits.p;
     p.n_hits = dev_out ? n_hits_out : one_copy ? reinterpret_cast<int32_t*>(s->d_hits.p + res_rows) : s->d_nhits.p;
 
@@ -2375,13 +2394,13 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (timed) SS_HIP(ctx, hipEventRecord(ctx->ev[1][0], st));
     hipStream_t wst = st;                        // where k_wave_prep / k_score_wave go
     hipStream_t sst = st;                        // ... and k_score_slices (with the phrase kernels in front of it)
-    if (pipe || pipe_s) {
+    if (pipe || pipe_s || small_alone) {
         const int n_ws = (int)std::min<int64_t>(ss_ctx::N_WAVE_STREAMS, std::max<int64_t>(1, ctx->opt("score.pipeline", 2)));
         const int wi = (int)(s->wave_turn++ % (unsigned)n_ws);
         if (!ctx->wave_stream[wi]) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->wave_stream[wi], hipStreamNonBlocking));
         if (!s->wave_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->wave_ev[pb], hipEventDisableTiming));
         wst = ctx->wave_stream[wi];
-        if (pipe_split) {
+        if (pipe_split || small_side) {
             const int si = (wi + 1) % n_ws;                        // (n_ws >= 2: "score.pipeline" >= 2)
             if (!ctx->wave_stream[si]) SS_HIP(ctx, hipStreamCreateWithFlags(&ctx->wave_stream[si], hipStreamNonBlocking));
             if (!s->slice_ev[pb]) SS_HIP(ctx, hipEventCreateWithFlags(&s->slice_ev[pb], hipEventDisableTiming));
@@ -2389,8 +2408,8 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         }
     }
     if (pipe_s) sst = wst;
-    if (n_small) {                     // writes its queries' hits itself: the caller's stream, like every kernel that does
-        const int32_t rc_s = ss::launch_score_small(&p, (unsigned)n_small_a, (unsigned)n_small_b, st);
+    if (n_small) {                     // writes its queries' hits itself: the caller's stream, like every kernel that does — or stages them
+        const int32_t rc_s = ss::launch_score_small(&p, (unsigned)n_small_a, (unsigned)n_small_b, !small_staged ? st : small_alone ? wst : sst);
         if (rc_s != 0) return ctx->fail(SS_ERR_HIP, "k_score_small: %s", hipGetErrorString((hipError_t)rc_s));
     }
     if (any_phrase) {                            // the phrase matches, in front of the kernel that merges them in (k_score_slices)
@@ -2411,10 +2430,15 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipEventRecord(s->wave_ev[pb], wst));
         SS_HIP(ctx, hipStreamWaitEvent(st, s->wave_ev[pb], 0));
     }
-    if (pipe_split) {
+    if (pipe_split || small_side) {
         SS_HIP(ctx, hipEventRecord(s->slice_ev[pb], sst));
         SS_HIP(ctx, hipStreamWaitEvent(st, s->slice_ev[pb], 0));
     }
+    if (small_alone) {
+        SS_HIP(ctx, hipEventRecord(s->wave_ev[pb], wst));
+        SS_HIP(ctx, hipStreamWaitEvent(st, s->wave_ev[pb], 0));
+    }
+    if (small_staged) ss::launch_small_copy(&p, (unsigned)n_small, st);
     if (!fused && n_slices > n_fast_slices) hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_q), dim3(TPB_M), lds_merge, st, p);
     if (pipe) {                                  // the merge, on the caller's stream, behind this batch's k_score_wave
         SS_HIP(ctx, hipEventRecord(s->wave_ev[pb], wst));

@@ -297,10 +297,26 @@ __global__ __launch_bounds__(ST) void k_score_small(ScoreParams p, uint32_t firs
             final_rank(T, B, mt, mb, qmag, sqd, title, body, fin);
             h.doc = d; h.title = title; h.body = body; h.pagerank = sqd; h.final = fin;
         }
-        p.hits[(size_t)q * p.k + i] = h;
+        // (a batch that is pipelined over internal streams: the rows go to a block of their own, and k_small_copy moves them into the
+        //  caller's buffer on the caller's stream — the hits must be complete in THAT stream's order)
+        if (p.small_stage) p.small_stage[(size_t)(first + blockIdx.x) * p.k + i] = h;
+        else p.hits[(size_t)q * p.k + i] = h;
     }
-    if (tid == 0) p.n_hits[q] = (int32_t)n_out;
+    if (tid == 0) {
+        if (p.small_stage) p.small_stage_n[first + blockIdx.x] = (int32_t)n_out;
+        else p.n_hits[q] = (int32_t)n_out;
+    }
     SSS_PH(5);
+}
+
+// the staged rows of k_score_small's queries -> the caller's buffers (one workgroup per query; ss_hit rows are 40 bytes = 5 words of 8)
+__global__ __launch_bounds__(128) void k_small_copy(ScoreParams p) {
+    const uint32_t q = reinterpret_cast<const SmallHdr*>(p.small_tab + (size_t)blockIdx.x * p.small_stride)->q;
+    const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(p.small_stage + (size_t)blockIdx.x * p.k);
+    uint64_t* __restrict__ dst = reinterpret_cast<uint64_t*>(p.hits + (size_t)q * p.k);
+    static_assert(sizeof(ss_hit) == 40, "ss_hit rows are copied as 8-byte words");
+    for (uint32_t i = threadIdx.x; i < (uint32_t)p.k * 5u; i += 128) dst[i] = src[i];
+    if (threadIdx.x == 0) p.n_hits[q] = p.small_stage_n[blockIdx.x];
 }
 
 }  // namespace
@@ -326,6 +342,11 @@ int32_t launch_score_small(const void* params, unsigned n_a, unsigned n_b, hipSt
     if (n_b) hipLaunchKernelGGL(k_score_small<S_B>, dim3(n_b), dim3(ST), small_lds_bytes<S_B>(), st, p, (uint32_t)n_a);    // the larger queries first
     if (n_a) hipLaunchKernelGGL(k_score_small<S_A>, dim3(n_a), dim3(ST), small_lds_bytes<S_A>(), st, p, 0u);
     return 0;
+}
+
+void launch_small_copy(const void* params, unsigned n_small, hipStream_t st) {
+    const ScoreParams& p = *static_cast<const ScoreParams*>(params);
+    if (n_small) hipLaunchKernelGGL(k_small_copy, dim3(n_small), dim3(128), 0, st, p);
 }
 
 void score_small_report() {

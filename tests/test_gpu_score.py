@@ -688,3 +688,56 @@ def test_small_query_kernel_auto_routing(ss_ctx, oracle):
             assert h0.tobytes() == hits.tobytes() and n0.tolist() == n_hits.tolist()
     finally:
         close_all(sc, ti, bi)
+
+
+@pytest.mark.parametrize("mix", ["small+slices", "small+wave", "small+wave+slices", "all-small"])
+def test_small_queries_staged_in_pipelined_batches(ss_ctx, oracle, mix):
+    """Option "score.small_batch" = 1: in a longer call with device outputs the small queries take k_score_small on an INTERNAL stream
+    (beside the slices kernel, beside the wave kernel on a side stream, or alone), their rows go to a staging block and k_small_copy
+    moves them into the caller's buffer on the caller's stream — so the hits are still complete in stream order: copies enqueued right
+    behind every call (buffers scribbled over behind the copies) must equal the oracle, batch after batch of changing size."""
+    import torch
+    n_docs, n_terms = 300000, 20000
+    title, body, mt, mb = build_weighted(oracle, n_docs, n_terms, 6000000, 400000, seed=51)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ss_ctx.set_stream(stream.cuda_stream)
+    rng = np.random.default_rng(77)
+    sc = ti = bi = None
+    try:
+        with torch.cuda.stream(stream):
+            sc, ti, bi = make_scorer(ss_ctx, n_docs, title, body, mt, mb)
+            batches = []
+            for i in range(10):
+                parts = [rng.integers(2000, n_terms, size=(70 + 20 * (i % 4), 3))]                  # tail terms: small queries
+                if "wave" in mix:
+                    parts.append(np.stack([rng.choice(300, size=3, replace=False) for _ in range(40 + 8 * (i % 3))]))
+                rows = [list(map(int, r)) for p_ in parts for r in p_]
+                if "slices" in mix:
+                    rows += [list(map(int, rng.choice(300, size=8, replace=False))) for _ in range(12 + 4 * (i % 2))]   # 8 terms: k_score_slices
+                order = rng.permutation(len(rows))
+                rows = [rows[j] for j in order]
+                qp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.uint32)
+                qt = np.array([t for r in rows for t in r], dtype=np.uint32)
+                batches.append((qp, qt))
+            k = 40
+            outs = [(torch.zeros(len(qp) * k * 40, dtype=torch.uint8, device=dev), torch.zeros(len(qp), dtype=torch.int32, device=dev))
+                    for qp, _ in batches]
+            with ss_ctx.options(score__wave_min_list=0, score__small=2, score__small_batch=1):
+                snaps = []
+                for (qp, qt), out in zip(batches, outs):
+                    sc.score_topk(qp, qt, k, out=out)
+                    snaps.append((out[0].clone(), out[1].clone()))
+                    out[0].fill_(0xEE)
+                    out[1].fill_(-7)
+                stream.synchronize()
+                for (qp, qt), (dh, dn) in zip(batches, snaps):
+                    nq = len(qp) - 1
+                    ref, ref_n = oracle.score_topk_batch(n_docs, title, body, mt, mb, qp, qt, k)
+                    hits = dh.cpu().numpy()[: nq * k * 40].view(engine.HIT_DTYPE).reshape(nq, k)
+                    assert_same_hits(hits, dn.cpu().numpy()[:nq], ref, ref_n)
+    finally:
+        for x in (sc, ti, bi):
+            if x is not None:
+                x.close()
+        ss_ctx.set_stream(None)

@@ -20,11 +20,12 @@ d_hits = torch.empty(nq * k * 40, dtype=torch.uint8, device=dev); d_n = torch.em
 qh = synth.make_queries(nq // 2, 3, 10_000, seed=45); qt_ = synth.make_queries(nq // 2, 3, 1_000_000, seed=47)
 half = (np.concatenate([qh[0], qh[0][-1] + qt_[0][1:]]).astype(np.uint32), np.concatenate([qh[1], qt_[1]]))
 batches = [("tail", synth.make_queries(nq, 3, 1_000_000, seed=47)), ("mixed", synth.make_queries(nq, 3, 100_000, seed=46)), ("half head / half tail", half)]
-caps = [int(x) for x in os.environ.get("CAPS", "1664").split(",")]
+cfgs = [("routing off", {"score.small": 0}), ("forced on the caller's stream", {"score.small": 1}),
+        ("staged, one table size", {"score.small": 2, "score.small_batch": 1}), ("staged, two table sizes", {"score.small": 2, "score.small_batch": 2})]
 for name, (qp, qt) in batches:
     ref = None
-    for small, cap in [(0, 0)] + [(1, c) for c in caps]:
-        ctx.set_option("score.small", small); ctx.set_option("score.small_cap", cap if small else None)
+    for label, opts in cfgs:
+        for o in ("score.small", "score.small_batch"): ctx.set_option(o, opts.get(o))
         for _ in range(20): sc.score_topk(qp, qt, k, out=(d_hits, d_n))
         ctx.synchronize()
         ws = []
@@ -34,11 +35,12 @@ for name, (qp, qt) in batches:
             ctx.synchronize(); ws.append((time.perf_counter() - t0) / 100)
         got = (d_hits.cpu().numpy().tobytes(), d_n.cpu().numpy().tobytes())
         if ref is None: ref = got
-        print(f"{name}: score.small={small} cap={cap}: {statistics.median(ws)*1e3:.4f} ms per batch (min {min(ws)*1e3:.4f})  hits == routing off: {got == ref}", flush=True)
+        print(f"{name}: {label}: {statistics.median(ws)*1e3:.4f} ms per batch (min {min(ws)*1e3:.4f})  hits == routing off: {got == ref}", flush=True)
+for o in ("score.small", "score.small_batch"): ctx.set_option(o, None)
 for nqs in (1, 8):
     qp, qt = synth.make_queries(nqs, 3, 1_000_000, seed=48)
     for small in (0, 1):
-        ctx.set_option("score.small", small); ctx.set_option("score.small_cap", None)
+        ctx.set_option("score.small", 2 if small else 0)
         for _ in range(10): sc.score_topk(qp, qt, 50)
         ls = []
         for _ in range(200):
