@@ -62,7 +62,11 @@ while time.time() < t_end:
     burst = [make_batch() for _ in range(int(rng.integers(2, 9)))]
     probs = [rng.dirichlet(np.ones(4), size=len(qp) - 1) if blend else None for _, qp, _, _ in burst]
     mode = int(rng.choice([0, 1, 1, 2]))                                 # 0: score.pipeline off, 1: default, 2: submit / collect
-    print(f"burst {n_bursts}: mode={mode} blend={blend} " + " ".join(f"{kind}:{len(qp) - 1}q/k{k}" for kind, qp, _, k in burst), flush=True)
+    # (round 5) k_score_small: the default routing (short all-small calls), with the small queries of longer calls staged on an internal
+    # stream (one or two table sizes), forced for every query that fits, or off
+    small, small_batch = [(2, 0), (2, 0), (2, 1), (2, 2), (1, 0), (0, 0)][int(rng.integers(0, 6))]
+    ctx.set_option("score.small", small); ctx.set_option("score.small_batch", small_batch)
+    print(f"burst {n_bursts}: mode={mode} small={small}/{small_batch} blend={blend} " + " ".join(f"{kind}:{len(qp) - 1}q/k{k}" for kind, qp, _, k in burst), flush=True)
     got = []
     if mode == 2:
         flight = []
@@ -87,7 +91,8 @@ while time.time() < t_end:
         for (_, qp, _, k), (dh, dn) in zip(burst, snaps):
             nq = len(qp) - 1
             got.append((dh.cpu().numpy().view(engine.HIT_DTYPE).reshape(nq, k), dn.cpu().numpy()))
-    with ctx.options(score__wave=0, score__pipeline=0):
+    ctx.set_option("score.small", None); ctx.set_option("score.small_batch", None)
+    with ctx.options(score__wave=0, score__pipeline=0, score__small=0):
         for i, ((kind, qp, qt, k), (h1, n1)) in enumerate(zip(burst, got)):
             h0, n0 = sc.score_topk(qp, qt, k, topic_probs=probs[i])
             if h1.tobytes() != h0.tobytes() or n1.tolist() != n0.tolist():
