@@ -1187,6 +1187,10 @@ def main() -> None:
                         result["config"]["parallelism"] = decomp[best]["parallelism"]
                         result["config"]["sweeps_per_sec"] = result["value"] / kt
                         decomp["headline"] = best
+                    #  said where the number is read: at N > 1 `value` is the FASTEST of the float64 variants that shard
+                    # the doc range and exchange per sweep, as measured in this run — not a fixed variant
+                    result["config"]["value_is"] = ("the fastest float64 doc-range / topic-group x doc-shard variant of this run (" +
+                                                    str(decomp.get("headline", "doc_range_shards")) + "); every variant's own number is under `decompositions`")
                     # the two-vector form on the shards (option "pr.affine": a TWO-column exchange per iteration whatever K is — 2/kt of the
                     # table's bytes per link; opt-in, not the reference's operation order) — reported here only, never as `value`
                     # (after the choice above and last of all: this variant is the newest code on the multi-rank path — if it stalls, the watchdog
