@@ -336,6 +336,8 @@ static const char* const k_option_names[] = {
                             //    (tests, A/B: a 1024-query tail batch is slower that way, 0.14 against 0.09 ms); 0: never.  Bit-identical hits (DESIGN K4c)
     "score.small_max_batch",// "score.small" = 2: longest call (queries) that may take k_score_small (default 64)
     "score.small_batch",    // 1 (with "score.small" = 2): longer calls with device outputs send their small queries to k_score_small too, on an internal stream, rows staged (default 0)
+    "score.debug_floor",    // EXPERIMENT, only in a library built with -DSS_EXP_FLOOR (tools/floor_exp.py; no effect in the product): 1 = every host-output call records its
+                            //    queries' k-th best FinalRank, and the next call of as many queries starts its filters from them (wrong hits if the batch changes)
     "score.small_cap",
     "score.pipeline",       // 0: every scoring kernel on the context's stream.  n >= 1: device-output batches that are all k_score_wave run k_wave_prep and
                             //    k_score_wave on one of n internal streams taken in turn (default 2, as include/spaghetti_rank.h says; at most 3) and

@@ -709,6 +709,12 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
             if (floor_l > 0.0f) atomicMax(thr0_bits, __float_as_uint(floor_l));
         }
     }
+#ifdef SS_EXP_FLOOR      // variant build only (tools/floor_exp.py): a per-query floor handed in by the host
+    if (tid == 0 && p.q_floor && !exact_all) {
+        const float f = p.q_floor[q];
+        if (f > 0.0f) atomicMax(thr0_bits, __float_as_uint(f));
+    }
+#endif
     __syncthreads();
     DIAG_NOW(t_s1);
     DIAG_ADD(6, t_s1 - t_k0);
@@ -1409,6 +1415,7 @@ struct ss_scorer {
     // for the GPU, so the next call plans (and fills the other buffer) while this one's copy and kernels run
     unsigned char* h_plan[TURNS] = {};
     size_t h_plan_cap[TURNS] = {};
+    std::vector<float> dbg_floor;    // experiment "score.debug_floor": the k-th best FinalRank of every query of the last host-output call, rounded down
     unsigned char* h_res = nullptr;  // pinned landing block of small host results (one device-to-host copy for hits + counts)
     static constexpr size_t H_RES_BYTES = 128 << 10;
     hipEvent_t plan_ev[TURNS] = {}; // recorded after the H2D copy of the buffer (on the context's second stream)
@@ -2187,6 +2194,12 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     const size_t o_mergeq = o; o = align16(o + h_mergeq.size() * sizeof(uint32_t));
     const size_t o_qfast = o;  o = align16(o + (size_t)n_q);
     const size_t o_smalltab = o; o = align16(o + n_small * small_stride);
+#ifdef SS_EXP_FLOOR
+    const bool use_floor = ctx->opt("score.debug_floor", 0) != 0 && s->dbg_floor.size() == (size_t)n_q;
+#else
+    const bool use_floor = false;
+#endif
+    const size_t o_qfloor = o; o = align16(o + (use_floor ? (size_t)n_q * sizeof(float) : 0));
     const size_t plan_bytes = o;
     const int pb = s->plan_turn;
     s->plan_turn = (s->plan_turn + 1) % ss_scorer::TURNS;
@@ -2230,6 +2243,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     if (!h_probs.empty()) std::memcpy(hp + o_probs, h_probs.data(), h_probs.size() * sizeof(double));
     if (!h_mergeq.empty()) std::memcpy(hp + o_mergeq, h_mergeq.data(), h_mergeq.size() * sizeof(uint32_t));
     std::memcpy(hp + o_qfast, h_fast.data(), (size_t)n_q);
+    if (use_floor) std::memcpy(hp + o_qfloor, s->dbg_floor.data(), (size_t)n_q * sizeof(float));
     {
         unsigned char* w = hp + o_smalltab;              // the 1024-slot queries first, then the larger ones (launch_score_small)
         for (const std::vector<SmallEnt>* v : {&h_small_a, &h_small_b})
@@ -2342,6 +2356,7 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
     p.small_q = nullptr;
     p.small_tab = dp + o_smalltab;
     p.small_stride = (uint32_t)small_stride;
+    p.q_floor = use_floor ? reinterpret_cast<const float*>(dp + o_qfloor) : nullptr;
     p.small_stage = small_staged ? s->d_small_stage[pb].p : nullptr;
     p.small_stage_n = small_staged ? s->d_small_stage_n[pb].p : nullptr;
     p.hits = dev_out ? hits_out : s->d_hits.p;
@@ -2456,12 +2471,27 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         fprintf(stderr, "[score trace] copies in + checks %.0f us, plan (%zu slices) %.0f us, staging %.0f us, H2D + allocs + params %.0f us, launches %.0f us%s\n",
                 t_us(th0, th1), n_slices, t_us(th1, th2), t_us(th2, th3), t_us(th3, th4), t_us(th4, t_now()), pipe ? " (k_score_wave on the wave stream)" : "");
     if (dev_out) return SS_OK;                   // ordered on the ctx stream; ss_synchronize (or the stream's owner) waits
+    auto capture_floor = [&]() {                 // experiment only: the next call of the same batch starts from these thresholds
+#ifndef SS_EXP_FLOOR
+        return;
+#endif
+        if (ctx->opt("score.debug_floor", 0) == 0) return;
+        s->dbg_floor.assign((size_t)n_q, 0.0f);
+        for (int q = 0; q < n_q; q++)
+            if (n_hits_out[q] == k) {
+                const double f = hits_out[(size_t)q * k + (k - 1)].final;
+                float ff = (float)f;
+                if ((double)ff > f) ff = std::nextafterf(ff, -INFINITY);
+                if (ff > 0.0f && f == f) s->dbg_floor[q] = ff;
+            }
+    };
     if (one_copy) {
         unsigned char* const hp1 = s->h_res;
         SS_HIP(ctx, hipMemcpyAsync(hp1, s->d_hits.p, res_bytes, hipMemcpyDeviceToHost, st));
         SS_HIP(ctx, hipStreamSynchronize(st));
         std::memcpy(hits_out, hp1, res_rows * sizeof(ss_hit));
         std::memcpy(n_hits_out, hp1 + res_rows * sizeof(ss_hit), (size_t)n_q * sizeof(int32_t));
+        capture_floor();
         return SS_OK;
     }
     SS_HIP(ctx, hipMemcpyAsync(hits_out, s->d_hits.p, (size_t)n_q * k * sizeof(ss_hit), hipMemcpyDefault, st));
@@ -2474,10 +2504,12 @@ static int32_t score_impl_inner(ss_scorer* s, int32_t n_q, const uint32_t* q_ptr
         SS_HIP(ctx, hipMemcpyAsync(hn, s->d_nhits.p, nh_bytes, hipMemcpyDeviceToHost, st));
         SS_HIP(ctx, hipStreamSynchronize(st));
         std::memcpy(n_hits_out, hn, nh_bytes);
+        capture_floor();
         return SS_OK;
     }
     SS_HIP(ctx, hipMemcpyAsync(n_hits_out, s->d_nhits.p, nh_bytes, hipMemcpyDefault, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
+    capture_floor();
     return SS_OK;
 }
 

@@ -143,6 +143,7 @@ struct ScoreParams {
     const uint32_t* small_q;  // k_score_small's queries (they have no slices; q_fast[q] & 2)
     const unsigned char* small_tab;   // k_score_small: entry b (small_stride bytes) = SmallHdr + the query's SmallList rows
     uint32_t small_stride;
+    const float* q_floor;             // experiment ("score.debug_floor"): a per-query lower bound of the k-th best FinalRank, or null
     ss_hit* small_stage;              // null: k_score_small writes row q of `hits`; else row b of this block (k_small_copy moves it on the caller's stream)
     int32_t* small_stage_n;
 };

@@ -824,7 +824,10 @@ __global__ __launch_bounds__(64, SSW_MINW) void k_score_wave(ScoreParams p, cons
     C.fx_scale = coef_max > 0.0f ? (float)FX_ONE / coef_max : 1.0f;
     w.coef_b = coef_raw_b * C.fx_scale * (1.0f + 0x1p-20f);
     w.coef_t = coef_raw_t * C.fx_scale * (1.0f + 0x1p-20f);
-    const float thr0_f = __uint_as_float(wave_max(__float_as_uint(floor_l)));
+    float thr0_f = __uint_as_float(wave_max(__float_as_uint(floor_l)));
+#ifdef SS_EXP_FLOOR      // variant build only (tools/floor_exp.py)
+    if (p.q_floor) thr0_f = fmaxf(thr0_f, p.q_floor[q]);
+#endif
     const uint64_t thr0_key = thr0_f > 0.0f ? fkey((double)thr0_f) : 0ull;
     C.tk = TopK{cd_key, cd_doc, &sc32[0], &sc64[0], reinterpret_cast<float*>(&sc32[2]), thr0_key, thr0_f > 0.0f ? thr0_f : -INFINITY, (uint32_t)WCB};
     if (lane == 0 && thr0_f > 0.0f) { sc64[0] = thr0_key; *reinterpret_cast<float*>(&sc32[2]) = thr0_f; }
