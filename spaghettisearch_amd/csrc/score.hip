@@ -50,7 +50,7 @@ namespace {
 #define SS_WGS_PER_CU 2
 #endif
 struct ScoreLds {                     // byte offsets into the dynamic LDS block
-    size_t s_rec, l_rec, l_w, sc64, cd_key, cd_doc, ht_key, ht_rec, sk, tbl, l_mult, l_field, f_cur, f_nxt, l_coef, sc32, off, total;
+    size_t s_rec, l_rec, l_w, sc64, cd_key, cd_doc, ht_key, ht_rec, sk, tbl, l_mult, l_field, f_cur, f_nxt, l_coef, sc32, sel, sel64, off, total;
 };
 __host__ __device__ inline ScoreLds score_lds_layout(int cb) {
     ScoreLds o{};
@@ -71,6 +71,8 @@ __host__ __device__ inline ScoreLds score_lds_layout(int cb) {
     o.f_nxt = p;   p += (size_t)MAXL * 4;
     o.l_coef = p;  p += (size_t)MAXL * 4;
     o.sc32 = p;    p += 16 * 4;
+    o.sel = p;     p += (256 + 8) * 4;              // topk_select_inl: histogram + scalars
+    o.sel64 = p;   p += 4 * 8;
     o.off = p;     p += (size_t)OFF_CAP * 2;
     o.total = (p + 15) & ~(size_t)15;
     return o;
@@ -94,6 +96,8 @@ struct SliceLds {
     float* l_coef;       // [MAXL] filter coefficient in fixed-point units: upper bound of (38|29)*mult/sqrt(queryLength) * scale
     uint16_t* off;       // [OFF_CAP] offset of list l inside window j: off[j*OS+l], count at [j*OS+OS-1]
     uint32_t* overflow;  // shared scalar
+    uint32_t* sel;       // [256 + 8] scratch of topk_select_inl
+    uint64_t* sel64;     // [4]
 };
 
 // generic window loop (L > LCH lists): records of one window as raw 8-byte vectors (one global_load_dwordx2 per posting)
@@ -177,7 +181,7 @@ __device__ __forceinline__ void score_owned(const SliceLds& S, const TopK& tk, c
         }
         lds_barrier();
         if (!*S.overflow) break;
-        topk_compact(tk, p.k);         // raises thr; count back to <= k
+        topk_cut(tk, p.k, S.sel, S.sel64);   // raises thr; count back to <= k (unordered: radix selection where one entry per thread fits)
         if (tid == 0) *S.overflow = 0;
         lds_barrier();
     }
@@ -482,7 +486,7 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
                 }
                 __syncthreads();
                 if (!*overflow) break;
-                topk_compact(tk, k);
+                topk_compact_net(tk, k);
                 if (tid == 0) *overflow = 0;
                 __syncthreads();
             }
@@ -510,7 +514,8 @@ __device__ __forceinline__ void merge_query(const ScoreParams& p, const uint32_t
     if (tid == 0) sc32[0] = min(sc32[0], (uint32_t)k);
     __syncthreads();
 #else
-    topk_compact(tk, k);
+    if (FLAT) topk_compact_net(tk, k);
+    else topk_compact(tk, k);
 #endif
     const uint32_t n_out = sc32[0];
 
@@ -633,6 +638,8 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     S.l_coef = reinterpret_cast<float*>(smem + lo_.l_coef);
     S.off = reinterpret_cast<uint16_t*>(smem + lo_.off);
     S.overflow = &sc32[1];
+    S.sel = reinterpret_cast<uint32_t*>(smem + lo_.sel);
+    S.sel64 = reinterpret_cast<uint64_t*>(smem + lo_.sel64);
 
     uint32_t& cand_count = sc32[0];
     float* thr_f_s = reinterpret_cast<float*>(&sc32[2]);
@@ -958,7 +965,7 @@ __global__ __launch_bounds__(TPB, (TPB / 256) * SS_WGS_PER_CU) void k_score_slic
     DIAG_NOW(t_k2);
     DIAG_ADD(10, t_k2 - t_k1);
 
-    topk_compact(tk, p.k);
+    topk_cut(tk, p.k, S.sel, S.sel64);  // (the slice's list goes to the merge unordered: merge_query filters and sorts what it gathers)
     const uint32_t n_out = cand_count;
     if (!p.q_ticket) {
         for (uint32_t i = tid; i < n_out; i += TPB) {

@@ -354,6 +354,10 @@ struct TopK {
 // (An enumeration sort — every entry counts the entries that precede it, 2 barriers instead of 38 — measured
 // 25 % slower end to end: 65k broadcast LDS reads cost more than the bitonic network's barriers.)
 // (by value: a reference would force the struct into scratch memory for the out-of-line call)
+#ifndef SS_COMPACT_PLACE
+#define SS_COMPACT_PLACE 1      // 0: variant build, the network everywhere (A/B)
+#endif
+template <bool PLACE = true>       // PLACE = false: the network only (k_score_wave's one-wave buffer: the other path is dead code there, and it cost the kernel 3.5 %)
 __device__ __forceinline__ void topk_compact_inl(const TopK& tk, int k) {
     DIAG_ADD(4, 1);
     lds_barrier();
@@ -361,6 +365,35 @@ __device__ __forceinline__ void topk_compact_inl(const TopK& tk, int k) {
     const uint32_t n = min(*tk.count, tk.cb);
     uint32_t n2 = 64;
     while (n2 < n) n2 <<= 1;
+    if (PLACE && n2 <= 128u && nthr >= 2u * n2) {
+        // Up to 128 entries and at least two threads per entry (round 5): PLACEMENT BY COUNTING instead of the network — every entry counts
+        // the entries that precede it ({key, doc} pairs are distinct: the counts are the places), `parts` neighbouring lanes share an
+        // entry's comparisons and add their counts by shuffles, eight broadcast reads in flight per thread; two barriers
+        // (tools/micro/compact_sorts.hip, 256 threads: 64 entries 2.7k cycles against 12k, 100 entries 7.5k against 15.5k; at 256
+        // entries the quadratic count loses, 31k against 21k: the network stays there).
+        uint32_t parts = 2;
+        while (parts < 8u && nthr >= 2u * parts * n2) parts <<= 1;
+        const uint32_t i = threadIdx.x / parts, part = threadIdx.x & (parts - 1u);
+        const bool in = i < n;                                    // (threads beyond parts * n2 have i >= n2 >= n)
+        const uint64_t my_k = in ? tk.key[i] : 0ull;
+        const uint32_t my_d = in ? tk.doc[i] : EMPTY;
+        uint32_t cnt = 0;
+        if (in) {
+            const uint32_t per = (n + parts - 1u) / parts, j0 = part * per, j1 = min(n, j0 + per);
+            for (uint32_t j = j0; j < j1; j += 4) {                // (four in flight: eight cost k_merge_flat its eighth wave per SIMD)
+                uint64_t kk[4];
+                uint32_t dd[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t jj = min(j + (uint32_t)u, j1 - 1u); kk[u] = tk.key[jj]; dd[u] = tk.doc[jj]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) cnt += (j + (uint32_t)u < j1 && better(kk[u], dd[u], my_k, my_d)) ? 1u : 0u;
+            }
+        }
+        for (uint32_t o = 1; o < parts; o <<= 1) cnt += (uint32_t)__shfl_xor((int)cnt, (int)o, 64);
+        lds_barrier();                                            // every entry has been read
+        if (in && part == 0u) { tk.key[cnt] = my_k; tk.doc[cnt] = my_d; }
+        lds_barrier();
+    } else {
     for (uint32_t i = n + threadIdx.x; i < n2; i += nthr) { tk.key[i] = 0ull; tk.doc[i] = EMPTY; }   // worst sentinels
     lds_barrier();
     for (uint32_t size = 2; size <= n2; size <<= 1) {
@@ -377,11 +410,109 @@ __device__ __forceinline__ void topk_compact_inl(const TopK& tk, int k) {
             lds_barrier();
         }
     }
+    }
     if (threadIdx.x == 0) {
         const uint32_t keep = min(n, (uint32_t)k);
         *tk.count = keep;
         const bool full = keep == (uint32_t)k;
         uint64_t t = full ? tk.key[k - 1] : 0ull;
+        float tf = -INFINITY;
+        if (full && t != 0ull) tf = __double2float_rd(funkey(t));
+        if (tk.thr0 > t) { t = tk.thr0; tf = tk.thr0_f; }
+        else if (tk.thr0_f > tf) tf = tk.thr0_f;
+        *tk.thr = t;
+        *tk.thr_f = tf;
+    }
+    lds_barrier();
+}
+// Cut the candidate buffer to its k best WITHOUT ordering them (round 5): what a compaction is for is the new threshold — the k-th best
+// key — and room in the buffer; the order only matters where hits are written, and that is the merge's own sort.  Radix selection on the
+// 96-bit key {key, ~doc} (the order of `better`): OR and AND of the keys give the first bit in which they differ, a pass counts the
+// entries still running by the next eight bits (256-bin histogram, one wave scans it from the top), keeps what lies above the bin of the
+// k-th, drops what lies below, and the passes end when the entries still running are exactly the ones still needed; the kept entries
+// move to the front, the smallest kept key is the new threshold.  One entry per thread (cb <= blockDim.x): ~13 barriers, where the
+// bitonic network over 256 entries is 36 barrier-separated steps of ~585 cycles (tools/micro/compact_sorts.hip: 21k cycles; 2.5
+// compactions per slice of a tail batch = a third of the slice).  Same survivors and same threshold as topk_compact_inl.
+__device__ __forceinline__ uint32_t sel_digit96(uint64_t key, uint32_t doc, int sh) {
+    if (sh >= 32) return (uint32_t)(key >> (sh - 32)) & 255u;
+    const uint64_t w = ((key & 0xFFFFFFFFull) << 32 | (uint64_t)(~doc)) >> sh;
+    return (uint32_t)w & 255u;
+}
+// sel: [256 + 8] words, sel64: [4] — LDS scratch of the caller (kept out of TopK: the struct lives in k_score_wave's registers)
+__device__ __forceinline__ void topk_select_inl(const TopK& tk, int k, uint32_t* sel, uint64_t* sel64) {
+    uint32_t* const hist = sel;             // [256]
+    uint32_t* const sw = sel + 256;         // [8]: bin, k_rem, n_alive, kept counter
+    uint64_t* const s64 = sel64;            // [4]: OR, AND, min kept key
+    lds_barrier();
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = min(*tk.count, tk.cb);
+    const bool mine = tid < n;              // (cb <= blockDim.x: entry tid is this thread's)
+    const uint64_t e_key = mine ? tk.key[tid] : 0ull;
+    const uint32_t e_doc = mine ? tk.doc[tid] : EMPTY;
+    if (tid == 0) { s64[0] = 0ull; s64[1] = ~0ull; s64[2] = ~0ull; sw[3] = 0u; }
+    lds_barrier();
+    bool keep = mine;                       // n <= k: everything stays
+    if (n > (uint32_t)k) {
+        uint64_t ko = e_key, ka = mine ? e_key : ~0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ko |= __shfl_xor(ko, o, 64); ka &= __shfl_xor(ka, o, 64); }
+        if ((tid & 63u) == 0u) { atomicOr(reinterpret_cast<unsigned long long*>(&s64[0]), ko); atomicAnd(reinterpret_cast<unsigned long long*>(&s64[1]), ka); }
+        lds_barrier();
+        const uint64_t diff = s64[0] ^ s64[1];
+        int sh = diff ? max(0, 32 + (63 - __clzll((long long)diff)) - 7) : 24;
+        uint32_t k_rem = (uint32_t)k, n_alive = n;
+        bool alive = mine;
+        keep = false;
+        for (;; sh = sh >= 8 ? sh - 8 : (sh > 0 ? 0 : -1)) {
+            if (n_alive == k_rem || sh < 0) { keep = keep || alive; break; }      // (sh < 0: equal {key, doc} pairs — cannot happen, docs are distinct)
+            if (tid < 256u) hist[tid] = 0u;
+            lds_barrier();
+            const uint32_t dg = sel_digit96(e_key, e_doc, sh);
+            if (alive) atomicAdd(&hist[dg], 1u);
+            lds_barrier();
+            if (tid < 64u) {
+                const uint4 c = reinterpret_cast<const uint4*>(hist)[tid];
+                const uint32_t s4 = c.x + c.y + c.z + c.w;
+                uint32_t incl = s4;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t y = (uint32_t)__shfl_down((int)incl, o, 64);
+                    if (tid + (uint32_t)o < 64u) incl += y;
+                }
+                uint32_t a = incl - s4;
+                if (a < k_rem && k_rem <= a + s4) {
+                    const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int bin = 3; bin >= 0; bin--) {
+                        if (k_rem <= a + cc[bin]) { sw[0] = 4u * tid + (uint32_t)bin; sw[1] = k_rem - a; sw[2] = cc[bin]; break; }
+                        a += cc[bin];
+                    }
+                }
+            }
+            lds_barrier();
+            const uint32_t d = sw[0];
+            k_rem = sw[1];
+            n_alive = sw[2];
+            if (alive) {
+                if (dg > d) keep = true;
+                if (dg != d) alive = false;
+            }
+        }
+    }
+    // the kept entries to the front (every thread holds its entry in registers), their smallest key = the new threshold
+    lds_barrier();
+    if (keep) {
+        const uint32_t pos = atomicAdd(&sw[3], 1u);
+        tk.key[pos] = e_key;
+        tk.doc[pos] = e_doc;
+        atomicMin(reinterpret_cast<unsigned long long*>(&s64[2]), e_key);
+    }
+    lds_barrier();
+    if (tid == 0) {
+        const uint32_t keepn = min(n, (uint32_t)k);
+        *tk.count = keepn;
+        const bool full = keepn == (uint32_t)k;
+        uint64_t t = full ? s64[2] : 0ull;
         float tf = -INFINITY;
         if (full && t != 0ull) tf = __double2float_rd(funkey(t));
         if (tk.thr0 > t) { t = tk.thr0; tf = tk.thr0_f; }
@@ -401,7 +532,33 @@ __device__ void topk_compact(const TopK tk, int k) {
     __builtin_assume(__builtin_amdgcn_is_shared(tk.thr));
     __builtin_assume(__builtin_amdgcn_is_shared(tk.thr_f));
 #endif
-    topk_compact_inl(tk, k);
+    topk_compact_inl<SS_COMPACT_PLACE != 0>(tk, k);
+}
+// the network only: k_merge_flat, whose 40 registers are what lets four of its waves sit beside two k_score_wave waves on a SIMD (with the
+// placement path it needs 46 -> 48: three, and config 3's pipelined period went from 0.342 to 0.361 ms)
+__device__ void topk_compact_net(const TopK tk, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.key));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.doc));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.count));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.thr));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.thr_f));
+#endif
+    topk_compact_inl<false>(tk, k);
+}
+// cut to the k best, unordered (radix selection) where one entry per thread fits; else the bitonic network
+__device__ void topk_cut(const TopK tk, int k, uint32_t* sel, uint64_t* sel64) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.key));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.doc));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.count));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.thr));
+    __builtin_assume(__builtin_amdgcn_is_shared(tk.thr_f));
+    __builtin_assume(__builtin_amdgcn_is_shared(sel));
+    __builtin_assume(__builtin_amdgcn_is_shared(sel64));
+#endif
+    if (tk.cb <= blockDim.x) topk_select_inl(tk, k, sel, sel64);
+    else topk_compact_inl(tk, k);
 }
 
 struct SliceQuery {      // per-query constants of the exact stage

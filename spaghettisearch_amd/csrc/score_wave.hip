@@ -204,7 +204,7 @@ __device__ __forceinline__ TopK wave_topk(uint64_t thr0_key, float thr0_f) {
 // the candidate buffer sorted and cut to k (topk_compact for one wave), as a call
 __device__ __noinline__ void wave_compact(int k) {
     const TopK tk = wave_topk(rs.thr0_key, rs.thr0_f);
-    topk_compact_inl(tk, k);
+    topk_compact_inl<false>(tk, k);
 }
 
 // sqd for the benchmark's 16 topics: the row's 16 doubles and the 16 probabilities requested together (the loop of runtime length
